@@ -1,0 +1,251 @@
+/* hvk_presets.c -- TV system presets for the modes the engine renders.
+ *
+ * Mirrors the reference's `vid_configs[]` lookup (src/video.c:1956-2008,
+ * used by `-m <id>` at src/hacktv.c:1078-1107): same mode ids, same numbers
+ * (the numbers are the broadcast standards' and the reference's level
+ * choices, src/video.c:50-1009). Presets are composed from a raster timing,
+ * a colour system and an RF/audio plan instead of one flat struct per mode.
+ */
+#include <string.h>
+#include "hacktv_amd.h"
+
+/* ---- raster timings ---- */
+
+static void _raster_625(hvk_config_t *c, double sync_rise)
+{
+	c->type = HVK_RASTER_625;
+	c->frame_rate = (hvk_rational_t) { 25, 1 };
+	c->lines = 625;
+	c->interlaced = 1;
+	c->active_lines = 576;
+	c->active_width = 0.00005195;        /* 51.95 us */
+	c->active_left = 0.00001040;         /* 10.40 us */
+	c->hsync_width = 0.00000470;         /*  4.70 us */
+	c->vsync_short_width = 0.00000235;   /*  2.35 us */
+	c->vsync_long_width = 0.00002730;    /* 27.30 us */
+	c->sync_rise = sync_rise;
+}
+
+static void _raster_525(hvk_config_t *c)
+{
+	c->type = HVK_RASTER_525;
+	c->frame_rate = (hvk_rational_t) { 30000, 1001 };
+	c->lines = 525;
+	c->interlaced = 1;
+	c->active_lines = 480;
+	c->active_width = 0.00005290;        /* 52.90 us */
+	c->active_left = 0.00000920;         /*  9.20 us */
+	c->hsync_width = 0.00000470;
+	c->vsync_short_width = 0.00000230;
+	c->vsync_long_width = 0.00002710;
+	c->sync_rise = 0.00000025;
+}
+
+/* ---- colour systems ---- */
+
+static void _colour_pal(hvk_config_t *c)
+{
+	c->colour_mode = HVK_PAL;
+	c->burst_width = 0.00000225;         /* 2.25 us */
+	c->burst_rise = 0.00000030;
+	c->burst_left = 0.00000560;          /* 5.6 us after 0H */
+	c->burst_level = 3.0 / 7.0;          /* of white - blanking */
+	c->colour_carrier = (hvk_rational_t) { 17734475, 4 }; /* 4433618.75 Hz */
+	c->colour_bw = 1.4e6;
+	c->ev_co = 0.877;
+	c->eu_co = 0.493;
+}
+
+static void _colour_ntsc(hvk_config_t *c)
+{
+	c->colour_mode = HVK_NTSC;
+	c->burst_width = 0.00000250;
+	c->burst_rise = 0.00000030;
+	c->burst_left = 0.00000530;
+	c->burst_level = 4.0 / 10.0;
+	c->colour_carrier = (hvk_rational_t) { 39375000, 11 }; /* 3579545.45 Hz */
+	c->colour_bw = 1.4e6;
+	c->ev_co = 0.877;
+	c->eu_co = 0.493;
+}
+
+static void _colour_secam(hvk_config_t *c)
+{
+	c->colour_mode = HVK_SECAM;
+	c->burst_width = 0.00005690;         /* sub-carrier envelope, 56.9 us */
+	c->burst_rise = 0.00000100;
+	c->burst_left = 0.00000560;
+	c->ev_co = -1.902 * 280e3;           /* D'R */
+	c->eu_co =  1.505 * 230e3;           /* D'B */
+}
+
+/* ---- signal plans ---- */
+
+static void _baseband(hvk_config_t *c, double white, double black, double blank, double sync)
+{
+	c->output_type = HVK_INT16_REAL;
+	c->modulation = HVK_NONE;
+	c->level = 1.0;
+	c->video_level = 1.0;
+	c->video_bw = 6.0e6;
+	c->white_level = white;
+	c->black_level = black;
+	c->blanking_level = blank;
+	c->sync_level = sync;
+}
+
+static void _vsb(hvk_config_t *c, double upper, double lower, double video_level,
+                 double white, double black, double blank, double sync)
+{
+	c->output_type = HVK_INT16_COMPLEX;
+	c->modulation = HVK_VSB;
+	c->vsb_upper_bw = upper;
+	c->vsb_lower_bw = lower;
+	c->level = 1.0;
+	c->video_level = video_level;
+	c->white_level = white;
+	c->black_level = black;
+	c->blanking_level = blank;
+	c->sync_level = sync;
+}
+
+static void _fm_sound(hvk_config_t *c, double level, double carrier, double deviation, int preemph)
+{
+	c->fm_mono_level = level;
+	c->fm_mono_carrier = carrier;
+	c->fm_mono_deviation = deviation;
+	c->fm_mono_preemph = preemph;
+}
+
+static void _nicam(hvk_config_t *c, double level, double carrier, double beta)
+{
+	c->nicam_level = level;
+	c->nicam_carrier = carrier;
+	c->nicam_beta = beta;
+}
+
+static const struct {
+	const char *id;
+	const char *desc;
+} _modes[] = {
+	{ "i",     "PAL colour, 25 fps, 625 lines, AM (complex), 6.0 MHz FM audio" },
+	{ "b",     "PAL colour, 25 fps, 625 lines, AM (complex), 5.5 MHz FM audio" },
+	{ "g",     "PAL colour, 25 fps, 625 lines, AM (complex), 5.5 MHz FM audio" },
+	{ "pal",   "PAL colour, 25 fps, 625 lines, unmodulated (real)" },
+	{ "l",     "SECAM colour, 25 fps, 625 lines, AM (complex), 6.5 MHz AM audio" },
+	{ "secam", "SECAM colour, 25 fps, 625 lines, unmodulated (real)" },
+	{ "m",     "NTSC colour, 30/1.001 fps, 525 lines, AM (complex), 4.5 MHz FM audio" },
+	{ "ntsc",  "NTSC colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
+	{ NULL, NULL },
+};
+
+const char *hvk_preset_id(int index)
+{
+	if(index < 0 || index >= (int) (sizeof(_modes) / sizeof(_modes[0])) - 1) return(NULL);
+	return(_modes[index].id);
+}
+
+const char *hvk_preset_desc(int index)
+{
+	if(index < 0 || index >= (int) (sizeof(_modes) / sizeof(_modes[0])) - 1) return(NULL);
+	return(_modes[index].desc);
+}
+
+int hvk_config_preset(hvk_config_t *c, const char *id)
+{
+	if(c == NULL || id == NULL) return(HVK_ERROR);
+
+	memset(c, 0, sizeof(*c));
+	c->volume = 256; /* src/hacktv.c:1431 with the default --volume 1.0 */
+
+	if(strcmp(id, "i") == 0)
+	{
+		/* src/video.c:50-102 */
+		_vsb(c, 5500000, 1250000, 0.71, 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000025);
+		_colour_pal(c);
+		_fm_sound(c, 0.22, 6000000 - 400, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 6552000, 1.0);
+	}
+	else if(strcmp(id, "b") == 0 || strcmp(id, "g") == 0)
+	{
+		/* src/video.c:104-156 */
+		_vsb(c, 5000000, 750000, 0.71, 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000020);
+		_colour_pal(c);
+		_fm_sound(c, 0.15, 5500000, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 5850000, 0.4);
+	}
+	else if(strcmp(id, "pal") == 0)
+	{
+		/* src/video.c:274-314 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		_raster_625(c, 0.00000020);
+		_colour_pal(c);
+	}
+	else if(strcmp(id, "l") == 0)
+	{
+		/* src/video.c:457-504 */
+		_vsb(c, 6000000, 1250000, 0.80 * (100.0 / 124.0), 1.00, 0.30, 0.30, 0.05);
+		_raster_625(c, 0.00000020);
+		_colour_secam(c);
+		c->am_audio_level = 0.10;
+		c->am_mono_carrier = 6500000;
+		_nicam(c, 0.04, 5850000, 0.4);
+	}
+	else if(strcmp(id, "secam") == 0)
+	{
+		/* src/video.c:716-753 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		_raster_625(c, 0.00000020);
+		_colour_secam(c);
+	}
+	else if(strcmp(id, "m") == 0)
+	{
+		/* src/video.c:755-803 */
+		_vsb(c, 4200000, 750000, 0.77, 0.125000, 0.703125, 0.750000, 1.000000);
+		_raster_525(c);
+		_colour_ntsc(c);
+		_fm_sound(c, 0.15, 4500000, 25000, HVK_75US);
+	}
+	else if(strcmp(id, "ntsc") == 0)
+	{
+		/* src/video.c:968-1008 */
+		_baseband(c, 100.0 / 140, 7.5 / 140, 0.0 / 140, -40.0 / 140);
+		_raster_525(c);
+		_colour_ntsc(c);
+	}
+	else
+	{
+		return(HVK_ERROR);
+	}
+
+	return(HVK_OK);
+}
+
+/* The command-line switches that edit a preset before vid_init()
+ * (src/hacktv.c:1126-1171, :1412-1415) */
+void hvk_config_apply_flags(hvk_config_t *c, int flags)
+{
+	if(flags & HVK_FLAG_NOCOLOUR)
+	{
+		if(c->colour_mode == HVK_PAL || c->colour_mode == HVK_SECAM || c->colour_mode == HVK_NTSC)
+		{
+			c->colour_mode = HVK_MONOCHROME;
+		}
+	}
+
+	if(flags & HVK_FLAG_NOAUDIO)
+	{
+		c->fm_mono_level = c->am_audio_level = c->nicam_level = 0;
+		c->fm_mono_carrier = c->nicam_carrier = c->am_mono_carrier = 0;
+	}
+
+	if(flags & HVK_FLAG_NONICAM)
+	{
+		c->nicam_level = 0;
+		c->nicam_carrier = 0;
+	}
+
+	if(flags & HVK_FLAG_FILTER) c->vfilter = 1;
+}

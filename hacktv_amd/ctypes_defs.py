@@ -1,0 +1,82 @@
+"""ctypes mirrors of the plain-data structs in include/hvk_config.h and
+include/hacktv_amd.h. Used by the Python binding (hacktv_amd.engine) and by the
+test harness for the oracle, which takes the same hvk_config_t."""
+import ctypes as C
+
+
+class HvkRational(C.Structure):
+    _fields_ = [("num", C.c_int64), ("den", C.c_int64)]
+
+
+class HvkConfig(C.Structure):
+    # field order == include/hvk_config.h
+    _fields_ = [
+        ("output_type", C.c_int),
+        ("modulation", C.c_int),
+        ("video_bw", C.c_double),
+        ("vsb_upper_bw", C.c_double),
+        ("vsb_lower_bw", C.c_double),
+        ("level", C.c_double),
+        ("video_level", C.c_double),
+        ("fm_mono_level", C.c_double),
+        ("am_audio_level", C.c_double),
+        ("nicam_level", C.c_double),
+        ("type", C.c_int),
+        ("frame_rate", HvkRational),
+        ("lines", C.c_int),
+        ("hline", C.c_int),
+        ("interlaced", C.c_int),
+        ("active_lines", C.c_int),
+        ("hsync_width", C.c_double),
+        ("vsync_short_width", C.c_double),
+        ("vsync_long_width", C.c_double),
+        ("sync_rise", C.c_double),
+        ("invert_video", C.c_int),
+        ("white_level", C.c_double),
+        ("black_level", C.c_double),
+        ("blanking_level", C.c_double),
+        ("sync_level", C.c_double),
+        ("active_width", C.c_double),
+        ("active_left", C.c_double),
+        ("gamma", C.c_double),
+        ("rw_co", C.c_double),
+        ("gw_co", C.c_double),
+        ("bw_co", C.c_double),
+        ("colour_mode", C.c_int),
+        ("colour_carrier", HvkRational),
+        ("colour_bw", C.c_double),
+        ("burst_width", C.c_double),
+        ("burst_left", C.c_double),
+        ("burst_level", C.c_double),
+        ("burst_rise", C.c_double),
+        ("ev_co", C.c_double),
+        ("eu_co", C.c_double),
+        ("secam_field_id", C.c_int),
+        ("secam_field_id_lines", C.c_int),
+        ("volume", C.c_int),
+        ("fm_mono_carrier", C.c_double),
+        ("fm_mono_deviation", C.c_double),
+        ("fm_mono_preemph", C.c_int),
+        ("nicam_carrier", C.c_double),
+        ("nicam_beta", C.c_double),
+        ("am_mono_carrier", C.c_double),
+        ("vfilter", C.c_int),
+    ]
+
+
+class HvkInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "sample_rate", "width", "half_width", "active_width", "active_left",
+        "lines", "active_lines",
+        "white_level", "black_level", "blanking_level", "sync_level",
+        "delay_lines", "frame_samples", "max_frames", "frame_slots",
+        "colour_lookup_width", "burst_left", "burst_width",
+        "has_carriers", "has_nicam")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
+
+HVK_OK, HVK_ERROR, HVK_OUT_OF_MEMORY, HVK_NO_DEVICE, HVK_UNSUPPORTED, HVK_UNDERRUN = 0, -1, -2, -3, -4, -5

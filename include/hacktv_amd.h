@@ -1,0 +1,173 @@
+/* hacktv_amd.h -- C ABI of the MI355X composite-video -> IQ engine (libhvk.so).
+ *
+ * This is the drop-in boundary for the one hot path of fsphil/hacktv that is
+ * rebuilt here: everything between the av_* source API and the rf_* sink API,
+ * i.e. what the reference implements in vid_init() / vid_next_line() /
+ * vid_free() (src/video.h:510-516, src/video.c:3812-4952) on top of fir.c,
+ * vbidata.c and nicam728.c.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, no C++/torch types. The
+ * reference's host program stays C and calls this through the video.h-shaped
+ * shim in hacktv_amd/csrc/shim/ (INTEGRATION.md shows the wiring). Python
+ * (tests/, bench.py) binds the same symbols with ctypes.
+ *
+ * Model. The reference renders one scanline per vid_next_line() call on the
+ * host. The engine renders WHOLE FRAMES on the GPU, many per launch:
+ *
+ *   hvk_open()            vid_init(): builds every table on the host (double +
+ *                         libm, bit-identical with the reference's) and
+ *                         uploads them once.
+ *   hvk_frame_upload()    what av_read_video() returned for a frame, copied
+ *                         into one of the engine's frame slots in HBM.
+ *   hvk_audio_write()     what av_read_audio() returned: 32 kHz stereo int16.
+ *                         Runs the audio-rate control path on the host
+ *                         (volume, limiter, NICAM framing, and the serial
+ *                         FM/AM phasor chains) and queues the
+ *                         per-sample side streams for upload.
+ *   hvk_render()          renders the next `nframes` frames of the stream
+ *                         into device memory: raster kernel, filter/audio
+ *                         kernel. Output: int16 I/Q pairs, frame after frame,
+ *                         line after line -- exactly the concatenation of the
+ *                         buffers the reference hands to rf_write()
+ *                         (src/hacktv.c:1579-1587).
+ *   hvk_fetch()           copies rendered samples to a host buffer for a
+ *                         host-side rf_* sink.
+ *
+ * All entry points return HVK_OK (0) or a negative HVK_* code, like the
+ * reference's VID_OK / VID_ERROR / VID_OUT_OF_MEMORY (src/video.h:45-47).
+ * There is no CPU fallback: if the HIP device is missing every call that
+ * would touch it fails with HVK_NO_DEVICE.
+ */
+#ifndef HACKTV_AMD_H
+#define HACKTV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "hvk_config.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVK_OK              0
+#define HVK_ERROR          -1   /* VID_ERROR */
+#define HVK_OUT_OF_MEMORY  -2   /* VID_OUT_OF_MEMORY */
+#define HVK_NO_DEVICE      -3
+#define HVK_UNSUPPORTED    -4   /* configuration outside the engine's scope */
+#define HVK_UNDERRUN       -5   /* not enough audio side-stream queued */
+
+/* hvk_config_apply_flags(): the reference CLI's preset edits */
+#define HVK_FLAG_FILTER    (1 << 0)  /* --filter   src/hacktv.c:1412 */
+#define HVK_FLAG_NOAUDIO   (1 << 1)  /* --noaudio  src/hacktv.c:1150 */
+#define HVK_FLAG_NONICAM   (1 << 2)  /* --nonicam  src/hacktv.c:1167 */
+#define HVK_FLAG_NOCOLOUR  (1 << 3)  /* --nocolour src/hacktv.c:1126 */
+
+/* ---- presets: vid_configs[] (src/video.c:1956-2008) ---- */
+int hvk_config_preset(hvk_config_t *conf, const char *mode_id);
+void hvk_config_apply_flags(hvk_config_t *conf, int flags);
+const char *hvk_preset_id(int index);
+const char *hvk_preset_desc(int index);
+
+/* ---- engine ---- */
+typedef struct hvk_engine hvk_engine_t;
+
+/* Geometry and levels vid_init() derives (src/video.c:3844-3881); the
+ * members hacktv.c reads from vid_t after vid_init() (src/hacktv.c:1503-1518)
+ * are all here. */
+typedef struct hvk_info_t {
+	int32_t sample_rate;
+	int32_t width;              /* samples per line */
+	int32_t half_width;
+	int32_t active_width;       /* source frame width the raster shows */
+	int32_t active_left;
+	int32_t lines;              /* lines per frame */
+	int32_t active_lines;       /* source frame height */
+	int32_t white_level, black_level, blanking_level, sync_level;
+	int32_t delay_lines;        /* filter latency in lines (dropped at start) */
+	int32_t frame_samples;      /* width * lines */
+	int32_t max_frames;         /* frames one hvk_render() call may take */
+	int32_t frame_slots;        /* source frame slots in HBM */
+	int32_t colour_lookup_width;
+	int32_t burst_left, burst_width;
+	int32_t has_carriers;       /* serial FM/AM audio carriers present */
+	int32_t has_nicam;
+} hvk_info_t;
+
+/* vid_init(): src/video.c:3812. `device` is the HIP device ordinal.
+ * `max_frames` bounds one render call (device buffers are sized for it). */
+int hvk_open(hvk_engine_t **e, const hvk_config_t *conf, unsigned int sample_rate, int device, int max_frames);
+
+/* vid_free(): src/video.c:4706 */
+void hvk_close(hvk_engine_t *e);
+
+int hvk_get_info(const hvk_engine_t *e, hvk_info_t *info);
+
+/* vid_get_framebuffer_length(): src/video.c:4862 */
+size_t hvk_get_framebuffer_length(const hvk_engine_t *e);
+
+/* The int16 values the reference's chroma filter reads past the end of its
+ * chrominance buffer (src/fir.c:365-372 called with samples = width,
+ * src/video.c:3019-3020). The default reproduces the reference
+ * CLI on glibc 2.35; a caller that embeds the reference differently can
+ * supply what its own heap holds. n <= 32. Call before the first render. */
+int hvk_set_chroma_ghost(hvk_engine_t *e, const int16_t *ghost, int n);
+int hvk_get_chroma_ghost(const hvk_engine_t *e, int16_t *ghost, int n);
+
+/* av_read_video() result -> frame slot. Strides are in pixels and may be
+ * negative (src/av.h:31-54). The frame is centre-cropped to the active area
+ * like src/video.c:4887-4897. fb == NULL stores an empty (black) frame. */
+int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
+                     int pixel_stride, int line_stride, int interlaced);
+
+/* av_read_audio() result: nsamples interleaved stereo pairs at 32 kHz. */
+int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples);
+
+/* 32 kHz stereo pairs still needed before `nframes` more frames can be
+ * rendered with audio (0 when the mode has no audio sub-carriers). */
+size_t hvk_audio_needed(const hvk_engine_t *e, int nframes);
+
+/* Render the next nframes frames of the stream. slots[i] names the frame
+ * slot shown by frame i. d_iq, if not NULL, is a DEVICE pointer to
+ * nframes * frame_samples * 2 int16 that receives the samples; if NULL the
+ * engine's own output buffer is used (read it back with hvk_fetch()).
+ * Missing audio is rendered as silence (src/video.c:3299-3304). */
+int hvk_render(hvk_engine_t *e, int nframes, const int32_t *slots, void *d_iq);
+
+/* Same, for a caller that shards the stream over several engines/GPUs: render
+ * frames first_frame, first_frame + stride, ... (nframes of them) of the
+ * stream this engine's audio queue describes. The audio side streams for
+ * every rendered frame must have been queued (hvk_audio_write() is stream
+ * ordered and must be fed the whole stream on every rank). */
+int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes,
+                       const int32_t *slots, void *d_iq);
+
+/* Wait for the engine's stream; returns HVK_OK or the HIP failure. */
+int hvk_sync(hvk_engine_t *e);
+
+/* Copy rendered samples [first, first + count) of the last render (engine
+ * buffer) to host memory: what the shim hands to rf_write(). */
+int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
+
+/* Device pointer of the engine's own output buffer (for HIP/RCCL callers) */
+void *hvk_output_device_ptr(hvk_engine_t *e);
+
+/* Average duration in milliseconds of each kernel over the launches since
+ * the last reset, measured with HIP events on the engine's stream.
+ * which: 0 raster kernel, 1 filter/audio kernel. */
+int hvk_timing_enable(hvk_engine_t *e, int on);
+int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches);
+
+/* ---- host tables (for parity tests): same names as the oracle's ---- */
+long hvk_table(const hvk_engine_t *e, const char *name, void *dst, long max_bytes);
+
+/* ---- stage taps (parity tests): the raster stream (int16 I) of the last
+ * render, as produced by the raster kernel, copied from device ---- */
+int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, size_t count);
+
+const char *hvk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,129 @@
+/* hvk_config.h -- mode configuration for the composite-video -> IQ engine.
+ *
+ * Plain data, no behaviour. `hvk_config_t` carries the subset of the
+ * reference's `vid_config_t` (src/video.h:125-292) that the hot path reads:
+ * raster geometry, levels, colour system, VSB/low-pass filter and audio
+ * sub-carrier parameters. Field names and units are the reference's, so a
+ * caller that holds a `vid_config_t` can fill this member by member (the
+ * video.h-compatible shim does exactly that).
+ *
+ * Everything the reference's engine supports but this engine does not render
+ * (scramblers, MAC, VITS/VITC/WSS/CC608/ACP/SiS inserters, DANCE, A2 stereo,
+ * FM video, offset, passthru, raw baseband input) has no field here; the
+ * shim refuses such configurations rather than silently dropping them.
+ */
+#ifndef HVK_CONFIG_H
+#define HVK_CONFIG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Output sample type: src/rf.h:27-28 (RF_INT16_COMPLEX / RF_INT16_REAL).
+ * The engine always produces interleaved I/Q pairs (src/video.h:306-311);
+ * REAL only tells the sink that Q carries nothing. */
+#define HVK_INT16_COMPLEX 0
+#define HVK_INT16_REAL    1
+
+/* Raster type: src/video.h:50-59 */
+#define HVK_RASTER_625 0
+#define HVK_RASTER_525 1
+
+/* Output modulation: src/video.h:70-73 */
+#define HVK_NONE 0
+#define HVK_AM   1
+#define HVK_VSB  2
+#define HVK_FM   3 /* not rendered by this engine (serial at video rate) */
+
+/* Colour modes: src/video.h:76-81 */
+#define HVK_MONOCHROME 0
+#define HVK_PAL        1
+#define HVK_NTSC       2
+#define HVK_SECAM      3
+
+/* Audio pre-emphasis: src/video.h:85-87 */
+#define HVK_50US 1
+#define HVK_75US 2
+#define HVK_J17  3
+
+typedef struct {
+	int64_t num;
+	int64_t den;
+} hvk_rational_t; /* r64_t, src/common.h:31-34 */
+
+typedef struct hvk_config_t {
+
+	int output_type;            /* HVK_INT16_COMPLEX | HVK_INT16_REAL */
+
+	int modulation;             /* HVK_NONE | HVK_AM | HVK_VSB */
+	double video_bw;            /* Hz, low-pass cut-off for AM / baseband */
+	double vsb_upper_bw;        /* Hz */
+	double vsb_lower_bw;        /* Hz */
+
+	double level;               /* overall signal level */
+	double video_level;
+	double fm_mono_level;
+	double am_audio_level;
+	double nicam_level;
+
+	int type;                   /* HVK_RASTER_625 | HVK_RASTER_525 */
+	hvk_rational_t frame_rate;
+	int lines;
+	int hline;                  /* 0 = derive, src/video.c:3832 */
+	int interlaced;             /* 0 none, 1 TFF, 2 BFF */
+	int active_lines;
+
+	double hsync_width;         /* seconds */
+	double vsync_short_width;
+	double vsync_long_width;
+	double sync_rise;           /* 10%-90% */
+
+	int invert_video;
+	double white_level;
+	double black_level;
+	double blanking_level;
+	double sync_level;
+
+	double active_width;        /* seconds */
+	double active_left;
+
+	double gamma;               /* <= 0 means 1.0 */
+	double rw_co, gw_co, bw_co; /* <= 0 means 0.299 / 0.587 / 0.114 */
+
+	int colour_mode;
+	hvk_rational_t colour_carrier; /* Hz */
+	double colour_bw;           /* Hz, gaussian chroma low-pass, 0 = none */
+
+	double burst_width;         /* seconds */
+	double burst_left;
+	double burst_level;
+	double burst_rise;
+
+	double ev_co;
+	double eu_co;
+
+	int secam_field_id;
+	int secam_field_id_lines;
+
+	int volume;                 /* 256 = unity, src/hacktv.c:1431 */
+
+	double fm_mono_carrier;     /* Hz */
+	double fm_mono_deviation;   /* +/- Hz */
+	int fm_mono_preemph;        /* HVK_50US | HVK_75US | HVK_J17 | 0 */
+
+	double nicam_carrier;       /* Hz */
+	double nicam_beta;
+
+	double am_mono_carrier;     /* Hz */
+
+	int vfilter;                /* --filter, src/hacktv.c:1412 */
+
+} hvk_config_t;
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,148 @@
+/* oracle/oracle_internal.h -- TEST INFRASTRUCTURE (not product code). */
+#ifndef ORACLE_INTERNAL_H
+#define ORACLE_INTERNAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "oracle_video.h"
+
+typedef struct { int16_t i, q; } c16_t;
+typedef struct { int32_t i, q; } c32_t;
+
+/* One pre-shaped pulse: `length` values that are ADDED to the line starting
+ * at sample `offset` (may be negative: spills into the previous line) */
+typedef struct {
+	int offset;
+	int length;
+	int16_t *value;
+} orc_pulse_t;
+
+/* 32 kHz soft limiter state (src/fir.c:758-870) */
+typedef struct {
+	int width;
+	int16_t level;
+	int16_t *shape;
+	int16_t *att;
+	int32_t *fix;
+	int32_t *var;
+	int p, h;
+	/* the two 65-tap int32 FIRs in front of it (src/fir.c:620-694) */
+	int ntaps;
+	int32_t *vtaps, *ftaps;
+	int32_t *vwin, *fwin;
+	int vpos, fpos;
+} orc_limiter_t;
+
+/* Phasor modulators (src/video.h:91-115) */
+typedef struct {
+	int on;
+	int16_t level;
+	int32_t counter;
+	c32_t phase;
+	c32_t *lut;       /* FM: 65536 steps indexed by sample + 32768 */
+	c32_t delta;      /* AM: constant step */
+	int16_t sample;
+	orc_limiter_t lim;
+	int has_lim;
+} orc_mod_t;
+
+/* NICAM-728 encoder + DQPSK modulator (src/nicam728.h:52-102) */
+typedef struct {
+	int on;
+	uint8_t mode, reserve;
+	unsigned int frame_no;
+	uint8_t prn[90];
+	int fir_p;
+	int16_t fir_l[83], fir_r[83];
+	int16_t audio[64];
+	int ntaps;
+	int16_t *taps;
+	int dsym;
+	c16_t *bb;
+	int bb_pos, bb_len;
+	int sps, ds, dsl, decimation;
+	c16_t *cc;
+	int cc_len, cc_pos;
+	uint8_t frame[91];
+	int frame_bit;
+} orc_nicam_t;
+
+struct orc_t {
+	hvk_config_t conf;
+	int sample_rate;
+	int pixel_rate;
+
+	/* geometry (src/video.c:3844-3853) */
+	int width, half_width, active_width, active_left;
+
+	/* levels (src/video.c:3878-3881) */
+	int16_t white_level, black_level, blanking_level, sync_level;
+
+	/* the five sync pulses: h, v, V, mid-v, mid-V (src/video.c:3885-3891) */
+	orc_pulse_t sync[5];
+	int16_t *sync_packed;       /* the reference's packed vbidata table, for comparison */
+	long sync_packed_len;
+
+	int16_t *yuv;               /* 0x1000000 x {y,u,v} */
+
+	unsigned int colour_lookup_width;
+	unsigned int colour_lookup_offset;
+	c16_t *colour_lookup;
+
+	c16_t burst_phase;
+	int burst_left, burst_width;
+	int16_t *burst_win;
+
+	int chroma_ntaps;
+	int16_t *chroma_taps;
+	int16_t ghost[32];
+	int16_t *chroma;            /* 2*width + slack */
+
+	/* video filter (src/video.c:3653-3764) */
+	int vf_type;                /* 0 none, 1 real->real, 3 real->complex */
+	int vf_ntaps;
+	int16_t *vf_itaps, *vf_qtaps;
+	int delay_lines;
+
+	/* current source frame */
+	const uint32_t *fb;
+	int fb_width, fb_height, fb_pixel_stride, fb_line_stride, fb_interlaced;
+
+	/* raster stream window: lines [s_first, s_first + s_count) */
+	int16_t *S;
+	long s_first, s_count, s_cap;
+	long rastered;              /* number of lines rastered so far (next g) */
+	long emitted;               /* number of lines emitted so far */
+
+	/* audio-rate state */
+	int interp;
+	const int16_t *audio_src;
+	long audio_len, audio_pos;
+	int audio_loop;
+	orc_mod_t fm_mono;
+	orc_mod_t am_mono;
+	orc_nicam_t nicam;
+	int16_t nicam_buf[64];
+	int nicam_buf_len;
+	int audio_primed;
+
+	/* stage taps of the last render call */
+	int16_t *last_raster; long last_raster_len;
+	int16_t *last_carrier; long last_carrier_len;
+};
+
+/* oracle_tables.c */
+int orc_build_tables(orc_t *s);
+void orc_free_tables(orc_t *s);
+double orc_rc_window(double t, double left, double width, double rise);
+
+/* oracle_raster.c */
+void orc_raster_line(orc_t *s, long g);
+int16_t *orc_line_ptr(orc_t *s, long g);
+
+/* oracle_audio.c */
+int orc_audio_init(orc_t *s);
+void orc_audio_free(orc_t *s);
+void orc_audio_line(orc_t *s, int16_t *iq, int width, int16_t *carrier_tap);
+
+#endif

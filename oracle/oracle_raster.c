@@ -1,0 +1,233 @@
+/* oracle/oracle_raster.c -- TEST INFRASTRUCTURE (not product code).
+ *
+ * CPU restatement of one scanline of hacktv's raster build for PAL / NTSC /
+ * monochrome modes: _vid_next_line_raster (src/video.c:2864-3066), the line
+ * sequence tables (src/video.c:2447-2862), the pulse renderer
+ * (src/vbidata.c:186-239) and the zero-history chroma FIR
+ * (src/fir.c:357-375 -> :304-355).
+ *
+ * The raster stream is kept as the I channel only (the reference's Q channel
+ * is zero until the filter / audio stages).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_internal.h"
+
+int16_t *orc_line_ptr(orc_t *s, long g)
+{
+	if(g < s->s_first || g >= s->s_first + s->s_count) return(NULL);
+	return(s->S + (g - s->s_first) * s->width);
+}
+
+/* Per-line content code. The reference keeps these as four-character strings
+ * per line number (src/video.c:2447-2810); restated here as field-position
+ * rules for the 625- and 525-line interlaced rasters.
+ *
+ * left:  0 none, 'h' line sync, 'v' short (equalising) pulse, 'V' long (broad) pulse
+ * mid:   0 none, 'v' or 'V' half-line pulse
+ * burst: 0 never, 1 always, 2 even frames only, 3 odd frames only (the
+ *        reference's '1' is tested as (frame & 1) == 0 and its '2' as
+ *        (frame & 1) == 1, src/video.c:2901-2903 -- the code, not the comment
+ *        at :2462-2463, is what is restated)
+ * la/ra: active video in the left / right half of the line */
+typedef struct {
+	char left, mid;
+	int burst;
+	int la, ra;
+} _linecode_t;
+
+static _linecode_t _line_code(int type, int line)
+{
+	_linecode_t c = { 'h', 0, 1, 1, 1 }; /* an ordinary picture line: "h0aa" */
+
+	if(type == HVK_RASTER_625)
+	{
+		if(line <= 2 || line == 314 || line == 315)       c = (_linecode_t) { 'V', 'V', 0, 0, 0 };
+		else if(line == 3)                                c = (_linecode_t) { 'V', 'v', 0, 0, 0 };
+		else if(line == 4 || line == 5 || line == 311 || line == 312 ||
+		        line == 316 || line == 317 || line >= 624) c = (_linecode_t) { 'v', 'v', 0, 0, 0 };
+		else if(line == 313)                              c = (_linecode_t) { 'v', 'V', 0, 0, 0 };
+		else if(line == 318)                              c = (_linecode_t) { 'v', 0, 0, 0, 0 };
+		else if(line == 6)                                c = (_linecode_t) { 'h', 0, 2, 0, 0 };
+		else if(line == 319)                              c = (_linecode_t) { 'h', 0, 3, 0, 0 };
+		else if(line <= 22 || (line >= 320 && line <= 335)) c = (_linecode_t) { 'h', 0, 1, 0, 0 };
+		else if(line == 23)                               c = (_linecode_t) { 'h', 0, 1, 0, 1 };
+		else if(line == 310 || line == 622)               c = (_linecode_t) { 'h', 0, 2, 1, 1 };
+		else if(line == 623)                              c = (_linecode_t) { 'h', 'v', 0, 1, 0 };
+	}
+	else if(type == HVK_RASTER_525)
+	{
+		if(line <= 3 || (line >= 7 && line <= 9) || line == 264 || line == 265 ||
+		   line == 270 || line == 271)                    c = (_linecode_t) { 'v', 'v', 0, 0, 0 };
+		else if(line <= 6 || line == 267 || line == 268)  c = (_linecode_t) { 'V', 'V', 0, 0, 0 };
+		else if(line == 266)                              c = (_linecode_t) { 'v', 'V', 0, 0, 0 };
+		else if(line == 269)                              c = (_linecode_t) { 'V', 'v', 0, 0, 0 };
+		else if(line == 272)                              c = (_linecode_t) { 'v', 0, 0, 0, 0 };
+		else if(line <= 20 || (line >= 273 && line <= 282)) c = (_linecode_t) { 'h', 0, 1, 0, 0 };
+		else if(line == 263)                              c = (_linecode_t) { 'h', 'v', 1, 1, 0 };
+		else if(line == 283)                              c = (_linecode_t) { 'h', 0, 1, 0, 1 };
+	}
+
+	return(c);
+}
+
+/* Source row shown on a line, before centring (src/video.c:2812-2862) */
+static int _source_row(int type, int line)
+{
+	if(type == HVK_RASTER_625) return(line < 313 ? (line - 23) * 2 : (line - 336) * 2 + 1);
+	if(type == HVK_RASTER_525) return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
+	return(-1);
+}
+
+/* Add one pulse to line g, continuing into the neighbouring lines when it
+ * starts before sample 0 or runs past the end. A line that is not part of
+ * the stream (before the first line) is a boundary: the part of the pulse
+ * that would land there is dropped (src/vbidata.c:211-236). */
+static void _add_pulse(orc_t *s, long g, const orc_pulse_t *p)
+{
+	long n = g * s->width + p->offset;
+	int x;
+
+	for(x = 0; x < p->length; x++, n++)
+	{
+		int16_t *l;
+		if(n < 0) continue;
+		l = orc_line_ptr(s, n / s->width);
+		if(l == NULL) continue;
+		l[n % s->width] += p->value[x];
+	}
+}
+
+/* Zero-history centred FIR over one interleaved channel of the chroma
+ * buffer, in place. Samples past the end of the channel come from
+ * s->chroma[2*width ...], where the caller has placed the ghost values. */
+static void _chroma_fir(orc_t *s, int16_t *ch)
+{
+	int h = s->chroma_ntaps / 2;
+	int W = s->width;
+	int16_t *in = malloc((W + 2 * h) * sizeof(int16_t));
+	int j, k;
+
+	for(j = 0; j < h; j++) in[j] = 0;
+	for(j = 0; j < W + h; j++) in[h + j] = ch[j * 2];
+
+	for(j = 0; j < W; j++)
+	{
+		int32_t a = 0;
+		for(k = 0; k < s->chroma_ntaps; k++) a += (int32_t) in[j + k] * s->chroma_taps[k];
+		a >>= 15;
+		ch[j * 2] = a < INT16_MIN ? INT16_MIN : (a > INT16_MAX ? INT16_MAX : a);
+	}
+
+	free(in);
+}
+
+void orc_raster_line(orc_t *s, long g)
+{
+	const hvk_config_t *c = &s->conf;
+	int frame = g / c->lines + 1;
+	int line = g % c->lines + 1;
+	_linecode_t code = _line_code(c->type, line);
+	int16_t *o = orc_line_ptr(s, g);
+	int W = s->width;
+	int vy, pal = 0, x;
+	const c16_t *lut = NULL;
+	int vframe_x = (s->active_width - s->fb_width) / 2;
+	int vframe_y = (c->active_lines - s->fb_height) / 2;
+
+	/* Building a line first blanks the one after it (src/video.c:2935-2939);
+	 * the very first line was blanked at start-up (:4659-4663) */
+	{
+		int16_t *nl = orc_line_ptr(s, g + 1);
+		if(g == 0) for(x = 0; x < W; x++) o[x] = s->blanking_level;
+		if(nl) for(x = 0; x < W; x++) nl[x] = s->blanking_level;
+	}
+
+	/* src/video.c:2884-2895 */
+	vy = _source_row(c->type, line);
+	if(vy >= 0 && c->interlaced != 0 && s->fb_interlaced != c->interlaced) vy += 1;
+	vy -= vframe_y;
+	if(vy < 0 || vy >= s->fb_height) vy = -1;
+
+	if(c->colour_mode == HVK_PAL || c->colour_mode == HVK_NTSC)
+	{
+		/* src/video.c:2900-2916 */
+		pal  = code.burst == 1;
+		pal |= code.burst == 2 && (frame & 1) == 0;
+		pal |= code.burst == 3 && (frame & 1) == 1;
+
+		lut = &s->colour_lookup[s->colour_lookup_offset];
+		s->colour_lookup_offset += W;
+		s->colour_lookup_offset %= s->colour_lookup_width;
+
+		if(c->colour_mode == HVK_PAL && pal && ((frame + line) & 1)) pal = -1;
+
+		if(pal)
+		{
+			memset(s->chroma, 0, sizeof(int16_t) * 2 * W);
+			memcpy(s->chroma + 2 * W, s->ghost, sizeof(s->ghost));
+		}
+	}
+
+	/* sync pulses, bit order h, v, V, mid-v, mid-V (src/video.c:2944-2958) */
+	if(code.left == 'h') _add_pulse(s, g, &s->sync[0]);
+	if(code.left == 'v') _add_pulse(s, g, &s->sync[1]);
+	if(code.left == 'V') _add_pulse(s, g, &s->sync[2]);
+	if(code.mid == 'v')  _add_pulse(s, g, &s->sync[3]);
+	if(code.mid == 'V')  _add_pulse(s, g, &s->sync[4]);
+
+	/* active video (src/video.c:2961-3009): luma is ASSIGNED, not added */
+	if(code.la || code.ra)
+	{
+		int al = code.la ? s->active_left : s->half_width;
+		int ar = code.ra ? s->active_left + s->active_width : s->half_width;
+		int16_t black = s->yuv[0];
+		const uint32_t *prgb = NULL;
+		int stride = 0;
+
+		for(x = al; x < s->active_left + vframe_x; x++) o[x] = black;
+
+		if(s->fb && vy >= 0)
+		{
+			prgb = &s->fb[vy * s->fb_line_stride];
+			prgb += (x - s->active_left - vframe_x) * s->fb_pixel_stride;
+			stride = s->fb_pixel_stride;
+		}
+
+		for(; x < s->active_left + vframe_x + s->fb_width && x < ar; x++)
+		{
+			uint32_t rgb = prgb ? (*prgb & 0xFFFFFF) : 0;
+			o[x] = s->yuv[rgb * 3 + 0];
+			if(pal)
+			{
+				s->chroma[x * 2 + 0] = s->yuv[rgb * 3 + 1];
+				s->chroma[x * 2 + 1] = s->yuv[rgb * 3 + 2];
+			}
+			if(prgb) prgb += stride;
+		}
+
+		for(; x < ar; x++) o[x] = black;
+	}
+
+	if(pal)
+	{
+		/* src/video.c:3015-3040 */
+		if(s->chroma_ntaps > 0)
+		{
+			_chroma_fir(s, s->chroma + 0);
+			_chroma_fir(s, s->chroma + 1);
+		}
+
+		for(x = 0; x < s->burst_width; x++)
+		{
+			s->chroma[(s->burst_left + x) * 2 + 0] = (s->burst_phase.i * s->burst_win[x]) >> 15;
+			s->chroma[(s->burst_left + x) * 2 + 1] = (s->burst_phase.q * s->burst_win[x]) >> 15;
+		}
+
+		for(x = 0; x < W; x++)
+		{
+			o[x] += (lut[x].i * s->chroma[x * 2 + 1] * pal +
+			         lut[x].q * s->chroma[x * 2 + 0]) >> 15;
+		}
+	}
+}

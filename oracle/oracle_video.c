@@ -1,0 +1,278 @@
+/* oracle/oracle_video.c -- TEST INFRASTRUCTURE (not product code).
+ *
+ * CPU restatement of hacktv's composite-video -> int16 IQ path
+ * (vid_init / vid_next_line, src/video.c:3812-4952) for the raster modes the
+ * MI355X engine covers. It is the checker the HIP path is compared with:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load
+ * it, never the product.
+ *
+ * Pinning: the reference ships no tests or golden vectors,
+ * so this restatement is pinned against the reference ITSELF, compiled
+ * unmodified from /root/reference by oracle/Makefile (oracle/_ref):
+ *   - every table against the reference's vid_init() output (tests/test_oracle_tables.py),
+ *   - the IQ stream against the reference CLI's output, both live
+ *     (tests/test_oracle_vs_ref.py, where oracle/_ref exists) and through
+ *     committed digests and line excerpts (tests/golden/, made by
+ *     oracle/make_golden.py).
+ *
+ * Structure. The reference is a ring of line buffers walked by a chain of
+ * line processes on threads (src/video.c:3543-3618, :4867-4934). The
+ * restatement keeps the same arithmetic but states each stage over the
+ * continuous sample stream:
+ *   raster   S[n]              oracle_raster.c   (I channel; sync edges spill
+ *                                                 into the previous line)
+ *   filter   F[n] = sum_k tap[k] * S[n - 25 + k] >> 15, clamped; S[n<0] = 0
+ *                                                 (src/fir.c:304-355, :564-615;
+ *                                                 delay src/video.c:3620-3625)
+ *   audio    out[n] = F[n] + carriers[n + delay_lines * width]
+ *                                                 oracle_audio.c (src/video.c:3261-3450;
+ *                                                 SURVEY.md H3 for the offset)
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_internal.h"
+
+orc_t *orc_open(const hvk_config_t *conf, unsigned int sample_rate)
+{
+	orc_t *s = calloc(1, sizeof(orc_t));
+	if(!s) return(NULL);
+
+	s->conf = *conf;
+	s->sample_rate = sample_rate;
+	s->pixel_rate = sample_rate;
+
+	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0)
+	{
+		orc_close(s);
+		return(NULL);
+	}
+
+	/* no frame yet: an empty frame the size of the active area (src/video.c:4169-4177) */
+	s->fb = NULL;
+	s->fb_width = s->active_width;
+	s->fb_height = s->conf.active_lines;
+
+	return(s);
+}
+
+void orc_close(orc_t *s)
+{
+	if(!s) return;
+	orc_free_tables(s);
+	orc_audio_free(s);
+	free(s->S);
+	free(s->last_raster);
+	free(s->last_carrier);
+	free(s);
+}
+
+int orc_info(orc_t *s, int32_t *out, int n)
+{
+	int32_t v[] = {
+		s->width, s->half_width, s->active_width, s->active_left,
+		s->conf.lines, s->conf.active_lines,
+		s->white_level, s->black_level, s->blanking_level, s->sync_level,
+		(int32_t) s->colour_lookup_width, s->burst_left, s->burst_width,
+		s->burst_phase.i, s->burst_phase.q,
+		s->chroma_ntaps, 0, s->width,
+		s->fm_mono.level, s->nicam.ntaps, s->nicam.sps, s->nicam.dsl, s->nicam.decimation,
+		s->nicam.cc_len,
+		s->am_mono.level, s->am_mono.delta.i, s->am_mono.delta.q,
+	};
+	int c = sizeof(v) / sizeof(v[0]);
+	if(n < c) c = n;
+	memcpy(out, v, c * sizeof(int32_t));
+	return(sizeof(v) / sizeof(v[0]));
+}
+
+static long _copy(void *dst, long max_bytes, const void *src, long bytes)
+{
+	if(src == NULL) return(0);
+	if(dst == NULL) return(bytes);
+	if(bytes > max_bytes) bytes = max_bytes;
+	memcpy(dst, src, bytes);
+	return(bytes);
+}
+
+long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
+{
+	if(strcmp(name, "syncs") == 0) return(_copy(dst, max_bytes, s->sync_packed, s->sync_packed_len * sizeof(int16_t)));
+	if(strcmp(name, "yuv") == 0) return(_copy(dst, max_bytes, s->yuv, 0x1000000L * 3 * sizeof(int16_t)));
+	if(strcmp(name, "colour_lookup") == 0) return(_copy(dst, max_bytes, s->colour_lookup, s->colour_lookup ? (long) (s->colour_lookup_width + s->width) * sizeof(c16_t) : 0));
+	if(strcmp(name, "burst_win") == 0) return(_copy(dst, max_bytes, s->burst_win, (long) s->burst_width * sizeof(int16_t)));
+	if(strcmp(name, "chroma_taps") == 0) return(_copy(dst, max_bytes, s->chroma_taps, (long) s->chroma_ntaps * sizeof(int16_t)));
+	if(strcmp(name, "chroma_ghost") == 0) return(_copy(dst, max_bytes, s->ghost, sizeof(s->ghost)));
+	if(strcmp(name, "vfilter_itaps") == 0) return(_copy(dst, max_bytes, s->vf_itaps, (long) s->vf_ntaps * sizeof(int16_t)));
+	if(strcmp(name, "vfilter_qtaps") == 0) return(_copy(dst, max_bytes, s->vf_qtaps, (long) s->vf_ntaps * sizeof(int16_t)));
+	if(strcmp(name, "fm_mono_lut") == 0) return(_copy(dst, max_bytes, s->fm_mono.lut, 65536L * sizeof(c32_t)));
+	if(strcmp(name, "nicam_taps") == 0) return(_copy(dst, max_bytes, s->nicam.taps, (long) s->nicam.ntaps * sizeof(int16_t)));
+	if(strcmp(name, "nicam_cc") == 0) return(_copy(dst, max_bytes, s->nicam.cc, (long) s->nicam.cc_len * sizeof(c16_t)));
+	if(strcmp(name, "limiter_shape") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.shape, (long) s->fm_mono.lim.width * sizeof(int16_t)));
+	if(strcmp(name, "limiter_vtaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.vtaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
+	if(strcmp(name, "limiter_ftaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.ftaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
+	return(-1);
+}
+
+void orc_set_ghost(orc_t *s, const int16_t *ghost, int n)
+{
+	memset(s->ghost, 0, sizeof(s->ghost));
+	if(n > 32) n = 32;
+	memcpy(s->ghost, ghost, n * sizeof(int16_t));
+}
+
+void orc_set_frame(orc_t *s, const uint32_t *fb, int width, int height, int pixel_stride, int line_stride, int interlaced)
+{
+	/* centre-crop to the active area (src/video.c:4887-4893, src/av.c:293-303) */
+	int x = (width - s->active_width) / 2;
+	int y = (height - s->conf.active_lines) / 2;
+	int w = s->active_width, h = s->conf.active_lines;
+
+	if(x < 0) { w += x; x = 0; }
+	if(y < 0) { h += y; y = 0; }
+	if(x + w > width) w = width - x;
+	if(y + h > height) h = height - y;
+
+	s->fb = fb ? fb + y * line_stride + x * pixel_stride : NULL;
+	s->fb_width = w;
+	s->fb_height = h;
+	s->fb_pixel_stride = pixel_stride;
+	s->fb_line_stride = line_stride;
+	s->fb_interlaced = interlaced;
+}
+
+void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop)
+{
+	s->audio_src = stereo;
+	s->audio_len = nsamples;
+	s->audio_pos = 0;
+	s->audio_loop = loop;
+}
+
+/* Make sure raster lines up to and including `last` exist. Lines older than
+ * `keep_from` may be dropped. */
+static void _raster_until(orc_t *s, long last, long keep_from)
+{
+	long need_first = keep_from < 0 ? 0 : keep_from;
+	long need_count = last + 2 - need_first; /* + the line blanked ahead */
+	int W = s->width;
+
+	if(need_first > s->s_first && s->s_count > 0)
+	{
+		long drop = need_first - s->s_first;
+		if(drop > s->s_count) drop = s->s_count;
+		memmove(s->S, s->S + drop * W, (s->s_count - drop) * W * sizeof(int16_t));
+		s->s_first += drop;
+		s->s_count -= drop;
+	}
+	if(s->s_count == 0) s->s_first = need_first;
+
+	if(need_count > s->s_cap)
+	{
+		s->S = realloc(s->S, need_count * W * sizeof(int16_t));
+		s->s_cap = need_count;
+	}
+	if(need_count > s->s_count)
+	{
+		/* new lines enter zeroed; the raster blanks each before use */
+		memset(s->S + s->s_count * W, 0, (need_count - s->s_count) * W * sizeof(int16_t));
+		s->s_count = need_count;
+	}
+
+	while(s->rastered <= last)
+	{
+		orc_raster_line(s, s->rastered);
+		s->rastered++;
+	}
+}
+
+static int16_t _sample(orc_t *s, long n)
+{
+	const int16_t *l;
+	if(n < 0) return(0);
+	l = orc_line_ptr(s, n / s->width);
+	return(l ? l[n % s->width] : 0);
+}
+
+long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
+{
+	int W = s->width;
+	long g0 = s->emitted, g, o = 0;
+	int x, k;
+
+	if(nlines <= 0) return(0);
+
+	/* Lines the pipeline produces before the first emitted one carry the
+	 * audio process too: the audio-rate state is advanced by
+	 * delay_lines * width samples before the first visible sample. */
+	if(!s->audio_primed)
+	{
+		for(k = 0; k < s->delay_lines; k++) orc_audio_line(s, NULL, W, NULL);
+		s->audio_primed = 1;
+	}
+
+	/* the filter looks 25 samples into the next line; every line also takes
+	 * the leading sync edge of its successor: raster one line ahead */
+	_raster_until(s, g0 + nlines, g0 - 1);
+
+	free(s->last_raster);
+	free(s->last_carrier);
+	s->last_raster = malloc(nlines * W * sizeof(int16_t));
+	s->last_carrier = calloc(nlines * W * 2, sizeof(int16_t));
+	s->last_raster_len = nlines * W;
+	s->last_carrier_len = nlines * W;
+
+	for(g = g0; g < g0 + nlines; g++)
+	{
+		int16_t *out = iq + o * 2;
+		long base = g * W;
+
+		memcpy(s->last_raster + (g - g0) * W, orc_line_ptr(s, g), W * sizeof(int16_t));
+
+		if(s->vf_type == 0)
+		{
+			for(x = 0; x < W; x++)
+			{
+				out[x * 2 + 0] = _sample(s, base + x);
+				out[x * 2 + 1] = 0;
+			}
+		}
+		else
+		{
+			int h = s->vf_ntaps / 2;
+			for(x = 0; x < W; x++)
+			{
+				int32_t ai = 0, aq = 0;
+				for(k = 0; k < s->vf_ntaps; k++)
+				{
+					int32_t v = _sample(s, base + x - h + k);
+					ai += v * s->vf_itaps[k];
+					if(s->vf_type == 3) aq += v * s->vf_qtaps[k];
+				}
+				ai >>= 15;
+				aq >>= 15;
+				out[x * 2 + 0] = ai < INT16_MIN ? INT16_MIN : (ai > INT16_MAX ? INT16_MAX : ai);
+				out[x * 2 + 1] = aq < INT16_MIN ? INT16_MIN : (aq > INT16_MAX ? INT16_MAX : aq);
+			}
+		}
+
+		orc_audio_line(s, out, W, s->last_carrier + (g - g0) * W * 2);
+		o += W;
+	}
+
+	s->emitted += nlines;
+	return(o);
+}
+
+long orc_last_raster(orc_t *s, int16_t *dst, long max_samples)
+{
+	long n = s->last_raster_len < max_samples ? s->last_raster_len : max_samples;
+	if(dst && n > 0) memcpy(dst, s->last_raster, n * sizeof(int16_t));
+	return(s->last_raster_len);
+}
+
+long orc_last_carrier(orc_t *s, int16_t *dst, long max_samples)
+{
+	long n = s->last_carrier_len < max_samples ? s->last_carrier_len : max_samples;
+	if(dst && n > 0) memcpy(dst, s->last_carrier, n * 2 * sizeof(int16_t));
+	return(s->last_carrier_len);
+}

@@ -1,0 +1,47 @@
+/* oracle/oracle_video.h -- TEST INFRASTRUCTURE (not product code).
+ *
+ * C ABI of the CPU restatement of hacktv's composite-video -> IQ path.
+ * Loaded with ctypes by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg only. The product (hacktv_amd/) never links or calls it.
+ */
+#ifndef ORACLE_VIDEO_H
+#define ORACLE_VIDEO_H
+
+#include <stdint.h>
+#include "../include/hvk_config.h"
+
+typedef struct orc_t orc_t;
+
+orc_t *orc_open(const hvk_config_t *conf, unsigned int sample_rate);
+void orc_close(orc_t *s);
+
+/* Geometry / levels in the order tests/refprobe.py INFO_NAMES lists */
+int orc_info(orc_t *s, int32_t *out, int n);
+
+/* Table dump, same names as oracle/ref_probe.c:ref_table */
+long orc_table(orc_t *s, const char *name, void *dst, long max_bytes);
+
+/* The int16 values the reference's chroma FIR over-reads past the end of
+ * its chrominance buffer. Default: the glibc-2.35 fresh-heap
+ * model (slack, chunk size word, burst window). */
+void orc_set_ghost(orc_t *s, const int16_t *ghost, int n);
+
+/* Current source frame (kept by reference, like av_read_video's contract) */
+void orc_set_frame(orc_t *s, const uint32_t *fb, int width, int height, int pixel_stride, int line_stride, int interlaced);
+
+/* 32 kHz interleaved stereo source; loop != 0 repeats it forever (av_test) */
+void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop);
+
+/* Render the next nlines emitted lines (interleaved I/Q int16). Returns
+ * the number of samples (pairs) written. */
+long orc_render_lines(orc_t *s, int16_t *iq, long nlines);
+
+/* Stage taps for tests: the final raster (I channel, before filter/audio) of
+ * the lines produced by the last orc_render_lines call */
+long orc_last_raster(orc_t *s, int16_t *dst, long max_samples);
+
+/* The serial-carrier contribution (FM/AM audio, I/Q int16 pairs) and NICAM
+ * symbol values added to the lines of the last call */
+long orc_last_carrier(orc_t *s, int16_t *dst, long max_samples);
+
+#endif

@@ -1,0 +1,303 @@
+/* oracle/ref_probe.c -- TEST INFRASTRUCTURE (not product code).
+ *
+ * A thin probe linked with the UNMODIFIED reference objects (oracle/Makefile,
+ * target _ref/libhacktv_ref.so). It drives the reference engine in-process the
+ * way the reference's own main() does (src/hacktv.c:1077-1587: preset lookup,
+ * flag overrides, vid_init, s.vid.av set-up, av_test_open, vid_next_line loop)
+ * and exposes, through a C ABI that tests/ load with ctypes:
+ *
+ *   - the lines the reference emits (int16 I/Q pairs), and
+ *   - the tables vid_init() built (src/video.c:3812-4162), so the product's
+ *     host table builder and the oracle restatement can be compared entry for
+ *     entry with the reference's own.
+ *
+ * Only tests/ and the golden-vector generator use this. It needs
+ * /root/reference at BUILD time only; the built .so travels to the GPU box.
+ */
+#include <stdlib.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <unistd.h>
+#include "hacktv.h"
+
+#define REF_FLAG_FILTER   (1 << 0)
+#define REF_FLAG_NOAUDIO  (1 << 1)
+#define REF_FLAG_NONICAM  (1 << 2)
+#define REF_FLAG_NOCOLOUR (1 << 3)
+
+typedef struct {
+	vid_t vid;
+	int open;
+	long rendered;
+} ref_probe_t;
+
+ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int pixel_rate, int flags, const char *teletext)
+{
+	const vid_configs_t *vc;
+	vid_config_t conf;
+	ref_probe_t *p;
+
+	for(vc = vid_configs; vc->id != NULL; vc++)
+	{
+		if(strcmp(mode, vc->id) == 0) break;
+	}
+	if(vc->id == NULL) return(NULL);
+
+	memcpy(&conf, vc->conf, sizeof(vid_config_t));
+
+	/* The same overrides main() applies for these flags
+	 * (src/hacktv.c:1126-1171, :1412-1415, :1431) */
+	if(flags & REF_FLAG_NOCOLOUR)
+	{
+		if(conf.colour_mode == VID_PAL || conf.colour_mode == VID_SECAM || conf.colour_mode == VID_NTSC)
+		{
+			conf.colour_mode = VID_NONE;
+		}
+	}
+	if(flags & REF_FLAG_NOAUDIO)
+	{
+		conf.fm_mono_level = conf.fm_left_level = conf.fm_right_level = 0;
+		conf.am_audio_level = conf.nicam_level = conf.dance_level = 0;
+		conf.fm_mono_carrier = conf.fm_left_carrier = conf.fm_right_carrier = 0;
+		conf.nicam_carrier = conf.dance_carrier = conf.am_mono_carrier = 0;
+	}
+	if(flags & REF_FLAG_NONICAM)
+	{
+		conf.nicam_level = 0;
+		conf.nicam_carrier = 0;
+	}
+	if(flags & REF_FLAG_FILTER) conf.vfilter = 1;
+	if(teletext && teletext[0]) conf.teletext = (char *) teletext;
+	conf.volume = 1.0 * 256 + 0.5;
+
+	p = calloc(1, sizeof(ref_probe_t));
+	if(!p) return(NULL);
+
+	if(vid_init(&p->vid, sample_rate, pixel_rate, &conf) != VID_OK)
+	{
+		free(p);
+		return(NULL);
+	}
+
+	/* src/hacktv.c:1503-1518 */
+	p->vid.av = (av_t) {
+		.frame_rate = (r64_t) {
+			.num = p->vid.conf.frame_rate.num * (p->vid.conf.interlace ? 2 : 1),
+			.den = p->vid.conf.frame_rate.den,
+		},
+		.display_aspect_ratios = { p->vid.conf.frame_aspects[0], p->vid.conf.frame_aspects[1] },
+		.fit_mode = AV_FIT_STRETCH,
+		.width = p->vid.active_width,
+		.height = p->vid.conf.active_lines,
+		.sample_rate = (r64_t) { HACKTV_AUDIO_SAMPLE_RATE, 1 },
+	};
+
+	if(av_test_open(&p->vid.av) != AV_OK)
+	{
+		vid_free(&p->vid);
+		free(p);
+		return(NULL);
+	}
+
+	p->open = 1;
+	return(p);
+}
+
+void ref_close(ref_probe_t *p)
+{
+	if(!p) return;
+	/* vid_free() is not usable from a long-lived test process: its worker
+	 * shutdown (src/video.c:4714-4721 against :3590-3613) races twice -- the
+	 * main thread stops taking part in the barrier as soon as it reads
+	 * nthreads == 0, and the workers decrement nthreads without a lock
+	 * (:3607), so with two or more workers the count can stick at 1 and a
+	 * worker waits at the barrier for ever (observed here). The reference CLI
+	 * survives because the process exits right after. The probe therefore
+	 * leaves the workers parked at their barrier (they hold no lock and never
+	 * run again), closes the source and releases the large tables by hand. */
+	if(p->open)
+	{
+		vid_t *s = &p->vid;
+		if(s->nthreads == 0)
+		{
+			vid_free(s);
+		}
+		else
+		{
+			/* let workers still finishing the line after the last barrier park */
+			usleep(50000);
+			av_close(&s->av);
+			free(s->yuv_level_lookup);
+			free(s->colour_lookup);
+			free(s->fm_mono.lut);
+			free(s->fm_secam.lut);
+			free(s->fm_secam_bell);
+		}
+	}
+	free(p);
+}
+
+/* Geometry and levels, in a fixed order the python side names */
+int ref_info(ref_probe_t *p, int32_t *out, int n)
+{
+	const vid_t *s = &p->vid;
+	int32_t v[] = {
+		s->width, s->half_width, s->active_width, s->active_left,
+		s->conf.lines, s->conf.active_lines,
+		s->white_level, s->black_level, s->blanking_level, s->sync_level,
+		(int32_t) s->colour_lookup_width, s->burst_left, s->burst_width,
+		s->burst_phase.i, s->burst_phase.q,
+		s->chrominance_fir.ataps, s->olines, s->max_width,
+		s->fm_mono.level, s->nicam.ntaps, s->nicam.sps, s->nicam.dsl, s->nicam.decimation,
+		(int32_t) (s->nicam.cc_end - s->nicam.cc_start),
+		s->am_mono.level, s->am_mono.delta.i, s->am_mono.delta.q,
+		s->fm_secam.level, s->fm_secam_dmin[0], s->fm_secam_dmax[0], s->fm_secam_dmin[1], s->fm_secam_dmax[1],
+		s->secam_fsync_level, s->secam_field_id_lines,
+	};
+	int c = sizeof(v) / sizeof(v[0]);
+	if(n < c) c = n;
+	memcpy(out, v, c * sizeof(int32_t));
+	return(sizeof(v) / sizeof(v[0]));
+}
+
+/* Copy the next emitted line. Returns its width in samples (pairs), or -1 */
+int ref_next_line(ref_probe_t *p, int16_t *iq, int max_samples, int32_t *frame, int32_t *line)
+{
+	vid_line_t *l = vid_next_line(&p->vid);
+	if(l == NULL) return(-1);
+	p->rendered++;
+	if(l->width > max_samples) return(-2);
+	memcpy(iq, l->output, sizeof(int16_t) * 2 * l->width);
+	if(frame) *frame = l->frame;
+	if(line) *line = l->line;
+	return(l->width);
+}
+
+/* Render n whole lines back to back into iq. Returns samples written */
+long ref_render_lines(ref_probe_t *p, int16_t *iq, long nlines)
+{
+	long i, o = 0;
+	for(i = 0; i < nlines; i++)
+	{
+		vid_line_t *l = vid_next_line(&p->vid);
+		if(l == NULL) break;
+		p->rendered++;
+		memcpy(iq + o * 2, l->output, sizeof(int16_t) * 2 * l->width);
+		o += l->width;
+	}
+	return(o);
+}
+
+static long _copy(void *dst, long max_bytes, const void *src, long bytes)
+{
+	if(src == NULL) return(0);
+	if(dst == NULL) return(bytes);
+	if(bytes > max_bytes) bytes = max_bytes;
+	memcpy(dst, src, bytes);
+	return(bytes);
+}
+
+static long _vbilut_bytes(const vbidata_lut_t *lut)
+{
+	const int16_t *p = (const int16_t *) lut;
+	long n = 0;
+	if(!lut) return(0);
+	while(p[n] != -1) n += 2 + p[n];
+	return((n + 1) * sizeof(int16_t));
+}
+
+/* Table dump: returns the table's size in bytes (copying up to max_bytes if
+ * dst != NULL), 0 if the table does not exist in this mode, -1 if unknown. */
+long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
+{
+	vid_t *s = &p->vid;
+
+	if(strcmp(name, "syncs") == 0)
+		return(_copy(dst, max_bytes, s->syncs, _vbilut_bytes(s->syncs)));
+	if(strcmp(name, "yuv") == 0)
+		return(_copy(dst, max_bytes, s->yuv_level_lookup, 0x1000000L * sizeof(_yuv16_t)));
+	if(strcmp(name, "colour_lookup") == 0)
+		return(_copy(dst, max_bytes, s->colour_lookup, s->colour_lookup ? (long) (s->colour_lookup_width + s->width) * sizeof(cint16_t) : 0));
+	if(strcmp(name, "burst_win") == 0)
+		return(_copy(dst, max_bytes, s->burst_win, s->burst_win ? (long) s->burst_width * sizeof(int16_t) : 0));
+	if(strcmp(name, "chroma_taps") == 0)
+		return(_copy(dst, max_bytes, s->chrominance_fir.itaps, s->chrominance_fir.itaps ? (long) s->chrominance_fir.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "chroma_ghost") == 0)
+	{
+		/* The int16s that follow the 2*width chrominance buffer on the heap:
+		 * the reference's chroma FIR reads ataps/2 of them per channel
+		 * (src/fir.c:365-372 with samples = width) */
+		return(_copy(dst, max_bytes, s->chrominance_buffer ? s->chrominance_buffer + 2 * s->width : NULL, 32 * sizeof(int16_t)));
+	}
+	if(strcmp(name, "vfilter_itaps") == 0 || strcmp(name, "vfilter_qtaps") == 0)
+	{
+		int i;
+		for(i = 0; i < s->nprocesses; i++)
+		{
+			if(strcmp(s->processes[i].name, "vfilter") == 0)
+			{
+				/* _vid_filter_process_t is private to video.c: { int channels; fir_int16_t fir[2]; } */
+				struct { int channels; fir_int16_t fir[2]; } *fp = s->processes[i].arg;
+				const int16_t *t = name[8] == 'i' ? fp->fir[0].itaps : fp->fir[0].qtaps;
+				return(_copy(dst, max_bytes, t, t ? (long) fp->fir[0].ntaps * sizeof(int16_t) : 0));
+			}
+		}
+		return(0);
+	}
+	if(strcmp(name, "fm_mono_lut") == 0)
+		return(_copy(dst, max_bytes, s->fm_mono.lut, s->fm_mono.lut ? 65536L * sizeof(cint32_t) : 0));
+	if(strcmp(name, "fm_secam_lut") == 0)
+		return(_copy(dst, max_bytes, s->fm_secam.lut, s->fm_secam.lut ? 65536L * sizeof(cint32_t) : 0));
+	if(strcmp(name, "fm_secam_bell") == 0)
+		return(_copy(dst, max_bytes, s->fm_secam_bell, s->fm_secam_bell ? 65535L * sizeof(cint16_t) : 0));
+	if(strcmp(name, "fm_secam_fir") == 0)
+		return(_copy(dst, max_bytes, s->fm_secam_fir.itaps, s->fm_secam_fir.itaps ? (long) s->fm_secam_fir.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "secam_l_fir") == 0)
+		return(_copy(dst, max_bytes, s->secam_l_fir.itaps, s->secam_l_fir.itaps ? (long) s->secam_l_fir.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "nicam_taps") == 0)
+		return(_copy(dst, max_bytes, s->nicam.taps, s->nicam.taps ? (long) s->nicam.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "nicam_cc") == 0)
+		return(_copy(dst, max_bytes, s->nicam.cc_start, s->nicam.cc_start ? (long) (s->nicam.cc_end - s->nicam.cc_start) * sizeof(cint16_t) : 0));
+	if(strcmp(name, "limiter_shape") == 0)
+		return(_copy(dst, max_bytes, s->fm_mono.limiter.shape, s->fm_mono.limiter.shape ? (long) s->fm_mono.limiter.width * sizeof(int16_t) : 0));
+	if(strcmp(name, "limiter_vtaps") == 0)
+		return(_copy(dst, max_bytes, s->fm_mono.limiter.vfir.itaps, s->fm_mono.limiter.vfir.itaps ? (long) s->fm_mono.limiter.vfir.ntaps * sizeof(int32_t) : 0));
+	if(strcmp(name, "limiter_ftaps") == 0)
+		return(_copy(dst, max_bytes, s->fm_mono.limiter.ffir.itaps, s->fm_mono.limiter.ffir.itaps ? (long) s->fm_mono.limiter.ffir.ntaps * sizeof(int32_t) : 0));
+	if(strcmp(name, "teletext_lut") == 0)
+		return(_copy(dst, max_bytes, s->tt.lut, s->conf.teletext ? _vbilut_bytes(s->tt.lut) : 0));
+
+	return(-1);
+}
+
+/* The test source's frame and audio loop, for building golden input fixtures.
+ * Must be called before any line is rendered. */
+long ref_test_frame(ref_probe_t *p, uint32_t *dst, long max_pixels)
+{
+	av_frame_t f;
+	long n;
+	if(p->vid.av.read_video == NULL) return(-1);
+	if(p->vid.av.read_video(p->vid.av.av_source_ctx, &f) != AV_OK) return(-1);
+	n = (long) f.width * f.height;
+	if(dst)
+	{
+		if(n > max_pixels) n = max_pixels;
+		memcpy(dst, f.framebuffer, n * sizeof(uint32_t));
+	}
+	return((long) f.width * f.height);
+}
+
+long ref_test_audio(ref_probe_t *p, int16_t *dst, long max_samples)
+{
+	int16_t *a;
+	size_t n;
+	if(p->vid.av.read_audio == NULL) return(-1);
+	if(p->vid.av.read_audio(p->vid.av.av_source_ctx, &a, &n) != AV_OK) return(-1);
+	if(dst)
+	{
+		if((long) n > max_samples) n = max_samples;
+		memcpy(dst, a, n * 2 * sizeof(int16_t));
+	}
+	return((long) n);
+}

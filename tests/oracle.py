@@ -1,0 +1,108 @@
+"""ctypes wrapper around oracle/liboracle.so -- the CPU restatement of the
+reference's composite-video -> IQ path (TEST INFRASTRUCTURE)."""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.orc_open.restype = C.c_void_p
+        L.orc_open.argtypes = [C.c_void_p, C.c_uint]
+        L.orc_close.argtypes = [C.c_void_p]
+        L.orc_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_table.restype = C.c_long
+        L.orc_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+        L.orc_set_ghost.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_set_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+        L.orc_render_lines.restype = C.c_long
+        L.orc_render_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_last_raster.restype = C.c_long
+        L.orc_last_raster.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_last_carrier.restype = C.c_long
+        L.orc_last_carrier.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        _lib = L
+    return _lib
+
+
+INFO_NAMES = [
+    "width", "half_width", "active_width", "active_left", "lines", "active_lines",
+    "white_level", "black_level", "blanking_level", "sync_level",
+    "colour_lookup_width", "burst_left", "burst_width", "burst_phase_i", "burst_phase_q",
+    "chroma_ataps", "olines", "max_width",
+    "fm_mono_level", "nicam_ntaps", "nicam_sps", "nicam_dsl", "nicam_decimation", "nicam_cc_len",
+    "am_mono_level", "am_mono_delta_i", "am_mono_delta_q",
+]
+
+
+class Oracle:
+    def __init__(self, conf, sample_rate):
+        self.conf = conf
+        self.p = lib().orc_open(C.addressof(conf), sample_rate)
+        if not self.p:
+            raise RuntimeError("orc_open failed")
+        v = np.zeros(64, np.int32)
+        n = lib().orc_info(self.p, v.ctypes.data, 64)
+        self.info = dict(zip(INFO_NAMES, v[:n].tolist()))
+        self._keep = []
+
+    def table(self, name, dtype):
+        n = lib().orc_table(self.p, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        a = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        if n:
+            lib().orc_table(self.p, name.encode(), a.ctypes.data, n)
+        return a
+
+    def set_ghost(self, ghost):
+        g = np.ascontiguousarray(ghost, np.int16)
+        lib().orc_set_ghost(self.p, g.ctypes.data, len(g))
+
+    def set_frame(self, fb, interlaced=0):
+        fb = np.ascontiguousarray(fb, np.uint32)
+        self._keep.append(fb)
+        h, w = fb.shape
+        lib().orc_set_frame(self.p, fb.ctypes.data, w, h, 1, w, interlaced)
+
+    def set_audio(self, stereo, loop=True):
+        a = np.ascontiguousarray(stereo, np.int16)
+        self._keep.append(a)
+        lib().orc_set_audio(self.p, a.ctypes.data, a.shape[0], 1 if loop else 0)
+
+    def render_lines(self, nlines):
+        w = self.info["width"]
+        buf = np.zeros(nlines * w * 2, np.int16)
+        got = lib().orc_render_lines(self.p, buf.ctypes.data, nlines)
+        return buf[: got * 2].reshape(got, 2)
+
+    def last_raster(self):
+        n = lib().orc_last_raster(self.p, None, 0)
+        a = np.zeros(n, np.int16)
+        lib().orc_last_raster(self.p, a.ctypes.data, n)
+        return a
+
+    def last_carrier(self):
+        n = lib().orc_last_carrier(self.p, None, 0)
+        a = np.zeros(n * 2, np.int16)
+        lib().orc_last_carrier(self.p, a.ctypes.data, n)
+        return a.reshape(n, 2)
+
+    def close(self):
+        if self.p:
+            lib().orc_close(self.p)
+            self.p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -1,0 +1,101 @@
+"""ctypes wrapper around oracle/_ref/libhacktv_ref.so (TEST INFRASTRUCTURE).
+
+The shared object is the UNMODIFIED reference engine plus oracle/ref_probe.c,
+built by oracle/Makefile where /root/reference exists. Tests that use it skip
+when it has not been built.
+"""
+import ctypes
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "_ref", "libhacktv_ref.so")
+BIN_PATH = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
+
+FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
+
+INFO_NAMES = [
+    "width", "half_width", "active_width", "active_left", "lines", "active_lines",
+    "white_level", "black_level", "blanking_level", "sync_level",
+    "colour_lookup_width", "burst_left", "burst_width", "burst_phase_i", "burst_phase_q",
+    "chroma_ataps", "olines", "max_width",
+    "fm_mono_level", "nicam_ntaps", "nicam_sps", "nicam_dsl", "nicam_decimation", "nicam_cc_len",
+    "am_mono_level", "am_mono_delta_i", "am_mono_delta_q",
+    "fm_secam_level", "secam_dmin0", "secam_dmax0", "secam_dmin1", "secam_dmax1",
+    "secam_fsync_level", "secam_field_id_lines",
+]
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(LIB_PATH)
+        L.ref_open.restype = ctypes.c_void_p
+        L.ref_open.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_char_p]
+        L.ref_close.argtypes = [ctypes.c_void_p]
+        L.ref_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ref_render_lines.restype = ctypes.c_long
+        L.ref_render_lines.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        L.ref_table.restype = ctypes.c_long
+        L.ref_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long]
+        L.ref_test_frame.restype = ctypes.c_long
+        L.ref_test_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        L.ref_test_audio.restype = ctypes.c_long
+        L.ref_test_audio.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        _lib = L
+    return _lib
+
+
+class RefProbe:
+    def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None):
+        self.p = lib().ref_open(mode.encode(), sample_rate, pixel_rate, flags,
+                                teletext.encode() if teletext else None)
+        if not self.p:
+            raise RuntimeError("ref_open failed for mode %r" % mode)
+        v = np.zeros(64, np.int32)
+        n = lib().ref_info(self.p, v.ctypes.data, 64)
+        self.info = dict(zip(INFO_NAMES, v[:n].tolist()))
+
+    def table(self, name, dtype):
+        n = lib().ref_table(self.p, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        a = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        if n:
+            lib().ref_table(self.p, name.encode(), a.ctypes.data, n)
+        return a
+
+    def test_frame(self):
+        n = lib().ref_test_frame(self.p, None, 0)
+        a = np.zeros(n, np.uint32)
+        lib().ref_test_frame(self.p, a.ctypes.data, n)
+        return a.reshape(self.info["active_lines"], self.info["active_width"])
+
+    def test_audio(self):
+        n = lib().ref_test_audio(self.p, None, 0)
+        a = np.zeros(n * 2, np.int16)
+        lib().ref_test_audio(self.p, a.ctypes.data, n)
+        return a.reshape(n, 2)
+
+    def render_lines(self, nlines):
+        w = self.info["max_width"]
+        buf = np.zeros(nlines * w * 2, np.int16)
+        got = lib().ref_render_lines(self.p, buf.ctypes.data, nlines)
+        return buf[: got * 2].reshape(got, 2)
+
+    def close(self):
+        if self.p:
+            lib().ref_close(self.p)
+            self.p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
