@@ -1,0 +1,9 @@
+"""hacktv_amd -- Python binding of libhvk, the MI355X composite-video -> IQ
+engine. The product is the C ABI in include/hacktv_amd.h; this package only
+loads it with ctypes for the test-suite, bench.py and __graft_entry__.py."""
+from .ctypes_defs import (HvkConfig, HvkInfo, HvkRational, FLAG_FILTER, FLAG_NOAUDIO,
+                          FLAG_NONICAM, FLAG_NOCOLOUR, HVK_OK, HVK_NO_DEVICE)
+from .engine import Engine, HvkError, lib, preset, LIB_PATH
+
+__all__ = ["Engine", "HvkError", "HvkConfig", "HvkInfo", "HvkRational", "lib", "preset", "LIB_PATH",
+           "FLAG_FILTER", "FLAG_NOAUDIO", "FLAG_NONICAM", "FLAG_NOCOLOUR", "HVK_OK", "HVK_NO_DEVICE"]

@@ -1,0 +1,627 @@
+/* hvk_audio.c -- host audio-rate control path of the MI355X engine.
+ *
+ * The reference adds its audio sub-carriers inside a per-sample loop on a
+ * pipeline thread (_vid_audio_process, src/video.c:3261-3450). Two different
+ * kinds of work hide in that loop:
+ *
+ *  (1) serial, non-associative recurrences: the FM / AM carrier phasors are
+ *      advanced by a complex multiply that is floored after every step
+ *      (cint32_mul, src/common.h:80-89; _fm_modulator_add, src/video.c:
+ *      2259-2276; _am_modulator_add, :2359-2378), and re-normalised through
+ *      libm every 32767 samples. Sample n cannot be had without sample n-1,
+ *      bit for bit. This stays on the host, on one core, and
+ *      its result -- the summed int16 I/Q contribution of all such carriers,
+ *      4 bytes per sample -- is a side INPUT of the device path;
+ *
+ *  (2) everything else: the 32 kHz control logic (volume, mono mix, soft
+ *      limiter with its two 65-tap FIRs, NICAM-728 companding / interleaving
+ *      / scrambling, the differential QPSK state) is cheap and sequential and
+ *      is done here too, but the per-sample NICAM work -- pulse shaping by
+ *      overlap-add and the mix onto the 6.552 MHz carrier, src/nicam728.c:
+ *      342-411 -- is data parallel and is done in the filter kernel from the
+ *      symbol values this file emits (1 byte per 44 samples).
+ *
+ * Ordering follows the reference exactly, including its line granularity:
+ * for every line of `width` samples the tick loop runs first and the NICAM
+ * modulator afterwards, which decides which 32-sample audio block a NICAM
+ * frame carries.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "hvk_internal.h"
+
+#define AUDIO_RATE      32000   /* src/hacktv.h:31 */
+#define NICAM_SYMRATE   364000
+#define NICAM_FRAME_BITS 728
+#define J17_TAPS        83
+#define SYM_HISTORY     64      /* symbols kept behind the newest request */
+
+/* ---- 65-tap int32 FIR, one sample at a time (src/fir.c:655-694) ---- */
+typedef struct {
+	const int32_t *taps;    /* taps[y] meets the sample 64 - y steps old */
+	int32_t hist[65];
+	int pos;                /* where the next sample goes == oldest sample */
+} _fir65_t;
+
+static int32_t _fir65(_fir65_t *f, int32_t in)
+{
+	int64_t acc = 0;
+	int y, p;
+
+	f->hist[f->pos] = in;
+	f->pos = f->pos == 64 ? 0 : f->pos + 1;
+
+	for(y = 0, p = f->pos; y < 65; y++)
+	{
+		acc += (int64_t) f->hist[p] * f->taps[y];
+		p = p == 64 ? 0 : p + 1;
+	}
+
+	acc >>= 15;
+	if(acc < INT32_MIN) return(INT32_MIN);
+	if(acc > INT32_MAX) return(INT32_MAX);
+	return((int32_t) acc);
+}
+
+/* ---- look-ahead soft limiter (src/fir.c:748-870), width 21 ---- */
+typedef struct {
+	_fir65_t vfir, ffir;
+	const int16_t *shape;
+	int32_t level;
+	int16_t att[21];
+	int32_t fix[21], var[21];
+	int p, h;
+} _limiter_t;
+
+static int16_t _limit(_limiter_t *l, int16_t in)
+{
+	const int W = 21;
+	int32_t a, b;
+	int j;
+
+	/* the same sample feeds the variable (pre-emphasised) and the fixed
+	 * (flat) branch: limiter_process(&lim, &s, &s, &s, 1, 1), src/video.c:3322 */
+	l->var[l->p] = _fir65(&l->vfir, in);
+	l->fix[l->p] = _fir65(&l->ffir, in);
+	l->att[l->p] = 0;
+
+	if(l->fix[l->p] < -l->level) l->fix[l->p] = -l->level;
+	else if(l->fix[l->p] > l->level) l->fix[l->p] = l->level;
+	l->var[l->p] -= l->fix[l->p];
+
+	if(++l->p == W) l->p = 0;
+	if(++l->h == W) l->h = 0;
+
+	a = abs(l->var[l->h] + l->fix[l->h]);
+	if(a > l->level)
+	{
+		a = INT16_MAX - (l->level + abs(l->var[l->h]) - a) * INT16_MAX / abs(l->var[l->h]);
+		for(j = 0; j < W; j++)
+		{
+			b = (a * l->shape[j]) >> 15;
+			if(b > l->att[l->p]) l->att[l->p] = b;
+			if(++l->p == W) l->p = 0;
+		}
+	}
+
+	a = l->fix[l->p] + (int32_t) (((int64_t) l->var[l->p] * (INT16_MAX - l->att[l->p])) >> 15);
+	if(a < -l->level) a = -l->level;
+	else if(a > l->level) a = l->level;
+
+	return((int16_t) a);
+}
+
+/* ---- carrier phasor ---- */
+typedef struct {
+	int on;
+	int32_t pi, pq;         /* phase, Q31 */
+	int32_t counter;        /* steps until the amplitude correction */
+	int32_t level;
+	int16_t sample;         /* modulating sample in force */
+} _phasor_t;
+
+static inline void _step(_phasor_t *p, int32_t ci, int32_t cq)
+{
+	int64_t i = (int64_t) p->pi * ci - (int64_t) p->pq * cq;
+	int64_t q = (int64_t) p->pi * cq + (int64_t) p->pq * ci;
+	p->pi = (int32_t) (i >> 31);
+	p->pq = (int32_t) (q >> 31);
+}
+
+static inline void _correct(_phasor_t *p)
+{
+	/* amplitude drift correction every INT16_MAX steps (src/video.c:2266-2275) */
+	if(--p->counter == 0)
+	{
+		double ra = atan2(p->pq, p->pi);
+		p->pi = lround(cos(ra) * INT32_MAX);
+		p->pq = lround(sin(ra) * INT32_MAX);
+		p->counter = INT16_MAX;
+	}
+}
+
+/* ---- NICAM-728 framing ---- */
+typedef struct {
+	unsigned int frame_no;
+	uint8_t prn[90];
+	int16_t l[J17_TAPS], r[J17_TAPS];
+	int pos;
+	int16_t block[64];      /* audio block the next frame will carry */
+	int16_t fill[64];
+	int fill_len;
+	uint8_t bits[91];       /* current frame */
+	int bit;                /* next bit pair to send */
+	int dsym;               /* differential phase state */
+	/* symbol schedule */
+	int64_t k;              /* index of the next symbol to be created */
+	int64_t next_start;     /* its first sample */
+	int sps, dsl, decimation, ds;
+} _nicam_t;
+
+/* J.17 pre-emphasis taps at 32 kHz (src/nicam728.c:37-44), first half */
+static const int16_t _j17[42] = {
+	-1, 0, -1, -1, -1, -1, -1, -1, -1, -1, -2, -2, -3, -3, -3, -3, -5, -5,
+	-6, -7, -9, -10, -13, -14, -18, -21, -27, -32, -42, -51, -69, -86, -120,
+	-159, -233, -332, -524, -814, -1402, -2372, -4502, 25590
+};
+
+static void _nicam_reset(_nicam_t *n, const hvk_tables_t *t)
+{
+	int x, i, lfsr = 0x1FF;
+
+	memset(n, 0, sizeof(*n));
+
+	/* 9-bit LFSR x^9 + x^4 + 1, all ones start (src/nicam728.c:96-126) */
+	for(x = 0; x < 90; x++)
+	{
+		for(i = 0; i < 8; i++)
+		{
+			int b = (lfsr ^ (lfsr >> 4)) & 1;
+			lfsr = (lfsr >> 1) | (b << 8);
+			n->prn[x] = (n->prn[x] << 1) | b;
+		}
+	}
+
+	n->bit = NICAM_FRAME_BITS; /* a frame is built before the first symbol */
+	n->sps = t->k.nicam_sps;
+	n->dsl = t->k.nicam_dsl;
+	n->decimation = t->k.nicam_decimation;
+}
+
+static int _range_of(const int16_t *pcm)
+{
+	/* smallest coding range that holds every sample of the block
+	 * (src/nicam728.c:70-94) */
+	int i, b = 1;
+	for(i = 0; i < 32 && b < 7; i++)
+	{
+		int16_t m = pcm[i * 2] < 0 ? ~pcm[i * 2] : pcm[i * 2];
+		while(b < 7 && (m >> (b + 8))) b++;
+	}
+	return(b);
+}
+
+static int _even_parity6(int v)
+{
+	v ^= v >> 4; v ^= v >> 2; v ^= v >> 1;
+	return(v & 1);
+}
+
+static void _nicam_build_frame(_nicam_t *n)
+{
+	/* range -> (3-bit scale factor code, down shift), src/nicam728.c:59-68 */
+	static const uint8_t code[8]  = { 0, 1, 2, 4, 3, 5, 6, 7 };
+	static const uint8_t shift[8] = { 2, 2, 2, 2, 3, 4, 5, 6 };
+	int16_t w[64];
+	int rng[2], x, k, at;
+
+	/* pre-emphasis: the newest sample is written, then the 83 taps sweep
+	 * the ring from the oldest sample (src/nicam728.c:147-162) */
+	for(x = 0; x < 32; x++)
+	{
+		int32_t al = 0, ar = 0;
+		int p;
+
+		n->l[n->pos] = n->block[x * 2 + 0];
+		n->r[n->pos] = n->block[x * 2 + 1];
+		n->pos = n->pos == J17_TAPS - 1 ? 0 : n->pos + 1;
+
+		for(k = 0, p = n->pos; k < J17_TAPS; k++)
+		{
+			int tap = _j17[k <= 41 ? k : 82 - k];
+			al += (int32_t) n->l[p] * tap;
+			ar += (int32_t) n->r[p] * tap;
+			p = p == J17_TAPS - 1 ? 0 : p + 1;
+		}
+
+		w[x * 2 + 0] = (int16_t) (al >> 15);
+		w[x * 2 + 1] = (int16_t) (ar >> 15);
+	}
+
+	rng[0] = _range_of(w + 0);
+	rng[1] = _range_of(w + 1);
+
+	/* 10-bit companded sample + parity over its 6 MSBs; the first 54 samples
+	 * also signal the scale factor through the parity bit (:165-182) */
+	for(x = 0; x < 64; x++)
+	{
+		int ch = x & 1;
+		int v = (w[x] >> shift[rng[ch]]) & 0x3FF;
+		v |= _even_parity6(v >> 4) << 10;
+		if(x < 54) v ^= ((code[rng[ch]] >> (2 - (x / 2 % 3))) & 1) << 10;
+		w[x] = v;
+	}
+
+	/* frame alignment word, control bits C0-C4 (C0 flips every 8 frames,
+	 * mode = stereo, reserve flag = 1: src/video.c:4524), AD bits zero */
+	memset(n->bits, 0, sizeof(n->bits));
+	n->bits[0] = 0x4E;
+	n->bits[1] = ((((~n->frame_no) >> 3) & 1) << 7) | (1 << 3);
+
+	/* 704 sound bits, 11 per sample LSB first, interleaved 16 apart (:221-240) */
+	for(x = 0, at = 0; x < 64; x++)
+	{
+		for(k = 0; k < 11; k++)
+		{
+			if((w[x] >> k) & 1) n->bits[3 + (at >> 3)] |= 0x80 >> (at & 7);
+			at += 16;
+			if(at >= 704) at -= 703;
+		}
+	}
+
+	for(x = 0; x < 90; x++) n->bits[x + 1] ^= n->prn[x];
+
+	n->frame_no++;
+}
+
+/* ---- the path ---- */
+
+struct hvk_audio {
+	const hvk_tables_t *t;
+	int width;
+	int sample_rate;
+
+	/* 32 kHz stereo source queue */
+	int16_t *src;
+	size_t src_len, src_cap, src_pos;
+
+	int interp;             /* 32 kHz tick accumulator (src/video.c:3273-3276) */
+	int64_t pos;            /* stream samples generated so far (multiple of width) */
+
+	_phasor_t fm, am;
+	_limiter_t lim;
+	int has_lim;
+
+	int nicam_on;
+	_nicam_t nicam;
+
+	/* symbols created so far: sym[i] belongs to symbol sym_k0 + i */
+	uint8_t *sym;
+	int64_t sym_k0;
+	size_t sym_len, sym_cap;
+
+	int16_t *scratch;       /* one line of carriers when the caller wants none */
+};
+
+hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
+{
+	hvk_audio_t *a = calloc(1, sizeof(hvk_audio_t));
+	if(!a) return(NULL);
+
+	a->t = t;
+	a->width = t->k.width;
+	a->sample_rate = t->sample_rate;
+
+	if(t->fm_lut)
+	{
+		a->fm.on = 1;
+		a->fm.pi = INT32_MAX;
+		a->fm.counter = INT16_MAX;
+		a->fm.level = t->fm_level;
+
+		if(t->has_limiter)
+		{
+			a->has_lim = 1;
+			a->lim.vfir.taps = t->limiter_vtaps;
+			a->lim.ffir.taps = t->limiter_ftaps;
+			a->lim.shape = t->limiter_shape;
+			a->lim.level = INT16_MAX;
+			a->lim.h = 21 / 2;
+		}
+	}
+
+	if(t->am_level)
+	{
+		a->am.on = 1;
+		a->am.pi = INT32_MAX;
+		a->am.counter = INT16_MAX;
+		a->am.level = t->am_level;
+	}
+
+	if(t->k.has_nicam)
+	{
+		a->nicam_on = 1;
+		_nicam_reset(&a->nicam, t);
+	}
+
+	a->scratch = malloc(sizeof(int16_t) * 2 * a->width);
+	if(!a->scratch) { free(a); return(NULL); }
+
+	return(a);
+}
+
+void hvk_audio_free(hvk_audio_t *a)
+{
+	if(!a) return;
+	free(a->src);
+	free(a->sym);
+	free(a->scratch);
+	free(a);
+}
+
+int64_t hvk_audio_position(const hvk_audio_t *a) { return(a->pos); }
+
+int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples)
+{
+	if(a->src_pos > 0 && a->src_pos == a->src_len) a->src_pos = a->src_len = 0;
+
+	if(a->src_len + nsamples > a->src_cap)
+	{
+		/* compact, then grow */
+		if(a->src_pos > 0)
+		{
+			memmove(a->src, a->src + a->src_pos * 2, (a->src_len - a->src_pos) * 2 * sizeof(int16_t));
+			a->src_len -= a->src_pos;
+			a->src_pos = 0;
+		}
+		if(a->src_len + nsamples > a->src_cap)
+		{
+			size_t cap = (a->src_len + nsamples) * 2;
+			int16_t *n = realloc(a->src, cap * 2 * sizeof(int16_t));
+			if(!n) return(HVK_OUT_OF_MEMORY);
+			a->src = n;
+			a->src_cap = cap;
+		}
+	}
+
+	memcpy(a->src + a->src_len * 2, stereo, nsamples * 2 * sizeof(int16_t));
+	a->src_len += nsamples;
+	return(HVK_OK);
+}
+
+/* 32 kHz source samples (beyond those queued) needed to reach stream
+ * position upto_pos: ticks fire when the accumulator crosses sample_rate */
+size_t hvk_audio_source_needed(const hvk_audio_t *a, int64_t upto_pos)
+{
+	int64_t n = upto_pos - a->pos;
+	int64_t ticks, have;
+	if(n <= 0) return(0);
+	ticks = ((int64_t) a->interp + n * AUDIO_RATE) / a->sample_rate;
+	have = (int64_t) (a->src_len - a->src_pos);
+	return(ticks > have ? (size_t) (ticks - have) : 0);
+}
+
+/* One 32 kHz tick: fetch, scale, distribute (src/video.c:3278-3377) */
+static void _tick(hvk_audio_t *a)
+{
+	int16_t s[2] = { 0, 0 };
+	int i;
+
+	if(a->src_pos < a->src_len)
+	{
+		for(i = 0; i < 2; i++)
+		{
+			int32_t v = ((int32_t) a->src[a->src_pos * 2 + i] * a->t->conf.volume + 128) >> 8;
+			s[i] = v < INT16_MIN ? INT16_MIN : (v > INT16_MAX ? INT16_MAX : v);
+		}
+		a->src_pos++;
+	}
+
+	if(a->am.on) a->am.sample = (s[0] + s[1]) / 2;
+
+	if(a->fm.on)
+	{
+		a->fm.sample = (s[0] + s[1]) / 2;
+		if(a->has_lim) a->fm.sample = _limit(&a->lim, a->fm.sample);
+	}
+
+	if(a->nicam_on)
+	{
+		_nicam_t *n = &a->nicam;
+		n->fill[n->fill_len++] = s[0];
+		n->fill[n->fill_len++] = s[1];
+		if(n->fill_len == 64)
+		{
+			memcpy(n->block, n->fill, sizeof(n->block));
+			n->fill_len = 0;
+		}
+	}
+}
+
+static void _sym_append(hvk_audio_t *a, uint8_t v)
+{
+	if(a->sym_len == a->sym_cap)
+	{
+		size_t cap = a->sym_cap ? a->sym_cap * 2 : 65536;
+		a->sym = realloc(a->sym, cap);
+		a->sym_cap = cap;
+	}
+	a->sym[a->sym_len++] = v;
+}
+
+/* Samples [x0, x1) of the current line with the modulating samples in force */
+static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
+{
+	int x;
+
+	if(!a->fm.on && !a->am.on)
+	{
+		for(x = x0; x < x1; x++) carriers[x * 2 + 0] = carriers[x * 2 + 1] = 0;
+		return;
+	}
+
+	{
+		/* the step is constant between two 32 kHz ticks */
+		const hvk_c32_t fm_step = a->fm.on ? a->t->fm_lut[a->fm.sample - INT16_MIN] : (hvk_c32_t) { 0, 0 };
+		const hvk_c32_t am_step = a->t->am_delta;
+		const int32_t am_s = ((int32_t) a->am.sample - INT16_MIN) / 2;
+
+		for(x = x0; x < x1; x++)
+		{
+			int16_t ai = 0, aq = 0;
+
+			if(a->fm.on)
+			{
+				_step(&a->fm, fm_step.i, fm_step.q);
+				ai += (int16_t) (((a->fm.pi >> 16) * a->fm.level) >> 15);
+				aq += (int16_t) (((a->fm.pq >> 16) * a->fm.level) >> 15);
+				_correct(&a->fm);
+			}
+
+			if(a->am.on)
+			{
+				_step(&a->am, am_step.i, am_step.q);
+				ai += (int16_t) (((((a->am.pi >> 16) * am_s) >> 15) * a->am.level) >> 15);
+				aq += (int16_t) (((((a->am.pq >> 16) * am_s) >> 15) * a->am.level) >> 15);
+				_correct(&a->am);
+			}
+
+			carriers[x * 2 + 0] = ai;
+			carriers[x * 2 + 1] = aq;
+		}
+	}
+}
+
+/* Advance the stream by one line; carriers (width int16 pairs) receives the
+ * summed contribution of the serial carriers. */
+static void _line(hvk_audio_t *a, int16_t *carriers)
+{
+	const int sr = a->sample_rate;
+	int W = a->width, x = 0;
+
+	while(x < W)
+	{
+		/* the accumulator next crosses sample_rate on the to_tick-th sample from here */
+		int to_tick = (sr - a->interp + AUDIO_RATE - 1) / AUDIO_RATE;
+		int quiet = to_tick - 1;
+
+		if(quiet > W - x) quiet = W - x;
+
+		_carriers(a, carriers, x, x + quiet);
+		a->interp += quiet * AUDIO_RATE;
+		x += quiet;
+
+		if(quiet == to_tick - 1 && x < W)
+		{
+			/* new audio first, then this sample is modulated with it */
+			a->interp += AUDIO_RATE - sr;
+			_tick(a);
+			_carriers(a, carriers, x, x + 1);
+			x++;
+		}
+	}
+
+	/* NICAM: every symbol that starts inside this line is created now, after
+	 * the whole line's ticks (src/video.c:3435-3438, src/nicam728.c:368-408) */
+	if(a->nicam_on)
+	{
+		static const uint8_t advance[4] = { 0, 3, 1, 2 };
+		_nicam_t *n = &a->nicam;
+		int64_t line_end = a->pos + W;
+
+		while(n->next_start < line_end)
+		{
+			int len;
+
+			if(n->bit == NICAM_FRAME_BITS)
+			{
+				_nicam_build_frame(n);
+				n->bit = 0;
+			}
+
+			n->dsym = (n->dsym + advance[(n->bits[n->bit >> 3] >> (6 - (n->bit & 7))) & 3]) & 3;
+			n->bit += 2;
+			_sym_append(a, n->dsym);
+
+			len = n->sps;
+			n->ds += n->dsl;
+			if(n->ds >= n->decimation) { len--; n->ds -= n->decimation; }
+
+			n->next_start += len;
+			n->k++;
+		}
+	}
+
+	a->pos += W;
+}
+
+/* Index of the symbol whose pulse starts at or before sample m (>= 0) */
+static int64_t _symbol_at(const hvk_audio_t *a, int64_t m)
+{
+	const _nicam_t *n = &a->nicam;
+	int64_t period = (int64_t) n->sps * n->decimation - n->dsl; /* samples per `decimation` symbols */
+	int64_t k = m * n->decimation / period;
+
+	/* start of symbol k: sps * k - floor(k * dsl / decimation) */
+	while(n->sps * (k + 1) - ((k + 1) * n->dsl) / n->decimation <= m) k++;
+	while(k > 0 && n->sps * k - (k * n->dsl) / n->decimation > m) k--;
+	return(k);
+}
+
+int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
+                       int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0)
+{
+	int W = a->width;
+	int64_t end = first + count;
+	int nsym = 0;
+
+	if(first % W || count % W) return(HVK_ERROR);
+	if(first < a->pos) return(HVK_ERROR);   /* the chains cannot be rewound */
+
+	while(a->pos < end)
+	{
+		int16_t *dst = (a->pos >= first && carriers) ? carriers + (a->pos - first) * 2 : a->scratch;
+		_line(a, dst);
+	}
+
+	if(a->nicam_on && symbols)
+	{
+		int64_t klo = _symbol_at(a, first) - 7;
+		int64_t khi = _symbol_at(a, end - 1);
+		int64_t k;
+
+		if(khi - klo + 1 > max_symbols) return(HVK_ERROR);
+		if(klo >= 0 && klo < a->sym_k0) return(HVK_ERROR); /* history already dropped */
+
+		for(k = klo; k <= khi; k++)
+		{
+			symbols[nsym++] = (k < 0) ? 0xFF : a->sym[k - a->sym_k0];
+		}
+		if(k0) *k0 = klo;
+
+		/* drop symbols no later request can need */
+		if(khi - SYM_HISTORY > a->sym_k0)
+		{
+			size_t drop = (size_t) (khi - SYM_HISTORY - a->sym_k0);
+			memmove(a->sym, a->sym + drop, a->sym_len - drop);
+			a->sym_len -= drop;
+			a->sym_k0 += drop;
+		}
+	}
+	else if(k0) *k0 = 0;
+
+	return(nsym);
+}
+
+/* The newest NICAM symbol whose pulse has started by stream sample m, and
+ * its first sample (closed form of the schedule in src/nicam728.c:398-407) */
+int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start)
+{
+	int64_t kk;
+	if(!a->nicam_on) return(HVK_ERROR);
+	kk = _symbol_at(a, m);
+	if(k) *k = kk;
+	if(start) *start = (int64_t) a->nicam.sps * kk - (kk * a->nicam.dsl) / a->nicam.decimation;
+	return(HVK_OK);
+}

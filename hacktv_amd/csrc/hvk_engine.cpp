@@ -1,0 +1,575 @@
+/* hvk_engine.cpp -- the C ABI of libhvk (include/hacktv_amd.h): engine
+ * life cycle, HBM residency of tables / frames / side streams, and the
+ * per-batch launch sequence on one HIP stream.
+ *
+ * What vid_init() / vid_next_line() / vid_free() are to the reference
+ * (src/video.c:3812, :4936, :4706), hvk_open() / hvk_render() / hvk_close()
+ * are here, at frame instead of line granularity. There is no CPU rendering
+ * path in this library: without a HIP device every render call fails.
+ *
+ * HBM layout (all allocated once in hvk_open, sized by max_frames):
+ *   yuv        2^24 x int16x4   128 MiB   RGB -> level table, expanded on device
+ *   clut       (clw + width) x int16x2    colour sub-carrier phasors
+ *   pool       frame_slots x active_w x active_h x 4 B   source frames (RGBx)
+ *   S          max_frames x (lines + 2) x width x 2 B    raster stream (int16 I)
+ *   carriers   max_frames x frame_samples x 4 B          serial-carrier side stream
+ *   symbols    max_frames x symbol_stride x 1 B          NICAM symbols
+ *   out        max_frames x frame_samples x 4 B          int16 I/Q (if the caller gives no buffer)
+ */
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include "hvk_internal.h"
+#include "hvk_kernels.h"
+
+#define HVK_VERSION "hacktv-amd 0.1 (gfx950)"
+#define HVK_FRAME_SLOTS 4
+#define HVK_TIMING_SLOTS 512
+
+extern "C" {
+int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
+}
+
+struct hvk_slot_t {
+	int valid;
+	int width, height;      /* after the centre crop */
+	int interlaced;
+};
+
+struct hvk_engine {
+	hvk_tables_t t;
+	hvk_audio_t *audio;
+	int device;             /* -1: host tables only */
+	int max_frames;
+	int frame_slots;
+	int symbol_stride;
+	hipStream_t stream;
+
+	/* constant tables */
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_ntaps, *d_ncc;
+	/* per batch */
+	uint32_t *d_pool;
+	hvk_framedesc_t *d_fdesc;
+	int16_t *d_S;
+	int16_t *d_car;
+	uint8_t *d_sym;
+	int16_t *d_out;
+
+	/* pinned staging */
+	hvk_framedesc_t *h_fdesc;
+	int16_t *h_car;
+	uint8_t *h_sym;
+	uint32_t *h_frame;
+
+	hvk_slot_t slots[HVK_FRAME_SLOTS];
+	hvk_packed_taps_t ctaps, itaps, qtaps;
+
+	int64_t next_frame;
+	int staged;             /* frames staged for the next launch */
+	int last_frames;        /* frames of the last launch (for fetch) */
+	int ghost_dirty;
+
+	/* kernel timing with HIP events on the engine's stream */
+	int timing;
+	hipEvent_t ev[HVK_TIMING_SLOTS][3];
+	int ev_used;
+	double t_sum[2];
+	int64_t t_n[2];
+};
+
+#define HIPCHK(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
+	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
+
+static void _pack_taps(hvk_packed_taps_t *p, const int16_t *taps, int ntaps)
+{
+	memset(p, 0, sizeof(*p));
+	for(int k = 0; k < ntaps && k < HVK_MAX_VF_TAPS; k++)
+	{
+		p->p[k / 2] |= (k & 1) ? ((int) taps[k] << 16) : ((int) taps[k] & 0xFFFF);
+	}
+}
+
+static int _upload(void **dst, const void *src, size_t bytes)
+{
+	*dst = NULL;
+	if(bytes == 0 || src == NULL) return(HVK_OK);
+	HIPCHK(hipMalloc(dst, bytes));
+	HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+	return(HVK_OK);
+}
+
+extern "C" const char *hvk_version(void) { return(HVK_VERSION); }
+
+extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned int sample_rate, int device, int max_frames)
+{
+	hvk_engine *e;
+	int r, ndev = 0;
+
+	if(!pe || !conf) return(HVK_ERROR);
+	*pe = NULL;
+	if(max_frames < 1) max_frames = 1;
+
+	e = (hvk_engine *) calloc(1, sizeof(hvk_engine));
+	if(!e) return(HVK_OUT_OF_MEMORY);
+	e->device = device;
+	e->max_frames = max_frames;
+	e->frame_slots = HVK_FRAME_SLOTS;
+
+	if((r = hvk_tables_build(&e->t, conf, sample_rate)) != HVK_OK) { hvk_close(e); return(r); }
+
+	if(e->t.k.colour) _pack_taps(&e->ctaps, e->t.chroma_taps, e->t.k.chroma_ntaps);
+	if(e->t.k.vf_type) _pack_taps(&e->itaps, e->t.vf_itaps, e->t.k.vf_ntaps);
+	if(e->t.k.vf_type == 3) _pack_taps(&e->qtaps, e->t.vf_qtaps, e->t.k.vf_ntaps);
+
+	if(e->t.k.has_carriers || e->t.k.has_nicam)
+	{
+		e->audio = hvk_audio_new(&e->t);
+		if(!e->audio) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
+	}
+
+	if(e->t.k.has_nicam)
+	{
+		e->symbol_stride = e->t.k.frame_samples / (e->t.k.nicam_sps - 1) + 32;
+		e->symbol_stride = (e->symbol_stride + 15) & ~15;
+	}
+
+	*pe = e;
+	if(device < 0) return(HVK_OK);   /* host tables only: parity tests without a GPU */
+
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev)
+	{
+		fprintf(stderr, "libhvk: no HIP device %d (found %d); this engine has no CPU path\n", device, ndev);
+		*pe = NULL;
+		e->device = -1;
+		hvk_close(e);
+		return(HVK_NO_DEVICE);
+	}
+
+	const hvk_kconst_t &k = e->t.k;
+	const size_t FS = k.frame_samples;
+
+#define OPENCHK(x) do { int _r = (x); if(_r != HVK_OK) { *pe = NULL; hvk_close(e); return(_r); } } while(0)
+#define OPENHIP(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
+	fprintf(stderr, "libhvk: %s failed: %s\n", #call, hipGetErrorString(_e)); *pe = NULL; hvk_close(e); \
+	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
+
+	OPENHIP(hipSetDevice(device));
+	OPENHIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+
+	OPENCHK(_upload(&e->d_yuvparams, &e->t.yuv, sizeof(e->t.yuv)));
+	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
+	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
+
+	OPENCHK(_upload(&e->d_desc, e->t.desc, sizeof(hvk_linedesc_t) * 2 * k.lines));
+	OPENCHK(_upload(&e->d_pulses, e->t.pulse_values, sizeof(int16_t) * (e->t.pulse_total + 8)));
+	OPENCHK(_upload(&e->d_clut, e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len));
+	OPENCHK(_upload(&e->d_burst, e->t.burst_win, sizeof(int16_t) * k.burst_width));
+	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
+	OPENCHK(_upload(&e->d_ntaps, e->t.nicam_taps, sizeof(int16_t) * k.nicam_ntaps));
+	OPENCHK(_upload(&e->d_ncc, e->t.nicam_cc, sizeof(hvk_c16_t) * k.nicam_cc_len));
+
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots));
+	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots));
+	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames));
+	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * (k.lines + 2) * k.width * 2 + 256));
+	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
+	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames, hipHostMallocDefault));
+	OPENHIP(hipHostMalloc((void **) &e->h_frame, frame_px * 4, hipHostMallocDefault));
+
+	if(e->t.k.has_carriers)
+	{
+		OPENHIP(hipMalloc((void **) &e->d_car, (size_t) max_frames * FS * 4));
+		OPENHIP(hipMemset(e->d_car, 0, (size_t) max_frames * FS * 4));
+		OPENHIP(hipHostMalloc((void **) &e->h_car, (size_t) max_frames * FS * 4, hipHostMallocDefault));
+	}
+	if(e->t.k.has_nicam)
+	{
+		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride));
+		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride, hipHostMallocDefault));
+	}
+
+	for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) OPENHIP(hipEventCreate(&e->ev[i][j]));
+
+	OPENHIP(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
+
+extern "C" void hvk_close(hvk_engine_t *e)
+{
+	if(!e) return;
+
+	if(e->device >= 0)
+	{
+		(void) hipSetDevice(e->device);
+		if(e->stream) (void) hipStreamSynchronize(e->stream);
+		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
+		                e->d_ntaps, e->d_ncc, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_out };
+		for(void *p : dev) if(p) (void) hipFree(p);
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_frame };
+		for(void *p : host) if(p) (void) hipHostFree(p);
+		if(e->stream) (void) hipStreamDestroy(e->stream);
+	}
+
+	hvk_audio_free(e->audio);
+	hvk_tables_free(&e->t);
+	free(e);
+}
+
+extern "C" int hvk_get_info(const hvk_engine_t *e, hvk_info_t *info)
+{
+	if(!e || !info) return(HVK_ERROR);
+	const hvk_kconst_t &k = e->t.k;
+	info->sample_rate = e->t.sample_rate;
+	info->width = k.width;
+	info->half_width = k.half_width;
+	info->active_width = k.active_width;
+	info->active_left = k.active_left;
+	info->lines = k.lines;
+	info->active_lines = k.active_lines;
+	info->white_level = e->t.white_level;
+	info->black_level = e->t.black_level;
+	info->blanking_level = e->t.blanking_level;
+	info->sync_level = e->t.sync_level;
+	info->delay_lines = k.delay_lines;
+	info->frame_samples = k.frame_samples;
+	info->max_frames = e->max_frames;
+	info->frame_slots = e->frame_slots;
+	info->colour_lookup_width = k.clw;
+	info->burst_left = k.burst_left;
+	info->burst_width = k.burst_width;
+	info->has_carriers = k.has_carriers;
+	info->has_nicam = k.has_nicam;
+	return(HVK_OK);
+}
+
+extern "C" size_t hvk_get_framebuffer_length(const hvk_engine_t *e)
+{
+	return(sizeof(uint32_t) * e->t.k.active_width * e->t.k.active_lines);
+}
+
+extern "C" int hvk_set_chroma_ghost(hvk_engine_t *e, const int16_t *ghost, int n)
+{
+	if(!e || n < 0 || n > HVK_GHOST_LEN) return(HVK_ERROR);
+	memset(e->t.ghost, 0, sizeof(e->t.ghost));
+	if(ghost) memcpy(e->t.ghost, ghost, n * sizeof(int16_t));
+	else hvk_tables_default_ghost(&e->t);
+	if(e->device >= 0 && e->d_ghost)
+	{
+		HIPCHK(hipSetDevice(e->device));
+		HIPCHK(hipMemcpyAsync(e->d_ghost, e->t.ghost, sizeof(e->t.ghost), hipMemcpyHostToDevice, e->stream));
+		HIPCHK(hipStreamSynchronize(e->stream));
+	}
+	return(HVK_OK);
+}
+
+extern "C" int hvk_get_chroma_ghost(const hvk_engine_t *e, int16_t *ghost, int n)
+{
+	if(!e || !ghost || n < 0 || n > HVK_GHOST_LEN) return(HVK_ERROR);
+	memcpy(ghost, e->t.ghost, n * sizeof(int16_t));
+	return(HVK_OK);
+}
+
+extern "C" long hvk_table(const hvk_engine_t *e, const char *name, void *dst, long max_bytes)
+{
+	if(!e || !name) return(-1);
+
+	if(!strcmp(name, "yuv"))
+	{
+		/* the device-expanded table, read back as the reference's {y,u,v} triples */
+		const long bytes = 0x1000000L * 6;
+		if(dst == NULL) return(bytes);
+		if(e->device < 0) return(-1);
+		std::vector<int16_t> q(0x1000000UL * 4);
+		if(hipSetDevice(e->device) != hipSuccess) return(-1);
+		if(hipMemcpy(q.data(), e->d_yuv, q.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return(-1);
+		int16_t *o = (int16_t *) dst;
+		long n = max_bytes / 6 < 0x1000000L ? max_bytes / 6 : 0x1000000L;
+		for(long i = 0; i < n; i++) { o[i * 3 + 0] = q[i * 4 + 0]; o[i * 3 + 1] = q[i * 4 + 1]; o[i * 3 + 2] = q[i * 4 + 2]; }
+		return(n * 6);
+	}
+
+	return(hvk_tables_get(&e->t, name, dst, max_bytes));
+}
+
+/* ---- inputs ---- */
+
+extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
+                                int pixel_stride, int line_stride, int interlaced)
+{
+	if(!e || slot < 0 || slot >= e->frame_slots) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+
+	const hvk_kconst_t &k = e->t.k;
+	hvk_slot_t *s = &e->slots[slot];
+
+	/* centre crop to the active area: src/video.c:4887-4893, src/av.c:293-303 */
+	int x = (width - k.active_width) / 2, y = (height - k.active_lines) / 2;
+	int w = k.active_width, h = k.active_lines;
+	if(x < 0) { w += x; x = 0; }
+	if(y < 0) { h += y; y = 0; }
+	if(x + w > width) w = width - x;
+	if(y + h > height) h = height - y;
+	if(w < 0) w = 0;
+	if(h < 0) h = 0;
+
+	s->valid = fb != NULL && w > 0 && h > 0;
+	s->width = fb ? w : 0;
+	s->height = fb ? h : 0;
+	s->interlaced = interlaced;
+	if(fb == NULL)
+	{
+		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
+		return(HVK_OK);
+	}
+
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));   /* staging buffer reuse */
+
+	/* gather into a dense w x h image: strides may be negative (flips) */
+	const uint32_t *src = fb + (int64_t) y * line_stride + (int64_t) x * pixel_stride;
+	for(int r = 0; r < h; r++)
+	{
+		const uint32_t *p = src + (int64_t) r * line_stride;
+		uint32_t *o = e->h_frame + (size_t) r * w;
+		if(pixel_stride == 1) memcpy(o, p, (size_t) w * 4);
+		else for(int c = 0; c < w; c++) o[c] = p[(int64_t) c * pixel_stride];
+	}
+
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, e->h_frame, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
+
+extern "C" int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples)
+{
+	if(!e) return(HVK_ERROR);
+	if(!e->audio || nsamples == 0) return(HVK_OK);
+	return(hvk_audio_push(e->audio, stereo, nsamples));
+}
+
+extern "C" size_t hvk_audio_needed(const hvk_engine_t *e, int nframes)
+{
+	if(!e || !e->audio) return(0);
+	const hvk_kconst_t &k = e->t.k;
+	int64_t upto = (e->next_frame + nframes) * (int64_t) k.frame_samples + (int64_t) k.delay_lines * k.width;
+	return(hvk_audio_source_needed(e->audio, upto));
+}
+
+extern "C" int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
+                                     int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0)
+{
+	if(!e) return(HVK_ERROR);
+	if(!e->audio) return(0);
+	return(hvk_audio_generate(e->audio, first, count, carriers, symbols, max_symbols, k0));
+}
+
+/* ---- render ---- */
+
+extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots)
+{
+	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+
+	const hvk_kconst_t &k = e->t.k;
+	const int64_t FS = k.frame_samples;
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));   /* pinned staging is reused */
+
+	for(int i = 0; i < nframes; i++)
+	{
+		hvk_framedesc_t *f = &e->h_fdesc[i];
+		const int slot = slots ? slots[i] : 0;
+		if(slot < 0 || slot >= e->frame_slots) return(HVK_ERROR);
+		const hvk_slot_t *s = &e->slots[slot];
+
+		memset(f, 0, sizeof(*f));
+		f->frame_index = first_frame + i * stride;
+		f->fb_offset = (int64_t) slot * frame_px;
+		f->fb_width = s->valid ? s->width : 0;
+		f->fb_height = s->valid ? s->height : 0;
+		f->pixel_stride = 1;
+		f->line_stride = s->width;
+		f->vframe_x = (k.active_width - f->fb_width) / 2;      /* src/video.c:4896-4897 */
+		f->vframe_y = (k.active_lines - f->fb_height) / 2;
+		f->fb_interlaced = s->interlaced;
+		f->fb_valid = s->valid;
+
+		if(e->audio)
+		{
+			const int64_t m0 = f->frame_index * FS + (int64_t) k.delay_lines * k.width;
+			int64_t k0 = 0;
+			int n = hvk_audio_generate(e->audio, m0, FS,
+				e->h_car ? e->h_car + (size_t) i * FS * 2 : NULL,
+				e->h_sym ? e->h_sym + (size_t) i * e->symbol_stride : NULL,
+				e->symbol_stride, &k0);
+			if(n < 0) return(n);
+
+			if(k.has_nicam)
+			{
+				int64_t kf, start;
+				hvk_audio_symbol_info(e->audio, m0, &kf, &start);
+				f->nicam_kf = kf;
+				f->nicam_k0 = k0;
+				f->nicam_cc0 = m0 % k.nicam_cc_len;
+				f->nicam_rf = (int32_t) (m0 - start);
+				f->nicam_ph = (int32_t) ((kf * k.nicam_dsl) % k.nicam_decimation);
+			}
+		}
+	}
+
+	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
+	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_sym) HIPCHK(hipMemcpyAsync(e->d_sym, e->h_sym, (size_t) nframes * e->symbol_stride, hipMemcpyHostToDevice, e->stream));
+
+	e->staged = nframes;
+	return(HVK_OK);
+}
+
+extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
+{
+	if(!e) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(e->staged < 1) return(HVK_ERROR);
+
+	HIPCHK(hipSetDevice(e->device));
+
+	hvk_raster_args_t ra;
+	memset(&ra, 0, sizeof(ra));
+	ra.k = e->t.k;
+	ra.ctaps = e->ctaps;
+	ra.desc = (const hvk_linedesc_t *) e->d_desc;
+	ra.pulses = (const int16_t *) e->d_pulses;
+	ra.yuv = e->d_yuv;
+	ra.clut = (const hvk_c16_t *) e->d_clut;
+	ra.burst_win = (const int16_t *) e->d_burst;
+	ra.ghost = (const int16_t *) e->d_ghost;
+	ra.pool = e->d_pool;
+	ra.fdesc = e->d_fdesc;
+	ra.S = e->d_S;
+	ra.nframes = e->staged;
+
+	hvk_filter_args_t fa;
+	memset(&fa, 0, sizeof(fa));
+	fa.k = e->t.k;
+	fa.itaps = e->itaps;
+	fa.qtaps = e->qtaps;
+	fa.fdesc = e->d_fdesc;
+	fa.S = e->d_S;
+	fa.carriers = (const hvk_c16_t *) e->d_car;
+	fa.symbols = e->d_sym;
+	fa.symbol_stride = e->symbol_stride;
+	fa.nicam_taps = (const int16_t *) e->d_ntaps;
+	fa.nicam_cc = (const hvk_c16_t *) e->d_ncc;
+	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
+	fa.nframes = e->staged;
+
+	const bool timed = e->timing && e->ev_used < HVK_TIMING_SLOTS;
+	hipEvent_t *ev = timed ? e->ev[e->ev_used] : NULL;
+	int r;
+
+	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
+	if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
+	if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
+	if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
+	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
+
+	e->last_frames = e->staged;
+	return(HVK_OK);
+}
+
+extern "C" int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes,
+                                  const int32_t *slots, void *d_iq)
+{
+	int r = hvk_stage_strided(e, first_frame, stride, nframes, slots);
+	if(r != HVK_OK) return(r);
+	return(hvk_launch(e, d_iq));
+}
+
+extern "C" int hvk_render(hvk_engine_t *e, int nframes, const int32_t *slots, void *d_iq)
+{
+	if(!e) return(HVK_ERROR);
+	int r = hvk_render_strided(e, e->next_frame, 1, nframes, slots, d_iq);
+	if(r == HVK_OK) e->next_frame += nframes;
+	return(r);
+}
+
+extern "C" int hvk_sync(hvk_engine_t *e)
+{
+	if(!e) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
+
+extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count)
+{
+	if(!e || !iq) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
+
+extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, size_t count)
+{
+	/* frame-local raster of the last launch: frame i's samples follow frame
+	 * i - 1's; the slab's halo lines are skipped */
+	if(!e || !dst) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	const hvk_kconst_t &k = e->t.k;
+	const size_t FS = k.frame_samples;
+	if(first + count > (size_t) e->last_frames * FS) return(HVK_ERROR);
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	while(count > 0)
+	{
+		const size_t fr = first / FS, off = first % FS;
+		const size_t n = count < FS - off ? count : FS - off;
+		HIPCHK(hipMemcpy(dst, e->d_S + fr * (size_t) (k.lines + 2) * k.width + k.width + off, n * 2, hipMemcpyDeviceToHost));
+		dst += n; first += n; count -= n;
+	}
+	return(HVK_OK);
+}
+
+extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
+
+extern "C" int hvk_timing_enable(hvk_engine_t *e, int on)
+{
+	if(!e) return(HVK_ERROR);
+	e->timing = on;
+	e->ev_used = 0;
+	e->t_sum[0] = e->t_sum[1] = 0;
+	e->t_n[0] = e->t_n[1] = 0;
+	return(HVK_OK);
+}
+
+extern "C" int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches)
+{
+	if(!e || which < 0 || which > 1) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	for(int i = 0; i < e->ev_used; i++)
+	{
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, e->ev[i][0], e->ev[i][1]));
+		e->t_sum[0] += ms; e->t_n[0]++;
+		HIPCHK(hipEventElapsedTime(&ms, e->ev[i][1], e->ev[i][2]));
+		e->t_sum[1] += ms; e->t_n[1]++;
+	}
+	e->ev_used = 0;
+	if(avg_ms) *avg_ms = e->t_n[which] ? e->t_sum[which] / e->t_n[which] : 0;
+	if(launches) *launches = e->t_n[which];
+	return(HVK_OK);
+}

@@ -1,0 +1,147 @@
+/* hvk_internal.h -- internal types shared by the host side (C) and the HIP
+ * side (C++) of libhvk. Everything the kernels read is plain data laid out
+ * for the device; the host builds it once in hvk_open(). */
+#ifndef HVK_INTERNAL_H
+#define HVK_INTERNAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "hacktv_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVK_MAX_PULSES   8
+#define HVK_GHOST_LEN    32
+#define HVK_SPL          8      /* samples per lane in both kernels */
+#define HVK_TILE         1024   /* samples per filter workgroup */
+#define HVK_MAX_VF_TAPS  64
+
+typedef struct { int16_t i, q; } hvk_c16_t;
+typedef struct { int32_t i, q; } hvk_c32_t;
+
+/* One scanline's content, indexed [frame & 1][line - 1]. Replaces the
+ * reference's per-line code strings (src/video.c:2447-2862). */
+typedef struct {
+	int16_t pulse_left;     /* pulse index or -1 */
+	int16_t pulse_mid;      /* pulse index or -1 */
+	int16_t pulse_next;     /* left pulse of the FOLLOWING line if it starts before sample 0, else -1 */
+	int16_t al, ar;         /* luma is assigned on [al, ar); al == ar: none */
+	int16_t src_row;        /* source row before centring / field shift, -1: none */
+	int16_t pal;            /* 0 no chroma, +1, -1 (PAL V switch) */
+	int16_t pad;
+} hvk_linedesc_t;
+
+/* RGB -> (Y,U,V) level conversion, evaluated in double on the device with
+ * contraction off, operation for operation as src/video.c:3912-3958 */
+typedef struct {
+	double glut[256];
+	double rw, gw, bw;
+	double eu, ev;
+	double black, range;    /* black_level, white_level - black_level */
+	double level;
+	double chroma_scale;    /* (white - black) * level */
+	int32_t secam;
+	int32_t pad;
+} hvk_yuvparams_t;
+
+/* Kernel-visible engine constants */
+typedef struct {
+	int32_t width;          /* samples per line */
+	int32_t lines;
+	int32_t half_width;
+	int32_t active_left;
+	int32_t active_width;
+	int32_t active_lines;
+	int32_t interlaced;
+	int32_t blanking;
+	int32_t colour;         /* PAL / NTSC sub-carrier present */
+	uint32_t clw;           /* colour lookup period in samples */
+	int32_t burst_left, burst_width;
+	int32_t burst_i, burst_q;
+	int32_t chroma_ntaps;
+	int32_t npulses;
+	int32_t pulse_offset[HVK_MAX_PULSES];
+	int32_t pulse_length[HVK_MAX_PULSES];
+	int32_t pulse_start[HVK_MAX_PULSES];   /* index into the flat value array */
+	int32_t black_y;        /* luma of RGB 000000 */
+	/* filter / audio stage */
+	int32_t vf_type;        /* 0 none, 1 real, 3 real -> complex */
+	int32_t vf_ntaps;
+	int32_t delay_lines;
+	int32_t has_carriers;
+	int32_t has_nicam;
+	int32_t nicam_ntaps, nicam_sps, nicam_dsl, nicam_decimation, nicam_cc_len;
+	int32_t frame_samples;
+} hvk_kconst_t;
+
+/* Per rendered frame */
+typedef struct {
+	int64_t frame_index;    /* 0-based frame number in the stream */
+	int64_t fb_offset;      /* pixel offset of the cropped frame's first pixel in the slot pool */
+	int32_t fb_width, fb_height;
+	int32_t pixel_stride, line_stride;
+	int32_t vframe_x, vframe_y;
+	int32_t fb_interlaced;
+	int32_t fb_valid;       /* 0: no pixels (black) */
+	/* NICAM bookkeeping for the audio-stream position m0 of the frame's
+	 * first output sample (frame_index * frame_samples + delay_lines * width) */
+	int64_t nicam_kf;       /* anchor: newest symbol that has started by m0 */
+	int64_t nicam_k0;       /* stream index of symbols[0] of this frame's slab */
+	int64_t nicam_cc0;      /* m0 mod nicam_cc_len */
+	int32_t nicam_rf;       /* m0 - start of the anchor symbol */
+	int32_t nicam_ph;       /* (nicam_kf * dsl) mod decimation */
+} hvk_framedesc_t;
+
+/* Host-built tables (hvk_tables.c) */
+typedef struct {
+	hvk_config_t conf;      /* with defaults applied */
+	int32_t sample_rate;
+	int32_t white_level, black_level, blanking_level, sync_level;
+	hvk_kconst_t k;
+	hvk_yuvparams_t yuv;
+	hvk_linedesc_t *desc;   /* [2][lines] */
+	int16_t *pulse_values; int32_t pulse_total;
+	int16_t *sync_packed; int32_t sync_packed_len;  /* reference layout, for tests */
+	hvk_c16_t *colour_lookup; int64_t colour_lookup_len;
+	int16_t *burst_win;
+	int16_t *chroma_taps;
+	int16_t ghost[HVK_GHOST_LEN];
+	int16_t *vf_itaps, *vf_qtaps;
+	/* audio */
+	int32_t fm_level; hvk_c32_t *fm_lut;
+	int32_t am_level; hvk_c32_t am_delta;
+	int16_t *nicam_taps; hvk_c16_t *nicam_cc;
+	int16_t limiter_shape[21];
+	int32_t limiter_vtaps[65], limiter_ftaps[65];
+	int32_t has_limiter;
+} hvk_tables_t;
+
+int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate);
+void hvk_tables_free(hvk_tables_t *t);
+void hvk_tables_default_ghost(hvk_tables_t *t);
+long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes);
+
+/* Host audio-rate control path (hvk_audio.c) */
+typedef struct hvk_audio hvk_audio_t;
+
+hvk_audio_t *hvk_audio_new(const hvk_tables_t *t);
+void hvk_audio_free(hvk_audio_t *a);
+int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples);
+size_t hvk_audio_source_needed(const hvk_audio_t *a, int64_t upto_pos);
+
+/* Generate the side streams for audio-stream positions [first, first + count)
+ * (count a multiple of width; first must be >= every earlier request's end or
+ * inside the retained window). carriers: count int16 pairs. Symbols: every
+ * NICAM symbol that can touch the range; *k0 receives the stream index of
+ * symbols[0]. Returns the number of symbols written, or < 0. */
+int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
+                       int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0);
+int64_t hvk_audio_position(const hvk_audio_t *a);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

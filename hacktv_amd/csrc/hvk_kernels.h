@@ -1,0 +1,58 @@
+/* hvk_kernels.h -- launch interface between the engine (host C++) and the
+ * gfx950 kernels in hvk_kernels.hip. */
+#ifndef HVK_KERNELS_H
+#define HVK_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include "hvk_internal.h"
+
+#define HVK_CHROMA_LEAD 16   /* int16 of slack either side of a chroma channel in LDS */
+
+/* FIR taps packed two int16 per dword, zero padded: passed by value so they
+ * live in SGPRs (wave-uniform operands of v_dot2c_i32_i16) */
+typedef struct {
+	int p[(HVK_MAX_VF_TAPS + 1) / 2];
+} hvk_packed_taps_t;
+
+typedef struct {
+	hvk_kconst_t k;
+	hvk_packed_taps_t ctaps;
+	const hvk_linedesc_t *desc;
+	const int16_t *pulses;
+	const void *yuv;            /* 2^24 x int16x4 */
+	const hvk_c16_t *clut;
+	const int16_t *burst_win;
+	const int16_t *ghost;
+	const uint32_t *pool;
+	const hvk_framedesc_t *fdesc;
+	int16_t *S;                 /* [nframes][lines + 2][width] */
+	int nframes;
+} hvk_raster_args_t;
+
+typedef struct {
+	hvk_kconst_t k;
+	hvk_packed_taps_t itaps, qtaps;
+	const hvk_framedesc_t *fdesc;
+	const int16_t *S;
+	const hvk_c16_t *carriers;
+	const uint8_t *symbols;
+	int symbol_stride;
+	const int16_t *nicam_taps;
+	const hvk_c16_t *nicam_cc;
+	int16_t *iq;
+	int nframes;
+} hvk_filter_args_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
+int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
+int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

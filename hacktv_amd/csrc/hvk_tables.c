@@ -1,0 +1,723 @@
+/* hvk_tables.c -- host-side table builder of the MI355X engine.
+ *
+ * Everything vid_init() precomputes for the hot path (src/video.c:3812-4162,
+ * :4375-4558 and the designers in src/fir.c:32-255, src/nicam728.c:257-331) is
+ * built here, once, in double precision with the host libm, and then uploaded
+ * to HBM by hvk_open(). The tables have to be produced on the host: entries
+ * such as round(cos(d * c) * 32767) over 2.56 M phases are only bit-identical
+ * with the reference when the same libm evaluates them.
+ *
+ * The layout is the device's, not the reference's: pulses are a flat value
+ * array with an index, the per-line code strings become a [2][lines] array of
+ * descriptors, filter taps are stored in the order they meet the samples.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "hvk_internal.h"
+
+#define EDGE_0_100 2.0738786   /* 10-90 % rise time -> full width of an integrated raised-cosine edge (src/common.h:28) */
+
+/* ------------------------------------------------------------------ */
+/* shaped edges                                                        */
+
+/* Integrated raised-cosine window: 1 inside, 0 outside, `rise` wide edges
+ * centred on left and left + width (src/common.c:231-257) */
+static double _window(double t, double left, double width, double rise)
+{
+	t -= left + width / 2;
+	t = fabs(t) - (width - rise) / 2;
+
+	if(t <= 0) return(1.0);
+	if(t >= rise) return(0.0);
+
+	t = 1.0 - t / rise * 2;
+	return(0.5 * (1.0 + t + sin(M_PI * t) / M_PI));
+}
+
+/* One sync pulse as the reference's vbidata step renderer quantises it
+ * (src/vbidata.c:36-81): samples floor(offset - rise/2) .. ceil(offset +
+ * width + rise/2), leading and trailing zeros trimmed. Appends the values to
+ * `out` (if not NULL) and returns their count; *first receives the sample
+ * index of the first value. */
+static int _quantise_pulse(int16_t *out, int *first, double offset, double width, double rise, int level)
+{
+	int x, x1 = floor(offset - rise / 2), x2 = ceil(offset + width + rise / 2);
+	int start = 0, len = 0;
+
+	for(x = x1; x <= x2; x++)
+	{
+		int v = round(_window(x, offset, width, rise) * level);
+		if(v == 0) continue;
+		if(len == 0) start = x;
+		if(out)
+		{
+			int i;
+			for(i = len; i < x - start; i++) out[i] = 0;
+			out[x - start] = v;
+		}
+		len = x - start + 1;
+	}
+
+	*first = start;
+	return(len);
+}
+
+/* ------------------------------------------------------------------ */
+/* line descriptors                                                    */
+
+/* Field structure of the two interlaced rasters as runs of lines. Pulse ids:
+ * 0 line sync, 1 equalising, 2 broad, 3 equalising at mid-line, 4 broad at
+ * mid-line, -1 none. burst: 'A' every frame, 'E' frames with (frame & 1) == 0,
+ * 'O' frames with (frame & 1) == 1, '-' none (the frame parity tests are
+ * src/video.c:2901-2903). act: bit 0 picture in the left half, bit 1 in the
+ * right half. Source: src/video.c:2479-2591. */
+typedef struct { short first, last; signed char left, mid; char burst; char act; } _run_t;
+
+static const _run_t _runs_625[] = {
+	{   1,   2, 2,  4, '-', 0 }, {   3,   3, 2,  3, '-', 0 }, {   4,   5, 1,  3, '-', 0 },
+	{   6,   6, 0, -1, 'E', 0 }, {   7,  22, 0, -1, 'A', 0 }, {  23,  23, 0, -1, 'A', 2 },
+	{  24, 309, 0, -1, 'A', 3 }, { 310, 310, 0, -1, 'E', 3 }, { 311, 312, 1,  3, '-', 0 },
+	{ 313, 313, 1,  4, '-', 0 }, { 314, 315, 2,  4, '-', 0 }, { 316, 317, 1,  3, '-', 0 },
+	{ 318, 318, 1, -1, '-', 0 }, { 319, 319, 0, -1, 'O', 0 }, { 320, 335, 0, -1, 'A', 0 },
+	{ 336, 621, 0, -1, 'A', 3 }, { 622, 622, 0, -1, 'E', 3 }, { 623, 623, 0,  3, '-', 1 },
+	{ 624, 625, 1,  3, '-', 0 }, { 0, 0, 0, 0, 0, 0 },
+};
+
+static const _run_t _runs_525[] = {
+	{   1,   3, 1,  3, '-', 0 }, {   4,   6, 2,  4, '-', 0 }, {   7,   9, 1,  3, '-', 0 },
+	{  10,  20, 0, -1, 'A', 0 }, {  21, 262, 0, -1, 'A', 3 }, { 263, 263, 0,  3, 'A', 1 },
+	{ 264, 265, 1,  3, '-', 0 }, { 266, 266, 1,  4, '-', 0 }, { 267, 268, 2,  4, '-', 0 },
+	{ 269, 269, 2,  3, '-', 0 }, { 270, 271, 1,  3, '-', 0 }, { 272, 272, 1, -1, '-', 0 },
+	{ 273, 282, 0, -1, 'A', 0 }, { 283, 283, 0, -1, 'A', 2 }, { 284, 525, 0, -1, 'A', 3 },
+	{ 0, 0, 0, 0, 0, 0 },
+};
+
+static const _run_t *_find_run(const _run_t *r, int line)
+{
+	for(; r->first; r++) if(line >= r->first && line <= r->last) return(r);
+	return(NULL);
+}
+
+/* First source row of each field (src/video.c:2818-2831) */
+static int _row_of_line(int type, int line)
+{
+	if(type == HVK_RASTER_625) return(line < 313 ? (line - 23) * 2 : (line - 336) * 2 + 1);
+	return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
+}
+
+static int _build_linedesc(hvk_tables_t *t)
+{
+	const hvk_config_t *c = &t->conf;
+	const _run_t *runs = c->type == HVK_RASTER_625 ? _runs_625 : _runs_525;
+	int colour = c->colour_mode == HVK_PAL || c->colour_mode == HVK_NTSC;
+	int p, line;
+
+	t->desc = calloc(2 * c->lines, sizeof(hvk_linedesc_t));
+	if(!t->desc) return(HVK_OUT_OF_MEMORY);
+
+	for(p = 0; p < 2; p++)
+	for(line = 1; line <= c->lines; line++)
+	{
+		hvk_linedesc_t *d = &t->desc[p * c->lines + line - 1];
+		const _run_t *r = _find_run(runs, line);
+		const _run_t *rn = _find_run(runs, line == c->lines ? 1 : line + 1);
+
+		if(!r || !rn) return(HVK_ERROR);
+
+		d->pulse_left = r->left;
+		d->pulse_mid = r->mid;
+		d->pulse_next = (rn->left >= 0 && t->k.pulse_offset[rn->left] < 0) ? rn->left : -1;
+
+		d->al = d->ar = 0;
+		if(r->act)
+		{
+			d->al = (r->act & 1) ? t->k.active_left : t->k.half_width;
+			d->ar = (r->act & 2) ? t->k.active_left + t->k.active_width : t->k.half_width;
+		}
+		d->src_row = _row_of_line(c->type, line);
+
+		d->pal = 0;
+		if(colour)
+		{
+			/* p is (frame & 1) */
+			if(r->burst == 'A' || (r->burst == 'E' && p == 0) || (r->burst == 'O' && p == 1)) d->pal = 1;
+			if(c->colour_mode == HVK_PAL && d->pal && ((p + line) & 1)) d->pal = -1;
+		}
+	}
+
+	return(HVK_OK);
+}
+
+/* ------------------------------------------------------------------ */
+/* FIR designers                                                       */
+
+/* modified Bessel I0 by its power series (src/fir.c:32-51) */
+static double _bessel_i0(double x)
+{
+	double sum = 1, u = 1, halfx = x / 2.0, temp;
+	int n = 1;
+
+	do
+	{
+		temp = halfx / (double) n;
+		n += 1;
+		temp *= temp;
+		u *= temp;
+		sum += u;
+	}
+	while(u >= 1e-21 * sum);
+
+	return(sum);
+}
+
+/* Kaiser-windowed sinc low pass with unity DC gain (src/fir.c:53-69, :89-137) */
+static void _design_low_pass(double *taps, int ntaps, double sample_rate, double cutoff)
+{
+	const double beta = 7.0;
+	double inv_i0 = 1.0 / _bessel_i0(beta);
+	double inm1 = 1.0 / ((double) (ntaps - 1));
+	double w = 2.0 * M_PI * cutoff / sample_rate;
+	double dc, gain = 1;
+	int M = (ntaps - 1) / 2, i, n;
+
+	taps[0] = taps[ntaps - 1] = inv_i0;
+	for(i = 1; i < ntaps - 1; i++)
+	{
+		double temp = 2 * i * inm1 - 1;
+		taps[i] = _bessel_i0(beta * sqrt(1.0 - temp * temp)) * inv_i0;
+	}
+
+	for(n = -M; n <= M; n++)
+	{
+		if(n == 0) taps[n + M] *= w / M_PI;
+		else taps[n + M] *= sin(n * w) / (n * M_PI);
+	}
+
+	dc = taps[M];
+	for(n = 1; n <= M; n++) dc += 2 * taps[n + M];
+
+	gain /= dc;
+	for(n = 0; n < ntaps; n++) taps[n] *= gain;
+}
+
+/* Gaussian low pass for the chroma baseband (src/fir.c:139-177) */
+static int _design_gaussian(double **ptaps, double sample_rate, double cutoff)
+{
+	int ntaps = ((int) ceil(sample_rate / 1.35e6 / (cutoff / 1.4e6))) | 1;
+	double *taps = calloc(ntaps, sizeof(double));
+	double f = 13.5e6 / sample_rate;
+	double s = 354372.0 / cutoff;
+	double sum = 0, gain = 1;
+	int h = ntaps / 2, x;
+
+	for(x = 0; x <= h; x++)
+	{
+		double t = (double) x / 5 * f;
+		double r = 1.0 / s * pow(2.0 * M_PI, 0.5) * pow(M_E, -pow(t, 2.0) / (2.0 * pow(s, 2)));
+		sum += r * (x > 0 ? 2 : 1);
+		taps[h + x] = taps[h - x] = r;
+	}
+
+	gain /= sum;
+	for(x = 0; x < ntaps; x++) taps[x] *= gain;
+
+	*ptaps = taps;
+	return(ntaps);
+}
+
+/* Quantise to Q15 in the order the taps meet the samples: the reference
+ * stores the design reversed (src/fir.c:279-286), so tap[k] multiplies the
+ * sample k places after the oldest one in the window. */
+static int16_t *_q15_applied(const double *taps, int ntaps, int stride)
+{
+	int16_t *q = calloc(ntaps, sizeof(int16_t));
+	int k;
+	if(q) for(k = 0; k < ntaps; k++) q[k] = lround(taps[(ntaps - 1 - k) * stride] * 32767.0);
+	return(q);
+}
+
+/* ------------------------------------------------------------------ */
+/* the ghost samples                                    */
+
+static long _malloc_chunk(long request)
+{
+	long c = (request + 8 + 15) & ~15L;
+	return(c < 32 ? 32 : c);
+}
+
+/* Default for what follows the reference's chrominance buffer in memory.
+ * The reference's zero-history chroma FIR is fed width + ntaps/2 samples per
+ * channel (src/fir.c:365-372 after the pre-load, with samples = width from
+ * src/video.c:3019-3020), i.e. it reads ntaps/2 interleaved samples past the
+ * 2*width int16 allocation (src/video.c:3990). In the reference CLI on glibc
+ * 2.35 those bytes are: the rest of the buffer's own chunk (never written:
+ * zero), the size word of the next chunk, and that chunk's contents. The next
+ * chunk is the temporary array of design taps (src/video.c:4004), freed at
+ * :4013 and immediately handed out again for the burst window (:4021 ->
+ * :2201) because both requests round to the same chunk size. */
+void hvk_tables_default_ghost(hvk_tables_t *t)
+{
+	long req = (long) sizeof(int16_t) * 2 * t->k.width;
+	long slack = (_malloc_chunk(req) - 8 - req) / (long) sizeof(int16_t);
+	long c_taps = _malloc_chunk((long) t->k.chroma_ntaps * (long) sizeof(double));
+	long c_bwin = _malloc_chunk((long) t->k.burst_width * (long) sizeof(int16_t));
+	int i, o;
+
+	memset(t->ghost, 0, sizeof(t->ghost));
+	if(t->k.chroma_ntaps == 0 || t->burst_win == NULL) return;
+
+	o = slack;
+	if(o + 4 > HVK_GHOST_LEN) return;
+	t->ghost[o] = (int16_t) ((c_taps | 1) & 0xFFFF); /* low 16 bits of size | PREV_INUSE */
+	o += 4;
+
+	if(c_taps != c_bwin) return;
+	for(i = 0; o < HVK_GHOST_LEN && i < t->k.burst_width; i++, o++) t->ghost[o] = t->burst_win[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* audio sub-carrier tables                                            */
+
+/* lround(x * 32767) of the 65-tap symmetric 32 kHz audio filters of
+ * src/video.c:2118-2168 (first 33 taps; tap[64 - k] == tap[k]) */
+static const int32_t _audio_flat[33] = {
+	0, -26, 10, -42, 25, -68, 44, -101, 63, -133, 71, -149, 52, -130, -13, -60,
+	-138, 77, -333, 283, -593, 550, -904, 856, -1235, 1169, -1552, 1450, -1814,
+	1663, -1987, 1777, 30719
+};
+static const int32_t _audio_50us[33] = {
+	40, -86, 95, -158, 177, -265, 290, -399, 409, -518, 478, -552, 418, -414,
+	138, -17, -437, 699, -1345, 1748, -2566, 3076, -4015, 4560, -5532, 5997,
+	-6890, 7033, -7753, 6441, -7411, -19876, 81829
+};
+static const int32_t _audio_75us[33] = {
+	65, -123, 147, -227, 270, -385, 440, -580, 619, -752, 726, -799, 641, -588,
+	231, 6, -616, 1073, -1956, 2632, -3763, 4603, -5910, 6798, -8169, 8898,
+	-10227, 10324, -11683, 9020, -11904, -32509, 116205
+};
+
+static void _mirror65(int32_t *dst, const int32_t *half)
+{
+	int k;
+	for(k = 0; k <= 32; k++) dst[k] = dst[64 - k] = half[k];
+}
+
+static hvk_c32_t _unit_phasor(double radians)
+{
+	hvk_c32_t r;
+	r.i = lround(cos(radians) * INT32_MAX);
+	r.q = lround(sin(radians) * INT32_MAX);
+	return(r);
+}
+
+static double _root_raised_cosine(double x, double b, double t)
+{
+	/* src/common.c:259-283 */
+	if(x == 0) return((1.0 / t) * (1.0 + b * (4.0 / M_PI - 1)));
+
+	if(fabs(x) == t / (4.0 * b))
+	{
+		return(b / (t * sqrt(2.0)) * ((1.0 + 2.0 / M_PI) * sin(M_PI / (4.0 * b)) + (1.0 - 2.0 / M_PI) * cos(M_PI / (4.0 * b))));
+	}
+
+	{
+		double t1 = (4.0 * b * (x / t));
+		double t2 = (sin(M_PI * (x / t) * (1.0 - b)) + 4.0 * b * (x / t) * cos(M_PI * (x / t) * (1.0 + b)));
+		double t3 = (M_PI * (x / t) * (1.0 - t1 * t1));
+		return((1.0 / t) * (t2 / t3));
+	}
+}
+
+static unsigned int _gcd_u(unsigned int a, unsigned int b)
+{
+	unsigned int c;
+	while((c = a % b)) { a = b; b = c; }
+	return(b);
+}
+
+static int _build_audio(hvk_tables_t *t, double slevel)
+{
+	const hvk_config_t *c = &t->conf;
+	int i;
+
+	t->k.has_carriers = 0;
+	t->k.has_nicam = 0;
+
+	/* FM sound carrier (src/video.c:4404-4441, :2218-2243) */
+	if(c->fm_mono_level > 0 && c->fm_mono_carrier != 0)
+	{
+		int r;
+
+		t->fm_level = (int16_t) round(INT16_MAX * (c->fm_mono_level * slevel));
+		t->fm_lut = malloc(sizeof(hvk_c32_t) * 65536);
+		if(!t->fm_lut) return(HVK_OUT_OF_MEMORY);
+
+		for(r = INT16_MIN; r <= INT16_MAX; r++)
+		{
+			double d = 2.0 * M_PI / t->sample_rate * (c->fm_mono_carrier + (double) r / INT16_MAX * c->fm_mono_deviation);
+			t->fm_lut[r - INT16_MIN] = _unit_phasor(d);
+		}
+
+		t->has_limiter = 0;
+		if(c->fm_mono_preemph == HVK_50US || c->fm_mono_preemph == HVK_75US)
+		{
+			_mirror65(t->limiter_vtaps, c->fm_mono_preemph == HVK_50US ? _audio_50us : _audio_75us);
+			_mirror65(t->limiter_ftaps, _audio_flat);
+			for(i = 0; i < 21; i++)
+			{
+				/* src/fir.c:800-803 with width 21 */
+				t->limiter_shape[i] = lround((1.0 - cos(2.0 * M_PI / (21 + 1) * (i + 1))) * 0.5 * INT16_MAX);
+			}
+			t->has_limiter = 1;
+		}
+		else if(c->fm_mono_preemph != 0) return(HVK_UNSUPPORTED);
+
+		t->k.has_carriers = 1;
+	}
+
+	/* AM sound carrier (src/video.c:4550-4558, :2343-2357) */
+	if(c->am_audio_level > 0 && c->am_mono_carrier != 0)
+	{
+		t->am_level = (int16_t) round(INT16_MAX * (c->am_audio_level * slevel));
+		t->am_delta = _unit_phasor(2.0 * M_PI / t->sample_rate * c->am_mono_carrier);
+		t->k.has_carriers = 1;
+	}
+
+	/* NICAM-728 (src/video.c:4522-4533, src/nicam728.c:257-331) */
+	if(c->nicam_level > 0 && c->nicam_carrier != 0)
+	{
+		unsigned int sr = t->sample_rate, freq = c->nicam_carrier, g;
+		double sps = (double) sr / 364000.0;
+		double level = c->nicam_level * slevel;
+		double d;
+		int h, x;
+
+		t->k.nicam_ntaps = ((unsigned int) (sps * 5) + 1) | 1;
+		t->nicam_taps = malloc(sizeof(int16_t) * t->k.nicam_ntaps);
+		if(!t->nicam_taps) return(HVK_OUT_OF_MEMORY);
+
+		h = t->k.nicam_ntaps / 2;
+		for(x = -h; x <= h; x++)
+		{
+			double tt = ((double) x) / sps;
+			double hx = (double) x / h;
+			double win = (hx < -1 || hx > 1) ? 0 : 0.54 - 0.46 * cos((M_PI * (1.0 + hx)));
+			double r = _root_raised_cosine(tt, c->nicam_beta, 1.0) * win;
+			r *= M_SQRT1_2 * INT16_MAX * level;
+			t->nicam_taps[x + h] = lround(r);
+		}
+
+		g = _gcd_u(sr, 364000);
+		t->k.nicam_decimation = 364000 / g;
+		t->k.nicam_sps = (sr + 364000 - 1) / 364000;
+		t->k.nicam_dsl = (t->k.nicam_sps * t->k.nicam_decimation) % (sr / g);
+
+		g = _gcd_u(sr, freq);
+		t->k.nicam_cc_len = sr / g;
+		t->nicam_cc = malloc(sizeof(hvk_c16_t) * t->k.nicam_cc_len);
+		if(!t->nicam_cc) return(HVK_OUT_OF_MEMORY);
+
+		d = 2.0 * M_PI / t->k.nicam_cc_len * (freq / g);
+		for(x = 0; x < t->k.nicam_cc_len; x++)
+		{
+			t->nicam_cc[x].i = round(cos(d * x) * 1.0 * INT16_MAX);
+			t->nicam_cc[x].q = round(sin(d * x) * 1.0 * INT16_MAX);
+		}
+
+		t->k.has_nicam = 1;
+	}
+
+	return(HVK_OK);
+}
+
+/* ------------------------------------------------------------------ */
+
+int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate)
+{
+	hvk_config_t *c;
+	double line_s, level, slevel, sync_amp;
+	int i, r;
+
+	memset(t, 0, sizeof(*t));
+	t->conf = *conf;
+	t->sample_rate = sample_rate;
+	c = &t->conf;
+
+	/* what the engine renders */
+	if(c->type != HVK_RASTER_625 && c->type != HVK_RASTER_525) return(HVK_UNSUPPORTED);
+	if(c->modulation == HVK_FM) return(HVK_UNSUPPORTED);
+	if(c->colour_mode == HVK_SECAM) return(HVK_UNSUPPORTED);
+	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
+	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
+
+	/* defaults (src/video.c:3832-3836) */
+	if(c->hline <= 0 && c->interlaced != 0) c->hline = (c->lines + 1) / 2;
+	if(c->gamma <= 0) c->gamma = 1.0;
+	if(c->rw_co <= 0) c->rw_co = 0.299;
+	if(c->gw_co <= 0) c->gw_co = 0.587;
+	if(c->bw_co <= 0) c->bw_co = 0.114;
+
+	/* geometry (src/video.c:3844-3853); pixel rate == sample rate */
+	line_s = (double) c->frame_rate.den / c->frame_rate.num / c->lines;
+	t->k.width = round((double) sample_rate * line_s);
+	t->k.half_width = round((double) sample_rate * line_s / 2);
+	t->k.active_left = round(sample_rate * c->active_left);
+	t->k.active_width = ceil(sample_rate * c->active_width);
+	if(t->k.active_width > t->k.width) t->k.active_width = t->k.width;
+	t->k.lines = c->lines;
+	t->k.active_lines = c->active_lines;
+	t->k.interlaced = c->interlaced;
+	t->k.frame_samples = t->k.width * t->k.lines;
+
+	if(t->k.width < 64 || t->k.width > 8192) return(HVK_UNSUPPORTED);
+
+	/* levels (src/video.c:3858-3881) */
+	slevel = c->level;
+	level = c->video_level * slevel;
+
+	if(c->invert_video)
+	{
+		double w = c->white_level;
+		c->white_level = c->sync_level;
+		c->sync_level = w;
+		c->blanking_level = c->sync_level - (c->blanking_level - c->white_level);
+		c->black_level = c->sync_level - (c->black_level - c->white_level);
+	}
+
+	t->white_level    = (int16_t) round(c->white_level    * level * INT16_MAX);
+	t->black_level    = (int16_t) round(c->black_level    * level * INT16_MAX);
+	t->blanking_level = (int16_t) round(c->blanking_level * level * INT16_MAX);
+	t->sync_level     = (int16_t) round(c->sync_level     * level * INT16_MAX);
+	t->k.blanking = t->blanking_level;
+
+	/* sync pulses (src/video.c:3884-3891): two passes, size then fill.
+	 * The amplitude reaches the renderer as an int (truncated). */
+	sync_amp = (c->sync_level - c->blanking_level) * level * INT16_MAX;
+	{
+		const double at[5]  = { 0, 0, 0, line_s / 2, line_s / 2 };
+		const double len[5] = { c->hsync_width, c->vsync_short_width, c->vsync_long_width,
+		                        c->vsync_short_width, c->vsync_long_width };
+		double rise = c->sync_rise * EDGE_0_100 * sample_rate;
+		int total = 0, o = 0, first;
+
+		t->k.npulses = 5;
+		for(i = 0; i < 5; i++)
+		{
+			t->k.pulse_length[i] = _quantise_pulse(NULL, &first, at[i] * sample_rate, len[i] * sample_rate, rise, (int) sync_amp);
+			t->k.pulse_offset[i] = first;
+			t->k.pulse_start[i] = total;
+			total += t->k.pulse_length[i];
+
+			/* a pulse must end inside its own line (true for every standard) */
+			if(first + t->k.pulse_length[i] > t->k.width || first < -t->k.width) return(HVK_UNSUPPORTED);
+		}
+
+		t->pulse_total = total;
+		t->pulse_values = calloc(total + 8, sizeof(int16_t));
+		t->sync_packed = calloc(total + 2 * 5 + 1, sizeof(int16_t));
+		if(!t->pulse_values || !t->sync_packed) return(HVK_OUT_OF_MEMORY);
+
+		for(i = 0; i < 5; i++)
+		{
+			_quantise_pulse(t->pulse_values + t->k.pulse_start[i], &first, at[i] * sample_rate, len[i] * sample_rate, rise, (int) sync_amp);
+
+			/* the same data in the reference's packed form, for table parity tests */
+			t->sync_packed[o++] = t->k.pulse_length[i];
+			t->sync_packed[o++] = t->k.pulse_offset[i];
+			memcpy(t->sync_packed + o, t->pulse_values + t->k.pulse_start[i], t->k.pulse_length[i] * sizeof(int16_t));
+			o += t->k.pulse_length[i];
+		}
+		t->sync_packed[o++] = -1;
+		t->sync_packed_len = o;
+	}
+
+	/* RGB -> level conversion parameters (src/video.c:3905-3958); the 2^24
+	 * entry table itself is expanded on the device */
+	for(i = 0; i < 256; i++) t->yuv.glut[i] = pow((double) i / 255, 1 / c->gamma);
+	t->yuv.rw = c->rw_co;
+	t->yuv.gw = c->gw_co;
+	t->yuv.bw = c->bw_co;
+	t->yuv.eu = c->eu_co;
+	t->yuv.ev = c->ev_co;
+	t->yuv.black = c->black_level;
+	t->yuv.range = c->white_level - c->black_level;
+	t->yuv.level = level;
+	t->yuv.chroma_scale = (c->white_level - c->black_level) * level;
+	t->yuv.secam = 0;
+	{
+		/* luma of black, used wherever the picture does not cover the active area */
+		double y = (c->black_level + (0.0 * (c->white_level - c->black_level))) * level;
+		y = y < -1 ? -1 : (y > 1 ? 1 : y);
+		t->k.black_y = (int16_t) round(y * INT16_MAX);
+	}
+
+	/* colour sub-carrier (src/video.c:3961-4014) */
+	t->k.colour = c->colour_mode == HVK_PAL || c->colour_mode == HVK_NTSC;
+	if(t->k.colour)
+	{
+		/* samples per sub-carrier cycle as a reduced fraction num/den:
+		 * the phase pattern repeats every `num` samples */
+		int64_t num = (int64_t) sample_rate * c->colour_carrier.den;
+		int64_t den = c->colour_carrier.num;
+		int64_t a = num, b = den, e, n;
+		double step;
+
+		if(den <= 0) return(HVK_ERROR);
+		while((e = a % b)) { a = b; b = e; }
+		num /= b;
+		den /= b;
+		if(num > 0x7FFFFFFF) return(HVK_UNSUPPORTED);
+
+		t->k.clw = num;
+		step = 2.0 * M_PI * ((double) den / num);
+
+		t->colour_lookup_len = num + t->k.width;
+		t->colour_lookup = malloc(t->colour_lookup_len * sizeof(hvk_c16_t));
+		if(!t->colour_lookup) return(HVK_OUT_OF_MEMORY);
+
+		for(n = 0; n < t->colour_lookup_len; n++)
+		{
+			t->colour_lookup[n].i = round(cos(step * n) * INT16_MAX);
+			t->colour_lookup[n].q = round(sin(step * n) * INT16_MAX);
+		}
+
+		if(c->colour_bw > 0)
+		{
+			double *taps;
+			t->k.chroma_ntaps = _design_gaussian(&taps, sample_rate, c->colour_bw);
+			t->chroma_taps = _q15_applied(taps, t->k.chroma_ntaps, 1);
+			free(taps);
+			if(!t->chroma_taps) return(HVK_OUT_OF_MEMORY);
+			if(t->k.chroma_ntaps / 2 * 2 > HVK_GHOST_LEN) return(HVK_UNSUPPORTED);
+		}
+	}
+
+	/* colour burst envelope (src/video.c:4017-4048, :2194-2214) */
+	if(c->burst_level > 0)
+	{
+		double rise = c->burst_rise * EDGE_0_100;
+		double amp = c->burst_level * (c->white_level - c->blanking_level) / 2 * level;
+
+		t->k.burst_left = round(sample_rate * (c->burst_left - c->burst_rise / 2));
+		t->k.burst_width = ceil(sample_rate * (c->burst_width + rise));
+		t->burst_win = malloc(t->k.burst_width * sizeof(int16_t));
+		if(!t->burst_win) return(HVK_OUT_OF_MEMORY);
+
+		for(i = 0; i < t->k.burst_width; i++)
+		{
+			double tt = 1.0 / sample_rate * i;
+			t->burst_win[i] = round(_window(tt, rise / 2, c->burst_width, rise) * amp * INT16_MAX);
+		}
+
+		if(c->colour_mode == HVK_PAL)
+		{
+			double p = 135.0 * (M_PI / 180.0);
+			t->k.burst_i = (int16_t) round(cos(p) * INT16_MAX);
+			t->k.burst_q = (int16_t) round(sin(p) * INT16_MAX);
+		}
+		else if(c->colour_mode == HVK_NTSC)
+		{
+			t->k.burst_i = -INT16_MAX;
+			t->k.burst_q = 0;
+		}
+
+		if(t->k.colour && t->k.burst_left + t->k.burst_width > t->k.width) return(HVK_UNSUPPORTED);
+	}
+	else if(t->k.colour) return(HVK_UNSUPPORTED);
+
+	hvk_tables_default_ghost(t);
+
+	/* video filter (src/video.c:3653-3764) */
+	t->k.vf_type = 0;
+	t->k.delay_lines = 0;
+	if(c->vfilter)
+	{
+		const int ntaps = 51;
+
+		if(c->modulation == HVK_VSB)
+		{
+			/* complex band pass = low pass of half the pass band rotated to the
+			 * band centre; the rotation phase is ACCUMULATED tap by tap
+			 * (src/fir.c:230-255) */
+			double lp[51], rot[51 * 2];
+			double freq = M_PI * (c->vsb_upper_bw + -c->vsb_lower_bw) / (double) sample_rate;
+			double phase = -freq * (ntaps >> 1);
+
+			_design_low_pass(lp, ntaps, sample_rate, (c->vsb_upper_bw - -c->vsb_lower_bw) / 2);
+			for(i = 0; i < ntaps; i++, phase += freq)
+			{
+				rot[i * 2 + 0] = lp[i] * cos(phase);
+				rot[i * 2 + 1] = lp[i] * sin(phase);
+			}
+
+			t->k.vf_type = 3;
+			t->k.vf_ntaps = ntaps;
+			t->vf_itaps = _q15_applied(rot + 0, ntaps, 2);
+			t->vf_qtaps = _q15_applied(rot + 1, ntaps, 2);
+			if(!t->vf_itaps || !t->vf_qtaps) return(HVK_OUT_OF_MEMORY);
+		}
+		else
+		{
+			double lp[51];
+			_design_low_pass(lp, ntaps, sample_rate, c->video_bw);
+			t->k.vf_type = 1;
+			t->k.vf_ntaps = ntaps;
+			t->vf_itaps = _q15_applied(lp, ntaps, 1);
+			if(!t->vf_itaps) return(HVK_OUT_OF_MEMORY);
+		}
+
+		/* whole lines of latency the reference's pipeline drops at start-up
+		 * (src/video.c:3620-3625, :3759) */
+		t->k.delay_lines = (ntaps / 2 + t->k.width - 1) / t->k.width;
+	}
+
+	if((r = _build_audio(t, slevel)) != HVK_OK) return(r);
+
+	return(_build_linedesc(t));
+}
+
+void hvk_tables_free(hvk_tables_t *t)
+{
+	free(t->desc);
+	free(t->pulse_values);
+	free(t->sync_packed);
+	free(t->colour_lookup);
+	free(t->burst_win);
+	free(t->chroma_taps);
+	free(t->vf_itaps);
+	free(t->vf_qtaps);
+	free(t->fm_lut);
+	free(t->nicam_taps);
+	free(t->nicam_cc);
+	memset(t, 0, sizeof(*t));
+}
+
+static long _give(void *dst, long max_bytes, const void *src, long bytes)
+{
+	if(src == NULL || bytes <= 0) return(0);
+	if(dst == NULL) return(bytes);
+	if(bytes > max_bytes) bytes = max_bytes;
+	memcpy(dst, src, bytes);
+	return(bytes);
+}
+
+/* Table access by the names the oracle and the reference probe use */
+long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes)
+{
+	if(!strcmp(name, "syncs"))         return(_give(dst, max_bytes, t->sync_packed, (long) t->sync_packed_len * 2));
+	if(!strcmp(name, "colour_lookup")) return(_give(dst, max_bytes, t->colour_lookup, (long) t->colour_lookup_len * 4));
+	if(!strcmp(name, "burst_win"))     return(_give(dst, max_bytes, t->burst_win, (long) t->k.burst_width * 2));
+	if(!strcmp(name, "chroma_taps"))   return(_give(dst, max_bytes, t->chroma_taps, (long) t->k.chroma_ntaps * 2));
+	if(!strcmp(name, "chroma_ghost"))  return(_give(dst, max_bytes, t->ghost, sizeof(t->ghost)));
+	if(!strcmp(name, "vfilter_itaps")) return(_give(dst, max_bytes, t->vf_itaps, (long) t->k.vf_ntaps * 2));
+	if(!strcmp(name, "vfilter_qtaps")) return(_give(dst, max_bytes, t->vf_qtaps, t->vf_qtaps ? (long) t->k.vf_ntaps * 2 : 0));
+	if(!strcmp(name, "fm_mono_lut"))   return(_give(dst, max_bytes, t->fm_lut, 65536L * 8));
+	if(!strcmp(name, "nicam_taps"))    return(_give(dst, max_bytes, t->nicam_taps, (long) t->k.nicam_ntaps * 2));
+	if(!strcmp(name, "nicam_cc"))      return(_give(dst, max_bytes, t->nicam_cc, (long) t->k.nicam_cc_len * 4));
+	if(!strcmp(name, "limiter_shape")) return(_give(dst, max_bytes, t->limiter_shape, t->has_limiter ? 21L * 2 : 0));
+	if(!strcmp(name, "limiter_vtaps")) return(_give(dst, max_bytes, t->limiter_vtaps, t->has_limiter ? 65L * 4 : 0));
+	if(!strcmp(name, "limiter_ftaps")) return(_give(dst, max_bytes, t->limiter_ftaps, t->has_limiter ? 65L * 4 : 0));
+	if(!strcmp(name, "linedesc"))      return(_give(dst, max_bytes, t->desc, (long) 2 * t->k.lines * sizeof(hvk_linedesc_t)));
+	return(-1);
+}

@@ -1,0 +1,192 @@
+"""ctypes binding of libhvk.so (include/hacktv_amd.h).
+
+The class mirrors the reference's engine interface at frame granularity:
+Engine(...) is vid_init(), render() is a batch of vid_next_line() calls,
+close() is vid_free() (src/video.h:510-516). There is no Python or CPU
+implementation behind it: if the shared library or the HIP device is missing
+the calls raise."""
+import ctypes as C
+import os
+import numpy as np
+
+from .ctypes_defs import HvkConfig, HvkInfo
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
+
+SYMBOLS = [
+    "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
+    "hvk_open", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
+    "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_audio_write",
+    "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
+    "hvk_host_side_streams", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
+    "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
+]
+
+_lib = None
+
+
+class HvkError(RuntimeError):
+    def __init__(self, what, code):
+        super().__init__("%s failed with code %d" % (what, code))
+        self.code = code
+
+
+def lib():
+    """Load libhvk.so (built by __graft_entry__.build() / hacktv_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        L.hvk_config_preset.argtypes = [vp, C.c_char_p]
+        L.hvk_config_apply_flags.argtypes = [vp, i32]
+        L.hvk_config_apply_flags.restype = None
+        L.hvk_preset_id.restype = C.c_char_p
+        L.hvk_preset_id.argtypes = [i32]
+        L.hvk_preset_desc.restype = C.c_char_p
+        L.hvk_preset_desc.argtypes = [i32]
+        L.hvk_open.argtypes = [C.POINTER(vp), vp, C.c_uint, i32, i32]
+        L.hvk_close.argtypes = [vp]
+        L.hvk_close.restype = None
+        L.hvk_get_info.argtypes = [vp, vp]
+        L.hvk_get_framebuffer_length.argtypes = [vp]
+        L.hvk_get_framebuffer_length.restype = C.c_size_t
+        L.hvk_set_chroma_ghost.argtypes = [vp, vp, i32]
+        L.hvk_get_chroma_ghost.argtypes = [vp, vp, i32]
+        L.hvk_frame_upload.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32]
+        L.hvk_audio_write.argtypes = [vp, vp, C.c_size_t]
+        L.hvk_audio_needed.argtypes = [vp, i32]
+        L.hvk_audio_needed.restype = C.c_size_t
+        L.hvk_render.argtypes = [vp, i32, vp, vp]
+        L.hvk_render_strided.argtypes = [vp, i64, i64, i32, vp, vp]
+        L.hvk_stage_strided.argtypes = [vp, i64, i64, i32, vp]
+        L.hvk_launch.argtypes = [vp, vp]
+        L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
+        L.hvk_sync.argtypes = [vp]
+        L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.hvk_output_device_ptr.argtypes = [vp]
+        L.hvk_output_device_ptr.restype = vp
+        L.hvk_timing_enable.argtypes = [vp, i32]
+        L.hvk_timing_read.argtypes = [vp, i32, vp, vp]
+        L.hvk_table.argtypes = [vp, C.c_char_p, vp, C.c_long]
+        L.hvk_table.restype = C.c_long
+        L.hvk_fetch_raster.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.hvk_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def preset(mode, flags=0):
+    """vid_configs[] lookup + the CLI's preset edits (src/hacktv.c:1078-1171)."""
+    c = HvkConfig()
+    r = lib().hvk_config_preset(C.byref(c), mode.encode())
+    if r != 0:
+        raise HvkError("hvk_config_preset(%r)" % mode, r)
+    lib().hvk_config_apply_flags(C.byref(c), flags)
+    return c
+
+
+class Engine:
+    def __init__(self, conf, sample_rate, device=0, max_frames=4):
+        self.h = C.c_void_p()
+        self.conf = conf
+        r = lib().hvk_open(C.byref(self.h), C.byref(conf), sample_rate, device, max_frames)
+        if r != 0:
+            self.h = None
+            raise HvkError("hvk_open", r)
+        info = HvkInfo()
+        lib().hvk_get_info(self.h, C.byref(info))
+        self.info = info.as_dict()
+        self.device = device
+
+    def _chk(self, what, r):
+        if r < 0:
+            raise HvkError(what, r)
+        return r
+
+    def close(self):
+        if self.h:
+            lib().hvk_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def table(self, name, dtype):
+        n = lib().hvk_table(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        a = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        if n:
+            got = lib().hvk_table(self.h, name.encode(), a.ctypes.data, n)
+            if got != n:
+                raise HvkError("hvk_table(%s)" % name, got)
+        return a
+
+    def set_chroma_ghost(self, ghost):
+        g = np.ascontiguousarray(ghost, np.int16)
+        self._chk("hvk_set_chroma_ghost", lib().hvk_set_chroma_ghost(self.h, g.ctypes.data, len(g)))
+
+    def chroma_ghost(self):
+        g = np.zeros(32, np.int16)
+        self._chk("hvk_get_chroma_ghost", lib().hvk_get_chroma_ghost(self.h, g.ctypes.data, 32))
+        return g
+
+    def frame_upload(self, slot, fb, interlaced=0):
+        if fb is None:
+            return self._chk("hvk_frame_upload", lib().hvk_frame_upload(self.h, slot, None, 0, 0, 0, 0, 0))
+        fb = np.ascontiguousarray(fb, np.uint32)
+        h, w = fb.shape
+        return self._chk("hvk_frame_upload", lib().hvk_frame_upload(self.h, slot, fb.ctypes.data, w, h, 1, w, interlaced))
+
+    def audio_write(self, stereo):
+        a = np.ascontiguousarray(stereo, np.int16)
+        return self._chk("hvk_audio_write", lib().hvk_audio_write(self.h, a.ctypes.data, a.shape[0]))
+
+    def audio_needed(self, nframes):
+        return lib().hvk_audio_needed(self.h, nframes)
+
+    def host_side_streams(self, first, count):
+        car = np.zeros((count, 2), np.int16)
+        sym = np.zeros(count // 16 + 64, np.uint8)
+        k0 = C.c_int64(0)
+        n = self._chk("hvk_host_side_streams", lib().hvk_host_side_streams(
+            self.h, first, count, car.ctypes.data, sym.ctypes.data, len(sym), C.byref(k0)))
+        return car, sym[:n], k0.value
+
+    def render(self, nframes, slots=None, d_iq=None):
+        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)
+        return self._chk("hvk_render", lib().hvk_render(self.h, nframes, s.ctypes.data, d_iq))
+
+    def stage(self, first_frame, stride, nframes, slots=None):
+        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)
+        return self._chk("hvk_stage_strided", lib().hvk_stage_strided(self.h, first_frame, stride, nframes, s.ctypes.data))
+
+    def launch(self, d_iq=None):
+        return self._chk("hvk_launch", lib().hvk_launch(self.h, d_iq))
+
+    def sync(self):
+        return self._chk("hvk_sync", lib().hvk_sync(self.h))
+
+    def fetch(self, first, count):
+        out = np.zeros((count, 2), np.int16)
+        self._chk("hvk_fetch", lib().hvk_fetch(self.h, out.ctypes.data, first, count))
+        return out
+
+    def fetch_raster(self, first, count):
+        out = np.zeros(count, np.int16)
+        self._chk("hvk_fetch_raster", lib().hvk_fetch_raster(self.h, out.ctypes.data, first, count))
+        return out
+
+    def timing_enable(self, on=True):
+        return self._chk("hvk_timing_enable", lib().hvk_timing_enable(self.h, 1 if on else 0))
+
+    def timing_read(self, which):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._chk("hvk_timing_read", lib().hvk_timing_read(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -141,6 +141,26 @@ int hvk_render(hvk_engine_t *e, int nframes, const int32_t *slots, void *d_iq);
 int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes,
                        const int32_t *slots, void *d_iq);
 
+/* The two halves of hvk_render_strided(), for callers that want the side
+ * inputs resident in HBM before they start a clock: hvk_stage_strided() runs
+ * the host audio control path for the named frames and uploads frame
+ * descriptors, carrier side stream and NICAM symbols; hvk_launch() enqueues
+ * the raster and filter kernels for the staged batch (it may be called
+ * repeatedly for the same staged batch). */
+int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots);
+int hvk_launch(hvk_engine_t *e, void *d_iq);
+
+/* The host half on its own: run the audio-rate control path up to stream
+ * position first + count and hand back the side streams for
+ * [first, first + count) -- count int16 I/Q pairs of serial-carrier samples
+ * and the NICAM symbols that touch the range (*k0 = stream index of
+ * symbols[0]; 0xFF marks "before the first symbol"). first and count are
+ * multiples of the line width; positions are audio-stream positions (output
+ * position + delay_lines * width). Needs no device. Returns the number of
+ * symbols written or a negative HVK_* code. */
+int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
+                          int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0);
+
 /* Wait for the engine's stream; returns HVK_OK or the HIP failure. */
 int hvk_sync(hvk_engine_t *e);
 

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE (not product code).
+
+Generates the committed fixtures under tests/golden/ from the UNMODIFIED
+reference built by oracle/Makefile (oracle/_ref). The reference ships no tests
+or golden vectors of its own, so these are outputs of the
+reference itself, run in the build container:
+
+  testsrc.npz        the built-in test source (src/av_test.c): the 832x576
+                     and 715x480 RGBx test cards and the 6.4 s stereo tone.
+  ref_digests.json   for every case: sha256 of the first N frames the
+                     reference CLI writes (`hacktv_ref <flags> -o - test`),
+                     and sha256 of every table vid_init() builds.
+  ref_lines.npz      for every case: a few whole lines of reference output
+                     (first line, a VBI line, picture lines, the line pair
+                     around a frame boundary) for diagnosable comparisons.
+
+Run from the repository root, after `make -C oracle ref`:
+    python oracle/make_golden.py
+/root/reference is needed only to BUILD oracle/_ref; this script and the
+tests never read it.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refprobe  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# id, mode, sample rate, CLI flags, probe flags, real output, frames hashed
+CASES = [
+    ("pal_bb",        "pal",  16000000, [],                        0,                                      True,  4),
+    ("pal_bb_filter", "pal",  16000000, ["--filter"],              refprobe.FLAG_FILTER,                   True,  2),
+    ("i_raster",      "i",    16000000, ["--noaudio"],             refprobe.FLAG_NOAUDIO,                  False, 4),
+    ("i_vsb",         "i",    16000000, ["--noaudio", "--filter"], refprobe.FLAG_NOAUDIO | refprobe.FLAG_FILTER, False, 4),
+    ("i_fm",          "i",    16000000, ["--nonicam"],             refprobe.FLAG_NONICAM,                  False, 2),
+    ("i_audio",       "i",    16000000, [],                        0,                                      False, 2),
+    ("i_full",        "i",    16000000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
+    ("i_mono",        "i",    16000000, ["--nocolour", "--filter"], refprobe.FLAG_NOCOLOUR | refprobe.FLAG_FILTER, False, 2),
+    ("g_full",        "g",    16000000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 2),
+    ("m_full",        "m",    13500000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
+    ("ntsc_bb",       "ntsc", 13500000, [],                        0,                                      True,  2),
+    ("i_20m",         "i",    20250000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 2),
+]
+
+TABLES = [
+    ("syncs", np.int16), ("yuv", np.int16), ("colour_lookup", np.int16), ("burst_win", np.int16),
+    ("chroma_taps", np.int16), ("vfilter_itaps", np.int16), ("vfilter_qtaps", np.int16),
+    ("fm_mono_lut", np.int32), ("nicam_taps", np.int16), ("nicam_cc", np.int16),
+    ("limiter_shape", np.int16), ("limiter_vtaps", np.int32), ("limiter_ftaps", np.int32),
+]
+
+
+def ref_cli(mode, sr, flags, nbytes):
+    p = subprocess.Popen([refprobe.BIN_PATH, "-m", mode, "-s", str(sr)] + flags + ["-o", "-", "test"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    out = bytearray()
+    while len(out) < nbytes:
+        chunk = p.stdout.read(nbytes - len(out))
+        if not chunk:
+            break
+        out += chunk
+    p.kill()
+    p.wait()
+    return bytes(out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    digests = {}
+    lines = {}
+    src = {}
+
+    for cid, mode, sr, flags, pflags, real, nframes in CASES:
+        with refprobe.RefProbe(mode, sr, pflags) as r:
+            info = dict(r.info)
+            key = "frame_%dx%d" % (info["active_width"], info["active_lines"])
+            if key not in src:
+                src[key] = r.test_frame()
+            if "audio" not in src:
+                src["audio"] = r.test_audio()
+            tabs = {}
+            for name, dt in TABLES:
+                a = r.table(name, dt)
+                tabs[name] = {"len": int(a.size), "sha256": hashlib.sha256(a.tobytes()).hexdigest()}
+
+        W, L = info["width"], info["lines"]
+        fs = W * L
+        bps = 2 if real else 4
+        data = ref_cli(mode, sr, flags, nframes * fs * bps)
+        assert len(data) == nframes * fs * bps, (cid, len(data))
+        per_frame = [hashlib.sha256(data[: (i + 1) * fs * bps]).hexdigest() for i in range(nframes)]
+
+        a = np.frombuffer(data, np.int16)
+        a = a.reshape(-1, 1) if real else a.reshape(-1, 2)
+        pick = sorted(set([0, 1, 5, 6, 22, 23, 100, 309, 310, 312, 313, 335, 622, 623, L - 1, L, L + 1, L + 6, L + 100]))
+        pick = [g for g in pick if g < nframes * L]
+        lines[cid + "_idx"] = np.array(pick, np.int32)
+        lines[cid] = np.stack([a[g * W:(g + 1) * W] for g in pick])
+
+        digests[cid] = {
+            "mode": mode, "sample_rate": sr, "cli_flags": flags, "probe_flags": pflags, "real": real,
+            "width": W, "lines": L, "frames": nframes,
+            "sha256_cumulative": per_frame,   # sha256 of the first 1, 2, ... frames
+            "info": info, "tables": tabs,
+        }
+        print(cid, per_frame[-1][:16], flush=True)
+
+    np.savez_compressed(os.path.join(GOLD, "testsrc.npz"), **src)
+    np.savez_compressed(os.path.join(GOLD, "ref_lines.npz"), **lines)
+    with open(os.path.join(GOLD, "ref_digests.json"), "w") as f:
+        json.dump(digests, f, indent=1, sort_keys=True)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -239,20 +239,26 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 		else
 		{
 			int h = s->vf_ntaps / 2;
+			int16_t *win = malloc((W + s->vf_ntaps) * sizeof(int16_t));
+
+			/* the samples this line's outputs see: 25 before, 25 after */
+			for(x = 0; x < W + s->vf_ntaps - 1; x++) win[x] = _sample(s, base + x - h);
+
 			for(x = 0; x < W; x++)
 			{
 				int32_t ai = 0, aq = 0;
-				for(k = 0; k < s->vf_ntaps; k++)
+				for(k = 0; k < s->vf_ntaps; k++) ai += (int32_t) win[x + k] * s->vf_itaps[k];
+				if(s->vf_type == 3)
 				{
-					int32_t v = _sample(s, base + x - h + k);
-					ai += v * s->vf_itaps[k];
-					if(s->vf_type == 3) aq += v * s->vf_qtaps[k];
+					for(k = 0; k < s->vf_ntaps; k++) aq += (int32_t) win[x + k] * s->vf_qtaps[k];
 				}
 				ai >>= 15;
 				aq >>= 15;
 				out[x * 2 + 0] = ai < INT16_MIN ? INT16_MIN : (ai > INT16_MAX ? INT16_MAX : ai);
 				out[x * 2 + 1] = aq < INT16_MIN ? INT16_MIN : (aq > INT16_MAX ? INT16_MAX : aq);
 			}
+
+			free(win);
 		}
 
 		orc_audio_line(s, out, W, s->last_carrier + (g - g0) * W * 2);

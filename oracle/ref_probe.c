@@ -122,6 +122,7 @@ void ref_close(ref_probe_t *p)
 		if(s->nthreads == 0)
 		{
 			vid_free(s);
+			free(p);
 		}
 		else
 		{
@@ -133,9 +134,11 @@ void ref_close(ref_probe_t *p)
 			free(s->fm_mono.lut);
 			free(s->fm_secam.lut);
 			free(s->fm_secam_bell);
+			/* p itself is NOT freed: the parked workers wait on the barrier
+			 * that lives inside it */
 		}
 	}
-	free(p);
+	else free(p);
 }
 
 /* Geometry and levels, in a fixed order the python side names */

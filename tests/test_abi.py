@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every entry point include/hacktv_amd.h
+declares (no device needed, nothing is computed)."""
+import ctypes
+import os
+import re
+
+import hacktv_amd as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "hacktv_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(hvk_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(H.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_binding_lists_every_declared_symbol():
+    from hacktv_amd.engine import SYMBOLS
+    assert sorted(SYMBOLS) == declared_functions()
+
+
+def test_presets_match_the_reference_mode_ids():
+    ids = []
+    i = 0
+    while H.lib().hvk_preset_id(i):
+        ids.append(H.lib().hvk_preset_id(i).decode())
+        i += 1
+    assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc"]
+    assert H.lib().hvk_config_preset(ctypes.byref(H.HvkConfig()), b"nope") == -1
+
+
+def test_no_cpu_path_without_a_device():
+    """device -1 builds host tables only; rendering must fail loudly."""
+    c = H.preset("i", H.FLAG_FILTER)
+    with H.Engine(c, 16000000, device=-1) as e:
+        assert e.info["width"] == 1024 and e.info["frame_samples"] == 640000
+        try:
+            e.render(1)
+        except H.HvkError as err:
+            assert err.code == H.HVK_NO_DEVICE
+        else:
+            raise AssertionError("render without a device did not fail")
+
+
+def test_unsupported_configurations_are_refused():
+    for mode in ("l", "secam"):
+        c = H.preset(mode)
+        try:
+            H.Engine(c, 16000000, device=-1)
+        except H.HvkError as err:
+            assert err.code == -4
+        else:
+            raise AssertionError("SECAM is not rendered yet and must be refused")

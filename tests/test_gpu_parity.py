@@ -1,0 +1,193 @@
+"""Parity of the HIP path (libhvk on a real MI355X, through the C ABI) with
+the oracle and with the committed outputs of the unmodified reference.
+Bit-exact: everything on this path is integer arithmetic."""
+import numpy as np
+import pytest
+
+import hacktv_amd as H
+import oracle
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0):
+    batch = batch or nframes
+    out = []
+    with H.Engine(conf, sr, device=0, max_frames=batch) as e:
+        e.frame_upload(0, frame, interlaced)
+        done = 0
+        while done < nframes:
+            n = min(batch, nframes - done)
+            while audio is not None and e.audio_needed(n) > 0:
+                e.audio_write(audio)
+            e.render(n)
+            out.append(e.fetch(0, n * e.info["frame_samples"]))
+            done += n
+    return np.concatenate(out)
+
+
+def test_device_yuv_table_equals_oracle(golden):
+    """The 2^24-entry RGB -> level table is expanded on the device in FP64 with
+    contraction off; every entry must equal the host/libm-built reference table."""
+    for case in ("i_full", "m_full"):
+        conf, sr = golden.conf(case)
+        with H.Engine(conf, sr, device=0, max_frames=1) as e, oracle.Oracle(conf, sr) as o:
+            dev = e.table("yuv", np.int16)
+            ref = o.table("yuv", np.int16)
+        assert dev.shape == ref.shape
+        bad = np.nonzero(dev != ref)[0]
+        assert bad.size == 0, "%s: %d entries differ, first at %d" % (case, bad.size, bad[0] if bad.size else -1)
+        assert util.sha256(dev.tobytes()) == golden.cases[case]["tables"]["yuv"]["sha256"]
+
+
+@pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "i_mono", "g_full",
+                                  "m_full", "ntsc_bb", "pal_bb_filter", "i_20m"])
+def test_stream_equals_reference_digests(golden, case):
+    """First frames of every configuration against sha256 of the reference CLI's output."""
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    nframes = c["frames"]
+    iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2)
+    fs = c["width"] * c["lines"]
+    # excerpted lines first: a readable failure
+    idx = golden.lines[case + "_idx"]
+    ref = golden.lines[case]
+    W = c["width"]
+    for j, g in enumerate(idx):
+        mine = iq[g * W:(g + 1) * W, : (1 if c["real"] else 2)]
+        if not np.array_equal(mine, ref[j]):
+            d = np.nonzero((mine != ref[j]).any(axis=1))[0]
+            raise AssertionError("%s line %d: %d samples differ, first x=%d got %s want %s" %
+                                 (case, g, d.size, d[0], mine[d[0]], ref[j][d[0]]))
+    for n in range(nframes):
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
+
+
+@pytest.mark.parametrize("case", ["i_full", "m_full"])
+def test_raster_stage_equals_oracle(golden, case):
+    """The raster kernel's output (before filter and audio) against the oracle's raster."""
+    conf, sr = golden.conf(case)
+    with H.Engine(conf, sr, device=0, max_frames=2) as e, oracle.Oracle(conf, sr) as o:
+        e.frame_upload(0, golden.frame(case))
+        e.audio_write(golden.audio)
+        e.render(2)
+        fs = e.info["frame_samples"]
+        got = e.fetch_raster(0, 2 * fs)
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        o.render_lines(2 * e.info["lines"])
+        want = o.last_raster()
+    assert np.array_equal(got, want)
+
+
+def test_batching_and_sharding_do_not_change_the_stream(golden):
+    """Whole frames shard independently: 6 frames in one launch == 1 + 2 + 3 ==
+    frames {0,2,4} and {1,3,5} rendered by two 'ranks' and interleaved."""
+    conf, sr = golden.conf("i_full")
+    frame, audio = golden.frame("i_full"), golden.audio
+    one = _render(conf, sr, frame, audio, 6, batch=6)
+    parts = []
+    with H.Engine(conf, sr, device=0, max_frames=3) as e:
+        e.frame_upload(0, frame)
+        for n in (1, 2, 3):
+            while e.audio_needed(n) > 0:
+                e.audio_write(audio)
+            e.render(n)
+            parts.append(e.fetch(0, n * e.info["frame_samples"]))
+    assert np.array_equal(one, np.concatenate(parts))
+
+    fs = 640000
+    ranks = []
+    for r in range(2):
+        with H.Engine(conf, sr, device=0, max_frames=3) as e:
+            e.frame_upload(0, frame)
+            for _ in range(2):
+                e.audio_write(audio)
+            e.stage(r, 2, 3)
+            e.launch()
+            ranks.append(e.fetch(0, 3 * fs).reshape(3, fs, 2))
+    inter = np.stack([ranks[0], ranks[1]], axis=1).reshape(6 * fs, 2)
+    assert np.array_equal(one, inter)
+
+
+def test_frame_geometry_edge_cases(golden):
+    """No frame, a small centred frame, an oversized (cropped) frame, a progressive vs
+    'top field first' source: all against the oracle."""
+    conf, sr = golden.conf("i_vsb")
+    rng = np.random.default_rng(7)
+    frames = {
+        "none": None,
+        "small": rng.integers(0, 1 << 24, size=(300, 400), dtype=np.uint32),
+        "large": rng.integers(0, 1 << 24, size=(700, 1000), dtype=np.uint32),
+        "noise": rng.integers(0, 1 << 24, size=(576, 832), dtype=np.uint32),
+    }
+    for name, fb in frames.items():
+        for interlaced in (0, 1):
+            with oracle.Oracle(conf, sr) as o:
+                if fb is not None:
+                    o.set_frame(fb, interlaced)
+                want = o.render_lines(625)
+            with H.Engine(conf, sr, device=0, max_frames=1) as e:
+                e.frame_upload(0, fb, interlaced)
+                e.render(1)
+                got = e.fetch(0, 640000)
+            assert np.array_equal(got, want), (name, interlaced)
+
+
+def test_changing_frames_within_a_batch(golden):
+    """Each frame of a batch may show a different frame slot."""
+    conf, sr = golden.conf("i_raster")
+    rng = np.random.default_rng(11)
+    fbs = [rng.integers(0, 1 << 24, size=(576, 832), dtype=np.uint32) for _ in range(3)]
+    with H.Engine(conf, sr, device=0, max_frames=3) as e:
+        for s, fb in enumerate(fbs):
+            e.frame_upload(s, fb)
+        e.render(3, slots=[2, 0, 1])
+        got = e.fetch(0, 3 * 640000)
+    with oracle.Oracle(conf, sr) as o:
+        want = []
+        for s in (2, 0, 1):
+            # the reference pulls a frame at line 1 of each frame (src/video.c:4873-4881);
+            # the line rastered one ahead of the emitted ones is a vertical-sync line
+            o.set_frame(fbs[s])
+            want.append(o.render_lines(625))
+    assert np.array_equal(got, np.concatenate(want))
+
+
+def test_late_frames_audio_is_additive_and_position_exact(golden):
+    """Full-size property, far into the stream: (with audio) - (without audio) equals the
+    host side streams rebuilt independently of the video, mod 2^16; and the
+    colour sub-carrier phase at frame 40 equals the oracle's."""
+    conf_a, sr = golden.conf("i_full")
+    conf_v, _ = golden.conf("i_vsb")
+    frame, audio = golden.frame("i_full"), golden.audio
+    first, fs = 40, 640000
+    with H.Engine(conf_a, sr, device=0, max_frames=2) as e:
+        e.frame_upload(0, frame)
+        for _ in range(12):
+            e.audio_write(audio)
+        e.stage(first, 1, 2)
+        e.launch()
+        with_audio = e.fetch(0, 2 * fs).astype(np.int64)
+    with H.Engine(conf_v, sr, device=0, max_frames=2) as e:
+        e.frame_upload(0, frame)
+        e.stage(first, 1, 2)
+        e.launch()
+        video = e.fetch(0, 2 * fs)
+    with oracle.Oracle(conf_v, sr) as o:
+        o.set_frame(frame)
+        o.render_lines(first * 625)   # walk the oracle to frame 40
+        want_video = o.render_lines(2 * 625)
+    assert np.array_equal(video, want_video)
+
+    from test_host_path import _nicam_from_symbols
+    with H.Engine(conf_a, sr, device=-1) as h:
+        for _ in range(12):
+            h.audio_write(audio)
+        m0 = first * fs + h.info["delay_lines"] * 1024
+        car, sym, k0 = h.host_side_streams(m0, 2 * fs)
+        nic = _nicam_from_symbols(h, sym, k0, m0, 2 * fs)
+    diff = (with_audio - video.astype(np.int64) - car.astype(np.int64) - nic) % 65536
+    assert not diff.any()

@@ -1,0 +1,53 @@
+"""The oracle (oracle/liboracle.so, the CPU restatement) against the committed
+outputs of the unmodified reference: tests/golden/ref_digests.json (sha256 of
+the reference CLI's first frames, sha256 of every vid_init() table) and
+ref_lines.npz (whole lines). This is what pins the oracle on a box that has no
+/root/reference."""
+import numpy as np
+import pytest
+
+import oracle
+import util
+
+CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_full", "ntsc_bb", "i_mono", "g_full",
+              "pal_bb_filter", "i_20m"]
+
+
+@pytest.mark.parametrize("case", CASES_FAST)
+def test_oracle_stream_matches_reference_cli(golden, case):
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    W, L = c["width"], c["lines"]
+    nframes = min(2, c["frames"])
+    with oracle.Oracle(conf, sr) as o:
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        iq = o.render_lines(nframes * L)
+    assert iq.shape[0] == nframes * W * L
+    for n in range(nframes):
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * W * L], c["real"]))
+        assert got == c["sha256_cumulative"][n], "frame %d of %s differs from the reference" % (n + 1, case)
+    # the excerpted lines, for a readable failure
+    idx = golden.lines[case + "_idx"]
+    ref = golden.lines[case]
+    for j, g in enumerate(idx):
+        if g >= nframes * L:
+            continue
+        mine = iq[g * W:(g + 1) * W, : (1 if c["real"] else 2)]
+        assert np.array_equal(mine, ref[j]), "line %d of %s" % (g, case)
+
+
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m"])
+def test_oracle_tables_match_reference(golden, case):
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    with oracle.Oracle(conf, sr) as o:
+        for k in ("width", "half_width", "active_width", "active_left", "white_level", "black_level",
+                  "blanking_level", "sync_level", "colour_lookup_width", "burst_left", "burst_width",
+                  "burst_phase_i", "burst_phase_q", "chroma_ataps", "fm_mono_level", "nicam_ntaps",
+                  "nicam_sps", "nicam_dsl", "nicam_decimation", "nicam_cc_len"):
+            assert o.info[k] == c["info"][k], k
+        for name, ref in c["tables"].items():
+            a = o.table(name, util.TABLE_DTYPES[name])
+            assert a.size == ref["len"], name
+            assert util.sha256(a.tobytes()) == ref["sha256"], name

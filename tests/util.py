@@ -1,0 +1,50 @@
+"""Shared helpers of the test-suite: golden fixtures, case table, hashing."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+TABLE_DTYPES = {
+    "syncs": np.int16, "yuv": np.int16, "colour_lookup": np.int16, "burst_win": np.int16,
+    "chroma_taps": np.int16, "chroma_ghost": np.int16, "vfilter_itaps": np.int16, "vfilter_qtaps": np.int16,
+    "fm_mono_lut": np.int32, "nicam_taps": np.int16, "nicam_cc": np.int16,
+    "limiter_shape": np.int16, "limiter_vtaps": np.int32, "limiter_ftaps": np.int32,
+}
+
+
+class Golden:
+    """tests/golden/: outputs of the unmodified reference (oracle/make_golden.py)."""
+
+    def __init__(self):
+        with open(os.path.join(GOLD, "ref_digests.json")) as f:
+            self.cases = json.load(f)
+        self.src = np.load(os.path.join(GOLD, "testsrc.npz"))
+        self.lines = np.load(os.path.join(GOLD, "ref_lines.npz"))
+
+    def frame(self, case):
+        i = self.cases[case]["info"]
+        return self.src["frame_%dx%d" % (i["active_width"], i["active_lines"])]
+
+    @property
+    def audio(self):
+        return self.src["audio"]
+
+    def conf(self, case):
+        import hacktv_amd as H
+        c = self.cases[case]
+        return H.preset(c["mode"], c["probe_flags"]), c["sample_rate"]
+
+
+def stream_bytes(iq, real):
+    """The bytes the reference's file sink writes for these samples
+    (src/rf_file.c: int16 real writes I only, int16 complex writes pairs)."""
+    iq = np.ascontiguousarray(iq, np.int16)
+    return (iq[:, 0].copy() if real else iq).tobytes()
+
+
+def sha256(b):
+    return hashlib.sha256(b).hexdigest()
