@@ -45,7 +45,8 @@ struct hvk_engine {
 	int max_frames;
 	int frame_slots;
 	int symbol_stride;
-	hipStream_t stream;
+	hipStream_t stream;         /* stream in use */
+	hipStream_t own_stream;
 
 	/* constant tables */
 	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_ntaps, *d_ncc;
@@ -157,7 +158,8 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
 
 	OPENHIP(hipSetDevice(device));
-	OPENHIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+	OPENHIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+	e->stream = e->own_stream;
 
 	OPENCHK(_upload(&e->d_yuvparams, &e->t.yuv, sizeof(e->t.yuv)));
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
@@ -212,7 +214,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_frame };
 		for(void *p : host) if(p) (void) hipHostFree(p);
-		if(e->stream) (void) hipStreamDestroy(e->stream);
+		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
 
 	hvk_audio_free(e->audio);
@@ -433,9 +435,25 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	return(HVK_OK);
 }
 
-extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
+extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
 {
 	if(!e) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	e->stream = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+	return(HVK_OK);
+}
+
+extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
+{
+	return(hvk_launch_strided_out(e, d_iq, 1));
+}
+
+extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride)
+{
+	if(!e || out_stride < 1) return(HVK_ERROR);
+	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	if(e->staged < 1) return(HVK_ERROR);
 
@@ -470,6 +488,7 @@ extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
 	fa.nicam_cc = (const hvk_c16_t *) e->d_ncc;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
+	fa.out_stride = out_stride;
 
 	const bool timed = e->timing && e->ev_used < HVK_TIMING_SLOTS;
 	hipEvent_t *ev = timed ? e->ev[e->ev_used] : NULL;

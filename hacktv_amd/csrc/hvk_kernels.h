@@ -41,6 +41,7 @@ typedef struct {
 	const hvk_c16_t *nicam_cc;
 	int16_t *iq;
 	int nframes;
+	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */
 } hvk_filter_args_t;
 
 #ifdef __cplusplus

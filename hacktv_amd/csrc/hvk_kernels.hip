@@ -149,7 +149,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	{
 		/* before the stream: the filter history is zero, not blanking
 		 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
-		if(x0 < W) *(int4v *) (out + x0) = (int4v) { 0, 0, 0, 0 };
+		for(int i = 0; i < SPL; i++) if(x0 + i < W) out[x0 + i] = 0;
 		return;
 	}
 
@@ -330,7 +330,8 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int symbol_stride,
                   const int16_t *__restrict__ nicam_taps,
                   const int *__restrict__ nicam_cc,
-                  int *__restrict__ iq)                  /* [frames][frame_samples] int16 pairs */
+                  int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
+                  const int64_t out_stride)
 {
 	constexpr int H = NT / 2;
 	constexpr int LEAD = H + (H & 1);           /* window lead, even */
@@ -403,13 +404,14 @@ void hvk_k_filter(const hvk_kconst_t k,
 		for(int i = 0; i < SPL; i++) { oi[i] = (n + i < FS) ? p[i] : 0; oq[i] = 0; }
 	}
 
-	const size_t obase = (size_t) blockIdx.y * FS + n;
+	const size_t cbase = (size_t) blockIdx.y * FS + n;
+	const size_t obase = (size_t) blockIdx.y * out_stride * FS + n;
 
 	/* serial carriers (FM / AM sound), computed on the host: a plain add
 	 * (src/video.c:3431-3432) */
 	if(k.has_carriers)
 	{
-		const int *c = carriers + obase;
+		const int *c = carriers + cbase;
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
@@ -543,7 +545,7 @@ static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	hipLaunchKernelGGL((hvk_k_filter<NT, VF>), dim3(tiles, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
 	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->symbols,
-	                   a->symbol_stride, a->nicam_taps, (const int *) a->nicam_cc, (int *) a->iq);
+	                   a->symbol_stride, a->nicam_taps, (const int *) a->nicam_cc, (int *) a->iq, a->out_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

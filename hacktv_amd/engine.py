@@ -18,6 +18,7 @@ SYMBOLS = [
     "hvk_open", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_audio_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
+    "hvk_launch_strided_out", "hvk_set_stream",
     "hvk_host_side_streams", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
@@ -62,6 +63,8 @@ def lib():
         L.hvk_render_strided.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hvk_stage_strided.argtypes = [vp, i64, i64, i32, vp]
         L.hvk_launch.argtypes = [vp, vp]
+        L.hvk_launch_strided_out.argtypes = [vp, vp, i64]
+        L.hvk_set_stream.argtypes = [vp, vp]
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -166,8 +169,13 @@ class Engine:
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)
         return self._chk("hvk_stage_strided", lib().hvk_stage_strided(self.h, first_frame, stride, nframes, s.ctypes.data))
 
-    def launch(self, d_iq=None):
-        return self._chk("hvk_launch", lib().hvk_launch(self.h, d_iq))
+    def launch(self, d_iq=None, out_stride=1):
+        if out_stride == 1:
+            return self._chk("hvk_launch", lib().hvk_launch(self.h, d_iq))
+        return self._chk("hvk_launch_strided_out", lib().hvk_launch_strided_out(self.h, d_iq, out_stride))
+
+    def set_stream(self, hip_stream):
+        return self._chk("hvk_set_stream", lib().hvk_set_stream(self.h, hip_stream))
 
     def sync(self):
         return self._chk("hvk_sync", lib().hvk_sync(self.h))

@@ -150,6 +150,16 @@ int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int
 int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots);
 int hvk_launch(hvk_engine_t *e, void *d_iq);
 
+/* As hvk_launch(), but frame i of the batch is written at frame position
+ * i * out_stride of d_iq (out_stride >= 1): a rank that renders every N-th
+ * frame writes straight into its slots of the interleaved stream buffer. */
+int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride);
+
+/* Run the engine on a caller's HIP stream (hipStream_t passed as void *),
+ * e.g. torch.cuda.current_stream().cuda_stream, so that its kernels order
+ * with the caller's work. NULL restores the engine's own stream. */
+int hvk_set_stream(hvk_engine_t *e, void *hip_stream);
+
 /* The host half on its own: run the audio-rate control path up to stream
  * position first + count and hand back the side streams for
  * [first, first + count) -- count int16 I/Q pairs of serial-carrier samples
