@@ -13,7 +13,8 @@
  *   pool       frame_slots x active_w x active_h x 4 B   source frames (RGBx)
  *   S          max_frames x (lines + 2) x width x 2 B    raster stream (int16 I)
  *   carriers   max_frames x frame_samples x 4 B          serial-carrier side stream
- *   symbols    max_frames x symbol_stride x 1 B          NICAM symbols
+ *   symtab     max_frames x symbol_stride x 4 B          NICAM symbols: start sample and value
+ *   tileinfo   max_frames x tiles x 8 B                  per filter tile: newest symbol, mixer position
  *   out        max_frames x frame_samples x 4 B          int16 I/Q (if the caller gives no buffer)
  */
 #include <hip/hip_runtime.h>
@@ -49,19 +50,23 @@ struct hvk_engine {
 	hipStream_t own_stream;
 
 	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_ntaps, *d_ncc;
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_ccb;
 	/* per batch */
 	uint32_t *d_pool;
 	hvk_framedesc_t *d_fdesc;
 	int16_t *d_S;
 	int16_t *d_car;
-	uint8_t *d_sym;
+	int32_t *d_sym;
+	int32_t *d_tile;
 	int16_t *d_out;
 
 	/* pinned staging */
 	hvk_framedesc_t *h_fdesc;
 	int16_t *h_car;
-	uint8_t *h_sym;
+	int32_t *h_sym;
+	int32_t *h_tile;
+	uint8_t *sym_tmp;
+	int tiles;
 	uint32_t *h_frame;
 
 	hvk_slot_t slots[HVK_FRAME_SLOTS];
@@ -170,8 +175,30 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	OPENCHK(_upload(&e->d_clut, e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len));
 	OPENCHK(_upload(&e->d_burst, e->t.burst_win, sizeof(int16_t) * k.burst_width));
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
-	OPENCHK(_upload(&e->d_ntaps, e->t.nicam_taps, sizeof(int16_t) * k.nicam_ntaps));
-	OPENCHK(_upload(&e->d_ncc, e->t.nicam_cc, sizeof(hvk_c16_t) * k.nicam_cc_len));
+	if(k.has_nicam)
+	{
+		/* device forms of the NICAM tables: the pulse with each tap in both
+		 * halves of a dword behind HVK_NICAM_LEAD zeros and zero padded, so a
+		 * packed multiply-add shapes I and Q at once and no bounds test is
+		 * needed; the mixer as the two rows of the rotation matrix,
+		 * (i, -q) and (q, i), extended by 8 entries past the wrap */
+		std::vector<int> tapd(HVK_NICAM_TAPD, 0), cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
+		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
+		for(int i = 0; i < k.nicam_ntaps; i++)
+		{
+			const int v = e->t.nicam_taps[i];
+			tapd[HVK_NICAM_LEAD + i] = (v & 0xFFFF) | (v << 16);
+		}
+		for(int i = 0; i < k.nicam_cc_len + 8; i++)
+		{
+			const hvk_c16_t c = e->t.nicam_cc[i % k.nicam_cc_len];
+			cca[i] = ((int) c.i & 0xFFFF) | ((int) c.q << 16);
+			ccb[i] = ((int) c.q & 0xFFFF) | ((int) c.i << 16);
+		}
+		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * 4));
+		OPENCHK(_upload(&e->d_cca, cca.data(), cca.size() * 4));
+		OPENCHK(_upload(&e->d_ccb, ccb.data(), ccb.size() * 4));
+	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots));
@@ -190,8 +217,13 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	}
 	if(e->t.k.has_nicam)
 	{
-		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride));
-		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride, hipHostMallocDefault));
+		e->tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride * 4));
+		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride * 4, hipHostMallocDefault));
+		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * 8));
+		OPENHIP(hipHostMalloc((void **) &e->h_tile, (size_t) max_frames * e->tiles * 8, hipHostMallocDefault));
+		e->sym_tmp = (uint8_t *) malloc(e->symbol_stride);
+		if(!e->sym_tmp) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
 	for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) OPENHIP(hipEventCreate(&e->ev[i][j]));
@@ -210,13 +242,14 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_ntaps, e->d_ncc, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_out };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_frame };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
 
+	free(e->sym_tmp);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
 	free(e);
@@ -403,6 +436,8 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		f->vframe_y = (k.active_lines - f->fb_height) / 2;
 		f->fb_interlaced = s->interlaced;
 		f->fb_valid = s->valid;
+		f->parity = (int32_t) ((f->frame_index + 1) & 1);
+		f->clut_off0 = k.colour ? (uint32_t) (((uint64_t) f->frame_index * (uint64_t) FS) % k.clw) : 0;
 
 		if(e->audio)
 		{
@@ -410,26 +445,47 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 			int64_t k0 = 0;
 			int n = hvk_audio_generate(e->audio, m0, FS,
 				e->h_car ? e->h_car + (size_t) i * FS * 2 : NULL,
-				e->h_sym ? e->h_sym + (size_t) i * e->symbol_stride : NULL,
-				e->symbol_stride, &k0);
+				e->sym_tmp, e->symbol_stride, &k0);
 			if(n < 0) return(n);
 
 			if(k.has_nicam)
 			{
-				int64_t kf, start;
-				hvk_audio_symbol_info(e->audio, m0, &kf, &start);
-				f->nicam_kf = kf;
-				f->nicam_k0 = k0;
-				f->nicam_cc0 = m0 % k.nicam_cc_len;
-				f->nicam_rf = (int32_t) (m0 - start);
-				f->nicam_ph = (int32_t) ((kf * k.nicam_dsl) % k.nicam_decimation);
+				/* tabulate the symbol schedule for the frame (src/nicam728.c:398-407):
+				 * symbol k starts at sps * k - floor(k * dsl / decimation); entries are
+				 * (start relative to the frame's first sample) << 3 | valid << 2 | value */
+				int32_t *tab = e->h_sym + (size_t) i * e->symbol_stride;
+				int32_t *tile = e->h_tile + (size_t) i * e->tiles * 2;
+				int newest = 0;
+
+				for(int j = 0; j < e->symbol_stride; j++)
+				{
+					const int64_t kk = k0 + j;
+					if(j >= n || kk < 0 || e->sym_tmp[j] == 0xFF) { tab[j] = 0; continue; }
+					const int64_t start = (int64_t) k.nicam_sps * kk - (kk * k.nicam_dsl) / k.nicam_decimation - m0;
+					tab[j] = (int32_t) (start * 8) | 4 | (e->sym_tmp[j] & 3);
+				}
+
+				/* per tile: the newest symbol that has started by the tile's first
+				 * sample, and the mixer table position of that sample */
+				while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
+				for(int b = 0; b < e->tiles; b++)
+				{
+					const int64_t pos = (int64_t) b * HVK_TILE;
+					while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
+					tile[b * 2 + 0] = newest;
+					tile[b * 2 + 1] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
+				}
 			}
 		}
 	}
 
 	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_sym) HIPCHK(hipMemcpyAsync(e->d_sym, e->h_sym, (size_t) nframes * e->symbol_stride, hipMemcpyHostToDevice, e->stream));
+	if(e->h_sym)
+	{
+		HIPCHK(hipMemcpyAsync(e->d_sym, e->h_sym, (size_t) nframes * e->symbol_stride * 4, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * 8, hipMemcpyHostToDevice, e->stream));
+	}
 
 	e->staged = nframes;
 	return(HVK_OK);
@@ -482,10 +538,12 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.fdesc = e->d_fdesc;
 	fa.S = e->d_S;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
-	fa.symbols = e->d_sym;
+	fa.symtab = e->d_sym;
+	fa.tileinfo = e->d_tile;
 	fa.symbol_stride = e->symbol_stride;
-	fa.nicam_taps = (const int16_t *) e->d_ntaps;
-	fa.nicam_cc = (const hvk_c16_t *) e->d_ncc;
+	fa.nicam_tapd = (const int *) e->d_tapd;
+	fa.nicam_cca = (const int *) e->d_cca;
+	fa.nicam_ccb = (const int *) e->d_ccb;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;

@@ -17,6 +17,8 @@ extern "C" {
 #define HVK_SPL          8      /* samples per lane in both kernels */
 #define HVK_TILE         1024   /* samples per filter workgroup */
 #define HVK_MAX_VF_TAPS  64
+#define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
+#define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
 
 typedef struct { int16_t i, q; } hvk_c16_t;
 typedef struct { int32_t i, q; } hvk_c32_t;
@@ -85,13 +87,8 @@ typedef struct {
 	int32_t vframe_x, vframe_y;
 	int32_t fb_interlaced;
 	int32_t fb_valid;       /* 0: no pixels (black) */
-	/* NICAM bookkeeping for the audio-stream position m0 of the frame's
-	 * first output sample (frame_index * frame_samples + delay_lines * width) */
-	int64_t nicam_kf;       /* anchor: newest symbol that has started by m0 */
-	int64_t nicam_k0;       /* stream index of symbols[0] of this frame's slab */
-	int64_t nicam_cc0;      /* m0 mod nicam_cc_len */
-	int32_t nicam_rf;       /* m0 - start of the anchor symbol */
-	int32_t nicam_ph;       /* (nicam_kf * dsl) mod decimation */
+	uint32_t clut_off0;     /* colour table position of the frame's first line: (frame_index * lines * width) mod clw */
+	int32_t parity;         /* (frame number) & 1 with frames counted from 1: (frame_index + 1) & 1 */
 } hvk_framedesc_t;
 
 /* Host-built tables (hvk_tables.c) */

@@ -7,6 +7,7 @@
 #include "hvk_internal.h"
 
 #define HVK_CHROMA_LEAD 16   /* int16 of slack either side of a chroma channel in LDS */
+#define HVK_NICAM_TAPD  384  /* dwords of the duplicated, zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
  * live in SGPRs (wave-uniform operands of v_dot2c_i32_i16) */
@@ -35,10 +36,12 @@ typedef struct {
 	const hvk_framedesc_t *fdesc;
 	const int16_t *S;
 	const hvk_c16_t *carriers;
-	const uint8_t *symbols;
+	const int *symtab;          /* [nframes][symbol_stride] */
 	int symbol_stride;
-	const int16_t *nicam_taps;
-	const hvk_c16_t *nicam_cc;
+	const int *tileinfo;        /* [nframes][tiles][2] */
+	const int *nicam_tapd;      /* HVK_NICAM_TAPD dwords: (tap, tap), zero padded */
+	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
+	const int *nicam_ccb;       /* nicam_cc_len + 8 dwords: (cc.q,  cc.i) */
 	int16_t *iq;
 	int nframes;
 	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */

@@ -37,6 +37,9 @@ typedef short  short2v __attribute__((ext_vector_type(2)));
 typedef short  short4v __attribute__((ext_vector_type(4)));
 typedef int    int4v   __attribute__((ext_vector_type(4)));
 typedef int    int2v   __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+/* four dwords that are only dword aligned: global_load_dwordx4 needs no more */
+typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 
 #define SPL HVK_SPL
 
@@ -48,6 +51,8 @@ __device__ __forceinline__ int dot2(int a, int b, int c)
 }
 /* (lo >> 16) | (hi << 16): the pair of int16 that starts one element later */
 __device__ __forceinline__ int shift_pair(int lo, int hi) { return((int) __builtin_amdgcn_alignbit((unsigned) hi, (unsigned) lo, 16)); }
+/* (sat16(lo) & 0xFFFF) | (sat16(hi) << 16) */
+__device__ __forceinline__ int sat_pack16(int lo, int hi) { return(__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(lo, hi))); }
 __device__ __forceinline__ int floordiv(int a, int b) { int q = a / b; return((a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q); }
 
 /* 8 consecutive FIR outputs from a register window of packed int16 pairs.
@@ -116,10 +121,11 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 
 /* ------------------------------------------------------------------ */
 
-/* LDS layout of the raster kernel: U and V channel arrays of
- * HVK_CHROMA_LEAD + width + HVK_CHROMA_LEAD int16 each. Element index
- * j <-> sample x = j - h (h = ntaps / 2), so a lane's FIR window starts at
- * its own first sample index: 16-byte aligned. */
+/* LDS layout of the raster kernel (int16 elements):
+ *   Y  [YL]  luma of the picture part of the line, index = sample x
+ *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
+ *   V  [CL]  a lane's FIR window starts at its own first sample index
+ * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
 template<int NT>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
@@ -136,16 +142,22 @@ void hvk_k_raster(const hvk_kconst_t k,
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
 
+	constexpr int H = NT / 2;
 	const int W = k.width;
 	const int t = threadIdx.x;
+	const int nth = blockDim.x;
 	const int x0 = t * SPL;
 	const hvk_framedesc_t &f = fdesc[blockIdx.y];
-	const int64_t g = f.frame_index * k.lines + (int) blockIdx.x - 1;   /* global line */
+	const int rel = (int) blockIdx.x - 1;       /* line of the frame, -1 and `lines` are the halo lines */
 	int16_t *out = S + ((size_t) blockIdx.y * (k.lines + 2) + blockIdx.x) * W;
 
-	int s[SPL];
+	/* which line of which frame, without dividing the global line number */
+	int line0 = rel, par = f.parity;
+	bool own = true;
+	if(rel < 0) { line0 = k.lines - 1; par ^= 1; own = false; }
+	else if(rel >= k.lines) { line0 = 0; par ^= 1; own = false; }
 
-	if(g < 0)
+	if(rel < 0 && f.frame_index == 0)
 	{
 		/* before the stream: the filter history is zero, not blanking
 		 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
@@ -153,11 +165,64 @@ void hvk_k_raster(const hvk_kconst_t k,
 		return;
 	}
 
-	const int64_t frame0 = g / k.lines;
-	const int line0 = (int) (g - frame0 * k.lines);
-	const hvk_linedesc_t d = desc[((frame0 + 1) & 1) * k.lines + line0];
-	const bool own = frame0 == f.frame_index;   /* halo lines carry no picture */
+	const hvk_linedesc_t d = desc[par * k.lines + line0];
+	const int pal = k.colour ? d.pal : 0;
 
+	const int YL = (W + 8 + 7) & ~7;
+	const int CL = (W + 2 * HVK_CHROMA_LEAD + 7) & ~7;
+	int16_t *Yb = lds, *U = lds + YL, *V = lds + YL + CL;
+
+	/* ---- picture: one pixel per lane per pass, coalesced row reads ---- */
+	int vy = d.src_row;
+	if(vy >= 0 && k.interlaced != 0 && f.fb_interlaced != k.interlaced) vy += 1;
+	vy -= f.vframe_y;
+	if(vy < 0 || vy >= f.fb_height || !own || !f.fb_valid) vy = -1;
+
+	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
+	const bool active = d.ar > d.al;
+	const bool has_pix = active && vy >= 0;
+	int ax0 = d.al > px0 ? d.al : px0;                          /* samples that show a source pixel */
+	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
+	if(!has_pix) ax1 = ax0 = 0;
+
+	if(pal)
+	{
+		/* clear both chroma channels; then the samples the reference reads past
+		 * the end of its buffer */
+		for(int j = t * 8; j < 2 * CL; j += nth * 8) *(int4v *) (U + j) = (int4v) { 0, 0, 0, 0 };
+		__syncthreads();
+		if(t < H)
+		{
+			U[H + W + t] = ghost[2 * t + 0];
+			V[H + W + t] = ghost[2 * t + 1];
+		}
+	}
+
+	if(has_pix)
+	{
+		const uint32_t *row = pool + f.fb_offset + (int64_t) vy * f.line_stride;
+		for(int x = ax0 + t; x < ax1; x += nth)
+		{
+			const uint32_t rgb = row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu;
+			const short4v c = yuv[rgb];
+			Yb[x] = c.x;
+			if(pal)
+			{
+				U[H + x] = c.y;
+				V[H + x] = c.z;
+			}
+		}
+	}
+
+	if(pal || has_pix) __syncthreads();
+
+	if(x0 >= W) return;
+
+	/* ---- 8 consecutive samples per lane ---- */
+	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
+	const int wx0 = __builtin_amdgcn_readfirstlane(x0);
+	const int wx1 = wx0 + 64 * SPL;
+	int s[SPL];
 #pragma unroll
 	for(int i = 0; i < SPL; i++) s[i] = k.blanking;
 
@@ -173,6 +238,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			const int off = k.pulse_offset[id] + (p == 2 ? W : 0);
 			const int len = k.pulse_length[id];
 			const int16_t *v = pulses + k.pulse_start[id];
+			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
 			if(x0 + SPL <= off || x0 >= off + len) continue;
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
@@ -185,107 +251,102 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	const int pal = k.colour ? d.pal : 0;
-	constexpr int H = NT / 2;
-	const int CL = W + 2 * HVK_CHROMA_LEAD;     /* channel length in LDS */
-	int16_t *U = lds, *V = lds + CL;
-
-	if(pal)
+	/* luma is assigned over whatever is there (src/video.c:2961-3009):
+	 * the picture where the frame covers the line, black elsewhere */
+	if(active && x0 < d.ar && x0 + SPL > d.al)
 	{
-		/* clear both channels, then place the samples the reference reads
-		 * past the end of its buffer */
-		for(int j = t * 8; j < 2 * CL; j += blockDim.x * 8) *(int4v *) (lds + j) = (int4v) { 0, 0, 0, 0 };
-		__syncthreads();
-		if(t < H)
+		if(x0 >= ax0 && x0 + SPL <= ax1)
 		{
-			U[H + W + t] = ghost[2 * t + 0];
-			V[H + W + t] = ghost[2 * t + 1];
+			const int4v y = *(const int4v *) (Yb + x0);
+			s[0] = (int) (short) (y.x & 0xFFFF); s[1] = y.x >> 16;
+			s[2] = (int) (short) (y.y & 0xFFFF); s[3] = y.y >> 16;
+			s[4] = (int) (short) (y.z & 0xFFFF); s[5] = y.z >> 16;
+			s[6] = (int) (short) (y.w & 0xFFFF); s[7] = y.w >> 16;
 		}
-	}
-
-	/* active picture: luma is assigned over whatever is there (src/video.c:2961-3009) */
-	if(d.ar > d.al && x0 < d.ar && x0 + SPL > d.al)
-	{
-		int vy = d.src_row;
-		if(vy >= 0 && k.interlaced != 0 && f.fb_interlaced != k.interlaced) vy += 1;
-		vy -= f.vframe_y;
-		if(vy < 0 || vy >= f.fb_height || !own || !f.fb_valid) vy = -1;
-
-		const uint32_t *row = pool + f.fb_offset + (int64_t) vy * f.line_stride;
-		const int px0 = k.active_left + f.vframe_x;
-
-#pragma unroll
-		for(int i = 0; i < SPL; i++)
+		else
 		{
-			const int x = x0 + i;
-			if(x < d.al || x >= d.ar) continue;
-			const int px = x - px0;
-			if(px >= 0 && px < f.fb_width)
-			{
-				const uint32_t rgb = vy >= 0 ? (row[(int64_t) px * f.pixel_stride] & 0xFFFFFFu) : 0u;
-				const short4v c = yuv[rgb];
-				s[i] = c.x;
-				if(pal)
-				{
-					U[H + x] = c.y;
-					V[H + x] = c.z;
-				}
-			}
-			else s[i] = k.black_y;
-		}
-	}
-
-	if(pal)
-	{
-		__syncthreads();
-
-		if(x0 < W)
-		{
-			int u[SPL], v[SPL];
-
-			/* zero-history low pass of both channels (src/fir.c:357-375) */
-			{
-				constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
-				int du[ND], dv[ND];
-				const int *pu = (const int *) (U + x0), *pv = (const int *) (V + x0);
-#pragma unroll
-				for(int m = 0; m < ND; m++) { du[m] = pu[m]; dv[m] = pv[m]; }
-				fir8<NT, 0>(du, ctaps.p, u);
-				fir8<NT, 0>(dv, ctaps.p, v);
-#pragma unroll
-				for(int i = 0; i < SPL; i++) { u[i] = clamp16(u[i] >> 15); v[i] = clamp16(v[i] >> 15); }
-			}
-
-			/* colour burst replaces the filtered samples (src/video.c:3024-3029) */
-			if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
-			{
-#pragma unroll
-				for(int i = 0; i < SPL; i++)
-				{
-					const int b = x0 + i - k.burst_left;
-					if(b >= 0 && b < k.burst_width)
-					{
-						const int w = burst_win[b];
-						u[i] = wrap16((k.burst_i * w) >> 15);
-						v[i] = wrap16((k.burst_q * w) >> 15);
-					}
-				}
-			}
-
-			/* quadrature modulation onto the sub-carrier (src/video.c:3032-3040);
-			 * the table position advances by one line per line, colour or not */
-			const unsigned coff = (unsigned) (((uint64_t) g * (uint64_t) W) % k.clw);
-			const int *cl = clut + coff + x0;
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
 			{
-				if(x0 + i < W)
+				const int x = x0 + i;
+				if(x >= d.al && x < d.ar) s[i] = (x >= ax0 && x < ax1) ? (int) Yb[x] : k.black_y;
+			}
+		}
+	}
+
+	if(pal)
+	{
+		int u[SPL], v[SPL];
+
+		/* zero-history low pass of both channels (src/fir.c:357-375). All-zero
+		 * input (no picture on this line) only matters where the ghost samples reach. */
+		if(has_pix || x0 + SPL + H > W)
+		{
+			constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
+			int du[ND], dv[ND];
+			const int4v *pu = (const int4v *) (U + x0), *pv = (const int4v *) (V + x0);
+#pragma unroll
+			for(int m = 0; m < (ND + 3) / 4; m++)
+			{
+				const int4v a = pu[m], b = pv[m];
+				if(m * 4 + 0 < ND) { du[m * 4 + 0] = a.x; dv[m * 4 + 0] = b.x; }
+				if(m * 4 + 1 < ND) { du[m * 4 + 1] = a.y; dv[m * 4 + 1] = b.y; }
+				if(m * 4 + 2 < ND) { du[m * 4 + 2] = a.z; dv[m * 4 + 2] = b.z; }
+				if(m * 4 + 3 < ND) { du[m * 4 + 3] = a.w; dv[m * 4 + 3] = b.w; }
+			}
+			fir8<NT, 0>(du, ctaps.p, u);
+			fir8<NT, 0>(dv, ctaps.p, v);
+#pragma unroll
+			for(int i = 0; i < SPL; i++) { u[i] = clamp16(u[i] >> 15); v[i] = clamp16(v[i] >> 15); }
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) u[i] = v[i] = 0;
+		}
+
+		/* colour burst replaces the filtered samples (src/video.c:3024-3029) */
+		if(wx1 > k.burst_left && wx0 < k.burst_left + k.burst_width)
+		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int b = x0 + i - k.burst_left;
+				if(b >= 0 && b < k.burst_width)
 				{
-					const int c = cl[i];
-					const int ci = (int) (short) (c & 0xFFFF), cq = c >> 16;
-					s[i] = wrap16(s[i] + ((ci * v[i] * pal + cq * u[i]) >> 15));
+					const int w = burst_win[b];
+					u[i] = wrap16((k.burst_i * w) >> 15);
+					v[i] = wrap16((k.burst_q * w) >> 15);
 				}
 			}
+		}
+
+		/* quadrature modulation onto the sub-carrier (src/video.c:3032-3040):
+		 *   s += (lut.i * V * pal + lut.q * U) >> 15
+		 * as one dot2 of the packed table entry (i, q) with (V, U); the PAL switch
+		 * negates lut.i, which never is -32768. The table position advances by one
+		 * line per line, colour or not: position of this line relative to the frame's. */
+		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
+		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
+		const int *cl = clut + coff + x0;
+		int c[SPL];
+		if(x0 + SPL <= W)
+		{
+			const int4u a = ((const int4u *) cl)[0], b = ((const int4u *) cl)[1];
+			c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) c[i] = (x0 + i < W) ? cl[i] : 0;
+		}
+#pragma unroll
+		for(int i = 0; i < SPL; i++)
+		{
+			const int ce = pal < 0 ? ((c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF)) : c[i];
+			const int vu = (v[i] & 0xFFFF) | (u[i] << 16);
+			s[i] = wrap16(s[i] + (dot2(ce, vu, 0) >> 15));
 		}
 	}
 
@@ -296,12 +357,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		o.y = (s[2] & 0xFFFF) | (s[3] << 16);
 		o.z = (s[4] & 0xFFFF) | (s[5] << 16);
 		o.w = (s[6] & 0xFFFF) | (s[7] << 16);
-		if((((size_t) (out + x0)) & 15) == 0) *(int4v *) (out + x0) = o;
-		else
-		{
-			int *q = (int *) (out + x0);
-			q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = o.w;
-		}
+		*(int4u *) (out + x0) = (int4u) { o.x, o.y, o.z, o.w };
 	}
 	else
 	{
@@ -311,12 +367,16 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 /* ------------------------------------------------------------------ */
 
-/* Start of symbol j relative to the frame's anchor symbol:
- * sps * j - floor((ph + j * dsl) / decimation)   (src/nicam728.c:400-407) */
-__device__ __forceinline__ int nicam_rel_start(const hvk_kconst_t &k, int ph, int j)
+__device__ __forceinline__ int pk_add16(int a, int b)
 {
-	return(k.nicam_sps * j - floordiv(ph + j * k.nicam_dsl, k.nicam_decimation));
+	return(__builtin_bit_cast(int, (ushort2v) (__builtin_bit_cast(ushort2v, a) + __builtin_bit_cast(ushort2v, b))));
 }
+__device__ __forceinline__ int pk_mad16(int a, int b, int c)
+{
+	return(__builtin_bit_cast(int, (ushort2v) (__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b) + __builtin_bit_cast(ushort2v, c))));
+}
+
+#define HVK_NICAM_SYMS 48   /* symbol table slots per tile */
 
 template<int NT, int VF>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL)
@@ -326,10 +386,12 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_framedesc_t *__restrict__ fdesc,
                   const int16_t *__restrict__ S,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
-                  const uint8_t *__restrict__ symbols,   /* [frames][symbol_stride] */
+                  const int *__restrict__ symtab,        /* [frames][symbol_stride]: (start << 3) | valid << 2 | dsym */
                   const int symbol_stride,
-                  const int16_t *__restrict__ nicam_taps,
-                  const int *__restrict__ nicam_cc,
+                  const int2v *__restrict__ tileinfo,    /* [frames][tiles]: { newest symbol at the tile's first sample, mixer position } */
+                  const int *__restrict__ nicam_tapd,    /* pulse taps, each duplicated into both halves of a dword, zero padded */
+                  const int *__restrict__ nicam_cca,     /* mixer phasors (i, q), 8 entries past the wrap */
+                  const int *__restrict__ nicam_ccb,     /* unused */
                   int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
                   const int64_t out_stride)
 {
@@ -337,14 +399,15 @@ void hvk_k_filter(const hvk_kconst_t k,
 	constexpr int LEAD = H + (H & 1);           /* window lead, even */
 	constexpr int NWIN = HVK_TILE + 2 * LEAD + 16;
 	__shared__ __attribute__((aligned(16))) int16_t win[NWIN];
-	__shared__ __attribute__((aligned(16))) int16_t ntaps_lds[256];
+	__shared__ __attribute__((aligned(16))) int tapd[HVK_NICAM_TAPD];
+	__shared__ int sym_st[HVK_NICAM_SYMS];
+	__shared__ int sym_sg[HVK_NICAM_SYMS];
 
 	const int W = k.width;
 	const int FS = k.frame_samples;
 	const int t = threadIdx.x;
 	const int n0 = blockIdx.x * HVK_TILE;       /* first output sample of the tile, frame local */
 	const int x0 = t * SPL;
-	const hvk_framedesc_t &f = fdesc[blockIdx.y];
 	const int16_t *slab = S + (size_t) blockIdx.y * (k.lines + 2) * W + W;   /* frame local sample 0 */
 
 	/* stage raster samples [n0 - LEAD, n0 + TILE + LEAD) as dwords; the slab
@@ -355,18 +418,44 @@ void hvk_k_filter(const hvk_kconst_t k,
 		const int limit = (FS + W - (n0 - LEAD)) / 2;         /* dwords available in the slab */
 		for(int q = t; q < NWIN / 2; q += blockDim.x) ((int *) win)[q] = q < limit ? src[q] : 0;
 	}
-	if(k.has_nicam) for(int q = t; q < k.nicam_ntaps; q += blockDim.x) ntaps_lds[q] = nicam_taps[q];
+
+	int cc_tile = 0;
+	if(k.has_nicam)
+	{
+		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) tapd[q] = nicam_tapd[q];
+
+		/* the symbols whose pulses can touch this tile, oldest first: start
+		 * (relative to the tile's first sample) and sign pair. The schedule
+		 * (src/nicam728.c:398-407) is tabulated per frame by the host. */
+		const int2v ti = tileinfo[(size_t) blockIdx.y * gridDim.x + blockIdx.x];
+		const int first = ti.x - (HVK_NICAM_BACK - 1);              /* slab index of the oldest symbol of interest */
+		const int *tab = symtab + (size_t) blockIdx.y * symbol_stride;
+		cc_tile = ti.y;
+		if(t < HVK_NICAM_SYMS)
+		{
+			const int i = first + t;
+			const int v = (i >= 0 && i < symbol_stride) ? tab[i] : 0;
+			const int st = (v >> 3) - n0;
+			const bool valid = (v & 4) && st < HVK_TILE;
+			/* constellation { 0, 1, 3, 2 }: bit 0 -> +I else -I, bit 1 -> +Q else -Q
+			 * (src/nicam728.c:33, :386-396) */
+			const int cs = (0x2310 >> ((v & 3) * 4)) & 3;
+			sym_st[t] = valid ? st : 0x3FFFFFFF;
+			sym_sg[t] = valid ? (((cs & 1) ? 0x0001 : 0xFFFF) | ((cs & 2) ? 0x00010000 : 0xFFFF0000)) : 0;
+		}
+	}
 	__syncthreads();
 
 	const int n = n0 + x0;                      /* this lane's first output, frame local */
 	if(n >= FS) return;
 
-	int oi[SPL], oq[SPL];
+	int o[SPL];                                 /* packed (I, Q) int16 */
 
 	if(VF != 0)
 	{
 		constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
 		int d[ND];
+		int ai[SPL];
 		const int4v *p = (const int4v *) (win + x0);
 #pragma unroll
 		for(int m = 0; m < (ND + 3) / 4; m++)
@@ -380,20 +469,20 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 		/* output i is centred on window element LEAD + x0 + i: first tap at
 		 * element LEAD - H + x0 + i */
-		fir8<NT, LEAD - H>(d, itaps.p, oi);
-#pragma unroll
-		for(int i = 0; i < SPL; i++) oi[i] = clamp16(oi[i] >> 15);
+		fir8<NT, LEAD - H>(d, itaps.p, ai);
 
 		if(VF == 3)
 		{
-			fir8<NT, LEAD - H>(d, qtaps.p, oq);
+			/* >> 15 and clamp to int16 (src/fir.c:605-608): v_cvt_pk_i16_i32 saturates both halves */
+			int aq[SPL];
+			fir8<NT, LEAD - H>(d, qtaps.p, aq);
 #pragma unroll
-			for(int i = 0; i < SPL; i++) oq[i] = clamp16(oq[i] >> 15);
+			for(int i = 0; i < SPL; i++) o[i] = sat_pack16(ai[i] >> 15, aq[i] >> 15);
 		}
 		else
 		{
 #pragma unroll
-			for(int i = 0; i < SPL; i++) oq[i] = 0;
+			for(int i = 0; i < SPL; i++) o[i] = sat_pack16(ai[i] >> 15, 0);
 		}
 	}
 	else
@@ -401,103 +490,89 @@ void hvk_k_filter(const hvk_kconst_t k,
 		/* no filter: the raster goes straight to I, Q = 0 */
 		const int16_t *p = slab + n;
 #pragma unroll
-		for(int i = 0; i < SPL; i++) { oi[i] = (n + i < FS) ? p[i] : 0; oq[i] = 0; }
+		for(int i = 0; i < SPL; i++) o[i] = (n + i < FS) ? ((int) p[i] & 0xFFFF) : 0;
 	}
 
 	const size_t cbase = (size_t) blockIdx.y * FS + n;
 	const size_t obase = (size_t) blockIdx.y * out_stride * FS + n;
+	const bool whole = n + SPL <= FS;
 
-	/* serial carriers (FM / AM sound), computed on the host: a plain add
-	 * (src/video.c:3431-3432) */
+	/* serial carriers (FM / AM sound), computed on the host: a plain add of
+	 * int16 pairs with wrap-around (src/video.c:3431-3432) */
 	if(k.has_carriers)
 	{
 		const int *c = carriers + cbase;
-#pragma unroll
-		for(int i = 0; i < SPL; i++)
+		if(whole)
 		{
-			if(n + i < FS)
-			{
-				const int v = c[i];
-				oi[i] = wrap16(oi[i] + (int) (short) (v & 0xFFFF));
-				oq[i] = wrap16(oq[i] + (v >> 16));
-			}
+			const int4u a = ((const int4u *) c)[0], b = ((const int4u *) c)[1];
+			o[0] = pk_add16(o[0], a.x); o[1] = pk_add16(o[1], a.y); o[2] = pk_add16(o[2], a.z); o[3] = pk_add16(o[3], a.w);
+			o[4] = pk_add16(o[4], b.x); o[5] = pk_add16(o[5], b.y); o[6] = pk_add16(o[6], b.z); o[7] = pk_add16(o[7], b.w);
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) if(n + i < FS) o[i] = pk_add16(o[i], c[i]);
 		}
 	}
 
-	/* NICAM: sum the pulses of the symbols in flight, mix, add
+	/* NICAM: sum the pulses of the symbols in flight (int16 wrap-around per
+	 * channel, both channels in one packed multiply-add), mix, add
 	 * (src/nicam728.c:350-365, :386-396) */
 	if(k.has_nicam)
 	{
-		const int r0 = f.nicam_rf + n;          /* position relative to the anchor symbol's start */
-		const int period = k.nicam_sps * k.nicam_decimation - k.nicam_dsl;
-		const int ph = f.nicam_ph;
-		const uint8_t *sym = symbols + (size_t) blockIdx.y * symbol_stride;
-		const int kbase = (int) (f.nicam_kf - f.nicam_k0);   /* slab index of the anchor symbol */
+		const int last = x0 + SPL - 1;          /* relative to the tile's first sample */
+		/* newest symbol that has started by this lane's last sample; slot
+		 * HVK_NICAM_BACK - 1 holds the newest one at the tile's first sample */
+		int idx = HVK_NICAM_BACK - 1 + (int) ((float) last * (1.0f / (float) k.nicam_sps));
+		if(idx > HVK_NICAM_SYMS - 2) idx = HVK_NICAM_SYMS - 2;
+		while(idx + 1 < HVK_NICAM_SYMS && sym_st[idx + 1] <= last) idx++;
+		while(idx > 0 && sym_st[idx] > last) idx--;
 
-		/* newest symbol that has started by this lane's last sample */
-		int j = (int) (((int64_t) (r0 + SPL - 1) * k.nicam_decimation) / period);
-		while(nicam_rel_start(k, ph, j + 1) <= r0 + SPL - 1) j++;
-		while(nicam_rel_start(k, ph, j) > r0 + SPL - 1) j--;
-
-		int bi[SPL], bq[SPL];
+		int bb[SPL];
 #pragma unroll
-		for(int i = 0; i < SPL; i++) bi[i] = bq[i] = 0;
+		for(int i = 0; i < SPL; i++) bb[i] = 0;
 
-		for(int back = 0; back < 7; back++)
+		for(int b = 0; b < HVK_NICAM_BACK; b++)
 		{
-			const int jj = j - back;
-			const int st = nicam_rel_start(k, ph, jj);
-			if(r0 + SPL - 1 - st < 0) continue;
-			if(r0 - st >= k.nicam_ntaps) break;
-			const int si = kbase + jj;
-			if(si < 0) break;
-			const unsigned sv = sym[si];
-			if(sv == 0xFF) break;               /* before the first symbol of the stream */
-			/* constellation { 0, 1, 3, 2 }: bit 0 -> I sign, bit 1 -> Q sign */
-			const int cs = (0x2310 >> (sv * 4)) & 3;
-			const int sgi = (cs & 1) ? 1 : -1, sgq = (cs & 2) ? 1 : -1;
+			const int ii = idx - b;
+			if(ii < 0) break;
+			if(sym_st[ii] > last) break;                            /* no symbol here (before the stream's first) */
+			const int base = x0 - sym_st[ii] + HVK_NICAM_LEAD;     /* >= 1: the symbol has started by `last` */
+			if(base >= HVK_NICAM_LEAD + k.nicam_ntaps) break;      /* pulse over before this lane's samples */
+			const int sg = sym_sg[ii];
+			const int *tp = tapd + base;
 #pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int idx = r0 + i - st;
-				if(idx >= 0 && idx < k.nicam_ntaps)
-				{
-					const int tp = ntaps_lds[idx];
-					bi[i] += sgi * tp;
-					bq[i] += sgq * tp;
-				}
-			}
+			for(int i = 0; i < SPL; i++) bb[i] = pk_mad16(tp[i], sg, bb[i]);
 		}
 
-		int cpos = (int) ((f.nicam_cc0 + (int64_t) n) % k.nicam_cc_len);
+		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
+		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
+		else cp %= k.nicam_cc_len;
+		/* mixer: one table of (i, q); (i, -q) and (q, i) are derived in registers */
+		const int4u c0 = ((const int4u *) (nicam_cca + cp))[0], c1 = ((const int4u *) (nicam_cca + cp))[1];
+		const int cc[SPL] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			const int c = nicam_cc[cpos];
-			const int ci = (int) (short) (c & 0xFFFF), cq = c >> 16;
-			const int b_i = wrap16(bi[i]), b_q = wrap16(bq[i]);
-			oi[i] = wrap16(oi[i] + ((b_i * ci - b_q * cq) >> 15));
-			oq[i] = wrap16(oq[i] + ((b_i * cq + b_q * ci) >> 15));
-			if(++cpos == k.nicam_cc_len) cpos = 0;
+			const int ca = (cc[i] & 0xFFFF) | ((0 - (cc[i] >> 16)) << 16);   /* q is never -32768 */
+			const int cq = shift_pair(cc[i], cc[i]);
+			const int mi = dot2(bb[i], ca, 0) >> 15;        /* bb.i * cc.i - bb.q * cc.q */
+			const int mq = dot2(bb[i], cq, 0) >> 15;        /* bb.i * cc.q + bb.q * cc.i */
+			o[i] = pk_add16(o[i], (mi & 0xFFFF) | (mq << 16));
 		}
 	}
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
-	int *o = iq + obase;
-	if(n + SPL <= FS && ((((size_t) o) & 15) == 0))
+	int *dst = iq + obase;
+	if(whole)
 	{
-		int4v a, b;
-		a.x = (oi[0] & 0xFFFF) | (oq[0] << 16); a.y = (oi[1] & 0xFFFF) | (oq[1] << 16);
-		a.z = (oi[2] & 0xFFFF) | (oq[2] << 16); a.w = (oi[3] & 0xFFFF) | (oq[3] << 16);
-		b.x = (oi[4] & 0xFFFF) | (oq[4] << 16); b.y = (oi[5] & 0xFFFF) | (oq[5] << 16);
-		b.z = (oi[6] & 0xFFFF) | (oq[6] << 16); b.w = (oi[7] & 0xFFFF) | (oq[7] << 16);
-		((int4v *) o)[0] = a;
-		((int4v *) o)[1] = b;
+		((int4u *) dst)[0] = (int4u) { o[0], o[1], o[2], o[3] };
+		((int4u *) dst)[1] = (int4u) { o[4], o[5], o[6], o[7] };
 	}
 	else
 	{
 #pragma unroll
-		for(int i = 0; i < SPL; i++) if(n + i < FS) o[i] = (oi[i] & 0xFFFF) | (oq[i] << 16);
+		for(int i = 0; i < SPL; i++) if(n + i < FS) dst[i] = o[i];
 	}
 }
 
@@ -517,7 +592,7 @@ static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
-	const size_t lds = (size_t) 2 * (W + 2 * HVK_CHROMA_LEAD) * sizeof(int16_t) + 64;
+	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
 	hipLaunchKernelGGL(hvk_k_raster<NT>, dim3(a->k.lines + 2, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S);
@@ -544,8 +619,8 @@ static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	hipLaunchKernelGGL((hvk_k_filter<NT, VF>), dim3(tiles, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
-	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->symbols,
-	                   a->symbol_stride, a->nicam_taps, (const int *) a->nicam_cc, (int *) a->iq, a->out_stride);
+	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->symtab,
+	                   a->symbol_stride, (const int2v *) a->tileinfo, a->nicam_tapd, a->nicam_cca, a->nicam_ccb, (int *) a->iq, a->out_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

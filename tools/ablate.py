@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""tools/ablate.py -- per-kernel time of the two kernels for configurations that
+switch stages off (HIP events on the launch stream). Run on the GPU box."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import hacktv_amd as H
+import util
+
+g = util.Golden()
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+cases = [("full: filter+fm+nicam", H.FLAG_FILTER), ("filter only (noaudio)", H.FLAG_FILTER | H.FLAG_NOAUDIO),
+         ("filter+fm (nonicam)", H.FLAG_FILTER | H.FLAG_NONICAM), ("audio only (no filter)", 0),
+         ("raster only", H.FLAG_NOAUDIO), ("mono + filter, noaudio", H.FLAG_FILTER | H.FLAG_NOAUDIO | H.FLAG_NOCOLOUR)]
+for name, flags in cases:
+    conf = H.preset("i", flags)
+    with H.Engine(conf, 16000000, device=0, max_frames=F) as e:
+        e.frame_upload(0, g.frame("i_full"))
+        while e.audio_needed(F) > 0:
+            e.audio_write(g.audio)
+        e.stage(0, 1, F)
+        for _ in range(2):
+            e.launch()
+        e.sync()
+        e.timing_enable(True)
+        for _ in range(10):
+            e.launch()
+        r, _ = e.timing_read(0)
+        f, _ = e.timing_read(1)
+        fs = e.info["frame_samples"]
+        print("%-28s raster %.4f ms  filter %.4f ms  -> %.1f Gsamples/s" % (name, r, f, F * fs / (r + f) / 1e6), flush=True)
