@@ -182,12 +182,13 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		 * packed multiply-add shapes I and Q at once and no bounds test is
 		 * needed; the mixer as the two rows of the rotation matrix,
 		 * (i, -q) and (q, i), extended by 8 entries past the wrap */
-		std::vector<int> tapd(HVK_NICAM_TAPD, 0), cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
+		std::vector<int> tapd(4 * HVK_NICAM_TAPD, 0), cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
 		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
 		for(int i = 0; i < k.nicam_ntaps; i++)
 		{
 			const int v = e->t.nicam_taps[i];
-			tapd[HVK_NICAM_LEAD + i] = (v & 0xFFFF) | (v << 16);
+			/* copy s holds entry j + s at position j */
+			for(int sft = 0; sft < 4; sft++) tapd[sft * HVK_NICAM_TAPD + HVK_NICAM_LEAD + i - sft] = (v & 0xFFFF) | (v << 16);
 		}
 		for(int i = 0; i < k.nicam_cc_len + 8; i++)
 		{

@@ -42,6 +42,7 @@ typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 
 #define SPL HVK_SPL
+#define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
 
 __device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
 __device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
@@ -185,6 +186,29 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
 	if(!has_pix) ax1 = ax0 = 0;
 
+	/* sub-carrier phasors of this lane's samples, fetched now so that the read is
+	 * in flight during the picture and filter phases. The table position advances
+	 * by one line per line, colour or not: position relative to the frame's. */
+	int c[SPL];
+#pragma unroll
+	for(int i = 0; i < SPL; i++) c[i] = 0;
+	if(pal && x0 < W)
+	{
+		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
+		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
+		const int *cl = clut + coff + x0;
+		if(x0 + SPL <= W)
+		{
+			const int4u a = ((const int4u *) cl)[0], b = ((const int4u *) cl)[1];
+			c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) c[i] = (x0 + i < W) ? cl[i] : 0;
+		}
+	}
+
 	if(pal)
 	{
 		/* clear both chroma channels; then the samples the reference reads past
@@ -200,16 +224,32 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(has_pix)
 	{
+		/* all row reads are issued before the first table look-up, all look-ups
+		 * before the first LDS write: the two dependent global loads per pixel are
+		 * paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width) */
 		const uint32_t *row = pool + f.fb_offset + (int64_t) vy * f.line_stride;
-		for(int x = ax0 + t; x < ax1; x += nth)
+		uint32_t rgb[HVK_PIX_PASSES];
+		short4v c[HVK_PIX_PASSES];
+#pragma unroll
+		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
-			const uint32_t rgb = row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu;
-			const short4v c = yuv[rgb];
-			Yb[x] = c.x;
-			if(pal)
+			const int x = ax0 + t + i * nth;
+			rgb[i] = x < ax1 ? (row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu) : 0u;
+		}
+#pragma unroll
+		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = yuv[rgb[i]];
+#pragma unroll
+		for(int i = 0; i < HVK_PIX_PASSES; i++)
+		{
+			const int x = ax0 + t + i * nth;
+			if(x < ax1)
 			{
-				U[H + x] = c.y;
-				V[H + x] = c.z;
+				Yb[x] = c[i].x;
+				if(pal)
+				{
+					U[H + x] = c[i].y;
+					V[H + x] = c[i].z;
+				}
 			}
 		}
 	}
@@ -325,22 +365,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		/* quadrature modulation onto the sub-carrier (src/video.c:3032-3040):
 		 *   s += (lut.i * V * pal + lut.q * U) >> 15
 		 * as one dot2 of the packed table entry (i, q) with (V, U); the PAL switch
-		 * negates lut.i, which never is -32768. The table position advances by one
-		 * line per line, colour or not: position of this line relative to the frame's. */
-		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
-		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
-		const int *cl = clut + coff + x0;
-		int c[SPL];
-		if(x0 + SPL <= W)
-		{
-			const int4u a = ((const int4u *) cl)[0], b = ((const int4u *) cl)[1];
-			c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-		}
-		else
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) c[i] = (x0 + i < W) ? cl[i] : 0;
-		}
+		 * negates lut.i, which never is -32768. */
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
@@ -399,7 +424,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	constexpr int LEAD = H + (H & 1);           /* window lead, even */
 	constexpr int NWIN = HVK_TILE + 2 * LEAD + 16;
 	__shared__ __attribute__((aligned(16))) int16_t win[NWIN];
-	__shared__ __attribute__((aligned(16))) int tapd[HVK_NICAM_TAPD];
+	__shared__ __attribute__((aligned(16))) int tapd[4 * HVK_NICAM_TAPD];
 	__shared__ int sym_st[HVK_NICAM_SYMS];
 	__shared__ int sym_sg[HVK_NICAM_SYMS];
 
@@ -416,13 +441,39 @@ void hvk_k_filter(const hvk_kconst_t k,
 	{
 		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
 		const int limit = (FS + W - (n0 - LEAD)) / 2;         /* dwords available in the slab */
-		for(int q = t; q < NWIN / 2; q += blockDim.x) ((int *) win)[q] = q < limit ? src[q] : 0;
+		constexpr int PASSES = (NWIN / 2 + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL);
+		int v[PASSES];
+#pragma unroll
+		for(int i = 0; i < PASSES; i++)
+		{
+			const int q = t + i * (HVK_TILE / HVK_SPL);
+			v[i] = (q < NWIN / 2 && q < limit) ? src[q] : 0;
+		}
+#pragma unroll
+		for(int i = 0; i < PASSES; i++)
+		{
+			const int q = t + i * (HVK_TILE / HVK_SPL);
+			if(q < NWIN / 2) ((int *) win)[q] = v[i];
+		}
+	}
+
+	/* the serial-carrier samples of this lane, fetched now so the read overlaps the filter */
+	const int nl = n0 + x0;
+	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
+	if(k.has_carriers && nl + SPL <= FS)
+	{
+		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
+		car0 = c[0];
+		car1 = c[1];
 	}
 
 	int cc_tile = 0;
 	if(k.has_nicam)
 	{
-		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) tapd[q] = nicam_tapd[q];
+		/* four copies of the pulse table, copy s shifted left by s entries, so that
+		 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts
+		 * instead of the 8-way of dword reads at a 32-byte lane stride) */
+		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
 
 		/* the symbols whose pulses can touch this tile, oldest first: start
 		 * (relative to the tile's first sample) and sign pair. The schedule
@@ -501,15 +552,14 @@ void hvk_k_filter(const hvk_kconst_t k,
 	 * int16 pairs with wrap-around (src/video.c:3431-3432) */
 	if(k.has_carriers)
 	{
-		const int *c = carriers + cbase;
 		if(whole)
 		{
-			const int4u a = ((const int4u *) c)[0], b = ((const int4u *) c)[1];
-			o[0] = pk_add16(o[0], a.x); o[1] = pk_add16(o[1], a.y); o[2] = pk_add16(o[2], a.z); o[3] = pk_add16(o[3], a.w);
-			o[4] = pk_add16(o[4], b.x); o[5] = pk_add16(o[5], b.y); o[6] = pk_add16(o[6], b.z); o[7] = pk_add16(o[7], b.w);
+			o[0] = pk_add16(o[0], car0.x); o[1] = pk_add16(o[1], car0.y); o[2] = pk_add16(o[2], car0.z); o[3] = pk_add16(o[3], car0.w);
+			o[4] = pk_add16(o[4], car1.x); o[5] = pk_add16(o[5], car1.y); o[6] = pk_add16(o[6], car1.z); o[7] = pk_add16(o[7], car1.w);
 		}
 		else
 		{
+			const int *c = carriers + cbase;
 #pragma unroll
 			for(int i = 0; i < SPL; i++) if(n + i < FS) o[i] = pk_add16(o[i], c[i]);
 		}
@@ -540,9 +590,12 @@ void hvk_k_filter(const hvk_kconst_t k,
 			const int base = x0 - sym_st[ii] + HVK_NICAM_LEAD;     /* >= 1: the symbol has started by `last` */
 			if(base >= HVK_NICAM_LEAD + k.nicam_ntaps) break;      /* pulse over before this lane's samples */
 			const int sg = sym_sg[ii];
-			const int *tp = tapd + base;
-#pragma unroll
-			for(int i = 0; i < SPL; i++) bb[i] = pk_mad16(tp[i], sg, bb[i]);
+			const int4v *tp = (const int4v *) (tapd + (base & 3) * HVK_NICAM_TAPD + (base & ~3));
+			const int4v ta = tp[0], tb = tp[1];
+			bb[0] = pk_mad16(ta.x, sg, bb[0]); bb[1] = pk_mad16(ta.y, sg, bb[1]);
+			bb[2] = pk_mad16(ta.z, sg, bb[2]); bb[3] = pk_mad16(ta.w, sg, bb[3]);
+			bb[4] = pk_mad16(tb.x, sg, bb[4]); bb[5] = pk_mad16(tb.y, sg, bb[5]);
+			bb[6] = pk_mad16(tb.z, sg, bb[6]); bb[7] = pk_mad16(tb.w, sg, bb[7]);
 		}
 
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
