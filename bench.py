@@ -103,6 +103,7 @@ def main():
     import torch
     import torch.distributed as dist
     import hacktv_amd as H
+    from hacktv_amd import sharding
     import util
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +136,7 @@ def main():
     e.frame_upload(0, g.frame("i_full"))
 
     # ---- stage the side inputs of this rank's block (untimed: inputs resident in HBM) ----
-    first_frame = rank * F          # block-cyclic: block b -> rank b mod N; the bench renders blocks 0..N-1
+    first_frame = sharding.first_frame_of(rank, N, 0, F)   # block-cyclic: block b -> rank b mod N; round 0
     t0 = time.perf_counter()
     while e.audio_needed(first_frame + F) > 0:
         e.audio_write(g.audio)
@@ -158,12 +159,7 @@ def main():
         if gather:
             # grouped ncclSend/ncclRecv: every peer sends its block straight into its
             # slot of the root's stream buffer, 7 peers -> 7 xGMI links at once
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, out[r], r) for r in range(1, N)]
-            else:
-                ops = [dist.P2POp(dist.isend, mine, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            sharding.gather_blocks(mine, out, rank, N)
 
     # ---- parity gate before any number: the first frame of the block against the reference digest ----
     step()

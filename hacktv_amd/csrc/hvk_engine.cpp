@@ -26,7 +26,8 @@
 #include "hvk_kernels.h"
 
 #define HVK_VERSION "hacktv-amd 0.1 (gfx950)"
-#define HVK_FRAME_SLOTS 4
+#define HVK_MIN_FRAME_SLOTS 4
+#define HVK_MAX_FRAME_SLOTS 256
 #define HVK_TIMING_SLOTS 512
 
 extern "C" {
@@ -69,7 +70,7 @@ struct hvk_engine {
 	int tiles;
 	uint32_t *h_frame;
 
-	hvk_slot_t slots[HVK_FRAME_SLOTS];
+	hvk_slot_t *slots;          /* [frame_slots] */
 	hvk_packed_taps_t ctaps, itaps, qtaps;
 
 	int64_t next_frame;
@@ -122,7 +123,11 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	if(!e) return(HVK_OUT_OF_MEMORY);
 	e->device = device;
 	e->max_frames = max_frames;
-	e->frame_slots = HVK_FRAME_SLOTS;
+	/* one source frame slot per frame of a batch, so a batch can show a different
+	 * picture on every frame (a static source needs only slot 0) */
+	e->frame_slots = max_frames < HVK_MIN_FRAME_SLOTS ? HVK_MIN_FRAME_SLOTS : (max_frames > HVK_MAX_FRAME_SLOTS ? HVK_MAX_FRAME_SLOTS : max_frames);
+	e->slots = (hvk_slot_t *) calloc(e->frame_slots, sizeof(hvk_slot_t));
+	if(!e->slots) { free(e); return(HVK_OUT_OF_MEMORY); }
 
 	if((r = hvk_tables_build(&e->t, conf, sample_rate)) != HVK_OK) { hvk_close(e); return(r); }
 
@@ -251,6 +256,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	}
 
 	free(e->sym_tmp);
+	free(e->slots);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
 	free(e);

@@ -316,14 +316,15 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(pal)
 	{
-		int u[SPL], v[SPL];
+		int vu[SPL];                            /* (V, U) packed int16: the dot2 operand of the modulator */
 
-		/* zero-history low pass of both channels (src/fir.c:357-375). All-zero
-		 * input (no picture on this line) only matters where the ghost samples reach. */
+		/* zero-history low pass of both channels (src/fir.c:357-375), >> 15 and
+		 * clamp by the saturating pack. All-zero input (no picture on this line)
+		 * only matters where the ghost samples reach. */
 		if(has_pix || x0 + SPL + H > W)
 		{
 			constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
-			int du[ND], dv[ND];
+			int du[ND], dv[ND], u[SPL], v[SPL];
 			const int4v *pu = (const int4v *) (U + x0), *pv = (const int4v *) (V + x0);
 #pragma unroll
 			for(int m = 0; m < (ND + 3) / 4; m++)
@@ -337,12 +338,12 @@ void hvk_k_raster(const hvk_kconst_t k,
 			fir8<NT, 0>(du, ctaps.p, u);
 			fir8<NT, 0>(dv, ctaps.p, v);
 #pragma unroll
-			for(int i = 0; i < SPL; i++) { u[i] = clamp16(u[i] >> 15); v[i] = clamp16(v[i] >> 15); }
+			for(int i = 0; i < SPL; i++) vu[i] = sat_pack16(v[i] >> 15, u[i] >> 15);
 		}
 		else
 		{
 #pragma unroll
-			for(int i = 0; i < SPL; i++) u[i] = v[i] = 0;
+			for(int i = 0; i < SPL; i++) vu[i] = 0;
 		}
 
 		/* colour burst replaces the filtered samples (src/video.c:3024-3029) */
@@ -356,8 +357,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 				if(b >= 0 && b < k.burst_width)
 				{
 					const int w = burst_win[b];
-					u[i] = wrap16((k.burst_i * w) >> 15);
-					v[i] = wrap16((k.burst_q * w) >> 15);
+					vu[i] = (((k.burst_q * w) >> 15) & 0xFFFF) | (((k.burst_i * w) >> 15) << 16);
 				}
 			}
 		}
@@ -366,13 +366,13 @@ void hvk_k_raster(const hvk_kconst_t k,
 		 *   s += (lut.i * V * pal + lut.q * U) >> 15
 		 * as one dot2 of the packed table entry (i, q) with (V, U); the PAL switch
 		 * negates lut.i, which never is -32768. */
-#pragma unroll
-		for(int i = 0; i < SPL; i++)
+		if(pal < 0)
 		{
-			const int ce = pal < 0 ? ((c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF)) : c[i];
-			const int vu = (v[i] & 0xFFFF) | (u[i] << 16);
-			s[i] = wrap16(s[i] + (dot2(ce, vu, 0) >> 15));
+#pragma unroll
+			for(int i = 0; i < SPL; i++) c[i] = (c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF);
 		}
+#pragma unroll
+		for(int i = 0; i < SPL; i++) s[i] = wrap16(s[i] + (dot2(c[i], vu[i], 0) >> 15));
 	}
 
 	if(x0 + SPL <= W)

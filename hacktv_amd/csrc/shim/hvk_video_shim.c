@@ -1,0 +1,301 @@
+/* hvk_video_shim.c -- the reference's video.h interface on top of libhvk.
+ *
+ * This file is what makes the MI355X engine a drop-in for the one hot path:
+ * it defines exactly the entry points the reference's main() calls
+ * (src/video.h:512-516; call sites src/hacktv.c:1440, :1446, :1581, :1599)
+ *
+ *     int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const vid_config_t *conf);
+ *     vid_line_t *vid_next_line(vid_t *s);
+ *     void vid_free(vid_t *s);
+ *     void vid_info(vid_t *s);
+ *     size_t vid_get_framebuffer_length(vid_t *s);
+ *
+ * with the reference's own types, so hacktv.c, av*.c and rf*.c compile and run
+ * unchanged. It is built AGAINST THE REFERENCE'S HEADERS (-I<reference>/src):
+ * nothing of the reference is copied here. INTEGRATION.md shows the two build
+ * recipes (replace video.c's engine entry points / link libhvk).
+ *
+ * Behaviour mirrored from the reference:
+ *  - vid_init() returns VID_OK / VID_ERROR / VID_OUT_OF_MEMORY and fills the
+ *    vid_t members main() reads afterwards: sample_rate, conf, active_width
+ *    (src/hacktv.c:1452, :1493, :1503-1518), plus width / levels for vid_info.
+ *  - video is pulled with av_eof / av_read_video at the start of every frame
+ *    (src/video.c:4873-4897), audio with av_read_audio as the 32 kHz tick needs
+ *    it (src/video.c:3278-3286); both from the calling thread.
+ *  - vid_next_line() hands out one scanline of interleaved int16 I/Q, valid
+ *    until the next call, with frame / line numbers starting at 1, and returns
+ *    NULL at the end of the source (src/video.c:4936-4952).
+ *  - configurations this engine does not render are REFUSED with VID_ERROR and
+ *    a message; nothing is silently dropped.
+ *
+ * Difference: frames are rendered HVK_BATCH at a time on the GPU (environment
+ * variable, default 4) and read back into a host buffer the lines point into.
+ * line->audio is always NULL (the file sink has no audio path).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "video.h"          /* the reference's */
+#include "hacktv_amd.h"
+
+typedef struct {
+	hvk_engine_t *e;
+	hvk_info_t info;
+	int batch;              /* frames per GPU launch */
+	int16_t *iq;            /* batch * frame_samples pairs */
+	int have;               /* frames rendered in iq */
+	int frame_in_batch;
+	int line;               /* next line of the current frame, 0-based */
+	int64_t frames_done;    /* frames handed out completely */
+	int ended;              /* source has ended: no more batches */
+	vid_line_t out;
+} shim_t;
+
+/* vid_t has no spare member; the engine handle rides in a pointer member the
+ * caller never touches (`processes` is private to the reference's video.c). */
+static shim_t *_shim(vid_t *s) { return((shim_t *) s->processes); }
+
+static int _refuse(const char *what)
+{
+	fprintf(stderr, "hacktv-amd: %s is not rendered by the MI355X engine (see DESIGN.md, scope)\n", what);
+	return(VID_ERROR);
+}
+
+static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sample_rate, unsigned int pixel_rate)
+{
+	memset(h, 0, sizeof(*h));
+
+	if(pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("--pixelrate (resampler)"));
+	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
+	if(c->modulation == VID_FM) return(_refuse("FM video"));
+	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC) return(_refuse("this colour mode"));
+	if(c->teletext || c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
+	   c->systercnr || c->acp || c->vits || c->vitc || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
+	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
+	if(c->offset != 0 || c->passthru || c->raw_bb_file || c->swap_iq || c->s_video) return(_refuse("offset / passthru / raw baseband / swap-iq / s-video"));
+	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
+	if(c->secam_field_id) return(_refuse("SECAM field id"));
+
+	h->output_type = c->output_type;
+	h->modulation = c->modulation;
+	h->video_bw = c->video_bw;
+	h->vsb_upper_bw = c->vsb_upper_bw;
+	h->vsb_lower_bw = c->vsb_lower_bw;
+	h->level = c->level;
+	h->video_level = c->video_level;
+	h->fm_mono_level = c->fm_mono_level;
+	h->am_audio_level = c->am_audio_level;
+	h->nicam_level = c->nicam_level;
+	h->type = c->type == VID_RASTER_625 ? HVK_RASTER_625 : HVK_RASTER_525;
+	h->frame_rate.num = c->frame_rate.num;
+	h->frame_rate.den = c->frame_rate.den;
+	h->lines = c->lines;
+	h->hline = c->hline;
+	h->interlaced = c->interlaced;
+	h->active_lines = c->active_lines;
+	h->hsync_width = c->hsync_width;
+	h->vsync_short_width = c->vsync_short_width;
+	h->vsync_long_width = c->vsync_long_width;
+	h->sync_rise = c->sync_rise;
+	h->invert_video = c->invert_video;
+	h->white_level = c->white_level;
+	h->black_level = c->black_level;
+	h->blanking_level = c->blanking_level;
+	h->sync_level = c->sync_level;
+	h->active_width = c->active_width;
+	h->active_left = c->active_left;
+	h->gamma = c->gamma;
+	h->rw_co = c->rw_co;
+	h->gw_co = c->gw_co;
+	h->bw_co = c->bw_co;
+	h->colour_mode = c->colour_mode == VID_PAL ? HVK_PAL : (c->colour_mode == VID_NTSC ? HVK_NTSC : HVK_MONOCHROME);
+	h->colour_carrier.num = c->colour_carrier.num;
+	h->colour_carrier.den = c->colour_carrier.den;
+	h->colour_bw = c->colour_bw;
+	h->burst_width = c->burst_width;
+	h->burst_left = c->burst_left;
+	h->burst_level = c->burst_level;
+	h->burst_rise = c->burst_rise;
+	h->ev_co = c->ev_co;
+	h->eu_co = c->eu_co;
+	h->volume = c->volume;
+	h->fm_mono_carrier = c->fm_mono_carrier;
+	h->fm_mono_deviation = c->fm_mono_deviation;
+	h->fm_mono_preemph = c->fm_mono_preemph;
+	h->nicam_carrier = c->nicam_carrier;
+	h->nicam_beta = c->nicam_beta;
+	h->am_mono_carrier = c->am_mono_carrier;
+	h->vfilter = c->vfilter;
+
+	return(VID_OK);
+}
+
+int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const vid_config_t * const conf)
+{
+	hvk_config_t hc;
+	shim_t *m;
+	const char *env;
+	int r, device = 0;
+
+	memset(s, 0, sizeof(vid_t));
+	s->conf = *conf;
+
+	if((r = _translate(&hc, conf, sample_rate, pixel_rate)) != VID_OK) return(r);
+
+	m = calloc(1, sizeof(shim_t));
+	if(!m) return(VID_OUT_OF_MEMORY);
+
+	m->batch = 4;
+	if((env = getenv("HVK_BATCH")) && atoi(env) > 0) m->batch = atoi(env);
+	if((env = getenv("HVK_DEVICE"))) device = atoi(env);
+
+	r = hvk_open(&m->e, &hc, sample_rate, device, m->batch);
+	if(r != HVK_OK)
+	{
+		free(m);
+		if(r == HVK_UNSUPPORTED) return(_refuse("this configuration"));
+		if(r == HVK_NO_DEVICE) fprintf(stderr, "hacktv-amd: no MI355X / HIP device; there is no CPU path\n");
+		return(r == HVK_OUT_OF_MEMORY ? VID_OUT_OF_MEMORY : VID_ERROR);
+	}
+
+	hvk_get_info(m->e, &m->info);
+
+	m->iq = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+	if(!m->iq)
+	{
+		hvk_close(m->e);
+		free(m);
+		return(VID_OUT_OF_MEMORY);
+	}
+
+	/* what main() and vid_info() read back (src/hacktv.c:1452-1518, src/video.c:4846-4860) */
+	if(s->conf.hline <= 0 && s->conf.interlaced != 0) s->conf.hline = (s->conf.lines + 1) / 2;
+	s->sample_rate = sample_rate;
+	s->pixel_rate = sample_rate;
+	s->width = m->info.width;
+	s->half_width = m->info.half_width;
+	s->max_width = m->info.width;
+	s->active_width = m->info.active_width;
+	s->active_left = m->info.active_left;
+	s->white_level = m->info.white_level;
+	s->black_level = m->info.black_level;
+	s->blanking_level = m->info.blanking_level;
+	s->sync_level = m->info.sync_level;
+	s->bframe = 1;
+	s->bline = 1;
+	s->processes = (void *) m;
+
+	return(VID_OK);
+}
+
+void vid_free(vid_t *s)
+{
+	shim_t *m = _shim(s);
+
+	av_close(&s->av);       /* src/video.c:4711 */
+
+	if(m)
+	{
+		hvk_close(m->e);
+		free(m->iq);
+		free(m);
+	}
+
+	memset(s, 0, sizeof(vid_t));
+}
+
+void vid_info(vid_t *s)
+{
+	/* same three lines as src/video.c:4846-4860 */
+	fprintf(stderr, "Video: %dx%d %.2f fps (full frame %dx%d)\n",
+		s->active_width, s->conf.active_lines,
+		(double) s->conf.frame_rate.num / s->conf.frame_rate.den,
+		s->width, s->conf.lines);
+	fprintf(stderr, "Sample rate: %d\n", s->sample_rate);
+	fprintf(stderr, "Engine: %s, %d frame(s) per launch\n", hvk_version(), _shim(s) ? _shim(s)->batch : 0);
+}
+
+size_t vid_get_framebuffer_length(vid_t *s)
+{
+	return(sizeof(uint32_t) * s->active_width * s->conf.active_lines);
+}
+
+/* Pull up to `batch` frames and the audio they need from the source, render them */
+static int _next_batch(vid_t *s, shim_t *m)
+{
+	int32_t slots[256];
+	int n = 0;
+
+	while(n < m->batch && n < 256)
+	{
+		av_frame_t f;
+
+		/* src/video.c:4873-4897: end of source is tested at the start of each frame */
+		if(av_eof(&s->av)) { m->ended = 1; break; }
+		av_read_video(&s->av, &f);
+
+		if(hvk_frame_upload(m->e, n, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
+		slots[n] = n;
+		n++;
+	}
+
+	if(n == 0) return(0);
+
+	/* 32 kHz audio for these frames (src/video.c:3278-3286); a source that runs dry
+	 * leaves silence (src/video.c:3299-3304) */
+	while(hvk_audio_needed(m->e, n) > 0)
+	{
+		int16_t *a = NULL;
+		size_t an = 0;
+		av_read_audio(&s->av, &a, &an);
+		if(a == NULL || an == 0) break;
+		if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+	}
+
+	if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);
+	if(hvk_fetch(m->e, m->iq, 0, (size_t) n * m->info.frame_samples) != HVK_OK) return(-1);
+
+	return(n);
+}
+
+vid_line_t *vid_next_line(vid_t *s)
+{
+	shim_t *m = _shim(s);
+	vid_line_t *l;
+
+	if(!m) return(NULL);
+
+	if(m->frame_in_batch >= m->have)
+	{
+		int n;
+		if(m->ended) return(NULL);
+		n = _next_batch(s, m);
+		if(n <= 0) return(NULL);
+		m->have = n;
+		m->frame_in_batch = 0;
+		m->line = 0;
+	}
+
+	l = &m->out;
+	l->output = m->iq + 2 * ((size_t) m->frame_in_batch * m->info.frame_samples + (size_t) m->line * m->info.width);
+	l->width = m->info.width;
+	l->frame = (int) (m->frames_done + 1);
+	l->line = m->line + 1;
+	l->lut = NULL;
+	l->vbialloc = 0;
+	l->audio = NULL;
+	l->audio_len = 0;
+	l->previous = l->next = l;
+
+	s->frame = l->frame;
+	s->line = l->line;
+
+	if(++m->line == m->info.lines)
+	{
+		m->line = 0;
+		m->frame_in_batch++;
+		m->frames_done++;
+	}
+
+	return(l);
+}

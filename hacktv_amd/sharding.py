@@ -1,0 +1,45 @@
+"""Frame sharding across ranks (one process per GPU) and reassembly of the
+contiguous IQ stream on the rank that feeds the rf_* sink.
+
+Whole frames are independent units. The stream is cut into
+blocks of `frames` frames; block b goes to rank b mod world ("block-cyclic"
+round-robin). After every rank has rendered its block of a round, the blocks are
+gathered to `root` with grouped point-to-point operations: every peer sends its
+block straight into its slot of the root's stream buffer, so on an xGMI node
+each peer uses its own link to the root; no ring.
+
+This module is transport plumbing over torch.distributed; it works with the
+`nccl` backend (RCCL on ROCm) on GPUs and with `gloo` on CPU tensors, which is
+how tests/test_sharding.py exercises it at world size 2."""
+import torch.distributed as dist
+
+
+def block_of(rank, world, round_index):
+    """Index of the block rank `rank` renders in round `round_index`."""
+    return round_index * world + rank
+
+
+def first_frame_of(rank, world, round_index, frames):
+    """First frame (0-based) of that block."""
+    return block_of(rank, world, round_index) * frames
+
+
+def gather_blocks(local, root_buf, rank, world, root=0, group=None):
+    """Reassemble one round of blocks on `root`.
+
+    local     1-D tensor holding this rank's rendered block
+    root_buf  on root: tensor [world, local.numel()], row r receives rank r's block
+              (root's own row may alias `local`, in which case nothing is copied)
+    Returns the list of work handles already waited on (empty for world == 1)."""
+    if world == 1:
+        return []
+    if rank == root:
+        if root_buf[root].data_ptr() != local.data_ptr():
+            root_buf[root].copy_(local)
+        ops = [dist.P2POp(dist.irecv, root_buf[r], r, group) for r in range(world) if r != root]
+    else:
+        ops = [dist.P2POp(dist.isend, local, root, group)]
+    works = dist.batch_isend_irecv(ops)
+    for w in works:
+        w.wait()
+    return works

@@ -191,3 +191,43 @@ def test_late_frames_audio_is_additive_and_position_exact(golden):
         nic = _nicam_from_symbols(h, sym, k0, m0, 2 * fs)
     diff = (with_audio - video.astype(np.int64) - car.astype(np.int64) - nic) % 65536
     assert not diff.any()
+
+
+def test_dropin_binary_equals_reference_cli(golden):
+    """the reference's own main(), av_test.c and rf_file.c, unmodified, linked
+    with the video.h shim + libhvk (oracle/_ref/hacktv_hvk), must write the same bytes as the
+    unmodified reference CLI. Compared through the committed digest of the reference's output
+    and, where the reference binary is present, directly."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hvk = os.path.join(root, "oracle", "_ref", "hacktv_hvk")
+    ref = os.path.join(root, "oracle", "_ref", "hacktv_ref")
+    if not os.path.exists(hvk):
+        pytest.skip("oracle/_ref/hacktv_hvk not built (needs /root/reference at build time)")
+
+    def run(binary, flags, nbytes):
+        env = dict(os.environ, HVK_BATCH="2")
+        p = subprocess.Popen([binary] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, env=env)
+        out = bytearray()
+        while len(out) < nbytes:
+            chunk = p.stdout.read(nbytes - len(out))
+            if not chunk:
+                break
+            out += chunk
+        p.kill()
+        p.wait()
+        return bytes(out)
+
+    for case in ("i_full", "pal_bb", "m_full"):
+        c = golden.cases[case]
+        fs = c["width"] * c["lines"]
+        bps = 2 if c["real"] else 4
+        nframes = 3
+        flags = ["-m", c["mode"], "-s", str(c["sample_rate"])] + c["cli_flags"]
+        got = run(hvk, flags, nframes * fs * bps)
+        assert len(got) == nframes * fs * bps, case
+        assert util.sha256(got[: 2 * fs * bps]) == c["sha256_cumulative"][1], case
+        if os.path.exists(ref):
+            assert got == run(ref, flags, nframes * fs * bps), case
