@@ -43,6 +43,11 @@ struct hvk_slot_t {
 struct hvk_engine {
 	hvk_tables_t t;
 	hvk_audio_t *audio;
+	hvk_secam_t *secam;
+	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
+	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
+	int16_t *d_chroma, *h_chroma;
+	hvk_packed_taps_t notch;
 	int device;             /* -1: host tables only */
 	int max_frames;
 	int frame_slots;
@@ -141,6 +146,14 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		if(!e->audio) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
+	if(e->t.k.secam)
+	{
+		e->secam = hvk_secam_new(&e->t);
+		e->host_frames = (uint32_t **) calloc(e->frame_slots, sizeof(uint32_t *));
+		if(!e->secam || !e->host_frames) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
+		_pack_taps(&e->notch, e->t.secam_notch, 51);
+	}
+
 	if(e->t.k.has_nicam)
 	{
 		e->symbol_stride = e->t.k.frame_samples / (e->t.k.nicam_sps - 1) + 32;
@@ -232,6 +245,13 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		if(!e->sym_tmp) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
+	if(e->t.k.secam)
+	{
+		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * FS * 2));
+		OPENHIP(hipMemset(e->d_chroma, 0, (size_t) max_frames * FS * 2));
+		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * FS * 2, hipHostMallocDefault));
+	}
+
 	for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) OPENHIP(hipEventCreate(&e->ev[i][j]));
 
 	OPENHIP(hipStreamSynchronize(e->stream));
@@ -248,14 +268,16 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
 
 	free(e->sym_tmp);
+	if(e->host_frames) { for(int i = 0; i < e->frame_slots; i++) free(e->host_frames[i]); free(e->host_frames); }
+	hvk_secam_free(e->secam);
 	free(e->slots);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
@@ -383,6 +405,13 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	if(e->secam)
+	{
+		/* the SECAM pre-pass reads the picture on the host */
+		if(!e->host_frames[slot]) e->host_frames[slot] = (uint32_t *) malloc(frame_px * 4);
+		if(!e->host_frames[slot]) return(HVK_OUT_OF_MEMORY);
+		memcpy(e->host_frames[slot], e->h_frame, (size_t) w * h * 4);
+	}
 	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, e->h_frame, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
 	return(HVK_OK);
@@ -409,6 +438,29 @@ extern "C" int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t cou
 	if(!e) return(HVK_ERROR);
 	if(!e->audio) return(0);
 	return(hvk_audio_generate(e->audio, first, count, carriers, symbols, max_symbols, k0));
+}
+
+extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int height, int interlaced, int16_t *out)
+{
+	if(!e || !out) return(HVK_ERROR);
+	if(!e->secam) return(HVK_UNSUPPORTED);
+
+	/* centre crop to the active area, dense copy (as hvk_frame_upload) */
+	const hvk_kconst_t &k = e->t.k;
+	int x = (width - k.active_width) / 2, y = (height - k.active_lines) / 2;
+	int w = k.active_width, h = k.active_lines;
+	if(x < 0) { w += x; x = 0; }
+	if(y < 0) { h += y; y = 0; }
+	if(x + w > width) w = width - x;
+	if(y + h > height) h = height - y;
+	if(!fb || w <= 0 || h <= 0) { w = h = 0; fb = NULL; }
+
+	std::vector<uint32_t> dense((size_t) w * h + 1);
+	for(int r = 0; r < h; r++) memcpy(dense.data() + (size_t) r * w, fb + (size_t) (y + r) * width + x, (size_t) w * 4);
+
+	int r = hvk_secam_frame(e->secam, e->secam_next, fb ? dense.data() : NULL, w, h, interlaced, out);
+	if(r == HVK_OK) e->secam_next++;
+	return(r);
 }
 
 /* ---- render ---- */
@@ -445,6 +497,16 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		f->fb_valid = s->valid;
 		f->parity = (int32_t) ((f->frame_index + 1) & 1);
 		f->clut_off0 = k.colour ? (uint32_t) (((uint64_t) f->frame_index * (uint64_t) FS) % k.clw) : 0;
+
+		if(e->secam)
+		{
+			/* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
+			if(f->frame_index != e->secam_next) return(HVK_UNSUPPORTED);
+			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
+			                        f->fb_width, f->fb_height, s->interlaced, e->h_chroma + (size_t) i * FS);
+			if(r != HVK_OK) return(r);
+			e->secam_next++;
+		}
 
 		if(e->audio)
 		{
@@ -487,6 +549,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	}
 
 	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
+	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * FS * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
 	{
@@ -526,6 +589,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	memset(&ra, 0, sizeof(ra));
 	ra.k = e->t.k;
 	ra.ctaps = e->ctaps;
+	ra.notch = e->notch;
+	ra.chroma = e->d_chroma;
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
 	ra.yuv = e->d_yuv;

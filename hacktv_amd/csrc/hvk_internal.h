@@ -76,6 +76,7 @@ typedef struct {
 	int32_t has_nicam;
 	int32_t nicam_ntaps, nicam_sps, nicam_dsl, nicam_decimation, nicam_cc_len;
 	int32_t frame_samples;
+	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
 } hvk_kconst_t;
 
 /* Per rendered frame */
@@ -113,12 +114,26 @@ typedef struct {
 	int16_t limiter_shape[21];
 	int32_t limiter_vtaps[65], limiter_ftaps[65];
 	int32_t has_limiter;
+	/* SECAM (src/video.c:4075-4162) */
+	int32_t secam_level;
+	hvk_c32_t *secam_lut;       /* 65536 FM steps at the pixel rate */
+	hvk_c16_t *secam_bell;      /* 65536 complex gains, indexed by the sample as uint16 */
+	int16_t *secam_fir;         /* 15 taps, applied order */
+	int16_t *secam_notch;       /* 51 taps, applied order */
+	int16_t secam_dmin[2], secam_dmax[2];
 } hvk_tables_t;
 
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate);
 void hvk_tables_free(hvk_tables_t *t);
 void hvk_tables_default_ghost(hvk_tables_t *t);
 long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes);
+
+/* Host SECAM colour pre-pass (hvk_secam.c) */
+typedef struct hvk_secam hvk_secam_t;
+hvk_secam_t *hvk_secam_new(const hvk_tables_t *t);
+void hvk_secam_free(hvk_secam_t *s);
+int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int fb_width, int fb_height,
+                    int fb_interlaced, int16_t *out);
 
 /* Host audio-rate control path (hvk_audio.c) */
 typedef struct hvk_audio hvk_audio_t;

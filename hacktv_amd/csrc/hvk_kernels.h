@@ -18,6 +18,8 @@ typedef struct {
 typedef struct {
 	hvk_kconst_t k;
 	hvk_packed_taps_t ctaps;
+	hvk_packed_taps_t notch;    /* SECAM luma notch */
+	const int16_t *chroma;      /* SECAM: [nframes][frame_samples] */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const void *yuv;            /* 2^24 x int16x4 */

@@ -105,8 +105,18 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 	v = (r - y) * p.ev;
 
 	y = (p.black + (y * p.range)) * p.level;
-	u *= p.chroma_scale;
-	v *= p.chroma_scale;
+	if(!p.secam)
+	{
+		u *= p.chroma_scale;
+		v *= p.chroma_scale;
+	}
+	else
+	{
+		/* frequency deviation of the D'b / D'r rest frequencies from the FM centre,
+		 * in units of the 1 MHz full scale (src/video.c:3951-3952, :45-48) */
+		u = (u + 4250000.0 - 4328125.0) / 1000000.0;
+		v = (v + 4406250.0 - 4328125.0) / 1000000.0;
+	}
 
 	y = y < -1 ? -1 : (y > 1 ? 1 : y);
 	u = u < -1 ? -1 : (u > 1 ? 1 : u);
@@ -127,10 +137,12 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
  *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
  *   V  [CL]  a lane's FIR window starts at its own first sample index
  * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
-template<int NT>
+template<int NT, int SECAM>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
+                  const hvk_packed_taps_t notch,        /* SECAM luma notch, 51 taps */
+                  const int16_t *__restrict__ chroma,   /* SECAM: [frames][frame_samples] values to add */
                   const hvk_linedesc_t *__restrict__ desc,
                   const int16_t *__restrict__ pulses,
                   const short4v *__restrict__ yuv,
@@ -256,7 +268,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(pal || has_pix) __syncthreads();
 
-	if(x0 >= W) return;
+	if(x0 >= W && !(SECAM && active)) return;
 
 	/* ---- 8 consecutive samples per lane ---- */
 	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
@@ -373,6 +385,65 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 #pragma unroll
 		for(int i = 0; i < SPL; i++) s[i] = wrap16(s[i] + (dot2(c[i], vu[i], 0) >> 15));
+	}
+
+	if(SECAM && active)
+	{
+		/* SECAM lines with picture (src/video.c:3202-3229): first the luma notch
+		 * over the active picture, a zero-history FIR whose input starts at
+		 * active_left (everything left of it counts as zero) and which looks 25
+		 * samples past the picture's right edge; then the sub-carrier, computed in
+		 * stream order by the host (hvk_secam.c), is added. */
+		constexpr int NH = 25, NLEAD = 26;
+		int16_t *Z = lds + YL;                  /* index j <-> sample x = j - NLEAD */
+
+		if(t < 4) *(int4v *) (Z + t * 8) = (int4v) { 0, 0, 0, 0 };   /* Z does not overlap the picture's luma in LDS */
+		{
+			int4v z;
+			int w[SPL];
+#pragma unroll
+			for(int i = 0; i < SPL; i++) w[i] = (x0 + i >= k.active_left) ? s[i] : 0;
+			z.x = (w[0] & 0xFFFF) | (w[1] << 16); z.y = (w[2] & 0xFFFF) | (w[3] << 16);
+			z.z = (w[4] & 0xFFFF) | (w[5] << 16); z.w = (w[6] & 0xFFFF) | (w[7] << 16);
+			*(int4u *) (Z + NLEAD + x0) = (int4u) { z.x, z.y, z.z, z.w };
+		}
+		/* windows that run past the line belong to outputs right of the picture, which are not kept */
+		__syncthreads();
+
+		if(x0 + SPL > k.active_left && x0 < k.active_left + k.active_width)
+		{
+			constexpr int ND = SPL / 2 + (51 + 1) / 2 + 1;
+			int dn[ND], a[SPL];
+			const int4v *pz = (const int4v *) (Z + x0);
+#pragma unroll
+			for(int m = 0; m < (ND + 3) / 4; m++)
+			{
+				const int4v v = pz[m];
+				if(m * 4 + 0 < ND) dn[m * 4 + 0] = v.x;
+				if(m * 4 + 1 < ND) dn[m * 4 + 1] = v.y;
+				if(m * 4 + 2 < ND) dn[m * 4 + 2] = v.z;
+				if(m * 4 + 3 < ND) dn[m * 4 + 3] = v.w;
+			}
+			fir8<51, NLEAD - NH>(dn, notch.p, a);
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int x = x0 + i;
+				if(x >= k.active_left && x < k.active_left + k.active_width) s[i] = clamp16(a[i] >> 15);
+			}
+		}
+
+		if(own && x0 + SPL <= W)
+		{
+			const int4u cv = *(const int4u *) (chroma + (size_t) blockIdx.y * k.frame_samples + (size_t) rel * W + x0);
+			const int cw[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int cs = (i & 1) ? (cw[i / 2] >> 16) : (int) (short) (cw[i / 2] & 0xFFFF);
+				s[i] = wrap16(s[i] + cs);
+			}
+		}
 	}
 
 	if(x0 + SPL <= W)
@@ -639,30 +710,31 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-template<int NT>
+template<int NT, int SECAM>
 static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL(hvk_k_raster<NT>, dim3(a->k.lines + 2, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3(a->k.lines + 2, a->nframes), dim3(threads), lds, stream,
+	                   a->k, a->ctaps, a->notch, a->chroma, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 {
+	if(a->k.secam) return(_launch_raster<1, 1>(a, stream));
 	switch(a->k.colour ? a->k.chroma_ntaps : 1)
 	{
-	case 1:  return(_launch_raster<1>(a, stream));   /* no chroma filter (taps = {32767}) or monochrome */
-	case 9:  return(_launch_raster<9>(a, stream));
-	case 11: return(_launch_raster<11>(a, stream));
-	case 13: return(_launch_raster<13>(a, stream));
-	case 15: return(_launch_raster<15>(a, stream));
-	case 17: return(_launch_raster<17>(a, stream));
-	case 21: return(_launch_raster<21>(a, stream));
+	case 1:  return(_launch_raster<1, 0>(a, stream));   /* monochrome */
+	case 9:  return(_launch_raster<9, 0>(a, stream));
+	case 11: return(_launch_raster<11, 0>(a, stream));
+	case 13: return(_launch_raster<13, 0>(a, stream));
+	case 15: return(_launch_raster<15, 0>(a, stream));
+	case 17: return(_launch_raster<17, 0>(a, stream));
+	case 21: return(_launch_raster<21, 0>(a, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

@@ -149,6 +149,8 @@ static int _build_linedesc(hvk_tables_t *t)
 	return(HVK_OK);
 }
 
+static hvk_c32_t _unit_phasor(double radians);
+
 /* ------------------------------------------------------------------ */
 /* FIR designers                                                       */
 
@@ -432,6 +434,107 @@ static int _build_audio(hvk_tables_t *t, double slevel)
 }
 
 /* ------------------------------------------------------------------ */
+/* SECAM                                                               */
+
+/* Kaiser-windowed band stop with unity DC gain (src/fir.c:179-228) */
+static void _design_band_reject(double *taps, int ntaps, double sample_rate, double low, double high)
+{
+	const double beta = 7.0;
+	double inv_i0 = 1.0 / _bessel_i0(beta);
+	double inm1 = 1.0 / ((double) (ntaps - 1));
+	double w0 = 2.0 * M_PI * low / sample_rate, w1 = 2.0 * M_PI * high / sample_rate;
+	double dc, gain = 1.0;
+	int M = (ntaps - 1) / 2, i, n;
+
+	taps[0] = taps[ntaps - 1] = inv_i0;
+	for(i = 1; i < ntaps - 1; i++)
+	{
+		double temp = 2 * i * inm1 - 1;
+		taps[i] = _bessel_i0(beta * sqrt(1.0 - temp * temp)) * inv_i0;
+	}
+
+	for(n = -M; n <= M; n++)
+	{
+		if(n == 0) taps[n + M] *= 1.0 + (w0 - w1) / M_PI;
+		else taps[n + M] *= (sin(n * w0) - sin(n * w1)) / (n * M_PI);
+	}
+
+	dc = taps[M];
+	for(n = 1; n <= M; n++) dc += 2 * taps[n + M];
+
+	gain /= dc;
+	for(n = 0; n < ntaps; n++) taps[n] *= gain;
+}
+
+static int _build_secam(hvk_tables_t *t, double level)
+{
+	const hvk_config_t *c = &t->conf;
+	const double fm_dev = 1000e3, fm_freq = 4328125, cb = 4250000, cr = 4406250;   /* src/video.c:45-48 */
+	double amp = (c->white_level - c->blanking_level) * level;
+	double taps[51], sum, rise;
+	int r, i;
+
+	t->k.secam = 1;
+
+	/* FM steps at the pixel rate, +/- 1 MHz full scale (src/video.c:4080, :2218-2243) */
+	t->secam_level = (int16_t) round(INT16_MAX * amp);
+	t->secam_lut = malloc(sizeof(hvk_c32_t) * 65536);
+	t->secam_bell = malloc(sizeof(hvk_c16_t) * 65536);
+	if(!t->secam_lut || !t->secam_bell) return(HVK_OUT_OF_MEMORY);
+
+	for(r = INT16_MIN; r <= INT16_MAX; r++)
+	{
+		double d = 2.0 * M_PI / t->sample_rate * (fm_freq + (double) r / INT16_MAX * fm_dev);
+		double f, lq, rq, den;
+
+		t->secam_lut[r - INT16_MIN] = _unit_phasor(d);
+
+		/* "bell" filter: complex gain at the instantaneous frequency
+		 * (src/video.c:2172-2185, :4122-4128) */
+		f = fm_freq + (double) r * fm_dev / INT16_MAX;
+		f = f / 4.286e6 - 4.286e6 / f;
+		lq = 16.0 * f;
+		rq = 1.26 * f;
+		den = 1.0 + rq * rq;
+		t->secam_bell[(uint16_t) r].i = lround(0.115 * (1.0 + lq * rq) / den * INT16_MAX);
+		t->secam_bell[(uint16_t) r].q = lround(0.115 * (lq - rq) / den * INT16_MAX);
+	}
+
+	/* colour-difference low pass (src/video.c:4097-4098) */
+	_design_low_pass(taps, 15, t->sample_rate, 1.70e6);
+	t->secam_fir = _q15_applied(taps, 15, 1);
+
+	/* luma notch at the sub-carrier, deliberately weakened (src/video.c:4100-4107) */
+	_design_band_reject(taps, 51, t->sample_rate, fm_freq - 1e6, fm_freq + 1e6);
+	taps[51 / 2] += 0.5;
+	for(sum = i = 0; i < 51; i++) sum += taps[i];
+	sum = sum / 1.0;
+	for(i = 0; i < 51; i++) taps[i] /= sum;
+	t->secam_notch = _q15_applied(taps, 51, 1);
+	if(!t->secam_fir || !t->secam_notch) return(HVK_OUT_OF_MEMORY);
+
+	/* deviation limits: [0] D'b lines, [1] D'r lines (src/video.c:4110-4113) */
+	t->secam_dmin[0] = lround((cb - fm_freq - 350e3) / fm_dev * INT16_MAX);
+	t->secam_dmax[0] = lround((cb - fm_freq + 506e3) / fm_dev * INT16_MAX);
+	t->secam_dmin[1] = lround((cr - fm_freq - 506e3) / fm_dev * INT16_MAX);
+	t->secam_dmax[1] = lround((cr - fm_freq + 350e3) / fm_dev * INT16_MAX);
+
+	/* sub-carrier envelope over the line (src/video.c:4140-4147) */
+	rise = c->burst_rise * EDGE_0_100;
+	t->k.burst_left = round(t->sample_rate * (c->burst_left - c->burst_rise / 2));
+	t->k.burst_width = ceil(t->sample_rate * (c->burst_width + rise));
+	t->burst_win = malloc(t->k.burst_width * sizeof(int16_t));
+	if(!t->burst_win) return(HVK_OUT_OF_MEMORY);
+	for(i = 0; i < t->k.burst_width; i++)
+	{
+		double tt = 1.0 / t->sample_rate * i;
+		t->burst_win[i] = round(_window(tt, rise / 2, c->burst_width, rise) * 1.0 * INT16_MAX);
+	}
+
+	return(HVK_OK);
+}
+
+/* ------------------------------------------------------------------ */
 
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate)
 {
@@ -447,7 +550,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	/* what the engine renders */
 	if(c->type != HVK_RASTER_625 && c->type != HVK_RASTER_525) return(HVK_UNSUPPORTED);
 	if(c->modulation == HVK_FM) return(HVK_UNSUPPORTED);
-	if(c->colour_mode == HVK_SECAM) return(HVK_UNSUPPORTED);
+	if(c->colour_mode == HVK_SECAM && c->secam_field_id) return(HVK_UNSUPPORTED);
 	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
 
@@ -544,7 +647,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->yuv.range = c->white_level - c->black_level;
 	t->yuv.level = level;
 	t->yuv.chroma_scale = (c->white_level - c->black_level) * level;
-	t->yuv.secam = 0;
+	t->yuv.secam = c->colour_mode == HVK_SECAM;
 	{
 		/* luma of black, used wherever the picture does not cover the active area */
 		double y = (c->black_level + (0.0 * (c->white_level - c->black_level))) * level;
@@ -626,6 +729,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	}
 	else if(t->k.colour) return(HVK_UNSUPPORTED);
 
+	if(c->colour_mode == HVK_SECAM && (r = _build_secam(t, level)) != HVK_OK) return(r);
+
 	hvk_tables_default_ghost(t);
 
 	/* video filter (src/video.c:3653-3764) */
@@ -690,6 +795,10 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->fm_lut);
 	free(t->nicam_taps);
 	free(t->nicam_cc);
+	free(t->secam_lut);
+	free(t->secam_bell);
+	free(t->secam_fir);
+	free(t->secam_notch);
 	memset(t, 0, sizeof(*t));
 }
 
@@ -718,6 +827,10 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
 	if(!strcmp(name, "limiter_shape")) return(_give(dst, max_bytes, t->limiter_shape, t->has_limiter ? 21L * 2 : 0));
 	if(!strcmp(name, "limiter_vtaps")) return(_give(dst, max_bytes, t->limiter_vtaps, t->has_limiter ? 65L * 4 : 0));
 	if(!strcmp(name, "limiter_ftaps")) return(_give(dst, max_bytes, t->limiter_ftaps, t->has_limiter ? 65L * 4 : 0));
+	if(!strcmp(name, "fm_secam_lut"))  return(_give(dst, max_bytes, t->secam_lut, t->secam_lut ? 65536L * 8 : 0));
+	if(!strcmp(name, "fm_secam_bell")) return(_give(dst, max_bytes, t->secam_bell, t->secam_bell ? 65535L * 4 : 0));
+	if(!strcmp(name, "fm_secam_fir"))  return(_give(dst, max_bytes, t->secam_fir, t->secam_fir ? 15L * 2 : 0));
+	if(!strcmp(name, "secam_l_fir"))   return(_give(dst, max_bytes, t->secam_notch, t->secam_notch ? 51L * 2 : 0));
 	if(!strcmp(name, "linedesc"))      return(_give(dst, max_bytes, t->desc, (long) 2 * t->k.lines * sizeof(hvk_linedesc_t)));
 	return(-1);
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_audio_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream",
-    "hvk_host_side_streams", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         L.hvk_launch_strided_out.argtypes = [vp, vp, i64]
         L.hvk_set_stream.argtypes = [vp, vp]
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
+        L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_output_device_ptr.argtypes = [vp]
@@ -160,6 +161,17 @@ class Engine:
         n = self._chk("hvk_host_side_streams", lib().hvk_host_side_streams(
             self.h, first, count, car.ctypes.data, sym.ctypes.data, len(sym), C.byref(k0)))
         return car, sym[:n], k0.value
+
+    def host_secam_stream(self, fb, interlaced=0):
+        out = np.zeros(self.info["frame_samples"], np.int16)
+        if fb is None:
+            r = lib().hvk_host_secam_stream(self.h, None, 0, 0, 0, out.ctypes.data)
+        else:
+            fb = np.ascontiguousarray(fb, np.uint32)
+            h, w = fb.shape
+            r = lib().hvk_host_secam_stream(self.h, fb.ctypes.data, w, h, interlaced, out.ctypes.data)
+        self._chk("hvk_host_secam_stream", r)
+        return out
 
     def render(self, nframes, slots=None, d_iq=None):
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)

@@ -171,6 +171,13 @@ int hvk_set_stream(hvk_engine_t *e, void *hip_stream);
 int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
                           int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0);
 
+/* SECAM only, host half on its own: the value the colour process adds to every
+ * sample of the NEXT frame of the stream (frame_samples int16), given the
+ * picture shown on it (fb == NULL: an empty frame). Frames are taken in stream
+ * order; the call advances the pre-pass, so use it instead of, not next to,
+ * hvk_render(). Needs no device. */
+int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int height, int interlaced, int16_t *out);
+
 /* Wait for the engine's stream; returns HVK_OK or the HIP failure. */
 int hvk_sync(hvk_engine_t *e);
 

@@ -48,6 +48,9 @@ CASES = [
     ("m_full",        "m",    13500000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
     ("ntsc_bb",       "ntsc", 13500000, [],                        0,                                      True,  2),
     ("i_20m",         "i",    20250000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 2),
+    ("secam_bb",      "secam", 16000000, [],                       0,                                      True,  3),
+    ("l_raster",      "l",    16000000, ["--noaudio"],             refprobe.FLAG_NOAUDIO,                  False, 2),
+    ("l_full",        "l",    16000000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
 ]
 
 TABLES = [
@@ -55,6 +58,7 @@ TABLES = [
     ("chroma_taps", np.int16), ("vfilter_itaps", np.int16), ("vfilter_qtaps", np.int16),
     ("fm_mono_lut", np.int32), ("nicam_taps", np.int16), ("nicam_cc", np.int16),
     ("limiter_shape", np.int16), ("limiter_vtaps", np.int32), ("limiter_ftaps", np.int32),
+    ("fm_secam_lut", np.int32), ("fm_secam_bell", np.int16), ("fm_secam_fir", np.int16), ("secam_l_fir", np.int16),
 ]
 
 

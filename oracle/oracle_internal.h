@@ -126,6 +126,15 @@ struct orc_t {
 	int nicam_buf_len;
 	int audio_primed;
 
+	/* SECAM colour process (oracle_secam.c) */
+	int16_t sc_level;
+	c32_t *sc_lut;
+	double sc_a1, sc_b0, sc_b1, sc_ix, sc_iy;
+	int16_t *sc_fir, *sc_notch;
+	int16_t sc_dmin[2], sc_dmax[2];
+	c16_t *sc_bell;
+	long sc_done;               /* lines the process has been applied to */
+
 	/* stage taps of the last render call */
 	int16_t *last_raster; long last_raster_len;
 	int16_t *last_carrier; long last_carrier_len;
@@ -139,6 +148,13 @@ double orc_rc_window(double t, double left, double width, double rise);
 /* oracle_raster.c */
 void orc_raster_line(orc_t *s, long g);
 int16_t *orc_line_ptr(orc_t *s, long g);
+
+void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, int *vy);
+
+/* oracle_secam.c */
+int orc_secam_init(orc_t *s);
+void orc_secam_free(orc_t *s);
+void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int active_r, int vy);
 
 /* oracle_audio.c */
 int orc_audio_init(orc_t *s);

@@ -231,3 +231,22 @@ void orc_raster_line(orc_t *s, long g)
 		}
 	}
 }
+
+/* What the SECAM process needs to know about a line (src/video.c:3078-3090) */
+void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, int *vy)
+{
+	const hvk_config_t *c = &s->conf;
+	int vframe_y = (c->active_lines - s->fb_height) / 2;
+	_linecode_t code;
+
+	*frame = g / c->lines + 1;
+	*line = g % c->lines + 1;
+	code = _line_code(c->type, *line);
+	*la = code.la;
+	*ra = code.ra;
+
+	*vy = _source_row(c->type, *line);
+	if(*vy >= 0 && c->interlaced != 0 && s->fb_interlaced != c->interlaced) *vy += 1;
+	*vy -= vframe_y;
+	if(*vy < 0 || *vy >= s->fb_height) *vy = -1;
+}

@@ -12,6 +12,10 @@
 #include <math.h>
 #include "oracle_internal.h"
 
+double orc_i_zero(double x);
+void orc_kaiser(double *taps, int ntaps, double beta);
+void orc_low_pass(double *taps, int ntaps, double sample_rate, double cutoff, double gain);
+
 #define IRT1090 2.0738786 /* src/common.h:28, 10-90% -> 0-100%, integrated raised cosine */
 
 /* ---- src/common.c:231-257 : integrated raised-cosine window ---- */
@@ -58,7 +62,7 @@ static void _pulse(orc_pulse_t *p, double offset, double width, double rise, int
 }
 
 /* ---- src/fir.c:32-69 : Kaiser window ---- */
-static double _i_zero(double x)
+double orc_i_zero(double x)
 {
 	double sum, u, halfx, temp;
 	int n;
@@ -78,9 +82,9 @@ static double _i_zero(double x)
 	return(sum);
 }
 
-static void _kaiser(double *taps, int ntaps, double beta)
+void orc_kaiser(double *taps, int ntaps, double beta)
 {
-	double i_beta = 1.0 / _i_zero(beta);
+	double i_beta = 1.0 / orc_i_zero(beta);
 	double inm1 = 1.0 / ((double) (ntaps - 1));
 	int i;
 
@@ -88,18 +92,18 @@ static void _kaiser(double *taps, int ntaps, double beta)
 	for(i = 1; i < ntaps - 1; i++)
 	{
 		double temp = 2 * i * inm1 - 1;
-		taps[i] = _i_zero(beta * sqrt(1.0 - temp * temp)) * i_beta;
+		taps[i] = orc_i_zero(beta * sqrt(1.0 - temp * temp)) * i_beta;
 	}
 	taps[ntaps - 1] = i_beta;
 }
 
 /* ---- src/fir.c:89-137 : windowed-sinc low pass, unity gain at DC ---- */
-static void _low_pass(double *taps, int ntaps, double sample_rate, double cutoff, double gain)
+void orc_low_pass(double *taps, int ntaps, double sample_rate, double cutoff, double gain)
 {
 	int n, M;
 	double fmax, fwT0;
 
-	_kaiser(taps, ntaps, 7.0);
+	orc_kaiser(taps, ntaps, 7.0);
 
 	M = (ntaps - 1) / 2;
 	fwT0 = 2.0 * M_PI * cutoff / sample_rate;
@@ -396,6 +400,8 @@ int orc_build_tables(orc_t *s)
 
 	_default_ghost(s);
 
+	if(c->colour_mode == HVK_SECAM && orc_secam_init(s) != 0) return(-1);
+
 	/* video filter: src/video.c:3653-3764 (the sample-rate line width, :3660) */
 	s->vf_type = 0;
 	s->delay_lines = 0;
@@ -412,7 +418,7 @@ int orc_build_tables(orc_t *s)
 			double freq = M_PI * (c->vsb_upper_bw + -c->vsb_lower_bw) / s->sample_rate;
 			double phase = -freq * (ntaps >> 1);
 
-			_low_pass(lp, ntaps, s->sample_rate, (c->vsb_upper_bw - -c->vsb_lower_bw) / 2, 1);
+			orc_low_pass(lp, ntaps, s->sample_rate, (c->vsb_upper_bw - -c->vsb_lower_bw) / 2, 1);
 			for(i = 0; i < ntaps; i++, phase += freq)
 			{
 				ct[i * 2 + 0] = lp[i] * cos(phase);
@@ -427,7 +433,7 @@ int orc_build_tables(orc_t *s)
 		else if(c->modulation == HVK_AM || c->modulation == HVK_NONE)
 		{
 			double lp[51];
-			_low_pass(lp, ntaps, s->sample_rate, c->video_bw, 1);
+			orc_low_pass(lp, ntaps, s->sample_rate, c->video_bw, 1);
 			s->vf_type = 1;
 			s->vf_ntaps = ntaps;
 			s->vf_itaps = _quantise_reversed(lp, ntaps, 1);
@@ -451,4 +457,5 @@ void orc_free_tables(orc_t *s)
 	free(s->burst_win);
 	free(s->vf_itaps);
 	free(s->vf_qtaps);
+	if(s->conf.colour_mode == HVK_SECAM) orc_secam_free(s);
 }

@@ -107,6 +107,10 @@ long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
 	if(strcmp(name, "fm_mono_lut") == 0) return(_copy(dst, max_bytes, s->fm_mono.lut, 65536L * sizeof(c32_t)));
 	if(strcmp(name, "nicam_taps") == 0) return(_copy(dst, max_bytes, s->nicam.taps, (long) s->nicam.ntaps * sizeof(int16_t)));
 	if(strcmp(name, "nicam_cc") == 0) return(_copy(dst, max_bytes, s->nicam.cc, (long) s->nicam.cc_len * sizeof(c16_t)));
+	if(strcmp(name, "fm_secam_lut") == 0) return(_copy(dst, max_bytes, s->sc_lut, s->sc_lut ? 65536L * sizeof(c32_t) : 0));
+	if(strcmp(name, "fm_secam_bell") == 0) return(_copy(dst, max_bytes, s->sc_bell, s->sc_bell ? 65535L * sizeof(c16_t) : 0));
+	if(strcmp(name, "fm_secam_fir") == 0) return(_copy(dst, max_bytes, s->sc_fir, s->sc_fir ? 15L * 2 : 0));
+	if(strcmp(name, "secam_l_fir") == 0) return(_copy(dst, max_bytes, s->sc_notch, s->sc_notch ? 51L * 2 : 0));
 	if(strcmp(name, "limiter_shape") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.shape, (long) s->fm_mono.lim.width * sizeof(int16_t)));
 	if(strcmp(name, "limiter_vtaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.vtaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
 	if(strcmp(name, "limiter_ftaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.ftaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
@@ -182,6 +186,37 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 	{
 		orc_raster_line(s, s->rastered);
 		s->rastered++;
+
+		/* SECAM colour is a separate line process two slots behind the raster
+		 * (src/video.c:4206-4212, :4676-4688): line r - 1 is processed once line
+		 * r has been built (and has put its sync edge into r - 1's tail). Before
+		 * the first real line the process is handed two never-emitted slots
+		 * with frame 1, line 0, which it treats as picture lines without a
+		 * picture; they advance its IIR state. */
+		if(s->conf.colour_mode == HVK_SECAM)
+		{
+			int frame, line, la, ra, vy;
+
+			if(s->sc_done == 0 && s->rastered == 1)
+			{
+				int16_t *scratch = malloc(W * sizeof(int16_t));
+				int k, x;
+				for(k = 0; k < 2; k++)
+				{
+					for(x = 0; x < W; x++) scratch[x] = s->blanking_level;
+					orc_secam_line(s, scratch, 1, 0, 1, 1, -1);
+				}
+				free(scratch);
+			}
+
+			if(s->rastered >= 2)
+			{
+				long g = s->rastered - 2;
+				orc_line_info(s, g, &frame, &line, &la, &ra, &vy);
+				orc_secam_line(s, orc_line_ptr(s, g), frame, line, la, ra, vy);
+				s->sc_done++;
+			}
+		}
 	}
 }
 

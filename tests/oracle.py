@@ -68,6 +68,10 @@ class Oracle:
         lib().orc_set_ghost(self.p, g.ctypes.data, len(g))
 
     def set_frame(self, fb, interlaced=0):
+        if fb is None:
+            # an empty 0 x 0 frame, what av_read_video() hands out past the end (src/av.c:55-59)
+            lib().orc_set_frame(self.p, None, 0, 0, 0, 0, 0)
+            return
         fb = np.ascontiguousarray(fb, np.uint32)
         self._keep.append(fb)
         h, w = fb.shape

@@ -53,11 +53,16 @@ def test_no_cpu_path_without_a_device():
 
 
 def test_unsupported_configurations_are_refused():
-    for mode in ("l", "secam"):
-        c = H.preset(mode)
+    """Configurations outside the engine's scope fail at open with HVK_UNSUPPORTED."""
+    bad = []
+    c = H.preset("l"); c.secam_field_id = 1; bad.append((c, 16000000))        # SECAM field identification lines
+    c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
+    c = H.preset("i"); c.modulation = 3; bad.append((c, 16000000))            # FM video
+    c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster other than 625 / 525
+    for conf, sr in bad:
         try:
-            H.Engine(c, 16000000, device=-1)
+            H.Engine(conf, sr, device=-1)
         except H.HvkError as err:
             assert err.code == -4
         else:
-            raise AssertionError("SECAM is not rendered yet and must be refused")
+            raise AssertionError("an unsupported configuration was accepted")

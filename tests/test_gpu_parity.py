@@ -30,7 +30,7 @@ def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0):
 def test_device_yuv_table_equals_oracle(golden):
     """The 2^24-entry RGB -> level table is expanded on the device in FP64 with
     contraction off; every entry must equal the host/libm-built reference table."""
-    for case in ("i_full", "m_full"):
+    for case in ("i_full", "m_full", "l_full"):
         conf, sr = golden.conf(case)
         with H.Engine(conf, sr, device=0, max_frames=1) as e, oracle.Oracle(conf, sr) as o:
             dev = e.table("yuv", np.int16)
@@ -42,7 +42,7 @@ def test_device_yuv_table_equals_oracle(golden):
 
 
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "i_mono", "g_full",
-                                  "m_full", "ntsc_bb", "pal_bb_filter", "i_20m"])
+                                  "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -220,7 +220,7 @@ def test_dropin_binary_equals_reference_cli(golden):
         p.wait()
         return bytes(out)
 
-    for case in ("i_full", "pal_bb", "m_full"):
+    for case in ("i_full", "pal_bb", "m_full", "l_full"):
         c = golden.cases[case]
         fs = c["width"] * c["lines"]
         bps = 2 if c["real"] else 4
@@ -231,3 +231,30 @@ def test_dropin_binary_equals_reference_cli(golden):
         assert util.sha256(got[: 2 * fs * bps]) == c["sha256_cumulative"][1], case
         if os.path.exists(ref):
             assert got == run(ref, flags, nframes * fs * bps), case
+
+
+def test_secam_moving_picture_and_geometry(golden):
+    """SECAM-L with a different picture on every frame (the vertical average reaches
+    across lines, the IIR across frames), a small centred picture and an empty frame."""
+    conf, sr = golden.conf("l_full")
+    rng = np.random.default_rng(5)
+    fbs = [rng.integers(0, 1 << 24, size=(576, 832), dtype=np.uint32),
+           rng.integers(0, 1 << 24, size=(300, 500), dtype=np.uint32),
+           None,
+           golden.frame("l_full")]
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        got = []
+        for i in (0, 2):
+            for s in range(2):
+                e.frame_upload(s, fbs[i + s])
+            while e.audio_needed(2) > 0:
+                e.audio_write(golden.audio)
+            e.render(2, slots=[0, 1])
+            got.append(e.fetch(0, 2 * 640000))
+    with oracle.Oracle(conf, sr) as o:
+        o.set_audio(golden.audio, True)
+        want = []
+        for fb in fbs:
+            o.set_frame(fb)
+            want.append(o.render_lines(625))
+    assert np.array_equal(np.concatenate(got), np.concatenate(want))

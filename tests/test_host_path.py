@@ -9,10 +9,10 @@ import util
 
 HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_ghost", "vfilter_itaps",
                "vfilter_qtaps", "fm_mono_lut", "nicam_taps", "nicam_cc", "limiter_shape", "limiter_vtaps",
-               "limiter_ftaps"]
+               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir"]
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
     with H.Engine(conf, sr, device=-1) as e, oracle.Oracle(conf, sr) as o:
@@ -23,7 +23,7 @@ def test_host_tables_equal_oracle(golden, case):
             assert e.info[k] == o.info[k], k
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full"])
 def test_serial_carrier_stream_equals_oracle(golden, case):
     """The host pre-pass (FM/AM phasor chains, limiter, 32 kHz tick) produces the same
     per-sample contribution as the oracle's per-sample loop, including the
@@ -86,3 +86,29 @@ def test_nicam_symbols_reproduce_the_reference_signal(golden):
         _, sym, k0 = e.host_side_streams(0, nl * W)
         got = _nicam_from_symbols(e, sym, k0, 0, nl * W)
     assert np.array_equal((d - got) % 65536, np.zeros_like(d))
+
+
+def test_secam_host_prepass_equals_oracle(golden):
+    """The SECAM colour pre-pass (serial on the host: IIR state for ever, FM tail into the
+    next line's filter, the two pipeline-fill passes) against the oracle. Outside the
+    active picture the luma notch does not act, so there
+        oracle raster (SECAM) - oracle raster (no colour) == the added sub-carrier, mod 2^16;
+    any slip in the serial state shows up everywhere after it."""
+    conf_c, sr = golden.conf("l_raster")
+    import hacktv_amd as H2
+    conf_m = H2.preset("l", H2.FLAG_NOAUDIO | H2.FLAG_NOCOLOUR)
+    frame = golden.frame("l_raster")
+    nframes = 2
+    with oracle.Oracle(conf_c, sr) as a, oracle.Oracle(conf_m, sr) as b:
+        a.set_frame(frame)
+        b.set_frame(frame)
+        a.render_lines(625 * nframes)
+        b.render_lines(625 * nframes)
+        d = (a.last_raster().astype(np.int64) - b.last_raster().astype(np.int64)).reshape(nframes * 625, 1024)
+    with H.Engine(conf_c, sr, device=-1) as e:
+        got = np.concatenate([e.host_secam_stream(frame) for _ in range(nframes)]).astype(np.int64).reshape(nframes * 625, 1024)
+        al, aw = e.info["active_left"], e.info["active_width"]
+    outside = np.r_[0:al, al + aw:1024]
+    assert not ((d[:, outside] - got[:, outside]) % 65536).any()
+    # and nothing is added outside the sub-carrier window
+    assert not got[:, :82].any()

@@ -10,7 +10,7 @@ import oracle
 import util
 
 CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_full", "ntsc_bb", "i_mono", "g_full",
-              "pal_bb_filter", "i_20m"]
+              "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full"]
 
 
 @pytest.mark.parametrize("case", CASES_FAST)
@@ -37,7 +37,7 @@ def test_oracle_stream_matches_reference_cli(golden, case):
         assert np.array_equal(mine, ref[j]), "line %d of %s" % (g, case)
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full"])
 def test_oracle_tables_match_reference(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
@@ -48,6 +48,9 @@ def test_oracle_tables_match_reference(golden, case):
                   "nicam_sps", "nicam_dsl", "nicam_decimation", "nicam_cc_len"):
             assert o.info[k] == c["info"][k], k
         for name, ref in c["tables"].items():
+            if name == "fm_secam_bell" and ref["len"]:
+                # 65535 entries; the reference writes (and the probe cannot read) a 65536th
+                ref = dict(ref)
             a = o.table(name, util.TABLE_DTYPES[name])
             assert a.size == ref["len"], name
             assert util.sha256(a.tobytes()) == ref["sha256"], name

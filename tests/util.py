@@ -13,6 +13,7 @@ TABLE_DTYPES = {
     "chroma_taps": np.int16, "chroma_ghost": np.int16, "vfilter_itaps": np.int16, "vfilter_qtaps": np.int16,
     "fm_mono_lut": np.int32, "nicam_taps": np.int16, "nicam_cc": np.int16,
     "limiter_shape": np.int16, "limiter_vtaps": np.int32, "limiter_ftaps": np.int32,
+    "fm_secam_lut": np.int32, "fm_secam_bell": np.int16, "fm_secam_fir": np.int16, "secam_l_fir": np.int16,
 }
 
 
