@@ -197,6 +197,10 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int ax0 = d.al > px0 ? d.al : px0;                          /* samples that show a source pixel */
 	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
 	if(!has_pix) ax1 = ax0 = 0;
+	/* the reference fills the border left of the picture without looking at the
+	 * right end of the active part (src/video.c:2972-2975): on a left-half line a
+	 * picture narrow enough to start beyond mid-line pushes the black fill past it */
+	const int ar_eff = (px0 > d.al && px0 > d.ar) ? px0 : d.ar;
 
 	/* sub-carrier phasors of this lane's samples, fetched now so that the read is
 	 * in flight during the picture and filter phases. The table position advances
@@ -305,7 +309,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	/* luma is assigned over whatever is there (src/video.c:2961-3009):
 	 * the picture where the frame covers the line, black elsewhere */
-	if(active && x0 < d.ar && x0 + SPL > d.al)
+	if(active && x0 < ar_eff && x0 + SPL > d.al)
 	{
 		if(x0 >= ax0 && x0 + SPL <= ax1)
 		{
@@ -321,7 +325,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int i = 0; i < SPL; i++)
 			{
 				const int x = x0 + i;
-				if(x >= d.al && x < d.ar) s[i] = (x >= ax0 && x < ax1) ? (int) Yb[x] : k.black_y;
+				if(x >= d.al && x < ar_eff) s[i] = (x >= ax0 && x < ax1) ? (int) Yb[x] : k.black_y;
 			}
 		}
 	}

@@ -251,8 +251,8 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int
 		vy -= vframe_y;
 		if(fb && vy >= 0 && vy < fb_height) row = fb + (size_t) vy * fb_width;
 
-		_line(s, frame, line, picture, right_half, row, fb ? fb_width : k->active_width, fb ? vframe_x : 0,
-		      out + (size_t) (line - 1) * k->width);
+		/* an empty frame (0 x 0, what a source past its end hands out) shows no pixels at all */
+		_line(s, frame, line, picture, right_half, row, fb_width, vframe_x, out + (size_t) (line - 1) * k->width);
 	}
 
 	s->next_frame++;

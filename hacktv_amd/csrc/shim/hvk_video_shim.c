@@ -68,7 +68,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("--pixelrate (resampler)"));
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
 	if(c->modulation == VID_FM) return(_refuse("FM video"));
-	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC) return(_refuse("this colour mode"));
+	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext || c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->acp || c->vits || c->vitc || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
@@ -108,7 +108,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->rw_co = c->rw_co;
 	h->gw_co = c->gw_co;
 	h->bw_co = c->bw_co;
-	h->colour_mode = c->colour_mode == VID_PAL ? HVK_PAL : (c->colour_mode == VID_NTSC ? HVK_NTSC : HVK_MONOCHROME);
+	h->colour_mode = c->colour_mode == VID_PAL ? HVK_PAL : (c->colour_mode == VID_NTSC ? HVK_NTSC : (c->colour_mode == VID_SECAM ? HVK_SECAM : HVK_MONOCHROME));
 	h->colour_carrier.num = c->colour_carrier.num;
 	h->colour_carrier.den = c->colour_carrier.den;
 	h->colour_bw = c->colour_bw;

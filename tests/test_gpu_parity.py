@@ -120,14 +120,14 @@ def test_frame_geometry_edge_cases(golden):
     frames = {
         "none": None,
         "small": rng.integers(0, 1 << 24, size=(300, 400), dtype=np.uint32),
+        "narrow": rng.integers(0, 1 << 24, size=(576, 100), dtype=np.uint32),
         "large": rng.integers(0, 1 << 24, size=(700, 1000), dtype=np.uint32),
         "noise": rng.integers(0, 1 << 24, size=(576, 832), dtype=np.uint32),
     }
     for name, fb in frames.items():
         for interlaced in (0, 1):
             with oracle.Oracle(conf, sr) as o:
-                if fb is not None:
-                    o.set_frame(fb, interlaced)
+                o.set_frame(fb, interlaced)     # None: the empty 0 x 0 frame of a source past its end
                 want = o.render_lines(625)
             with H.Engine(conf, sr, device=0, max_frames=1) as e:
                 e.frame_upload(0, fb, interlaced)
