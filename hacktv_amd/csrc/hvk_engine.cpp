@@ -47,6 +47,9 @@ struct hvk_engine {
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
+	int32_t *d_tt_sym; int16_t *d_tt_val;
+	uint32_t *d_tt_pk, *h_tt_pk;    /* [max_frames][32][12] */
+	uint32_t *d_tt_mask, *h_tt_mask; /* [max_frames] */
 	hvk_packed_taps_t notch;
 	int device;             /* -1: host tables only */
 	int max_frames;
@@ -245,6 +248,19 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		if(!e->sym_tmp) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
+	if(e->t.k.teletext)
+	{
+		void *p;
+		OPENCHK(_upload(&p, e->t.tt_symbols, sizeof(int32_t) * 360 * 3)); e->d_tt_sym = (int32_t *) p;
+		OPENCHK(_upload(&p, e->t.tt_values, sizeof(int16_t) * (e->t.tt_total + 8))); e->d_tt_val = (int16_t *) p;
+		OPENHIP(hipMalloc((void **) &e->d_tt_pk, (size_t) max_frames * 32 * 12 * 4));
+		OPENHIP(hipMalloc((void **) &e->d_tt_mask, (size_t) max_frames * 4));
+		OPENHIP(hipHostMalloc((void **) &e->h_tt_pk, (size_t) max_frames * 32 * 12 * 4, hipHostMallocDefault));
+		OPENHIP(hipHostMalloc((void **) &e->h_tt_mask, (size_t) max_frames * 4, hipHostMallocDefault));
+		memset(e->h_tt_pk, 0, (size_t) max_frames * 32 * 12 * 4);
+		memset(e->h_tt_mask, 0, (size_t) max_frames * 4);
+	}
+
 	if(e->t.k.secam)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * FS * 2));
@@ -268,9 +284,9 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -417,6 +433,27 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	return(HVK_OK);
 }
 
+extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask)
+{
+	if(!e || !packets || frame_in_batch < 0 || frame_in_batch >= e->max_frames) return(HVK_ERROR);
+	if(!e->t.k.teletext) return(HVK_UNSUPPORTED);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+
+	/* the staging buffers may still be in flight from the previous batch */
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipStreamSynchronize(e->stream));
+
+	uint32_t *dst = e->h_tt_pk + (size_t) frame_in_batch * 32 * 12;
+	for(int r = 0; r < 32; r++)
+	{
+		uint8_t row[48] = { 0 };
+		memcpy(row, packets + r * 45, 45);
+		memcpy(dst + r * 12, row, 48);     /* little endian: bit b of the packet is bit b & 31 of word b >> 5 */
+	}
+	e->h_tt_mask[frame_in_batch] = mask;
+	return(HVK_OK);
+}
+
 extern "C" int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples)
 {
 	if(!e) return(HVK_ERROR);
@@ -549,6 +586,14 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	}
 
 	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
+	if(e->h_tt_pk)
+	{
+		HIPCHK(hipMemcpyAsync(e->d_tt_pk, e->h_tt_pk, (size_t) nframes * 32 * 12 * 4, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(hipMemcpyAsync(e->d_tt_mask, e->h_tt_mask, (size_t) nframes * 4, hipMemcpyHostToDevice, e->stream));
+		/* packets are consumed by the batch they were queued for */
+		HIPCHK(hipStreamSynchronize(e->stream));
+		memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
+	}
 	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * FS * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
@@ -591,6 +636,10 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.ctaps = e->ctaps;
 	ra.notch = e->notch;
 	ra.chroma = e->d_chroma;
+	ra.tt_sym = e->d_tt_sym;
+	ra.tt_val = e->d_tt_val;
+	ra.tt_pk = e->d_tt_pk;
+	ra.tt_mask = e->d_tt_mask;
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
 	ra.yuv = e->d_yuv;

@@ -77,6 +77,7 @@ typedef struct {
 	int32_t nicam_ntaps, nicam_sps, nicam_dsl, nicam_decimation, nicam_cc_len;
 	int32_t frame_samples;
 	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
+	int32_t teletext;       /* teletext symbol table present */
 } hvk_kconst_t;
 
 /* Per rendered frame */
@@ -114,6 +115,9 @@ typedef struct {
 	int16_t limiter_shape[21];
 	int32_t limiter_vtaps[65], limiter_ftaps[65];
 	int32_t has_limiter;
+	/* teletext symbols (src/teletext.c:1057-1074): [360] { offset, length, start in tt_values } */
+	int32_t *tt_symbols;
+	int16_t *tt_values; int32_t tt_total;
 	/* SECAM (src/video.c:4075-4162) */
 	int32_t secam_level;
 	hvk_c32_t *secam_lut;       /* 65536 FM steps at the pixel rate */

@@ -20,6 +20,10 @@ typedef struct {
 	hvk_packed_taps_t ctaps;
 	hvk_packed_taps_t notch;    /* SECAM luma notch */
 	const int16_t *chroma;      /* SECAM: [nframes][frame_samples] */
+	const int *tt_sym;          /* teletext symbol index */
+	const int16_t *tt_val;
+	const unsigned *tt_pk;      /* [nframes][32][12] */
+	const unsigned *tt_mask;    /* [nframes] */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const void *yuv;            /* 2^24 x int16x4 */

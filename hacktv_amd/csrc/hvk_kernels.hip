@@ -143,6 +143,10 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
                   const hvk_packed_taps_t notch,        /* SECAM luma notch, 51 taps */
                   const int16_t *__restrict__ chroma,   /* SECAM: [frames][frame_samples] values to add */
+                  const int *__restrict__ tt_sym,       /* teletext: [360] { offset, length, start } */
+                  const int16_t *__restrict__ tt_val,   /* teletext: symbol values */
+                  const unsigned *__restrict__ tt_pk,   /* teletext: [frames][32][12] packet bits, LSB first */
+                  const unsigned *__restrict__ tt_mask, /* teletext: [frames] rows present */
                   const hvk_linedesc_t *__restrict__ desc,
                   const int16_t *__restrict__ pulses,
                   const short4v *__restrict__ yuv,
@@ -180,6 +184,15 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	const hvk_linedesc_t d = desc[par * k.lines + line0];
 	const int pal = k.colour ? d.pal : 0;
+
+	/* teletext rides on lines 7..22 and 320..335 (src/teletext.c:1222-1224) */
+	int tt_row = -1;
+	if(k.teletext && own)
+	{
+		if(line0 >= 6 && line0 <= 21) tt_row = line0 - 6;
+		else if(line0 >= 319 && line0 <= 334) tt_row = 16 + line0 - 319;
+		if(tt_row >= 0 && !((tt_mask[blockIdx.y] >> tt_row) & 1)) tt_row = -1;
+	}
 
 	const int YL = (W + 8 + 7) & ~7;
 	const int CL = (W + 2 * HVK_CHROMA_LEAD + 7) & ~7;
@@ -272,7 +285,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(pal || has_pix) __syncthreads();
 
-	if(x0 >= W && !(SECAM && active)) return;
+	if(x0 >= W && !(SECAM && active) && tt_row < 0) return;
 
 	/* ---- 8 consecutive samples per lane ---- */
 	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
@@ -330,7 +343,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(pal)
+	if(pal && x0 < W)
 	{
 		int vu[SPL];                            /* (V, U) packed int16: the dot2 operand of the modulator */
 
@@ -447,6 +460,45 @@ void hvk_k_raster(const hvk_kconst_t k,
 				const int cs = (i & 1) ? (cw[i / 2] >> 16) : (int) (short) (cw[i / 2] & 0xFFFF);
 				s[i] = wrap16(s[i] + cs);
 			}
+		}
+	}
+
+	if(tt_row >= 0)
+	{
+		/* One packet = 360 shaped symbols, each a run of up to ~100 samples, added
+		 * for every set bit, least significant bit of each byte first
+		 * (src/vbidata.c:186-239). Set bits are walked by the whole workgroup (the
+		 * packet words are wave-uniform); lane t adds the t-th value of the symbol
+		 * into an int32 line accumulator in LDS. */
+		int *acc = (int *) lds;
+		const unsigned *pk = tt_pk + ((size_t) blockIdx.y * 32 + tt_row) * 12;
+
+		__syncthreads();
+		for(int j = t; j < W; j += nth) acc[j] = 0;
+		__syncthreads();
+
+		for(int w = 0; w < 12; w++)
+		{
+			unsigned word = __builtin_amdgcn_readfirstlane(pk[w]);
+			if(w == 11) word &= 0xFF;           /* 360 bits */
+			while(word)
+			{
+				const int b = w * 32 + __builtin_ctz(word);
+				word &= word - 1;
+				const int off = tt_sym[b * 3 + 0], len = tt_sym[b * 3 + 1];
+				const int16_t *v = tt_val + tt_sym[b * 3 + 2];
+				for(int j = t; j < len; j += nth)
+				{
+					if(off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
+				}
+			}
+		}
+		__syncthreads();
+
+		if(x0 < W)
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
 		}
 	}
 
@@ -722,7 +774,7 @@ static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
 	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3(a->k.lines + 2, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->notch, a->chroma, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
+	                   a->k, a->ctaps, a->notch, a->chroma, a->tt_sym, a->tt_val, a->tt_pk, a->tt_mask, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }

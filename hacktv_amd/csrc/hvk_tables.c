@@ -434,6 +434,68 @@ static int _build_audio(hvk_tables_t *t, double slevel)
 }
 
 /* ------------------------------------------------------------------ */
+/* teletext                                                            */
+
+/* 360 raised-cosine data symbols (beta 0.7) at 444 x line rate, 66 % of
+ * white - black, first symbol 12 us less 12 bit periods after 0H: the table
+ * tt_init() asks vbidata_init() for (src/teletext.c:1057-1074,
+ * src/vbidata.c:26-35, :83-121). Each symbol keeps the samples from its first
+ * to its last non-zero value. */
+static int _build_teletext(hvk_tables_t *t)
+{
+	const int W = t->k.width;
+	int level = round((t->white_level - t->black_level) * 0.66);
+	double bw = (double) W / 444;
+	double offset = t->sample_rate * (12e-6 - (64e-6 / 444 * 12));
+	int16_t *row = malloc(W * sizeof(int16_t));
+	int b, x, total = 0, pass;
+
+	t->tt_symbols = calloc(360 * 3, sizeof(int32_t));
+	if(!row || !t->tt_symbols) { free(row); return(HVK_OUT_OF_MEMORY); }
+
+	for(pass = 0; pass < 2; pass++)
+	{
+		if(pass == 1)
+		{
+			t->tt_total = total;
+			t->tt_values = calloc(total + 8, sizeof(int16_t));
+			if(!t->tt_values) { free(row); return(HVK_OUT_OF_MEMORY); }
+			total = 0;
+		}
+
+		for(b = 0; b < 360; b++)
+		{
+			double t0 = -bw * b - offset;
+			int first = 0, len = 0;
+
+			for(x = 0; x < W; x++)
+			{
+				double u = (t0 + x) / bw, h;
+				if(u == 0) h = 1.0;
+				else h = (sin(M_PI * (u / 1)) / (M_PI * (u / 1))) * (cos(M_PI * 0.7 * u / 1) / (1.0 - (4.0 * 0.7 * 0.7 * u * u / (1 * 1))));
+				row[x] = round(h * level);
+				if(row[x] == 0) continue;
+				if(len == 0) first = x;
+				len = x - first + 1;
+			}
+
+			if(pass == 1)
+			{
+				t->tt_symbols[b * 3 + 0] = first;
+				t->tt_symbols[b * 3 + 1] = len;
+				t->tt_symbols[b * 3 + 2] = total;
+				memcpy(t->tt_values + total, row + first, len * sizeof(int16_t));
+			}
+			total += len;
+		}
+	}
+
+	free(row);
+	t->k.teletext = 1;
+	return(HVK_OK);
+}
+
+/* ------------------------------------------------------------------ */
 /* SECAM                                                               */
 
 /* Kaiser-windowed band stop with unity DC gain (src/fir.c:179-228) */
@@ -779,6 +841,13 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	if((r = _build_audio(t, slevel)) != HVK_OK) return(r);
 
+	if(c->teletext)
+	{
+		/* 625-line systems only (src/hacktv.c:1182-1186) */
+		if(c->lines != 625) return(HVK_UNSUPPORTED);
+		if((r = _build_teletext(t)) != HVK_OK) return(r);
+	}
+
 	return(_build_linedesc(t));
 }
 
@@ -795,6 +864,8 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->fm_lut);
 	free(t->nicam_taps);
 	free(t->nicam_cc);
+	free(t->tt_symbols);
+	free(t->tt_values);
 	free(t->secam_lut);
 	free(t->secam_bell);
 	free(t->secam_fir);
@@ -831,6 +902,29 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
 	if(!strcmp(name, "fm_secam_bell")) return(_give(dst, max_bytes, t->secam_bell, t->secam_bell ? 65535L * 4 : 0));
 	if(!strcmp(name, "fm_secam_fir"))  return(_give(dst, max_bytes, t->secam_fir, t->secam_fir ? 15L * 2 : 0));
 	if(!strcmp(name, "secam_l_fir"))   return(_give(dst, max_bytes, t->secam_notch, t->secam_notch ? 51L * 2 : 0));
+	if(!strcmp(name, "teletext_lut"))
+	{
+		/* the reference's packed layout [length][offset][values...]...[-1] */
+		long n = 1, o = 0;
+		int b;
+		int16_t *q;
+		if(!t->tt_symbols) return(0);
+		for(b = 0; b < 360; b++) n += 2 + t->tt_symbols[b * 3 + 1];
+		if(dst == NULL) return(n * 2);
+		q = malloc(n * 2);
+		if(!q) return(-1);
+		for(b = 0; b < 360; b++)
+		{
+			q[o++] = t->tt_symbols[b * 3 + 1];
+			q[o++] = t->tt_symbols[b * 3 + 0];
+			memcpy(q + o, t->tt_values + t->tt_symbols[b * 3 + 2], t->tt_symbols[b * 3 + 1] * 2);
+			o += t->tt_symbols[b * 3 + 1];
+		}
+		q[o++] = -1;
+		n = _give(dst, max_bytes, q, n * 2);
+		free(q);
+		return(n);
+	}
 	if(!strcmp(name, "linedesc"))      return(_give(dst, max_bytes, t->desc, (long) 2 * t->k.lines * sizeof(hvk_linedesc_t)));
 	return(-1);
 }

@@ -31,6 +31,12 @@
  * Difference: frames are rendered HVK_BATCH at a time on the GPU (environment
  * variable, default 4) and read back into a host buffer the lines point into.
  * line->audio is always NULL (the file sink has no audio path).
+ *
+ * Teletext: which packet goes on which line -- the TTI page store, the magazine
+ * scheduler, the wall clock (src/teletext.c:489-990) -- is host control logic and
+ * stays the reference's own code: the shim calls tt_init() and, for the 32 VBI
+ * lines of every frame in line order (src/teletext.c:1222-1224), tt_next_packet();
+ * the engine shapes and adds the symbols on the GPU (hvk_teletext_packets()).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +54,7 @@ typedef struct {
 	int line;               /* next line of the current frame, 0-based */
 	int64_t frames_done;    /* frames handed out completely */
 	int ended;              /* source has ended: no more batches */
+	int frame_in_batch_pull;
 	vid_line_t out;
 } shim_t;
 
@@ -69,7 +76,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
 	if(c->modulation == VID_FM) return(_refuse("FM video"));
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
-	if(c->teletext || c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
+	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
+	if(c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->acp || c->vits || c->vitc || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->offset != 0 || c->passthru || c->raw_bb_file || c->swap_iq || c->s_video) return(_refuse("offset / passthru / raw baseband / swap-iq / s-video"));
@@ -126,6 +134,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->nicam_beta = c->nicam_beta;
 	h->am_mono_carrier = c->am_mono_carrier;
 	h->vfilter = c->vfilter;
+	h->teletext = c->teletext != NULL;
 
 	return(VID_OK);
 }
@@ -185,6 +194,16 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	s->bline = 1;
 	s->processes = (void *) m;
 
+	if(s->conf.teletext)
+	{
+		/* tt_init() reads width, pixel_rate and the levels from vid_t (src/teletext.c:1057-1074) */
+		if((r = tt_init(&s->tt, s, s->conf.teletext)) != VID_OK)
+		{
+			vid_free(s);
+			return(r);
+		}
+	}
+
 	return(VID_OK);
 }
 
@@ -193,6 +212,8 @@ void vid_free(vid_t *s)
 	shim_t *m = _shim(s);
 
 	av_close(&s->av);       /* src/video.c:4711 */
+
+	if(s->conf.teletext && s->tt.vid) tt_free(&s->tt);
 
 	if(m)
 	{
@@ -226,6 +247,8 @@ static int _next_batch(vid_t *s, shim_t *m)
 	int32_t slots[256];
 	int n = 0;
 
+	m->frame_in_batch_pull = 0;
+
 	while(n < m->batch && n < 256)
 	{
 		av_frame_t f;
@@ -236,6 +259,23 @@ static int _next_batch(vid_t *s, shim_t *m)
 
 		if(hvk_frame_upload(m->e, n, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
 		slots[n] = n;
+
+		if(s->conf.teletext)
+		{
+			/* the packets of this frame, asked for in the order the lines go out */
+			uint8_t rows[32][45];
+			uint32_t mask = 0;
+			int frame = (int) (m->frames_done + m->frame_in_batch_pull + 1), row;
+
+			for(row = 0; row < 32; row++)
+			{
+				int line = row < 16 ? 7 + row : 320 + row - 16;
+				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
+			}
+			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);
+		}
+
+		m->frame_in_batch_pull++;
 		n++;
 	}
 

@@ -61,6 +61,7 @@ class HvkConfig(C.Structure):
         ("nicam_beta", C.c_double),
         ("am_mono_carrier", C.c_double),
         ("vfilter", C.c_int),
+        ("teletext", C.c_int),
     ]
 
 

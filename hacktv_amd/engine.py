@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
 SYMBOLS = [
     "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
     "hvk_open", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
-    "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_audio_write",
+    "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
@@ -56,6 +56,7 @@ def lib():
         L.hvk_set_chroma_ghost.argtypes = [vp, vp, i32]
         L.hvk_get_chroma_ghost.argtypes = [vp, vp, i32]
         L.hvk_frame_upload.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32]
+        L.hvk_teletext_packets.argtypes = [vp, i32, vp, C.c_uint32]
         L.hvk_audio_write.argtypes = [vp, vp, C.c_size_t]
         L.hvk_audio_needed.argtypes = [vp, i32]
         L.hvk_audio_needed.restype = C.c_size_t
@@ -146,6 +147,11 @@ class Engine:
         fb = np.ascontiguousarray(fb, np.uint32)
         h, w = fb.shape
         return self._chk("hvk_frame_upload", lib().hvk_frame_upload(self.h, slot, fb.ctypes.data, w, h, 1, w, interlaced))
+
+    def teletext_packets(self, frame_in_batch, packets, mask=0xFFFFFFFF):
+        p = np.ascontiguousarray(packets, np.uint8)
+        assert p.shape == (32, 45)
+        return self._chk("hvk_teletext_packets", lib().hvk_teletext_packets(self.h, frame_in_batch, p.ctypes.data, mask))
 
     def audio_write(self, stereo):
         a = np.ascontiguousarray(stereo, np.int16)

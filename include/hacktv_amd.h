@@ -119,6 +119,18 @@ int hvk_get_chroma_ghost(const hvk_engine_t *e, int16_t *ghost, int n);
 int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
                      int pixel_stride, int line_stride, int interlaced);
 
+/* Teletext (conf.teletext != 0): the packets for the VBI lines of frame
+ * `frame_in_batch` (0-based) of the NEXT hvk_render() / hvk_stage_strided()
+ * call. packets is [32][45] bytes -- row 0..15 for lines 7..22, row 16..31 for
+ * lines 320..335 (src/teletext.c:1222-1224), each row the 45 bytes the
+ * reference's tt_next_packet() fills (src/teletext.c:1178-1209): clock run-in
+ * 55 55, framing code 27, 42 data bytes. Bit i of mask set: row i is sent
+ * (TT_OK); clear: the line stays empty (TT_NO_PACKET). Which packet goes where
+ * is the caller's page store / scheduler; the engine shapes the 360 symbols
+ * and adds them to the line (vbidata_render, src/vbidata.c:186-239). Frames
+ * without a call carry no teletext. */
+int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask);
+
 /* av_read_audio() result: nsamples interleaved stereo pairs at 32 kHz. */
 int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples);
 

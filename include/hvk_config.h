@@ -120,6 +120,10 @@ typedef struct hvk_config_t {
 
 	int vfilter;                /* --filter, src/hacktv.c:1412 */
 
+	int teletext;               /* != 0: teletext packets will be supplied for the VBI lines
+	                             * (625-line modes; the reference's conf.teletext names the page
+	                             * source, which stays with the caller: hvk_teletext_packets()) */
+
 } hvk_config_t;
 
 #ifdef __cplusplus

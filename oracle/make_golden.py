@@ -51,6 +51,9 @@ CASES = [
     ("secam_bb",      "secam", 16000000, [],                       0,                                      True,  3),
     ("l_raster",      "l",    16000000, ["--noaudio"],             refprobe.FLAG_NOAUDIO,                  False, 2),
     ("l_full",        "l",    16000000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
+    # teletext from a raw packet file (tests/golden/ttraw.bin: 42-byte records, no wall clock involved)
+    ("i_tt",          "i",    16000000, ["--noaudio", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO,  False, 3),
+    ("l_tt",          "l",    16000000, ["--filter", "--teletext", "raw:@TTRAW@"],  refprobe.FLAG_FILTER,   False, 3),
 ]
 
 TABLES = [
@@ -59,6 +62,7 @@ TABLES = [
     ("fm_mono_lut", np.int32), ("nicam_taps", np.int16), ("nicam_cc", np.int16),
     ("limiter_shape", np.int16), ("limiter_vtaps", np.int32), ("limiter_ftaps", np.int32),
     ("fm_secam_lut", np.int32), ("fm_secam_bell", np.int16), ("fm_secam_fir", np.int16), ("secam_l_fir", np.int16),
+    ("teletext_lut", np.int16),
 ]
 
 
@@ -82,8 +86,10 @@ def main():
     lines = {}
     src = {}
 
+    ttraw = os.path.join(GOLD, "ttraw.bin")
     for cid, mode, sr, flags, pflags, real, nframes in CASES:
-        with refprobe.RefProbe(mode, sr, pflags) as r:
+        teletext = any("@TTRAW@" in f for f in flags)
+        with refprobe.RefProbe(mode, sr, pflags, teletext=("raw:" + ttraw) if teletext else None) as r:
             info = dict(r.info)
             key = "frame_%dx%d" % (info["active_width"], info["active_lines"])
             if key not in src:
@@ -98,7 +104,7 @@ def main():
         W, L = info["width"], info["lines"]
         fs = W * L
         bps = 2 if real else 4
-        data = ref_cli(mode, sr, flags, nframes * fs * bps)
+        data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw) for f in flags], nframes * fs * bps)
         assert len(data) == nframes * fs * bps, (cid, len(data))
         per_frame = [hashlib.sha256(data[: (i + 1) * fs * bps]).hexdigest() for i in range(nframes)]
 
@@ -111,7 +117,7 @@ def main():
 
         digests[cid] = {
             "mode": mode, "sample_rate": sr, "cli_flags": flags, "probe_flags": pflags, "real": real,
-            "width": W, "lines": L, "frames": nframes,
+            "width": W, "lines": L, "frames": nframes, "teletext": teletext,
             "sha256_cumulative": per_frame,   # sha256 of the first 1, 2, ... frames
             "info": info, "tables": tabs,
         }

@@ -135,6 +135,10 @@ struct orc_t {
 	c16_t *sc_bell;
 	long sc_done;               /* lines the process has been applied to */
 
+	/* teletext render (oracle_teletext.c): symbol table and the packets queued per frame */
+	orc_pulse_t *tt_sym;
+	struct { long frame; uint32_t mask; uint8_t packets[32][45]; } tt_queue[16];
+
 	/* stage taps of the last render call */
 	int16_t *last_raster; long last_raster_len;
 	int16_t *last_carrier; long last_carrier_len;
@@ -155,6 +159,11 @@ void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, in
 int orc_secam_init(orc_t *s);
 void orc_secam_free(orc_t *s);
 void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int active_r, int vy);
+
+/* oracle_teletext.c */
+int orc_teletext_init(orc_t *s);
+void orc_teletext_free(orc_t *s);
+void orc_teletext_render(orc_t *s, int16_t *o, const uint8_t packet[45]);
 
 /* oracle_audio.c */
 int orc_audio_init(orc_t *s);

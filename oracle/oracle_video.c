@@ -60,6 +60,7 @@ void orc_close(orc_t *s)
 	if(!s) return;
 	orc_free_tables(s);
 	orc_audio_free(s);
+	orc_teletext_free(s);
 	free(s->S);
 	free(s->last_raster);
 	free(s->last_carrier);
@@ -111,10 +112,44 @@ long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
 	if(strcmp(name, "fm_secam_bell") == 0) return(_copy(dst, max_bytes, s->sc_bell, s->sc_bell ? 65535L * sizeof(c16_t) : 0));
 	if(strcmp(name, "fm_secam_fir") == 0) return(_copy(dst, max_bytes, s->sc_fir, s->sc_fir ? 15L * 2 : 0));
 	if(strcmp(name, "secam_l_fir") == 0) return(_copy(dst, max_bytes, s->sc_notch, s->sc_notch ? 51L * 2 : 0));
+	if(strcmp(name, "teletext_lut") == 0)
+	{
+		/* the reference's packed layout [length][offset][values...]...[-1] (src/vbidata.c:196-202) */
+		long n = 0, o = 0;
+		int b;
+		int16_t *t;
+		if(!s->tt_sym) return(0);
+		for(b = 0; b < 360; b++) n += 2 + s->tt_sym[b].length;
+		n += 1;
+		if(dst == NULL) return(n * 2);
+		t = malloc(n * 2);
+		for(b = 0; b < 360; b++)
+		{
+			t[o++] = s->tt_sym[b].length;
+			t[o++] = s->tt_sym[b].offset;
+			memcpy(t + o, s->tt_sym[b].value, s->tt_sym[b].length * 2);
+			o += s->tt_sym[b].length;
+		}
+		t[o++] = -1;
+		n = _copy(dst, max_bytes, t, n * 2);
+		free(t);
+		return(n);
+	}
 	if(strcmp(name, "limiter_shape") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.shape, (long) s->fm_mono.lim.width * sizeof(int16_t)));
 	if(strcmp(name, "limiter_vtaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.vtaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
 	if(strcmp(name, "limiter_ftaps") == 0) return(_copy(dst, max_bytes, s->fm_mono.lim.ftaps, (long) s->fm_mono.lim.ntaps * sizeof(int32_t)));
 	return(-1);
+}
+
+int orc_teletext_packets(orc_t *s, long frame_index, const uint8_t *packets, uint32_t mask)
+{
+	int q = frame_index % 16;
+	if(s->conf.lines != 625) return(-1);
+	if(!s->tt_sym && orc_teletext_init(s) != 0) return(-1);
+	s->tt_queue[q].frame = frame_index + 1;     /* 0 marks an empty entry */
+	s->tt_queue[q].mask = mask;
+	memcpy(s->tt_queue[q].packets, packets, 32 * 45);
+	return(0);
 }
 
 void orc_set_ghost(orc_t *s, const int16_t *ghost, int n)
@@ -215,6 +250,21 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 				orc_line_info(s, g, &frame, &line, &la, &ra, &vy);
 				orc_secam_line(s, orc_line_ptr(s, g), frame, line, la, ra, vy);
 				s->sc_done++;
+			}
+		}
+
+		/* teletext comes after the colour process and before the filter
+		 * (src/video.c:4346-4359): 16 lines per field (src/teletext.c:1222-1224) */
+		if(s->tt_sym && s->rastered >= 2)
+		{
+			long g = s->rastered - 2;
+			long fi = g / s->conf.lines;
+			int line = g % s->conf.lines + 1;
+			int slot = (line >= 7 && line <= 22) ? line - 7 : ((line >= 320 && line <= 335) ? 16 + line - 320 : -1);
+			int q = fi % 16;
+			if(slot >= 0 && s->tt_queue[q].frame == fi + 1 && ((s->tt_queue[q].mask >> slot) & 1))
+			{
+				orc_teletext_render(s, orc_line_ptr(s, g), s->tt_queue[q].packets[slot]);
 			}
 		}
 	}

@@ -32,6 +32,12 @@ void orc_set_frame(orc_t *s, const uint32_t *fb, int width, int height, int pixe
 /* 32 kHz interleaved stereo source; loop != 0 repeats it forever (av_test) */
 void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop);
 
+/* Teletext packets for one frame (0-based stream frame index): slot 0..15 are
+ * lines 7..22, slot 16..31 lines 320..335; bit i of mask says slot i carries
+ * packets[i] (45 bytes: clock run-in, framing code, 42 data bytes). 625-line
+ * modes only. Up to 16 frames may be queued ahead. */
+int orc_teletext_packets(orc_t *s, long frame_index, const uint8_t *packets, uint32_t mask);
+
 /* Render the next nlines emitted lines (interleaved I/Q int16). Returns
  * the number of samples (pairs) written. */
 long orc_render_lines(orc_t *s, int16_t *iq, long nlines);

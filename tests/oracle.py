@@ -23,6 +23,7 @@ def lib():
         L.orc_set_ghost.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+        L.orc_teletext_packets.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_uint32]
         L.orc_render_lines.restype = C.c_long
         L.orc_render_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_last_raster.restype = C.c_long
@@ -81,6 +82,12 @@ class Oracle:
         a = np.ascontiguousarray(stereo, np.int16)
         self._keep.append(a)
         lib().orc_set_audio(self.p, a.ctypes.data, a.shape[0], 1 if loop else 0)
+
+    def teletext_packets(self, frame_index, packets, mask):
+        p = np.ascontiguousarray(packets, np.uint8)
+        assert p.shape == (32, 45)
+        if lib().orc_teletext_packets(self.p, frame_index, p.ctypes.data, mask) != 0:
+            raise RuntimeError("orc_teletext_packets failed")
 
     def render_lines(self, nlines):
         w = self.info["width"]

@@ -11,7 +11,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0):
+def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=None):
     batch = batch or nframes
     out = []
     with H.Engine(conf, sr, device=0, max_frames=batch) as e:
@@ -21,6 +21,9 @@ def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0):
             n = min(batch, nframes - done)
             while audio is not None and e.audio_needed(n) > 0:
                 e.audio_write(audio)
+            if teletext is not None:
+                for i in range(n):
+                    e.teletext_packets(i, teletext(done + i))
             e.render(n)
             out.append(e.fetch(0, n * e.info["frame_samples"]))
             done += n
@@ -42,13 +45,15 @@ def test_device_yuv_table_equals_oracle(golden):
 
 
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "i_mono", "g_full",
-                                  "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full"])
+                                  "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full",
+                                  "i_tt", "l_tt"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     nframes = c["frames"]
-    iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2)
+    iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
+                 teletext=golden.teletext_rows if c.get("teletext") else None)
     fs = c["width"] * c["lines"]
     # excerpted lines first: a readable failure
     idx = golden.lines[case + "_idx"]
@@ -220,12 +225,12 @@ def test_dropin_binary_equals_reference_cli(golden):
         p.wait()
         return bytes(out)
 
-    for case in ("i_full", "pal_bb", "m_full", "l_full"):
+    for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt"):
         c = golden.cases[case]
         fs = c["width"] * c["lines"]
         bps = 2 if c["real"] else 4
         nframes = 3
-        flags = ["-m", c["mode"], "-s", str(c["sample_rate"])] + c["cli_flags"]
+        flags = ["-m", c["mode"], "-s", str(c["sample_rate"])] + golden.cli_flags(case)
         got = run(hvk, flags, nframes * fs * bps)
         assert len(got) == nframes * fs * bps, case
         assert util.sha256(got[: 2 * fs * bps]) == c["sha256_cumulative"][1], case

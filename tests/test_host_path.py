@@ -9,13 +9,15 @@ import util
 
 HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_ghost", "vfilter_itaps",
                "vfilter_qtaps", "fm_mono_lut", "nicam_taps", "nicam_cc", "limiter_shape", "limiter_vtaps",
-               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir"]
+               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir", "teletext_lut"]
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
     with H.Engine(conf, sr, device=-1) as e, oracle.Oracle(conf, sr) as o:
+        if golden.cases[case].get("teletext"):
+            o.teletext_packets(0, golden.teletext_rows(0), 0)
         for name in HOST_TABLES:
             assert np.array_equal(e.table(name, util.TABLE_DTYPES[name]), o.table(name, util.TABLE_DTYPES[name])), name
         for k in ("width", "half_width", "active_width", "active_left", "lines", "active_lines", "white_level",

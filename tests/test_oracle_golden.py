@@ -10,7 +10,7 @@ import oracle
 import util
 
 CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_full", "ntsc_bb", "i_mono", "g_full",
-              "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full"]
+              "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full", "i_tt", "l_tt"]
 
 
 @pytest.mark.parametrize("case", CASES_FAST)
@@ -22,6 +22,9 @@ def test_oracle_stream_matches_reference_cli(golden, case):
     with oracle.Oracle(conf, sr) as o:
         o.set_frame(golden.frame(case))
         o.set_audio(golden.audio, True)
+        if c.get("teletext"):
+            for f in range(nframes + 1):
+                o.teletext_packets(f, golden.teletext_rows(f), 0xFFFFFFFF)
         iq = o.render_lines(nframes * L)
     assert iq.shape[0] == nframes * W * L
     for n in range(nframes):
@@ -37,11 +40,13 @@ def test_oracle_stream_matches_reference_cli(golden, case):
         assert np.array_equal(mine, ref[j]), "line %d of %s" % (g, case)
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full", "l_tt"])
 def test_oracle_tables_match_reference(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     with oracle.Oracle(conf, sr) as o:
+        if c.get("teletext"):
+            o.teletext_packets(0, golden.teletext_rows(0), 0)
         for k in ("width", "half_width", "active_width", "active_left", "white_level", "black_level",
                   "blanking_level", "sync_level", "colour_lookup_width", "burst_left", "burst_width",
                   "burst_phase_i", "burst_phase_q", "chroma_ataps", "fm_mono_level", "nicam_ntaps",

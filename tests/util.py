@@ -14,6 +14,7 @@ TABLE_DTYPES = {
     "fm_mono_lut": np.int32, "nicam_taps": np.int16, "nicam_cc": np.int16,
     "limiter_shape": np.int16, "limiter_vtaps": np.int32, "limiter_ftaps": np.int32,
     "fm_secam_lut": np.int32, "fm_secam_bell": np.int16, "fm_secam_fir": np.int16, "secam_l_fir": np.int16,
+    "teletext_lut": np.int16,
 }
 
 
@@ -37,7 +38,23 @@ class Golden:
     def conf(self, case):
         import hacktv_amd as H
         c = self.cases[case]
-        return H.preset(c["mode"], c["probe_flags"]), c["sample_rate"]
+        conf = H.preset(c["mode"], c["probe_flags"])
+        conf.teletext = 1 if c.get("teletext") else 0
+        return conf, c["sample_rate"]
+
+    def teletext_rows(self, frame):
+        """The 32 packets the reference's raw: source yields for a frame from
+        tests/golden/ttraw.bin: 55 55 27 + the next 42-byte record (src/teletext.c:1188-1201)."""
+        rec = np.frombuffer(open(os.path.join(GOLD, "ttraw.bin"), "rb").read(), np.uint8).reshape(-1, 42)
+        p = np.zeros((32, 45), np.uint8)
+        p[:, 0] = 0x55
+        p[:, 1] = 0x55
+        p[:, 2] = 0x27
+        p[:, 3:] = rec[frame * 32:(frame + 1) * 32]
+        return p
+
+    def cli_flags(self, case):
+        return [f.replace("@TTRAW@", os.path.join(GOLD, "ttraw.bin")) for f in self.cases[case]["cli_flags"]]
 
 
 def stream_bytes(iq, real):
