@@ -24,14 +24,30 @@ def first_frame_of(rank, world, round_index, frames):
     return block_of(rank, world, round_index) * frames
 
 
-def gather_blocks(local, root_buf, rank, world, root=0, group=None):
+def gather_blocks(local, root_buf, rank, world, root=0, group=None, via_host=False):
     """Reassemble one round of blocks on `root`.
+
+    via_host: stage device tensors through host memory (for a `gloo` group on a
+    box without RCCL peers; used to dry-run the multi-rank bench on one GPU).
 
     local     1-D tensor holding this rank's rendered block
     root_buf  on root: tensor [world, local.numel()], row r receives rank r's block
               (root's own row may alias `local`, in which case nothing is copied)
     Returns the list of work handles already waited on (empty for world == 1)."""
     if world == 1:
+        return []
+    if via_host:
+        if rank == root:
+            for r in range(world):
+                if r == root:
+                    if root_buf[root].data_ptr() != local.data_ptr():
+                        root_buf[root].copy_(local)
+                    continue
+                tmp = local.new_empty(local.shape, device="cpu")
+                dist.recv(tmp, r, group)
+                root_buf[r].copy_(tmp)
+        else:
+            dist.send(local.cpu(), root, group)
         return []
     if rank == root:
         if root_buf[root].data_ptr() != local.data_ptr():
