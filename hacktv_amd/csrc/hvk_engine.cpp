@@ -68,6 +68,7 @@ struct hvk_engine {
 	int32_t *d_sym;
 	int32_t *d_tile;
 	int16_t *d_out;
+	void *d_conv; size_t conv_bytes;   /* hvk_fetch_as scratch */
 
 	/* pinned staging */
 	hvk_framedesc_t *h_fdesc;
@@ -284,7 +285,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -717,6 +718,33 @@ extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t coun
 	HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
 	return(HVK_OK);
+}
+
+extern "C" long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t count, int type, int complex_out)
+{
+	if(!e || !dst || type < HVK_UINT8 || type > HVK_FLOAT) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+
+	const size_t unit = (type <= HVK_INT8 ? 1 : (type <= HVK_INT16 ? 2 : 4)) * (complex_out ? 2 : 1);
+	const size_t bytes = count * unit;
+	HIPCHK(hipSetDevice(e->device));
+
+	/* converted samples go through a scratch buffer sized on first use */
+	if(bytes > e->conv_bytes)
+	{
+		if(e->d_conv) HIPCHK(hipFree(e->d_conv));
+		e->d_conv = NULL;
+		e->conv_bytes = 0;
+		HIPCHK(hipMalloc(&e->d_conv, bytes));
+		e->conv_bytes = bytes;
+	}
+
+	int r = hvk_launch_convert(e->d_out + first * 2, count, type, complex_out != 0, e->d_conv, e->stream);
+	if(r != HVK_OK) return(r);
+	HIPCHK(hipMemcpyAsync(dst, e->d_conv, bytes, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return((long) bytes);
 }
 
 extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, size_t count)

@@ -757,6 +757,82 @@ void hvk_k_filter(const hvk_kconst_t k,
 }
 
 /* ------------------------------------------------------------------ */
+
+/* The file sink's sample formats (src/rf_file.c:34-277), two complex samples or
+ * four real ones per lane; grid-stride over the range. */
+template<int TYPE, int CPLX>
+__global__ void hvk_k_convert(const int *__restrict__ iq, size_t count, void *__restrict__ dst)
+{
+	const size_t stride = (size_t) gridDim.x * blockDim.x;
+	for(size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+	{
+		const int p = iq[i];
+		const int vi = (int) (short) (p & 0xFFFF), vq = p >> 16;
+
+		if(TYPE == HVK_UINT8)
+		{
+			const unsigned a = (unsigned) (vi + 32768) >> 8, b = (unsigned) (vq + 32768) >> 8;
+			if(CPLX) ((uint16_t *) dst)[i] = (uint16_t) (a | (b << 8));
+			else ((uint8_t *) dst)[i] = (uint8_t) a;
+		}
+		else if(TYPE == HVK_INT8)
+		{
+			const int a = vi >> 8, b = vq >> 8;
+			if(CPLX) ((uint16_t *) dst)[i] = (uint16_t) ((a & 0xFF) | ((b & 0xFF) << 8));
+			else ((int8_t *) dst)[i] = (int8_t) a;
+		}
+		else if(TYPE == HVK_UINT16)
+		{
+			const unsigned a = (unsigned) (vi + 32768) & 0xFFFF, b = (unsigned) (vq + 32768) & 0xFFFF;
+			if(CPLX) ((unsigned *) dst)[i] = a | (b << 16);
+			else ((uint16_t *) dst)[i] = (uint16_t) a;
+		}
+		else if(TYPE == HVK_INT16)
+		{
+			if(CPLX) ((int *) dst)[i] = p;
+			else ((int16_t *) dst)[i] = (int16_t) vi;
+		}
+		else if(TYPE == HVK_INT32)
+		{
+			const int a = (int) ((unsigned) vi << 16) + vi, b = (int) ((unsigned) vq << 16) + vq;
+			if(CPLX) ((int2v *) dst)[i] = (int2v) { a, b };
+			else ((int *) dst)[i] = a;
+		}
+		else
+		{
+			/* (float) v * (1.0 / 32767.0): the product is formed in double */
+			const float a = (float) ((double) (float) vi * (1.0 / 32767.0)), b = (float) ((double) (float) vq * (1.0 / 32767.0));
+			if(CPLX) ((float2 *) dst)[i] = make_float2(a, b);
+			else ((float *) dst)[i] = a;
+		}
+	}
+}
+
+template<int TYPE>
+static int _launch_convert(const void *iq, size_t count, int cplx, void *dst, hipStream_t stream)
+{
+	const int blocks = (int) ((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+	if(cplx) hipLaunchKernelGGL((hvk_k_convert<TYPE, 1>), dim3(blocks), dim3(256), 0, stream, (const int *) iq, count, dst);
+	else     hipLaunchKernelGGL((hvk_k_convert<TYPE, 0>), dim3(blocks), dim3(256), 0, stream, (const int *) iq, count, dst);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cplx, void *dst, hipStream_t stream)
+{
+	if(count == 0) return(HVK_OK);
+	switch(type)
+	{
+	case HVK_UINT8:  return(_launch_convert<HVK_UINT8>(iq, count, cplx, dst, stream));
+	case HVK_INT8:   return(_launch_convert<HVK_INT8>(iq, count, cplx, dst, stream));
+	case HVK_UINT16: return(_launch_convert<HVK_UINT16>(iq, count, cplx, dst, stream));
+	case HVK_INT16:  return(_launch_convert<HVK_INT16>(iq, count, cplx, dst, stream));
+	case HVK_INT32:  return(_launch_convert<HVK_INT32>(iq, count, cplx, dst, stream));
+	case HVK_FLOAT:  return(_launch_convert<HVK_FLOAT>(iq, count, cplx, dst, stream));
+	}
+	return(HVK_ERROR);
+}
+
+/* ------------------------------------------------------------------ */
 /* launchers                                                           */
 
 extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream)

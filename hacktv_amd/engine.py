@@ -19,7 +19,7 @@ SYMBOLS = [
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -70,6 +70,8 @@ def lib():
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.hvk_fetch_as.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, i32]
+        L.hvk_fetch_as.restype = C.c_long
         L.hvk_output_device_ptr.argtypes = [vp]
         L.hvk_output_device_ptr.restype = vp
         L.hvk_timing_enable.argtypes = [vp, i32]
@@ -201,6 +203,15 @@ class Engine:
     def fetch(self, first, count):
         out = np.zeros((count, 2), np.int16)
         self._chk("hvk_fetch", lib().hvk_fetch(self.h, out.ctypes.data, first, count))
+        return out
+
+    FILE_TYPES = {"uint8": (0, np.uint8), "int8": (1, np.int8), "uint16": (2, np.uint16),
+                  "int16": (3, np.int16), "int32": (4, np.int32), "float": (5, np.float32)}
+
+    def fetch_as(self, first, count, type_name, complex_out=True):
+        code, dt = self.FILE_TYPES[type_name]
+        out = np.zeros(count * (2 if complex_out else 1), dt)
+        self._chk("hvk_fetch_as", lib().hvk_fetch_as(self.h, out.ctypes.data, first, count, code, 1 if complex_out else 0))
         return out
 
     def fetch_raster(self, first, count):

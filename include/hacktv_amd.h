@@ -197,6 +197,23 @@ int hvk_sync(hvk_engine_t *e);
  * buffer) to host memory: what the shim hands to rf_write(). */
 int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
 
+/* Sample formats of the reference's file sink (src/rf.h:31-36) */
+#define HVK_UINT8  0
+#define HVK_INT8   1
+#define HVK_UINT16 2
+#define HVK_INT16  3
+#define HVK_INT32  4
+#define HVK_FLOAT  5
+
+/* hvk_fetch() with the file sink's sample-format conversion done on the device
+ * (src/rf_file.c:34-277; int8 complex is also what the HackRF sink sends,
+ * src/rf_hackrf.c:246-276): samples [first, first + count) of the last render
+ * are converted to `type`, I only (complex == 0) or I/Q pairs, and only the
+ * converted bytes cross PCIe -- 2 B/sample for int8 complex instead of 4.
+ * dst receives count * (complex ? 2 : 1) values. Returns the bytes written or
+ * a negative HVK_* code. */
+long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t count, int type, int complex_out);
+
 /* Device pointer of the engine's own output buffer (for HIP/RCCL callers) */
 void *hvk_output_device_ptr(hvk_engine_t *e);
 

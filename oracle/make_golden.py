@@ -123,6 +123,17 @@ def main():
         }
         print(cid, per_frame[-1][:16], flush=True)
 
+    # the file sink's sample formats (src/rf_file.c): first frame of a complex and of a real mode
+    sink = {}
+    for cid, mode, sr, flags, bytes_per in (("i_full", "i", 16000000, ["--filter"], 2), ("pal_bb", "pal", 16000000, [], 1)):
+        for tname, size in (("uint8", 1), ("int8", 1), ("uint16", 2), ("int16", 2), ("int32", 4), ("float", 4)):
+            n = 640000 * size * bytes_per
+            data = ref_cli(mode, sr, flags + ["-t", tname], n)
+            assert len(data) == n
+            sink["%s:%s" % (cid, tname)] = hashlib.sha256(data).hexdigest()
+    digests["_sink_formats"] = sink
+    print("sink formats", len(sink), flush=True)
+
     np.savez_compressed(os.path.join(GOLD, "testsrc.npz"), **src)
     np.savez_compressed(os.path.join(GOLD, "ref_lines.npz"), **lines)
     with open(os.path.join(GOLD, "ref_digests.json"), "w") as f:

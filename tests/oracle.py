@@ -30,8 +30,25 @@ def lib():
         L.orc_last_raster.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_last_carrier.restype = C.c_long
         L.orc_last_carrier.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_sink_convert.restype = C.c_long
+        L.orc_sink_convert.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
+
+
+SINK_TYPES = {"uint8": (0, np.uint8), "int8": (1, np.int8), "uint16": (2, np.uint16),
+              "int16": (3, np.int16), "int32": (4, np.int32), "float": (5, np.float32)}
+
+
+def sink_convert(iq, type_name, complex_out):
+    """rf_file.c's sample-format conversion (oracle/oracle_sink.c)."""
+    iq = np.ascontiguousarray(iq, np.int16)
+    code, dt = SINK_TYPES[type_name]
+    n = iq.shape[0]
+    out = np.zeros(n * (2 if complex_out else 1), dt)
+    r = lib().orc_sink_convert(iq.ctypes.data, n, code, 1 if complex_out else 0, out.ctypes.data)
+    assert r == out.nbytes
+    return out
 
 
 INFO_NAMES = [

@@ -263,3 +263,23 @@ def test_secam_moving_picture_and_geometry(golden):
             o.set_frame(fb)
             want.append(o.render_lines(625))
     assert np.array_equal(np.concatenate(got), np.concatenate(want))
+
+
+@pytest.mark.parametrize("case", ["i_full", "pal_bb"])
+def test_sink_formats_on_device(golden, case):
+    """hvk_fetch_as(): the file sink's sample-format conversion done on the GPU, against
+    the oracle's restatement and the digests of `hacktv_ref -t <type>`; odd offsets too."""
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    cplx = not c["real"]
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        e.frame_upload(0, golden.frame(case))
+        e.audio_write(golden.audio)
+        e.render(2)
+        iq = e.fetch(0, 2 * 640000)
+        for tname in oracle.SINK_TYPES:
+            got = e.fetch_as(0, 640000, tname, cplx)
+            assert util.sha256(got.tobytes()) == golden.sink_formats["%s:%s" % (case, tname)], tname
+            part = e.fetch_as(640001, 12345, tname, cplx)
+            want = oracle.sink_convert(iq[640001:640001 + 12345], tname, cplx)
+            assert np.array_equal(part.view(np.uint8), want.view(np.uint8)), tname

@@ -59,3 +59,17 @@ def test_oracle_tables_match_reference(golden, case):
             a = o.table(name, util.TABLE_DTYPES[name])
             assert a.size == ref["len"], name
             assert util.sha256(a.tobytes()) == ref["sha256"], name
+
+
+@pytest.mark.parametrize("case", ["i_full", "pal_bb"])
+def test_oracle_sink_formats_match_reference(golden, case):
+    """rf_file.c's six sample formats (oracle/oracle_sink.c) against `hacktv_ref -t <type>`."""
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    with oracle.Oracle(conf, sr) as o:
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        iq = o.render_lines(625)
+    for tname in oracle.SINK_TYPES:
+        out = oracle.sink_convert(iq, tname, not c["real"])
+        assert util.sha256(out.tobytes()) == golden.sink_formats["%s:%s" % (case, tname)], tname

@@ -24,6 +24,7 @@ class Golden:
     def __init__(self):
         with open(os.path.join(GOLD, "ref_digests.json")) as f:
             self.cases = json.load(f)
+        self.sink_formats = self.cases.pop("_sink_formats", {})
         self.src = np.load(os.path.join(GOLD, "testsrc.npz"))
         self.lines = np.load(os.path.join(GOLD, "ref_lines.npz"))
 
