@@ -84,6 +84,7 @@ struct hvk_engine {
 
 	int64_t next_frame;
 	int staged;             /* frames staged for the next launch */
+	int64_t staged_first, staged_stride;
 	int last_frames;        /* frames of the last launch (for fetch) */
 	int ghost_dirty;
 
@@ -139,6 +140,8 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	if(!e->slots) { free(e); return(HVK_OUT_OF_MEMORY); }
 
 	if((r = hvk_tables_build(&e->t, conf, sample_rate)) != HVK_OK) { hvk_close(e); return(r); }
+
+	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));   /* tools/ablate.py: results are WRONG when set */
 
 	if(e->t.k.colour) _pack_taps(&e->ctaps, e->t.chroma_taps, e->t.k.chroma_ntaps);
 	if(e->t.k.vf_type) _pack_taps(&e->itaps, e->t.vf_itaps, e->t.k.vf_ntaps);
@@ -215,7 +218,7 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		for(int i = 0; i < k.nicam_cc_len + 8; i++)
 		{
 			const hvk_c16_t c = e->t.nicam_cc[i % k.nicam_cc_len];
-			cca[i] = ((int) c.i & 0xFFFF) | ((int) c.q << 16);
+			cca[i] = ((int) c.i & 0xFFFF) | ((-(int) c.q) << 16);
 			ccb[i] = ((int) c.q & 0xFFFF) | ((int) c.i << 16);
 		}
 		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * 4));
@@ -243,8 +246,8 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		e->tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride * 4, hipHostMallocDefault));
-		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * 8));
-		OPENHIP(hipHostMalloc((void **) &e->h_tile, (size_t) max_frames * e->tiles * 8, hipHostMallocDefault));
+		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4));
+		OPENHIP(hipHostMalloc((void **) &e->h_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4, hipHostMallocDefault));
 		e->sym_tmp = (uint8_t *) malloc(e->symbol_stride);
 		if(!e->sym_tmp) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
@@ -561,7 +564,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 				 * symbol k starts at sps * k - floor(k * dsl / decimation); entries are
 				 * (start relative to the frame's first sample) << 3 | valid << 2 | value */
 				int32_t *tab = e->h_sym + (size_t) i * e->symbol_stride;
-				int32_t *tile = e->h_tile + (size_t) i * e->tiles * 2;
+				int32_t *tile = e->h_tile + (size_t) i * e->tiles * HVK_NICAM_ROW;
 				int newest = 0;
 
 				for(int j = 0; j < e->symbol_stride; j++)
@@ -572,15 +575,21 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 					tab[j] = (int32_t) (start * 8) | 4 | (e->sym_tmp[j] & 3);
 				}
 
-				/* per tile: the newest symbol that has started by the tile's first
-				 * sample, and the mixer table position of that sample */
+				/* per tile a dense row: the HVK_NICAM_SYMS symbols from 6 before the newest
+				 * one that has started by the tile's first sample, then the mixer table
+				 * position of that sample */
 				while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
 				for(int b = 0; b < e->tiles; b++)
 				{
 					const int64_t pos = (int64_t) b * HVK_TILE;
+					int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
 					while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
-					tile[b * 2 + 0] = newest;
-					tile[b * 2 + 1] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
+					for(int q = 0; q < HVK_NICAM_SYMS; q++)
+					{
+						const int j = newest - (HVK_NICAM_BACK - 1) + q;
+						row[q] = (j >= 0 && j < e->symbol_stride) ? tab[j] : 0;
+					}
+					row[HVK_NICAM_SYMS] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
 				}
 			}
 		}
@@ -599,11 +608,12 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
 	{
-		HIPCHK(hipMemcpyAsync(e->d_sym, e->h_sym, (size_t) nframes * e->symbol_stride * 4, hipMemcpyHostToDevice, e->stream));
-		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * 8, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
 	}
 
 	e->staged = nframes;
+	e->staged_first = first_frame;
+	e->staged_stride = stride;
 	return(HVK_OK);
 }
 
@@ -651,6 +661,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.fdesc = e->d_fdesc;
 	ra.S = e->d_S;
 	ra.nframes = e->staged;
+	ra.first_frame = e->staged_first;
+	ra.frame_stride = e->staged_stride;
 
 	hvk_filter_args_t fa;
 	memset(&fa, 0, sizeof(fa));
@@ -660,9 +672,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.fdesc = e->d_fdesc;
 	fa.S = e->d_S;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
-	fa.symtab = e->d_sym;
-	fa.tileinfo = e->d_tile;
-	fa.symbol_stride = e->symbol_stride;
+	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;
 	fa.nicam_cca = (const int *) e->d_cca;
 	fa.nicam_ccb = (const int *) e->d_ccb;

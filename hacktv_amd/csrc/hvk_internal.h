@@ -78,6 +78,7 @@ typedef struct {
 	int32_t frame_samples;
 	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
 	int32_t teletext;       /* teletext symbol table present */
+	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;
 
 /* Per rendered frame */

@@ -7,6 +7,8 @@
 #include "hvk_internal.h"
 
 #define HVK_CHROMA_LEAD 16   /* int16 of slack either side of a chroma channel in LDS */
+#define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
+#define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_NICAM_TAPD  384  /* dwords of the duplicated, zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
@@ -34,6 +36,7 @@ typedef struct {
 	const hvk_framedesc_t *fdesc;
 	int16_t *S;                 /* [nframes][lines + 2][width] */
 	int nframes;
+	int64_t first_frame, frame_stride;
 } hvk_raster_args_t;
 
 typedef struct {
@@ -42,9 +45,7 @@ typedef struct {
 	const hvk_framedesc_t *fdesc;
 	const int16_t *S;
 	const hvk_c16_t *carriers;
-	const int *symtab;          /* [nframes][symbol_stride] */
-	int symbol_stride;
-	const int *tileinfo;        /* [nframes][tiles][2] */
+	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
 	const int *nicam_tapd;      /* HVK_NICAM_TAPD dwords: (tap, tap), zero padded */
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const int *nicam_ccb;       /* nicam_cc_len + 8 dwords: (cc.q,  cc.i) */

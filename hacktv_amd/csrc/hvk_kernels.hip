@@ -43,6 +43,7 @@ typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 
 #define SPL HVK_SPL
 #define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
+#define HVK_TILES_PER_WG 1    /* consecutive filter tiles walked by one workgroup (4 measured 10 % slower: fewer independent workgroups to overlap) */
 
 __device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
 __device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
@@ -155,9 +156,17 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const int16_t *__restrict__ ghost,
                   const uint32_t *__restrict__ pool,
                   const hvk_framedesc_t *__restrict__ fdesc,
-                  int16_t *__restrict__ S)
+                  int16_t *__restrict__ S,
+                  const int64_t first_frame,            /* frame y of the batch is stream frame first_frame + y * frame_stride */
+                  const int64_t frame_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
+
+	/* the grid's x extent is padded to a multiple of 8 so that, with workgroups
+	 * dealt round-robin to the 8 XCDs, line x of EVERY frame runs on XCD x % 8:
+	 * the slices of the colour table and of the source frame a line needs then
+	 * stay in that XCD's L2 from frame to frame */
+	if((int) blockIdx.x >= k.lines + 2) return;
 
 	constexpr int H = NT / 2;
 	const int W = k.width;
@@ -169,12 +178,14 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int16_t *out = S + ((size_t) blockIdx.y * (k.lines + 2) + blockIdx.x) * W;
 
 	/* which line of which frame, without dividing the global line number */
-	int line0 = rel, par = f.parity;
+	/* frame number and parity by arithmetic: the descriptor fetch below does not wait for fdesc */
+	const int64_t frame_index = first_frame + (int64_t) blockIdx.y * frame_stride;
+	int line0 = rel, par = (int) ((frame_index + 1) & 1);
 	bool own = true;
 	if(rel < 0) { line0 = k.lines - 1; par ^= 1; own = false; }
 	else if(rel >= k.lines) { line0 = 0; par ^= 1; own = false; }
 
-	if(rel < 0 && f.frame_index == 0)
+	if(rel < 0 && frame_index == 0)
 	{
 		/* before the stream: the filter history is zero, not blanking
 		 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
@@ -221,7 +232,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int c[SPL];
 #pragma unroll
 	for(int i = 0; i < SPL; i++) c[i] = 0;
-	if(pal && x0 < W)
+	if(pal && x0 < W && !(k.ablate & 4))
 	{
 		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
 		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
@@ -251,7 +262,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(has_pix)
+	if(has_pix && !(k.ablate & 8))
 	{
 		/* all row reads are issued before the first table look-up, all look-ups
 		 * before the first LDS write: the two dependent global loads per pixel are
@@ -266,7 +277,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			rgb[i] = x < ax1 ? (row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu) : 0u;
 		}
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = yuv[rgb[i]];
+		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = (k.ablate & 1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i]];
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
@@ -350,7 +361,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		/* zero-history low pass of both channels (src/fir.c:357-375), >> 15 and
 		 * clamp by the saturating pack. All-zero input (no picture on this line)
 		 * only matters where the ghost samples reach. */
-		if(has_pix || x0 + SPL + H > W)
+		if((has_pix || x0 + SPL + H > W) && !(k.ablate & 2))
 		{
 			constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
 			int du[ND], dv[ND], u[SPL], v[SPL];
@@ -528,7 +539,6 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 	return(__builtin_bit_cast(int, (ushort2v) (__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b) + __builtin_bit_cast(ushort2v, c))));
 }
 
-#define HVK_NICAM_SYMS 48   /* symbol table slots per tile */
 
 template<int NT, int VF>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL)
@@ -538,29 +548,43 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_framedesc_t *__restrict__ fdesc,
                   const int16_t *__restrict__ S,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
-                  const int *__restrict__ symtab,        /* [frames][symbol_stride]: (start << 3) | valid << 2 | dsym */
-                  const int symbol_stride,
-                  const int2v *__restrict__ tileinfo,    /* [frames][tiles]: { newest symbol at the tile's first sample, mixer position } */
+                  const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW]: symbols (start << 3 | valid << 2 | dsym), mixer position */
                   const int *__restrict__ nicam_tapd,    /* pulse taps, each duplicated into both halves of a dword, zero padded */
-                  const int *__restrict__ nicam_cca,     /* mixer phasors (i, q), 8 entries past the wrap */
-                  const int *__restrict__ nicam_ccb,     /* unused */
+                  const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
+                  const int *__restrict__ nicam_ccb,     /* mixer (q,  i) */
                   int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
-                  const int64_t out_stride)
+                  const int64_t out_stride,
+                  const int tiles)                       /* 1024-sample tiles per frame */
 {
 	constexpr int H = NT / 2;
 	constexpr int LEAD = H + (H & 1);           /* window lead, even */
 	constexpr int NWIN = HVK_TILE + 2 * LEAD + 16;
 	__shared__ __attribute__((aligned(16))) int16_t win[NWIN];
 	__shared__ __attribute__((aligned(16))) int tapd[4 * HVK_NICAM_TAPD];
-	__shared__ int sym_st[HVK_NICAM_SYMS];
-	__shared__ int sym_sg[HVK_NICAM_SYMS];
+	__shared__ int sym_st[HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
+	__shared__ __attribute__((aligned(16))) int4v sym_ent[HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
 
 	const int W = k.width;
 	const int FS = k.frame_samples;
 	const int t = threadIdx.x;
-	const int n0 = blockIdx.x * HVK_TILE;       /* first output sample of the tile, frame local */
 	const int x0 = t * SPL;
 	const int16_t *slab = S + (size_t) blockIdx.y * (k.lines + 2) * W + W;   /* frame local sample 0 */
+
+	/* four copies of the NICAM pulse table, copy s shifted left by s entries, so that
+	 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts instead of
+	 * the 8-way of dword reads at a 32-byte lane stride); staged once per workgroup */
+	if(k.has_nicam && !(k.ablate & 16))
+	{
+		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
+	}
+
+	/* a workgroup walks HVK_TILES_PER_WG consecutive tiles: its fixed costs (kernel
+	 * arguments into SGPRs, the pulse table) are paid once */
+	for(int it = 0; it < HVK_TILES_PER_WG; it++)
+	{
+	const int tile = blockIdx.x * HVK_TILES_PER_WG + it;
+	if(tile >= tiles) break;
+	const int n0 = tile * HVK_TILE;             /* first output sample of the tile, frame local */
 
 	/* stage raster samples [n0 - LEAD, n0 + TILE + LEAD) as dwords; the slab
 	 * keeps one line before and one after the frame */
@@ -597,35 +621,35 @@ void hvk_k_filter(const hvk_kconst_t k,
 	int cc_tile = 0;
 	if(k.has_nicam)
 	{
-		/* four copies of the pulse table, copy s shifted left by s entries, so that
-		 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts
-		 * instead of the 8-way of dword reads at a 32-byte lane stride) */
-		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
-
 		/* the symbols whose pulses can touch this tile, oldest first: start
 		 * (relative to the tile's first sample) and sign pair. The schedule
 		 * (src/nicam728.c:398-407) is tabulated per frame by the host. */
-		const int2v ti = tileinfo[(size_t) blockIdx.y * gridDim.x + blockIdx.x];
-		const int first = ti.x - (HVK_NICAM_BACK - 1);              /* slab index of the oldest symbol of interest */
-		const int *tab = symtab + (size_t) blockIdx.y * symbol_stride;
-		cc_tile = ti.y;
+		/* one dense row per tile, prepared by the host: HVK_NICAM_SYMS symbol words
+		 * then the mixer position of the tile's first sample -- a single load
+		 * that depends on nothing but the block index */
+		const int *row = tilesyms + ((size_t) blockIdx.y * tiles + tile) * HVK_NICAM_ROW;
+		cc_tile = row[HVK_NICAM_SYMS];
 		if(t < HVK_NICAM_SYMS)
 		{
-			const int i = first + t;
-			const int v = (i >= 0 && i < symbol_stride) ? tab[i] : 0;
+			const int v = row[t];
 			const int st = (v >> 3) - n0;
 			const bool valid = (v & 4) && st < HVK_TILE;
 			/* constellation { 0, 1, 3, 2 }: bit 0 -> +I else -I, bit 1 -> +Q else -Q
 			 * (src/nicam728.c:33, :386-396) */
 			const int cs = (0x2310 >> ((v & 3) * 4)) & 3;
 			sym_st[t] = valid ? st : 0x3FFFFFFF;
-			sym_sg[t] = valid ? (((cs & 1) ? 0x0001 : 0xFFFF) | ((cs & 2) ? 0x00010000 : 0xFFFF0000)) : 0;
+			/* x0 is a multiple of 8, so which of the four shifted copies of the pulse
+			 * table a lane needs depends on the symbol only. A slot without a symbol
+			 * gets an offset that clamps into the table's zero tail. */
+			const int rel = HVK_NICAM_LEAD - st;
+			const int sgn = (int) (((cs & 1) ? 0x0001u : 0xFFFFu) | ((cs & 2) ? 0x00010000u : 0xFFFF0000u));
+			sym_ent[t] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgn, 0 }
+			                   : (int4v) { 0x10000000, 0, 0, 0 };
 		}
 	}
 	__syncthreads();
 
-	const int n = n0 + x0;                      /* this lane's first output, frame local */
-	if(n >= FS) return;
+	const int n = n0 + x0;                      /* this lane's first output, frame local; lanes past the frame compute and store nothing */
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
 
@@ -709,16 +733,18 @@ void hvk_k_filter(const hvk_kconst_t k,
 #pragma unroll
 		for(int i = 0; i < SPL; i++) bb[i] = 0;
 
-		for(int b = 0; b < HVK_NICAM_BACK; b++)
+		/* the newest symbol and the six before it: everything older is over. A pulse
+		 * that is over (or a slot without a symbol) reads the zero tail of the table:
+		 * no branch. idx >= HVK_NICAM_BACK - 1 by construction. */
+#pragma unroll 1
+		for(int b = 0; b < ((k.ablate & 32) ? 0 : HVK_NICAM_BACK); b++)
 		{
-			const int ii = idx - b;
-			if(ii < 0) break;
-			if(sym_st[ii] > last) break;                            /* no symbol here (before the stream's first) */
-			const int base = x0 - sym_st[ii] + HVK_NICAM_LEAD;     /* >= 1: the symbol has started by `last` */
-			if(base >= HVK_NICAM_LEAD + k.nicam_ntaps) break;      /* pulse over before this lane's samples */
-			const int sg = sym_sg[ii];
-			const int4v *tp = (const int4v *) (tapd + (base & 3) * HVK_NICAM_TAPD + (base & ~3));
+			const int4v en = sym_ent[idx - b];
+			int base = x0 + en.x;                                   /* >= 1 */
+			base = base < HVK_NICAM_TAPD - SPL ? base : HVK_NICAM_TAPD - SPL;
+			const int4v *tp = (const int4v *) (tapd + en.y + (base & ~3));
 			const int4v ta = tp[0], tb = tp[1];
+			const int sg = en.z;
 			bb[0] = pk_mad16(ta.x, sg, bb[0]); bb[1] = pk_mad16(ta.y, sg, bb[1]);
 			bb[2] = pk_mad16(ta.z, sg, bb[2]); bb[3] = pk_mad16(ta.w, sg, bb[3]);
 			bb[4] = pk_mad16(tb.x, sg, bb[4]); bb[5] = pk_mad16(tb.y, sg, bb[5]);
@@ -728,17 +754,22 @@ void hvk_k_filter(const hvk_kconst_t k,
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
 		else cp %= k.nicam_cc_len;
-		/* mixer: one table of (i, q); (i, -q) and (q, i) are derived in registers */
-		const int4u c0 = ((const int4u *) (nicam_cca + cp))[0], c1 = ((const int4u *) (nicam_cca + cp))[1];
-		const int cc[SPL] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+		/* mixer: the two rows of the rotation, (i, -q) and (q, i), tabulated */
+		if(!(k.ablate & 64))
+		{
+		const int4u a0 = ((const int4u *) (nicam_cca + cp))[0], a1 = ((const int4u *) (nicam_cca + cp))[1];
+		const int4u q0 = ((const int4u *) (nicam_ccb + cp))[0], q1 = ((const int4u *) (nicam_ccb + cp))[1];
+		const int ca[SPL] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+		const int cq[SPL] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			const int ca = (cc[i] & 0xFFFF) | ((0 - (cc[i] >> 16)) << 16);   /* q is never -32768 */
-			const int cq = shift_pair(cc[i], cc[i]);
-			const int mi = dot2(bb[i], ca, 0) >> 15;        /* bb.i * cc.i - bb.q * cc.q */
-			const int mq = dot2(bb[i], cq, 0) >> 15;        /* bb.i * cc.q + bb.q * cc.i */
-			o[i] = pk_add16(o[i], (mi & 0xFFFF) | (mq << 16));
+			const int mi = dot2(bb[i], ca[i], 0);           /* bb.i * cc.i - bb.q * cc.q */
+			const int mq = dot2(bb[i], cq[i], 0);           /* bb.i * cc.q + bb.q * cc.i */
+			/* ((mi >> 15) & 0xFFFF) | ((mq >> 15) << 16) */
+			const int pk = (int) ((((unsigned) mq << 1) & 0xFFFF0000u) | (((unsigned) mi >> 15) & 0xFFFFu));
+			o[i] = pk_add16(o[i], pk);
+		}
 		}
 	}
 
@@ -753,6 +784,9 @@ void hvk_k_filter(const hvk_kconst_t k,
 	{
 #pragma unroll
 		for(int i = 0; i < SPL; i++) if(n + i < FS) dst[i] = o[i];
+	}
+
+	__syncthreads();                            /* the next tile re-uses the LDS window and symbol table */
 	}
 }
 
@@ -849,9 +883,9 @@ static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3(a->k.lines + 2, a->nframes), dim3(threads), lds, stream,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3((a->k.lines + 2 + 7) & ~7, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->notch, a->chroma, a->tt_sym, a->tt_val, a->tt_pk, a->tt_mask, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
-	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S);
+	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
@@ -875,9 +909,9 @@ template<int NT, int VF>
 static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-	hipLaunchKernelGGL((hvk_k_filter<NT, VF>), dim3(tiles, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
-	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->symtab,
-	                   a->symbol_stride, (const int2v *) a->tileinfo, a->nicam_tapd, a->nicam_cca, a->nicam_ccb, (int *) a->iq, a->out_stride);
+	hipLaunchKernelGGL((hvk_k_filter<NT, VF>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
+	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
+	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, (int *) a->iq, a->out_stride, tiles);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

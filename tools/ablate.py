@@ -13,7 +13,14 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 cases = [("full: filter+fm+nicam", H.FLAG_FILTER), ("filter only (noaudio)", H.FLAG_FILTER | H.FLAG_NOAUDIO),
          ("filter+fm (nonicam)", H.FLAG_FILTER | H.FLAG_NONICAM), ("audio only (no filter)", 0),
          ("raster only", H.FLAG_NOAUDIO), ("mono + filter, noaudio", H.FLAG_FILTER | H.FLAG_NOAUDIO | H.FLAG_NOCOLOUR)]
-for name, flags in cases:
+abl = [("", 0)]
+if len(sys.argv) > 2:
+    abl = [("filter: no pulse-table staging", 16), ("filter: no shaping loop", 32), ("filter: no mixer", 64), ("filter: no staging+loop+mixer", 112)] if sys.argv[2] == "filter" else [("raster: no level-table gather", 1), ("raster: no chroma FIR", 2), ("raster: no colour-table read", 4), ("raster: no picture phase at all", 8), ("raster: none of the four", 15)]
+    cases = cases[:1]
+for aname, aval in abl:
+  os.environ["HVK_ABLATE"] = str(aval)
+  for name, flags in cases:
+    name = aname or name
     conf = H.preset("i", flags)
     with H.Engine(conf, 16000000, device=0, max_frames=F) as e:
         e.frame_upload(0, g.frame("i_full"))
@@ -29,4 +36,4 @@ for name, flags in cases:
         r, _ = e.timing_read(0)
         f, _ = e.timing_read(1)
         fs = e.info["frame_samples"]
-        print("%-28s raster %.4f ms  filter %.4f ms  -> %.1f Gsamples/s" % (name, r, f, F * fs / (r + f) / 1e6), flush=True)
+        print("%-34s raster %.4f ms  filter %.4f ms  -> %.1f Gsamples/s" % (name, r, f, F * fs / (r + f) / 1e6), flush=True)
