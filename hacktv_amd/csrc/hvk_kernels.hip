@@ -513,6 +513,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
+	if((k.ablate & 128) && s[0] != 12345) return;   /* profiling: no store */
 	if(x0 + SPL <= W)
 	{
 		int4v o;

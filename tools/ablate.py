@@ -15,7 +15,7 @@ cases = [("full: filter+fm+nicam", H.FLAG_FILTER), ("filter only (noaudio)", H.F
          ("raster only", H.FLAG_NOAUDIO), ("mono + filter, noaudio", H.FLAG_FILTER | H.FLAG_NOAUDIO | H.FLAG_NOCOLOUR)]
 abl = [("", 0)]
 if len(sys.argv) > 2:
-    abl = [("filter: no pulse-table staging", 16), ("filter: no shaping loop", 32), ("filter: no mixer", 64), ("filter: no staging+loop+mixer", 112)] if sys.argv[2] == "filter" else [("raster: no level-table gather", 1), ("raster: no chroma FIR", 2), ("raster: no colour-table read", 4), ("raster: no picture phase at all", 8), ("raster: none of the four", 15)]
+    abl = [("filter: no pulse-table staging", 16), ("filter: no shaping loop", 32), ("filter: no mixer", 64), ("filter: no staging+loop+mixer", 112)] if sys.argv[2] == "filter" else [("raster: no level-table gather", 1), ("raster: no chroma FIR", 2), ("raster: no colour-table read", 4), ("raster: no picture phase at all", 8), ("raster: none of the four", 15), ("raster: none of the four, no store", 143), ("raster: no store", 128)]
     cases = cases[:1]
 for aname, aval in abl:
   os.environ["HVK_ABLATE"] = str(aval)
