@@ -51,6 +51,13 @@ struct hvk_engine {
 	uint32_t *d_tt_pk, *h_tt_pk;    /* [max_frames][32][12] */
 	uint32_t *d_tt_mask, *h_tt_mask; /* [max_frames] */
 	hvk_packed_taps_t notch;
+	hvk_tail_t *tail;           /* FM video / offset / passthru serial state (hvk_tail.c) */
+	int16_t *d_off, *h_off;     /* offset phasor side stream, int16 pairs */
+	int16_t *d_pass, *h_pass;   /* passthru samples, int16 pairs */
+	int16_t *h_fm;              /* FM video: the batch's modulated samples (host) */
+	int64_t fm_batch_pos;       /* output position of the staged batch's first sample */
+	size_t fm_done;             /* samples of the batch modulated so far */
+	int fm_launched;            /* the staged batch has been rendered and is not fully modulated yet */
 	int device;             /* -1: host tables only */
 	int max_frames;
 	int frame_slots;
@@ -159,6 +166,12 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		e->host_frames = (uint32_t **) calloc(e->frame_slots, sizeof(uint32_t *));
 		if(!e->secam || !e->host_frames) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 		_pack_taps(&e->notch, e->t.secam_notch, 51);
+	}
+
+	if(e->t.k.fm_video || e->t.k.has_offset || e->t.k.has_passthru)
+	{
+		e->tail = hvk_tail_new(&e->t);
+		if(!e->tail) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
 	if(e->t.k.has_nicam)
@@ -272,6 +285,24 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * FS * 2, hipHostMallocDefault));
 	}
 
+	if(e->t.k.fm_video)
+	{
+		OPENHIP(hipHostMalloc((void **) &e->h_fm, (size_t) max_frames * FS * 4, hipHostMallocDefault));
+	}
+	else
+	{
+		if(e->t.k.has_offset)
+		{
+			OPENHIP(hipMalloc((void **) &e->d_off, (size_t) max_frames * FS * 4));
+			OPENHIP(hipHostMalloc((void **) &e->h_off, (size_t) max_frames * FS * 4, hipHostMallocDefault));
+		}
+		if(e->t.k.has_passthru)
+		{
+			OPENHIP(hipMalloc((void **) &e->d_pass, (size_t) max_frames * FS * 4));
+			OPENHIP(hipHostMalloc((void **) &e->h_pass, (size_t) max_frames * FS * 4, hipHostMallocDefault));
+		}
+	}
+
 	for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) OPENHIP(hipEventCreate(&e->ev[i][j]));
 
 	OPENHIP(hipStreamSynchronize(e->stream));
@@ -288,9 +319,9 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv, e->d_off, e->d_pass };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_off, e->h_pass, e->h_fm };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -298,6 +329,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	free(e->sym_tmp);
 	if(e->host_frames) { for(int i = 0; i < e->frame_slots; i++) free(e->host_frames[i]); free(e->host_frames); }
 	hvk_secam_free(e->secam);
+	hvk_tail_free(e->tail);
 	free(e->slots);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
@@ -506,6 +538,51 @@ extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int wi
 
 /* ---- render ---- */
 
+/* FM video: bring the host copy of the current batch up to `upto` samples -- fetch the
+ * modulator's input from the device and run the serial tail over it (hvk_tail.c) */
+static int _fm_upto(hvk_engine *e, size_t upto)
+{
+	if(upto <= e->fm_done) return(HVK_OK);
+	if(upto > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	const size_t n = upto - e->fm_done;
+	HIPCHK(hipMemcpyAsync(e->h_fm + e->fm_done * 2, e->d_out + e->fm_done * 2, n * 4, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	int r = hvk_tail_fm_apply(e->tail, e->fm_batch_pos + (int64_t) e->fm_done, (int64_t) n, e->h_fm + e->fm_done * 2);
+	if(r != HVK_OK) return(r);
+	e->fm_done = upto;
+	return(HVK_OK);
+}
+
+/* ... and to its end, so that the phasor stands at the next batch's first sample */
+static int _fm_finish(hvk_engine *e)
+{
+	if(!e->fm_launched) return(HVK_OK);
+	int r = _fm_upto(e, (size_t) e->last_frames * e->t.k.frame_samples);
+	if(r == HVK_OK) e->fm_launched = 0;
+	return(r);
+}
+
+extern "C" int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsamples)
+{
+	if(!e) return(HVK_ERROR);
+	if(!e->t.k.has_passthru || !e->tail) return(HVK_UNSUPPORTED);
+	return(hvk_tail_passthru_push(e->tail, iq, nsamples));
+}
+
+extern "C" int hvk_host_offset_stream(hvk_engine_t *e, int64_t first, int64_t count, int16_t *out)
+{
+	if(!e || !out) return(HVK_ERROR);
+	if(!e->t.k.has_offset || !e->tail) return(HVK_UNSUPPORTED);
+	return(hvk_tail_offset_stream(e->tail, first, count, out));
+}
+
+extern "C" int hvk_host_fm_video(hvk_engine_t *e, int16_t *iq, int64_t count)
+{
+	if(!e || !iq) return(HVK_ERROR);
+	if(!e->t.k.fm_video || !e->tail) return(HVK_UNSUPPORTED);
+	return(hvk_tail_fm_apply(e->tail, hvk_tail_fm_position(e->tail), count, iq));
+}
+
 extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots)
 {
 	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
@@ -517,6 +594,17 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 
 	HIPCHK(hipSetDevice(e->device));
 	HIPCHK(hipStreamSynchronize(e->stream));   /* pinned staging is reused */
+
+	if(k.fm_video)
+	{
+		/* the FM phasor is one serial chain over the stream (hvk_tail.c): finish the
+		 * previous batch, then take frames in order, no gaps */
+		int r = _fm_finish(e);
+		if(r != HVK_OK) return(r);
+		if(stride != 1 || first_frame * FS != hvk_tail_fm_position(e->tail)) return(HVK_UNSUPPORTED);
+		e->fm_batch_pos = first_frame * FS;
+		e->fm_done = 0;
+	}
 
 	for(int i = 0; i < nframes; i++)
 	{
@@ -547,6 +635,17 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 			                        f->fb_width, f->fb_height, s->interlaced, e->h_chroma + (size_t) i * FS);
 			if(r != HVK_OK) return(r);
 			e->secam_next++;
+		}
+
+		if(e->h_off)
+		{
+			int r = hvk_tail_offset_stream(e->tail, f->frame_index * FS, FS, e->h_off + (size_t) i * FS * 2);
+			if(r != HVK_OK) return(r);
+		}
+		if(e->h_pass)
+		{
+			int r = hvk_tail_passthru_stream(e->tail, f->frame_index * FS, FS, e->h_pass + (size_t) i * FS * 2);
+			if(r != HVK_OK) return(r);
 		}
 
 		if(e->audio)
@@ -606,6 +705,8 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	}
 	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * FS * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_off) HIPCHK(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_pass) HIPCHK(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
 	{
 		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
@@ -638,6 +739,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	if(e->staged < 1) return(HVK_ERROR);
+	/* FM video: the device buffer holds the modulator's input; the samples exist on the host only (hvk_fetch) */
+	if(e->t.k.fm_video && d_iq != NULL) return(HVK_UNSUPPORTED);
 
 	HIPCHK(hipSetDevice(e->device));
 
@@ -689,8 +792,13 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
 	if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
 	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
+	if(!e->t.k.fm_video && (e->t.k.swap_iq || e->d_off || e->d_pass))
+	{
+		if((r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream)) != HVK_OK) return(r);
+	}
 
 	e->last_frames = e->staged;
+	e->fm_launched = e->t.k.fm_video;
 	return(HVK_OK);
 }
 
@@ -725,6 +833,13 @@ extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t coun
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
+	if(e->t.k.fm_video)
+	{
+		int r = _fm_upto(e, first + count);
+		if(r != HVK_OK) return(r);
+		memcpy(iq, e->h_fm + first * 2, count * 4);
+		return(HVK_OK);
+	}
 	HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
 	return(HVK_OK);
@@ -734,6 +849,7 @@ extern "C" long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t co
 {
 	if(!e || !dst || type < HVK_UINT8 || type > HVK_FLOAT) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(e->t.k.fm_video) return(HVK_UNSUPPORTED);   /* the final samples are not on the device */
 	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
 
 	const size_t unit = (type <= HVK_INT8 ? 1 : (type <= HVK_INT16 ? 2 : 4)) * (complex_out ? 2 : 1);

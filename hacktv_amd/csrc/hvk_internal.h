@@ -78,6 +78,8 @@ typedef struct {
 	int32_t frame_samples;
 	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
 	int32_t teletext;       /* teletext symbol table present */
+	int32_t fm_video;       /* the engine's device output is the FM modulator's input (hvk_tail.c does the rest) */
+	int32_t swap_iq, has_offset, has_passthru;   /* complex tail done by hvk_k_tail (not FM video) */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;
 
@@ -126,6 +128,9 @@ typedef struct {
 	int16_t *secam_fir;         /* 15 taps, applied order */
 	int16_t *secam_notch;       /* 51 taps, applied order */
 	int16_t secam_dmin[2], secam_dmax[2];
+	/* FM video and frequency offset (src/video.c:4563-4607) */
+	int32_t fmv_level; hvk_c32_t *fmv_lut;
+	hvk_c32_t offset_delta;
 } hvk_tables_t;
 
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate);
@@ -139,6 +144,21 @@ hvk_secam_t *hvk_secam_new(const hvk_tables_t *t);
 void hvk_secam_free(hvk_secam_t *s);
 int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int fb_width, int fb_height,
                     int fb_interlaced, int16_t *out);
+
+/* The serial part of the output tail (hvk_tail.c): FM video phasor, offset phasor, passthru queue */
+typedef struct hvk_tail hvk_tail_t;
+hvk_tail_t *hvk_tail_new(const hvk_tables_t *t);
+void hvk_tail_free(hvk_tail_t *s);
+int hvk_tail_passthru_push(hvk_tail_t *s, const int16_t *iq, size_t nsamples);
+/* offset phasor (int16 pairs, phase >> 16) for output positions [first, first + count); forward only */
+int hvk_tail_offset_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out);
+/* passthru samples added to output positions [first, first + count) (whole lines; zeros where the
+ * source has ended); forward only */
+int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out);
+/* FM video: the whole tail on the host, in place, for output positions [first, first + count);
+ * strictly sequential */
+int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq);
+int64_t hvk_tail_fm_position(const hvk_tail_t *s);
 
 /* Host audio-rate control path (hvk_audio.c) */
 typedef struct hvk_audio hvk_audio_t;

@@ -61,6 +61,8 @@ extern "C" {
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
+int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
+                    int nframes, hipStream_t stream);
 int hvk_launch_convert(const void *iq, size_t count, int type, int cplx, void *dst, hipStream_t stream);
 
 #ifdef __cplusplus

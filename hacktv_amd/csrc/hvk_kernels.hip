@@ -868,6 +868,81 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
 }
 
 /* ------------------------------------------------------------------ */
+/* The complex tail of the line pipeline for modes whose modulator is on the
+ * device (everything but FM video): swap_iq, frequency offset, passthru, in the
+ * reference's order (src/video.c:4587-4645). One I/Q pair (one dword) per lane
+ * and step: the accesses of a wavefront are 256 contiguous bytes per stream.
+ * off: the host's offset phasor, phase >> 16 as int16 pairs (hvk_tail.c);
+ * pass: the external samples, zero where the source has ended. Both are dense
+ * over the batch; frame i of the output sits at frame slot i * out_stride. */
+template<int SWAP, int OFFSET, int PASS>
+__global__ __launch_bounds__(256) void hvk_k_tail(int *__restrict__ iq, const int *__restrict__ off, const int *__restrict__ pass,
+                                                  long frame_samples, long out_stride, long total)
+{
+	const long step = (long) gridDim.x * blockDim.x;
+
+	for(long n = (long) blockIdx.x * blockDim.x + threadIdx.x; n < total; n += step)
+	{
+		const long f = n / frame_samples;
+		const long o = f * out_stride * frame_samples + (n - f * frame_samples);
+		const int v = iq[o];
+		int i = (short) v, q = v >> 16;
+
+		if(SWAP)
+		{
+			const int x = i;
+			i = q;
+			q = x;
+		}
+
+		if(OFFSET)
+		{
+			/* cint16_mul, src/common.h:58-67 */
+			const int b = off[n];
+			const int bi = (short) b, bq = b >> 16;
+			const int ri = i * bi - q * bq;
+			const int rq = i * bq + q * bi;
+			i = (short) (ri >> 15);
+			q = (short) (rq >> 15);
+		}
+
+		if(PASS)
+		{
+			/* int16 wrap-around add, src/video.c:3535-3538 */
+			const int a = pass[n];
+			i = (short) (i + (short) a);
+			q = (short) (q + (a >> 16));
+		}
+
+		iq[o] = (i & 0xFFFF) | (q << 16);
+	}
+}
+
+extern "C" int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
+                               int nframes, hipStream_t stream)
+{
+	const long total = frame_samples * nframes;
+	long blocks = (total + 255) / 256;
+	if(blocks > 256 * 32) blocks = 256 * 32;
+	if(total <= 0 || (!swap && !off && !pass)) return(HVK_OK);
+
+#define TAIL(S, O, P) hipLaunchKernelGGL((hvk_k_tail<S, O, P>), dim3(blocks), dim3(256), 0, stream, \
+	(int *) iq, (const int *) off, (const int *) pass, frame_samples, out_stride, total)
+	switch((swap ? 4 : 0) | (off ? 2 : 0) | (pass ? 1 : 0))
+	{
+	case 1: TAIL(0, 0, 1); break;
+	case 2: TAIL(0, 1, 0); break;
+	case 3: TAIL(0, 1, 1); break;
+	case 4: TAIL(1, 0, 0); break;
+	case 5: TAIL(1, 0, 1); break;
+	case 6: TAIL(1, 1, 0); break;
+	case 7: TAIL(1, 1, 1); break;
+	}
+#undef TAIL
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+/* ------------------------------------------------------------------ */
 /* launchers                                                           */
 
 extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream)

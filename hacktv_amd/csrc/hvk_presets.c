@@ -109,6 +109,20 @@ static void _vsb(hvk_config_t *c, double upper, double lower, double video_level
 	c->sync_level = sync;
 }
 
+static void _fm_video(hvk_config_t *c, double deviation, double white, double black, double blank, double sync)
+{
+	c->output_type = HVK_INT16_COMPLEX;
+	c->modulation = HVK_FM;
+	c->fm_level = 1.0;
+	c->fm_deviation = deviation;         /* Hz per unit of signal */
+	c->level = 1.0;
+	c->video_level = 1.0;
+	c->white_level = white;
+	c->black_level = black;
+	c->blanking_level = blank;
+	c->sync_level = sync;
+}
+
 static void _fm_sound(hvk_config_t *c, double level, double carrier, double deviation, int preemph)
 {
 	c->fm_mono_level = level;
@@ -136,6 +150,9 @@ static const struct {
 	{ "secam", "SECAM colour, 25 fps, 625 lines, unmodulated (real)" },
 	{ "m",     "NTSC colour, 30/1.001 fps, 525 lines, AM (complex), 4.5 MHz FM audio" },
 	{ "ntsc",  "NTSC colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
+	{ "pal-fm",   "PAL colour, 25 fps, 625 lines, FM (complex), 6.5 MHz FM audio" },
+	{ "secam-fm", "SECAM colour, 25 fps, 625 lines, FM (complex), 6.5 MHz FM audio" },
+	{ "ntsc-fm",  "NTSC colour, 30/1.001 fps, 525 lines, FM (complex), 6.5 MHz FM audio" },
 	{ NULL, NULL },
 };
 
@@ -214,6 +231,30 @@ int hvk_config_preset(hvk_config_t *c, const char *id)
 		_baseband(c, 100.0 / 140, 7.5 / 140, 0.0 / 140, -40.0 / 140);
 		_raster_525(c);
 		_colour_ntsc(c);
+	}
+	else if(strcmp(id, "pal-fm") == 0)
+	{
+		/* src/video.c:213-272 (satellite FM, 16 MHz/V) */
+		_fm_video(c, 16e6, 0.50, -0.20, -0.20, -0.50);
+		_raster_625(c, 0.00000020);
+		_colour_pal(c);
+		_fm_sound(c, 0.06, 6500000, 85000, HVK_50US);
+	}
+	else if(strcmp(id, "secam-fm") == 0)
+	{
+		/* src/video.c:659-714 */
+		_fm_video(c, 16e6, 0.50, -0.20, -0.20, -0.50);
+		_raster_625(c, 0.00000020);
+		_colour_secam(c);
+		_fm_sound(c, 0.05, 6500000, 85000, HVK_50US);
+	}
+	else if(strcmp(id, "ntsc-fm") == 0)
+	{
+		/* src/video.c:859-918 */
+		_fm_video(c, 16e6, 0.5000, -0.1607, -0.2143, -0.5000);
+		_raster_525(c);
+		_colour_ntsc(c);
+		_fm_sound(c, 0.05, 6500000, 85000, HVK_50US);
 	}
 	else
 	{

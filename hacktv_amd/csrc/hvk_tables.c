@@ -611,7 +611,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	/* what the engine renders */
 	if(c->type != HVK_RASTER_625 && c->type != HVK_RASTER_525) return(HVK_UNSUPPORTED);
-	if(c->modulation == HVK_FM) return(HVK_UNSUPPORTED);
+	/* FM video with --filter uses fixed pre-emphasis tap tables designed outside the reference
+	 * (src/video.c:2017-2113); they are not reproduced here */
+	if(c->modulation == HVK_FM && c->vfilter) return(HVK_UNSUPPORTED);
+	if(c->modulation == HVK_FM && (c->fm_level <= 0 || c->fm_deviation <= 0)) return(HVK_ERROR);
 	if(c->colour_mode == HVK_SECAM && c->secam_field_id) return(HVK_UNSUPPORTED);
 	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
@@ -638,7 +641,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(t->k.width < 64 || t->k.width > 8192) return(HVK_UNSUPPORTED);
 
 	/* levels (src/video.c:3858-3881) */
-	slevel = c->level;
+	/* sub-carriers ride on the FM baseband at unit level; the overall level then scales the FM phasor */
+	slevel = c->modulation == HVK_FM ? 1.0 : c->level;
 	level = c->video_level * slevel;
 
 	if(c->invert_video)
@@ -841,6 +845,25 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	if((r = _build_audio(t, slevel)) != HVK_OK) return(r);
 
+	/* FM video: carrier at 0 Hz, deviation per unit of signal (src/video.c:4563-4585, :2218-2243) */
+	if(c->modulation == HVK_FM)
+	{
+		t->fmv_level = (int16_t) round(INT16_MAX * (c->fm_level * c->level));
+		t->fmv_lut = malloc(sizeof(hvk_c32_t) * 65536);
+		if(!t->fmv_lut) return(HVK_OUT_OF_MEMORY);
+		for(i = INT16_MIN; i <= INT16_MAX; i++)
+		{
+			t->fmv_lut[i - INT16_MIN] = _unit_phasor(2.0 * M_PI / t->sample_rate * (0 + (double) i / INT16_MAX * c->fm_deviation));
+		}
+		t->k.fm_video = 1;
+	}
+
+	/* complex tail (src/video.c:4587-4645) */
+	t->k.swap_iq = c->swap_iq != 0;
+	t->k.has_offset = c->offset != 0;
+	t->k.has_passthru = c->passthru != 0;
+	if(c->offset != 0) t->offset_delta = _unit_phasor(2.0 * M_PI / t->sample_rate * c->offset);
+
 	if(c->teletext)
 	{
 		/* 625-line systems only (src/hacktv.c:1182-1186) */
@@ -870,6 +893,7 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->secam_bell);
 	free(t->secam_fir);
 	free(t->secam_notch);
+	free(t->fmv_lut);
 	memset(t, 0, sizeof(*t));
 }
 
@@ -893,6 +917,7 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
 	if(!strcmp(name, "vfilter_itaps")) return(_give(dst, max_bytes, t->vf_itaps, (long) t->k.vf_ntaps * 2));
 	if(!strcmp(name, "vfilter_qtaps")) return(_give(dst, max_bytes, t->vf_qtaps, t->vf_qtaps ? (long) t->k.vf_ntaps * 2 : 0));
 	if(!strcmp(name, "fm_mono_lut"))   return(_give(dst, max_bytes, t->fm_lut, 65536L * 8));
+	if(!strcmp(name, "fm_video_lut"))  return(_give(dst, max_bytes, t->fmv_lut, t->fmv_lut ? 65536L * 8 : 0));
 	if(!strcmp(name, "nicam_taps"))    return(_give(dst, max_bytes, t->nicam_taps, (long) t->k.nicam_ntaps * 2));
 	if(!strcmp(name, "nicam_cc"))      return(_give(dst, max_bytes, t->nicam_cc, (long) t->k.nicam_cc_len * 4));
 	if(!strcmp(name, "limiter_shape")) return(_give(dst, max_bytes, t->limiter_shape, t->has_limiter ? 21L * 2 : 0));

@@ -1,0 +1,280 @@
+/* hvk_tail.c -- the serial part of the output tail of the line pipeline.
+ *
+ * After the audio process the reference runs up to four more processes on the
+ * finished I/Q line, in this order (src/video.c:4563-4645):
+ *
+ *   fmmod     FM video: the I sample steers a Q31 phasor, which replaces the
+ *             sample (src/video.c:3452-3464, :2299-2335)
+ *   swap_iq   exchanges I and Q (src/video.c:3466-3480)
+ *   offset    multiplies by a free-running Q31 phasor (src/video.c:3482-3515)
+ *   passthru  adds an external int16 I/Q stream, whole lines at a time
+ *             (src/video.c:3517-3541)
+ *
+ * Both phasors are the floor-after-every-step recurrence of src/common.h:80-89
+ * with an atan2/cos/sin re-normalisation every 32767 samples: sample n needs
+ * sample n - 1 bit for bit, so they run here, once, in stream
+ * order on the host.
+ *
+ *  - The offset phasor does not depend on the signal: it is generated as a
+ *    side stream (int16 pairs, phase >> 16) and the multiply is device work
+ *    (hvk_k_tail), as are the swap and the passthru add.
+ *  - The FM video phasor depends on every sample of the composite, which the
+ *    device renders: hvk_tail_fm_apply() runs the whole tail over the fetched
+ *    baseband on the host. It is the engine's only sample-rate host pass.
+ *
+ * Pipeline fill: with the video filter on, the line pipeline hands these
+ * processes delay_lines never-emitted lines of full width before the first real
+ * one (src/video.c:3235-3248 sets their width); the offset phasor advances over
+ * them and the passthru source loses its first delay_lines * width samples.
+ * FM video never runs with the filter here (hvk_tables.c refuses it).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "hvk_internal.h"
+
+struct hvk_tail {
+	const hvk_tables_t *t;
+	int W;
+	int64_t prime;              /* delay_lines * width */
+
+	/* offset phasor; steps counts the multiplications done so far */
+	hvk_c32_t off_phase, off_delta;
+	int32_t off_counter;
+	int64_t off_steps;
+
+	/* FM video phasor */
+	hvk_c32_t fm_phase;
+	int32_t fm_counter;
+	int64_t fm_pos;             /* next output position to modulate */
+
+	/* passthru queue: q[0] is source sample q_base */
+	int16_t *q;
+	size_t q_len, q_cap;
+	int64_t q_base;
+	int ended;                  /* a line found the source short: nothing is added from then on */
+};
+
+hvk_tail_t *hvk_tail_new(const hvk_tables_t *t)
+{
+	hvk_tail_t *s = calloc(1, sizeof(hvk_tail_t));
+	if(!s) return(NULL);
+
+	s->t = t;
+	s->W = t->k.width;
+	s->prime = (int64_t) t->k.delay_lines * t->k.width;
+
+	/* src/video.c:4596-4602: the offset phasor starts at INT16_MAX (sic), so
+	 * its >> 16 is zero until the first re-normalisation */
+	s->off_phase.i = INT16_MAX;
+	s->off_phase.q = 0;
+	s->off_counter = INT16_MAX;
+	s->off_delta = t->offset_delta;
+
+	/* src/video.c:2225-2227 */
+	s->fm_phase.i = INT32_MAX;
+	s->fm_phase.q = 0;
+	s->fm_counter = INT16_MAX;
+
+	return(s);
+}
+
+void hvk_tail_free(hvk_tail_t *s)
+{
+	if(!s) return;
+	free(s->q);
+	free(s);
+}
+
+/* src/common.h:80-89 */
+static inline hvk_c32_t _mul(hvk_c32_t a, hvk_c32_t b)
+{
+	hvk_c32_t r;
+	r.i = (int32_t) (((int64_t) a.i * b.i - (int64_t) a.q * b.q) >> 31);
+	r.q = (int32_t) (((int64_t) a.i * b.q + (int64_t) a.q * b.i) >> 31);
+	return(r);
+}
+
+static inline hvk_c32_t _renormalise(hvk_c32_t p)
+{
+	const double ra = atan2(p.q, p.i);
+	hvk_c32_t r;
+	r.i = lround(cos(ra) * INT32_MAX);
+	r.q = lround(sin(ra) * INT32_MAX);
+	return(r);
+}
+
+/* one step of the offset process: the value the sample is multiplied by */
+static inline hvk_c16_t _offset_step(hvk_tail_t *s)
+{
+	hvk_c16_t b;
+
+	s->off_phase = _mul(s->off_phase, s->off_delta);
+	b.i = s->off_phase.i >> 16;
+	b.q = s->off_phase.q >> 16;
+
+	if(--s->off_counter == 0)
+	{
+		s->off_phase = _renormalise(s->off_phase);
+		s->off_counter = INT16_MAX;
+	}
+
+	s->off_steps++;
+	return(b);
+}
+
+int hvk_tail_offset_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out)
+{
+	const int64_t want = s->prime + first;
+	int64_t n;
+
+	if(first < 0 || count < 0 || want < s->off_steps) return(HVK_ERROR);
+
+	while(s->off_steps < want) (void) _offset_step(s);
+
+	for(n = 0; n < count; n++)
+	{
+		const hvk_c16_t b = _offset_step(s);
+		out[n * 2 + 0] = b.i;
+		out[n * 2 + 1] = b.q;
+	}
+
+	return(HVK_OK);
+}
+
+int hvk_tail_passthru_push(hvk_tail_t *s, const int16_t *iq, size_t nsamples)
+{
+	if(nsamples == 0) return(HVK_OK);
+	if(!iq) return(HVK_ERROR);
+
+	if(s->q_len + nsamples > s->q_cap)
+	{
+		size_t cap = s->q_cap ? s->q_cap : 1 << 16;
+		int16_t *q;
+		while(cap < s->q_len + nsamples) cap *= 2;
+		q = realloc(s->q, cap * 2 * sizeof(int16_t));
+		if(!q) return(HVK_OUT_OF_MEMORY);
+		s->q = q;
+		s->q_cap = cap;
+	}
+
+	memcpy(s->q + s->q_len * 2, iq, nsamples * 2 * sizeof(int16_t));
+	s->q_len += nsamples;
+	return(HVK_OK);
+}
+
+/* Drop queued source samples below source index `upto` */
+static void _passthru_discard(hvk_tail_t *s, int64_t upto)
+{
+	int64_t drop = upto - s->q_base;
+	if(drop <= 0) return;
+	if((size_t) drop > s->q_len) drop = s->q_len;
+	memmove(s->q, s->q + drop * 2, (s->q_len - drop) * 2 * sizeof(int16_t));
+	s->q_len -= drop;
+	s->q_base += drop;
+}
+
+int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out)
+{
+	const int W = s->W;
+	int64_t p;
+
+	if(first < 0 || count < 0 || first % W || count % W) return(HVK_ERROR);
+
+	memset(out, 0, count * 2 * sizeof(int16_t));
+
+	for(p = first; p < first + count && !s->ended; p += W)
+	{
+		/* the line at output position p takes source samples [p + prime, p + prime + W),
+		 * all of them or -- once the source is short -- none, now and ever after
+		 * (src/video.c:3522-3533) */
+		const int64_t src = p + s->prime;
+
+		if(src < s->q_base) return(HVK_ERROR);   /* forward only */
+
+		if(src + W > s->q_base + (int64_t) s->q_len)
+		{
+			s->ended = 1;
+			break;
+		}
+
+		memcpy(out + (p - first) * 2, s->q + (src - s->q_base) * 2, W * 2 * sizeof(int16_t));
+	}
+
+	_passthru_discard(s, first + count + s->prime);
+	return(HVK_OK);
+}
+
+int64_t hvk_tail_fm_position(const hvk_tail_t *s)
+{
+	return(s->fm_pos);
+}
+
+int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)
+{
+	const hvk_tables_t *t = s->t;
+	const hvk_c32_t *lut = t->fmv_lut;
+	const int32_t level = t->fmv_level;
+	const int swap = t->k.swap_iq, offset = t->k.has_offset, pass = t->k.has_passthru;
+	int16_t *line = NULL;
+	int64_t n;
+
+	if(!lut || first != s->fm_pos || count < 0) return(HVK_ERROR);
+	if(pass && (first % s->W || count % s->W)) return(HVK_ERROR);
+
+	if(pass)
+	{
+		line = malloc((size_t) s->W * 2 * sizeof(int16_t));
+		if(!line) return(HVK_OUT_OF_MEMORY);
+	}
+
+	for(n = 0; n < count; n++)
+	{
+		int16_t i, q;
+
+		/* src/video.c:2321-2335 */
+		s->fm_phase = _mul(s->fm_phase, lut[iq[n * 2] - INT16_MIN]);
+		i = (int16_t) (((s->fm_phase.i >> 16) * level) >> 15);
+		q = (int16_t) (((s->fm_phase.q >> 16) * level) >> 15);
+
+		if(--s->fm_counter == 0)
+		{
+			s->fm_phase = _renormalise(s->fm_phase);
+			s->fm_counter = INT16_MAX;
+		}
+
+		if(swap)
+		{
+			const int16_t x = i;
+			i = q;
+			q = x;
+		}
+
+		if(offset)
+		{
+			/* src/common.h:58-67 */
+			const hvk_c16_t b = _offset_step(s);
+			const int32_t ri = (int32_t) i * b.i - (int32_t) q * b.q;
+			const int32_t rq = (int32_t) i * b.q + (int32_t) q * b.i;
+			i = (int16_t) (ri >> 15);
+			q = (int16_t) (rq >> 15);
+		}
+
+		iq[n * 2 + 0] = i;
+		iq[n * 2 + 1] = q;
+
+		if(pass && (n + 1) % s->W == 0)
+		{
+			/* the line that just ended */
+			const int64_t p = first + n + 1 - s->W;
+			int x;
+			int r = hvk_tail_passthru_stream(s, p, s->W, line);
+			if(r != HVK_OK) { free(line); return(r); }
+			for(x = 0; x < s->W * 2; x++) iq[(p - first) * 2 + x] = (int16_t) (iq[(p - first) * 2 + x] + line[x]);
+		}
+	}
+
+	free(line);
+	s->fm_pos += count;
+	return(HVK_OK);
+}

@@ -55,6 +55,8 @@ typedef struct {
 	int64_t frames_done;    /* frames handed out completely */
 	int ended;              /* source has ended: no more batches */
 	int frame_in_batch_pull;
+	int passthru_primed;    /* the start-up line's share of the passthru source has been queued */
+	int16_t *passbuf;
 	vid_line_t out;
 } shim_t;
 
@@ -74,13 +76,14 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 
 	if(pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("--pixelrate (resampler)"));
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
-	if(c->modulation == VID_FM) return(_refuse("FM video"));
+	if(c->modulation == VID_FM && c->fm_energy_dispersal) return(_refuse("FM energy dispersal"));
+	if(c->modulation == VID_FM && c->vfilter) return(_refuse("the FM video pre-emphasis filter (--filter with an FM mode)"));
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->acp || c->vits || c->vitc || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
-	if(c->offset != 0 || c->passthru || c->raw_bb_file || c->swap_iq || c->s_video) return(_refuse("offset / passthru / raw baseband / swap-iq / s-video"));
+	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
 	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
 	if(c->secam_field_id) return(_refuse("SECAM field id"));
 
@@ -135,6 +138,11 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->am_mono_carrier = c->am_mono_carrier;
 	h->vfilter = c->vfilter;
 	h->teletext = c->teletext != NULL;
+	h->fm_level = c->fm_level;
+	h->fm_deviation = c->fm_deviation;
+	h->swap_iq = c->swap_iq;
+	h->offset = c->offset;
+	h->passthru = c->passthru != NULL;
 
 	return(VID_OK);
 }
@@ -194,6 +202,18 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	s->bline = 1;
 	s->processes = (void *) m;
 
+	if(s->conf.passthru)
+	{
+		/* src/video.c:4609-4622 */
+		s->passthru = strcmp(s->conf.passthru, "-") == 0 ? stdin : fopen(s->conf.passthru, "rb");
+		if(!s->passthru)
+		{
+			perror(s->conf.passthru);
+			vid_free(s);
+			return(VID_ERROR);
+		}
+	}
+
 	if(s->conf.teletext)
 	{
 		/* tt_init() reads width, pixel_rate and the levels from vid_t (src/teletext.c:1057-1074) */
@@ -214,11 +234,13 @@ void vid_free(vid_t *s)
 	av_close(&s->av);       /* src/video.c:4711 */
 
 	if(s->conf.teletext && s->tt.vid) tt_free(&s->tt);
+	if(s->passthru && s->passthru != stdin) fclose(s->passthru);   /* src/video.c:4783-4786 */
 
 	if(m)
 	{
 		hvk_close(m->e);
 		free(m->iq);
+		free(m->passbuf);
 		free(m);
 	}
 
@@ -290,6 +312,31 @@ static int _next_batch(vid_t *s, shim_t *m)
 		av_read_audio(&s->av, &a, &an);
 		if(a == NULL || an == 0) break;
 		if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+	}
+
+	/* --passthru: the lines of these frames (and, once, of the filter's start-up lines) from the
+	 * external signal (src/video.c:3517-3541); a short source simply ends */
+	if(s->passthru)
+	{
+		size_t want = (size_t) n * m->info.frame_samples, got;
+
+		if(!m->passthru_primed)
+		{
+			want += (size_t) m->info.delay_lines * m->info.width;
+			m->passthru_primed = 1;
+		}
+
+		if(!m->passbuf) m->passbuf = malloc(sizeof(int16_t) * 2 * ((size_t) m->batch * m->info.frame_samples + (size_t) m->info.delay_lines * m->info.width));
+		if(!m->passbuf) return(-1);
+
+		got = 0;
+		while(got < want && !feof(s->passthru))
+		{
+			size_t r = fread(m->passbuf + got * 2, sizeof(int16_t) * 2, want - got, s->passthru);
+			if(r == 0) break;
+			got += r;
+		}
+		if(hvk_passthru_write(m->e, m->passbuf, got) != HVK_OK) return(-1);
 	}
 
 	if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);

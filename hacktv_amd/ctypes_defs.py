@@ -62,6 +62,11 @@ class HvkConfig(C.Structure):
         ("am_mono_carrier", C.c_double),
         ("vfilter", C.c_int),
         ("teletext", C.c_int),
+        ("fm_level", C.c_double),
+        ("fm_deviation", C.c_double),
+        ("swap_iq", C.c_int),
+        ("offset", C.c_int64),
+        ("passthru", C.c_int),
     ]
 
 

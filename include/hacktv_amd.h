@@ -138,6 +138,16 @@ int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples);
  * rendered with audio (0 when the mode has no audio sub-carriers). */
 size_t hvk_audio_needed(const hvk_engine_t *e, int nframes);
 
+/* --passthru (conf.passthru != 0): the next nsamples int16 I/Q pairs of the
+ * external signal that is added to the output (src/video.c:3517-3541), in
+ * stream order from the source's first sample. Like the reference the engine
+ * adds whole lines only: a line for which the source is short gets nothing,
+ * and neither does any later line (the reference's end-of-file behaviour), so
+ * queue at least the samples of the frames about to be rendered -- plus, once,
+ * delay_lines * width more when the video filter is on: the line pipeline
+ * feeds its never-emitted start-up line through the process as well. */
+int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsamples);
+
 /* Render the next nframes frames of the stream. slots[i] names the frame
  * slot shown by frame i. d_iq, if not NULL, is a DEVICE pointer to
  * nframes * frame_samples * 2 int16 that receives the samples; if NULL the
@@ -190,11 +200,32 @@ int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
  * hvk_render(). Needs no device. */
 int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int height, int interlaced, int16_t *out);
 
+/* --offset, host half on its own: the values the offset process multiplies
+ * output samples [first, first + count) by (src/video.c:3482-3515): count int16
+ * pairs, the free-running Q31 phasor >> 16, advanced over the pipeline's
+ * start-up line first when the video filter is on. Forward only. Needs no
+ * device. */
+int hvk_host_offset_stream(hvk_engine_t *e, int64_t first, int64_t count, int16_t *out);
+
+/* FM video, host half on its own: run the serial tail (FM phasor, then swap,
+ * offset and passthru as configured) over the next `count` samples of the
+ * stream, in place: iq holds the modulator's input in its I values on entry
+ * and the modulated I/Q pairs on return. Use it instead of, not next to,
+ * hvk_fetch(). Needs no device. */
+int hvk_host_fm_video(hvk_engine_t *e, int16_t *iq, int64_t count);
+
 /* Wait for the engine's stream; returns HVK_OK or the HIP failure. */
 int hvk_sync(hvk_engine_t *e);
 
 /* Copy rendered samples [first, first + count) of the last render (engine
- * buffer) to host memory: what the shim hands to rf_write(). */
+ * buffer) to host memory: what the shim hands to rf_write().
+ * FM video modes (conf.modulation == HVK_FM): the device renders the
+ * modulator's input (composite + sound carriers); the FM phasor -- a serial
+ * recurrence over every sample, src/video.c:2299-2335 -- and whatever follows
+ * it (swap, offset, passthru) run on the host inside this call, once per
+ * sample and in stream order: frames must be rendered consecutively, d_iq must
+ * be NULL, hvk_fetch_as() is not available, and samples of a batch that were
+ * never fetched are modulated when the next batch is staged. */
 int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
 
 /* Sample formats of the reference's file sink (src/rf.h:31-36) */

@@ -9,8 +9,8 @@
  *
  * Everything the reference's engine supports but this engine does not render
  * (scramblers, MAC, VITS/VITC/WSS/CC608/ACP/SiS inserters, DANCE, A2 stereo,
- * FM video, offset, passthru, raw baseband input) has no field here; the
- * shim refuses such configurations rather than silently dropping them.
+ * FM energy dispersal, raw baseband input) has no field here; the shim
+ * refuses such configurations rather than silently dropping them.
  */
 #ifndef HVK_CONFIG_H
 #define HVK_CONFIG_H
@@ -35,7 +35,7 @@ extern "C" {
 #define HVK_NONE 0
 #define HVK_AM   1
 #define HVK_VSB  2
-#define HVK_FM   3 /* not rendered by this engine (serial at video rate) */
+#define HVK_FM   3 /* the composite is rendered on the device; the FM phasor itself is a serial host pass */
 
 /* Colour modes: src/video.h:76-81 */
 #define HVK_MONOCHROME 0
@@ -57,7 +57,7 @@ typedef struct hvk_config_t {
 
 	int output_type;            /* HVK_INT16_COMPLEX | HVK_INT16_REAL */
 
-	int modulation;             /* HVK_NONE | HVK_AM | HVK_VSB */
+	int modulation;             /* HVK_NONE | HVK_AM | HVK_VSB | HVK_FM */
 	double video_bw;            /* Hz, low-pass cut-off for AM / baseband */
 	double vsb_upper_bw;        /* Hz */
 	double vsb_lower_bw;        /* Hz */
@@ -123,6 +123,17 @@ typedef struct hvk_config_t {
 	int teletext;               /* != 0: teletext packets will be supplied for the VBI lines
 	                             * (625-line modes; the reference's conf.teletext names the page
 	                             * source, which stays with the caller: hvk_teletext_packets()) */
+
+	/* FM video (modulation == HVK_FM), src/video.h:141-142 */
+	double fm_level;
+	double fm_deviation;        /* Hz per unit of signal */
+
+	/* The complex-output tail of the line pipeline (src/video.c:4589-4645), applied in this order */
+	int swap_iq;                /* --swap-iq */
+	int64_t offset;             /* --offset: frequency shift in Hz, 0 = none */
+	int passthru;               /* != 0: an int16 I/Q stream is added to the output; the samples are
+	                             * supplied with hvk_passthru_write() (the reference's conf.passthru
+	                             * names the file, which stays with the caller) */
 
 } hvk_config_t;
 

@@ -31,6 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refprobe  # noqa: E402
+import util  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -54,6 +55,15 @@ CASES = [
     # teletext from a raw packet file (tests/golden/ttraw.bin: 42-byte records, no wall clock involved)
     ("i_tt",          "i",    16000000, ["--noaudio", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO,  False, 3),
     ("l_tt",          "l",    16000000, ["--filter", "--teletext", "raw:@TTRAW@"],  refprobe.FLAG_FILTER,   False, 3),
+    # the complex tail of the pipeline: swap_iq, frequency offset, passthru (util.passthru_signal written to a
+    # scratch file), and FM video -- an 8th element names the hvk_config_t members the flags set
+    ("i_offset",      "i",    16000000, ["--filter", "--offset", "1000000"], refprobe.FLAG_FILTER,          False, 3, {"offset": 1000000}),
+    ("i_swap_pass",   "i",    16000000, ["--filter", "--swap-iq", "--passthru", "@PASS@"], refprobe.FLAG_FILTER, False, 4, {"swap_iq": 1, "passthru": 1}),
+    ("m_offset_pass", "m",    13500000, ["--offset", "-250000", "--passthru", "@PASS@"], 0,                 False, 4, {"offset": -250000, "passthru": 1}),
+    ("pal_fm",        "pal-fm", 16000000, [],                      0,                                      False, 3),
+    ("ntsc_fm",       "ntsc-fm", 13500000, [],                     0,                                      False, 2),
+    ("secam_fm_tail", "secam-fm", 16000000, ["--swap-iq", "--offset", "500000"], 0,                        False, 3, {"swap_iq": 1, "offset": 500000}),
+    ("pal_fm_pass",   "pal-fm", 16000000, ["--offset", "300000", "--passthru", "@PASS@"], 0,               False, 4, {"offset": 300000, "passthru": 1}),
 ]
 
 TABLES = [
@@ -62,7 +72,7 @@ TABLES = [
     ("fm_mono_lut", np.int32), ("nicam_taps", np.int16), ("nicam_cc", np.int16),
     ("limiter_shape", np.int16), ("limiter_vtaps", np.int32), ("limiter_ftaps", np.int32),
     ("fm_secam_lut", np.int32), ("fm_secam_bell", np.int16), ("fm_secam_fir", np.int16), ("secam_l_fir", np.int16),
-    ("teletext_lut", np.int16),
+    ("teletext_lut", np.int16), ("fm_video_lut", np.int32),
 ]
 
 
@@ -87,7 +97,11 @@ def main():
     src = {}
 
     ttraw = os.path.join(GOLD, "ttraw.bin")
-    for cid, mode, sr, flags, pflags, real, nframes in CASES:
+    passfile = "/tmp/hvk_passthru.bin"
+    util.passthru_signal().tofile(passfile)
+    for case in CASES:
+        cid, mode, sr, flags, pflags, real, nframes = case[:7]
+        extra = case[7] if len(case) > 7 else {}
         teletext = any("@TTRAW@" in f for f in flags)
         with refprobe.RefProbe(mode, sr, pflags, teletext=("raw:" + ttraw) if teletext else None) as r:
             info = dict(r.info)
@@ -104,7 +118,7 @@ def main():
         W, L = info["width"], info["lines"]
         fs = W * L
         bps = 2 if real else 4
-        data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw) for f in flags], nframes * fs * bps)
+        data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw).replace("@PASS@", passfile) for f in flags], nframes * fs * bps)
         assert len(data) == nframes * fs * bps, (cid, len(data))
         per_frame = [hashlib.sha256(data[: (i + 1) * fs * bps]).hexdigest() for i in range(nframes)]
 
@@ -117,7 +131,7 @@ def main():
 
         digests[cid] = {
             "mode": mode, "sample_rate": sr, "cli_flags": flags, "probe_flags": pflags, "real": real,
-            "width": W, "lines": L, "frames": nframes, "teletext": teletext,
+            "width": W, "lines": L, "frames": nframes, "teletext": teletext, "extra": extra,
             "sha256_cumulative": per_frame,   # sha256 of the first 1, 2, ... frames
             "info": info, "tables": tabs,
         }

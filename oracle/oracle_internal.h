@@ -126,6 +126,15 @@ struct orc_t {
 	int nicam_buf_len;
 	int audio_primed;
 
+	/* FM video, offset, passthru (oracle_tail.c) */
+	orc_mod_t fm_video;
+	c32_t offset_phase, offset_delta;
+	int32_t offset_counter;
+	const int16_t *pass_src;
+	long pass_len, pass_pos;
+	int pass_eof;
+	int16_t *passline;
+
 	/* SECAM colour process (oracle_secam.c) */
 	int16_t sc_level;
 	c32_t *sc_lut;
@@ -164,6 +173,11 @@ void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int
 int orc_teletext_init(orc_t *s);
 void orc_teletext_free(orc_t *s);
 void orc_teletext_render(orc_t *s, int16_t *o, const uint8_t packet[45]);
+
+/* oracle_tail.c */
+int orc_tail_init(orc_t *s);
+void orc_tail_free(orc_t *s);
+void orc_tail_line(orc_t *s, int16_t *iq, int width);
 
 /* oracle_audio.c */
 int orc_audio_init(orc_t *s);

@@ -41,7 +41,7 @@ orc_t *orc_open(const hvk_config_t *conf, unsigned int sample_rate)
 	s->sample_rate = sample_rate;
 	s->pixel_rate = sample_rate;
 
-	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0)
+	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0)
 	{
 		orc_close(s);
 		return(NULL);
@@ -60,6 +60,7 @@ void orc_close(orc_t *s)
 	if(!s) return;
 	orc_free_tables(s);
 	orc_audio_free(s);
+	orc_tail_free(s);
 	orc_teletext_free(s);
 	free(s->S);
 	free(s->last_raster);
@@ -106,6 +107,7 @@ long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
 	if(strcmp(name, "vfilter_itaps") == 0) return(_copy(dst, max_bytes, s->vf_itaps, (long) s->vf_ntaps * sizeof(int16_t)));
 	if(strcmp(name, "vfilter_qtaps") == 0) return(_copy(dst, max_bytes, s->vf_qtaps, (long) s->vf_ntaps * sizeof(int16_t)));
 	if(strcmp(name, "fm_mono_lut") == 0) return(_copy(dst, max_bytes, s->fm_mono.lut, 65536L * sizeof(c32_t)));
+	if(strcmp(name, "fm_video_lut") == 0) return(_copy(dst, max_bytes, s->fm_video.lut, s->fm_video.lut ? 65536L * sizeof(c32_t) : 0));
 	if(strcmp(name, "nicam_taps") == 0) return(_copy(dst, max_bytes, s->nicam.taps, (long) s->nicam.ntaps * sizeof(int16_t)));
 	if(strcmp(name, "nicam_cc") == 0) return(_copy(dst, max_bytes, s->nicam.cc, (long) s->nicam.cc_len * sizeof(c16_t)));
 	if(strcmp(name, "fm_secam_lut") == 0) return(_copy(dst, max_bytes, s->sc_lut, s->sc_lut ? 65536L * sizeof(c32_t) : 0));
@@ -291,7 +293,16 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 	 * delay_lines * width samples before the first visible sample. */
 	if(!s->audio_primed)
 	{
-		for(k = 0; k < s->delay_lines; k++) orc_audio_line(s, NULL, W, NULL);
+		for(k = 0; k < s->delay_lines; k++)
+		{
+			/* ... and so do the processes behind it: the offset phasor advances over the
+			 * start-up line and the passthru source loses a line to it (the filter gives
+			 * that line its full width, src/video.c:3235-3248) */
+			int16_t *fill = calloc(W * 2, sizeof(int16_t));
+			orc_audio_line(s, NULL, W, NULL);
+			orc_tail_line(s, fill, W);
+			free(fill);
+		}
 		s->audio_primed = 1;
 	}
 
@@ -347,6 +358,7 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 		}
 
 		orc_audio_line(s, out, W, s->last_carrier + (g - g0) * W * 2);
+		orc_tail_line(s, out, W);
 		o += W;
 	}
 

@@ -38,6 +38,9 @@ void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop);
  * modes only. Up to 16 frames may be queued ahead. */
 int orc_teletext_packets(orc_t *s, long frame_index, const uint8_t *packets, uint32_t mask);
 
+/* --passthru: the external int16 I/Q signal (kept by reference), from its first sample */
+void orc_set_passthru(orc_t *s, const int16_t *iq, long nsamples);
+
 /* Render the next nlines emitted lines (interleaved I/Q int16). Returns
  * the number of samples (pairs) written. */
 long orc_render_lines(orc_t *s, int16_t *iq, long nlines);

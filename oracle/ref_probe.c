@@ -250,6 +250,8 @@ long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
 	}
 	if(strcmp(name, "fm_mono_lut") == 0)
 		return(_copy(dst, max_bytes, s->fm_mono.lut, s->fm_mono.lut ? 65536L * sizeof(cint32_t) : 0));
+	if(strcmp(name, "fm_video_lut") == 0)
+		return(_copy(dst, max_bytes, s->fm_video.lut, s->fm_video.lut ? 65536L * sizeof(cint32_t) : 0));
 	if(strcmp(name, "fm_secam_lut") == 0)
 		return(_copy(dst, max_bytes, s->fm_secam.lut, s->fm_secam.lut ? 65536L * sizeof(cint32_t) : 0));
 	if(strcmp(name, "fm_secam_bell") == 0)

@@ -24,6 +24,8 @@ def lib():
         L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
         L.orc_teletext_packets.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_uint32]
+        L.orc_set_passthru.restype = None
+        L.orc_set_passthru.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_render_lines.restype = C.c_long
         L.orc_render_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_last_raster.restype = C.c_long
@@ -99,6 +101,11 @@ class Oracle:
         a = np.ascontiguousarray(stereo, np.int16)
         self._keep.append(a)
         lib().orc_set_audio(self.p, a.ctypes.data, a.shape[0], 1 if loop else 0)
+
+    def set_passthru(self, iq):
+        a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)
+        self._keep.append(a)
+        lib().orc_set_passthru(self.p, a.ctypes.data, a.shape[0])
 
     def teletext_packets(self, frame_index, packets, mask):
         p = np.ascontiguousarray(packets, np.uint8)

@@ -35,7 +35,7 @@ def test_presets_match_the_reference_mode_ids():
     while H.lib().hvk_preset_id(i):
         ids.append(H.lib().hvk_preset_id(i).decode())
         i += 1
-    assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc"]
+    assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc", "pal-fm", "secam-fm", "ntsc-fm"]
     assert H.lib().hvk_config_preset(ctypes.byref(H.HvkConfig()), b"nope") == -1
 
 
@@ -57,7 +57,7 @@ def test_unsupported_configurations_are_refused():
     bad = []
     c = H.preset("l"); c.secam_field_id = 1; bad.append((c, 16000000))        # SECAM field identification lines
     c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
-    c = H.preset("i"); c.modulation = 3; bad.append((c, 16000000))            # FM video
+    c = H.preset("pal-fm", H.FLAG_FILTER); bad.append((c, 16000000))          # FM video with the fixed pre-emphasis tap tables
     c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster other than 625 / 525
     for conf, sr in bad:
         try:

@@ -11,11 +11,13 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=None):
+def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=None, passthru=None):
     batch = batch or nframes
     out = []
     with H.Engine(conf, sr, device=0, max_frames=batch) as e:
         e.frame_upload(0, frame, interlaced)
+        if passthru is not None:
+            e.passthru_write(passthru)
         done = 0
         while done < nframes:
             n = min(batch, nframes - done)
@@ -46,14 +48,17 @@ def test_device_yuv_table_equals_oracle(golden):
 
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "i_mono", "g_full",
                                   "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full",
-                                  "i_tt", "l_tt"])
+                                  "i_tt", "l_tt",
+                                  "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
+                                  "pal_fm_pass"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     nframes = c["frames"]
     iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
-                 teletext=golden.teletext_rows if c.get("teletext") else None)
+                 teletext=golden.teletext_rows if c.get("teletext") else None,
+                 passthru=util.passthru_signal() if conf.passthru else None)
     fs = c["width"] * c["lines"]
     # excerpted lines first: a readable failure
     idx = golden.lines[case + "_idx"]
@@ -225,7 +230,8 @@ def test_dropin_binary_equals_reference_cli(golden):
         p.wait()
         return bytes(out)
 
-    for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt"):
+    util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
+    for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail"):
         c = golden.cases[case]
         fs = c["width"] * c["lines"]
         bps = 2 if c["real"] else 4

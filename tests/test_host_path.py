@@ -9,10 +9,11 @@ import util
 
 HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_ghost", "vfilter_itaps",
                "vfilter_qtaps", "fm_mono_lut", "nicam_taps", "nicam_cc", "limiter_shape", "limiter_vtaps",
-               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir", "teletext_lut"]
+               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir", "teletext_lut", "fm_video_lut"]
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt",
+                                  "pal_fm", "ntsc_fm", "secam_fm_tail"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
     with H.Engine(conf, sr, device=-1) as e, oracle.Oracle(conf, sr) as o:
@@ -114,3 +115,83 @@ def test_secam_host_prepass_equals_oracle(golden):
     assert not ((d[:, outside] - got[:, outside]) % 65536).any()
     # and nothing is added outside the sub-carrier window
     assert not got[:, :82].any()
+
+
+# ---- the complex tail: offset phasor, passthru queue, FM video (hvk_tail.c) ----
+
+def _oracle_frames(golden, conf, sr, case, nlines, passthru=False):
+    with oracle.Oracle(conf, sr) as o:
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        if passthru:
+            o.set_passthru(util.passthru_signal())
+        return o.render_lines(nlines)
+
+
+@pytest.mark.parametrize("case", ["i_offset", "m_offset_pass"])
+def test_offset_stream_reproduces_the_oracle(golden, case):
+    """out_with_offset == cint16_mul(out_without, host offset stream): the host phasor chain
+    (incl. its start at INT16_MAX, the 32767-sample re-normalisation and the start-up line it
+    runs over when the filter is on) against the oracle's per-line process."""
+    conf, sr = golden.conf(case)
+    c = golden.cases[case]
+    W, nl = c["width"], 700
+    want = _oracle_frames(golden, conf, sr, case, nl, passthru=bool(conf.passthru)).astype(np.int32)
+    plain_conf, _ = golden.conf(case)
+    plain_conf.offset = 0
+    plain_conf.passthru = 0
+    a = _oracle_frames(golden, plain_conf, sr, case, nl).astype(np.int32)
+    with H.Engine(conf, sr, device=-1) as e:
+        # forward only, in two pieces
+        b = np.concatenate([e.host_offset_stream(0, 300 * W), e.host_offset_stream(300 * W, (nl - 300) * W)]).astype(np.int32)
+        prime = e.info["delay_lines"] * W
+    assert np.abs(b[:32766 - prime]).max() <= 1 and np.abs(b[40000:41000]).max() > 30000   # the reference's quirk
+    got = np.empty_like(a)
+    got[:, 0] = (a[:, 0] * b[:, 0] - a[:, 1] * b[:, 1]) >> 15
+    got[:, 1] = (a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0]) >> 15
+    got = got.astype(np.int16).astype(np.int32)
+    if conf.passthru:
+        p = util.passthru_signal().astype(np.int32)
+        n = min(len(p) // W, nl) * W     # whole lines only
+        got[:n] = (got[:n] + p[:n]).astype(np.int16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"])
+def test_fm_video_host_tail_equals_oracle(golden, case):
+    """hvk_host_fm_video() over the oracle's un-modulated composite == the oracle's FM output
+    (pinned to the reference CLI by test_oracle_golden): FM phasor, then swap / offset /
+    passthru on the host, fed in uneven pieces."""
+    conf, sr = golden.conf(case)
+    c = golden.cases[case]
+    W, L = c["width"], c["lines"]
+    nl = 3 * L if conf.passthru else 400
+    want = _oracle_frames(golden, conf, sr, case, nl, passthru=bool(conf.passthru))
+    pre_conf, _ = golden.conf(case)
+    pre_conf.modulation = 0          # HVK_NONE: same levels (conf.level is 1), no modulator
+    pre_conf.swap_iq = pre_conf.passthru = 0
+    pre_conf.offset = 0
+    pre = _oracle_frames(golden, pre_conf, sr, case, nl)
+    with H.Engine(conf, sr, device=-1) as e:
+        if conf.passthru:
+            sig = util.passthru_signal()
+            e.passthru_write(sig[:1000])
+            e.passthru_write(sig[1000:])
+        cuts = [0, 7 * W, 8 * W, 250 * W, nl * W]
+        got = np.concatenate([e.host_fm_video(pre[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, want)
+
+
+def test_passthru_needs_whole_lines_and_stays_ended(golden):
+    conf, sr = golden.conf("pal_fm_pass")
+    W = golden.cases["pal_fm_pass"]["width"]
+    with H.Engine(conf, sr, device=-1) as e:
+        e.passthru_write(np.ones((W + 10, 2), np.int16))
+        z = np.zeros((3 * W, 2), np.int16)
+        a = e.host_fm_video(z)
+        e.passthru_write(np.ones((4 * W, 2), np.int16))     # too late: the source has ended
+        b = e.host_fm_video(z)
+    conf.passthru = 0
+    with H.Engine(conf, sr, device=-1) as e:
+        ref = np.concatenate([e.host_fm_video(z), e.host_fm_video(z)])
+    assert np.array_equal(a[:W], ref[:W] + 1) and np.array_equal(a[W:], ref[W:3 * W]) and np.array_equal(b, ref[3 * W:])

@@ -11,17 +11,21 @@ import util
 
 CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_full", "ntsc_bb", "i_mono", "g_full",
               "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full", "i_tt", "l_tt"]
+# the complex tail (swap_iq, offset, passthru) and FM video; the passthru source ends inside frame 3
+CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     W, L = c["width"], c["lines"]
-    nframes = min(2, c["frames"])
+    nframes = c["frames"] if c.get("extra", {}).get("passthru") else min(2, c["frames"])
     with oracle.Oracle(conf, sr) as o:
         o.set_frame(golden.frame(case))
         o.set_audio(golden.audio, True)
+        if conf.passthru:
+            o.set_passthru(util.passthru_signal())
         if c.get("teletext"):
             for f in range(nframes + 1):
                 o.teletext_packets(f, golden.teletext_rows(f), 0xFFFFFFFF)
@@ -40,7 +44,7 @@ def test_oracle_stream_matches_reference_cli(golden, case):
         assert np.array_equal(mine, ref[j]), "line %d of %s" % (g, case)
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full", "l_tt"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full", "l_tt", "pal_fm", "ntsc_fm"])
 def test_oracle_tables_match_reference(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)

@@ -14,8 +14,18 @@ TABLE_DTYPES = {
     "fm_mono_lut": np.int32, "nicam_taps": np.int16, "nicam_cc": np.int16,
     "limiter_shape": np.int16, "limiter_vtaps": np.int32, "limiter_ftaps": np.int32,
     "fm_secam_lut": np.int32, "fm_secam_bell": np.int16, "fm_secam_fir": np.int16, "secam_l_fir": np.int16,
-    "teletext_lut": np.int16,
+    "teletext_lut": np.int16, "fm_video_lut": np.int32,
 }
+
+
+def passthru_signal(nsamples=1600300):
+    """The external I/Q signal of the --passthru cases: a fixed integer pattern (int16 pairs), 2.5 PAL
+    frames and a bit long so that runs end inside it -- in the middle of a line."""
+    n = np.arange(nsamples, dtype=np.int64)
+    iq = np.empty((nsamples, 2), np.int16)
+    iq[:, 0] = (n * 7919) % 4001 - 2000
+    iq[:, 1] = (n * 104729) % 3001 - 1500
+    return iq
 
 
 class Golden:
@@ -41,6 +51,8 @@ class Golden:
         c = self.cases[case]
         conf = H.preset(c["mode"], c["probe_flags"])
         conf.teletext = 1 if c.get("teletext") else 0
+        for k, v in c.get("extra", {}).items():
+            setattr(conf, k, v)
         return conf, c["sample_rate"]
 
     def teletext_rows(self, frame):
@@ -54,8 +66,10 @@ class Golden:
         p[:, 3:] = rec[frame * 32:(frame + 1) * 32]
         return p
 
-    def cli_flags(self, case):
-        return [f.replace("@TTRAW@", os.path.join(GOLD, "ttraw.bin")) for f in self.cases[case]["cli_flags"]]
+    def cli_flags(self, case, passfile="/tmp/hvk_passthru.bin"):
+        """The reference CLI's flags for the case; passthru cases expect passthru_signal() at `passfile`."""
+        return [f.replace("@TTRAW@", os.path.join(GOLD, "ttraw.bin")).replace("@PASS@", passfile)
+                for f in self.cases[case]["cli_flags"]]
 
 
 def stream_bytes(iq, real):
