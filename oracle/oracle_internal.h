@@ -103,6 +103,20 @@ struct orc_t {
 	int vf_ntaps;
 	int16_t *vf_itaps, *vf_qtaps;
 	int delay_lines;
+	int vf_delay;               /* extra samples of window: _calc_filter_delay (src/video.c:3620-3625) */
+	int16_t *vf_win;            /* the last vf_ntaps + vf_delay input samples, oldest first */
+
+	/* --pixelrate resampler (src/video.c:3627-3651, src/fir.c:393-428) */
+	int rs_L, rs_D, rs_ataps, rs_d;
+	int16_t *rs_taps;           /* [L][ataps], the order they are applied in; NULL: no resampler */
+	int16_t *rs_win;
+	int max_width;              /* widest chunk the pipeline can emit */
+
+	/* pipeline state (oracle_video.c) */
+	long chunks_done;
+	int16_t *cbuf, *ciq, *ccar, *prev_r;
+	int *prev_w;
+	int *last_widths; long last_nwidths;
 
 	/* current source frame */
 	const uint32_t *fb;

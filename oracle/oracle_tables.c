@@ -439,7 +439,52 @@ int orc_build_tables(orc_t *s)
 			s->vf_itaps = _quantise_reversed(lp, ntaps, 1);
 		}
 
-		if(s->vf_type) s->delay_lines = (ntaps / 2 + fw - 1) / fw; /* :3759 */
+		if(s->vf_type)
+		{
+			s->delay_lines = (ntaps / 2 + fw - 1) / fw; /* :3759 */
+			s->vf_delay = fw - ((ntaps / 2) % fw);      /* _calc_filter_delay, :3620-3625 */
+			s->vf_win = calloc(ntaps + s->vf_delay, sizeof(int16_t));
+		}
+	}
+
+	/* --pixelrate: rational resampler pixel rate -> sample rate (src/video.c:3627-3651,
+	 * src/fir.c:393-428 and :260-296) */
+	s->max_width = s->width;
+	if(s->pixel_rate != s->sample_rate)
+	{
+		int64_t a = s->sample_rate, b = s->pixel_rate, t;
+		int L, D, ntaps, total, j;
+		double *taps;
+
+		while(b) { t = a % b; a = b; b = t; }
+		L = s->sample_rate / a;
+		D = s->pixel_rate / a;
+
+		ntaps = (21 * L) | 1;
+		taps = calloc(ntaps, sizeof(double));
+		if(!taps) return(-1);
+
+		if(L > D) orc_low_pass(taps, ntaps, L, 0.45, L);              /* up */
+		else      orc_low_pass(taps, ntaps, L, 0.45 * L / D, L);      /* down */
+
+		/* poly-phase order: phase p's taps are itaps[p * ataps ...], oldest sample first */
+		s->rs_L = L;
+		s->rs_D = D;
+		s->rs_ataps = (ntaps + L - 1) / L;
+		total = s->rs_ataps * L;
+		s->rs_taps = calloc(total, sizeof(int16_t));
+		s->rs_win = calloc(s->rs_ataps, sizeof(int16_t));
+		j = total - s->rs_ataps;
+		for(i = ntaps - 1; i >= 0; i--)
+		{
+			s->rs_taps[j] = lround(taps[i] * 32767.0);
+			j -= s->rs_ataps;
+			if(j < 0) j += total + 1;
+		}
+		free(taps);
+
+		s->rs_d = L;
+		s->max_width = ((long) s->width * L + D - 1) / D;    /* fir_int16_output_size */
 	}
 
 	return(0);
@@ -457,5 +502,8 @@ void orc_free_tables(orc_t *s)
 	free(s->burst_win);
 	free(s->vf_itaps);
 	free(s->vf_qtaps);
+	free(s->vf_win);
+	free(s->rs_taps);
+	free(s->rs_win);
 	if(s->conf.colour_mode == HVK_SECAM) orc_secam_free(s);
 }

@@ -34,12 +34,17 @@
 
 orc_t *orc_open(const hvk_config_t *conf, unsigned int sample_rate)
 {
+	return(orc_open_rates(conf, sample_rate, 0));
+}
+
+orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate)
+{
 	orc_t *s = calloc(1, sizeof(orc_t));
 	if(!s) return(NULL);
 
 	s->conf = *conf;
 	s->sample_rate = sample_rate;
-	s->pixel_rate = sample_rate;
+	s->pixel_rate = pixel_rate ? pixel_rate : sample_rate;   /* src/video.c:3839 */
 
 	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0)
 	{
@@ -65,6 +70,12 @@ void orc_close(orc_t *s)
 	free(s->S);
 	free(s->last_raster);
 	free(s->last_carrier);
+	free(s->last_widths);
+	free(s->cbuf);
+	free(s->ciq);
+	free(s->ccar);
+	free(s->prev_r);
+	free(s->prev_w);
 	free(s);
 }
 
@@ -76,7 +87,7 @@ int orc_info(orc_t *s, int32_t *out, int n)
 		s->white_level, s->black_level, s->blanking_level, s->sync_level,
 		(int32_t) s->colour_lookup_width, s->burst_left, s->burst_width,
 		s->burst_phase.i, s->burst_phase.q,
-		s->chroma_ntaps, 0, s->width,
+		s->chroma_ntaps, 0, s->max_width,
 		s->fm_mono.level, s->nicam.ntaps, s->nicam.sps, s->nicam.dsl, s->nicam.decimation,
 		s->nicam.cc_len,
 		s->am_mono.level, s->am_mono.delta.i, s->am_mono.delta.q,
@@ -272,98 +283,172 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 	}
 }
 
-static int16_t _sample(orc_t *s, long n)
+/* ---- the line pipeline behind the raster, one chunk (= one raster line's worth of samples) at a time ----
+ *
+ * The reference's processes pass line slots down a ring (src/video.c:4676-4688): a process with
+ * a two-slot window (resampler, filter) reads the newer slot and writes the older one, so its
+ * output for raster line N lands in the slot of line N - 1, and at start-up in a slot whose line
+ * number is still 0. Slots with line < 1 are dropped at the output (src/video.c:4936-4952) but
+ * they do carry samples, and every later process runs over them. Hence:
+ *   - the video filter carries `width` samples of latency (ntaps / 2 + its configured delay,
+ *     src/video.c:3620-3625), exactly the one slot its output is shifted by: with the filter on,
+ *     chunk c of the output holds the filtered raster line c - 1 and the first chunk is dropped;
+ *   - the resampler (src/video.c:3627-3651) has NO latency to make up for its slot shift: its first
+ *     chunk -- the resampled raster line 1 -- is dropped as well, and the stream starts with line 2;
+ *   - the audio process and the tail run over the dropped chunks too: their state
+ *     is ahead by the dropped chunks' widths when the first emitted sample is made. */
+
+/* the poly-phase resampler of src/fir.c:304-355 (fir_int16_process with interpolation L,
+ * decimation D): returns the number of samples made from `n` inputs */
+static int _resample(orc_t *s, const int16_t *in, int n, int16_t *out)
 {
-	const int16_t *l;
-	if(n < 0) return(0);
-	l = orc_line_ptr(s, n / s->width);
-	return(l ? l[n % s->width] : 0);
+	int x = 0, i, y;
+
+	for(i = 0; i < n;)
+	{
+		if(s->rs_d >= s->rs_L)
+		{
+			s->rs_d -= s->rs_L;
+			memmove(s->rs_win, s->rs_win + 1, (s->rs_ataps - 1) * sizeof(int16_t));
+			s->rs_win[s->rs_ataps - 1] = in[i++];
+		}
+
+		for(; s->rs_d < s->rs_L; s->rs_d += s->rs_D)
+		{
+			const int16_t *taps = &s->rs_taps[s->rs_d * s->rs_ataps];
+			int32_t a = 0;
+			for(y = 0; y < s->rs_ataps; y++) a += (int32_t) s->rs_win[y] * taps[y];
+			a >>= 15;
+			out[x++] = a < INT16_MIN ? INT16_MIN : (a > INT16_MAX ? INT16_MAX : a);
+		}
+	}
+
+	return(x);
+}
+
+/* the video filter as the reference runs it (src/fir.c:304-355 real, :564-615 real -> complex):
+ * a window of ataps + delay samples; each output is made from the OLDEST ataps of them */
+static void _filter(orc_t *s, const int16_t *in, int n, int16_t *iq)
+{
+	const int lwin = s->vf_ntaps + s->vf_delay;
+	int x, k;
+
+	for(x = 0; x < n; x++)
+	{
+		int32_t ai = 0, aq = 0;
+
+		memmove(s->vf_win, s->vf_win + 1, (lwin - 1) * sizeof(int16_t));
+		s->vf_win[lwin - 1] = in[x];
+
+		for(k = 0; k < s->vf_ntaps; k++) ai += (int32_t) s->vf_win[k] * s->vf_itaps[k];
+		if(s->vf_type == 3)
+		{
+			for(k = 0; k < s->vf_ntaps; k++) aq += (int32_t) s->vf_win[k] * s->vf_qtaps[k];
+		}
+		ai >>= 15;
+		aq >>= 15;
+		iq[x * 2 + 0] = ai < INT16_MIN ? INT16_MIN : (ai > INT16_MAX ? INT16_MAX : ai);
+		iq[x * 2 + 1] = aq < INT16_MIN ? INT16_MIN : (aq > INT16_MAX ? INT16_MAX : aq);
+	}
 }
 
 long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 {
-	int W = s->width;
-	long g0 = s->emitted, g, o = 0;
-	int x, k;
+	const int W = s->width;
+	const int ndrop = (s->rs_taps ? 1 : 0) + s->delay_lines;
+	long o = 0, emitted = 0;
+	int x;
 
 	if(nlines <= 0) return(0);
 
-	/* Lines the pipeline produces before the first emitted one carry the
-	 * audio process too: the audio-rate state is advanced by
-	 * delay_lines * width samples before the first visible sample. */
-	if(!s->audio_primed)
+	if(!s->cbuf)
 	{
-		for(k = 0; k < s->delay_lines; k++)
-		{
-			/* ... and so do the processes behind it: the offset phasor advances over the
-			 * start-up line and the passthru source loses a line to it (the filter gives
-			 * that line its full width, src/video.c:3235-3248) */
-			int16_t *fill = calloc(W * 2, sizeof(int16_t));
-			orc_audio_line(s, NULL, W, NULL);
-			orc_tail_line(s, fill, W);
-			free(fill);
-		}
-		s->audio_primed = 1;
+		s->cbuf = malloc(s->max_width * sizeof(int16_t));
+		s->ciq = malloc(s->max_width * 2 * sizeof(int16_t));
+		s->ccar = malloc(s->max_width * 2 * sizeof(int16_t));
+		s->prev_r = calloc((size_t) (s->delay_lines + 1) * s->max_width, sizeof(int16_t));
+		s->prev_w = calloc(s->delay_lines + 1, sizeof(int));
 	}
-
-	/* the filter looks 25 samples into the next line; every line also takes
-	 * the leading sync edge of its successor: raster one line ahead */
-	_raster_until(s, g0 + nlines, g0 - 1);
 
 	free(s->last_raster);
 	free(s->last_carrier);
-	s->last_raster = malloc(nlines * W * sizeof(int16_t));
-	s->last_carrier = calloc(nlines * W * 2, sizeof(int16_t));
-	s->last_raster_len = nlines * W;
-	s->last_carrier_len = nlines * W;
+	free(s->last_widths);
+	s->last_raster = malloc(nlines * s->max_width * sizeof(int16_t));
+	s->last_carrier = calloc(nlines * s->max_width * 2, sizeof(int16_t));
+	s->last_widths = calloc(nlines, sizeof(int));
+	s->last_raster_len = 0;
+	s->last_carrier_len = 0;
+	s->last_nwidths = 0;
 
-	for(g = g0; g < g0 + nlines; g++)
+	while(emitted < nlines)
 	{
-		int16_t *out = iq + o * 2;
-		long base = g * W;
+		const long c = s->chunks_done;
+		const int16_t *line;
+		int w, slot;
 
-		memcpy(s->last_raster + (g - g0) * W, orc_line_ptr(s, g), W * sizeof(int16_t));
+		/* every line also takes the leading sync edge of its successor: raster one line ahead */
+		_raster_until(s, c + 1, c - 1);
+		line = orc_line_ptr(s, c);
+
+		if(s->rs_taps) w = _resample(s, line, W, s->cbuf);
+		else
+		{
+			memcpy(s->cbuf, line, W * sizeof(int16_t));
+			w = W;
+		}
+
+		/* the chunk the filter's output is centred on: delay_lines chunks back */
+		slot = c % (s->delay_lines + 1);
+		if(emitted < nlines && c >= ndrop)
+		{
+			const int back = (int) ((c - s->delay_lines) % (s->delay_lines + 1));
+			const int bw = s->delay_lines ? s->prev_w[back] : w;
+			const int16_t *br = s->delay_lines ? s->prev_r + (size_t) back * s->max_width : s->cbuf;
+			memcpy(s->last_raster + s->last_raster_len, br, bw * sizeof(int16_t));
+			s->last_raster_len += bw;
+		}
+		if(s->delay_lines)
+		{
+			memcpy(s->prev_r + (size_t) slot * s->max_width, s->cbuf, w * sizeof(int16_t));
+			s->prev_w[slot] = w;
+		}
 
 		if(s->vf_type == 0)
 		{
-			for(x = 0; x < W; x++)
+			for(x = 0; x < w; x++)
 			{
-				out[x * 2 + 0] = _sample(s, base + x);
-				out[x * 2 + 1] = 0;
+				s->ciq[x * 2 + 0] = s->cbuf[x];
+				s->ciq[x * 2 + 1] = 0;
 			}
 		}
-		else
+		else _filter(s, s->cbuf, w, s->ciq);
+
+		memset(s->ccar, 0, w * 2 * sizeof(int16_t));
+		orc_audio_line(s, s->ciq, w, s->ccar);
+		orc_tail_line(s, s->ciq, w);
+
+		if(c >= ndrop)
 		{
-			int h = s->vf_ntaps / 2;
-			int16_t *win = malloc((W + s->vf_ntaps) * sizeof(int16_t));
-
-			/* the samples this line's outputs see: 25 before, 25 after */
-			for(x = 0; x < W + s->vf_ntaps - 1; x++) win[x] = _sample(s, base + x - h);
-
-			for(x = 0; x < W; x++)
-			{
-				int32_t ai = 0, aq = 0;
-				for(k = 0; k < s->vf_ntaps; k++) ai += (int32_t) win[x + k] * s->vf_itaps[k];
-				if(s->vf_type == 3)
-				{
-					for(k = 0; k < s->vf_ntaps; k++) aq += (int32_t) win[x + k] * s->vf_qtaps[k];
-				}
-				ai >>= 15;
-				aq >>= 15;
-				out[x * 2 + 0] = ai < INT16_MIN ? INT16_MIN : (ai > INT16_MAX ? INT16_MAX : ai);
-				out[x * 2 + 1] = aq < INT16_MIN ? INT16_MIN : (aq > INT16_MAX ? INT16_MAX : aq);
-			}
-
-			free(win);
+			memcpy(iq + o * 2, s->ciq, w * 2 * sizeof(int16_t));
+			memcpy(s->last_carrier + s->last_carrier_len * 2, s->ccar, w * 2 * sizeof(int16_t));
+			s->last_carrier_len += w;
+			s->last_widths[s->last_nwidths++] = w;
+			o += w;
+			emitted++;
 		}
 
-		orc_audio_line(s, out, W, s->last_carrier + (g - g0) * W * 2);
-		orc_tail_line(s, out, W);
-		o += W;
+		s->chunks_done++;
 	}
 
 	s->emitted += nlines;
 	return(o);
+}
+
+long orc_last_widths(orc_t *s, int32_t *dst, long max)
+{
+	long n = s->last_nwidths < max ? s->last_nwidths : max, i;
+	for(i = 0; dst && i < n; i++) dst[i] = s->last_widths[i];
+	return(s->last_nwidths);
 }
 
 long orc_last_raster(orc_t *s, int16_t *dst, long max_samples)

@@ -13,6 +13,8 @@
 typedef struct orc_t orc_t;
 
 orc_t *orc_open(const hvk_config_t *conf, unsigned int sample_rate);
+/* with --pixelrate: the raster is built at pixel_rate and resampled to sample_rate (0: same rate) */
+orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate);
 void orc_close(orc_t *s);
 
 /* Geometry / levels in the order tests/refprobe.py INFO_NAMES lists */
@@ -44,6 +46,9 @@ void orc_set_passthru(orc_t *s, const int16_t *iq, long nsamples);
 /* Render the next nlines emitted lines (interleaved I/Q int16). Returns
  * the number of samples (pairs) written. */
 long orc_render_lines(orc_t *s, int16_t *iq, long nlines);
+
+/* Widths of the lines the last orc_render_lines call emitted (they vary with --pixelrate) */
+long orc_last_widths(orc_t *s, int32_t *dst, long max);
 
 /* Stage taps for tests: the final raster (I channel, before filter/audio) of
  * the lines produced by the last orc_render_lines call */

@@ -24,6 +24,10 @@ def lib():
         L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
         L.orc_teletext_packets.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_uint32]
+        L.orc_open_rates.restype = C.c_void_p
+        L.orc_open_rates.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+        L.orc_last_widths.restype = C.c_long
+        L.orc_last_widths.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_passthru.restype = None
         L.orc_set_passthru.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_render_lines.restype = C.c_long
@@ -64,9 +68,9 @@ INFO_NAMES = [
 
 
 class Oracle:
-    def __init__(self, conf, sample_rate):
+    def __init__(self, conf, sample_rate, pixel_rate=0):
         self.conf = conf
-        self.p = lib().orc_open(C.addressof(conf), sample_rate)
+        self.p = lib().orc_open_rates(C.addressof(conf), sample_rate, pixel_rate)
         if not self.p:
             raise RuntimeError("orc_open failed")
         v = np.zeros(64, np.int32)
@@ -114,10 +118,16 @@ class Oracle:
             raise RuntimeError("orc_teletext_packets failed")
 
     def render_lines(self, nlines):
-        w = self.info["width"]
+        w = self.info["max_width"]
         buf = np.zeros(nlines * w * 2, np.int16)
         got = lib().orc_render_lines(self.p, buf.ctypes.data, nlines)
         return buf[: got * 2].reshape(got, 2)
+
+    def last_widths(self):
+        n = lib().orc_last_widths(self.p, None, 0)
+        a = np.zeros(n, np.int32)
+        lib().orc_last_widths(self.p, a.ctypes.data, n)
+        return a
 
     def last_raster(self):
         n = lib().orc_last_raster(self.p, None, 0)
