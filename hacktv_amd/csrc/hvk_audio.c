@@ -287,7 +287,10 @@ struct hvk_audio {
 	size_t src_len, src_cap, src_pos;
 
 	int interp;             /* 32 kHz tick accumulator (src/video.c:3273-3276) */
-	int64_t pos;            /* stream samples generated so far (multiple of width) */
+	int64_t pos;            /* stream samples generated so far (always a line boundary) */
+	int64_t line_no;        /* lines generated so far */
+	int64_t last_pos;       /* first sample of the line held in `scratch` */
+	int last_w;             /* its width; 0: none yet */
 
 	_phasor_t fm, am;
 	_limiter_t lim;
@@ -301,7 +304,7 @@ struct hvk_audio {
 	int64_t sym_k0;
 	size_t sym_len, sym_cap;
 
-	int16_t *scratch;       /* one line of carriers when the caller wants none */
+	int16_t *scratch;       /* the carriers of the last line generated */
 };
 
 hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
@@ -345,7 +348,7 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		_nicam_reset(&a->nicam, t);
 	}
 
-	a->scratch = malloc(sizeof(int16_t) * 2 * a->width);
+	a->scratch = malloc(sizeof(int16_t) * 2 * t->max_width);
 	if(!a->scratch) { free(a); return(NULL); }
 
 	return(a);
@@ -493,12 +496,22 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 	}
 }
 
-/* Advance the stream by one line; carriers (width int16 pairs) receives the
+/* Width of line g of the audio process's stream. The process runs line by line on what
+ * the stage before it hands over: raster lines, or -- with the resampler -- its chunks,
+ * the outputs made from raster line g: [ceil(g W L / D), ceil((g + 1) W L / D)). */
+static int _line_width(const hvk_audio_t *a, int64_t g)
+{
+	const hvk_kconst_t *k = &a->t->k;
+	if(k->rs_L == 0) return(k->width);
+	return((int) ((((g + 1) * k->width * k->rs_L + k->rs_D - 1) / k->rs_D) - ((g * k->width * k->rs_L + k->rs_D - 1) / k->rs_D)));
+}
+
+/* Advance the stream by one line of W samples; carriers (W int16 pairs) receives the
  * summed contribution of the serial carriers. */
-static void _line(hvk_audio_t *a, int16_t *carriers)
+static void _line(hvk_audio_t *a, int16_t *carriers, const int W)
 {
 	const int sr = a->sample_rate;
-	int W = a->width, x = 0;
+	int x = 0;
 
 	while(x < W)
 	{
@@ -554,6 +567,7 @@ static void _line(hvk_audio_t *a, int16_t *carriers)
 	}
 
 	a->pos += W;
+	a->line_no++;
 }
 
 /* Index of the symbol whose pulse starts at or before sample m (>= 0) */
@@ -572,17 +586,27 @@ static int64_t _symbol_at(const hvk_audio_t *a, int64_t m)
 int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
                        int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0)
 {
-	int W = a->width;
 	int64_t end = first + count;
 	int nsym = 0;
 
-	if(first % W || count % W) return(HVK_ERROR);
-	if(first < a->pos) return(HVK_ERROR);   /* the chains cannot be rewound */
+	/* the chains cannot be rewound: a request may start inside the line generated last, not before it */
+	if(first < (a->last_w ? a->last_pos : a->pos)) return(HVK_ERROR);
 
-	while(a->pos < end)
+	for(;;)
 	{
-		int16_t *dst = (a->pos >= first && carriers) ? carriers + (a->pos - first) * 2 : a->scratch;
-		_line(a, dst);
+		/* the part of the line in `scratch` that the request covers */
+		if(a->last_w && carriers)
+		{
+			const int64_t lo = first > a->last_pos ? first : a->last_pos;
+			const int64_t hi = end < a->last_pos + a->last_w ? end : a->last_pos + a->last_w;
+			if(hi > lo) memcpy(carriers + (lo - first) * 2, a->scratch + (lo - a->last_pos) * 2, (hi - lo) * 2 * sizeof(int16_t));
+		}
+
+		if(a->pos >= end) break;
+
+		a->last_pos = a->pos;
+		a->last_w = _line_width(a, a->line_no);
+		_line(a, a->scratch, a->last_w);
 	}
 
 	if(a->nicam_on && symbols)

@@ -71,6 +71,7 @@ struct hvk_engine {
 	uint32_t *d_pool;
 	hvk_framedesc_t *d_fdesc;
 	int16_t *d_S;
+	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
 	int16_t *d_car;
 	int32_t *d_sym;
 	int32_t *d_tile;
@@ -129,6 +130,12 @@ extern "C" const char *hvk_version(void) { return(HVK_VERSION); }
 
 extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned int sample_rate, int device, int max_frames)
 {
+	return(hvk_open_rates(pe, conf, sample_rate, 0, device, max_frames));
+}
+
+extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
+                              int device, int max_frames)
+{
 	hvk_engine *e;
 	int r, ndev = 0;
 
@@ -146,7 +153,7 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	e->slots = (hvk_slot_t *) calloc(e->frame_slots, sizeof(hvk_slot_t));
 	if(!e->slots) { free(e); return(HVK_OUT_OF_MEMORY); }
 
-	if((r = hvk_tables_build(&e->t, conf, sample_rate)) != HVK_OK) { hvk_close(e); return(r); }
+	if((r = hvk_tables_build(&e->t, conf, sample_rate, pixel_rate)) != HVK_OK) { hvk_close(e); return(r); }
 
 	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));   /* tools/ablate.py: results are WRONG when set */
 
@@ -243,7 +250,12 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots));
 	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots));
 	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames));
-	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * (k.lines + 2) * k.width * 2 + 256));
+	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
+	if(k.rs_L)
+	{
+		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
+		OPENCHK(_upload(&e->d_rs_taps, e->t.rs_taps, sizeof(int16_t) * k.rs_L * k.rs_ataps));
+	}
 	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
 	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames, hipHostMallocDefault));
 	OPENHIP(hipHostMalloc((void **) &e->h_frame, frame_px * 4, hipHostMallocDefault));
@@ -280,9 +292,10 @@ extern "C" int hvk_open(hvk_engine_t **pe, const hvk_config_t *conf, unsigned in
 
 	if(e->t.k.secam)
 	{
-		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * FS * 2));
-		OPENHIP(hipMemset(e->d_chroma, 0, (size_t) max_frames * FS * 2));
-		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * FS * 2, hipHostMallocDefault));
+		const size_t RS = k.raster_samples;   /* the colour side stream is at the pixel rate */
+		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * RS * 2));
+		OPENHIP(hipMemset(e->d_chroma, 0, (size_t) max_frames * RS * 2));
+		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * RS * 2, hipHostMallocDefault));
 	}
 
 	if(e->t.k.fm_video)
@@ -319,7 +332,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv, e->d_off, e->d_pass };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_off, e->h_pass, e->h_fm };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -360,6 +373,9 @@ extern "C" int hvk_get_info(const hvk_engine_t *e, hvk_info_t *info)
 	info->burst_width = k.burst_width;
 	info->has_carriers = k.has_carriers;
 	info->has_nicam = k.has_nicam;
+	info->pixel_rate = e->t.pixel_rate;
+	info->max_width = e->t.max_width;
+	info->startup_samples = k.out_prime;
 	return(HVK_OK);
 }
 
@@ -501,7 +517,7 @@ extern "C" size_t hvk_audio_needed(const hvk_engine_t *e, int nframes)
 {
 	if(!e || !e->audio) return(0);
 	const hvk_kconst_t &k = e->t.k;
-	int64_t upto = (e->next_frame + nframes) * (int64_t) k.frame_samples + (int64_t) k.delay_lines * k.width;
+	int64_t upto = (e->next_frame + nframes) * (int64_t) k.frame_samples + (int64_t) k.out_prime;
 	return(hvk_audio_source_needed(e->audio, upto));
 }
 
@@ -569,6 +585,13 @@ extern "C" int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsa
 	return(hvk_tail_passthru_push(e->tail, iq, nsamples));
 }
 
+extern "C" int hvk_line_widths(const hvk_engine_t *e, int64_t first_line, int nlines, int32_t *widths)
+{
+	if(!e || !widths || first_line < 0 || nlines < 0) return(HVK_ERROR);
+	hvk_tables_line_widths(&e->t, first_line, nlines, widths);
+	return(HVK_OK);
+}
+
 extern "C" int hvk_host_offset_stream(hvk_engine_t *e, int64_t first, int64_t count, int16_t *out)
 {
 	if(!e || !out) return(HVK_ERROR);
@@ -625,14 +648,14 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		f->fb_interlaced = s->interlaced;
 		f->fb_valid = s->valid;
 		f->parity = (int32_t) ((f->frame_index + 1) & 1);
-		f->clut_off0 = k.colour ? (uint32_t) (((uint64_t) f->frame_index * (uint64_t) FS) % k.clw) : 0;
+		f->clut_off0 = k.colour ? (uint32_t) (((uint64_t) f->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
 
 		if(e->secam)
 		{
 			/* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
 			if(f->frame_index != e->secam_next) return(HVK_UNSUPPORTED);
 			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
-			                        f->fb_width, f->fb_height, s->interlaced, e->h_chroma + (size_t) i * FS);
+			                        f->fb_width, f->fb_height, s->interlaced, e->h_chroma + (size_t) i * k.raster_samples);
 			if(r != HVK_OK) return(r);
 			e->secam_next++;
 		}
@@ -650,7 +673,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 
 		if(e->audio)
 		{
-			const int64_t m0 = f->frame_index * FS + (int64_t) k.delay_lines * k.width;
+			const int64_t m0 = f->frame_index * FS + (int64_t) k.out_prime;
 			int64_t k0 = 0;
 			int n = hvk_audio_generate(e->audio, m0, FS,
 				e->h_car ? e->h_car + (size_t) i * FS * 2 : NULL,
@@ -703,7 +726,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		HIPCHK(hipStreamSynchronize(e->stream));
 		memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
 	}
-	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * FS * 2, hipMemcpyHostToDevice, e->stream));
+	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_pass) HIPCHK(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
@@ -773,7 +796,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.itaps = e->itaps;
 	fa.qtaps = e->qtaps;
 	fa.fdesc = e->d_fdesc;
-	fa.S = e->d_S;
+	fa.S = e->t.k.rs_L ? e->d_S2 : e->d_S;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
 	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;
@@ -789,6 +812,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 
 	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
 	if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
+	if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->stream)) != HVK_OK) return(r);
 	if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
 	if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
 	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
@@ -880,7 +904,7 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 	if(!e || !dst) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	const hvk_kconst_t &k = e->t.k;
-	const size_t FS = k.frame_samples;
+	const size_t FS = k.raster_samples;
 	if(first + count > (size_t) e->last_frames * FS) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
 	HIPCHK(hipStreamSynchronize(e->stream));
@@ -888,7 +912,7 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 	{
 		const size_t fr = first / FS, off = first % FS;
 		const size_t n = count < FS - off ? count : FS - off;
-		HIPCHK(hipMemcpy(dst, e->d_S + fr * (size_t) (k.lines + 2) * k.width + k.width + off, n * 2, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(dst, e->d_S + fr * (size_t) k.slab_lines * k.width + k.width + off, n * 2, hipMemcpyDeviceToHost));
 		dst += n; first += n; count -= n;
 	}
 	return(HVK_OK);

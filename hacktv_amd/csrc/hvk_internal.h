@@ -75,7 +75,13 @@ typedef struct {
 	int32_t has_carriers;
 	int32_t has_nicam;
 	int32_t nicam_ntaps, nicam_sps, nicam_dsl, nicam_decimation, nicam_cc_len;
-	int32_t frame_samples;
+	int32_t frame_samples;  /* OUTPUT samples per frame (sample rate) */
+	int32_t raster_samples; /* width * lines (pixel rate); == frame_samples without the resampler */
+	int32_t slab_lines;     /* raster lines kept per frame: lines + 2, + 1 with the resampler */
+	int32_t s_lead, s_stride;   /* the filter kernel's input: samples in front of a frame's first one, samples between frames */
+	int32_t out_prime;      /* samples of the never-emitted start-up lines the audio / tail processes run over */
+	int32_t rs_L, rs_D, rs_ataps;   /* --pixelrate poly-phase resampler: interpolation, decimation, taps per phase; rs_L == 0: none */
+	int32_t rs_shift;       /* resampled-stream index (frame local) of output sample 0's filter centre */
 	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
 	int32_t teletext;       /* teletext symbol table present */
 	int32_t fm_video;       /* the engine's device output is the FM modulator's input (hvk_tail.c does the rest) */
@@ -99,7 +105,9 @@ typedef struct {
 /* Host-built tables (hvk_tables.c) */
 typedef struct {
 	hvk_config_t conf;      /* with defaults applied */
-	int32_t sample_rate;
+	int32_t sample_rate, pixel_rate;
+	int32_t max_width;      /* widest output line */
+	int16_t *rs_taps;       /* [rs_L][rs_ataps] in the order they are applied */
 	int32_t white_level, black_level, blanking_level, sync_level;
 	hvk_kconst_t k;
 	hvk_yuvparams_t yuv;
@@ -133,7 +141,9 @@ typedef struct {
 	hvk_c32_t offset_delta;
 } hvk_tables_t;
 
-int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate);
+int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate);
+/* widths of output lines [first, first + n) of the stream (they vary with the resampler) */
+void hvk_tables_line_widths(const hvk_tables_t *t, int64_t first, int n, int32_t *widths);
 void hvk_tables_free(hvk_tables_t *t);
 void hvk_tables_default_ghost(hvk_tables_t *t);
 long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes);

@@ -61,6 +61,7 @@ extern "C" {
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
+int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
                     int nframes, hipStream_t stream);
 int hvk_launch_convert(const void *iq, size_t count, int type, int cplx, void *dst, hipStream_t stream);

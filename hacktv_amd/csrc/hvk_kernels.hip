@@ -40,6 +40,7 @@ typedef int    int2v   __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 /* four dwords that are only dword aligned: global_load_dwordx4 needs no more */
 typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
+typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
 
 #define SPL HVK_SPL
 #define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
@@ -166,7 +167,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * dealt round-robin to the 8 XCDs, line x of EVERY frame runs on XCD x % 8:
 	 * the slices of the colour table and of the source frame a line needs then
 	 * stay in that XCD's L2 from frame to frame */
-	if((int) blockIdx.x >= k.lines + 2) return;
+	if((int) blockIdx.x >= k.slab_lines) return;
 
 	constexpr int H = NT / 2;
 	const int W = k.width;
@@ -174,8 +175,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
 	const hvk_framedesc_t &f = fdesc[blockIdx.y];
-	const int rel = (int) blockIdx.x - 1;       /* line of the frame, -1 and `lines` are the halo lines */
-	int16_t *out = S + ((size_t) blockIdx.y * (k.lines + 2) + blockIdx.x) * W;
+	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
+	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
 
 	/* which line of which frame, without dividing the global line number */
 	/* frame number and parity by arithmetic: the descriptor fetch below does not wait for fdesc */
@@ -183,7 +184,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int line0 = rel, par = (int) ((frame_index + 1) & 1);
 	bool own = true;
 	if(rel < 0) { line0 = k.lines - 1; par ^= 1; own = false; }
-	else if(rel >= k.lines) { line0 = 0; par ^= 1; own = false; }
+	else if(rel >= k.lines) { line0 = rel - k.lines; par ^= 1; own = false; }
 
 	if(rel < 0 && frame_index == 0)
 	{
@@ -463,7 +464,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 		if(own && x0 + SPL <= W)
 		{
-			const int4u cv = *(const int4u *) (chroma + (size_t) blockIdx.y * k.frame_samples + (size_t) rel * W + x0);
+			const int4u cv = *(const int4u *) (chroma + (size_t) blockIdx.y * k.raster_samples + (size_t) rel * W + x0);
 			const int cw[4] = { cv.x, cv.y, cv.z, cv.w };
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
@@ -565,11 +566,10 @@ void hvk_k_filter(const hvk_kconst_t k,
 	__shared__ int sym_st[HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
 	__shared__ __attribute__((aligned(16))) int4v sym_ent[HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
 
-	const int W = k.width;
 	const int FS = k.frame_samples;
 	const int t = threadIdx.x;
 	const int x0 = t * SPL;
-	const int16_t *slab = S + (size_t) blockIdx.y * (k.lines + 2) * W + W;   /* frame local sample 0 */
+	const int16_t *slab = S + (size_t) blockIdx.y * k.s_stride + k.s_lead;    /* frame local sample 0 */
 
 	/* four copies of the NICAM pulse table, copy s shifted left by s entries, so that
 	 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts instead of
@@ -592,7 +592,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	if(VF != 0)
 	{
 		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
-		const int limit = (FS + W - (n0 - LEAD)) / 2;         /* dwords available in the slab */
+		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
 		constexpr int PASSES = (NWIN / 2 + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL);
 		int v[PASSES];
 #pragma unroll
@@ -868,6 +868,79 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
 }
 
 /* ------------------------------------------------------------------ */
+/* --pixelrate: rational poly-phase resampler, pixel-rate raster -> sample-rate
+ * stream (src/video.c:3627-3651; arithmetic of fir_int16_process with
+ * interpolation L and decimation D, src/fir.c:304-355). Output r of the
+ * resampled stream is made from raster sample n = floor(r D / L) and the
+ * ataps - 1 before it with the taps of phase (r D) mod L:
+ *     out[r] = clamp16((sum_y x[n - ataps + 1 + y] * taps[phase][y]) >> 15)
+ * A frame of the raster resamples to a whole number of outputs (hvk_tables.c
+ * insists), so phase and position are frame local. One workgroup makes 1024
+ * consecutive slab samples, 4 per lane: the raster samples they need and the
+ * whole tap table are staged in LDS; stores are 8 bytes per lane, contiguous.
+ * The slab written here is what hvk_k_filter reads: s_lead samples before a
+ * frame's output sample 0, whose filter centre is resampled sample rs_shift. */
+#define HVK_RS_TILE 1024
+#define HVK_RS_WIN  (4 * HVK_RS_TILE + 72 + 8)
+__global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int16_t *__restrict__ taps,
+                                                      int16_t *__restrict__ S2)
+{
+	__shared__ int16_t win[HVK_RS_WIN];
+	__shared__ int16_t tp[8192];
+
+	const int t = threadIdx.x;
+	const int L = k.rs_L, D = k.rs_D, A = k.rs_ataps;
+	const long slab_in = (long) k.slab_lines * k.width;
+	const int16_t *in = Sp + (size_t) blockIdx.y * slab_in;     /* raster line -1 of the frame first */
+	int16_t *out = S2 + (size_t) blockIdx.y * k.s_stride;
+
+	const int q0 = blockIdx.x * HVK_RS_TILE;                    /* first slab sample of the tile */
+	const long r0 = (long) q0 - k.s_lead + k.rs_shift;          /* its resampled-stream index, frame local (>= 0) */
+	const long n_lo = (r0 * D) / L - (A - 1);                   /* first raster sample needed, frame local */
+	const long n_hi = ((r0 + HVK_RS_TILE - 1) * D) / L;
+	const int count = (int) (n_hi - n_lo + 1);
+
+	for(int j = t; j < L * A; j += 256) tp[j] = taps[j];
+	for(int j = t; j < count; j += 256)
+	{
+		const long p = n_lo + j + k.width;                      /* slab position: one halo line in front */
+		win[j] = (p >= 0 && p < slab_in) ? in[p] : (int16_t) 0;
+	}
+	__syncthreads();
+
+	short v[4];
+#pragma unroll
+	for(int i = 0; i < 4; i++)
+	{
+		const long r = r0 + t * 4 + i;
+		const long rd = r * D;
+		const int n = (int) (rd / L - n_lo) - (A - 1);          /* window start in win[] */
+		const int16_t *c = tp + (int) (rd % L) * A;
+		int a = 0;
+		for(int y = 0; y < A; y++) a += (int) win[n + y] * c[y];
+		a >>= 15;
+		v[i] = (short) (a < -32768 ? -32768 : (a > 32767 ? 32767 : a));
+	}
+
+	const int q = q0 + t * 4;
+	if(q + 4 <= k.s_stride)
+	{
+		*(int2u *) (out + q) = (int2u) { ((int) v[0] & 0xFFFF) | ((int) v[1] << 16), ((int) v[2] & 0xFFFF) | ((int) v[3] << 16) };
+	}
+	else
+	{
+		for(int i = 0; i < 4; i++) if(q + i < k.s_stride) out[q + i] = v[i];
+	}
+}
+
+extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream)
+{
+	const int tiles = (k->s_stride + HVK_RS_TILE - 1) / HVK_RS_TILE;
+	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int16_t *) taps, (int16_t *) S2);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+/* ------------------------------------------------------------------ */
 /* The complex tail of the line pipeline for modes whose modulator is on the
  * device (everything but FM video): swap_iq, frequency offset, passthru, in the
  * reference's order (src/video.c:4587-4645). One I/Q pair (one dword) per lane
@@ -959,7 +1032,7 @@ static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3((a->k.lines + 2 + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->notch, a->chroma, a->tt_sym, a->tt_val, a->tt_pk, a->tt_mask, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);

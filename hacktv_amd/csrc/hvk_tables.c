@@ -174,13 +174,20 @@ static double _bessel_i0(double x)
 }
 
 /* Kaiser-windowed sinc low pass with unity DC gain (src/fir.c:53-69, :89-137) */
+static void _design_low_pass_gain(double *taps, int ntaps, double sample_rate, double cutoff, double gain);
+
 static void _design_low_pass(double *taps, int ntaps, double sample_rate, double cutoff)
+{
+	_design_low_pass_gain(taps, ntaps, sample_rate, cutoff, 1);
+}
+
+static void _design_low_pass_gain(double *taps, int ntaps, double sample_rate, double cutoff, double gain)
 {
 	const double beta = 7.0;
 	double inv_i0 = 1.0 / _bessel_i0(beta);
 	double inm1 = 1.0 / ((double) (ntaps - 1));
 	double w = 2.0 * M_PI * cutoff / sample_rate;
-	double dc, gain = 1;
+	double dc;
 	int M = (ntaps - 1) / 2, i, n;
 
 	taps[0] = taps[ntaps - 1] = inv_i0;
@@ -446,7 +453,7 @@ static int _build_teletext(hvk_tables_t *t)
 	const int W = t->k.width;
 	int level = round((t->white_level - t->black_level) * 0.66);
 	double bw = (double) W / 444;
-	double offset = t->sample_rate * (12e-6 - (64e-6 / 444 * 12));
+	double offset = t->pixel_rate * (12e-6 - (64e-6 / 444 * 12));
 	int16_t *row = malloc(W * sizeof(int16_t));
 	int b, x, total = 0, pass;
 
@@ -546,7 +553,7 @@ static int _build_secam(hvk_tables_t *t, double level)
 
 	for(r = INT16_MIN; r <= INT16_MAX; r++)
 	{
-		double d = 2.0 * M_PI / t->sample_rate * (fm_freq + (double) r / INT16_MAX * fm_dev);
+		double d = 2.0 * M_PI / t->pixel_rate * (fm_freq + (double) r / INT16_MAX * fm_dev);
 		double f, lq, rq, den;
 
 		t->secam_lut[r - INT16_MIN] = _unit_phasor(d);
@@ -563,11 +570,11 @@ static int _build_secam(hvk_tables_t *t, double level)
 	}
 
 	/* colour-difference low pass (src/video.c:4097-4098) */
-	_design_low_pass(taps, 15, t->sample_rate, 1.70e6);
+	_design_low_pass(taps, 15, t->pixel_rate, 1.70e6);
 	t->secam_fir = _q15_applied(taps, 15, 1);
 
 	/* luma notch at the sub-carrier, deliberately weakened (src/video.c:4100-4107) */
-	_design_band_reject(taps, 51, t->sample_rate, fm_freq - 1e6, fm_freq + 1e6);
+	_design_band_reject(taps, 51, t->pixel_rate, fm_freq - 1e6, fm_freq + 1e6);
 	taps[51 / 2] += 0.5;
 	for(sum = i = 0; i < 51; i++) sum += taps[i];
 	sum = sum / 1.0;
@@ -583,13 +590,13 @@ static int _build_secam(hvk_tables_t *t, double level)
 
 	/* sub-carrier envelope over the line (src/video.c:4140-4147) */
 	rise = c->burst_rise * EDGE_0_100;
-	t->k.burst_left = round(t->sample_rate * (c->burst_left - c->burst_rise / 2));
-	t->k.burst_width = ceil(t->sample_rate * (c->burst_width + rise));
+	t->k.burst_left = round(t->pixel_rate * (c->burst_left - c->burst_rise / 2));
+	t->k.burst_width = ceil(t->pixel_rate * (c->burst_width + rise));
 	t->burst_win = malloc(t->k.burst_width * sizeof(int16_t));
 	if(!t->burst_win) return(HVK_OUT_OF_MEMORY);
 	for(i = 0; i < t->k.burst_width; i++)
 	{
-		double tt = 1.0 / t->sample_rate * i;
+		double tt = 1.0 / t->pixel_rate * i;
 		t->burst_win[i] = round(_window(tt, rise / 2, c->burst_width, rise) * 1.0 * INT16_MAX);
 	}
 
@@ -598,7 +605,7 @@ static int _build_secam(hvk_tables_t *t, double level)
 
 /* ------------------------------------------------------------------ */
 
-int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate)
+int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate)
 {
 	hvk_config_t *c;
 	double line_s, level, slevel, sync_amp;
@@ -607,6 +614,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	memset(t, 0, sizeof(*t));
 	t->conf = *conf;
 	t->sample_rate = sample_rate;
+	if(pixel_rate == 0) pixel_rate = sample_rate;    /* src/video.c:3839 */
+	t->pixel_rate = pixel_rate;
 	c = &t->conf;
 
 	/* what the engine renders */
@@ -628,15 +637,18 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	/* geometry (src/video.c:3844-3853); pixel rate == sample rate */
 	line_s = (double) c->frame_rate.den / c->frame_rate.num / c->lines;
-	t->k.width = round((double) sample_rate * line_s);
-	t->k.half_width = round((double) sample_rate * line_s / 2);
-	t->k.active_left = round(sample_rate * c->active_left);
-	t->k.active_width = ceil(sample_rate * c->active_width);
+	t->k.width = round((double) pixel_rate * line_s);
+	t->k.half_width = round((double) pixel_rate * line_s / 2);
+	t->k.active_left = round(pixel_rate * c->active_left);
+	t->k.active_width = ceil(pixel_rate * c->active_width);
 	if(t->k.active_width > t->k.width) t->k.active_width = t->k.width;
 	t->k.lines = c->lines;
 	t->k.active_lines = c->active_lines;
 	t->k.interlaced = c->interlaced;
 	t->k.frame_samples = t->k.width * t->k.lines;
+	t->k.raster_samples = t->k.frame_samples;
+	t->k.slab_lines = t->k.lines + 2;
+	t->max_width = t->k.width;
 
 	if(t->k.width < 64 || t->k.width > 8192) return(HVK_UNSUPPORTED);
 
@@ -667,13 +679,13 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		const double at[5]  = { 0, 0, 0, line_s / 2, line_s / 2 };
 		const double len[5] = { c->hsync_width, c->vsync_short_width, c->vsync_long_width,
 		                        c->vsync_short_width, c->vsync_long_width };
-		double rise = c->sync_rise * EDGE_0_100 * sample_rate;
+		double rise = c->sync_rise * EDGE_0_100 * pixel_rate;
 		int total = 0, o = 0, first;
 
 		t->k.npulses = 5;
 		for(i = 0; i < 5; i++)
 		{
-			t->k.pulse_length[i] = _quantise_pulse(NULL, &first, at[i] * sample_rate, len[i] * sample_rate, rise, (int) sync_amp);
+			t->k.pulse_length[i] = _quantise_pulse(NULL, &first, at[i] * pixel_rate, len[i] * pixel_rate, rise, (int) sync_amp);
 			t->k.pulse_offset[i] = first;
 			t->k.pulse_start[i] = total;
 			total += t->k.pulse_length[i];
@@ -689,7 +701,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 		for(i = 0; i < 5; i++)
 		{
-			_quantise_pulse(t->pulse_values + t->k.pulse_start[i], &first, at[i] * sample_rate, len[i] * sample_rate, rise, (int) sync_amp);
+			_quantise_pulse(t->pulse_values + t->k.pulse_start[i], &first, at[i] * pixel_rate, len[i] * pixel_rate, rise, (int) sync_amp);
 
 			/* the same data in the reference's packed form, for table parity tests */
 			t->sync_packed[o++] = t->k.pulse_length[i];
@@ -727,7 +739,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	{
 		/* samples per sub-carrier cycle as a reduced fraction num/den:
 		 * the phase pattern repeats every `num` samples */
-		int64_t num = (int64_t) sample_rate * c->colour_carrier.den;
+		int64_t num = (int64_t) pixel_rate * c->colour_carrier.den;
 		int64_t den = c->colour_carrier.num;
 		int64_t a = num, b = den, e, n;
 		double step;
@@ -754,7 +766,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		if(c->colour_bw > 0)
 		{
 			double *taps;
-			t->k.chroma_ntaps = _design_gaussian(&taps, sample_rate, c->colour_bw);
+			t->k.chroma_ntaps = _design_gaussian(&taps, pixel_rate, c->colour_bw);
 			t->chroma_taps = _q15_applied(taps, t->k.chroma_ntaps, 1);
 			free(taps);
 			if(!t->chroma_taps) return(HVK_OUT_OF_MEMORY);
@@ -768,14 +780,14 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		double rise = c->burst_rise * EDGE_0_100;
 		double amp = c->burst_level * (c->white_level - c->blanking_level) / 2 * level;
 
-		t->k.burst_left = round(sample_rate * (c->burst_left - c->burst_rise / 2));
-		t->k.burst_width = ceil(sample_rate * (c->burst_width + rise));
+		t->k.burst_left = round(pixel_rate * (c->burst_left - c->burst_rise / 2));
+		t->k.burst_width = ceil(pixel_rate * (c->burst_width + rise));
 		t->burst_win = malloc(t->k.burst_width * sizeof(int16_t));
 		if(!t->burst_win) return(HVK_OUT_OF_MEMORY);
 
 		for(i = 0; i < t->k.burst_width; i++)
 		{
-			double tt = 1.0 / sample_rate * i;
+			double tt = 1.0 / pixel_rate * i;
 			t->burst_win[i] = round(_window(tt, rise / 2, c->burst_width, rise) * amp * INT16_MAX);
 		}
 
@@ -805,6 +817,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->vfilter)
 	{
 		const int ntaps = 51;
+		const int fw = round((double) sample_rate * line_s);   /* the line width at the sample rate, src/video.c:3660 */
 
 		if(c->modulation == HVK_VSB)
 		{
@@ -840,7 +853,84 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 		/* whole lines of latency the reference's pipeline drops at start-up
 		 * (src/video.c:3620-3625, :3759) */
-		t->k.delay_lines = (ntaps / 2 + t->k.width - 1) / t->k.width;
+		t->k.delay_lines = (ntaps / 2 + fw - 1) / fw;
+	}
+
+	/* --pixelrate (src/video.c:3627-3651, src/fir.c:393-428, :260-296): the raster is built at the
+	 * pixel rate and a rational poly-phase FIR takes it to the sample rate. Output sample r of the
+	 * resampled stream is made from input n = floor(r * D / L) and the ataps - 1 inputs before it
+	 * with the taps of phase (r * D) mod L. */
+	if(pixel_rate != sample_rate)
+	{
+		int64_t a = sample_rate, b = pixel_rate, g;
+		int L, D, ntaps, total, j;
+		double *taps, cutoff;
+		int64_t w0, w1;
+
+		while(b) { g = a % b; a = b; b = g; }
+		L = sample_rate / a;
+		D = pixel_rate / a;
+
+		/* what the device kernel is sized for, and frames of constant length */
+		if(L > 256 || D > 4 * L || ((int64_t) t->k.raster_samples * L) % D != 0) return(HVK_UNSUPPORTED);
+		/* passthru adds whole lines of the width they come out with; not combined with varying widths */
+		if(c->passthru) return(HVK_UNSUPPORTED);
+
+		ntaps = (21 * L) | 1;
+		taps = calloc(ntaps, sizeof(double));
+		if(!taps) return(HVK_OUT_OF_MEMORY);
+
+		cutoff = L > D ? 0.45 : 0.45 * L / D;    /* up / down */
+		_design_low_pass_gain(taps, ntaps, L, cutoff, L);
+
+		t->k.rs_L = L;
+		t->k.rs_D = D;
+		t->k.rs_ataps = (ntaps + L - 1) / L;
+		total = t->k.rs_ataps * L;
+		if(total > 8192) { free(taps); return(HVK_UNSUPPORTED); }
+		t->rs_taps = calloc(total, sizeof(int16_t));
+		if(!t->rs_taps) { free(taps); return(HVK_OUT_OF_MEMORY); }
+
+		/* phase p's taps at [p * ataps, (p + 1) * ataps), oldest sample first (src/fir.c:277-284) */
+		j = total - t->k.rs_ataps;
+		for(i = ntaps - 1; i >= 0; i--)
+		{
+			t->rs_taps[j] = lround(taps[i] * 32767.0);
+			j -= t->k.rs_ataps;
+			if(j < 0) j += total + 1;
+		}
+		free(taps);
+
+		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D);
+		t->k.slab_lines = t->k.lines + 3;
+		t->max_width = (int32_t) (((int64_t) t->k.width * L + D - 1) / D);   /* fir_int16_output_size, src/fir.c:376-381 */
+
+		/* Start-up: the resampler's output for raster line N lands in the slot
+		 * of line N - 1 and it has no latency to make up for that, so its first chunk -- the resampled
+		 * raster line 1, w0 samples -- never leaves the pipeline; with the filter on the next slot
+		 * (w1 samples) is the filter's start-up line. The filter's own latency is `fw` samples. */
+		w0 = ((int64_t) t->k.width * L + D - 1) / D;
+		w1 = ((int64_t) 2 * t->k.width * L + D - 1) / D - w0;
+		t->k.rs_shift = (int32_t) (w0 + (t->k.vf_type ? w1 - round((double) sample_rate * line_s) : 0));
+		t->k.out_prime = (int32_t) (w0 + (t->k.vf_type ? w1 : 0));
+		if(t->k.rs_shift < 64) return(HVK_UNSUPPORTED);
+	}
+	else
+	{
+		t->k.out_prime = t->k.delay_lines * t->k.width;
+	}
+
+	/* the filter kernel's input slab: the raster itself (one halo line either side), or the
+	 * resampled stream with 64 samples either side */
+	if(t->k.rs_L)
+	{
+		t->k.s_lead = 64;
+		t->k.s_stride = (t->k.frame_samples + 2 * 64 + 7) & ~7;
+	}
+	else
+	{
+		t->k.s_lead = t->k.width;
+		t->k.s_stride = (t->k.lines + 2) * t->k.width;
 	}
 
 	if((r = _build_audio(t, slevel)) != HVK_OK) return(r);
@@ -894,7 +984,28 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->secam_fir);
 	free(t->secam_notch);
 	free(t->fmv_lut);
+	free(t->rs_taps);
 	memset(t, 0, sizeof(*t));
+}
+
+void hvk_tables_line_widths(const hvk_tables_t *t, int64_t first, int n, int32_t *widths)
+{
+	const hvk_kconst_t *k = &t->k;
+	int i;
+
+	for(i = 0; i < n; i++)
+	{
+		if(k->rs_L == 0) widths[i] = k->width;
+		else
+		{
+			/* emitted line j is resampler chunk j + (chunks dropped at start-up); chunk g holds the
+			 * outputs made from raster line g: [ceil(g W L / D), ceil((g + 1) W L / D)) */
+			const int64_t g = first + i + 1 + (k->vf_type ? k->delay_lines : 0);
+			const int64_t lo = (g * k->width * k->rs_L + k->rs_D - 1) / k->rs_D;
+			const int64_t hi = ((g + 1) * k->width * k->rs_L + k->rs_D - 1) / k->rs_D;
+			widths[i] = (int32_t) (hi - lo);
+		}
+	}
 }
 
 static long _give(void *dst, long max_bytes, const void *src, long bytes)
@@ -918,6 +1029,7 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
 	if(!strcmp(name, "vfilter_qtaps")) return(_give(dst, max_bytes, t->vf_qtaps, t->vf_qtaps ? (long) t->k.vf_ntaps * 2 : 0));
 	if(!strcmp(name, "fm_mono_lut"))   return(_give(dst, max_bytes, t->fm_lut, 65536L * 8));
 	if(!strcmp(name, "fm_video_lut"))  return(_give(dst, max_bytes, t->fmv_lut, t->fmv_lut ? 65536L * 8 : 0));
+	if(!strcmp(name, "resampler_taps")) return(_give(dst, max_bytes, t->rs_taps, t->rs_taps ? (long) t->k.rs_L * t->k.rs_ataps * 2 : 0));
 	if(!strcmp(name, "nicam_taps"))    return(_give(dst, max_bytes, t->nicam_taps, (long) t->k.nicam_ntaps * 2));
 	if(!strcmp(name, "nicam_cc"))      return(_give(dst, max_bytes, t->nicam_cc, (long) t->k.nicam_cc_len * 4));
 	if(!strcmp(name, "limiter_shape")) return(_give(dst, max_bytes, t->limiter_shape, t->has_limiter ? 21L * 2 : 0));

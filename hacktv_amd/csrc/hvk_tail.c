@@ -36,7 +36,7 @@
 struct hvk_tail {
 	const hvk_tables_t *t;
 	int W;
-	int64_t prime;              /* delay_lines * width */
+	int64_t prime;              /* samples of the start-up lines (delay_lines * width; see hvk_tables.c for --pixelrate) */
 
 	/* offset phasor; steps counts the multiplications done so far */
 	hvk_c32_t off_phase, off_delta;
@@ -61,8 +61,8 @@ hvk_tail_t *hvk_tail_new(const hvk_tables_t *t)
 	if(!s) return(NULL);
 
 	s->t = t;
-	s->W = t->k.width;
-	s->prime = (int64_t) t->k.delay_lines * t->k.width;
+	s->W = t->k.width;      /* passthru is refused together with the resampler: lines are `width` samples */
+	s->prime = t->k.out_prime;
 
 	/* src/video.c:4596-4602: the offset phasor starts at INT16_MAX (sic), so
 	 * its >> 16 is zero until the first re-normalisation */

@@ -56,6 +56,8 @@ typedef struct {
 	int ended;              /* source has ended: no more batches */
 	int frame_in_batch_pull;
 	int passthru_primed;    /* the start-up line's share of the passthru source has been queued */
+	int32_t *widths;        /* widths of the lines of the frame being handed out (they vary with --pixelrate) */
+	size_t line_at;         /* sample offset of the next line in iq */
 	int16_t *passbuf;
 	vid_line_t out;
 } shim_t;
@@ -74,7 +76,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 {
 	memset(h, 0, sizeof(*h));
 
-	if(pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("--pixelrate (resampler)"));
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
 	if(c->modulation == VID_FM && c->fm_energy_dispersal) return(_refuse("FM energy dispersal"));
 	if(c->modulation == VID_FM && c->vfilter) return(_refuse("the FM video pre-emphasis filter (--filter with an FM mode)"));
@@ -166,7 +167,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	if((env = getenv("HVK_BATCH")) && atoi(env) > 0) m->batch = atoi(env);
 	if((env = getenv("HVK_DEVICE"))) device = atoi(env);
 
-	r = hvk_open(&m->e, &hc, sample_rate, device, m->batch);
+	r = hvk_open_rates(&m->e, &hc, sample_rate, pixel_rate, device, m->batch);
 	if(r != HVK_OK)
 	{
 		free(m);
@@ -178,8 +179,11 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	hvk_get_info(m->e, &m->info);
 
 	m->iq = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
-	if(!m->iq)
+	m->widths = malloc(sizeof(int32_t) * m->info.lines);
+	if(!m->iq || !m->widths)
 	{
+		free(m->iq);
+		free(m->widths);
 		hvk_close(m->e);
 		free(m);
 		return(VID_OUT_OF_MEMORY);
@@ -188,10 +192,10 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	/* what main() and vid_info() read back (src/hacktv.c:1452-1518, src/video.c:4846-4860) */
 	if(s->conf.hline <= 0 && s->conf.interlaced != 0) s->conf.hline = (s->conf.lines + 1) / 2;
 	s->sample_rate = sample_rate;
-	s->pixel_rate = sample_rate;
+	s->pixel_rate = m->info.pixel_rate;
 	s->width = m->info.width;
 	s->half_width = m->info.half_width;
-	s->max_width = m->info.width;
+	s->max_width = m->info.max_width;
 	s->active_width = m->info.active_width;
 	s->active_left = m->info.active_left;
 	s->white_level = m->info.white_level;
@@ -240,6 +244,7 @@ void vid_free(vid_t *s)
 	{
 		hvk_close(m->e);
 		free(m->iq);
+		free(m->widths);
 		free(m->passbuf);
 		free(m);
 	}
@@ -361,11 +366,19 @@ vid_line_t *vid_next_line(vid_t *s)
 		m->have = n;
 		m->frame_in_batch = 0;
 		m->line = 0;
+		m->line_at = 0;
+	}
+
+	if(m->line == 0)
+	{
+		/* the widths of this frame's lines: constant without the resampler (src/video.c:3246) */
+		if(hvk_line_widths(m->e, m->frames_done * m->info.lines, m->info.lines, m->widths) != HVK_OK) return(NULL);
 	}
 
 	l = &m->out;
-	l->output = m->iq + 2 * ((size_t) m->frame_in_batch * m->info.frame_samples + (size_t) m->line * m->info.width);
-	l->width = m->info.width;
+	l->output = m->iq + 2 * m->line_at;
+	l->width = m->widths[m->line];
+	m->line_at += l->width;
 	l->frame = (int) (m->frames_done + 1);
 	l->line = m->line + 1;
 	l->lut = NULL;

@@ -77,7 +77,7 @@ class HvkInfo(C.Structure):
         "white_level", "black_level", "blanking_level", "sync_level",
         "delay_lines", "frame_samples", "max_frames", "frame_slots",
         "colour_lookup_width", "burst_left", "burst_width",
-        "has_carriers", "has_nicam")]
+        "has_carriers", "has_nicam", "pixel_rate", "max_width", "startup_samples")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

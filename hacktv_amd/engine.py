@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
 
 SYMBOLS = [
     "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
-    "hvk_open", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
+    "hvk_open", "hvk_open_rates", "hvk_line_widths", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
@@ -49,6 +49,8 @@ def lib():
         L.hvk_preset_desc.restype = C.c_char_p
         L.hvk_preset_desc.argtypes = [i32]
         L.hvk_open.argtypes = [C.POINTER(vp), vp, C.c_uint, i32, i32]
+        L.hvk_open_rates.argtypes = [C.POINTER(vp), vp, C.c_uint, C.c_uint, i32, i32]
+        L.hvk_line_widths.argtypes = [vp, i64, i32, vp]
         L.hvk_close.argtypes = [vp]
         L.hvk_close.restype = None
         L.hvk_get_info.argtypes = [vp, vp]
@@ -99,10 +101,10 @@ def preset(mode, flags=0):
 
 
 class Engine:
-    def __init__(self, conf, sample_rate, device=0, max_frames=4):
+    def __init__(self, conf, sample_rate, device=0, max_frames=4, pixel_rate=0):
         self.h = C.c_void_p()
         self.conf = conf
-        r = lib().hvk_open(C.byref(self.h), C.byref(conf), sample_rate, device, max_frames)
+        r = lib().hvk_open_rates(C.byref(self.h), C.byref(conf), sample_rate, pixel_rate, device, max_frames)
         if r != 0:
             self.h = None
             raise HvkError("hvk_open", r)
@@ -158,6 +160,11 @@ class Engine:
         p = np.ascontiguousarray(packets, np.uint8)
         assert p.shape == (32, 45)
         return self._chk("hvk_teletext_packets", lib().hvk_teletext_packets(self.h, frame_in_batch, p.ctypes.data, mask))
+
+    def line_widths(self, first_line, nlines):
+        w = np.zeros(nlines, np.int32)
+        self._chk("hvk_line_widths", lib().hvk_line_widths(self.h, first_line, nlines, w.ctypes.data))
+        return w
 
     def audio_write(self, stereo):
         a = np.ascontiguousarray(stereo, np.int16)

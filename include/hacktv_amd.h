@@ -91,11 +91,30 @@ typedef struct hvk_info_t {
 	int32_t burst_left, burst_width;
 	int32_t has_carriers;       /* serial FM/AM audio carriers present */
 	int32_t has_nicam;
+	int32_t pixel_rate;         /* rate the raster is built at; width, half_width, active_* are in pixels of it */
+	int32_t max_width;          /* widest line handed out (== width unless the resampler is on) */
+	int32_t startup_samples;    /* samples of the never-emitted start-up lines the audio and tail processes
+	                             * run over before the first output sample (delay_lines * width without the
+	                             * resampler) */
 } hvk_info_t;
 
 /* vid_init(): src/video.c:3812. `device` is the HIP device ordinal.
  * `max_frames` bounds one render call (device buffers are sized for it). */
 int hvk_open(hvk_engine_t **e, const hvk_config_t *conf, unsigned int sample_rate, int device, int max_frames);
+
+/* vid_init() with --pixelrate (src/video.c:3812, :3839, :4361-4367): the raster is built at
+ * pixel_rate and a rational poly-phase FIR resamples it to sample_rate before the video
+ * filter (src/video.c:3627-3651, src/fir.c:393-428). 0 or == sample_rate: no resampler.
+ * Frame-regular rates only: raster samples per frame * L / D must be whole (L / D the
+ * reduced sample_rate / pixel_rate), L <= 256, D <= 4 L. info.frame_samples is the OUTPUT
+ * frame length; lines have the widths hvk_line_widths() reports. As in the reference the
+ * resampled first raster line never leaves the pipeline: the stream starts with line 2. */
+int hvk_open_rates(hvk_engine_t **e, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
+                   int device, int max_frames);
+
+/* Widths of output lines [first_line, first_line + nlines) of the stream, counted from 0 (what
+ * vid_next_line() puts in vid_line_t.width): always info.width without the resampler. */
+int hvk_line_widths(const hvk_engine_t *e, int64_t first_line, int nlines, int32_t *widths);
 
 /* vid_free(): src/video.c:4706 */
 void hvk_close(hvk_engine_t *e);
@@ -186,9 +205,9 @@ int hvk_set_stream(hvk_engine_t *e, void *hip_stream);
  * position first + count and hand back the side streams for
  * [first, first + count) -- count int16 I/Q pairs of serial-carrier samples
  * and the NICAM symbols that touch the range (*k0 = stream index of
- * symbols[0]; 0xFF marks "before the first symbol"). first and count are
- * multiples of the line width; positions are audio-stream positions (output
- * position + delay_lines * width). Needs no device. Returns the number of
+ * symbols[0]; 0xFF marks "before the first symbol"). Positions are audio-stream
+ * positions (output position + info.startup_samples); requests go forward
+ * (a request may start inside the line the previous one ended in). Needs no device. Returns the number of
  * symbols written or a negative HVK_* code. */
 int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
                           int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0);

@@ -64,6 +64,13 @@ CASES = [
     ("ntsc_fm",       "ntsc-fm", 13500000, [],                     0,                                      False, 2),
     ("secam_fm_tail", "secam-fm", 16000000, ["--swap-iq", "--offset", "500000"], 0,                        False, 3, {"swap_iq": 1, "offset": 500000}),
     ("pal_fm_pass",   "pal-fm", 16000000, ["--offset", "300000", "--passthru", "@PASS@"], 0,               False, 4, {"offset": 300000, "passthru": 1}),
+    # --pixelrate: raster at the pixel rate, poly-phase resampler to the sample rate (9th element: the pixel rate)
+    ("i_px135",       "i",    16000000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      False, 3, {}, 13500000),
+    ("i_px2025",      "i",    16000000, ["--noaudio", "--pixelrate", "20250000"], refprobe.FLAG_NOAUDIO,    False, 2, {}, 20250000),
+    ("l_px2025",      "l",    16000000, ["--filter", "--pixelrate", "20250000"], refprobe.FLAG_FILTER,      False, 2, {}, 20250000),
+    ("pal_px16_s14",  "pal",  14000000, ["--pixelrate", "16000000"], 0,                                    True,  2, {}, 16000000),
+    ("m_px135_s27",   "m",    27000000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      False, 2, {}, 13500000),
+    ("pal_px135_s136", "pal", 13600000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      True,  3, {}, 13500000),   # lines of 870 / 871 samples
 ]
 
 TABLES = [
@@ -72,7 +79,7 @@ TABLES = [
     ("fm_mono_lut", np.int32), ("nicam_taps", np.int16), ("nicam_cc", np.int16),
     ("limiter_shape", np.int16), ("limiter_vtaps", np.int32), ("limiter_ftaps", np.int32),
     ("fm_secam_lut", np.int32), ("fm_secam_bell", np.int16), ("fm_secam_fir", np.int16), ("secam_l_fir", np.int16),
-    ("teletext_lut", np.int16), ("fm_video_lut", np.int32),
+    ("teletext_lut", np.int16), ("fm_video_lut", np.int32), ("resampler_taps", np.int16),
 ]
 
 
@@ -102,8 +109,9 @@ def main():
     for case in CASES:
         cid, mode, sr, flags, pflags, real, nframes = case[:7]
         extra = case[7] if len(case) > 7 else {}
+        pixel_rate = case[8] if len(case) > 8 else 0
         teletext = any("@TTRAW@" in f for f in flags)
-        with refprobe.RefProbe(mode, sr, pflags, teletext=("raw:" + ttraw) if teletext else None) as r:
+        with refprobe.RefProbe(mode, sr, pflags, pixel_rate=pixel_rate, teletext=("raw:" + ttraw) if teletext else None) as r:
             info = dict(r.info)
             key = "frame_%dx%d" % (info["active_width"], info["active_lines"])
             if key not in src:
@@ -117,6 +125,11 @@ def main():
 
         W, L = info["width"], info["lines"]
         fs = W * L
+        if pixel_rate:
+            # the cases are chosen so that a frame and a line resample to whole numbers of samples
+            assert (fs * sr) % pixel_rate == 0
+            fs = fs * sr // pixel_rate
+            W = fs // L     # the nominal line; where lines vary in width the excerpts are just windows of the stream
         bps = 2 if real else 4
         data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw).replace("@PASS@", passfile) for f in flags], nframes * fs * bps)
         assert len(data) == nframes * fs * bps, (cid, len(data))
@@ -131,7 +144,7 @@ def main():
 
         digests[cid] = {
             "mode": mode, "sample_rate": sr, "cli_flags": flags, "probe_flags": pflags, "real": real,
-            "width": W, "lines": L, "frames": nframes, "teletext": teletext, "extra": extra,
+            "width": W, "lines": L, "frames": nframes, "teletext": teletext, "extra": extra, "pixel_rate": pixel_rate, "frame_samples": fs,
             "sha256_cumulative": per_frame,   # sha256 of the first 1, 2, ... frames
             "info": info, "tables": tabs,
         }

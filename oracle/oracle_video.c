@@ -118,6 +118,7 @@ long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
 	if(strcmp(name, "vfilter_itaps") == 0) return(_copy(dst, max_bytes, s->vf_itaps, (long) s->vf_ntaps * sizeof(int16_t)));
 	if(strcmp(name, "vfilter_qtaps") == 0) return(_copy(dst, max_bytes, s->vf_qtaps, (long) s->vf_ntaps * sizeof(int16_t)));
 	if(strcmp(name, "fm_mono_lut") == 0) return(_copy(dst, max_bytes, s->fm_mono.lut, 65536L * sizeof(c32_t)));
+	if(strcmp(name, "resampler_taps") == 0) return(_copy(dst, max_bytes, s->rs_taps, s->rs_taps ? (long) s->rs_L * s->rs_ataps * sizeof(int16_t) : 0));
 	if(strcmp(name, "fm_video_lut") == 0) return(_copy(dst, max_bytes, s->fm_video.lut, s->fm_video.lut ? 65536L * sizeof(c32_t) : 0));
 	if(strcmp(name, "nicam_taps") == 0) return(_copy(dst, max_bytes, s->nicam.taps, (long) s->nicam.ntaps * sizeof(int16_t)));
 	if(strcmp(name, "nicam_cc") == 0) return(_copy(dst, max_bytes, s->nicam.cc, (long) s->nicam.cc_len * sizeof(c16_t)));

@@ -248,6 +248,19 @@ long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
 		}
 		return(0);
 	}
+	if(strcmp(name, "resampler_taps") == 0)
+	{
+		int i;
+		for(i = 0; i < s->nprocesses; i++)
+		{
+			if(strcmp(s->processes[i].name, "vresampler") == 0)
+			{
+				struct { int channels; fir_int16_t fir[2]; } *fp = s->processes[i].arg;
+				return(_copy(dst, max_bytes, fp->fir[0].itaps, (long) fp->fir[0].ntaps * sizeof(int16_t)));
+			}
+		}
+		return(0);
+	}
 	if(strcmp(name, "fm_mono_lut") == 0)
 		return(_copy(dst, max_bytes, s->fm_mono.lut, s->fm_mono.lut ? 65536L * sizeof(cint32_t) : 0));
 	if(strcmp(name, "fm_video_lut") == 0)

@@ -11,10 +11,10 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=None, passthru=None):
+def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=None, passthru=None, pixel_rate=0):
     batch = batch or nframes
     out = []
-    with H.Engine(conf, sr, device=0, max_frames=batch) as e:
+    with H.Engine(conf, sr, device=0, max_frames=batch, pixel_rate=pixel_rate) as e:
         e.frame_upload(0, frame, interlaced)
         if passthru is not None:
             e.passthru_write(passthru)
@@ -50,7 +50,8 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full",
                                   "i_tt", "l_tt",
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
-                                  "pal_fm_pass"])
+                                  "pal_fm_pass",
+                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -58,8 +59,8 @@ def test_stream_equals_reference_digests(golden, case):
     nframes = c["frames"]
     iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
                  teletext=golden.teletext_rows if c.get("teletext") else None,
-                 passthru=util.passthru_signal() if conf.passthru else None)
-    fs = c["width"] * c["lines"]
+                 passthru=util.passthru_signal() if conf.passthru else None, pixel_rate=c.get("pixel_rate", 0))
+    fs = c.get("frame_samples", c["width"] * c["lines"])
     # excerpted lines first: a readable failure
     idx = golden.lines[case + "_idx"]
     ref = golden.lines[case]
@@ -231,9 +232,10 @@ def test_dropin_binary_equals_reference_cli(golden):
         return bytes(out)
 
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
-    for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail"):
+    for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
+                 "i_px135", "pal_px135_s136"):
         c = golden.cases[case]
-        fs = c["width"] * c["lines"]
+        fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4
         nframes = 3
         flags = ["-m", c["mode"], "-s", str(c["sample_rate"])] + golden.cli_flags(case)

@@ -9,14 +9,16 @@ import util
 
 HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_ghost", "vfilter_itaps",
                "vfilter_qtaps", "fm_mono_lut", "nicam_taps", "nicam_cc", "limiter_shape", "limiter_vtaps",
-               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir", "teletext_lut", "fm_video_lut"]
+               "limiter_ftaps", "fm_secam_lut", "fm_secam_bell", "fm_secam_fir", "secam_l_fir", "teletext_lut", "fm_video_lut", "resampler_taps"]
 
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt",
-                                  "pal_fm", "ntsc_fm", "secam_fm_tail"])
+                                  "pal_fm", "ntsc_fm", "secam_fm_tail", "i_px135", "i_px2025", "l_px2025", "pal_px16_s14",
+                                  "m_px135_s27", "pal_px135_s136"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
-    with H.Engine(conf, sr, device=-1) as e, oracle.Oracle(conf, sr) as o:
+    pr = golden.cases[case].get("pixel_rate", 0)
+    with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e, oracle.Oracle(conf, sr, pr) as o:
         if golden.cases[case].get("teletext"):
             o.teletext_packets(0, golden.teletext_rows(0), 0)
         for name in HOST_TABLES:
@@ -24,6 +26,15 @@ def test_host_tables_equal_oracle(golden, case):
         for k in ("width", "half_width", "active_width", "active_left", "lines", "active_lines", "white_level",
                   "black_level", "blanking_level", "sync_level", "colour_lookup_width", "burst_left", "burst_width"):
             assert e.info[k] == o.info[k], k
+        assert e.info["max_width"] == o.info["max_width"]
+        if pr:
+            # geometry of the resampled stream: frame length, line widths, start-up samples
+            assert e.info["frame_samples"] == golden.cases[case]["frame_samples"]
+            o.set_frame(golden.frame(case))
+            o.render_lines(700)
+            w = o.last_widths()
+            assert np.array_equal(e.line_widths(0, 700), w)
+            assert np.array_equal(e.line_widths(650, 50), w[650:])
 
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full"])
@@ -179,6 +190,25 @@ def test_fm_video_host_tail_equals_oracle(golden, case):
             e.passthru_write(sig[1000:])
         cuts = [0, 7 * W, 8 * W, 250 * W, nl * W]
         got = np.concatenate([e.host_fm_video(pre[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, want)
+
+
+def test_audio_runs_over_the_resamplers_startup_lines(golden):
+    """--pixelrate: the audio process has run over the never-emitted start-up chunks
+    (info.startup_samples) when the first output sample is made."""
+    case = "i_px135"
+    conf, sr = golden.conf(case)
+    pr = golden.cases[case]["pixel_rate"]
+    nl = 400
+    with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e, oracle.Oracle(conf, sr, pr) as o:
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        o.render_lines(nl)
+        want = o.last_carrier()
+        for _ in range(2):
+            e.audio_write(golden.audio)
+        assert e.info["startup_samples"] == 2048
+        got, _, _ = e.host_side_streams(e.info["startup_samples"], len(want))
     assert np.array_equal(got, want)
 
 

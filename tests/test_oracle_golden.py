@@ -12,16 +12,18 @@ import util
 CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_full", "ntsc_bb", "i_mono", "g_full",
               "pal_bb_filter", "i_20m", "secam_bb", "l_raster", "l_full", "i_tt", "l_tt"]
 # the complex tail (swap_iq, offset, passthru) and FM video; the passthru source ends inside frame 3
+# --pixelrate: raster at the pixel rate + poly-phase resampler (the last one has lines of 870 / 871 samples)
+CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     W, L = c["width"], c["lines"]
     nframes = c["frames"] if c.get("extra", {}).get("passthru") else min(2, c["frames"])
-    with oracle.Oracle(conf, sr) as o:
+    with oracle.Oracle(conf, sr, c.get("pixel_rate", 0)) as o:
         o.set_frame(golden.frame(case))
         o.set_audio(golden.audio, True)
         if conf.passthru:
@@ -30,9 +32,10 @@ def test_oracle_stream_matches_reference_cli(golden, case):
             for f in range(nframes + 1):
                 o.teletext_packets(f, golden.teletext_rows(f), 0xFFFFFFFF)
         iq = o.render_lines(nframes * L)
-    assert iq.shape[0] == nframes * W * L
+    fs = c.get("frame_samples", W * L)
+    assert iq.shape[0] == nframes * fs
     for n in range(nframes):
-        got = util.sha256(util.stream_bytes(iq[: (n + 1) * W * L], c["real"]))
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
         assert got == c["sha256_cumulative"][n], "frame %d of %s differs from the reference" % (n + 1, case)
     # the excerpted lines, for a readable failure
     idx = golden.lines[case + "_idx"]
@@ -44,11 +47,12 @@ def test_oracle_stream_matches_reference_cli(golden, case):
         assert np.array_equal(mine, ref[j]), "line %d of %s" % (g, case)
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full", "l_tt", "pal_fm", "ntsc_fm"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "i_20m", "l_full", "l_tt", "pal_fm", "ntsc_fm",
+                                  "i_px135", "l_px2025", "pal_px135_s136"])
 def test_oracle_tables_match_reference(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
-    with oracle.Oracle(conf, sr) as o:
+    with oracle.Oracle(conf, sr, c.get("pixel_rate", 0)) as o:
         if c.get("teletext"):
             o.teletext_packets(0, golden.teletext_rows(0), 0)
         for k in ("width", "half_width", "active_width", "active_left", "white_level", "black_level",

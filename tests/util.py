@@ -14,7 +14,7 @@ TABLE_DTYPES = {
     "fm_mono_lut": np.int32, "nicam_taps": np.int16, "nicam_cc": np.int16,
     "limiter_shape": np.int16, "limiter_vtaps": np.int32, "limiter_ftaps": np.int32,
     "fm_secam_lut": np.int32, "fm_secam_bell": np.int16, "fm_secam_fir": np.int16, "secam_l_fir": np.int16,
-    "teletext_lut": np.int16, "fm_video_lut": np.int32,
+    "teletext_lut": np.int16, "fm_video_lut": np.int32, "resampler_taps": np.int16,
 }
 
 
