@@ -19,6 +19,9 @@ extern "C" {
 #define HVK_MAX_VF_TAPS  64
 #define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
 #define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
+#define HVK_VBI_OPS      48     /* VBI data lines per frame (32 teletext + WSS + 4 VITC + spare) */
+#define HVK_VBI_OPWORDS  16     /* dwords per op: sym_base, nbits, blank range, spare, 12 data words */
+#define HVK_VBI_LUTS     3      /* 0 teletext, 1 WSS, 2 VITC */
 
 typedef struct { int16_t i, q; } hvk_c16_t;
 typedef struct { int32_t i, q; } hvk_c32_t;
@@ -84,6 +87,11 @@ typedef struct {
 	int32_t rs_shift;       /* resampled-stream index (frame local) of output sample 0's filter centre */
 	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
 	int32_t teletext;       /* teletext symbol table present */
+	int32_t vbi;            /* VBI data lines (teletext / WSS / VITC ops) may be present */
+	int32_t vits;           /* insertion test signals: 0 none, else the number of VITS lines (2 or 4) */
+	int32_t vits_line[4];   /* their 0-based line numbers */
+	int32_t vits_pi, vits_pq;   /* chroma phase of the insertion signal, Q15 */
+	int32_t black;          /* black level (WSS blanks part of line 23 to it) */
 	int32_t fm_video;       /* the engine's device output is the FM modulator's input (hvk_tail.c does the rest) */
 	int32_t swap_iq, has_offset, has_passthru;   /* complex tail done by hvk_k_tail (not FM video) */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
@@ -129,6 +137,15 @@ typedef struct {
 	/* teletext symbols (src/teletext.c:1057-1074): [360] { offset, length, start in tt_values } */
 	int32_t *tt_symbols;
 	int16_t *tt_values; int32_t tt_total;
+	/* all vbidata look-up tables in one store (hvk_tables.c:_vbi_store): symbol i of LUT u is
+	 * vbi_sym[(lut_base[u] + i) * 3 ...] = { first sample, length, start in vbi_val } */
+	int32_t *vbi_sym; int32_t vbi_nsym;
+	int16_t *vbi_val; int32_t vbi_total;
+	int32_t lut_base[HVK_VBI_LUTS], lut_nsym[HVK_VBI_LUTS];
+	uint8_t wss_bits[18];       /* line 23's 137 bits, MSB first (src/wss.c:118-136) */
+	int32_t wss_blank_lo, wss_blank_hi;
+	int32_t vitc_lines[2], vitc_fps, vitc_drop;
+	int16_t *vits_l, *vits_c;   /* [vits][width]: luma added, chroma amplitude */
 	/* SECAM (src/video.c:4075-4162) */
 	int32_t secam_level;
 	hvk_c32_t *secam_lut;       /* 65536 FM steps at the pixel rate */
@@ -147,6 +164,10 @@ void hvk_tables_line_widths(const hvk_tables_t *t, int64_t first, int n, int32_t
 void hvk_tables_free(hvk_tables_t *t);
 void hvk_tables_default_ghost(hvk_tables_t *t);
 long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes);
+
+/* The 90 bits of a VITC line (src/vitc.c:120-196) as 12 bytes, least significant bit first;
+ * frame counts from 1, line is the 1-based line number. Returns the number of bits. */
+int hvk_vitc_bits(const hvk_tables_t *t, int frame, int line, uint8_t data[12]);
 
 /* Host SECAM colour pre-pass (hvk_secam.c) */
 typedef struct hvk_secam hvk_secam_t;

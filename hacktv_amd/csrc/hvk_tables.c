@@ -603,6 +603,316 @@ static int _build_secam(hvk_tables_t *t, double level)
 	return(HVK_OK);
 }
 
+/* ---- step-shaped vbidata tables (src/vbidata.c:58-81, :145-184): symbol b is a pulse of
+ * `width` samples at offset + width * b with integrated raised-cosine edges, exactly the
+ * quantiser the sync pulses use ---- */
+static int _append_step_lut(hvk_tables_t *t, int lut, int nsymbols, int level, double width, double rise, double offset)
+{
+	int b, first, total = 0;
+	int32_t *sym;
+	int16_t *val;
+
+	for(b = 0; b < nsymbols; b++) total += _quantise_pulse(NULL, &first, offset + width * b, width, rise, level);
+
+	sym = realloc(t->vbi_sym, (size_t) (t->vbi_nsym + nsymbols) * 3 * sizeof(int32_t));
+	if(!sym) return(HVK_OUT_OF_MEMORY);
+	t->vbi_sym = sym;
+	val = realloc(t->vbi_val, (size_t) (t->vbi_total + total + 8) * sizeof(int16_t));
+	if(!val) return(HVK_OUT_OF_MEMORY);
+	t->vbi_val = val;
+
+	t->lut_base[lut] = t->vbi_nsym;
+	t->lut_nsym[lut] = nsymbols;
+
+	for(b = 0; b < nsymbols; b++)
+	{
+		int len = _quantise_pulse(t->vbi_val + t->vbi_total, &first, offset + width * b, width, rise, level);
+		sym[(t->vbi_nsym + b) * 3 + 0] = len ? first : 0;
+		sym[(t->vbi_nsym + b) * 3 + 1] = len;
+		sym[(t->vbi_nsym + b) * 3 + 2] = t->vbi_total;
+		t->vbi_total += len;
+	}
+	memset(t->vbi_val + t->vbi_total, 0, 8 * sizeof(int16_t));
+	t->vbi_nsym += nsymbols;
+	return(HVK_OK);
+}
+
+/* teletext's raised-cosine table joins the same store */
+static int _append_teletext_lut(hvk_tables_t *t)
+{
+	int32_t *sym = realloc(t->vbi_sym, (size_t) (t->vbi_nsym + 360) * 3 * sizeof(int32_t));
+	int16_t *val;
+	int b;
+
+	if(!sym) return(HVK_OUT_OF_MEMORY);
+	t->vbi_sym = sym;
+	val = realloc(t->vbi_val, (size_t) (t->vbi_total + t->tt_total + 8) * sizeof(int16_t));
+	if(!val) return(HVK_OUT_OF_MEMORY);
+	t->vbi_val = val;
+
+	t->lut_base[0] = t->vbi_nsym;
+	t->lut_nsym[0] = 360;
+	for(b = 0; b < 360; b++)
+	{
+		sym[(t->vbi_nsym + b) * 3 + 0] = t->tt_symbols[b * 3 + 0];
+		sym[(t->vbi_nsym + b) * 3 + 1] = t->tt_symbols[b * 3 + 1];
+		sym[(t->vbi_nsym + b) * 3 + 2] = t->vbi_total + t->tt_symbols[b * 3 + 2];
+	}
+	memcpy(t->vbi_val + t->vbi_total, t->tt_values, t->tt_total * sizeof(int16_t));
+	t->vbi_total += t->tt_total;
+	memset(t->vbi_val + t->vbi_total, 0, 8 * sizeof(int16_t));
+	t->vbi_nsym += 360;
+	return(HVK_OK);
+}
+
+/* Widescreen signalling (src/wss.c:46-137): run-in and start code, then four groups of
+ * bi-phase coded bits; 137 step symbols of 200 ns starting 11 us after 0H, 5/7 of white */
+static void _wss_group(uint8_t *vbi, uint8_t code, int *offset, int length)
+{
+	int i, o = *offset;
+
+	while(length--)
+	{
+		for(i = 0; i < 6; i++, o++)
+		{
+			const int b = 7 - (o % 8);
+			if(i == 3) code ^= 1;
+			vbi[o / 8] &= ~(1 << b);
+			vbi[o / 8] |= (code & 1) << b;
+		}
+		code >>= 1;
+	}
+
+	*offset = o;
+}
+
+static int _build_wss(hvk_tables_t *t)
+{
+	static const uint8_t lead[7] = { 0xF8, 0xE3, 0x8E, 0x38, 0xF1, 0xE0, 0xF8 };
+	const hvk_config_t *c = &t->conf;
+	int level = round((t->white_level - t->black_level) * (5.0 / 7.0));
+	int o = 29 + 24, r;
+
+	if(c->lines != 625) return(HVK_UNSUPPORTED);            /* src/hacktv.c: 625-line modes only */
+	if(c->wss < 0 || c->wss > 0x0F) return(HVK_UNSUPPORTED); /* "auto" (0xFF) needs the source's pixel aspect */
+
+	r = _append_step_lut(t, 1, 137, level, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 11e-6);
+	if(r != HVK_OK) return(r);
+
+	memset(t->wss_bits, 0, sizeof(t->wss_bits));
+	memcpy(t->wss_bits, lead, sizeof(lead));
+	_wss_group(t->wss_bits, c->wss, &o, 4);     /* aspect ratio */
+	_wss_group(t->wss_bits, 0x00, &o, 4);       /* enhanced services */
+	_wss_group(t->wss_bits, 0x00, &o, 3);       /* subtitles */
+	_wss_group(t->wss_bits, 0x00, &o, 3);       /* reserved */
+
+	/* 42.5 us of the line are blanked first, from mid-line (sic, src/wss.c:176-182) */
+	t->wss_blank_lo = t->k.half_width;
+	t->wss_blank_hi = round(t->pixel_rate * 42.5e-6);
+	return(HVK_OK);
+}
+
+/* Vertical interval time code (src/vitc.c:42-112): 116 (625) / 115 (525) step symbols per line */
+static int _build_vitc(hvk_tables_t *t)
+{
+	const hvk_config_t *c = &t->conf;
+	int hr, level = round((t->white_level - t->black_level) * 0.785);
+
+	if(c->type == HVK_RASTER_625) { t->vitc_lines[0] = 19; t->vitc_lines[1] = 332; hr = 116; }
+	else { t->vitc_lines[0] = 14; t->vitc_lines[1] = 277; hr = 115; }
+
+	if(c->frame_rate.num <= 30 && c->frame_rate.den == 1) { t->vitc_fps = c->frame_rate.num; t->vitc_drop = 0; }
+	else if(c->frame_rate.num == 30000 && c->frame_rate.den == 1001) { t->vitc_fps = 30; t->vitc_drop = 1; }
+	else return(HVK_UNSUPPORTED);
+
+	return(_append_step_lut(t, 2, hr, level, (double) t->k.width / hr, t->pixel_rate * 200e-9, 0));
+}
+
+static int _put_bits(uint8_t *data, int offset, uint64_t bits, int nbits)
+{
+	for(; nbits; nbits--, offset++, bits >>= 1)
+	{
+		if(bits & 1) data[offset >> 3] |= 1 << (offset & 7);
+		else data[offset >> 3] &= ~(1 << (offset & 7));
+	}
+	return(offset);
+}
+
+int hvk_vitc_bits(const hvk_tables_t *t, int frame, int line, uint8_t data[12])
+{
+	const int fps = t->vitc_fps, second_field = line >= t->vitc_lines[1];
+	uint32_t tc;
+	uint8_t crc = 0;
+	int fn = frame, x = 0, i;
+
+	if(t->vitc_drop)
+	{
+		/* drop-frame numbering for 29.97 fps */
+		fn += (fn / 17982) * 18;
+		fn += (fn % 18000 - 2) / 1798 * 2;
+	}
+
+	tc  = (fn % fps % 10) << 0;
+	tc |= (fn % fps / 10) << 4;
+	tc |= (t->vitc_drop ? 1 : 0) << 6;
+	tc |= 1 << 7;                               /* colour framing */
+	fn /= fps;
+	tc |= (fn % 10) << 8;
+	tc |= (fn / 10 % 6) << 12;
+	if(t->conf.type != HVK_RASTER_625) tc |= (uint32_t) second_field << 15;
+	fn /= 60;
+	tc |= (fn % 10) << 16;
+	tc |= (fn / 10 % 6) << 20;
+	fn /= 60;
+	tc |= (fn % 24 % 10) << 24;
+	tc |= (uint32_t) (fn % 24 / 10) << 28;
+	if(t->conf.type == HVK_RASTER_625) tc |= (uint32_t) second_field << 31;
+
+	memset(data, 0, 12);
+	for(i = 0; i < 8; i++)
+	{
+		x = _put_bits(data, x, 0x01, 2);        /* sync */
+		x = _put_bits(data, x, tc >> (i * 4), 4);
+		x = _put_bits(data, x, 0, 4);           /* user bits */
+	}
+	x = _put_bits(data, x, 0x01, 2);
+	_put_bits(data, x, 0, 8);
+	for(i = 0; i < 11; i++) crc ^= data[i];
+	crc = ((crc << 6) | (crc >> 2)) & 0xFF;
+	x = _put_bits(data, x, crc, 8);
+	return(x);
+}
+
+/* Insertion test signals (src/vits.c:53-296): per line a luma waveform that is added and a
+ * chroma amplitude that rides on the line's sub-carrier */
+static double _sin2_pulse(double t, double position, double width, double amplitude)
+{
+	double a;
+	t -= position - width;
+	if(t <= 0 || t >= width * 2) return(0);
+	a = t / (width * 2) * M_PI;
+	return(pow(sin(a), 2) * amplitude);
+}
+
+static int _build_vits(hvk_tables_t *t)
+{
+	static const double b625[6] = { 0.5e6, 1.0e6, 2.0e6, 4.0e6, 4.8e6, 5.8e6 };
+	static const double b525[6] = { 0.50e6, 1.00e6, 2.00e6, 3.00e6, 3.58e6, 4.20e6 };
+	const int W = t->k.width, is625 = t->conf.lines == 625;
+	const int n = is625 ? 4 : 2;
+	const int level = t->white_level - t->blanking_level;   /* src/video.c:4217-4221 */
+	const double unit = is625 ? 0.7 : 100;
+	double ts, h, bs[6];
+	int i, x, b;
+
+	t->vits_l = calloc((size_t) n * W, sizeof(int16_t));
+	t->vits_c = calloc((size_t) n * W, sizeof(int16_t));
+	if(!t->vits_l || !t->vits_c) return(HVK_OUT_OF_MEMORY);
+
+	ts = is625 ? 1.0 / 25 / 625 : 1001.0 / 30000 / 525;
+	h = is625 ? ts / 32 : ts / 128;
+	ts = ts / W;
+	for(b = 0; b < 6; b++) bs[b] = 2.0 * M_PI * (is625 ? b625[b] : b525[b]);
+
+	for(i = 0; i < n; i++)
+	{
+		for(x = 0; x < W; x++)
+		{
+			double tt = ts * x, r = 0.0, c = 0.0;
+
+			if(is625 && i == 0)                 /* line 17 */
+			{
+				r += _window(tt, 6 * h, 5 * h, 200e-9) * 0.70;
+				r += _sin2_pulse(tt, 13 * h, 200e-9, 0.70);
+				r += _sin2_pulse(tt, 16 * h, 2000e-9, 0.70 / 2);
+				c += _sin2_pulse(tt, 16 * h, 2000e-9, 0.70 / 2);
+				r += _window(tt, 20 * h, 2 * h, 200e-9) * 0.14;
+				r += _window(tt, 22 * h, 2 * h, 200e-9) * 0.28;
+				r += _window(tt, 24 * h, 2 * h, 200e-9) * 0.42;
+				r += _window(tt, 26 * h, 2 * h, 200e-9) * 0.56;
+				r += _window(tt, 28 * h, 3 * h, 200e-9) * 0.70;
+			}
+			else if(is625 && i == 1)            /* line 18 */
+			{
+				r += _window(tt, 6 * h, 25 * h, 200e-9) *  0.35;
+				r += _window(tt, 6 * h,  2 * h, 200e-9) *  0.21;
+				r += _window(tt, 8 * h,  2 * h, 200e-9) * -0.21;
+				for(b = 0; b < 6; b++)
+				{
+					r += _window(tt, (12 + 3 * b) * h, 2 * h, 200e-9) * 0.21
+					   * sin((tt - (12 + 3 * b) * h) * bs[b]);
+				}
+			}
+			else if(is625 && i == 2)            /* line 330 */
+			{
+				r += _window(tt, 6 * h, 5 * h, 200e-9) * 0.70;
+				r += _sin2_pulse(tt, 13 * h, 200e-9, 0.70);
+				c += _window(tt, 15 * h, 15 * h, 1e-6) * 0.28 / 2;
+				r += _window(tt, 20 * h, 2 * h, 200e-9) * 0.14;
+				r += _window(tt, 22 * h, 2 * h, 200e-9) * 0.28;
+				r += _window(tt, 24 * h, 2 * h, 200e-9) * 0.42;
+				r += _window(tt, 26 * h, 2 * h, 200e-9) * 0.56;
+				r += _window(tt, 28 * h, 3 * h, 200e-9) * 0.70;
+			}
+			else if(is625)                      /* line 331 */
+			{
+				r += _window(tt, 6 * h, 25 * h, 200e-9) * 0.35;
+				c += _window(tt, 7 * h, 7 * h, 1e-6) * 0.70 / 2;
+				c += _window(tt, 17 * h, 13 * h, 1e-6) * 0.42 / 2;
+			}
+			else if(i == 0)                     /* 525: line 17 */
+			{
+				r += _window(tt, 24 * h, 36 * h, 125e-9) * 100;
+				r += _sin2_pulse(tt, 68 * h, 250e-9, 100);
+				r += _sin2_pulse(tt, 75 * h, 1570e-9, 100 / 2);
+				c += _sin2_pulse(tt, 75 * h, 1570e-9, 100 / 2);
+				r += _window(tt,  92 * h,  6 * h, 250e-9) * 18;
+				r += _window(tt,  98 * h,  6 * h, 250e-9) * 36;
+				r += _window(tt, 104 * h,  6 * h, 250e-9) * 54;
+				r += _window(tt, 110 * h,  6 * h, 250e-9) * 72;
+				r += _window(tt, 116 * h,  8 * h, 250e-9) * 90;
+				c += _window(tt,  84 * h, 38 * h, 400e-9) * 40 / 2;
+			}
+			else                                /* 525: line 280 */
+			{
+				r += _window(tt, 24 * h, 8 * h, 125e-9) * 100;
+				r += _window(tt, 32 * h, 92 * h, 125e-9) * 50;
+				r += _window(tt, 36 * h, 12 * h, 250e-9) * 50 / 2 * sin((tt - 36 * h) * bs[0]);
+				for(b = 1; b < 6; b++)
+				{
+					r += _window(tt, (40 + 8 * b) * h, 8 * h, 250e-9) * 50 / 2
+					   * sin((tt - (40 + 8 * b) * h) * bs[b]);
+				}
+				c += _window(tt,  92 * h,  8 * h, 400e-9) * 20 / 2;
+				c += _window(tt, 100 * h,  8 * h, 400e-9) * 40 / 2;
+				c += _window(tt, 108 * h, 12 * h, 400e-9) * 80 / 2;
+			}
+
+			t->vits_l[(size_t) i * W + x] = lround(r / unit * level);
+			t->vits_c[(size_t) i * W + x] = lround(c / unit * level);
+		}
+	}
+
+	t->k.vits = n;
+	if(is625) { t->k.vits_line[0] = 16; t->k.vits_line[1] = 17; t->k.vits_line[2] = 329; t->k.vits_line[3] = 330; }
+	else { t->k.vits_line[0] = 16; t->k.vits_line[1] = 279; }
+
+	if(t->conf.colour_mode == HVK_PAL)
+	{
+		/* 60 degrees from the +(B-Y) axis */
+		const double p = 60.0 * (M_PI / 180.0);
+		t->k.vits_pi = (int16_t) round(cos(p) * INT16_MAX);
+		t->k.vits_pq = (int16_t) round(sin(p) * INT16_MAX);
+	}
+	else
+	{
+		t->k.vits_pi = 0;
+		t->k.vits_pq = -INT16_MAX;
+	}
+
+	return(HVK_OK);
+}
+
 /* ------------------------------------------------------------------ */
 
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate)
@@ -954,12 +1264,20 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->k.has_passthru = c->passthru != 0;
 	if(c->offset != 0) t->offset_delta = _unit_phasor(2.0 * M_PI / t->sample_rate * c->offset);
 
+	t->k.black = t->black_level;
+
 	if(c->teletext)
 	{
 		/* 625-line systems only (src/hacktv.c:1182-1186) */
 		if(c->lines != 625) return(HVK_UNSUPPORTED);
 		if((r = _build_teletext(t)) != HVK_OK) return(r);
+		if((r = _append_teletext_lut(t)) != HVK_OK) return(r);
 	}
+
+	if(c->wss && (r = _build_wss(t)) != HVK_OK) return(r);
+	if(c->vitc && (r = _build_vitc(t)) != HVK_OK) return(r);
+	if(c->vits && (r = _build_vits(t)) != HVK_OK) return(r);
+	t->k.vbi = t->vbi_nsym > 0;
 
 	return(_build_linedesc(t));
 }
@@ -985,6 +1303,10 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->secam_notch);
 	free(t->fmv_lut);
 	free(t->rs_taps);
+	free(t->vbi_sym);
+	free(t->vbi_val);
+	free(t->vits_l);
+	free(t->vits_c);
 	memset(t, 0, sizeof(*t));
 }
 

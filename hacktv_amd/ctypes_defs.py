@@ -62,6 +62,9 @@ class HvkConfig(C.Structure):
         ("am_mono_carrier", C.c_double),
         ("vfilter", C.c_int),
         ("teletext", C.c_int),
+        ("wss", C.c_int),
+        ("vits", C.c_int),
+        ("vitc", C.c_int),
         ("fm_level", C.c_double),
         ("fm_deviation", C.c_double),
         ("swap_iq", C.c_int),

@@ -124,6 +124,14 @@ typedef struct hvk_config_t {
 	                             * (625-line modes; the reference's conf.teletext names the page
 	                             * source, which stays with the caller: hvk_teletext_packets()) */
 
+	/* VBI inserters whose data are a function of the configuration and the frame number */
+	int wss;                    /* widescreen signalling on line 23 (625 lines): 0 none, else the reference's
+	                             * mode byte, src/wss.c:33-44 -- 0x08 4:3, 0x01 14:9-letterbox, 0x02 14:9-top,
+	                             * 0x0B 16:9-letterbox, 0x04 16:9-top, 0x0D 16:9+-letterbox, 0x0E 14:9-window,
+	                             * 0x07 16:9 ("auto" depends on the source's pixel aspect: not supported) */
+	int vits;                   /* --vits: insertion test signals, lines 17/18/330/331 (625) or 17/280 (525) */
+	int vitc;                   /* --vitc: vertical interval time code, lines 19/21/332/334 (625) or 14/16/277/279 (525) */
+
 	/* FM video (modulation == HVK_FM), src/video.h:141-142 */
 	double fm_level;
 	double fm_deviation;        /* Hz per unit of signal */

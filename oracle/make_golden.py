@@ -70,6 +70,12 @@ CASES = [
     ("l_px2025",      "l",    16000000, ["--filter", "--pixelrate", "20250000"], refprobe.FLAG_FILTER,      False, 2, {}, 20250000),
     ("pal_px16_s14",  "pal",  14000000, ["--pixelrate", "16000000"], 0,                                    True,  2, {}, 16000000),
     ("m_px135_s27",   "m",    27000000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      False, 2, {}, 13500000),
+    # VBI inserters: insertion test signals, widescreen signalling, time code (with teletext they take lines from it)
+    ("i_vbi",         "i",    16000000, ["--filter", "--wss", "16:9", "--vitc", "--vits"], refprobe.FLAG_FILTER, False, 3, {"wss": 0x07, "vitc": 1, "vits": 1}),
+    ("i_vbi_tt",      "i",    16000000, ["--noaudio", "--wss", "4:3", "--vitc", "--vits", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO, False, 2, {"wss": 0x08, "vitc": 1, "vits": 1}),
+    ("m_vbi",         "m",    13500000, ["--filter", "--vitc", "--vits"], refprobe.FLAG_FILTER,             False, 3, {"vitc": 1, "vits": 1}),
+    ("l_vbi",         "l",    16000000, ["--filter", "--wss", "14:9-window", "--vitc", "--vits"], refprobe.FLAG_FILTER, False, 2, {"wss": 0x0E, "vitc": 1, "vits": 1}),
+    ("pal_vbi_px",    "pal",  16000000, ["--vits", "--vitc", "--wss", "16:9-top", "--pixelrate", "13500000"], 0, True, 2, {"wss": 0x04, "vitc": 1, "vits": 1}, 13500000),
     ("pal_px135_s136", "pal", 13600000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      True,  3, {}, 13500000),   # lines of 870 / 871 samples
 ]
 

@@ -162,6 +162,14 @@ struct orc_t {
 	orc_pulse_t *tt_sym;
 	struct { long frame; uint32_t mask; uint8_t packets[32][45]; } tt_queue[16];
 
+	/* VBI inserters (oracle_vbi.c) */
+	int16_t *vits_line[4];
+	c16_t vits_phase;
+	orc_pulse_t *wss_lut, *vitc_lut;
+	uint8_t wss_vbi[18];
+	int wss_blank_width;
+	int vitc_lines[2], vitc_hr, vitc_fps, vitc_drop;
+
 	/* stage taps of the last render call */
 	int16_t *last_raster; long last_raster_len;
 	int16_t *last_carrier; long last_carrier_len;
@@ -187,6 +195,12 @@ void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int
 int orc_teletext_init(orc_t *s);
 void orc_teletext_free(orc_t *s);
 void orc_teletext_render(orc_t *s, int16_t *o, const uint8_t packet[45]);
+
+/* oracle_vbi.c */
+int orc_vbi_init(orc_t *s);
+void orc_vbi_free(orc_t *s);
+void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut);
+int orc_vbi_allocated(orc_t *s, int line);
 
 /* oracle_tail.c */
 int orc_tail_init(orc_t *s);

@@ -46,7 +46,7 @@ orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsign
 	s->sample_rate = sample_rate;
 	s->pixel_rate = pixel_rate ? pixel_rate : sample_rate;   /* src/video.c:3839 */
 
-	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0)
+	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0 || orc_vbi_init(s) != 0)
 	{
 		orc_close(s);
 		return(NULL);
@@ -66,6 +66,7 @@ void orc_close(orc_t *s)
 	orc_free_tables(s);
 	orc_audio_free(s);
 	orc_tail_free(s);
+	orc_vbi_free(s);
 	orc_teletext_free(s);
 	free(s->S);
 	free(s->last_raster);
@@ -265,6 +266,20 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 				orc_secam_line(s, orc_line_ptr(s, g), frame, line, la, ra, vy);
 				s->sc_done++;
 			}
+		}
+
+		/* VITS, WSS, VITC: line processes between the colour process and teletext
+		 * (src/video.c:4214-4316) */
+		if((s->conf.vits || s->conf.wss || s->conf.vitc) && s->rastered >= 2)
+		{
+			long g = s->rastered - 2;
+			const c16_t *lut = NULL;
+			if(s->colour_lookup && (s->conf.colour_mode == HVK_PAL || s->conf.colour_mode == HVK_NTSC))
+			{
+				/* the table position advances by one line per line (src/video.c:2906-2910) */
+				lut = &s->colour_lookup[(unsigned long) (((unsigned long long) g * s->width) % s->colour_lookup_width)];
+			}
+			orc_vbi_line(s, g, (int) (g / s->conf.lines) + 1, (int) (g % s->conf.lines) + 1, lut);
 		}
 
 		/* teletext comes after the colour process and before the filter

@@ -25,7 +25,7 @@ def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=
                 e.audio_write(audio)
             if teletext is not None:
                 for i in range(n):
-                    e.teletext_packets(i, teletext(done + i))
+                    e.teletext_packets(i, *teletext(done + i))
             e.render(n)
             out.append(e.fetch(0, n * e.info["frame_samples"]))
             done += n
@@ -58,7 +58,7 @@ def test_stream_equals_reference_digests(golden, case):
     conf, sr = golden.conf(case)
     nframes = c["frames"]
     iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
-                 teletext=golden.teletext_rows if c.get("teletext") else None,
+                 teletext=(lambda f: golden.teletext_rows(f, golden.teletext_skip(case))) if c.get("teletext") else None,
                  passthru=util.passthru_signal() if conf.passthru else None, pixel_rate=c.get("pixel_rate", 0))
     fs = c.get("frame_samples", c["width"] * c["lines"])
     # excerpted lines first: a readable failure

@@ -20,7 +20,7 @@ def test_host_tables_equal_oracle(golden, case):
     pr = golden.cases[case].get("pixel_rate", 0)
     with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e, oracle.Oracle(conf, sr, pr) as o:
         if golden.cases[case].get("teletext"):
-            o.teletext_packets(0, golden.teletext_rows(0), 0)
+            o.teletext_packets(0, golden.teletext_rows(0)[0], 0)
         for name in HOST_TABLES:
             assert np.array_equal(e.table(name, util.TABLE_DTYPES[name]), o.table(name, util.TABLE_DTYPES[name])), name
         for k in ("width", "half_width", "active_width", "active_left", "lines", "active_lines", "white_level",

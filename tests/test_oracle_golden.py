@@ -14,10 +14,12 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 # the complex tail (swap_iq, offset, passthru) and FM video; the passthru source ends inside frame 3
 # --pixelrate: raster at the pixel rate + poly-phase resampler (the last one has lines of 870 / 871 samples)
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"]
+# VBI inserters (insertion test signals, widescreen signalling, time code)
+CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
@@ -30,7 +32,7 @@ def test_oracle_stream_matches_reference_cli(golden, case):
             o.set_passthru(util.passthru_signal())
         if c.get("teletext"):
             for f in range(nframes + 1):
-                o.teletext_packets(f, golden.teletext_rows(f), 0xFFFFFFFF)
+                o.teletext_packets(f, *golden.teletext_rows(f, golden.teletext_skip(case)))
         iq = o.render_lines(nframes * L)
     fs = c.get("frame_samples", W * L)
     assert iq.shape[0] == nframes * fs
@@ -54,7 +56,7 @@ def test_oracle_tables_match_reference(golden, case):
     conf, sr = golden.conf(case)
     with oracle.Oracle(conf, sr, c.get("pixel_rate", 0)) as o:
         if c.get("teletext"):
-            o.teletext_packets(0, golden.teletext_rows(0), 0)
+            o.teletext_packets(0, golden.teletext_rows(0)[0], 0)
         for k in ("width", "half_width", "active_width", "active_left", "white_level", "black_level",
                   "blanking_level", "sync_level", "colour_lookup_width", "burst_left", "burst_width",
                   "burst_phase_i", "burst_phase_q", "chroma_ataps", "fm_mono_level", "nicam_ntaps",

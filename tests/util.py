@@ -55,16 +55,29 @@ class Golden:
             setattr(conf, k, v)
         return conf, c["sample_rate"]
 
-    def teletext_rows(self, frame):
-        """The 32 packets the reference's raw: source yields for a frame from
-        tests/golden/ttraw.bin: 55 55 27 + the next 42-byte record (src/teletext.c:1188-1201)."""
+    def teletext_rows(self, frame, skip=()):
+        """The packets the reference's raw: source yields for a frame from tests/golden/ttraw.bin:
+        55 55 27 + the next 42-byte record (src/teletext.c:1188-1201), one per teletext line
+        (rows 0..15 lines 7..22, rows 16..31 lines 320..335). Rows in `skip` are lines another
+        inserter holds: teletext leaves them alone and keeps the packet for the next line
+        (src/teletext.c:1219). Returns (rows, mask)."""
         rec = np.frombuffer(open(os.path.join(GOLD, "ttraw.bin"), "rb").read(), np.uint8).reshape(-1, 42)
+        use = [r for r in range(32) if r not in skip]
         p = np.zeros((32, 45), np.uint8)
         p[:, 0] = 0x55
         p[:, 1] = 0x55
         p[:, 2] = 0x27
-        p[:, 3:] = rec[frame * 32:(frame + 1) * 32]
-        return p
+        p[use, 3:] = rec[frame * len(use):(frame + 1) * len(use)]
+        mask = 0
+        for r in use:
+            mask |= 1 << r
+        return p, mask
+
+    def teletext_skip(self, case):
+        """Teletext rows (625 lines) held by the case's other inserters: VITS 17/18/330/331, VITC 19/21/332/334."""
+        x = self.cases[case].get("extra", {})
+        lines = ([17, 18, 330, 331] if x.get("vits") else []) + ([19, 21, 332, 334] if x.get("vitc") else [])
+        return tuple(l - 7 if l < 300 else 16 + l - 320 for l in lines)
 
     def cli_flags(self, case, passfile="/tmp/hvk_passthru.bin"):
         """The reference CLI's flags for the case; passthru cases expect passthru_signal() at `passfile`."""
