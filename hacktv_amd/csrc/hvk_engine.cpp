@@ -47,9 +47,13 @@ struct hvk_engine {
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
-	int32_t *d_tt_sym; int16_t *d_tt_val;
-	uint32_t *d_tt_pk, *h_tt_pk;    /* [max_frames][32][12] */
-	uint32_t *d_tt_mask, *h_tt_mask; /* [max_frames] */
+	uint32_t *h_tt_pk;          /* teletext packets queued for the next batch: [max_frames][32][12] */
+	uint32_t *h_tt_mask;        /* [max_frames] rows present */
+	/* VBI data lines (teletext, WSS, VITC): symbol store, per-frame op list and line map */
+	void *d_vbi_sym, *d_vbi_val;
+	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
+	int8_t *d_map, *h_map;      /* [max_frames][lines] */
+	void *d_vits_l, *d_vits_c;
 	hvk_packed_taps_t notch;
 	hvk_tail_t *tail;           /* FM video / offset / passthru serial state (hvk_tail.c) */
 	int16_t *d_off, *h_off;     /* offset phasor side stream, int16 pairs */
@@ -279,15 +283,25 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	if(e->t.k.teletext)
 	{
-		void *p;
-		OPENCHK(_upload(&p, e->t.tt_symbols, sizeof(int32_t) * 360 * 3)); e->d_tt_sym = (int32_t *) p;
-		OPENCHK(_upload(&p, e->t.tt_values, sizeof(int16_t) * (e->t.tt_total + 8))); e->d_tt_val = (int16_t *) p;
-		OPENHIP(hipMalloc((void **) &e->d_tt_pk, (size_t) max_frames * 32 * 12 * 4));
-		OPENHIP(hipMalloc((void **) &e->d_tt_mask, (size_t) max_frames * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_tt_pk, (size_t) max_frames * 32 * 12 * 4, hipHostMallocDefault));
 		OPENHIP(hipHostMalloc((void **) &e->h_tt_mask, (size_t) max_frames * 4, hipHostMallocDefault));
 		memset(e->h_tt_pk, 0, (size_t) max_frames * 32 * 12 * 4);
 		memset(e->h_tt_mask, 0, (size_t) max_frames * 4);
+	}
+
+	if(e->t.k.vbi)
+	{
+		OPENCHK(_upload(&e->d_vbi_sym, e->t.vbi_sym, sizeof(int32_t) * 3 * e->t.vbi_nsym));
+		OPENCHK(_upload(&e->d_vbi_val, e->t.vbi_val, sizeof(int16_t) * (e->t.vbi_total + 8)));
+		OPENHIP(hipMalloc((void **) &e->d_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4));
+		OPENHIP(hipHostMalloc((void **) &e->h_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipHostMallocDefault));
+		OPENHIP(hipMalloc((void **) &e->d_map, (size_t) max_frames * k.lines));
+		OPENHIP(hipHostMalloc((void **) &e->h_map, (size_t) max_frames * k.lines, hipHostMallocDefault));
+	}
+	if(e->t.k.vits)
+	{
+		OPENCHK(_upload(&e->d_vits_l, e->t.vits_l, sizeof(int16_t) * k.vits * k.width));
+		OPENCHK(_upload(&e->d_vits_c, e->t.vits_c, sizeof(int16_t) * k.vits * k.width));
 	}
 
 	if(e->t.k.secam)
@@ -332,9 +346,9 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_tt_sym, e->d_tt_val, e->d_tt_pk, e->d_tt_mask, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_off, e->h_pass, e->h_fm };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -554,6 +568,76 @@ extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int wi
 
 /* ---- render ---- */
 
+/* The VBI data lines of the staged frames (h_fdesc holds their stream frame numbers): per
+ * frame a list of ops -- which symbol table, how many bits, the bits -- and a line -> op map.
+ * One op per line: the first inserter to claim a line keeps it, in the reference's process
+ * order WSS, VITC, teletext (src/video.c:4234-4358; teletext's own vbialloc test,
+ * src/teletext.c:1219, is the caller's business: it decides which rows carry packets). */
+static void _build_vbi_ops(hvk_engine *e, int nframes)
+{
+	const hvk_tables_t &t = e->t;
+	const int lines = t.k.lines;
+
+	memset(e->h_map, 0xFF, (size_t) nframes * lines);
+	memset(e->h_ops, 0, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4);
+
+	for(int i = 0; i < nframes; i++)
+	{
+		uint32_t *ops = e->h_ops + (size_t) i * HVK_VBI_OPS * HVK_VBI_OPWORDS;
+		int8_t *map = e->h_map + (size_t) i * lines;
+		int n = 0;
+
+		auto add = [&](int line0, int lut, int first_symbol, int nbits, const uint8_t *lsb_first_bits, int blank_lo, int blank_hi)
+		{
+			if(n >= HVK_VBI_OPS || line0 < 0 || line0 >= lines || map[line0] >= 0) return;
+			if(nbits > t.lut_nsym[lut] - first_symbol) nbits = t.lut_nsym[lut] - first_symbol;   /* the table's end stops the render */
+			if(nbits > 384) nbits = 384;
+			uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
+			uint8_t bytes[48] = { 0 };
+			memcpy(bytes, lsb_first_bits, (nbits + 7) / 8);
+			op[0] = (uint32_t) (t.lut_base[lut] + first_symbol);
+			op[1] = (uint32_t) nbits;
+			op[2] = (uint32_t) blank_lo | ((uint32_t) blank_hi << 16);
+			memcpy(op + 4, bytes, 48);
+			map[line0] = (int8_t) n++;
+		};
+
+		if(t.conf.wss)
+		{
+			/* line 23; the table's bits are MSB first (src/wss.c:184) */
+			uint8_t rev[18];
+			for(int b = 0; b < 18; b++)
+			{
+				uint8_t v = t.wss_bits[b], r = 0;
+				for(int q = 0; q < 8; q++) if(v & (1 << q)) r |= 0x80 >> q;
+				rev[b] = r;
+			}
+			add(22, 1, 0, 137, rev, t.wss_blank_lo, t.wss_blank_hi > t.wss_blank_lo ? t.wss_blank_hi : t.wss_blank_lo);
+		}
+
+		if(t.conf.vitc)
+		{
+			const int frame = (int) (e->h_fdesc[i].frame_index + 1);
+			const int vl[4] = { t.vitc_lines[0], t.vitc_lines[0] + 2, t.vitc_lines[1], t.vitc_lines[1] + 2 };
+			for(int q = 0; q < 4; q++)
+			{
+				uint8_t data[12];
+				const int nb = hvk_vitc_bits(&t, frame, vl[q], data);
+				add(vl[q] - 1, 2, 21, nb, data, 0, 0);      /* src/vitc.c:193: the first 21 symbols stay empty */
+			}
+		}
+
+		if(t.k.teletext && e->h_tt_mask[i])
+		{
+			for(int r = 0; r < 32; r++)
+			{
+				if(!((e->h_tt_mask[i] >> r) & 1)) continue;
+				add(r < 16 ? 6 + r : 319 + r - 16, 0, 0, 360, (const uint8_t *) (e->h_tt_pk + ((size_t) i * 32 + r) * 12), 0, 0);
+			}
+		}
+	}
+}
+
 /* FM video: bring the host copy of the current batch up to `upto` samples -- fetch the
  * modulator's input from the device and run the serial tail over it (hvk_tail.c) */
 static int _fm_upto(hvk_engine *e, size_t upto)
@@ -718,13 +802,13 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	}
 
 	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
-	if(e->h_tt_pk)
+	if(e->h_ops)
 	{
-		HIPCHK(hipMemcpyAsync(e->d_tt_pk, e->h_tt_pk, (size_t) nframes * 32 * 12 * 4, hipMemcpyHostToDevice, e->stream));
-		HIPCHK(hipMemcpyAsync(e->d_tt_mask, e->h_tt_mask, (size_t) nframes * 4, hipMemcpyHostToDevice, e->stream));
-		/* packets are consumed by the batch they were queued for */
-		HIPCHK(hipStreamSynchronize(e->stream));
-		memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
+		_build_vbi_ops(e, nframes);
+		HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipMemcpyHostToDevice, e->stream));
+		HIPCHK(hipMemcpyAsync(e->d_map, e->h_map, (size_t) nframes * k.lines, hipMemcpyHostToDevice, e->stream));
+		/* teletext packets are consumed by the batch they were queued for */
+		if(e->h_tt_mask) memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
 	}
 	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
@@ -773,10 +857,12 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.ctaps = e->ctaps;
 	ra.notch = e->notch;
 	ra.chroma = e->d_chroma;
-	ra.tt_sym = e->d_tt_sym;
-	ra.tt_val = e->d_tt_val;
-	ra.tt_pk = e->d_tt_pk;
-	ra.tt_mask = e->d_tt_mask;
+	ra.vbi_sym = (const int *) e->d_vbi_sym;
+	ra.vbi_val = (const int16_t *) e->d_vbi_val;
+	ra.vbi_ops = e->d_ops;
+	ra.vbi_map = (const signed char *) e->d_map;
+	ra.vits_l = (const int16_t *) e->d_vits_l;
+	ra.vits_c = (const int16_t *) e->d_vits_c;
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
 	ra.yuv = e->d_yuv;

@@ -22,10 +22,11 @@ typedef struct {
 	hvk_packed_taps_t ctaps;
 	hvk_packed_taps_t notch;    /* SECAM luma notch */
 	const int16_t *chroma;      /* SECAM: [nframes][frame_samples] */
-	const int *tt_sym;          /* teletext symbol index */
-	const int16_t *tt_val;
-	const unsigned *tt_pk;      /* [nframes][32][12] */
-	const unsigned *tt_mask;    /* [nframes] */
+	const int *vbi_sym;         /* VBI data lines: symbol index of every table */
+	const int16_t *vbi_val;
+	const unsigned *vbi_ops;    /* [nframes][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
+	const signed char *vbi_map; /* [nframes][lines] */
+	const int16_t *vits_l, *vits_c;
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const void *yuv;            /* 2^24 x int16x4 */

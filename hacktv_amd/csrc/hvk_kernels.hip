@@ -145,10 +145,12 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
                   const hvk_packed_taps_t notch,        /* SECAM luma notch, 51 taps */
                   const int16_t *__restrict__ chroma,   /* SECAM: [frames][frame_samples] values to add */
-                  const int *__restrict__ tt_sym,       /* teletext: [360] { offset, length, start } */
-                  const int16_t *__restrict__ tt_val,   /* teletext: symbol values */
-                  const unsigned *__restrict__ tt_pk,   /* teletext: [frames][32][12] packet bits, LSB first */
-                  const unsigned *__restrict__ tt_mask, /* teletext: [frames] rows present */
+                  const int *__restrict__ vbi_sym,      /* VBI data lines: every table's symbols, { first sample, length, start } */
+                  const int16_t *__restrict__ vbi_val,  /*   symbol values */
+                  const unsigned *__restrict__ vbi_ops, /*   [frames][HVK_VBI_OPS][16]: symbol base, bits, blank range, -, 12 data words (LSB first) */
+                  const signed char *__restrict__ vbi_map, /* [frames][lines]: op of the line or -1 */
+                  const int16_t *__restrict__ vits_l,   /* VITS: [n][width] luma added */
+                  const int16_t *__restrict__ vits_c,   /*       [n][width] chroma amplitude */
                   const hvk_linedesc_t *__restrict__ desc,
                   const int16_t *__restrict__ pulses,
                   const short4v *__restrict__ yuv,
@@ -197,13 +199,12 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const hvk_linedesc_t d = desc[par * k.lines + line0];
 	const int pal = k.colour ? d.pal : 0;
 
-	/* teletext rides on lines 7..22 and 320..335 (src/teletext.c:1222-1224) */
-	int tt_row = -1;
-	if(k.teletext && own)
+	/* a VBI data line (teletext packet, WSS, VITC: the host lists them per frame), an insertion test signal */
+	int vbi_op = -1, vits_i = -1;
+	if(k.vbi && own) vbi_op = __builtin_amdgcn_readfirstlane((int) vbi_map[(size_t) blockIdx.y * k.lines + line0]);
+	if(k.vits && own)
 	{
-		if(line0 >= 6 && line0 <= 21) tt_row = line0 - 6;
-		else if(line0 >= 319 && line0 <= 334) tt_row = 16 + line0 - 319;
-		if(tt_row >= 0 && !((tt_mask[blockIdx.y] >> tt_row) & 1)) tt_row = -1;
+		for(int i = 0; i < 4; i++) if(i < k.vits && line0 == k.vits_line[i]) vits_i = i;
 	}
 
 	const int YL = (W + 8 + 7) & ~7;
@@ -233,7 +234,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int c[SPL];
 #pragma unroll
 	for(int i = 0; i < SPL; i++) c[i] = 0;
-	if(pal && x0 < W && !(k.ablate & 4))
+	if((pal || (vits_i >= 0 && k.colour)) && x0 < W && !(k.ablate & 4))
 	{
 		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
 		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
@@ -297,7 +298,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(pal || has_pix) __syncthreads();
 
-	if(x0 >= W && !(SECAM && active) && tt_row < 0) return;
+	if(x0 >= W && !(SECAM && active) && vbi_op < 0) return;
 
 	/* ---- 8 consecutive samples per lane ---- */
 	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
@@ -475,33 +476,64 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(tt_row >= 0)
+	if(vits_i >= 0 && x0 < W)
 	{
-		/* One packet = 360 shaped symbols, each a run of up to ~100 samples, added
-		 * for every set bit, least significant bit of each byte first
-		 * (src/vbidata.c:186-239). Set bits are walked by the whole workgroup (the
-		 * packet words are wave-uniform); lane t adds the t-th value of the symbol
-		 * into an int32 line accumulator in LDS. */
+		/* insertion test signal (src/vits.c:270-311): the line's luma waveform is added; its
+		 * chroma amplitude rides on the line's sub-carrier, rotated to the insertion phase */
+		const int16_t *vl = vits_l + (size_t) vits_i * W + x0, *vc = vits_c + (size_t) vits_i * W + x0;
+#pragma unroll
+		for(int i = 0; i < SPL; i++)
+		{
+			if(x0 + i < W)
+			{
+				s[i] = wrap16(s[i] + vl[i]);
+				if(k.colour)
+				{
+					/* on a V-switched line the chroma stage has negated the table's i half in place */
+					const int li = (pal < 0 ? -1 : 1) * (int) (short) (c[i] & 0xFFFF), lq = c[i] >> 16;
+					s[i] = wrap16(s[i] + ((((k.vits_pi * lq + k.vits_pq * li) >> 15) * (int) vc[i]) >> 15));
+				}
+			}
+		}
+	}
+
+	if(vbi_op >= 0)
+	{
+		/* One data line = up to 384 shaped symbols, each a run of samples added for every set
+		 * bit (vbidata_render, src/vbidata.c:186-239). Set bits are walked by the whole
+		 * workgroup (the data words are wave-uniform); lane t adds the t-th value of the
+		 * symbol into an int32 line accumulator in LDS. */
 		int *acc = (int *) lds;
-		const unsigned *pk = tt_pk + ((size_t) blockIdx.y * 32 + tt_row) * 12;
+		const unsigned *op = vbi_ops + ((size_t) blockIdx.y * HVK_VBI_OPS + vbi_op) * HVK_VBI_OPWORDS;
+		const int sym_base = __builtin_amdgcn_readfirstlane((int) op[0]);
+		const int nbits = __builtin_amdgcn_readfirstlane((int) op[1]);
+		const int blank = __builtin_amdgcn_readfirstlane((int) op[2]);
+		const int blank_lo = blank & 0xFFFF, blank_hi = blank >> 16;
+
+		/* WSS first sets part of the line to black (src/wss.c:176-182) */
+		if(blank_hi > blank_lo)
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) if(x0 + i >= blank_lo && x0 + i < blank_hi) s[i] = k.black;
+		}
 
 		__syncthreads();
 		for(int j = t; j < W; j += nth) acc[j] = 0;
 		__syncthreads();
 
-		for(int w = 0; w < 12; w++)
+		for(int w = 0; w * 32 < nbits && w < 12; w++)
 		{
-			unsigned word = __builtin_amdgcn_readfirstlane(pk[w]);
-			if(w == 11) word &= 0xFF;           /* 360 bits */
+			unsigned word = __builtin_amdgcn_readfirstlane(op[4 + w]);
+			if(nbits - w * 32 < 32) word &= (1u << (nbits - w * 32)) - 1;
 			while(word)
 			{
-				const int b = w * 32 + __builtin_ctz(word);
+				const int b = sym_base + w * 32 + __builtin_ctz(word);
 				word &= word - 1;
-				const int off = tt_sym[b * 3 + 0], len = tt_sym[b * 3 + 1];
-				const int16_t *v = tt_val + tt_sym[b * 3 + 2];
+				const int off = vbi_sym[b * 3 + 0], len = vbi_sym[b * 3 + 1];
+				const int16_t *v = vbi_val + vbi_sym[b * 3 + 2];
 				for(int j = t; j < len; j += nth)
 				{
-					if(off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
+					if(off + j >= 0 && off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
 				}
 			}
 		}
@@ -1033,7 +1065,7 @@ static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
 	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->notch, a->chroma, a->tt_sym, a->tt_val, a->tt_pk, a->tt_mask, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
+	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }

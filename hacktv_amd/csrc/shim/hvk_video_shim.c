@@ -41,6 +41,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include "video.h"          /* the reference's */
 #include "hacktv_amd.h"
 
@@ -81,8 +82,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->modulation == VID_FM && c->vfilter) return(_refuse("the FM video pre-emphasis filter (--filter with an FM mode)"));
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
-	if(c->wss || c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
-	   c->systercnr || c->acp || c->vits || c->vitc || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
+	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
+	   c->systercnr || c->acp || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
 	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
@@ -139,6 +140,20 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->am_mono_carrier = c->am_mono_carrier;
 	h->vfilter = c->vfilter;
 	h->teletext = c->teletext != NULL;
+	h->vits = c->vits;
+	h->vitc = c->vitc;
+	if(c->wss)
+	{
+		/* mode name -> the aspect ratio group of ETSI EN 300 294 with its odd parity bit, as src/wss.c:33-44 */
+		static const struct { const char *id; int code; } modes[] = {
+			{ "4:3", 0x08 }, { "14:9-letterbox", 0x01 }, { "14:9-top", 0x02 }, { "16:9-letterbox", 0x0B },
+			{ "16:9-top", 0x04 }, { "16:9+-letterbox", 0x0D }, { "14:9-window", 0x0E }, { "16:9", 0x07 }, { NULL, 0 },
+		};
+		int i;
+		for(i = 0; modes[i].id && strcasecmp(c->wss, modes[i].id) != 0; i++);
+		if(!modes[i].id) return(_refuse(strcasecmp(c->wss, "auto") == 0 ? "--wss auto (needs the source's pixel aspect per frame)" : "this WSS mode"));
+		h->wss = modes[i].code;
+	}
 	h->fm_level = c->fm_level;
 	h->fm_deviation = c->fm_deviation;
 	h->swap_iq = c->swap_iq;
@@ -297,6 +312,10 @@ static int _next_batch(vid_t *s, shim_t *m)
 			for(row = 0; row < 32; row++)
 			{
 				int line = row < 16 ? 7 + row : 320 + row - 16;
+				/* a line another inserter holds is left alone and the packet kept for the
+				 * next one (vbialloc, src/teletext.c:1219): VITS 17/18/330/331, VITC 19/21/332/334 */
+				if(s->conf.vits && (line == 17 || line == 18 || line == 330 || line == 331)) continue;
+				if(s->conf.vitc && (line == 19 || line == 21 || line == 332 || line == 334)) continue;
 				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
 			}
 			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);

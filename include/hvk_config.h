@@ -8,7 +8,7 @@
  * video.h-compatible shim does exactly that).
  *
  * Everything the reference's engine supports but this engine does not render
- * (scramblers, MAC, VITS/VITC/WSS/CC608/ACP/SiS inserters, DANCE, A2 stereo,
+ * (scramblers, MAC, CC608/ACP/SiS inserters, DANCE, A2 stereo,
  * FM energy dispersal, raw baseband input) has no field here; the shim
  * refuses such configurations rather than silently dropping them.
  */

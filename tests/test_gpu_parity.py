@@ -51,7 +51,8 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_tt", "l_tt",
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
                                   "pal_fm_pass",
-                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"])
+                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
+                                  "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -233,7 +234,7 @@ def test_dropin_binary_equals_reference_cli(golden):
 
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
-                 "i_px135", "pal_px135_s136"):
+                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4

@@ -41,20 +41,43 @@ def test_oracle_tables_equal_the_probe(golden):
             assert np.array_equal(r.table(name, dt), o.table(name, dt)), name
 
 
+_GHOST_CHECK = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import oracle, refprobe, util
+g = util.Golden()
+conf, sr = g.conf("i_raster")
+with refprobe.RefProbe("i", sr, refprobe.FLAG_NOAUDIO) as r:
+    ghost = r.table("chroma_ghost", np.int16)
+    ref = r.render_lines(40)
+    again = r.table("chroma_ghost", np.int16)
+with oracle.Oracle(conf, sr) as o:
+    o.set_ghost(ghost)
+    o.set_frame(g.frame("i_raster"))
+    mine = o.render_lines(40)
+print("STABLE" if np.array_equal(ghost, again) else "MOVED", "EQUAL" if np.array_equal(ref, mine) else "DIFFERENT")
+"""
+
+
 def test_ghost_samples_follow_the_heap(golden):
     """the reference's colour-line tails depend on what follows its
     chrominance buffer on the heap. In-process (a different heap from the CLI's) the
     probe sees other values; feeding THOSE to the oracle reproduces the in-process
-    reference, which shows the ghost input is the right abstraction."""
-    conf, sr = golden.conf("i_raster")
-    with refprobe.RefProbe("i", sr, refprobe.FLAG_NOAUDIO) as r:
-        ghost = r.table("chroma_ghost", np.int16)
-        ref = r.render_lines(40)
-    with oracle.Oracle(conf, sr) as o:
-        o.set_ghost(ghost)
-        o.set_frame(golden.frame("i_raster"))
-        mine = o.render_lines(40)
-    assert np.array_equal(ref, mine)
+    reference, which shows the ghost input is the right abstraction. Run in a fresh
+    interpreter: in a long-lived test process the bytes behind the buffer belong to
+    whoever allocated last and can change between the read-out and the render."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _GHOST_CHECK % (root, os.path.join(root, "tests"))],
+                         capture_output=True, text=True, timeout=300)
+    words = out.stdout.split()[-2:] if out.stdout.split() else []
+    assert out.returncode == 0 and len(words) == 2, out.stderr[-2000:]
+    if words[0] == "MOVED":
+        pytest.skip("the heap behind the reference's chroma buffer changed during the run")
+    assert words[1] == "EQUAL"
 
 
 @pytest.mark.parametrize("mode,sr,flags,pflags", [
