@@ -66,3 +66,53 @@ def test_unsupported_configurations_are_refused():
             assert err.code == -4
         else:
             raise AssertionError("an unsupported configuration was accepted")
+
+
+def test_bad_arguments_fail_with_codes_not_crashes():
+    """Every entry point checks its arguments (host-tables engine: no device needed)."""
+    L = H.lib()
+    c = H.preset("i", H.FLAG_FILTER)
+    with H.Engine(c, 16000000, device=-1) as e:
+        h = e.h
+        buf = (ctypes.c_int16 * 64)()
+        w = (ctypes.c_int32 * 4)()
+        assert L.hvk_get_info(h, None) == H.HVK_ERROR
+        assert L.hvk_frame_upload(h, 99, None, 0, 0, 0, 0, 0) == H.HVK_ERROR          # no such slot
+        assert L.hvk_teletext_packets(h, 0, buf, 1) == H.HVK_UNSUPPORTED              # not a teletext configuration
+        assert L.hvk_passthru_write(h, buf, 16) == H.HVK_UNSUPPORTED                  # no --passthru
+        assert L.hvk_host_offset_stream(h, 0, 16, buf) == H.HVK_UNSUPPORTED           # no --offset
+        assert L.hvk_host_fm_video(h, buf, 16) == H.HVK_UNSUPPORTED                   # not FM video
+        assert L.hvk_line_widths(h, -1, 4, w) == H.HVK_ERROR
+        assert L.hvk_line_widths(h, 0, 4, w) == H.HVK_OK and list(w) == [1024] * 4
+        assert L.hvk_render(h, 1, None, None) == H.HVK_NO_DEVICE
+        assert L.hvk_fetch(h, buf, 0, 16) == H.HVK_NO_DEVICE
+        assert L.hvk_fetch_as(h, buf, 0, 16, 99, 0) == H.HVK_ERROR                    # no such sample type
+        assert L.hvk_sync(h) == H.HVK_NO_DEVICE
+        assert L.hvk_set_chroma_ghost(h, buf, 1000) == H.HVK_ERROR
+        assert L.hvk_audio_write(h, None, 0) in (H.HVK_OK, H.HVK_ERROR)
+    assert L.hvk_get_info(None, None) == H.HVK_ERROR
+    assert L.hvk_render(None, 1, None, None) == H.HVK_ERROR
+    L.hvk_close(None)
+
+
+def test_rate_pairs_the_resampler_refuses():
+    """--pixelrate: only rate pairs that keep frames a whole number of samples (and small L / D)."""
+    c = H.preset("m", 0)
+    for sr, pr in ((16000000, 13500000),      # 450450 * 32 / 27 is not whole
+                   (16000001, 13500000)):     # L = 16000001
+        try:
+            H.Engine(c, sr, device=-1, pixel_rate=pr)
+        except H.HvkError as err:
+            assert err.code == H.HVK_UNSUPPORTED
+        else:
+            raise AssertionError("accepted %d / %d" % (sr, pr))
+    c = H.preset("i", 0)
+    c.passthru = 1
+    try:
+        H.Engine(c, 16000000, device=-1, pixel_rate=13500000)
+    except H.HvkError as err:
+        assert err.code == H.HVK_UNSUPPORTED
+    else:
+        raise AssertionError("--pixelrate with --passthru accepted")
+    with H.Engine(H.preset("i", 0), 16000000, device=-1, pixel_rate=16000000) as e:   # same rate: no resampler
+        assert e.info["max_width"] == 1024 and e.info["startup_samples"] == 0
