@@ -54,6 +54,7 @@ struct hvk_engine {
 	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	int8_t *d_map, *h_map;      /* [max_frames][lines] */
 	void *d_vits_l, *d_vits_c;
+	uint8_t *cc_pairs;          /* CC608: [max_frames][3] { present, c1, c2 } queued for the next batch */
 	hvk_packed_taps_t notch;
 	hvk_tail_t *tail;           /* FM video / offset / passthru serial state (hvk_tail.c) */
 	int16_t *d_off, *h_off;     /* offset phasor side stream, int16 pairs */
@@ -185,6 +186,12 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		if(!e->tail) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
+	if(e->t.conf.cc608)
+	{
+		e->cc_pairs = (uint8_t *) calloc((size_t) max_frames, 3);
+		if(!e->cc_pairs) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
+	}
+
 	if(e->t.k.has_nicam)
 	{
 		e->symbol_stride = e->t.k.frame_samples / (e->t.k.nicam_sps - 1) + 32;
@@ -291,8 +298,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	if(e->t.k.vbi)
 	{
-		OPENCHK(_upload(&e->d_vbi_sym, e->t.vbi_sym, sizeof(int32_t) * 3 * e->t.vbi_nsym));
-		OPENCHK(_upload(&e->d_vbi_val, e->t.vbi_val, sizeof(int16_t) * (e->t.vbi_total + 8)));
+		if(e->t.vbi_nsym)
+		{
+			OPENCHK(_upload(&e->d_vbi_sym, e->t.vbi_sym, sizeof(int32_t) * 3 * e->t.vbi_nsym));
+			OPENCHK(_upload(&e->d_vbi_val, e->t.vbi_val, sizeof(int16_t) * (e->t.vbi_total + 8)));
+		}
 		OPENHIP(hipMalloc((void **) &e->d_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipHostMallocDefault));
 		OPENHIP(hipMalloc((void **) &e->d_map, (size_t) max_frames * k.lines));
@@ -354,6 +364,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	}
 
 	free(e->sym_tmp);
+	free(e->cc_pairs);
 	if(e->host_frames) { for(int i = 0; i < e->frame_slots; i++) free(e->host_frames[i]); free(e->host_frames); }
 	hvk_secam_free(e->secam);
 	hvk_tail_free(e->tail);
@@ -520,6 +531,18 @@ extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const u
 	return(HVK_OK);
 }
 
+extern "C" int hvk_cc608_write(hvk_engine_t *e, int frame_in_batch, uint8_t c1, uint8_t c2)
+{
+	if(!e || frame_in_batch < 0 || frame_in_batch >= e->max_frames) return(HVK_ERROR);
+	if(!e->cc_pairs) return(HVK_UNSUPPORTED);
+	/* empty pairs are not sent (src/cc608.c:60-64) */
+	if(((c1 | c2) & 0x7F) == 0) return(HVK_OK);
+	e->cc_pairs[(size_t) frame_in_batch * 3 + 0] = 1;
+	e->cc_pairs[(size_t) frame_in_batch * 3 + 1] = c1;
+	e->cc_pairs[(size_t) frame_in_batch * 3 + 2] = c2;
+	return(HVK_OK);
+}
+
 extern "C" int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples)
 {
 	if(!e) return(HVK_ERROR);
@@ -570,9 +593,10 @@ extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int wi
 
 /* The VBI data lines of the staged frames (h_fdesc holds their stream frame numbers): per
  * frame a list of ops -- which symbol table, how many bits, the bits -- and a line -> op map.
- * One op per line: the first inserter to claim a line keeps it, in the reference's process
- * order WSS, VITC, teletext (src/video.c:4234-4358; teletext's own vbialloc test,
- * src/teletext.c:1219, is the caller's business: it decides which rows carry packets). */
+ * Ops of one line are chained in the reference's process order WSS, ACP, VITC, CC608, teletext
+ * (src/video.c:4234-4358). Of the inserters only ACP and teletext yield to a line that is
+ * already held (vbialloc, src/acp.c:108, src/teletext.c:1219): ACP's test is done here,
+ * teletext's is the caller's business -- it decides which rows carry packets. */
 static void _build_vbi_ops(hvk_engine *e, int nframes)
 {
 	const hvk_tables_t &t = e->t;
@@ -587,19 +611,31 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 		int8_t *map = e->h_map + (size_t) i * lines;
 		int n = 0;
 
+		/* hang op n on its line: the first op goes into the map, later ones behind the line's last op
+		 * (op word 0: symbol base | (next op + 1) << 16) */
+		auto link = [&](int line0)
+		{
+			if(map[line0] < 0) { map[line0] = (int8_t) n; return; }
+			uint32_t *last = ops + (size_t) map[line0] * HVK_VBI_OPWORDS;
+			while(last[0] >> 16) last = ops + (size_t) ((last[0] >> 16) - 1) * HVK_VBI_OPWORDS;
+			last[0] |= (uint32_t) (n + 1) << 16;
+		};
+
 		auto add = [&](int line0, int lut, int first_symbol, int nbits, const uint8_t *lsb_first_bits, int blank_lo, int blank_hi)
 		{
-			if(n >= HVK_VBI_OPS || line0 < 0 || line0 >= lines || map[line0] >= 0) return;
+			if(n >= HVK_VBI_OPS || line0 < 0 || line0 >= lines) return;
 			if(nbits > t.lut_nsym[lut] - first_symbol) nbits = t.lut_nsym[lut] - first_symbol;   /* the table's end stops the render */
 			if(nbits > 384) nbits = 384;
 			uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
 			uint8_t bytes[48] = { 0 };
+			if(nbits < 0) nbits = 0;
 			memcpy(bytes, lsb_first_bits, (nbits + 7) / 8);
 			op[0] = (uint32_t) (t.lut_base[lut] + first_symbol);
 			op[1] = (uint32_t) nbits;
 			op[2] = (uint32_t) blank_lo | ((uint32_t) blank_hi << 16);
 			memcpy(op + 4, bytes, 48);
-			map[line0] = (int8_t) n++;
+			link(line0);
+			n++;
 		};
 
 		if(t.conf.wss)
@@ -615,6 +651,38 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 			add(22, 1, 0, 137, rev, t.wss_blank_lo, t.wss_blank_hi > t.wss_blank_lo ? t.wss_blank_hi : t.wss_blank_lo);
 		}
 
+		if(t.conf.acp)
+		{
+			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where
+			 * VITS holds the line (src/acp.c:93-108); the AGC level moves with the frame number */
+			const int frame = (int) (e->h_fdesc[i].frame_index + 1);
+			const int agc = hvk_acp_agc_level(&t, frame);
+			const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
+			const int count = lines == 625 ? 10 : 8;
+			for(int fld = 0; fld < 2; fld++)
+			{
+				for(int l = first[fld]; l < first[fld] + count; l++)
+				{
+					bool vits = false;
+					for(int q = 0; q < t.k.vits; q++) if(t.k.vits_line[q] == l - 1) vits = true;
+					if(vits || n >= HVK_VBI_OPS) continue;
+					uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
+					op[0] = 0;
+					op[1] = 1u << 16;       /* mode 1: assign list */
+					op[2] = 0;
+					op[3] = ((uint32_t) t.acp_psync_level & 0xFFFF) | ((uint32_t) agc << 16);
+					for(int q = 0; q < 6; q++)
+					{
+						const uint32_t a = t.acp_left[q], b = a + t.acp_psync_width, c = b + t.acp_pagc_width;
+						op[4 + q * 2 + 0] = a | (b << 16);
+						op[4 + q * 2 + 1] = b | (c << 16);
+					}
+					link(l - 1);
+					n++;
+				}
+			}
+		}
+
 		if(t.conf.vitc)
 		{
 			const int frame = (int) (e->h_fdesc[i].frame_index + 1);
@@ -625,6 +693,18 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 				const int nb = hvk_vitc_bits(&t, frame, vl[q], data);
 				add(vl[q] - 1, 2, 21, nb, data, 0, 0);      /* src/vitc.c:193: the first 21 symbols stay empty */
 			}
+		}
+
+		if(t.conf.cc608)
+		{
+			/* the frame's byte pair (zeros without one), 17 bits, and the clock run-in: symbol 32 of
+			 * the table, whose bit is always set (src/cc608.c:188-221) */
+			uint8_t bits[8] = { 0 };
+			const uint8_t *pr = e->cc_pairs + (size_t) i * 3;
+			hvk_cc608_bits(pr[0] ? pr[1] : 0, pr[0] ? pr[2] : 0, bits);
+			bits[2] &= 1;
+			bits[4] |= 1;           /* bit 32 */
+			add(t.cc608_line - 1, 3, 0, 33, bits, 0, 0);
 		}
 
 		if(t.k.teletext && e->h_tt_mask[i])
@@ -807,8 +887,9 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		_build_vbi_ops(e, nframes);
 		HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipMemcpyHostToDevice, e->stream));
 		HIPCHK(hipMemcpyAsync(e->d_map, e->h_map, (size_t) nframes * k.lines, hipMemcpyHostToDevice, e->stream));
-		/* teletext packets are consumed by the batch they were queued for */
+		/* teletext packets and caption pairs are consumed by the batch they were queued for */
 		if(e->h_tt_mask) memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
+		if(e->cc_pairs) memset(e->cc_pairs, 0, (size_t) e->max_frames * 3);
 	}
 	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));

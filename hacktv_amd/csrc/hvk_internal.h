@@ -19,9 +19,9 @@ extern "C" {
 #define HVK_MAX_VF_TAPS  64
 #define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
 #define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
-#define HVK_VBI_OPS      48     /* VBI data lines per frame (32 teletext + WSS + 4 VITC + spare) */
+#define HVK_VBI_OPS      64     /* VBI lines per frame (32 teletext + WSS + 4 VITC + CC608 + 20 ACP + spare) */
 #define HVK_VBI_OPWORDS  16     /* dwords per op: sym_base, nbits, blank range, spare, 12 data words */
-#define HVK_VBI_LUTS     3      /* 0 teletext, 1 WSS, 2 VITC */
+#define HVK_VBI_LUTS     4      /* 0 teletext, 1 WSS, 2 VITC, 3 CC608 (32 bit cells + the clock run-in as a 33rd symbol) */
 
 typedef struct { int16_t i, q; } hvk_c16_t;
 typedef struct { int32_t i, q; } hvk_c32_t;
@@ -145,6 +145,9 @@ typedef struct {
 	uint8_t wss_bits[18];       /* line 23's 137 bits, MSB first (src/wss.c:118-136) */
 	int32_t wss_blank_lo, wss_blank_hi;
 	int32_t vitc_lines[2], vitc_fps, vitc_drop;
+	int32_t cc608_line;         /* 1-based */
+	int32_t acp_left[6], acp_psync_width, acp_pagc_width, acp_psync_level;
+	int32_t grey_y[256];        /* luma level of RGB (i, i, i): what ACP's AGC pulse follows */
 	int16_t *vits_l, *vits_c;   /* [vits][width]: luma added, chroma amplitude */
 	/* SECAM (src/video.c:4075-4162) */
 	int32_t secam_level;
@@ -168,6 +171,11 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
 /* The 90 bits of a VITC line (src/vitc.c:120-196) as 12 bytes, least significant bit first;
  * frame counts from 1, line is the 1-based line number. Returns the number of bits. */
 int hvk_vitc_bits(const hvk_tables_t *t, int frame, int line, uint8_t data[12]);
+
+/* ACP: the AGC pulse level of a frame (counted from 1), src/acp.c:78-90 */
+int hvk_acp_agc_level(const hvk_tables_t *t, int frame);
+/* CC608: the 17 bits of a caption byte pair, LSB first (src/cc608.c:170-186) */
+void hvk_cc608_bits(uint8_t c1, uint8_t c2, uint8_t data[3]);
 
 /* Host SECAM colour pre-pass (hvk_secam.c) */
 typedef struct hvk_secam hvk_secam_t;

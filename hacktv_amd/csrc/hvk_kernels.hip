@@ -497,16 +497,20 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(vbi_op >= 0)
+	/* the line's ops, in the reference's process order (an anti-copy line can also carry VITC) */
+	for(int opi = vbi_op; opi >= 0;)
 	{
 		/* One data line = up to 384 shaped symbols, each a run of samples added for every set
 		 * bit (vbidata_render, src/vbidata.c:186-239). Set bits are walked by the whole
 		 * workgroup (the data words are wave-uniform); lane t adds the t-th value of the
 		 * symbol into an int32 line accumulator in LDS. */
 		int *acc = (int *) lds;
-		const unsigned *op = vbi_ops + ((size_t) blockIdx.y * HVK_VBI_OPS + vbi_op) * HVK_VBI_OPWORDS;
-		const int sym_base = __builtin_amdgcn_readfirstlane((int) op[0]);
-		const int nbits = __builtin_amdgcn_readfirstlane((int) op[1]);
+		const unsigned *op = vbi_ops + ((size_t) blockIdx.y * HVK_VBI_OPS + opi) * HVK_VBI_OPWORDS;
+		const int base_next = __builtin_amdgcn_readfirstlane((int) op[0]);
+		const int sym_base = base_next & 0xFFFF;
+		opi = (base_next >> 16) - 1;            /* next op of this line, -1: none */
+		const int bits_mode = __builtin_amdgcn_readfirstlane((int) op[1]);
+		const int nbits = bits_mode & 0xFFFF, mode = bits_mode >> 16;
 		const int blank = __builtin_amdgcn_readfirstlane((int) op[2]);
 		const int blank_lo = blank & 0xFFFF, blank_hi = blank >> 16;
 
@@ -517,32 +521,48 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int i = 0; i < SPL; i++) if(x0 + i >= blank_lo && x0 + i < blank_hi) s[i] = k.black;
 		}
 
-		__syncthreads();
-		for(int j = t; j < W; j += nth) acc[j] = 0;
-		__syncthreads();
-
-		for(int w = 0; w * 32 < nbits && w < 12; w++)
+		if(mode == 1)
 		{
-			unsigned word = __builtin_amdgcn_readfirstlane(op[4 + w]);
-			if(nbits - w * 32 < 32) word &= (1u << (nbits - w * 32)) - 1;
-			while(word)
+			/* anti-copy pulse pairs (src/acp.c:113-126): twelve runs of samples SET to one of two levels */
+			const int lv = __builtin_amdgcn_readfirstlane((int) op[3]);
+			const int la = (int) (short) (lv & 0xFFFF), lb = lv >> 16;
+			for(int q = 0; q < 12; q++)
 			{
-				const int b = sym_base + w * 32 + __builtin_ctz(word);
-				word &= word - 1;
-				const int off = vbi_sym[b * 3 + 0], len = vbi_sym[b * 3 + 1];
-				const int16_t *v = vbi_val + vbi_sym[b * 3 + 2];
-				for(int j = t; j < len; j += nth)
-				{
-					if(off + j >= 0 && off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
-				}
+				const int seg = __builtin_amdgcn_readfirstlane((int) op[4 + q]);
+				const int lo = seg & 0xFFFF, hi = (unsigned) seg >> 16;
+#pragma unroll
+				for(int i = 0; i < SPL; i++) if(x0 + i >= lo && x0 + i < hi) s[i] = (q & 1) ? lb : la;
 			}
 		}
-		__syncthreads();
-
-		if(x0 < W)
+		else if(nbits > 0)
 		{
+			__syncthreads();
+			for(int j = t; j < W; j += nth) acc[j] = 0;
+			__syncthreads();
+
+			for(int w = 0; w * 32 < nbits && w < 12; w++)
+			{
+				unsigned word = __builtin_amdgcn_readfirstlane(op[4 + w]);
+				if(nbits - w * 32 < 32) word &= (1u << (nbits - w * 32)) - 1;
+				while(word)
+				{
+					const int b = sym_base + w * 32 + __builtin_ctz(word);
+					word &= word - 1;
+					const int off = vbi_sym[b * 3 + 0], len = vbi_sym[b * 3 + 1];
+					const int16_t *v = vbi_val + vbi_sym[b * 3 + 2];
+					for(int j = t; j < len; j += nth)
+					{
+						if(off + j >= 0 && off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
+					}
+				}
+			}
+			__syncthreads();
+
+			if(x0 < W)
+			{
 #pragma unroll
-			for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
+				for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
+			}
 		}
 	}
 

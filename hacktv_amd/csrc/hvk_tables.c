@@ -783,6 +783,103 @@ int hvk_vitc_bits(const hvk_tables_t *t, int frame, int line, uint8_t data[12])
 	return(x);
 }
 
+/* CEA/EIA-608 captions (src/cc608.c:97-160): 32 bit cells of width / 32 starting 27.5 us
+ * (27.382 us on 525 lines) after 0H at half of white - black, and in front of them seven
+ * cycles of clock run-in -- a fixed waveform, kept here as a 33rd symbol whose bit is always set */
+static int _build_cc608(hvk_tables_t *t)
+{
+	const hvk_config_t *c = &t->conf;
+	const int W = t->k.width;
+	const double offset = c->type == HVK_RASTER_525 ? 27.382e-6 : 27.5e-6;
+	const double level = round((t->white_level - t->black_level) * 0.5);
+	const double w = (double) W * 7 / 32;
+	const double x = (double) t->pixel_rate * offset - (W * 8.75 / 32);
+	const int cri_x = x, cri_len = ceil(w);
+	int32_t *sym;
+	int16_t *val;
+	int i, r;
+
+	t->cc608_line = c->type == HVK_RASTER_525 ? 21 : 22;
+
+	r = _append_step_lut(t, 3, 32, (int) level, (double) W / 32, t->pixel_rate * 240e-9 * EDGE_0_100, t->pixel_rate * offset);
+	if(r != HVK_OK) return(r);
+
+	sym = realloc(t->vbi_sym, (size_t) (t->vbi_nsym + 1) * 3 * sizeof(int32_t));
+	if(!sym) return(HVK_OUT_OF_MEMORY);
+	t->vbi_sym = sym;
+	val = realloc(t->vbi_val, (size_t) (t->vbi_total + cri_len + 8) * sizeof(int16_t));
+	if(!val) return(HVK_OUT_OF_MEMORY);
+	t->vbi_val = val;
+
+	sym[t->vbi_nsym * 3 + 0] = cri_x;
+	sym[t->vbi_nsym * 3 + 1] = cri_len;
+	sym[t->vbi_nsym * 3 + 2] = t->vbi_total;
+	for(i = 0; i < cri_len; i++)
+	{
+		/* truncated, not rounded (src/cc608.c:150) */
+		val[t->vbi_total + i] = (0.5 - cos(((double) i - (x - cri_x)) * (2 * M_PI / w * 7)) * 0.5) * level;
+	}
+	t->vbi_total += cri_len;
+	memset(val + t->vbi_total, 0, 8 * sizeof(int16_t));
+	t->vbi_nsym += 1;
+	t->lut_nsym[3] = 33;
+	return(HVK_OK);
+}
+
+void hvk_cc608_bits(uint8_t c1, uint8_t c2, uint8_t data[3])
+{
+	int i;
+
+	/* odd parity in bit 7 */
+	c1 = (c1 & 0x7F) | 0x80;
+	c2 = (c2 & 0x7F) | 0x80;
+	for(i = 1; i < 8; i++)
+	{
+		c1 ^= (c1 << i) & 0x80;
+		c2 ^= (c2 << i) & 0x80;
+	}
+
+	/* a start bit, then the two characters */
+	data[0] = (c1 << 1) | 0x01;
+	data[1] = (c2 << 1) | (c1 >> 7);
+	data[2] = (c2 >> 7);
+}
+
+/* Anti-copy pulses (src/acp.c:26-64): six P-sync / AGC pulse pairs per line; levels are assigned */
+static void _build_acp(hvk_tables_t *t)
+{
+	const int is625 = t->conf.lines == 625;
+	const double left = is625 ? 8.88e-6 : 8.288e-6;
+	const double spacing = is625 ? 5.92e-6 : 8.288e-6;
+	const double psync_width = is625 ? 2.368e-6 : 2.222e-6;
+	const hvk_yuvparams_t *p = &t->yuv;
+	int i;
+
+	t->acp_psync_level = (int16_t) (t->sync_level + round((t->white_level - t->sync_level) * 0.06));
+	t->acp_psync_width = round(t->pixel_rate * psync_width);
+	t->acp_pagc_width = round(t->pixel_rate * 2.7e-6);
+	for(i = 0; i < 6; i++) t->acp_left[i] = round(t->pixel_rate * (left + spacing * i));
+
+	/* luma of the greys, as the level table has it (src/video.c:3917-3958) */
+	for(i = 0; i < 256; i++)
+	{
+		double g = p->glut[i];
+		double y = g * p->rw + g * p->gw + g * p->bw;
+		y = (p->black + (y * p->range)) * p->level;
+		y = y < -1 ? -1 : (y > 1 ? 1 : y);
+		t->grey_y[i] = (int16_t) round(y * INT16_MAX);
+	}
+}
+
+int hvk_acp_agc_level(const hvk_tables_t *t, int frame)
+{
+	/* a clipped sawtooth over 428 frames (src/acp.c:80-89) */
+	int i = abs(frame * 4 % 1712 - 856) - 150;
+	if(i < 0) i = 0;
+	else if(i > 255) i = 255;
+	return((int16_t) (t->sync_level + round((t->grey_y[i] - t->sync_level) * 1.10)));
+}
+
 /* Insertion test signals (src/vits.c:53-296): per line a luma waveform that is added and a
  * chroma amplitude that rides on the line's sub-carrier */
 static double _sin2_pulse(double t, double position, double width, double amplitude)
@@ -1276,8 +1373,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	if(c->wss && (r = _build_wss(t)) != HVK_OK) return(r);
 	if(c->vitc && (r = _build_vitc(t)) != HVK_OK) return(r);
+	if(c->cc608 && (r = _build_cc608(t)) != HVK_OK) return(r);
 	if(c->vits && (r = _build_vits(t)) != HVK_OK) return(r);
-	t->k.vbi = t->vbi_nsym > 0;
+	if(c->acp) _build_acp(t);
+	t->k.vbi = t->vbi_nsym > 0 || c->acp;
 
 	return(_build_linedesc(t));
 }

@@ -83,7 +83,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
-	   c->systercnr || c->acp || c->cc608 || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
+	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
 	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
@@ -142,6 +142,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->teletext = c->teletext != NULL;
 	h->vits = c->vits;
 	h->vitc = c->vitc;
+	h->acp = c->acp;
+	h->cc608 = c->cc608;
 	if(c->wss)
 	{
 		/* mode name -> the aspect ratio group of ETSI EN 300 294 with its odd parity bit, as src/wss.c:33-44 */
@@ -301,6 +303,7 @@ static int _next_batch(vid_t *s, shim_t *m)
 
 		if(hvk_frame_upload(m->e, n, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
 		slots[n] = n;
+		if(s->conf.cc608 && hvk_cc608_write(m->e, n, f.cc608[0], f.cc608[1]) != HVK_OK) return(-1);
 
 		if(s->conf.teletext)
 		{
@@ -316,6 +319,8 @@ static int _next_batch(vid_t *s, shim_t *m)
 				 * next one (vbialloc, src/teletext.c:1219): VITS 17/18/330/331, VITC 19/21/332/334 */
 				if(s->conf.vits && (line == 17 || line == 18 || line == 330 || line == 331)) continue;
 				if(s->conf.vitc && (line == 19 || line == 21 || line == 332 || line == 334)) continue;
+				if(s->conf.acp && ((line >= 9 && line <= 18) || (line >= 321 && line <= 330))) continue;
+				if(s->conf.cc608 && line == 22) continue;
 				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
 			}
 			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);

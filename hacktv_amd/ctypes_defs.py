@@ -65,6 +65,8 @@ class HvkConfig(C.Structure):
         ("wss", C.c_int),
         ("vits", C.c_int),
         ("vitc", C.c_int),
+        ("acp", C.c_int),
+        ("cc608", C.c_int),
         ("fm_level", C.c_double),
         ("fm_deviation", C.c_double),
         ("swap_iq", C.c_int),

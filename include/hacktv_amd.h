@@ -150,6 +150,12 @@ int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, i
  * without a call carry no teletext. */
 int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask);
 
+/* --cc608 (conf.cc608 != 0): the caption byte pair av_read_video() delivered with frame
+ * `frame_in_batch` of the NEXT render (av_frame_t.cc608, src/av.h:52; queued by
+ * src/video.c:4901-4904, sent on line 22 / 21 by src/cc608.c:188-221). Frames without a call,
+ * or with an empty pair, send the parity-only null code. */
+int hvk_cc608_write(hvk_engine_t *e, int frame_in_batch, uint8_t c1, uint8_t c2);
+
 /* av_read_audio() result: nsamples interleaved stereo pairs at 32 kHz. */
 int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples);
 

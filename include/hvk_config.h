@@ -8,7 +8,7 @@
  * video.h-compatible shim does exactly that).
  *
  * Everything the reference's engine supports but this engine does not render
- * (scramblers, MAC, CC608/ACP/SiS inserters, DANCE, A2 stereo,
+ * (scramblers, MAC, sound-in-syncs, DANCE, A2 stereo,
  * FM energy dispersal, raw baseband input) has no field here; the shim
  * refuses such configurations rather than silently dropping them.
  */
@@ -131,6 +131,9 @@ typedef struct hvk_config_t {
 	                             * 0x07 16:9 ("auto" depends on the source's pixel aspect: not supported) */
 	int vits;                   /* --vits: insertion test signals, lines 17/18/330/331 (625) or 17/280 (525) */
 	int vitc;                   /* --vitc: vertical interval time code, lines 19/21/332/334 (625) or 14/16/277/279 (525) */
+	int acp;                    /* --acp: P-sync / AGC pulse pairs on lines 9-18, 321-330 (625) or 12-19, 275-282 (525) */
+	int cc608;                  /* --cc608: CEA/EIA-608 caption line 22 (625) / 21 (525); the byte pairs are supplied
+	                             * per frame with hvk_cc608_write(), zeros otherwise */
 
 	/* FM video (modulation == HVK_FM), src/video.h:141-142 */
 	double fm_level;

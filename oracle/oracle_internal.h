@@ -169,6 +169,12 @@ struct orc_t {
 	uint8_t wss_vbi[18];
 	int wss_blank_width;
 	int vitc_lines[2], vitc_hr, vitc_fps, vitc_drop;
+	int acp_left[6], acp_psync_width, acp_pagc_width;
+	int16_t acp_psync_level, acp_pagc_level;
+	orc_pulse_t *cc_lut;
+	int16_t *cc_cri;
+	int cc_cri_x, cc_cri_len, cc_line;
+	long cc_frame; uint8_t cc_pair[2];
 
 	/* stage taps of the last render call */
 	int16_t *last_raster; long last_raster_len;
@@ -201,6 +207,7 @@ int orc_vbi_init(orc_t *s);
 void orc_vbi_free(orc_t *s);
 void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut);
 int orc_vbi_allocated(orc_t *s, int line);
+int orc_vbi_allocated_by_vits(orc_t *s, int line);
 
 /* oracle_tail.c */
 int orc_tail_init(orc_t *s);

@@ -261,12 +261,57 @@ int orc_vbi_init(orc_t *s)
 		s->vitc_lut = _step_table(s->vitc_hr, level, (double) s->width / s->vitc_hr, s->pixel_rate * 200e-9, 0);
 	}
 
+	if(c->acp)
+	{
+		/* src/acp.c:26-64 */
+		double left = c->lines == 625 ? 8.88e-6 : 8.288e-6;
+		double spacing = c->lines == 625 ? 5.92e-6 : 8.288e-6;
+		double psync_width = c->lines == 625 ? 2.368e-6 : 2.222e-6;
+		int i;
+		s->acp_psync_level = s->sync_level + round((s->white_level - s->sync_level) * 0.06);
+		s->acp_pagc_level  = s->sync_level + round((s->white_level - s->sync_level) * 1.10);
+		s->acp_psync_width = round(s->pixel_rate * psync_width);
+		s->acp_pagc_width  = round(s->pixel_rate * 2.7e-6);
+		for(i = 0; i < 6; i++) s->acp_left[i] = round(s->pixel_rate * (left + spacing * i));
+	}
+
+	if(c->cc608)
+	{
+		/* src/cc608.c:97-160 */
+		double offset, x, w, level;
+		int i;
+
+		if(c->type == HVK_RASTER_525) { s->cc_line = 21; offset = 27.382e-6; }
+		else { s->cc_line = 22; offset = 27.5e-6; }
+
+		s->cc_lut = _step_table(32, level = round((s->white_level - s->black_level) * 0.5), (double) s->width / 32,
+		                        s->pixel_rate * 240e-9 * 2.0738786, s->pixel_rate * offset);
+		w = (double) s->width * 7 / 32;
+		x = (double) s->pixel_rate * offset - (s->width * 8.75 / 32);
+		s->cc_cri_x = x;
+		s->cc_cri_len = ceil(w);
+		s->cc_cri = malloc(sizeof(int16_t) * s->cc_cri_len);
+		for(i = 0; i < s->cc_cri_len; i++)
+		{
+			s->cc_cri[i] = (0.5 - cos(((double) i - (x - s->cc_cri_x)) * (2 * M_PI / w * 7)) * 0.5) * level;
+		}
+	}
+
 	return(0);
+}
+
+void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2)
+{
+	s->cc_frame = frame_index + 1;
+	s->cc_pair[0] = c1;
+	s->cc_pair[1] = c2;
 }
 
 void orc_vbi_free(orc_t *s)
 {
 	int i;
+	_free_table(s->cc_lut, 32);
+	free(s->cc_cri);
 	for(i = 0; i < 4; i++) free(s->vits_line[i]);
 	_free_table(s->wss_lut, 137);
 	_free_table(s->vitc_lut, s->vitc_hr);
@@ -322,6 +367,35 @@ void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut)
 		_render(s, g, s->wss_lut, 137, s->wss_vbi, 0, 137, 1);
 	}
 
+	if(c->acp)
+	{
+		/* src/acp.c:73-128 */
+		int on = 0;
+
+		if(line == 1)
+		{
+			/* the AGC pulse level follows a clipped sawtooth */
+			i = abs(frame * 4 % 1712 - 856) - 150;
+			if(i < 0) i = 0;
+			else if(i > 255) i = 255;
+			i = s->yuv[(long) (i << 16 | i << 8 | i) * 3 + 0];
+			s->acp_pagc_level = s->sync_level + round((i - s->sync_level) * 1.10);
+		}
+
+		if(c->lines == 625) on = (line >= 9 && line <= 18) || (line >= 321 && line <= 330);
+		else on = (line >= 12 && line <= 19) || (line >= 275 && line <= 282);
+
+		/* lines another inserter holds are left alone: only VITS comes earlier */
+		if(on && !(c->vits && orc_vbi_allocated_by_vits(s, line)))
+		{
+			for(i = 0; i < 6; i++)
+			{
+				for(x = s->acp_left[i]; x < s->acp_left[i] + s->acp_psync_width; x++) o[x] = s->acp_psync_level;
+				for(; x < s->acp_left[i] + s->acp_psync_width + s->acp_pagc_width; x++) o[x] = s->acp_pagc_level;
+			}
+		}
+	}
+
 	if(c->vitc && (line == s->vitc_lines[0] || line == s->vitc_lines[0] + 2 || line == s->vitc_lines[1] || line == s->vitc_lines[1] + 2))
 	{
 		uint32_t timecode;
@@ -364,6 +438,33 @@ void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut)
 
 		_render(s, g, s->vitc_lut, s->vitc_hr, data, 21, n, 0);
 	}
+
+	if(c->cc608 && line == s->cc_line)
+	{
+		/* src/cc608.c:188-221: the frame's byte pair, zeros when there is none */
+		uint8_t c1 = 0, c2 = 0, data[3];
+
+		if(s->cc_frame == frame) { c1 = s->cc_pair[0]; c2 = s->cc_pair[1]; }
+		c1 = (c1 & 0x7F) | 0x80;
+		c2 = (c2 & 0x7F) | 0x80;
+		for(i = 1; i < 8; i++)
+		{
+			c1 ^= (c1 << i) & 0x80;
+			c2 ^= (c2 << i) & 0x80;
+		}
+		data[0] = (c1 << 1) | 0x01;
+		data[1] = (c2 << 1) | (c1 >> 7);
+		data[2] = (c2 >> 7);
+
+		for(i = 0; i < s->cc_cri_len; i++) o[s->cc_cri_x + i] += s->cc_cri[i];
+		_render(s, g, s->cc_lut, 32, data, 0, 17, 0);
+	}
+}
+
+int orc_vbi_allocated_by_vits(orc_t *s, int line)
+{
+	if(s->conf.lines == 625) return(line == 17 || line == 18 || line == 330 || line == 331);
+	return(line == 17 || line == 280);
 }
 
 /* does one of the inserters above occupy this line? (teletext leaves such lines alone,
@@ -377,6 +478,9 @@ int orc_vbi_allocated(orc_t *s, int line)
 		if(c->lines == 525 && (line == 17 || line == 280)) return(1);
 	}
 	if(c->wss && line == 23) return(1);
+	if(c->acp && c->lines == 625 && ((line >= 9 && line <= 18) || (line >= 321 && line <= 330))) return(1);
+	if(c->acp && c->lines == 525 && ((line >= 12 && line <= 19) || (line >= 275 && line <= 282))) return(1);
+	if(c->cc608 && line == s->cc_line) return(1);
 	if(c->vitc && (line == s->vitc_lines[0] || line == s->vitc_lines[0] + 2 || line == s->vitc_lines[1] || line == s->vitc_lines[1] + 2)) return(1);
 	return(0);
 }

@@ -270,7 +270,7 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 
 		/* VITS, WSS, VITC: line processes between the colour process and teletext
 		 * (src/video.c:4214-4316) */
-		if((s->conf.vits || s->conf.wss || s->conf.vitc) && s->rastered >= 2)
+		if((s->conf.vits || s->conf.wss || s->conf.vitc || s->conf.acp || s->conf.cc608) && s->rastered >= 2)
 		{
 			long g = s->rastered - 2;
 			const c16_t *lut = NULL;

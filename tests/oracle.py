@@ -28,6 +28,8 @@ def lib():
         L.orc_open_rates.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
         L.orc_last_widths.restype = C.c_long
         L.orc_last_widths.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_set_cc608.restype = None
+        L.orc_set_cc608.argtypes = [C.c_void_p, C.c_long, C.c_uint8, C.c_uint8]
         L.orc_set_passthru.restype = None
         L.orc_set_passthru.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_render_lines.restype = C.c_long
@@ -105,6 +107,9 @@ class Oracle:
         a = np.ascontiguousarray(stereo, np.int16)
         self._keep.append(a)
         lib().orc_set_audio(self.p, a.ctypes.data, a.shape[0], 1 if loop else 0)
+
+    def set_cc608(self, frame_index, c1, c2):
+        lib().orc_set_cc608(self.p, frame_index, c1, c2)
 
     def set_passthru(self, iq):
         a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)

@@ -52,7 +52,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
                                   "pal_fm_pass",
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
-                                  "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px"])
+                                  "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -234,7 +234,7 @@ def test_dropin_binary_equals_reference_cli(golden):
 
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
-                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi"):
+                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4
@@ -292,3 +292,35 @@ def test_sink_formats_on_device(golden, case):
             part = e.fetch_as(640001, 12345, tname, cplx)
             want = oracle.sink_convert(iq[640001:640001 + 12345], tname, cplx)
             assert np.array_equal(part.view(np.uint8), want.view(np.uint8)), tname
+
+
+def test_caption_pairs_and_moving_acp_level(golden):
+    """CC608 with real byte pairs (the test source has none, so the reference digests only cover the
+    null code) and ACP over enough frames for the AGC level to move (it is flat for the first 38),
+    against the oracle."""
+    conf, sr = golden.conf("m_acp_cc")
+    pairs = {0: (0x14, 0x2C), 1: (0x48, 0x69), 3: (0x80, 0x00), 4: (0x21, 0x7F)}   # frame 3: an empty pair
+    first, n = 36, 5
+    L, W = golden.cases["m_acp_cc"]["lines"], golden.cases["m_acp_cc"]["width"]
+    with oracle.Oracle(conf, sr) as o:
+        o.set_frame(golden.frame("m_acp_cc"))
+        o.set_audio(golden.audio, True)
+        want = []
+        for f in range(first + n):
+            if f - first in pairs and (pairs[f - first][0] | pairs[f - first][1]) & 0x7F:
+                o.set_cc608(f, *pairs[f - first])
+            out = o.render_lines(L)
+            if f >= first:
+                want.append(out)
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=first) as e:
+        e.frame_upload(0, golden.frame("m_acp_cc"))
+        while e.audio_needed(first + n) > 0:
+            e.audio_write(golden.audio)
+        e.render(first)
+        for f, (c1, c2) in pairs.items():
+            e.cc608_write(f, c1, c2)
+        e.render(n)
+        got = e.fetch(0, n * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // W, bad[0] % W)

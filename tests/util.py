@@ -74,10 +74,12 @@ class Golden:
         return p, mask
 
     def teletext_skip(self, case):
-        """Teletext rows (625 lines) held by the case's other inserters: VITS 17/18/330/331, VITC 19/21/332/334."""
+        """Teletext rows (625 lines) held by the case's other inserters: VITS 17/18/330/331, VITC
+        19/21/332/334, ACP 9-18/321-330, CC608 22."""
         x = self.cases[case].get("extra", {})
         lines = ([17, 18, 330, 331] if x.get("vits") else []) + ([19, 21, 332, 334] if x.get("vitc") else [])
-        return tuple(l - 7 if l < 300 else 16 + l - 320 for l in lines)
+        lines += (list(range(9, 19)) + list(range(321, 331)) if x.get("acp") else []) + ([22] if x.get("cc608") else [])
+        return tuple(sorted(set(l - 7 if l < 300 else 16 + l - 320 for l in lines)))
 
     def cli_flags(self, case, passfile="/tmp/hvk_passthru.bin"):
         """The reference CLI's flags for the case; passthru cases expect passthru_signal() at `passfile`."""
