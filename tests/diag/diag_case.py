@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/diag_case.py CASE [NFRAMES] -- render a golden case on the GPU and with the oracle; list the lines that differ."""
+"""tests/diag/diag_case.py CASE [NFRAMES] -- render a golden case on the GPU and with the oracle; list the lines that differ."""
 import os
 import sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hacktv_amd as H  # noqa: E402
