@@ -21,7 +21,8 @@
  *    (src/hacktv.c:1452, :1493, :1503-1518), plus width / levels for vid_info.
  *  - video is pulled with av_eof / av_read_video at the start of every frame
  *    (src/video.c:4873-4897), audio with av_read_audio as the 32 kHz tick needs
- *    it (src/video.c:3278-3286); both from the calling thread.
+ *    it (src/video.c:3278-3286). The reference pulls video on the main thread and audio on
+ *    its audio thread; here one worker thread pulls both, in stream order.
  *  - vid_next_line() hands out one scanline of interleaved int16 I/Q, valid
  *    until the next call, with frame / line numbers starting at 1, and returns
  *    NULL at the end of the source (src/video.c:4936-4952).
@@ -29,7 +30,9 @@
  *    a message; nothing is silently dropped.
  *
  * Difference: frames are rendered HVK_BATCH at a time on the GPU (environment
- * variable, default 4) and read back into a host buffer the lines point into.
+ * variable, default 4) and read back into a host buffer the lines point into;
+ * a worker thread prepares the next batch (source pulls, host pre-passes, render,
+ * read-back) while the lines of the current one are handed out.
  * line->audio is always NULL (the file sink has no audio path).
  *
  * Teletext: which packet goes on which line -- the TTI page store, the magazine
@@ -42,6 +45,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <pthread.h>
 #include "video.h"          /* the reference's */
 #include "hacktv_amd.h"
 
@@ -49,8 +53,19 @@ typedef struct {
 	hvk_engine_t *e;
 	hvk_info_t info;
 	int batch;              /* frames per GPU launch */
-	int16_t *iq;            /* batch * frame_samples pairs */
+	int16_t *iq;            /* the batch being handed out: batch * frame_samples pairs */
 	int have;               /* frames rendered in iq */
+	/* the next batch is pulled, rendered and fetched by a worker thread while this one goes out */
+	int16_t *buf[2];
+	int ready[2];           /* 0: free for the worker, 1: filled */
+	int count[2];           /* frames in the buffer; 0: the source has ended, < 0: failure */
+	int cur;                /* buffer being handed out, -1: none yet */
+	int stop;
+	pthread_t worker;
+	int worker_on;
+	pthread_mutex_t lock;
+	pthread_cond_t cond;
+	int64_t frames_pulled;  /* frames taken from the source so far (worker side) */
 	int frame_in_batch;
 	int line;               /* next line of the current frame, 0-based */
 	int64_t frames_done;    /* frames handed out completely */
@@ -195,11 +210,16 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 
 	hvk_get_info(m->e, &m->info);
 
-	m->iq = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+	m->buf[0] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+	m->buf[1] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
 	m->widths = malloc(sizeof(int32_t) * m->info.lines);
-	if(!m->iq || !m->widths)
+	m->cur = -1;
+	pthread_mutex_init(&m->lock, NULL);
+	pthread_cond_init(&m->cond, NULL);
+	if(!m->buf[0] || !m->buf[1] || !m->widths)
 	{
-		free(m->iq);
+		free(m->buf[0]);
+		free(m->buf[1]);
 		free(m->widths);
 		hvk_close(m->e);
 		free(m);
@@ -252,15 +272,28 @@ void vid_free(vid_t *s)
 {
 	shim_t *m = _shim(s);
 
-	av_close(&s->av);       /* src/video.c:4711 */
-
 	if(s->conf.teletext && s->tt.vid) tt_free(&s->tt);
 	if(s->passthru && s->passthru != stdin) fclose(s->passthru);   /* src/video.c:4783-4786 */
+
+	if(m && m->worker_on)
+	{
+		/* the worker is the only caller of the engine and the source: stop it first */
+		pthread_mutex_lock(&m->lock);
+		m->stop = 1;
+		pthread_cond_broadcast(&m->cond);
+		pthread_mutex_unlock(&m->lock);
+		pthread_join(m->worker, NULL);
+	}
+
+	av_close(&s->av);       /* src/video.c:4711 */
 
 	if(m)
 	{
 		hvk_close(m->e);
-		free(m->iq);
+		free(m->buf[0]);
+		free(m->buf[1]);
+		pthread_mutex_destroy(&m->lock);
+		pthread_cond_destroy(&m->cond);
 		free(m->widths);
 		free(m->passbuf);
 		free(m);
@@ -285,8 +318,8 @@ size_t vid_get_framebuffer_length(vid_t *s)
 	return(sizeof(uint32_t) * s->active_width * s->conf.active_lines);
 }
 
-/* Pull up to `batch` frames and the audio they need from the source, render them */
-static int _next_batch(vid_t *s, shim_t *m)
+/* Pull up to `batch` frames and the audio they need from the source, render them into iq */
+static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 {
 	int32_t slots[256];
 	int n = 0;
@@ -310,7 +343,7 @@ static int _next_batch(vid_t *s, shim_t *m)
 			/* the packets of this frame, asked for in the order the lines go out */
 			uint8_t rows[32][45];
 			uint32_t mask = 0;
-			int frame = (int) (m->frames_done + m->frame_in_batch_pull + 1), row;
+			int frame = (int) (m->frames_pulled + 1), row;
 
 			for(row = 0; row < 32; row++)
 			{
@@ -327,6 +360,7 @@ static int _next_batch(vid_t *s, shim_t *m)
 		}
 
 		m->frame_in_batch_pull++;
+		m->frames_pulled++;
 		n++;
 	}
 
@@ -369,9 +403,41 @@ static int _next_batch(vid_t *s, shim_t *m)
 	}
 
 	if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);
-	if(hvk_fetch(m->e, m->iq, 0, (size_t) n * m->info.frame_samples) != HVK_OK) return(-1);
+	if(hvk_fetch(m->e, iq, 0, (size_t) n * m->info.frame_samples) != HVK_OK) return(-1);
 
 	return(n);
+}
+
+/* The worker: keeps the buffer that is not being handed out filled. It alone talks to the source
+ * (av_read_video / av_read_audio / tt_next_packet / the passthru file) and to the engine. */
+static void *_worker(void *arg)
+{
+	vid_t *s = arg;
+	shim_t *m = _shim(s);
+	int b = 0;
+
+	for(;;)
+	{
+		int n;
+
+		pthread_mutex_lock(&m->lock);
+		while(m->ready[b] && !m->stop) pthread_cond_wait(&m->cond, &m->lock);
+		if(m->stop) { pthread_mutex_unlock(&m->lock); break; }
+		pthread_mutex_unlock(&m->lock);
+
+		n = m->ended ? 0 : _next_batch(s, m, m->buf[b]);
+
+		pthread_mutex_lock(&m->lock);
+		m->count[b] = n;
+		m->ready[b] = 1;
+		pthread_cond_broadcast(&m->cond);
+		pthread_mutex_unlock(&m->lock);
+
+		if(n <= 0) break;       /* end of the source (or a failure): nothing more to render */
+		b ^= 1;
+	}
+
+	return(NULL);
 }
 
 vid_line_t *vid_next_line(vid_t *s)
@@ -383,10 +449,25 @@ vid_line_t *vid_next_line(vid_t *s)
 
 	if(m->frame_in_batch >= m->have)
 	{
-		int n;
-		if(m->ended) return(NULL);
-		n = _next_batch(s, m);
-		if(n <= 0) return(NULL);
+		int nb = m->cur < 0 ? 0 : m->cur ^ 1, n;
+
+		if(!m->worker_on)
+		{
+			/* started on the first line, once main() has filled in s->av (src/hacktv.c:1493) */
+			if(pthread_create(&m->worker, NULL, _worker, s) != 0) return(NULL);
+			m->worker_on = 1;
+		}
+
+		/* hand the finished buffer back, wait for the next one */
+		pthread_mutex_lock(&m->lock);
+		if(m->cur >= 0) { m->ready[m->cur] = 0; pthread_cond_broadcast(&m->cond); }
+		while(!m->ready[nb]) pthread_cond_wait(&m->cond, &m->lock);
+		n = m->count[nb];
+		pthread_mutex_unlock(&m->lock);
+
+		if(n <= 0) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
+		m->cur = nb;
+		m->iq = m->buf[nb];
 		m->have = n;
 		m->frame_in_batch = 0;
 		m->line = 0;
