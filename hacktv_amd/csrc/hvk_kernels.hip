@@ -933,45 +933,72 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
  * The slab written here is what hvk_k_filter reads: s_lead samples before a
  * frame's output sample 0, whose filter centre is resampled sample rs_shift. */
 #define HVK_RS_TILE 1024
-#define HVK_RS_WIN  (4 * HVK_RS_TILE + 72 + 8)
+#define HVK_RS_WIN  (4 * HVK_RS_TILE + 72 + 8)      /* raster samples a tile can need: 1024 D / L + ataps, D <= 4 L */
+#define HVK_RS_NP   11                              /* tap pairs per phase: ataps is 21 or 22 for every L (ntaps = 21 L | 1) */
+#define HVK_RS_ROW  12                              /* dwords per phase row in LDS: 16-byte aligned rows */
 __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int16_t *__restrict__ taps,
                                                       int16_t *__restrict__ S2)
 {
-	__shared__ int16_t win[HVK_RS_WIN];
-	__shared__ int16_t tp[8192];
+	__shared__ __attribute__((aligned(16))) int win[HVK_RS_WIN / 2];        /* raster samples, two per dword */
+	__shared__ __attribute__((aligned(16))) int tp[256 * HVK_RS_ROW];       /* taps, two per dword, one row per phase */
 
 	const int t = threadIdx.x;
-	const int L = k.rs_L, D = k.rs_D, A = k.rs_ataps;
+	const unsigned L = k.rs_L, D = k.rs_D;
+	const int A = k.rs_ataps;
 	const long slab_in = (long) k.slab_lines * k.width;
 	const int16_t *in = Sp + (size_t) blockIdx.y * slab_in;     /* raster line -1 of the frame first */
 	int16_t *out = S2 + (size_t) blockIdx.y * k.s_stride;
 
 	const int q0 = blockIdx.x * HVK_RS_TILE;                    /* first slab sample of the tile */
-	const long r0 = (long) q0 - k.s_lead + k.rs_shift;          /* its resampled-stream index, frame local (>= 0) */
-	const long n_lo = (r0 * D) / L - (A - 1);                   /* first raster sample needed, frame local */
-	const long n_hi = ((r0 + HVK_RS_TILE - 1) * D) / L;
-	const int count = (int) (n_hi - n_lo + 1);
+	const unsigned r0 = (unsigned) (q0 - k.s_lead + k.rs_shift); /* its resampled-stream index, frame local (>= 0; r D < 2^32, hvk_tables.c) */
+	/* first raster sample staged, frame local, rounded down to an even index so that pairs are dwords */
+	const long n_lo = (((long) ((r0 * D) / L) - (A - 1)) & ~1L);
+	const long n_hi = (long) (((r0 + HVK_RS_TILE - 1) * D) / L);
+	const int count2 = (int) ((n_hi - n_lo + 2) / 2);           /* dwords */
 
-	for(int j = t; j < L * A; j += 256) tp[j] = taps[j];
-	for(int j = t; j < count; j += 256)
+	/* taps of phase p: pairs (t[0], t[1]) ... oldest sample first; a 21-tap phase gets a zero 22nd */
+	for(int j = t; j < (int) L * HVK_RS_ROW; j += 256)
 	{
-		const long p = n_lo + j + k.width;                      /* slab position: one halo line in front */
-		win[j] = (p >= 0 && p < slab_in) ? in[p] : (int16_t) 0;
+		const int p = j / HVK_RS_ROW, m = j % HVK_RS_ROW;
+		const int lo = 2 * m < A ? taps[p * A + 2 * m] : 0, hi = 2 * m + 1 < A ? taps[p * A + 2 * m + 1] : 0;
+		tp[j] = (lo & 0xFFFF) | (hi << 16);
+	}
+	for(int j = t; j < count2 + 1 && j < HVK_RS_WIN / 2; j += 256)
+	{
+		const long p = n_lo + 2 * j + k.width;                  /* slab position: one halo line in front */
+		const int lo = (p >= 0 && p < slab_in) ? in[p] : 0, hi = (p + 1 >= 0 && p + 1 < slab_in) ? in[p + 1] : 0;
+		win[j] = (lo & 0xFFFF) | (hi << 16);
 	}
 	__syncthreads();
+
+	/* this lane's first output: position and phase by one division, the next three by stepping */
+	unsigned rd = (r0 + t * 4) * D;
+	long n = rd / L;
+	unsigned ph = rd - (unsigned) n * L;
 
 	short v[4];
 #pragma unroll
 	for(int i = 0; i < 4; i++)
 	{
-		const long r = r0 + t * 4 + i;
-		const long rd = r * D;
-		const int n = (int) (rd / L - n_lo) - (A - 1);          /* window start in win[] */
-		const int16_t *c = tp + (int) (rd % L) * A;
-		int a = 0;
-		for(int y = 0; y < A; y++) a += (int) win[n + y] * c[y];
+		const int ws = (int) (n - n_lo) - (A - 1);              /* window start in samples */
+		const int *w = win + (ws >> 1);
+		const int sh = (ws & 1) * 16;                           /* odd start: every pair straddles two dwords */
+		const int4v *c = (const int4v *) (tp + ph * HVK_RS_ROW);
+		const int4v c0 = c[0], c1 = c[1], c2 = c[2];
+		const int ct[HVK_RS_ROW] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w };
+		int a = 0, cur = w[0];
+#pragma unroll
+		for(int m = 0; m < HVK_RS_NP; m++)
+		{
+			const int nxt = w[m + 1];
+			a = dot2((int) __builtin_amdgcn_alignbit((unsigned) nxt, (unsigned) cur, sh), ct[m], a);
+			cur = nxt;
+		}
 		a >>= 15;
 		v[i] = (short) (a < -32768 ? -32768 : (a > 32767 ? 32767 : a));
+
+		ph += D;
+		while(ph >= L) { ph -= L; n++; }
 	}
 
 	const int q = q0 + t * 4;

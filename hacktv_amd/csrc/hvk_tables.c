@@ -1308,6 +1308,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		}
 		free(taps);
 
+		/* the kernel's position arithmetic is 32-bit: (frame-local resampled index) * D */
+		if(((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; return(HVK_UNSUPPORTED); }
 		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D);
 		t->k.slab_lines = t->k.lines + 3;
 		t->max_width = (int32_t) (((int64_t) t->k.width * L + D - 1) / D);   /* fir_int16_output_size, src/fir.c:376-381 */
