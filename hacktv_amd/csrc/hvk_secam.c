@@ -108,6 +108,17 @@ void hvk_secam_free(hvk_secam_t *s)
 	free(s);
 }
 
+/* lround() without the library call: truncate, then look at the (exactly representable) rest.
+ * |x| < 2^31 here. Halves go away from zero, like lround. */
+static inline int32_t _round_away(double x)
+{
+	int32_t i = (int32_t) x;
+	double f = x - (double) i;
+	if(f >= 0.5) i++;
+	else if(f <= -0.5) i--;
+	return(i);
+}
+
 /* One line of the process. `row` points at the source pixels shown on this
  * line (NULL: none); out receives the W values to add to the line (NULL: a
  * pipeline-fill slot whose result is never emitted). */
@@ -177,7 +188,7 @@ static void _line(hvk_secam_t *s, int frame, int line, int picture, int right_ha
 			const double in = (double) s->line[x];
 			iy = in * 2.90456054 + ix * -2.80912108 - iy * -0.90456054;
 			ix = in;
-			s->line[x] = lround(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
+			s->line[x] = _round_away(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
 		}
 		s->ix = ix;
 		s->iy = iy;
