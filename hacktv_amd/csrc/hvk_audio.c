@@ -295,6 +295,8 @@ struct hvk_audio {
 	_phasor_t fm, am;
 	_limiter_t lim;
 	int has_lim;
+	_phasor_t a2, a2_pilot, a2_signal;  /* A2 stereo: second FM carrier, pilot and identification tones */
+	_limiter_t a2_lim;
 
 	int nicam_on;
 	_nicam_t nicam;
@@ -332,6 +334,26 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 			a->lim.level = INT16_MAX;
 			a->lim.h = 21 / 2;
 		}
+	}
+
+	if(t->a2_lut)
+	{
+		a->a2.on = 1;
+		a->a2.pi = INT32_MAX;
+		a->a2.counter = INT16_MAX;
+		a->a2.level = t->a2_level;
+		if(t->has_limiter)
+		{
+			a->a2_lim.vfir.taps = t->limiter_vtaps;
+			a->a2_lim.ffir.taps = t->limiter_ftaps;
+			a->a2_lim.shape = t->limiter_shape;
+			a->a2_lim.level = INT16_MAX;
+			a->a2_lim.h = 21 / 2;
+		}
+		a->a2_pilot.pi = a->a2_signal.pi = INT32_MAX;
+		a->a2_pilot.counter = a->a2_signal.counter = INT16_MAX;
+		a->a2_pilot.level = t->a2_pilot_level;
+		a->a2_signal.level = t->a2_signal_level;
 	}
 
 	if(t->am_level)
@@ -427,6 +449,16 @@ static void _tick(hvk_audio_t *a)
 	{
 		a->fm.sample = (s[0] + s[1]) / 2;
 		if(a->has_lim) a->fm.sample = _limit(&a->lim, a->fm.sample);
+		/* room for the pilot in A2 stereo mode (src/video.c:3325-3327): int16 *= double truncates */
+		if(a->a2.on) a->fm.sample *= 0.95;
+	}
+
+	if(a->a2.on)
+	{
+		/* the right channel (src/video.c:3340-3350) */
+		a->a2.sample = s[1];
+		if(a->has_lim) a->a2.sample = _limit(&a->a2_lim, a->a2.sample);
+		a->a2.sample *= 0.95;
 	}
 
 	if(a->nicam_on)
@@ -480,6 +512,32 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 				ai += (int16_t) (((a->fm.pi >> 16) * a->fm.level) >> 15);
 				aq += (int16_t) (((a->fm.pq >> 16) * a->fm.level) >> 15);
 				_correct(&a->fm);
+			}
+
+			if(a->a2.on)
+			{
+				/* second carrier (src/video.c:3402-3424): right channel (L - R on system M) plus the
+				 * pilot, itself amplitude modulated by the identification tone -- its step
+				 * changes with every sample */
+				const hvk_tables_t *t = a->t;
+				int16_t m = t->a2_system_m ? (int16_t) (a->fm.sample - a->a2.sample) : a->a2.sample;
+				int32_t tone, pilot;
+				hvk_c32_t st;
+
+				_step(&a->a2_signal, t->a2_signal_delta.i, t->a2_signal_delta.q);
+				tone = (int16_t) (((((a->a2_signal.pi >> 16) * 16384) >> 15) * a->a2_signal.level) >> 15);
+				_correct(&a->a2_signal);
+
+				_step(&a->a2_pilot, t->a2_pilot_delta.i, t->a2_pilot_delta.q);
+				pilot = (int16_t) (((((a->a2_pilot.pi >> 16) * ((tone - INT16_MIN) / 2)) >> 15) * a->a2_pilot.level) >> 15);
+				_correct(&a->a2_pilot);
+
+				m = (int16_t) (m + pilot);
+				st = t->a2_lut[m - INT16_MIN];
+				_step(&a->a2, st.i, st.q);
+				ai += (int16_t) (((a->a2.pi >> 16) * a->a2.level) >> 15);
+				aq += (int16_t) (((a->a2.pq >> 16) * a->a2.level) >> 15);
+				_correct(&a->a2);
 			}
 
 			if(a->am.on)

@@ -130,6 +130,11 @@ typedef struct {
 	/* audio */
 	int32_t fm_level; hvk_c32_t *fm_lut;
 	int32_t am_level; hvk_c32_t am_delta;
+	/* A2 stereo (src/video.c:4375-4400): second FM carrier, pilot and identification tones */
+	int32_t a2_level; hvk_c32_t *a2_lut;
+	int32_t a2_system_m;
+	int32_t a2_pilot_level, a2_signal_level;
+	hvk_c32_t a2_pilot_delta, a2_signal_delta;
 	int16_t *nicam_taps; hvk_c16_t *nicam_cc;
 	int16_t limiter_shape[21];
 	int32_t limiter_vtaps[65], limiter_ftaps[65];

@@ -393,8 +393,34 @@ static int _build_audio(hvk_tables_t *t, double slevel)
 		t->k.has_carriers = 1;
 	}
 
+	/* Zweikanalton (src/video.c:4375-4400): a second FM carrier derived from the first (-7 dB,
+	 * 242.1875 kHz above it; 224.213 kHz on system M), a 54.6875 kHz pilot amplitude modulated
+	 * with the 117.5 Hz "stereo" identification tone. NICAM is switched off. */
+	if(c->a2stereo && t->fm_lut)
+	{
+		int r;
+		double carrier;
+
+		t->a2_system_m = c->fm_mono_carrier == 4500000;
+		carrier = c->fm_mono_carrier + (t->a2_system_m ? 224213 : 242187.5);
+
+		t->a2_level = (int16_t) round(INT16_MAX * ((c->fm_mono_level * 0.446684) * slevel));
+		t->a2_lut = malloc(sizeof(hvk_c32_t) * 65536);
+		if(!t->a2_lut) return(HVK_OUT_OF_MEMORY);
+		for(r = INT16_MIN; r <= INT16_MAX; r++)
+		{
+			double d = 2.0 * M_PI / t->sample_rate * (carrier + (double) r / INT16_MAX * c->fm_mono_deviation);
+			t->a2_lut[r - INT16_MIN] = _unit_phasor(d);
+		}
+
+		t->a2_pilot_level = (int16_t) round(INT16_MAX * 0.05);
+		t->a2_pilot_delta = _unit_phasor(2.0 * M_PI / t->sample_rate * (t->a2_system_m ? 55.06993e3 : 54.6875e3));
+		t->a2_signal_level = (int16_t) round(INT16_MAX * 1.0);
+		t->a2_signal_delta = _unit_phasor(2.0 * M_PI / t->sample_rate * (t->a2_system_m ? 149.9 : 117.5));
+	}
+
 	/* NICAM-728 (src/video.c:4522-4533, src/nicam728.c:257-331) */
-	if(c->nicam_level > 0 && c->nicam_carrier != 0)
+	if(c->nicam_level > 0 && c->nicam_carrier != 0 && !c->a2stereo)
 	{
 		unsigned int sr = t->sample_rate, freq = c->nicam_carrier, g;
 		double sps = (double) sr / 364000.0;
@@ -1394,6 +1420,7 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->vf_itaps);
 	free(t->vf_qtaps);
 	free(t->fm_lut);
+	free(t->a2_lut);
 	free(t->nicam_taps);
 	free(t->nicam_cc);
 	free(t->tt_symbols);

@@ -99,7 +99,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
-	if(c->a2stereo || c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
+	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
 	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
 	if(c->secam_field_id) return(_refuse("SECAM field id"));
@@ -153,6 +153,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->nicam_carrier = c->nicam_carrier;
 	h->nicam_beta = c->nicam_beta;
 	h->am_mono_carrier = c->am_mono_carrier;
+	h->a2stereo = c->a2stereo;
 	h->vfilter = c->vfilter;
 	h->teletext = c->teletext != NULL;
 	h->vits = c->vits;

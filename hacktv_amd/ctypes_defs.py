@@ -60,6 +60,7 @@ class HvkConfig(C.Structure):
         ("nicam_carrier", C.c_double),
         ("nicam_beta", C.c_double),
         ("am_mono_carrier", C.c_double),
+        ("a2stereo", C.c_int),
         ("vfilter", C.c_int),
         ("teletext", C.c_int),
         ("wss", C.c_int),

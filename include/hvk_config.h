@@ -8,7 +8,7 @@
  * video.h-compatible shim does exactly that).
  *
  * Everything the reference's engine supports but this engine does not render
- * (scramblers, MAC, sound-in-syncs, DANCE, A2 stereo,
+ * (scramblers, MAC, sound-in-syncs, DANCE, separate L/R FM sub-carriers,
  * FM energy dispersal, raw baseband input) has no field here; the shim
  * refuses such configurations rather than silently dropping them.
  */
@@ -117,6 +117,10 @@ typedef struct hvk_config_t {
 	double nicam_beta;
 
 	double am_mono_carrier;     /* Hz */
+
+	int a2stereo;               /* --a2stereo (Zweikanalton): a second FM carrier 242.1875 kHz (224.213 kHz on
+	                             * system M) above the first with the right channel (L - R on M) and the
+	                             * 54.6875 kHz pilot; replaces NICAM (src/video.c:4375-4400, :3404-3424) */
 
 	int vfilter;                /* --filter, src/hacktv.c:1412 */
 

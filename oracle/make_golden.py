@@ -79,6 +79,9 @@ CASES = [
     # anti-copy pulses and the CEA-608 caption line (no captions from the test source: parity-only codes)
     ("i_acp_cc",      "i",    16000000, ["--noaudio", "--acp", "--cc608", "--vits", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO, False, 3, {"acp": 1, "cc608": 1, "vits": 1}),
     ("m_acp_cc",      "m",    13500000, ["--filter", "--acp", "--cc608", "--vitc"], refprobe.FLAG_FILTER,   False, 2, {"acp": 1, "cc608": 1, "vitc": 1}),
+    # Zweikanalton: second FM carrier with pilot instead of NICAM (system M carries L - R)
+    ("g_a2",          "g",    16000000, ["--filter", "--a2stereo"], refprobe.FLAG_FILTER,                   False, 3, {"a2stereo": 1}),
+    ("m_a2",          "m",    13500000, ["--a2stereo"],             0,                                      False, 2, {"a2stereo": 1}),
     ("pal_px135_s136", "pal", 13600000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER,      True,  3, {}, 13500000),   # lines of 870 / 871 samples
 ]
 

@@ -467,8 +467,45 @@ int orc_audio_init(orc_t *s)
 		else if(c->fm_mono_preemph != 0) return(-1); /* J.17 FM pre-emphasis: not restated */
 	}
 
-	/* src/video.c:4522-4533 */
-	if(c->nicam_level > 0 && c->nicam_carrier != 0)
+	/* Zweikanalton (src/video.c:4375-4400): the second carrier is derived from the first, the pilot
+	 * is a 54.6875 kHz tone amplitude modulated with the 117.5 Hz "stereo" identification */
+	if(c->a2stereo && s->fm_mono.on)
+	{
+		orc_mod_t *m = &s->fm_right;
+		double carrier, d;
+
+		s->a2_system_m = c->fm_mono_carrier == 4500000;
+		carrier = c->fm_mono_carrier + (s->a2_system_m ? 224213 : 242187.5);
+
+		m->on = 1;
+		m->level = round(INT16_MAX * ((c->fm_mono_level * 0.446684) * slevel));
+		m->counter = INT16_MAX;
+		m->phase.i = INT32_MAX;
+		m->phase.q = 0;
+		_mod_lut(m, s->sample_rate, carrier, c->fm_mono_deviation);
+		if(c->fm_mono_preemph == HVK_50US || c->fm_mono_preemph == HVK_75US)
+		{
+			_limiter_init(&m->lim, INT16_MAX, 21, c->fm_mono_preemph == HVK_50US ? _50us_half : _75us_half, _flat_half);
+			m->has_lim = 1;
+		}
+
+		d = 2.0 * M_PI / s->sample_rate * (s->a2_system_m ? 55.06993e3 : 54.6875e3);
+		s->a2_pilot.level = round(INT16_MAX * 0.05);
+		s->a2_pilot.counter = INT16_MAX;
+		s->a2_pilot.phase.i = INT32_MAX;
+		s->a2_pilot.delta.i = lround(cos(d) * INT32_MAX);
+		s->a2_pilot.delta.q = lround(sin(d) * INT32_MAX);
+
+		d = 2.0 * M_PI / s->sample_rate * (s->a2_system_m ? 149.9 : 117.5);
+		s->a2_signal.level = round(INT16_MAX * 1.0);
+		s->a2_signal.counter = INT16_MAX;
+		s->a2_signal.phase.i = INT32_MAX;
+		s->a2_signal.delta.i = lround(cos(d) * INT32_MAX);
+		s->a2_signal.delta.q = lround(sin(d) * INT32_MAX);
+	}
+
+	/* src/video.c:4522-4533; A2 stereo switches NICAM off (:4397-4399) */
+	if(c->nicam_level > 0 && c->nicam_carrier != 0 && !c->a2stereo)
 	{
 		_nicam_init(&s->nicam, s->sample_rate, c->nicam_carrier, c->nicam_beta, c->nicam_level * slevel);
 		s->nicam_buf_len = 0;
@@ -495,6 +532,8 @@ void orc_audio_free(orc_t *s)
 {
 	free(s->fm_mono.lut);
 	if(s->fm_mono.has_lim) _limiter_free(&s->fm_mono.lim);
+	free(s->fm_right.lut);
+	if(s->fm_right.has_lim) _limiter_free(&s->fm_right.lim);
 	free(s->nicam.taps);
 	free(s->nicam.bb);
 	free(s->nicam.cc);
@@ -545,6 +584,18 @@ void orc_audio_line(orc_t *s, int16_t *iq, int width, int16_t *carrier_tap)
 				{
 					s->fm_mono.sample = _limiter_step(&s->fm_mono.lim, s->fm_mono.sample, s->fm_mono.sample);
 				}
+				/* room for the pilot (:3325-3327) */
+				if(c->a2stereo) s->fm_mono.sample *= 0.95;
+			}
+
+			if(s->fm_right.on)
+			{
+				s->fm_right.sample = audio[1];
+				if(s->fm_right.has_lim)
+				{
+					s->fm_right.sample = _limiter_step(&s->fm_right.lim, s->fm_right.sample, s->fm_right.sample);
+				}
+				s->fm_right.sample *= 0.95;
 			}
 
 			if(s->nicam.on)
@@ -560,6 +611,19 @@ void orc_audio_line(orc_t *s, int16_t *iq, int width, int16_t *carrier_tap)
 		}
 
 		if(s->fm_mono.on) _fm_add(&s->fm_mono, add, s->fm_mono.sample);
+		if(s->fm_right.on)
+		{
+			/* src/video.c:3402-3424 */
+			int16_t a2 = s->fm_right.sample;
+			int16_t s1[2] = { 0, 0 }, s2[2] = { 0, 0 };
+
+			if(s->a2_system_m) a2 = s->fm_mono.sample - s->fm_right.sample;    /* L - R on system M */
+			_am_add(&s->a2_signal, s1, 0);
+			_am_add(&s->a2_pilot, s2, s1[0]);
+			a2 += s2[0];
+
+			_fm_add(&s->fm_right, add, a2);
+		}
 		if(s->am_mono.on) _am_add(&s->am_mono, add, s->am_mono.sample);
 
 		if(iq)

@@ -134,6 +134,9 @@ struct orc_t {
 	long audio_len, audio_pos;
 	int audio_loop;
 	orc_mod_t fm_mono;
+	orc_mod_t fm_right;         /* A2 stereo: the second sound carrier */
+	orc_mod_t a2_pilot, a2_signal;
+	int a2_system_m;
 	orc_mod_t am_mono;
 	orc_nicam_t nicam;
 	int16_t nicam_buf[64];

@@ -52,7 +52,8 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
                                   "pal_fm_pass",
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
-                                  "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc"])
+                                  "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
+                                  "g_a2", "m_a2"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]

@@ -37,7 +37,7 @@ def test_host_tables_equal_oracle(golden, case):
             assert np.array_equal(e.line_widths(650, 50), w[650:])
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full", "g_a2", "m_a2"])
 def test_serial_carrier_stream_equals_oracle(golden, case):
     """The host pre-pass (FM/AM phasor chains, limiter, 32 kHz tick) produces the same
     per-sample contribution as the oracle's per-sample loop, including the
