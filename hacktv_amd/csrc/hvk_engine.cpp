@@ -38,6 +38,7 @@ struct hvk_slot_t {
 	int valid;
 	int width, height;      /* after the centre crop */
 	int interlaced;
+	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
 };
 
 struct hvk_engine {
@@ -97,6 +98,7 @@ struct hvk_engine {
 
 	int64_t next_frame;
 	int staged;             /* frames staged for the next launch */
+	int32_t *staged_slots;  /* [max_frames] the slot each of them shows */
 	int64_t staged_first, staged_stride;
 	int last_frames;        /* frames of the last launch (for fetch) */
 	int ghost_dirty;
@@ -156,7 +158,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	 * picture on every frame (a static source needs only slot 0) */
 	e->frame_slots = max_frames < HVK_MIN_FRAME_SLOTS ? HVK_MIN_FRAME_SLOTS : (max_frames > HVK_MAX_FRAME_SLOTS ? HVK_MAX_FRAME_SLOTS : max_frames);
 	e->slots = (hvk_slot_t *) calloc(e->frame_slots, sizeof(hvk_slot_t));
-	if(!e->slots) { free(e); return(HVK_OUT_OF_MEMORY); }
+	e->staged_slots = (int32_t *) calloc(max_frames, sizeof(int32_t));
+	if(!e->slots || !e->staged_slots) { free(e->slots); free(e->staged_slots); free(e); return(HVK_OUT_OF_MEMORY); }
 
 	if((r = hvk_tables_build(&e->t, conf, sample_rate, pixel_rate)) != HVK_OK) { hvk_close(e); return(r); }
 
@@ -369,6 +372,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	hvk_secam_free(e->secam);
 	hvk_tail_free(e->tail);
 	free(e->slots);
+	free(e->staged_slots);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
 	free(e);
@@ -510,6 +514,14 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	return(HVK_OK);
 }
 
+extern "C" int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den)
+{
+	if(!e || slot < 0 || slot >= e->frame_slots || par_num <= 0 || par_den <= 0) return(HVK_ERROR);
+	e->slots[slot].par_num = par_num;
+	e->slots[slot].par_den = par_den;
+	return(HVK_OK);
+}
+
 extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask)
 {
 	if(!e || !packets || frame_in_batch < 0 || frame_in_batch >= e->max_frames) return(HVK_ERROR);
@@ -641,10 +653,12 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 		if(t.conf.wss)
 		{
 			/* line 23; the table's bits are MSB first (src/wss.c:184) */
-			uint8_t rev[18];
+			uint8_t rev[18], bits[18];
+			const hvk_slot_t &sl = e->slots[e->staged_slots[i]];
+			hvk_wss_bits(&t, sl.par_den ? sl.par_num : 1, sl.par_den ? sl.par_den : 1, bits);
 			for(int b = 0; b < 18; b++)
 			{
-				uint8_t v = t.wss_bits[b], r = 0;
+				uint8_t v = bits[b], r = 0;
 				for(int q = 0; q < 8; q++) if(v & (1 << q)) r |= 0x80 >> q;
 				rev[b] = r;
 			}
@@ -799,6 +813,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		const int slot = slots ? slots[i] : 0;
 		if(slot < 0 || slot >= e->frame_slots) return(HVK_ERROR);
 		const hvk_slot_t *s = &e->slots[slot];
+		e->staged_slots[i] = slot;
 
 		memset(f, 0, sizeof(*f));
 		f->frame_index = first_frame + i * stride;

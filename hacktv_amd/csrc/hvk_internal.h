@@ -177,6 +177,8 @@ long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max
  * frame counts from 1, line is the 1-based line number. Returns the number of bits. */
 int hvk_vitc_bits(const hvk_tables_t *t, int frame, int line, uint8_t data[12]);
 
+/* WSS: line 23's 137 bits (MSB first) for a frame whose source has the given pixel aspect */
+void hvk_wss_bits(const hvk_tables_t *t, int64_t par_num, int64_t par_den, uint8_t bits[18]);
 /* ACP: the AGC pulse level of a frame (counted from 1), src/acp.c:78-90 */
 int hvk_acp_agc_level(const hvk_tables_t *t, int frame);
 /* CC608: the 17 bits of a caption byte pair, LSB first (src/cc608.c:170-186) */

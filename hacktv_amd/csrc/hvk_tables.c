@@ -720,14 +720,14 @@ static int _build_wss(hvk_tables_t *t)
 	int o = 29 + 24, r;
 
 	if(c->lines != 625) return(HVK_UNSUPPORTED);            /* src/hacktv.c: 625-line modes only */
-	if(c->wss < 0 || c->wss > 0x0F) return(HVK_UNSUPPORTED); /* "auto" (0xFF) needs the source's pixel aspect */
+	if(c->wss != 0xFF && (c->wss < 0 || c->wss > 0x0F)) return(HVK_UNSUPPORTED);
 
 	r = _append_step_lut(t, 1, 137, level, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 11e-6);
 	if(r != HVK_OK) return(r);
 
 	memset(t->wss_bits, 0, sizeof(t->wss_bits));
 	memcpy(t->wss_bits, lead, sizeof(lead));
-	_wss_group(t->wss_bits, c->wss, &o, 4);     /* aspect ratio */
+	_wss_group(t->wss_bits, c->wss, &o, 4);     /* aspect ratio ("auto": rewritten per frame, hvk_wss_bits) */
 	_wss_group(t->wss_bits, 0x00, &o, 4);       /* enhanced services */
 	_wss_group(t->wss_bits, 0x00, &o, 3);       /* subtitles */
 	_wss_group(t->wss_bits, 0x00, &o, 3);       /* reserved */
@@ -736,6 +736,22 @@ static int _build_wss(hvk_tables_t *t)
 	t->wss_blank_lo = t->k.half_width;
 	t->wss_blank_hi = round(t->pixel_rate * 42.5e-6);
 	return(HVK_OK);
+}
+
+/* Line 23's bits for a frame whose source has pixel aspect par_num / par_den. "auto" (0xFF,
+ * src/wss.c:166-179) signals 4:3 up to the pixel aspect at which the active area is 14:9 wide,
+ * 16:9 beyond; every other mode ignores the source. */
+void hvk_wss_bits(const hvk_tables_t *t, int64_t par_num, int64_t par_den, uint8_t bits[18])
+{
+	memcpy(bits, t->wss_bits, 18);
+	if(t->conf.wss == 0xFF)
+	{
+		/* threshold = (14 / 9) / (active_width / active_lines), compared as fractions (src/common.c:76-80) */
+		const int64_t tn = (int64_t) 14 * t->k.active_lines, td = (int64_t) 9 * t->k.active_width;
+		const int64_t c = par_num * td - par_den * tn;
+		int o = 29 + 24;
+		_wss_group(bits, c <= 0 ? 0x08 : 0x07, &o, 4);
+	}
 }
 
 /* Vertical interval time code (src/vitc.c:42-112): 116 (625) / 115 (525) step symbols per line */

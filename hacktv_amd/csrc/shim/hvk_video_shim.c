@@ -169,8 +169,9 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 		};
 		int i;
 		for(i = 0; modes[i].id && strcasecmp(c->wss, modes[i].id) != 0; i++);
-		if(!modes[i].id) return(_refuse(strcasecmp(c->wss, "auto") == 0 ? "--wss auto (needs the source's pixel aspect per frame)" : "this WSS mode"));
-		h->wss = modes[i].code;
+		if(modes[i].id) h->wss = modes[i].code;
+		else if(strcasecmp(c->wss, "auto") == 0) h->wss = 0xFF;    /* per frame, from its pixel aspect */
+		else return(_refuse("this WSS mode"));
 	}
 	h->fm_level = c->fm_level;
 	h->fm_deviation = c->fm_deviation;
@@ -337,6 +338,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 
 		if(hvk_frame_upload(m->e, n, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
 		slots[n] = n;
+		if(s->conf.wss && hvk_frame_aspect(m->e, n, f.pixel_aspect_ratio.num, f.pixel_aspect_ratio.den) != HVK_OK) return(-1);
 		if(s->conf.cc608 && hvk_cc608_write(m->e, n, f.cc608[0], f.cc608[1]) != HVK_OK) return(-1);
 
 		if(s->conf.teletext)

@@ -138,6 +138,10 @@ int hvk_get_chroma_ghost(const hvk_engine_t *e, int16_t *ghost, int n);
 int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
                      int pixel_stride, int line_stride, int interlaced);
 
+/* The pixel aspect ratio of the frame in `slot` (av_frame_t.pixel_aspect_ratio, src/av.h:43):
+ * only `--wss auto` (conf.wss == 0xFF) looks at it (src/wss.c:166-179). 1:1 unless set. */
+int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den);
+
 /* Teletext (conf.teletext != 0): the packets for the VBI lines of frame
  * `frame_in_batch` (0-based) of the NEXT hvk_render() / hvk_stage_strided()
  * call. packets is [32][45] bytes -- row 0..15 for lines 7..22, row 16..31 for

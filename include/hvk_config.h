@@ -132,7 +132,8 @@ typedef struct hvk_config_t {
 	int wss;                    /* widescreen signalling on line 23 (625 lines): 0 none, else the reference's
 	                             * mode byte, src/wss.c:33-44 -- 0x08 4:3, 0x01 14:9-letterbox, 0x02 14:9-top,
 	                             * 0x0B 16:9-letterbox, 0x04 16:9-top, 0x0D 16:9+-letterbox, 0x0E 14:9-window,
-	                             * 0x07 16:9 ("auto" depends on the source's pixel aspect: not supported) */
+	                             * 0x07 16:9; 0xFF "auto": 4:3 or 16:9 from the pixel aspect of the frame shown
+	                             * (hvk_frame_aspect()) */
 	int vits;                   /* --vits: insertion test signals, lines 17/18/330/331 (625) or 17/280 (525) */
 	int vitc;                   /* --vitc: vertical interval time code, lines 19/21/332/334 (625) or 14/16/277/279 (525) */
 	int acp;                    /* --acp: P-sync / AGC pulse pairs on lines 9-18, 321-330 (625) or 12-19, 275-282 (525) */

@@ -121,6 +121,7 @@ struct orc_t {
 	/* current source frame */
 	const uint32_t *fb;
 	int fb_width, fb_height, fb_pixel_stride, fb_line_stride, fb_interlaced;
+	long long fb_par_num, fb_par_den;   /* pixel aspect of the source frame, 0: 1:1 */
 
 	/* raster stream window: lines [s_first, s_first + s_count) */
 	int16_t *S;

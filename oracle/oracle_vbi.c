@@ -239,7 +239,7 @@ int orc_vbi_init(orc_t *s)
 		static const uint8_t lead[7] = { 0xF8, 0xE3, 0x8E, 0x38, 0xF1, 0xE0, 0xF8 };
 		int level = round((s->white_level - s->black_level) * (5.0 / 7.0)), o;
 
-		if(c->lines != 625 || c->wss > 0x0F) return(-1);
+		if(c->lines != 625 || (c->wss > 0x0F && c->wss != 0xFF)) return(-1);
 		s->wss_lut = _step_table(137, level, (double) s->pixel_rate * 200e-9, (double) s->pixel_rate * 200e-9, (double) s->pixel_rate * 11e-6);
 		memset(s->wss_vbi, 0, sizeof(s->wss_vbi));
 		memcpy(s->wss_vbi, lead, sizeof(lead));
@@ -298,6 +298,12 @@ int orc_vbi_init(orc_t *s)
 	}
 
 	return(0);
+}
+
+void orc_set_frame_aspect(orc_t *s, long long par_num, long long par_den)
+{
+	s->fb_par_num = par_num;
+	s->fb_par_den = par_den;
 }
 
 void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2)
@@ -363,6 +369,14 @@ void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut)
 
 	if(c->wss && line == 23)
 	{
+		if(c->wss == 0xFF)
+		{
+			/* auto (src/wss.c:166-179): 4:3 or 16:9 from the source's pixel aspect against the
+			 * aspect at which the active area is 14:9 wide; r64_cmp, src/common.c:76-80 */
+			long long pn = s->fb_par_den ? s->fb_par_num : 1, pd = s->fb_par_den ? s->fb_par_den : 1;
+			long long tn = 14LL * c->active_lines, td = 9LL * s->active_width;
+			_group_bits(s->wss_vbi, (pn * td - pd * tn) <= 0 ? 0x08 : 0x07, 29 + 24, 4);
+		}
 		for(x = s->half_width; x < s->wss_blank_width; x++) o[x] = s->black_level;
 		_render(s, g, s->wss_lut, 137, s->wss_vbi, 0, 137, 1);
 	}

@@ -40,6 +40,9 @@ void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop);
  * modes only. Up to 16 frames may be queued ahead. */
 int orc_teletext_packets(orc_t *s, long frame_index, const uint8_t *packets, uint32_t mask);
 
+/* the pixel aspect ratio of the current source frame (only --wss auto looks at it) */
+void orc_set_frame_aspect(orc_t *s, long long par_num, long long par_den);
+
 /* --cc608: the caption byte pair of a frame (0-based stream frame index); frames without a call send zeros */
 void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2);
 

@@ -16,6 +16,7 @@ def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=
     out = []
     with H.Engine(conf, sr, device=0, max_frames=batch, pixel_rate=pixel_rate) as e:
         e.frame_upload(0, frame, interlaced)
+        e.frame_aspect(0, 12, 13)        # the test source: 4:3 on 832 x 576 (src/av_test.c:50)
         if passthru is not None:
             e.passthru_write(passthru)
         done = 0
@@ -53,7 +54,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pal_fm_pass",
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
-                                  "g_a2", "m_a2"])
+                                  "g_a2", "m_a2", "i_wss_auto"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -325,3 +326,25 @@ def test_caption_pairs_and_moving_acp_level(golden):
         got = e.fetch(0, n * e.info["frame_samples"])
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // W, bad[0] % W)
+
+
+def test_wss_auto_follows_the_frames_pixel_aspect(golden):
+    """--wss auto with a 4:3 frame, an anamorphic 16:9 one and the threshold itself, per frame slot, against the oracle."""
+    conf, sr = golden.conf("i_wss_auto")
+    L = golden.cases["i_wss_auto"]["lines"]
+    pars = [(12, 13), (16, 11), (14 * 576, 9 * 832), (14 * 576 + 1, 9 * 832)]
+    with oracle.Oracle(conf, sr) as o:
+        o.set_frame(golden.frame("i_wss_auto"))
+        want = []
+        for n, d in pars:
+            o.set_frame_aspect(n, d)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=len(pars)) as e:
+        for slot, (n, d) in enumerate(pars):
+            e.frame_upload(slot, golden.frame("i_wss_auto"))
+            e.frame_aspect(slot, n, d)
+        e.render(len(pars), slots=list(range(len(pars))))
+        got = e.fetch(0, len(pars) * e.info["frame_samples"])
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got[:L * 1024], got[L * 1024:2 * L * 1024])     # 4:3 and 16:9 do differ

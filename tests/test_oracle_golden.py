@@ -15,7 +15,7 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 # --pixelrate: raster at the pixel rate + poly-phase resampler (the last one has lines of 870 / 871 samples)
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
-CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc"]
+CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
 CASES_A2 = ["g_a2", "m_a2"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"]
 
@@ -28,6 +28,7 @@ def test_oracle_stream_matches_reference_cli(golden, case):
     nframes = c["frames"] if c.get("extra", {}).get("passthru") else min(2, c["frames"])
     with oracle.Oracle(conf, sr, c.get("pixel_rate", 0)) as o:
         o.set_frame(golden.frame(case))
+        o.set_frame_aspect(12, 13)       # the test source: 4:3 on 832 x 576 (src/av_test.c:50)
         o.set_audio(golden.audio, True)
         if conf.passthru:
             o.set_passthru(util.passthru_signal())
