@@ -540,6 +540,10 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int j = t; j < W; j += nth) acc[j] = 0;
 			__syncthreads();
 
+			/* set bits are dealt round-robin to the workgroup's waves: a symbol is a run of a few
+			 * dozen samples, one wave's worth */
+			const int nwaves = nth >> 6, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+			int turn = 0;
 			for(int w = 0; w * 32 < nbits && w < 12; w++)
 			{
 				unsigned word = __builtin_amdgcn_readfirstlane(op[4 + w]);
@@ -548,9 +552,10 @@ void hvk_k_raster(const hvk_kconst_t k,
 				{
 					const int b = sym_base + w * 32 + __builtin_ctz(word);
 					word &= word - 1;
+					if(turn++ % nwaves != wave) continue;
 					const int off = vbi_sym[b * 3 + 0], len = vbi_sym[b * 3 + 1];
 					const int16_t *v = vbi_val + vbi_sym[b * 3 + 2];
-					for(int j = t; j < len; j += nth)
+					for(int j = lane; j < len; j += 64)
 					{
 						if(off + j >= 0 && off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
 					}
