@@ -156,7 +156,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	e->max_frames = max_frames;
 	/* one source frame slot per frame of a batch, so a batch can show a different
 	 * picture on every frame (a static source needs only slot 0) */
-	e->frame_slots = max_frames < HVK_MIN_FRAME_SLOTS ? HVK_MIN_FRAME_SLOTS : (max_frames > HVK_MAX_FRAME_SLOTS ? HVK_MAX_FRAME_SLOTS : max_frames);
+	{
+		/* --interlace shows a different source frame on each field */
+		const int want = max_frames * ((conf->interlace && conf->interlaced) ? 2 : 1);
+		e->frame_slots = want < HVK_MIN_FRAME_SLOTS ? HVK_MIN_FRAME_SLOTS : (want > HVK_MAX_FRAME_SLOTS ? HVK_MAX_FRAME_SLOTS : want);
+	}
 	e->slots = (hvk_slot_t *) calloc(e->frame_slots, sizeof(hvk_slot_t));
 	e->staged_slots = (int32_t *) calloc(max_frames, sizeof(int32_t));
 	if(!e->slots || !e->staged_slots) { free(e->slots); free(e->staged_slots); free(e); return(HVK_OUT_OF_MEMORY); }
@@ -263,7 +267,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots));
 	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots));
-	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames));
+	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 2));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.rs_L)
 	{
@@ -271,7 +275,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_rs_taps, e->t.rs_taps, sizeof(int16_t) * k.rs_L * k.rs_ataps));
 	}
 	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
-	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames, hipHostMallocDefault));
+	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames * 2, hipHostMallocDefault));
 	OPENHIP(hipHostMalloc((void **) &e->h_frame, frame_px * 4, hipHostMallocDefault));
 
 	if(e->t.k.has_carriers)
@@ -596,7 +600,8 @@ extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int wi
 	std::vector<uint32_t> dense((size_t) w * h + 1);
 	for(int r = 0; r < h; r++) memcpy(dense.data() + (size_t) r * w, fb + (size_t) (y + r) * width + x, (size_t) w * 4);
 
-	int r = hvk_secam_frame(e->secam, e->secam_next, fb ? dense.data() : NULL, w, h, interlaced, out);
+	int r = hvk_secam_frame(e->secam, e->secam_next, fb ? dense.data() : NULL, w, h, interlaced,
+	                        fb ? dense.data() : NULL, w, h, interlaced, out);
 	if(r == HVK_OK) e->secam_next++;
 	return(r);
 }
@@ -669,7 +674,7 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 		{
 			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where
 			 * VITS holds the line (src/acp.c:93-108); the AGC level moves with the frame number */
-			const int frame = (int) (e->h_fdesc[i].frame_index + 1);
+			const int frame = (int) (e->h_fdesc[(size_t) i * t.k.fields].frame_index + 1);
 			const int agc = hvk_acp_agc_level(&t, frame);
 			const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
 			const int count = lines == 625 ? 10 : 8;
@@ -699,7 +704,7 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 
 		if(t.conf.vitc)
 		{
-			const int frame = (int) (e->h_fdesc[i].frame_index + 1);
+			const int frame = (int) (e->h_fdesc[(size_t) i * t.k.fields].frame_index + 1);
 			const int vl[4] = { t.vitc_lines[0], t.vitc_lines[0] + 2, t.vitc_lines[1], t.vitc_lines[1] + 2 };
 			for(int q = 0; q < 4; q++)
 			{
@@ -807,34 +812,47 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		e->fm_done = 0;
 	}
 
+	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
+
 	for(int i = 0; i < nframes; i++)
 	{
-		hvk_framedesc_t *f = &e->h_fdesc[i];
-		const int slot = slots ? slots[i] : 0;
-		if(slot < 0 || slot >= e->frame_slots) return(HVK_ERROR);
+		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * fields];
+		const int slot = slots ? slots[(size_t) i * fields] : 0;
+		const int slot2 = (slots && fields == 2) ? slots[(size_t) i * fields + 1] : slot;
+		if(slot < 0 || slot >= e->frame_slots || slot2 < 0 || slot2 >= e->frame_slots) return(HVK_ERROR);
 		const hvk_slot_t *s = &e->slots[slot];
 		e->staged_slots[i] = slot;
 
-		memset(f, 0, sizeof(*f));
-		f->frame_index = first_frame + i * stride;
-		f->fb_offset = (int64_t) slot * frame_px;
-		f->fb_width = s->valid ? s->width : 0;
-		f->fb_height = s->valid ? s->height : 0;
-		f->pixel_stride = 1;
-		f->line_stride = s->width;
-		f->vframe_x = (k.active_width - f->fb_width) / 2;      /* src/video.c:4896-4897 */
-		f->vframe_y = (k.active_lines - f->fb_height) / 2;
-		f->fb_interlaced = s->interlaced;
-		f->fb_valid = s->valid;
-		f->parity = (int32_t) ((f->frame_index + 1) & 1);
-		f->clut_off0 = k.colour ? (uint32_t) (((uint64_t) f->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
+		for(int fld = 0; fld < fields; fld++)
+		{
+			hvk_framedesc_t *d = f + fld;
+			const int sl = fld ? slot2 : slot;
+			const hvk_slot_t *ss = &e->slots[sl];
+
+			memset(d, 0, sizeof(*d));
+			d->frame_index = first_frame + i * stride;
+			d->fb_offset = (int64_t) sl * frame_px;
+			d->fb_width = ss->valid ? ss->width : 0;
+			d->fb_height = ss->valid ? ss->height : 0;
+			d->pixel_stride = 1;
+			d->line_stride = ss->width;
+			d->vframe_x = (k.active_width - d->fb_width) / 2;      /* src/video.c:4896-4897 */
+			d->vframe_y = (k.active_lines - d->fb_height) / 2;
+			d->fb_interlaced = ss->interlaced;
+			d->fb_valid = ss->valid;
+			d->parity = (int32_t) ((d->frame_index + 1) & 1);
+			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
+		}
 
 		if(e->secam)
 		{
 			/* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
 			if(f->frame_index != e->secam_next) return(HVK_UNSUPPORTED);
+			const hvk_slot_t *s2 = &e->slots[slot2];
 			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
-			                        f->fb_width, f->fb_height, s->interlaced, e->h_chroma + (size_t) i * k.raster_samples);
+			                        f->fb_width, f->fb_height, s->interlaced,
+			                        s2->valid ? e->host_frames[slot2] : NULL, s2->valid ? s2->width : 0, s2->valid ? s2->height : 0, s2->interlaced,
+			                        e->h_chroma + (size_t) i * k.raster_samples);
 			if(r != HVK_OK) return(r);
 			e->secam_next++;
 		}
@@ -896,7 +914,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		}
 	}
 
-	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * fields, hipMemcpyHostToDevice, e->stream));
 	if(e->h_ops)
 	{
 		_build_vbi_ops(e, nframes);

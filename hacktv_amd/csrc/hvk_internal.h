@@ -60,6 +60,8 @@ typedef struct {
 	int32_t active_width;
 	int32_t active_lines;
 	int32_t interlaced;
+	int32_t fields;         /* frame descriptors per frame: 2 with --interlace (one source frame per field), else 1 */
+	int32_t hline;          /* first line (1-based) of the second field */
 	int32_t blanking;
 	int32_t colour;         /* PAL / NTSC sub-carrier present */
 	uint32_t clw;           /* colour lookup period in samples */
@@ -188,8 +190,9 @@ void hvk_cc608_bits(uint8_t c1, uint8_t c2, uint8_t data[3]);
 typedef struct hvk_secam hvk_secam_t;
 hvk_secam_t *hvk_secam_new(const hvk_tables_t *t);
 void hvk_secam_free(hvk_secam_t *s);
+/* fb2 .. : the frame the second field shows (--interlace); pass the first field's again otherwise */
 int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int fb_width, int fb_height,
-                    int fb_interlaced, int16_t *out);
+                    int fb_interlaced, const uint32_t *fb2, int fb2_width, int fb2_height, int fb2_interlaced, int16_t *out);
 
 /* The serial part of the output tail (hvk_tail.c): FM video phasor, offset phasor, passthru queue */
 typedef struct hvk_tail hvk_tail_t;

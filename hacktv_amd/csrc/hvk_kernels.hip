@@ -176,8 +176,9 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const int t = threadIdx.x;
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
-	const hvk_framedesc_t &f = fdesc[blockIdx.y];
 	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
+	/* one descriptor per frame, or per field with --interlace: the second field shows its own source frame */
+	const hvk_framedesc_t &f = fdesc[blockIdx.y * k.fields + ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 1 : 0)];
 	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
 
 	/* which line of which frame, without dividing the global line number */

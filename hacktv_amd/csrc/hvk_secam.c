@@ -228,14 +228,12 @@ static void _line(hvk_secam_t *s, int frame, int line, int picture, int right_ha
 /* Chroma contribution of one whole frame (frame_samples int16). fb is the
  * cropped, dense frame shown on it (NULL: none). Frames must be presented in
  * stream order. */
-int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int fb_width, int fb_height,
-                    int fb_interlaced, int16_t *out)
+int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, int fb1_width, int fb1_height,
+                    int fb1_interlaced, const uint32_t *fb2, int fb2_width, int fb2_height, int fb2_interlaced, int16_t *out)
 {
 	const hvk_tables_t *t = s->t;
 	const hvk_kconst_t *k = &t->k;
 	const int frame = (int) (frame_index + 1);
-	const int vframe_x = (k->active_width - fb_width) / 2;
-	const int vframe_y = (k->active_lines - fb_height) / 2;
 	int line;
 
 	if(frame_index != s->next_frame) return(HVK_ERROR);
@@ -255,6 +253,13 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int
 		const hvk_linedesc_t *d = &t->desc[(frame & 1) * k->lines + line - 1];
 		const int picture = d->ar > d->al;
 		const int right_half = picture && d->ar > k->half_width;
+		/* the frame the line's field shows */
+		const int second = k->fields == 2 && line >= k->hline;
+		const uint32_t *fb = second ? fb2 : fb1;
+		const int fb_width = second ? fb2_width : fb1_width, fb_height = second ? fb2_height : fb1_height;
+		const int fb_interlaced = second ? fb2_interlaced : fb1_interlaced;
+		const int vframe_x = (k->active_width - fb_width) / 2;
+		const int vframe_y = (k->active_lines - fb_height) / 2;
 		const uint32_t *row = NULL;
 		int vy = d->src_row;
 

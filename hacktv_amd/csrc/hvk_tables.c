@@ -1094,6 +1094,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->k.lines = c->lines;
 	t->k.active_lines = c->active_lines;
 	t->k.interlaced = c->interlaced;
+	t->k.fields = (c->interlace && c->interlaced != 0) ? 2 : 1;   /* src/video.c:4873: needs a second field to load for */
+	t->k.hline = c->hline;
 	t->k.frame_samples = t->k.width * t->k.lines;
 	t->k.raster_samples = t->k.frame_samples;
 	t->k.slab_lines = t->k.lines + 2;

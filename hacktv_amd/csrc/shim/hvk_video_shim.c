@@ -101,7 +101,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
-	if(c->interlace || c->frame_orientation) return(_refuse("--interlace / frame orientation"));
+	if(c->frame_orientation) return(_refuse("frame orientation"));
 	if(c->secam_field_id) return(_refuse("SECAM field id"));
 
 	h->output_type = c->output_type;
@@ -120,6 +120,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->lines = c->lines;
 	h->hline = c->hline;
 	h->interlaced = c->interlaced;
+	h->interlace = c->interlace;
 	h->active_lines = c->active_lines;
 	h->hsync_width = c->hsync_width;
 	h->vsync_short_width = c->vsync_short_width;
@@ -323,22 +324,36 @@ size_t vid_get_framebuffer_length(vid_t *s)
 /* Pull up to `batch` frames and the audio they need from the source, render them into iq */
 static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 {
-	int32_t slots[256];
+	int32_t slots[512];
+	const int fields = (s->conf.interlace && s->conf.interlaced) ? 2 : 1;
 	int n = 0;
 
 	m->frame_in_batch_pull = 0;
 
 	while(n < m->batch && n < 256)
 	{
-		av_frame_t f;
+		av_frame_t f, f2;
+		const int slot = n * fields;
 
-		/* src/video.c:4873-4897: end of source is tested at the start of each frame */
+		/* src/video.c:4873-4897: end of source is tested at the start of each frame -- and, with
+		 * --interlace, of each field, which shows a frame of its own. (A source that ends between the
+		 * two fields ends the stream with the frame before; the reference would still emit that
+		 * frame's first field.) */
 		if(av_eof(&s->av)) { m->ended = 1; break; }
 		av_read_video(&s->av, &f);
 
-		if(hvk_frame_upload(m->e, n, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
-		slots[n] = n;
-		if(s->conf.wss && hvk_frame_aspect(m->e, n, f.pixel_aspect_ratio.num, f.pixel_aspect_ratio.den) != HVK_OK) return(-1);
+		if(hvk_frame_upload(m->e, slot, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
+		slots[slot] = slot;
+
+		if(fields == 2)
+		{
+			if(av_eof(&s->av)) { m->ended = 1; break; }
+			av_read_video(&s->av, &f2);
+			if(hvk_frame_upload(m->e, slot + 1, f2.framebuffer, f2.width, f2.height, f2.pixel_stride, f2.line_stride, f2.interlaced) != HVK_OK) return(-1);
+			slots[slot + 1] = slot + 1;
+		}
+
+		if(s->conf.wss && hvk_frame_aspect(m->e, slot, f.pixel_aspect_ratio.num, f.pixel_aspect_ratio.den) != HVK_OK) return(-1);
 		if(s->conf.cc608 && hvk_cc608_write(m->e, n, f.cc608[0], f.cc608[1]) != HVK_OK) return(-1);
 
 		if(s->conf.teletext)

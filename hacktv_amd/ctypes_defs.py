@@ -26,6 +26,7 @@ class HvkConfig(C.Structure):
         ("lines", C.c_int),
         ("hline", C.c_int),
         ("interlaced", C.c_int),
+        ("interlace", C.c_int),
         ("active_lines", C.c_int),
         ("hsync_width", C.c_double),
         ("vsync_short_width", C.c_double),

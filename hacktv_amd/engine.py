@@ -215,11 +215,11 @@ class Engine:
         return out
 
     def render(self, nframes, slots=None, d_iq=None):
-        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)
+        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)
         return self._chk("hvk_render", lib().hvk_render(self.h, nframes, s.ctypes.data, d_iq))
 
     def stage(self, first_frame, stride, nframes, slots=None):
-        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes), np.int32)
+        s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)
         return self._chk("hvk_stage_strided", lib().hvk_stage_strided(self.h, first_frame, stride, nframes, s.ctypes.data))
 
     def launch(self, d_iq=None, out_stride=1):

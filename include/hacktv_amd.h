@@ -178,7 +178,10 @@ size_t hvk_audio_needed(const hvk_engine_t *e, int nframes);
 int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsamples);
 
 /* Render the next nframes frames of the stream. slots[i] names the frame
- * slot shown by frame i. d_iq, if not NULL, is a DEVICE pointer to
+ * slot shown by frame i -- with conf.interlace slots[2 i] and slots[2 i + 1]
+ * name the slots the first and the second field of frame i show (the
+ * reference takes a new source frame at the start of each field,
+ * src/video.c:4873). d_iq, if not NULL, is a DEVICE pointer to
  * nframes * frame_samples * 2 int16 that receives the samples; if NULL the
  * engine's own output buffer is used (read it back with hvk_fetch()).
  * Missing audio is rendered as silence (src/video.c:3299-3304). */

@@ -73,6 +73,8 @@ typedef struct hvk_config_t {
 	int lines;
 	int hline;                  /* 0 = derive, src/video.c:3832 */
 	int interlaced;             /* 0 none, 1 TFF, 2 BFF */
+	int interlace;              /* --interlace (src/video.c:4873): a new source frame is taken at the start of EACH
+	                             * field; render calls then name two frame slots per frame (first field, second field) */
 	int active_lines;
 
 	double hsync_width;         /* seconds */

@@ -122,6 +122,8 @@ struct orc_t {
 	const uint32_t *fb;
 	int fb_width, fb_height, fb_pixel_stride, fb_line_stride, fb_interlaced;
 	long long fb_par_num, fb_par_den;   /* pixel aspect of the source frame, 0: 1:1 */
+	/* --interlace: the frame shown by each field; the fields above are set from these per line */
+	struct { const uint32_t *fb; int width, height, pixel_stride, line_stride, interlaced; } field_fb[2];
 
 	/* raster stream window: lines [s_first, s_first + s_count) */
 	int16_t *S;
@@ -195,6 +197,9 @@ void orc_raster_line(orc_t *s, long g);
 int16_t *orc_line_ptr(orc_t *s, long g);
 
 void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, int *vy);
+
+/* the source frame in force on a line: with --interlace the second field has its own (src/video.c:4873) */
+void orc_select_frame(orc_t *s, int line);
 
 /* oracle_secam.c */
 int orc_secam_init(orc_t *s);

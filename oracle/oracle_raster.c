@@ -132,8 +132,11 @@ void orc_raster_line(orc_t *s, long g)
 	int W = s->width;
 	int vy, pal = 0, x;
 	const c16_t *lut = NULL;
-	int vframe_x = (s->active_width - s->fb_width) / 2;
-	int vframe_y = (c->active_lines - s->fb_height) / 2;
+	int vframe_x, vframe_y;
+
+	orc_select_frame(s, line);
+	vframe_x = (s->active_width - s->fb_width) / 2;
+	vframe_y = (c->active_lines - s->fb_height) / 2;
 
 	/* Building a line first blanks the one after it (src/video.c:2935-2939);
 	 * the very first line was blanked at start-up (:4659-4663) */
@@ -236,11 +239,13 @@ void orc_raster_line(orc_t *s, long g)
 void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, int *vy)
 {
 	const hvk_config_t *c = &s->conf;
-	int vframe_y = (c->active_lines - s->fb_height) / 2;
+	int vframe_y;
 	_linecode_t code;
 
 	*frame = g / c->lines + 1;
 	*line = g % c->lines + 1;
+	orc_select_frame(s, *line);
+	vframe_y = (c->active_lines - s->fb_height) / 2;
 	code = _line_code(c->type, *line);
 	*la = code.la;
 	*ra = code.ra;

@@ -187,7 +187,12 @@ void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int
 	int16_t *cb = s->chroma;
 	int sl = 0, sr = 0;
 	int dr = ((frame * c->lines) + line) & 1;
-	int vframe_x = (s->active_width - s->fb_width) / 2;
+	int vframe_x;
+
+	/* (the reference's process looks at the frame the RASTER is on, two lines ahead; the lines
+	 * around a field change show no picture, so the line's own field is the same thing) */
+	if(line >= 1) orc_select_frame(s, line);
+	vframe_x = (s->active_width - s->fb_width) / 2;
 
 	if(line == 1 || line == c->hline) memset(cb, 0, sizeof(int16_t) * 2 * W);
 

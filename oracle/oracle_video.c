@@ -56,6 +56,8 @@ orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsign
 	s->fb = NULL;
 	s->fb_width = s->active_width;
 	s->fb_height = s->conf.active_lines;
+	s->field_fb[0].width = s->field_fb[1].width = s->active_width;
+	s->field_fb[0].height = s->field_fb[1].height = s->conf.active_lines;
 
 	return(s);
 }
@@ -192,6 +194,38 @@ void orc_set_frame(orc_t *s, const uint32_t *fb, int width, int height, int pixe
 	s->fb_pixel_stride = pixel_stride;
 	s->fb_line_stride = line_stride;
 	s->fb_interlaced = interlaced;
+
+	/* both fields show it until orc_set_frame2() says otherwise */
+	s->field_fb[0].fb = s->fb; s->field_fb[0].width = w; s->field_fb[0].height = h;
+	s->field_fb[0].pixel_stride = pixel_stride; s->field_fb[0].line_stride = line_stride; s->field_fb[0].interlaced = interlaced;
+	s->field_fb[1] = s->field_fb[0];
+}
+
+void orc_set_frame2(orc_t *s, const uint32_t *fb, int width, int height, int pixel_stride, int line_stride, int interlaced)
+{
+	int x = (width - s->active_width) / 2;
+	int y = (height - s->conf.active_lines) / 2;
+	int w = s->active_width, h = s->conf.active_lines;
+
+	if(x < 0) { w += x; x = 0; }
+	if(y < 0) { h += y; y = 0; }
+	if(x + w > width) w = width - x;
+	if(y + h > height) h = height - y;
+
+	s->field_fb[1].fb = fb ? fb + y * line_stride + x * pixel_stride : NULL;
+	s->field_fb[1].width = w; s->field_fb[1].height = h;
+	s->field_fb[1].pixel_stride = pixel_stride; s->field_fb[1].line_stride = line_stride; s->field_fb[1].interlaced = interlaced;
+}
+
+void orc_select_frame(orc_t *s, int line)
+{
+	const int f = (s->conf.interlace && s->conf.hline > 0 && line >= s->conf.hline) ? 1 : 0;
+	s->fb = s->field_fb[f].fb;
+	s->fb_width = s->field_fb[f].width;
+	s->fb_height = s->field_fb[f].height;
+	s->fb_pixel_stride = s->field_fb[f].pixel_stride;
+	s->fb_line_stride = s->field_fb[f].line_stride;
+	s->fb_interlaced = s->field_fb[f].interlaced;
 }
 
 void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop)

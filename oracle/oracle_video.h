@@ -31,6 +31,10 @@ void orc_set_ghost(orc_t *s, const int16_t *ghost, int n);
 /* Current source frame (kept by reference, like av_read_video's contract) */
 void orc_set_frame(orc_t *s, const uint32_t *fb, int width, int height, int pixel_stride, int line_stride, int interlaced);
 
+/* --interlace (conf.interlace): the frame the SECOND field of the frames rendered from now on shows
+ * (the reference pulls a new frame at line hline, src/video.c:4873). Call after orc_set_frame(). */
+void orc_set_frame2(orc_t *s, const uint32_t *fb, int width, int height, int pixel_stride, int line_stride, int interlaced);
+
 /* 32 kHz interleaved stereo source; loop != 0 repeats it forever (av_test) */
 void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop);
 

@@ -23,6 +23,8 @@ def lib():
         L.orc_set_ghost.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_set_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+        L.orc_set_frame2.restype = None
+        L.orc_set_frame2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_teletext_packets.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_uint32]
         L.orc_open_rates.restype = C.c_void_p
         L.orc_open_rates.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
@@ -104,6 +106,12 @@ class Oracle:
         self._keep.append(fb)
         h, w = fb.shape
         lib().orc_set_frame(self.p, fb.ctypes.data, w, h, 1, w, interlaced)
+
+    def set_frame2(self, fb, interlaced=0):
+        fb = np.ascontiguousarray(fb, np.uint32)
+        self._keep.append(fb)
+        h, w = fb.shape
+        lib().orc_set_frame2(self.p, fb.ctypes.data, w, h, 1, w, interlaced)
 
     def set_audio(self, stereo, loop=True):
         a = np.ascontiguousarray(stereo, np.int16)

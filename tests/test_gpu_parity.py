@@ -348,3 +348,44 @@ def test_wss_auto_follows_the_frames_pixel_aspect(golden):
         got = e.fetch(0, len(pars) * e.info["frame_samples"])
     assert np.array_equal(got, want)
     assert not np.array_equal(got[:L * 1024], got[L * 1024:2 * L * 1024])     # 4:3 and 16:9 do differ
+
+
+@pytest.mark.parametrize("mode", ["i", "l"])
+def test_interlace_shows_a_frame_per_field(golden, mode):
+    """--interlace: the second field shows its own source frame (slots[2 i], slots[2 i + 1]), PAL and SECAM
+    (whose colour pre-pass averages across the lines of one field), against the oracle. With the static
+    test card the reference's output does not change with --interlace (checked through the digest)."""
+    case = "i_full" if mode == "i" else "l_full"
+    conf, sr = golden.conf(case)
+    conf.interlace = 1
+    L = golden.cases[case]["lines"]
+    base = golden.frame(case)
+    rng = np.random.default_rng(11)
+    frames = [base, (rng.integers(0, 1 << 24, base.shape, dtype=np.uint32)), base[::-1].copy(), np.roll(base, 37, axis=1)]
+    n = 2
+    with oracle.Oracle(conf, sr) as o:
+        o.set_audio(golden.audio, True)
+        want = []
+        for i in range(n):
+            o.set_frame(frames[2 * i])
+            o.set_frame2(frames[2 * i + 1])
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=n) as e:
+        for slot, f in enumerate(frames):
+            e.frame_upload(slot, f)
+        while e.audio_needed(n) > 0:
+            e.audio_write(golden.audio)
+        e.render(n, slots=[0, 1, 2, 3])
+        got = e.fetch(0, n * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // 1024, bad[0] % 1024)
+
+    # same picture on both fields == no --interlace at all == the reference's digest
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        e.frame_upload(0, base)
+        while e.audio_needed(2) > 0:
+            e.audio_write(golden.audio)
+        e.render(2, slots=[0, 0, 0, 0])
+        same = e.fetch(0, 2 * e.info["frame_samples"])
+    assert util.sha256(util.stream_bytes(same, False)) == golden.cases[case]["sha256_cumulative"][1]
