@@ -25,6 +25,13 @@
 #define REF_FLAG_NOAUDIO  (1 << 1)
 #define REF_FLAG_NONICAM  (1 << 2)
 #define REF_FLAG_NOCOLOUR (1 << 3)
+#define REF_FLAG_INTERLACE (1 << 4)
+#define REF_FLAG_A2STEREO (1 << 5)
+#define REF_FLAG_CC608    (1 << 6)
+#define REF_FLAG_WSS_AUTO (1 << 7)
+#define REF_FLAG_ACP      (1 << 8)
+#define REF_FLAG_VITS     (1 << 9)
+#define REF_FLAG_VITC     (1 << 10)
 
 typedef struct {
 	vid_t vid;
@@ -68,6 +75,14 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 		conf.nicam_carrier = 0;
 	}
 	if(flags & REF_FLAG_FILTER) conf.vfilter = 1;
+	/* src/hacktv.c:1121-1124, :1174-1177, :1341-1397, :1401-1410 */
+	if(flags & REF_FLAG_INTERLACE) conf.interlace = 1;
+	if(flags & REF_FLAG_A2STEREO) conf.a2stereo = 1;
+	if(flags & REF_FLAG_CC608) conf.cc608 = 1;
+	if(flags & REF_FLAG_WSS_AUTO) conf.wss = "auto";
+	if(flags & REF_FLAG_ACP) conf.acp = 1;
+	if(flags & REF_FLAG_VITS) conf.vits = 1;
+	if(flags & REF_FLAG_VITC) conf.vitc = 1;
 	if(teletext && teletext[0]) conf.teletext = (char *) teletext;
 	conf.volume = 1.0 * 256 + 0.5;
 
@@ -102,6 +117,58 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 
 	p->open = 1;
 	return(p);
+}
+
+/* ---- a source of the caller's own: frames and audio handed to the reference through its
+ * av_* callbacks (src/av.h:57-75), so that it can be run on pictures and sound the built-in test
+ * source does not have (moving pictures, saturated colours, loud audio, caption pairs) ---- */
+typedef struct {
+	const uint32_t *frames;
+	int nframes, width, height, interlaced, pos;
+	const uint8_t *cc;          /* nframes x 2 caption bytes or NULL */
+	int par_num, par_den;
+	const int16_t *audio;
+	long nsamples, apos;
+} _src_t;
+
+static _src_t _src;
+
+static int _src_read_video(void *ctx, av_frame_t *frame)
+{
+	_src_t *c = ctx;
+	const int i = c->pos % c->nframes;
+	av_frame_init(frame, c->width, c->height, (uint32_t *) c->frames + (size_t) i * c->width * c->height, 1, c->width);
+	frame->interlaced = c->interlaced;
+	frame->pixel_aspect_ratio = (r64_t) { c->par_num, c->par_den };
+	if(c->cc) { frame->cc608[0] = c->cc[i * 2]; frame->cc608[1] = c->cc[i * 2 + 1]; }
+	c->pos++;
+	return(AV_OK);
+}
+
+static int _src_read_audio(void *ctx, int16_t **samples, size_t *nsamples)
+{
+	/* the whole loop at a time, like src/av_test.c:54-60 */
+	_src_t *c = ctx;
+	if(!c->audio || c->nsamples <= 0) return(AV_EOF);
+	*samples = (int16_t *) c->audio;
+	*nsamples = c->nsamples;
+	return(AV_OK);
+}
+
+static int _src_close(void *ctx) { return(AV_OK); }
+
+/* Replace the test source. frames: nframes x height x width RGBx, shown in turn (one per frame, one
+ * per field with --interlace); audio: nsamples stereo pairs at 32 kHz, looped. Call before the first line. */
+void ref_set_source(ref_probe_t *p, const uint32_t *frames, int nframes, int width, int height, int interlaced,
+                    int par_num, int par_den, const uint8_t *cc, const int16_t *audio, long nsamples)
+{
+	av_close(&p->vid.av);
+	_src = (_src_t) { .frames = frames, .nframes = nframes, .width = width, .height = height, .interlaced = interlaced,
+	                  .cc = cc, .par_num = par_num, .par_den = par_den, .audio = audio, .nsamples = nsamples };
+	p->vid.av.av_source_ctx = &_src;
+	p->vid.av.read_video = _src_read_video;
+	p->vid.av.read_audio = _src_read_audio;
+	p->vid.av.close = _src_close;
 }
 
 void ref_close(ref_probe_t *p)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""tests/ref_random_check.py SETUP -- TEST INFRASTRUCTURE.
+
+Runs the UNMODIFIED reference in-process (oracle/_ref/libhacktv_ref.so through oracle/ref_probe.c)
+on a source of our own -- random pictures that change every frame (every field with --interlace),
+saturated colours, full-scale noise and bursts as audio, caption pairs, an anamorphic pixel aspect --
+and the oracle on the same input. Prints "EQUAL" or the first difference. One setup per process:
+the reference's heap over-read is read out of this process's heap, which has to be
+the same at read-out and at render time. Used by tests/test_oracle_vs_ref.py.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hacktv_amd as H  # noqa: E402
+import oracle  # noqa: E402
+import refprobe as R  # noqa: E402
+
+SETUPS = {
+    # name: (mode, sample rate, probe flags, hvk flags, conf members, frames)
+    "i_loud":      ("i", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {}, 3),
+    "m_loud":      ("m", 13500000, R.FLAG_FILTER, H.FLAG_FILTER, {}, 3),
+    "l_moving":    ("l", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {}, 3),
+    "g_a2_loud":   ("g", 16000000, R.FLAG_FILTER | R.FLAG_A2STEREO, H.FLAG_FILTER, {"a2stereo": 1}, 3),
+    "i_interlace": ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_INTERLACE, H.FLAG_NOAUDIO, {"interlace": 1}, 3),
+    "l_interlace": ("l", 16000000, R.FLAG_NOAUDIO | R.FLAG_INTERLACE, H.FLAG_NOAUDIO, {"interlace": 1}, 3),
+    "m_vbi_cc":    ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_ACP | R.FLAG_VITS | R.FLAG_VITC, H.FLAG_NOAUDIO,
+                    {"cc608": 1, "acp": 1, "vits": 1, "vitc": 1}, 3),
+    "i_wss_auto":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_WSS_AUTO, H.FLAG_NOAUDIO, {"wss": 0xFF}, 2),
+}
+
+
+def main():
+    name = sys.argv[1]
+    mode, sr, pflags, hflags, members, nframes = SETUPS[name]
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
+    conf = H.preset(mode, hflags)
+    for k, v in members.items():
+        setattr(conf, k, v)
+
+    with R.RefProbe(mode, sr, pflags) as r:
+        info = dict(r.info)
+        w, h, L = info["active_width"], info["active_lines"], info["lines"]
+        fields = 2 if members.get("interlace") else 1
+        nsrc = nframes * fields + 2
+        frames = rng.integers(0, 1 << 24, (nsrc, h, w), dtype=np.uint32)
+        frames[1, : h // 2] = 0xFFFFFF                       # white / saturated primaries: the level clamps
+        frames[1, h // 2:, : w // 3] = 0xFF0000
+        frames[1, h // 2:, w // 3: 2 * w // 3] = 0x00FF00
+        frames[1, h // 2:, 2 * w // 3:] = 0x0000FF
+        frames[2] = (np.arange(w, dtype=np.uint32) * 0x010101 % 0xFFFFFF)[None, :]
+        audio = rng.integers(-32768, 32768, (4096 + 37, 2), dtype=np.int64).astype(np.int16)
+        audio[1000:1400] = 32767                              # a clipped burst into the limiter
+        audio[2000:2300, 0] = -32768
+        cc = rng.integers(0, 256, (nsrc, 2), dtype=np.int64).astype(np.uint8)
+        cc[1] = 0
+        par = (16, 11) if name == "i_wss_auto" else (1, 1)
+        r.set_source(frames, audio, par=par, cc=cc)
+        ghost = r.table("chroma_ghost", np.int16)
+        ref = r.render_lines(nframes * L)
+        ghost_after = r.table("chroma_ghost", np.int16)
+
+    with oracle.Oracle(conf, sr) as o:
+        o.set_ghost(ghost)
+        o.set_audio(audio, True)
+        out = []
+        for f in range(nframes):
+            o.set_frame(frames[f * fields])
+            if fields == 2:
+                o.set_frame2(frames[f * fields + 1])
+            o.set_frame_aspect(*par)
+            c = cc[f * fields]
+            if (int(c[0]) | int(c[1])) & 0x7F:
+                o.set_cc608(f, int(c[0]), int(c[1]))
+            out.append(o.render_lines(L))
+        mine = np.concatenate(out)
+
+    if conf.colour_mode != 3 and not np.array_equal(ghost, ghost_after):    # SECAM has no over-read chroma filter
+        print("MOVED")
+        return
+    if np.array_equal(ref, mine):
+        print("EQUAL")
+        return
+    W = info["width"]
+    d = np.nonzero((ref != mine).any(axis=1))[0]
+    print("DIFFERENT %d samples, first at line %d x %d: ref %s oracle %s" % (len(d), d[0] // W, d[0] % W, ref[d[0]].tolist(), mine[d[0]].tolist()))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(ROOT, "oracle", "_ref", "libhacktv_ref.so")
 BIN_PATH = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
 
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
+FLAG_INTERLACE, FLAG_A2STEREO, FLAG_CC608, FLAG_WSS_AUTO, FLAG_ACP, FLAG_VITS, FLAG_VITC = 16, 32, 64, 128, 256, 512, 1024
 
 INFO_NAMES = [
     "width", "half_width", "active_width", "active_left", "lines", "active_lines",
@@ -39,6 +40,9 @@ def lib():
         L.ref_open.restype = ctypes.c_void_p
         L.ref_open.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_char_p]
         L.ref_close.argtypes = [ctypes.c_void_p]
+        L.ref_set_source.restype = None
+        L.ref_set_source.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         L.ref_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.ref_render_lines.restype = ctypes.c_long
         L.ref_render_lines.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
@@ -61,6 +65,15 @@ class RefProbe:
         v = np.zeros(64, np.int32)
         n = lib().ref_info(self.p, v.ctypes.data, 64)
         self.info = dict(zip(INFO_NAMES, v[:n].tolist()))
+
+    def set_source(self, frames, audio, interlaced=0, par=(1, 1), cc=None):
+        """Replace the test source: frames [n][h][w] RGBx shown in turn, audio [m][2] looped."""
+        f = np.ascontiguousarray(frames, np.uint32)
+        a = np.ascontiguousarray(audio, np.int16)
+        c = np.ascontiguousarray(cc, np.uint8) if cc is not None else None
+        self._keep = (f, a, c)
+        lib().ref_set_source(self.p, f.ctypes.data, f.shape[0], f.shape[2], f.shape[1], interlaced, par[0], par[1],
+                             c.ctypes.data if c is not None else None, a.ctypes.data, a.shape[0])
 
     def table(self, name, dtype):
         n = lib().ref_table(self.p, name.encode(), None, 0)

@@ -389,3 +389,40 @@ def test_interlace_shows_a_frame_per_field(golden, mode):
         e.render(2, slots=[0, 0, 0, 0])
         same = e.fetch(0, 2 * e.info["frame_samples"])
     assert util.sha256(util.stream_bytes(same, False)) == golden.cases[case]["sha256_cumulative"][1]
+
+
+@pytest.mark.parametrize("case,members", [("i_full", {}), ("m_full", {}), ("g_full", {"a2stereo": 1}), ("l_full", {})])
+def test_random_pictures_and_loud_audio(golden, case, members):
+    """Random pictures that change every frame, saturated colours, full-scale noise and clipped bursts as
+    audio (limiter, NICAM companding, the A2 pilot): the same kind of input tests/ref_random_check.py pins
+    the oracle with against the real reference; here the device path against the oracle."""
+    conf, sr = golden.conf(case)
+    for k, v in members.items():
+        setattr(conf, k, v)
+    c = golden.cases[case]
+    L, n = c["lines"], 3
+    base = golden.frame(case)
+    rng = np.random.default_rng(len(case) + 7 * len(members))
+    frames = rng.integers(0, 1 << 24, (n,) + base.shape, dtype=np.uint32)
+    frames[1, : base.shape[0] // 2] = 0xFFFFFF
+    frames[1, base.shape[0] // 2:, : base.shape[1] // 2] = 0xFF0000
+    frames[1, base.shape[0] // 2:, base.shape[1] // 2:] = 0x0000FF
+    audio = rng.integers(-32768, 32768, (4096 + 37, 2), dtype=np.int64).astype(np.int16)
+    audio[1000:1400] = 32767
+    audio[2000:2300, 0] = -32768
+    with oracle.Oracle(conf, sr) as o:
+        o.set_audio(audio, True)
+        want = []
+        for f in range(n):
+            o.set_frame(frames[f])
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=n) as e:
+        for f in range(n):
+            e.frame_upload(f, frames[f])
+        while e.audio_needed(n) > 0:
+            e.audio_write(audio)
+        e.render(n, slots=list(range(n)))
+        got = e.fetch(0, n * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // c["width"], bad[0] % c["width"])
