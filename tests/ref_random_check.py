@@ -31,6 +31,8 @@ SETUPS = {
     "m_vbi_cc":    ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_ACP | R.FLAG_VITS | R.FLAG_VITC, H.FLAG_NOAUDIO,
                     {"cc608": 1, "acp": 1, "vits": 1, "vitc": 1}, 3),
     "i_wss_auto":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_WSS_AUTO, H.FLAG_NOAUDIO, {"wss": 0xFF}, 2),
+    # 44 frames: the anti-copy AGC level starts to move at frame 39; time code minutes stay 0 but seconds tick
+    "i_acp_long":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_VITC, H.FLAG_NOAUDIO, {"acp": 1, "vitc": 1}, 44),
 }
 
 
@@ -46,7 +48,7 @@ def main():
         info = dict(r.info)
         w, h, L = info["active_width"], info["active_lines"], info["lines"]
         fields = 2 if members.get("interlace") else 1
-        nsrc = nframes * fields + 2
+        nsrc = min(nframes * fields + 2, 5)                  # shown in turn, over and over
         frames = rng.integers(0, 1 << 24, (nsrc, h, w), dtype=np.uint32)
         frames[1, : h // 2] = 0xFFFFFF                       # white / saturated primaries: the level clamps
         frames[1, h // 2:, : w // 3] = 0xFF0000
@@ -69,11 +71,11 @@ def main():
         o.set_audio(audio, True)
         out = []
         for f in range(nframes):
-            o.set_frame(frames[f * fields])
+            o.set_frame(frames[(f * fields) % nsrc])
             if fields == 2:
-                o.set_frame2(frames[f * fields + 1])
+                o.set_frame2(frames[(f * fields + 1) % nsrc])
             o.set_frame_aspect(*par)
-            c = cc[f * fields]
+            c = cc[(f * fields) % nsrc]
             if (int(c[0]) | int(c[1])) & 0x7F:
                 o.set_cc608(f, int(c[0]), int(c[1]))
             out.append(o.render_lines(L))
