@@ -77,6 +77,7 @@ struct hvk_engine {
 	uint32_t *d_pool;
 	hvk_framedesc_t *d_fdesc;
 	int16_t *d_S;
+	int16_t *d_C;           /* --s-video: the sub-carrier slab */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
 	int16_t *d_car;
 	int32_t *d_sym;
@@ -269,6 +270,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots));
 	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 2));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
+	if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.rs_L)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
@@ -363,7 +365,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -986,6 +988,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.pool = e->d_pool;
 	ra.fdesc = e->d_fdesc;
 	ra.S = e->d_S;
+	ra.C = e->d_C;
 	ra.nframes = e->staged;
 	ra.first_frame = e->staged_first;
 	ra.frame_stride = e->staged_stride;
@@ -997,6 +1000,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.qtaps = e->qtaps;
 	fa.fdesc = e->d_fdesc;
 	fa.S = e->t.k.rs_L ? e->d_S2 : e->d_S;
+	fa.C = e->d_C;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
 	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;

@@ -36,6 +36,7 @@ typedef struct {
 	const uint32_t *pool;
 	const hvk_framedesc_t *fdesc;
 	int16_t *S;                 /* [nframes][lines + 2][width] */
+	int16_t *C;                 /* --s-video: the sub-carrier, same geometry */
 	int nframes;
 	int64_t first_frame, frame_stride;
 } hvk_raster_args_t;
@@ -45,6 +46,7 @@ typedef struct {
 	hvk_packed_taps_t itaps, qtaps;
 	const hvk_framedesc_t *fdesc;
 	const int16_t *S;
+	const int16_t *C;           /* --s-video: the Q channel, laid out like S */
 	const hvk_c16_t *carriers;
 	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
 	const int *nicam_tapd;      /* HVK_NICAM_TAPD dwords: (tap, tap), zero padded */

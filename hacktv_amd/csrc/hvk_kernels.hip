@@ -139,7 +139,7 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
  *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
  *   V  [CL]  a lane's FIR window starts at its own first sample index
  * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
-template<int NT, int SECAM>
+template<int NT, int SECAM, int SV>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
@@ -160,6 +160,7 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const uint32_t *__restrict__ pool,
                   const hvk_framedesc_t *__restrict__ fdesc,
                   int16_t *__restrict__ S,
+                  int16_t *__restrict__ Cq,             /* --s-video: the sub-carrier alone, same slab geometry as S */
                   const int64_t first_frame,            /* frame y of the batch is stream frame first_frame + y * frame_stride */
                   const int64_t frame_stride)
 {
@@ -306,8 +307,9 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const int wx0 = __builtin_amdgcn_readfirstlane(x0);
 	const int wx1 = wx0 + 64 * SPL;
 	int s[SPL];
+	int cq[SPL];                                /* S-Video: the line's Q channel */
 #pragma unroll
-	for(int i = 0; i < SPL; i++) s[i] = k.blanking;
+	for(int i = 0; i < SPL; i++) { s[i] = k.blanking; cq[i] = 0; }
 
 	/* sync pulses: this line's own, and the part of the next line's left
 	 * pulse that starts before its sample 0 (src/vbidata.c:211-216) */
@@ -414,8 +416,17 @@ void hvk_k_raster(const hvk_kconst_t k,
 #pragma unroll
 			for(int i = 0; i < SPL; i++) c[i] = (c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF);
 		}
+		if(SV)
+		{
+			/* S-Video: onto the (empty) Q channel instead of the luma (src/video.c:3032) */
 #pragma unroll
-		for(int i = 0; i < SPL; i++) s[i] = wrap16(s[i] + (dot2(c[i], vu[i], 0) >> 15));
+			for(int i = 0; i < SPL; i++) cq[i] = wrap16(dot2(c[i], vu[i], 0) >> 15);
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) s[i] = wrap16(s[i] + (dot2(c[i], vu[i], 0) >> 15));
+		}
 	}
 
 	if(SECAM && active)
@@ -428,6 +439,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 		constexpr int NH = 25, NLEAD = 26;
 		int16_t *Z = lds + YL;                  /* index j <-> sample x = j - NLEAD */
 
+		if(!SV)                          /* S-Video leaves the luma alone (src/video.c:3206) */
+		{
 		if(t < 4) *(int4v *) (Z + t * 8) = (int4v) { 0, 0, 0, 0 };   /* Z does not overlap the picture's luma in LDS */
 		{
 			int4v z;
@@ -463,6 +476,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 				if(x >= k.active_left && x < k.active_left + k.active_width) s[i] = clamp16(a[i] >> 15);
 			}
 		}
+		}
 
 		if(own && x0 + SPL <= W)
 		{
@@ -472,7 +486,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int i = 0; i < SPL; i++)
 			{
 				const int cs = (i & 1) ? (cw[i / 2] >> 16) : (int) (short) (cw[i / 2] & 0xFFFF);
-				s[i] = wrap16(s[i] + cs);
+				if(SV) cq[i] = cs;
+				else s[i] = wrap16(s[i] + cs);
 			}
 		}
 	}
@@ -586,6 +601,12 @@ void hvk_k_raster(const hvk_kconst_t k,
 	{
 		for(int i = 0; i < SPL; i++) if(x0 + i < W) out[x0 + i] = (int16_t) s[i];
 	}
+
+	if(SV)
+	{
+		int16_t *oc = Cq + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
+		for(int i = 0; i < SPL; i++) if(x0 + i < W) oc[x0 + i] = (int16_t) cq[i];
+	}
 }
 
 /* ------------------------------------------------------------------ */
@@ -600,7 +621,7 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 }
 
 
-template<int NT, int VF>
+template<int NT, int VF, int SV>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL)
 void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_packed_taps_t itaps,
@@ -612,6 +633,7 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int *__restrict__ nicam_tapd,    /* pulse taps, each duplicated into both halves of a dword, zero padded */
                   const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
                   const int *__restrict__ nicam_ccb,     /* mixer (q,  i) */
+                  const int16_t *__restrict__ Cq,        /* --s-video: the Q channel, laid out like S */
                   int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
                   const int64_t out_stride,
                   const int tiles)                       /* 1024-sample tiles per frame */
@@ -752,6 +774,15 @@ void hvk_k_filter(const hvk_kconst_t k,
 		const int16_t *p = slab + n;
 #pragma unroll
 		for(int i = 0; i < SPL; i++) o[i] = (n + i < FS) ? ((int) p[i] & 0xFFFF) : 0;
+	}
+
+	if(SV)
+	{
+		/* S-Video: Q is the sub-carrier of the same sample position (the filter only delays the luma
+		 * by the line its output slot is shifted by, src/video.c:3235-3248) */
+		const int16_t *cp = Cq + (size_t) blockIdx.y * k.s_stride + k.s_lead + n;
+#pragma unroll
+		for(int i = 0; i < SPL; i++) if(n + i < FS) o[i] = (o[i] & 0xFFFF) | ((int) cp[i] << 16);
 	}
 
 	const size_t cbase = (size_t) blockIdx.y * FS + n;
@@ -1110,50 +1141,71 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-template<int NT, int SECAM>
+template<int NT, int SECAM, int SV>
 static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
-	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->first_frame, a->frame_stride);
+	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->C, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 {
-	if(a->k.secam) return(_launch_raster<1, 1>(a, stream));
+	/* S-Video (baseband modes only) has kernels of its own: the benchmark path carries none of it */
+	if(a->k.s_video)
+	{
+		if(a->k.secam) return(_launch_raster<1, 1, 1>(a, stream));
+		switch(a->k.colour ? a->k.chroma_ntaps : 1)
+		{
+		case 9:  return(_launch_raster<9, 0, 1>(a, stream));
+		case 11: return(_launch_raster<11, 0, 1>(a, stream));
+		case 13: return(_launch_raster<13, 0, 1>(a, stream));
+		case 15: return(_launch_raster<15, 0, 1>(a, stream));
+		case 17: return(_launch_raster<17, 0, 1>(a, stream));
+		case 21: return(_launch_raster<21, 0, 1>(a, stream));
+		}
+		return(HVK_UNSUPPORTED);
+	}
+	if(a->k.secam) return(_launch_raster<1, 1, 0>(a, stream));
 	switch(a->k.colour ? a->k.chroma_ntaps : 1)
 	{
-	case 1:  return(_launch_raster<1, 0>(a, stream));   /* monochrome */
-	case 9:  return(_launch_raster<9, 0>(a, stream));
-	case 11: return(_launch_raster<11, 0>(a, stream));
-	case 13: return(_launch_raster<13, 0>(a, stream));
-	case 15: return(_launch_raster<15, 0>(a, stream));
-	case 17: return(_launch_raster<17, 0>(a, stream));
-	case 21: return(_launch_raster<21, 0>(a, stream));
+	case 1:  return(_launch_raster<1, 0, 0>(a, stream));   /* monochrome */
+	case 9:  return(_launch_raster<9, 0, 0>(a, stream));
+	case 11: return(_launch_raster<11, 0, 0>(a, stream));
+	case 13: return(_launch_raster<13, 0, 0>(a, stream));
+	case 15: return(_launch_raster<15, 0, 0>(a, stream));
+	case 17: return(_launch_raster<17, 0, 0>(a, stream));
+	case 21: return(_launch_raster<21, 0, 0>(a, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }
 
-template<int NT, int VF>
+template<int NT, int VF, int SV>
 static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-	hipLaunchKernelGGL((hvk_k_filter<NT, VF>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
+	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
 	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
-	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, (int *) a->iq, a->out_stride, tiles);
+	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, a->C, (int *) a->iq, a->out_stride, tiles);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 {
-	if(a->k.vf_type == 0) return(_launch_filter<1, 0>(a, stream));
+	if(a->k.s_video)
+	{
+		if(a->k.vf_type == 0) return(_launch_filter<1, 0, 1>(a, stream));
+		if(a->k.vf_type == 1 && a->k.vf_ntaps == 51) return(_launch_filter<51, 1, 1>(a, stream));
+		return(HVK_UNSUPPORTED);
+	}
+	if(a->k.vf_type == 0) return(_launch_filter<1, 0, 0>(a, stream));
 	if(a->k.vf_ntaps != 51) return(HVK_UNSUPPORTED);
-	if(a->k.vf_type == 1) return(_launch_filter<51, 1>(a, stream));
-	if(a->k.vf_type == 3) return(_launch_filter<51, 3>(a, stream));
+	if(a->k.vf_type == 1) return(_launch_filter<51, 1, 0>(a, stream));
+	if(a->k.vf_type == 3) return(_launch_filter<51, 3, 0>(a, stream));
 	return(HVK_UNSUPPORTED);
 }

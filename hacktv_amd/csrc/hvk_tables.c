@@ -1401,6 +1401,13 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		t->k.fm_video = 1;
 	}
 
+	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); the resampler's second channel is not built */
+	if(c->s_video)
+	{
+		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME || t->k.rs_L) return(HVK_UNSUPPORTED);
+		t->k.s_video = 1;
+	}
+
 	/* complex tail (src/video.c:4587-4645) */
 	t->k.swap_iq = c->swap_iq != 0;
 	t->k.has_offset = c->offset != 0;

@@ -100,7 +100,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
-	if(c->raw_bb_file || c->s_video) return(_refuse("raw baseband / s-video"));
+	if(c->raw_bb_file) return(_refuse("raw baseband input"));
+	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
 	if(c->frame_orientation) return(_refuse("frame orientation"));
 	if(c->secam_field_id) return(_refuse("SECAM field id"));
 
@@ -156,6 +157,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->am_mono_carrier = c->am_mono_carrier;
 	h->a2stereo = c->a2stereo;
 	h->vfilter = c->vfilter;
+	h->s_video = c->s_video;
 	h->teletext = c->teletext != NULL;
 	h->vits = c->vits;
 	h->vitc = c->vitc;

@@ -63,6 +63,7 @@ class HvkConfig(C.Structure):
         ("am_mono_carrier", C.c_double),
         ("a2stereo", C.c_int),
         ("vfilter", C.c_int),
+        ("s_video", C.c_int),
         ("teletext", C.c_int),
         ("wss", C.c_int),
         ("vits", C.c_int),

@@ -126,6 +126,9 @@ typedef struct hvk_config_t {
 
 	int vfilter;                /* --filter, src/hacktv.c:1412 */
 
+	int s_video;                /* --s-video (baseband PAL / NTSC / SECAM only, src/hacktv.c:1136-1148): the colour
+	                             * sub-carrier goes to the Q channel instead of onto the luma (src/video.c:3032, :3219) */
+
 	int teletext;               /* != 0: teletext packets will be supplied for the VBI lines
 	                             * (625-line modes; the reference's conf.teletext names the page
 	                             * source, which stays with the caller: hvk_teletext_packets()) */

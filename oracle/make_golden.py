@@ -76,6 +76,10 @@ CASES = [
     ("m_vbi",         "m",    13500000, ["--filter", "--vitc", "--vits"], refprobe.FLAG_FILTER,             False, 3, {"vitc": 1, "vits": 1}),
     ("l_vbi",         "l",    16000000, ["--filter", "--wss", "14:9-window", "--vitc", "--vits"], refprobe.FLAG_FILTER, False, 2, {"wss": 0x0E, "vitc": 1, "vits": 1}),
     ("pal_vbi_px",    "pal",  16000000, ["--vits", "--vitc", "--wss", "16:9-top", "--pixelrate", "13500000"], 0, True, 2, {"wss": 0x04, "vitc": 1, "vits": 1}, 13500000),
+    # S-Video: luma on I, the colour sub-carrier on Q (the file sink then writes pairs)
+    ("pal_sv",        "pal",  16000000, ["--s-video"],               0,                                     False, 2, {"s_video": 1}),
+    ("ntsc_sv_f",     "ntsc", 13500000, ["--s-video", "--filter"],   refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
+    ("secam_sv",      "secam", 16000000, ["--s-video", "--filter"],  refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
     # --wss auto: the test source is 4:3 (pixel aspect 12:13 at 832 x 576)
     ("i_wss_auto",    "i",    16000000, ["--noaudio", "--wss", "auto"], refprobe.FLAG_NOAUDIO,             False, 2, {"wss": 0xFF}),
     # anti-copy pulses and the CEA-608 caption line (no captions from the test source: parity-only codes)

@@ -127,6 +127,7 @@ struct orc_t {
 
 	/* raster stream window: lines [s_first, s_first + s_count) */
 	int16_t *S;
+	int16_t *C;                 /* --s-video: the Q channel of the same lines (the colour sub-carrier) */
 	long s_first, s_count, s_cap;
 	long rastered;              /* number of lines rastered so far (next g) */
 	long emitted;               /* number of lines emitted so far */
@@ -195,6 +196,7 @@ double orc_rc_window(double t, double left, double width, double rise);
 /* oracle_raster.c */
 void orc_raster_line(orc_t *s, long g);
 int16_t *orc_line_ptr(orc_t *s, long g);
+int16_t *orc_cline_ptr(orc_t *s, long g);    /* the line's Q channel (--s-video) */
 
 void orc_line_info(orc_t *s, long g, int *frame, int *line, int *la, int *ra, int *vy);
 
@@ -204,7 +206,8 @@ void orc_select_frame(orc_t *s, int line);
 /* oracle_secam.c */
 int orc_secam_init(orc_t *s);
 void orc_secam_free(orc_t *s);
-void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int active_r, int vy);
+/* oq: the line's Q channel, where the sub-carrier goes with --s-video (may be NULL) */
+void orc_secam_line(orc_t *s, int16_t *o, int16_t *oq, int frame, int line, int active_l, int active_r, int vy);
 
 /* oracle_teletext.c */
 int orc_teletext_init(orc_t *s);

@@ -19,6 +19,12 @@ int16_t *orc_line_ptr(orc_t *s, long g)
 	return(s->S + (g - s->s_first) * s->width);
 }
 
+int16_t *orc_cline_ptr(orc_t *s, long g)
+{
+	if(!s->C || g < s->s_first || g >= s->s_first + s->s_count) return(NULL);
+	return(s->C + (g - s->s_first) * s->width);
+}
+
 /* Per-line content code. The reference keeps these as four-character strings
  * per line number (src/video.c:2447-2810); restated here as field-position
  * rules for the 625- and 525-line interlaced rasters.
@@ -142,8 +148,12 @@ void orc_raster_line(orc_t *s, long g)
 	 * the very first line was blanked at start-up (:4659-4663) */
 	{
 		int16_t *nl = orc_line_ptr(s, g + 1);
+		int16_t *cl = orc_cline_ptr(s, g), *ncl = orc_cline_ptr(s, g + 1);
 		if(g == 0) for(x = 0; x < W; x++) o[x] = s->blanking_level;
 		if(nl) for(x = 0; x < W; x++) nl[x] = s->blanking_level;
+		/* ... and its Q channel is cleared (src/video.c:2938) */
+		if(g == 0 && cl) memset(cl, 0, W * sizeof(int16_t));
+		if(ncl) memset(ncl, 0, W * sizeof(int16_t));
 	}
 
 	/* src/video.c:2884-2895 */
@@ -227,10 +237,14 @@ void orc_raster_line(orc_t *s, long g)
 			s->chroma[(s->burst_left + x) * 2 + 1] = (s->burst_phase.q * s->burst_win[x]) >> 15;
 		}
 
-		for(x = 0; x < W; x++)
 		{
-			o[x] += (lut[x].i * s->chroma[x * 2 + 1] * pal +
-			         lut[x].q * s->chroma[x * 2 + 0]) >> 15;
+			/* onto the luma, or -- S-Video -- into the Q channel (src/video.c:3032) */
+			int16_t *dst = c->s_video ? orc_cline_ptr(s, g) : o;
+			for(x = 0; x < W; x++)
+			{
+				dst[x] += (lut[x].i * s->chroma[x * 2 + 1] * pal +
+				           lut[x].q * s->chroma[x * 2 + 0]) >> 15;
+			}
 		}
 	}
 }

@@ -180,7 +180,7 @@ static void _fir_block(int16_t *buf, int n, int step, const int16_t *taps, int n
 
 /* The process on one line. `o` is the line's I channel (width samples, final
  * raster). frame / line are 1-based; line 0 is a pipeline-fill slot. */
-void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int active_r, int vy)
+void orc_secam_line(orc_t *s, int16_t *o, int16_t *oq, int frame, int line, int active_l, int active_r, int vy)
 {
 	const hvk_config_t *c = &s->conf;
 	int W = s->width, x;
@@ -231,8 +231,8 @@ void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int
 		c32_t phase;
 		int16_t dmin = s->sc_dmin[dr], dmax = s->sc_dmax[dr];
 
-		/* luma notch over the active picture, zero history (src/video.c:3206) */
-		_fir_block(o + s->active_left, s->active_width, 1, s->sc_notch, 51);
+		/* luma notch over the active picture, zero history; not with S-Video (src/video.c:3206) */
+		if(!c->s_video) _fir_block(o + s->active_left, s->active_width, 1, s->sc_notch, 51);
 
 		/* chroma low pass over the whole line; the over-read reaches the first
 		 * entries of the upper half (src/video.c:3207) */
@@ -275,7 +275,7 @@ void orc_secam_line(orc_t *s, int16_t *o, int frame, int line, int active_l, int
 
 			/* x can run past the line: the result stays in the buffer's upper
 			 * half, the add lands outside the line and is never emitted */
-			if(x < W) o[x] += (cb[x] * s->burst_win[x - sl]) >> 15;
+			if(x < W) (c->s_video && oq ? oq : o)[x] += (cb[x] * s->burst_win[x - sl]) >> 15;
 		}
 	}
 }

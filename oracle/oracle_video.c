@@ -46,6 +46,10 @@ orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsign
 	s->sample_rate = sample_rate;
 	s->pixel_rate = pixel_rate ? pixel_rate : sample_rate;   /* src/video.c:3839 */
 
+	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); the two-channel resampler is not restated */
+	if(conf->s_video && (conf->output_type != HVK_INT16_REAL || conf->colour_mode == HVK_MONOCHROME ||
+	                     (pixel_rate && pixel_rate != sample_rate))) { free(s); return(NULL); }
+
 	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0 || orc_vbi_init(s) != 0)
 	{
 		orc_close(s);
@@ -71,6 +75,7 @@ void orc_close(orc_t *s)
 	orc_vbi_free(s);
 	orc_teletext_free(s);
 	free(s->S);
+	free(s->C);
 	free(s->last_raster);
 	free(s->last_carrier);
 	free(s->last_widths);
@@ -249,6 +254,7 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 		long drop = need_first - s->s_first;
 		if(drop > s->s_count) drop = s->s_count;
 		memmove(s->S, s->S + drop * W, (s->s_count - drop) * W * sizeof(int16_t));
+		if(s->C) memmove(s->C, s->C + drop * W, (s->s_count - drop) * W * sizeof(int16_t));
 		s->s_first += drop;
 		s->s_count -= drop;
 	}
@@ -257,12 +263,14 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 	if(need_count > s->s_cap)
 	{
 		s->S = realloc(s->S, need_count * W * sizeof(int16_t));
+		if(s->conf.s_video) s->C = realloc(s->C, need_count * W * sizeof(int16_t));
 		s->s_cap = need_count;
 	}
 	if(need_count > s->s_count)
 	{
 		/* new lines enter zeroed; the raster blanks each before use */
 		memset(s->S + s->s_count * W, 0, (need_count - s->s_count) * W * sizeof(int16_t));
+		if(s->C) memset(s->C + s->s_count * W, 0, (need_count - s->s_count) * W * sizeof(int16_t));
 		s->s_count = need_count;
 	}
 
@@ -288,7 +296,7 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 				for(k = 0; k < 2; k++)
 				{
 					for(x = 0; x < W; x++) scratch[x] = s->blanking_level;
-					orc_secam_line(s, scratch, 1, 0, 1, 1, -1);
+					orc_secam_line(s, scratch, NULL, 1, 0, 1, 1, -1);
 				}
 				free(scratch);
 			}
@@ -297,7 +305,7 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 			{
 				long g = s->rastered - 2;
 				orc_line_info(s, g, &frame, &line, &la, &ra, &vy);
-				orc_secam_line(s, orc_line_ptr(s, g), frame, line, la, ra, vy);
+				orc_secam_line(s, orc_line_ptr(s, g), orc_cline_ptr(s, g), frame, line, la, ra, vy);
 				s->sc_done++;
 			}
 		}
@@ -472,6 +480,14 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 			}
 		}
 		else _filter(s, s->cbuf, w, s->ciq);
+
+		/* S-Video: the filter leaves the Q channel alone, and the slot it writes the luma of
+		 * line c - delay_lines into is that line's own: Q is its sub-carrier (src/video.c:3235-3248) */
+		if(s->conf.s_video)
+		{
+			const int16_t *cq = orc_cline_ptr(s, c - s->delay_lines);
+			for(x = 0; x < w; x++) s->ciq[x * 2 + 1] = cq ? cq[x] : 0;
+		}
 
 		memset(s->ccar, 0, w * 2 * sizeof(int16_t));
 		orc_audio_line(s, s->ciq, w, s->ccar);
