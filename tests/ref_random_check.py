@@ -81,13 +81,23 @@ def main():
             out.append(o.render_lines(L))
         mine = np.concatenate(out)
 
+    W = info["width"]
     if conf.colour_mode != 3 and not np.array_equal(ghost, ghost_after):    # SECAM has no over-read chroma filter
-        print("MOVED")
+        # The bytes behind the reference's chroma buffer changed while it ran (they belong to whatever
+        # the allocator keeps there), so no single ghost describes the run. They only reach the last
+        # chroma samples of a line, and through the 51-tap filter the samples around the line end:
+        # compare everything else.
+        x = np.arange(len(ref)) % W
+        keep = (x >= 32) & (x < W - 40)
+        if np.array_equal(ref[keep], mine[keep]):
+            print("EQUAL-EXCEPT-LINE-ENDS (%d of %d samples compared)" % (keep.sum(), len(ref)))
+        else:
+            d = np.nonzero(keep & (ref != mine).any(axis=1))[0]
+            print("DIFFERENT %d samples away from the line ends, first at line %d x %d" % (len(d), d[0] // W, d[0] % W))
         return
     if np.array_equal(ref, mine):
         print("EQUAL")
         return
-    W = info["width"]
     d = np.nonzero((ref != mine).any(axis=1))[0]
     print("DIFFERENT %d samples, first at line %d x %d: ref %s oracle %s" % (len(d), d[0] // W, d[0] % W, ref[d[0]].tolist(), mine[d[0]].tolist()))
 

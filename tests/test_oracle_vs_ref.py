@@ -111,8 +111,7 @@ def test_random_source_through_the_real_reference(setup):
         pytest.skip("oracle/_ref/libhacktv_ref.so not built")
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "ref_random_check.py"), setup],
                          capture_output=True, text=True, timeout=600)
-    words = [l for l in out.stdout.splitlines() if l.split() and l.split()[0] in ("EQUAL", "MOVED", "DIFFERENT")]
+    words = [l for l in out.stdout.splitlines() if l.startswith(("EQUAL", "DIFFERENT"))]
     assert out.returncode == 0 and words, out.stderr[-2000:]
-    if words[-1].startswith("MOVED"):
-        pytest.skip("the heap behind the reference's chroma buffer changed during the run")
-    assert words[-1] == "EQUAL", words[-1]
+    # "EQUAL-EXCEPT-LINE-ENDS": the heap bytes the reference over-reads changed during its run
+    assert words[-1].startswith("EQUAL"), words[-1]
