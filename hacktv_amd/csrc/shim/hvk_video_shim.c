@@ -30,7 +30,7 @@
  *    a message; nothing is silently dropped.
  *
  * Difference: frames are rendered HVK_BATCH at a time on the GPU (environment
- * variable, default 4) and read back into a host buffer the lines point into;
+ * variable, default 8) and read back into a host buffer the lines point into;
  * a worker thread prepares the next batch (source pulls, host pre-passes, render,
  * read-back) while the lines of the current one are handed out.
  * line->audio is always NULL (the file sink has no audio path).
@@ -200,7 +200,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	m = calloc(1, sizeof(shim_t));
 	if(!m) return(VID_OUT_OF_MEMORY);
 
-	m->batch = 4;
+	m->batch = 8;
 	if((env = getenv("HVK_BATCH")) && atoi(env) > 0) m->batch = atoi(env);
 	if((env = getenv("HVK_DEVICE"))) device = atoi(env);
 
