@@ -426,3 +426,24 @@ def test_random_pictures_and_loud_audio(golden, case, members):
         got = e.fetch(0, n * e.info["frame_samples"])
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // c["width"], bad[0] % c["width"])
+
+
+def test_frame_numbers_far_beyond_32_bits_of_samples(golden):
+    """Without sound the stream has a period of 4 frames at 16 Msps (colour table position, PAL
+    sequence): frames 4 000 000 .. 4 000 003 -- 2.56e12 samples in, a month of signal -- must equal frames
+    0 .. 3 but for the very first line's zero filter history. Catches 32-bit position arithmetic."""
+    conf, sr = golden.conf("i_vsb")
+    with H.Engine(conf, sr, device=0, max_frames=4) as e:
+        e.frame_upload(0, golden.frame("i_vsb"))
+        fs = e.info["frame_samples"]
+        e.stage(0, 1, 4)
+        e.launch()
+        a = e.fetch(0, 4 * fs)
+        e.stage(4, 1, 4)
+        e.launch()
+        b = e.fetch(0, 4 * fs)
+        e.stage(4000000, 1, 4)
+        e.launch()
+        c = e.fetch(0, 4 * fs)
+    assert np.array_equal(b, c)
+    assert np.array_equal(a[64:], c[64:]) and not np.array_equal(a[:64], c[:64])
