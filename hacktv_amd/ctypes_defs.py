@@ -93,4 +93,4 @@ class HvkInfo(C.Structure):
 
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
 
-HVK_OK, HVK_ERROR, HVK_OUT_OF_MEMORY, HVK_NO_DEVICE, HVK_UNSUPPORTED, HVK_UNDERRUN = 0, -1, -2, -3, -4, -5
+HVK_OK, HVK_ERROR, HVK_OUT_OF_MEMORY, HVK_NO_DEVICE, HVK_UNSUPPORTED = 0, -1, -2, -3, -4

@@ -54,7 +54,6 @@ extern "C" {
 #define HVK_OUT_OF_MEMORY  -2   /* VID_OUT_OF_MEMORY */
 #define HVK_NO_DEVICE      -3
 #define HVK_UNSUPPORTED    -4   /* configuration outside the engine's scope */
-#define HVK_UNDERRUN       -5   /* not enough audio side-stream queued */
 
 /* hvk_config_apply_flags(): the reference CLI's preset edits */
 #define HVK_FLAG_FILTER    (1 << 0)  /* --filter   src/hacktv.c:1412 */
