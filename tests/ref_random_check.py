@@ -31,6 +31,10 @@ SETUPS = {
     "m_vbi_cc":    ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_ACP | R.FLAG_VITS | R.FLAG_VITC, H.FLAG_NOAUDIO,
                     {"cc608": 1, "acp": 1, "vits": 1, "vitc": 1}, 3),
     "i_wss_auto":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_WSS_AUTO, H.FLAG_NOAUDIO, {"wss": 0xFF}, 2),
+    # the resampler on moving pictures with loud sound; FM video (a serial modulator over all of it)
+    "i_px_moving": ("i", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {}, 3, 13500000),
+    "palfm_loud":  ("pal-fm", 16000000, 0, 0, {}, 2),
+    "secamfm_mov": ("secam-fm", 16000000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 2),
     # 44 frames: the anti-copy AGC level starts to move at frame 39; time code minutes stay 0 but seconds tick
     "i_acp_long":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_VITC, H.FLAG_NOAUDIO, {"acp": 1, "vitc": 1}, 44),
 }
@@ -38,13 +42,14 @@ SETUPS = {
 
 def main():
     name = sys.argv[1]
-    mode, sr, pflags, hflags, members, nframes = SETUPS[name]
+    mode, sr, pflags, hflags, members, nframes = SETUPS[name][:6]
+    pixel_rate = SETUPS[name][6] if len(SETUPS[name]) > 6 else 0
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
     conf = H.preset(mode, hflags)
     for k, v in members.items():
         setattr(conf, k, v)
 
-    with R.RefProbe(mode, sr, pflags) as r:
+    with R.RefProbe(mode, sr, pflags, pixel_rate=pixel_rate) as r:
         info = dict(r.info)
         w, h, L = info["active_width"], info["active_lines"], info["lines"]
         fields = 2 if members.get("interlace") else 1
@@ -66,7 +71,7 @@ def main():
         ref = r.render_lines(nframes * L)
         ghost_after = r.table("chroma_ghost", np.int16)
 
-    with oracle.Oracle(conf, sr) as o:
+    with oracle.Oracle(conf, sr, pixel_rate) as o:
         o.set_ghost(ghost)
         o.set_audio(audio, True)
         out = []
@@ -81,7 +86,7 @@ def main():
             out.append(o.render_lines(L))
         mine = np.concatenate(out)
 
-    W = info["width"]
+    W = len(ref) // (nframes * L)          # the output line (differs from info["width"] with the resampler)
     if conf.colour_mode != 3 and not np.array_equal(ghost, ghost_after):    # SECAM has no over-read chroma filter
         # The bytes behind the reference's chroma buffer changed while it ran (they belong to whatever
         # the allocator keeps there), so no single ghost describes the run. They only reach the last

@@ -97,7 +97,8 @@ def test_oracle_long_run_equals_cli(golden, mode, sr, flags, pflags):
     assert np.array_equal(ref, iq.reshape(-1))
 
 
-@pytest.mark.parametrize("setup", ["i_loud", "m_loud", "l_moving", "g_a2_loud", "i_interlace", "l_interlace", "m_vbi_cc", "i_wss_auto", "i_acp_long"])
+@pytest.mark.parametrize("setup", ["i_loud", "m_loud", "l_moving", "g_a2_loud", "i_interlace", "l_interlace", "m_vbi_cc", "i_wss_auto", "i_acp_long",
+                                   "i_px_moving", "palfm_loud", "secamfm_mov"])
 def test_random_source_through_the_real_reference(setup):
     """The unmodified reference, in-process, on a source of our own (tests/ref_random_check.py): random
     pictures that change every frame or field, saturated colours, full-scale noise and clipped bursts as
