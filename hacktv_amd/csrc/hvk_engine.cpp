@@ -11,11 +11,14 @@
  *   yuv        2^24 x int16x4   128 MiB   RGB -> level table, expanded on device
  *   clut       (clw + width) x int16x2    colour sub-carrier phasors
  *   pool       frame_slots x active_w x active_h x 4 B   source frames (RGBx)
- *   S          max_frames x (lines + 2) x width x 2 B    raster stream (int16 I)
+ *   S          max_frames x (lines + 2 [+ 1]) x width x 2 B  raster stream (int16 I), halo lines either side
  *   carriers   max_frames x frame_samples x 4 B          serial-carrier side stream
  *   symtab     max_frames x symbol_stride x 4 B          NICAM symbols: start sample and value
  *   tileinfo   max_frames x tiles x 8 B                  per filter tile: newest symbol, mixer position
  *   out        max_frames x frame_samples x 4 B          int16 I/Q (if the caller gives no buffer)
+ * and, only with the option that needs them: S2 (resampled stream), C (S-Video sub-carrier),
+ * off / pass (offset phasor, passthru samples), chroma (SECAM), vbi_sym / vbi_val / ops / map
+ * (VBI data lines), vits tables. DESIGN.md section 2 has the sizes.
  */
 #include <hip/hip_runtime.h>
 #include <stdlib.h>

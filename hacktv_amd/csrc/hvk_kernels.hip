@@ -1,6 +1,7 @@
 /* hvk_kernels.hip -- CDNA4 (gfx950) kernels of the composite-video -> IQ engine.
  *
- * Three kernels, all integer except the one-off table expansion:
+ * All integer except the one-off table expansion. The two kernels of every
+ * render are hvk_k_raster and hvk_k_filter; the others serve options:
  *
  *   hvk_k_expand_yuv   once per engine: expands the 2^24-entry RGB -> (Y,U,V)
  *                      level table in HBM from 256 gamma values and a handful
@@ -24,6 +25,19 @@
  *                      serial-carrier side stream and the NICAM DQPSK signal
  *                      (pulse overlap-add + mixer, src/nicam728.c:342-411),
  *                      and stores interleaved int16 I/Q, 32 bytes per lane.
+ *
+ *   hvk_k_resample     --pixelrate: rational poly-phase FIR between the two,
+ *                      pixel-rate raster -> sample-rate stream (src/fir.c:304-355
+ *                      with interpolation / decimation).
+ *   hvk_k_tail         --swap-iq / --offset / --passthru, in place on the output
+ *                      (src/video.c:3466-3541).
+ *   hvk_k_convert      the file sink's sample formats (src/rf_file.c:34-277).
+ *
+ * Inside hvk_k_raster, behind wave-uniform tests that cost the plain path a
+ * scalar compare each: SECAM (luma notch + the host's FM sub-carrier stream),
+ * insertion test signals, and the VBI data lines (teletext, WSS, VITC, CC608
+ * symbols from one table store; anti-copy pulse runs) listed per frame by the
+ * host. S-Video has kernel variants of its own (template parameter).
  *
  * Nothing here is a dense contraction: no MFMA. The work is bounded by VALU
  * issue (dot2 count) and by the 4 B/sample HBM write.
