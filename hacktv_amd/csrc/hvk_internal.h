@@ -35,7 +35,7 @@ typedef struct {
 	int16_t al, ar;         /* luma is assigned on [al, ar); al == ar: none */
 	int16_t src_row;        /* source row before centring / field shift, -1: none */
 	int16_t pal;            /* 0 no chroma, +1, -1 (PAL V switch) */
-	int16_t pad;
+	int16_t secam_fid;      /* SECAM field identification line: sub-carrier (and luma notch) without a picture */
 } hvk_linedesc_t;
 
 /* RGB -> (Y,U,V) level conversion, evaluated in double on the device with
@@ -164,6 +164,7 @@ typedef struct {
 	int16_t *secam_fir;         /* 15 taps, applied order */
 	int16_t *secam_notch;       /* 51 taps, applied order */
 	int16_t secam_dmin[2], secam_dmax[2];
+	int16_t secam_fsync_level; int32_t secam_fid_lines;   /* field identification lines, src/video.c:4130-4137 */
 	/* FM video and frequency offset (src/video.c:4563-4607) */
 	int32_t fmv_level; hvk_c32_t *fmv_lut;
 	hvk_c32_t offset_delta;

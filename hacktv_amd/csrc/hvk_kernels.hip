@@ -314,7 +314,9 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	if(pal || has_pix) __syncthreads();
 
-	if(x0 >= W && !(SECAM && active) && vbi_op < 0) return;
+	/* SECAM: picture lines and field identification lines carry the sub-carrier and get the luma notch */
+	const bool sc_line = SECAM && (active || d.secam_fid);
+	if(x0 >= W && !sc_line && vbi_op < 0) return;
 
 	/* ---- 8 consecutive samples per lane ---- */
 	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
@@ -443,7 +445,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(SECAM && active)
+	if(sc_line)
 	{
 		/* SECAM lines with picture (src/video.c:3202-3229): first the luma notch
 		 * over the active picture, a zero-history FIR whose input starts at

@@ -122,14 +122,14 @@ static inline int32_t _round_away(double x)
 /* One line of the process. `row` points at the source pixels shown on this
  * line (NULL: none); out receives the W values to add to the line (NULL: a
  * pipeline-fill slot whose result is never emitted). */
-static void _line(hvk_secam_t *s, int frame, int line, int picture, int right_half,
+static void _line(hvk_secam_t *s, int frame, int line, int picture, int right_half, int field_id,
                   const uint32_t *row, int row_width, int vframe_x, int16_t *out)
 {
 	const hvk_tables_t *t = s->t;
 	const int W = s->W;
 	const int dr = ((frame * s->lines) + line) & 1;    /* D'r line, else D'b */
 	const int sl = t->k.burst_left;
-	const int sr = right_half ? sl + t->k.burst_width : t->k.half_width;
+	const int sr = (right_half || field_id) ? sl + t->k.burst_width : t->k.half_width;
 	int x;
 
 	if(out) memset(out, 0, sizeof(int16_t) * W);
@@ -141,8 +141,25 @@ static void _line(hvk_secam_t *s, int frame, int line, int picture, int right_ha
 		memset(s->held, 0, sizeof(int16_t) * W);
 	}
 
-	if(!picture || sr <= sl) return;
+	if((!picture && !field_id) || sr <= sl) return;
 
+	if(field_id)
+	{
+		/* field identification line (src/video.c:3101-3133): the sub-carrier ramps from the line's
+		 * rest frequency by 350 kHz over 15 us (D'r) / 18 us (D'b); the held component is left alone */
+		const int16_t level = s->uv[dr ? 1 : 0];            /* of RGB 000000 */
+		const int16_t dev = dr ? t->secam_fsync_level : -t->secam_fsync_level;
+		const double rw = dr ? 15e-6 : 18e-6;
+
+		for(x = 0; x < W; x++)
+		{
+			double tt = (double) (x - t->k.active_left) / t->pixel_rate / rw;
+			if(tt < 0) tt = 0;
+			else if(tt > 1) tt = 1;
+			s->line[x] = level + dev * tt;
+		}
+	}
+	else
 	/* colour difference of this line, averaged with the previous line's
 	 * (src/video.c:3149-3196): D'r lines carry v and keep u for the next line */
 	{
@@ -244,8 +261,8 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 	 * :4665-4667) */
 	if(frame_index == 0)
 	{
-		_line(s, 1, 0, 1, 1, NULL, k->active_width, 0, NULL);
-		_line(s, 1, 0, 1, 1, NULL, k->active_width, 0, NULL);
+		_line(s, 1, 0, 1, 1, 0, NULL, k->active_width, 0, NULL);
+		_line(s, 1, 0, 1, 1, 0, NULL, k->active_width, 0, NULL);
 	}
 
 	for(line = 1; line <= k->lines; line++)
@@ -268,7 +285,7 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 		if(fb && vy >= 0 && vy < fb_height) row = fb + (size_t) vy * fb_width;
 
 		/* an empty frame (0 x 0, what a source past its end hands out) shows no pixels at all */
-		_line(s, frame, line, picture, right_half, row, fb_width, vframe_x, out + (size_t) (line - 1) * k->width);
+		_line(s, frame, line, picture, right_half, d->secam_fid, row, fb_width, vframe_x, out + (size_t) (line - 1) * k->width);
 	}
 
 	s->next_frame++;

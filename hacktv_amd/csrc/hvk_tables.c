@@ -137,6 +137,10 @@ static int _build_linedesc(hvk_tables_t *t)
 		}
 		d->src_row = _row_of_line(c->type, line);
 
+		/* SECAM field identification lines at the top of each field (src/video.c:3101-3103) */
+		d->secam_fid = c->colour_mode == HVK_SECAM && c->secam_field_id && c->lines == 625 &&
+		               ((line >= 7 && line < 7 + t->secam_fid_lines) || (line >= 320 && line < 320 + t->secam_fid_lines));
+
 		d->pal = 0;
 		if(colour)
 		{
@@ -609,6 +613,11 @@ static int _build_secam(hvk_tables_t *t, double level)
 	if(!t->secam_fir || !t->secam_notch) return(HVK_OUT_OF_MEMORY);
 
 	/* deviation limits: [0] D'b lines, [1] D'r lines (src/video.c:4110-4113) */
+	/* field identification lines (src/video.c:4130-4137) */
+	t->secam_fsync_level = (int16_t) round(350e3 / fm_dev * INT16_MAX);
+	t->secam_fid_lines = c->secam_field_id_lines;
+	if(t->secam_fid_lines < 1 || t->secam_fid_lines > 9) t->secam_fid_lines = 9;
+
 	t->secam_dmin[0] = lround((cb - fm_freq - 350e3) / fm_dev * INT16_MAX);
 	t->secam_dmax[0] = lround((cb - fm_freq + 506e3) / fm_dev * INT16_MAX);
 	t->secam_dmin[1] = lround((cr - fm_freq - 506e3) / fm_dev * INT16_MAX);
@@ -1073,7 +1082,6 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	 * (src/video.c:2017-2113); they are not reproduced here */
 	if(c->modulation == HVK_FM && c->vfilter) return(HVK_UNSUPPORTED);
 	if(c->modulation == HVK_FM && (c->fm_level <= 0 || c->fm_deviation <= 0)) return(HVK_ERROR);
-	if(c->colour_mode == HVK_SECAM && c->secam_field_id) return(HVK_UNSUPPORTED);
 	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
 

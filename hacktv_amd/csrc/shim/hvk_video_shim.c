@@ -103,7 +103,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->raw_bb_file) return(_refuse("raw baseband input"));
 	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
 	if(c->frame_orientation) return(_refuse("frame orientation"));
-	if(c->secam_field_id) return(_refuse("SECAM field id"));
 
 	h->output_type = c->output_type;
 	h->modulation = c->modulation;
@@ -148,6 +147,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->burst_rise = c->burst_rise;
 	h->ev_co = c->ev_co;
 	h->eu_co = c->eu_co;
+	h->secam_field_id = c->secam_field_id;
+	h->secam_field_id_lines = c->secam_field_id_lines;
 	h->volume = c->volume;
 	h->fm_mono_carrier = c->fm_mono_carrier;
 	h->fm_mono_deviation = c->fm_mono_deviation;
@@ -374,6 +375,12 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 				if(s->conf.vitc && (line == 19 || line == 21 || line == 332 || line == 334)) continue;
 				if(s->conf.acp && ((line >= 9 && line <= 18) || (line >= 321 && line <= 330))) continue;
 				if(s->conf.cc608 && line == 22) continue;
+				if(s->conf.colour_mode == VID_SECAM && s->conf.secam_field_id)
+				{
+					/* src/video.c:3101-3103, :4132-4137 */
+					int nl = (s->conf.secam_field_id_lines < 1 || s->conf.secam_field_id_lines > 9) ? 9 : s->conf.secam_field_id_lines;
+					if((line >= 7 && line < 7 + nl) || (line >= 320 && line < 320 + nl)) continue;
+				}
 				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
 			}
 			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);

@@ -80,6 +80,9 @@ CASES = [
     ("pal_sv",        "pal",  16000000, ["--s-video"],               0,                                     False, 2, {"s_video": 1}),
     ("ntsc_sv_f",     "ntsc", 13500000, ["--s-video", "--filter"],   refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
     ("secam_sv",      "secam", 16000000, ["--s-video", "--filter"],  refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
+    # SECAM field identification lines in the vertical interval
+    ("l_fid",         "l",    16000000, ["--filter", "--secam-field-id"], refprobe.FLAG_FILTER,            False, 3, {"secam_field_id": 1}),
+    ("secam_fid4",    "secam", 16000000, ["--secam-field-id", "--secam-field-id-lines", "4"], 0,            True,  2, {"secam_field_id": 1, "secam_field_id_lines": 4}),
     # --wss auto: the test source is 4:3 (pixel aspect 12:13 at 832 x 576)
     ("i_wss_auto",    "i",    16000000, ["--noaudio", "--wss", "auto"], refprobe.FLAG_NOAUDIO,             False, 2, {"wss": 0xFF}),
     # anti-copy pulses and the CEA-608 caption line (no captions from the test source: parity-only codes)

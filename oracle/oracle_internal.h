@@ -164,6 +164,8 @@ struct orc_t {
 	int16_t sc_dmin[2], sc_dmax[2];
 	c16_t *sc_bell;
 	long sc_done;               /* lines the process has been applied to */
+	int16_t sc_fsync_level;
+	int sc_fid_lines;
 
 	/* teletext render (oracle_teletext.c): symbol table and the packets queued per frame */
 	orc_pulse_t *tt_sym;

@@ -103,6 +103,11 @@ int orc_secam_init(orc_t *s)
 	for(i = 0; i < 51; i++) taps[i] /= a;
 	s->sc_notch = _q15_reversed(taps, 51);
 
+	/* field identification lines (src/video.c:4130-4137) */
+	s->sc_fsync_level = round(350e3 / SECAM_FM_DEV * INT16_MAX);
+	s->sc_fid_lines = c->secam_field_id_lines;
+	if(s->sc_fid_lines < 1 || s->sc_fid_lines > 9) s->sc_fid_lines = 9;
+
 	/* deviation limits (src/video.c:4110-4113): [0] D'b, [1] D'r */
 	s->sc_dmin[0] = lround((SECAM_CB_FREQ - SECAM_FM_FREQ - 350e3) / SECAM_FM_DEV * INT16_MAX);
 	s->sc_dmax[0] = lround((SECAM_CB_FREQ - SECAM_FM_FREQ + 506e3) / SECAM_FM_DEV * INT16_MAX);
@@ -196,7 +201,26 @@ void orc_secam_line(orc_t *s, int16_t *o, int16_t *oq, int frame, int line, int 
 
 	if(line == 1 || line == c->hline) memset(cb, 0, sizeof(int16_t) * 2 * W);
 
-	if(active_l || active_r)
+	if(c->secam_field_id && ((line >= 7 && line < 7 + s->sc_fid_lines) || (line >= 320 && line < 320 + s->sc_fid_lines)))
+	{
+		/* field identification ("bottle") lines, src/video.c:3101-3133: the sub-carrier ramps from
+		 * the line's rest frequency by 350 kHz over 15 us (D'r) / 18 us (D'b) */
+		int16_t level = dr ? s->yuv[2] : s->yuv[1];
+		int16_t dev = dr ? s->sc_fsync_level : -s->sc_fsync_level;
+		double rw = dr ? 15e-6 : 18e-6;
+
+		for(x = 0; x < W; x++)
+		{
+			double t = (double) (x - s->active_left) / s->pixel_rate / rw;
+			if(t < 0) t = 0;
+			else if(t > 1) t = 1;
+			cb[x] = level + dev * t;
+		}
+
+		sl = s->burst_left;
+		sr = sl + s->burst_width;
+	}
+	else if(active_l || active_r)
 	{
 		const uint32_t *prgb = NULL;
 		int stride = 0;

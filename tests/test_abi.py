@@ -55,7 +55,6 @@ def test_no_cpu_path_without_a_device():
 def test_unsupported_configurations_are_refused():
     """Configurations outside the engine's scope fail at open with HVK_UNSUPPORTED."""
     bad = []
-    c = H.preset("l"); c.secam_field_id = 1; bad.append((c, 16000000))        # SECAM field identification lines
     c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
     c = H.preset("pal-fm", H.FLAG_FILTER); bad.append((c, 16000000))          # FM video with the fixed pre-emphasis tap tables
     c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster other than 625 / 525

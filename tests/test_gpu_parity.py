@@ -54,7 +54,8 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pal_fm_pass",
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
-                                  "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv"])
+                                  "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv",
+                                  "l_fid", "secam_fid4"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -236,7 +237,7 @@ def test_dropin_binary_equals_reference_cli(golden):
 
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
-                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f"):
+                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4
