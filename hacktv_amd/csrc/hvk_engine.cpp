@@ -25,6 +25,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <algorithm>
 #include "hvk_internal.h"
 #include "hvk_kernels.h"
 
@@ -58,6 +59,9 @@ struct hvk_engine {
 	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	int8_t *d_map, *h_map;      /* [max_frames][lines] */
 	void *d_vits_l, *d_vits_c;
+	/* --raw-bb-file: queued stream (raw_q[0] is sample raw_base) and its per-batch slab */
+	std::vector<int16_t> *raw_q; int64_t raw_base;
+	int16_t *d_raw, *h_raw;
 	uint8_t *cc_pairs;          /* CC608: [max_frames][3] { present, c1, c2 } queued for the next batch */
 	hvk_packed_taps_t notch;
 	hvk_tail_t *tail;           /* FM video / offset / passthru serial state (hvk_tail.c) */
@@ -197,6 +201,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		if(!e->tail) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
+	if(e->t.k.rawbb) e->raw_q = new std::vector<int16_t>();
+
 	if(e->t.conf.cc608)
 	{
 		e->cc_pairs = (uint8_t *) calloc((size_t) max_frames, 3);
@@ -326,6 +332,13 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_vits_c, e->t.vits_c, sizeof(int16_t) * k.vits * k.width));
 	}
 
+	if(k.rawbb)
+	{
+		const size_t bytes = (size_t) max_frames * k.slab_lines * k.width * 2;
+		OPENHIP(hipMalloc((void **) &e->d_raw, bytes));
+		OPENHIP(hipHostMalloc((void **) &e->h_raw, bytes, hipHostMallocDefault));
+	}
+
 	if(e->t.k.secam)
 	{
 		const size_t RS = k.raster_samples;   /* the colour side stream is at the pixel rate */
@@ -368,15 +381,16 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
 
 	free(e->sym_tmp);
 	free(e->cc_pairs);
+	delete e->raw_q;
 	if(e->host_frames) { for(int i = 0; i < e->frame_slots; i++) free(e->host_frames[i]); free(e->host_frames); }
 	hvk_secam_free(e->secam);
 	hvk_tail_free(e->tail);
@@ -549,6 +563,15 @@ extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const u
 		memcpy(dst + r * 12, row, 48);     /* little endian: bit b of the packet is bit b & 31 of word b >> 5 */
 	}
 	e->h_tt_mask[frame_in_batch] = mask;
+	return(HVK_OK);
+}
+
+extern "C" int hvk_rawbb_write(hvk_engine_t *e, const int16_t *samples, size_t nsamples)
+{
+	if(!e) return(HVK_ERROR);
+	if(!e->raw_q) return(HVK_UNSUPPORTED);
+	if(nsamples && !samples) return(HVK_ERROR);
+	e->raw_q->insert(e->raw_q->end(), samples, samples + nsamples);
 	return(HVK_OK);
 }
 
@@ -862,6 +885,21 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 			e->secam_next++;
 		}
 
+		if(e->h_raw)
+		{
+			/* the lines of this frame's slab: the last line of the frame before, the frame, the first
+			 * line of the next (the filter looks 25 samples into it); zeros where nothing is queued */
+			const int W = k.width;
+			int16_t *dst = e->h_raw + (size_t) i * k.slab_lines * W;
+			for(int j = 0; j < k.slab_lines; j++)
+			{
+				const int64_t g = f->frame_index * k.lines + j - 1;
+				const int64_t at = g * W - e->raw_base;
+				if(g >= 0 && at >= 0 && at + W <= (int64_t) e->raw_q->size()) memcpy(dst + (size_t) j * W, e->raw_q->data() + at, (size_t) W * 2);
+				else memset(dst + (size_t) j * W, 0, (size_t) W * 2);
+			}
+		}
+
 		if(e->h_off)
 		{
 			int r = hvk_tail_offset_stream(e->tail, f->frame_index * FS, FS, e->h_off + (size_t) i * FS * 2);
@@ -929,6 +967,18 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		if(e->h_tt_mask) memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
 		if(e->cc_pairs) memset(e->cc_pairs, 0, (size_t) e->max_frames * 3);
 	}
+	if(e->h_raw)
+	{
+		HIPCHK(hipMemcpyAsync(e->d_raw, e->h_raw, (size_t) nframes * k.slab_lines * k.width * 2, hipMemcpyHostToDevice, e->stream));
+		/* what no later frame can need goes: everything before the last line of the last frame staged */
+		const int64_t keep = ((first_frame + (int64_t) (nframes - 1) * stride + 1) * k.lines - 1) * k.width;
+		if(keep > e->raw_base)
+		{
+			const int64_t drop = std::min<int64_t>(keep - e->raw_base, (int64_t) e->raw_q->size());
+			e->raw_q->erase(e->raw_q->begin(), e->raw_q->begin() + drop);
+			e->raw_base += drop;
+		}
+	}
 	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
@@ -975,7 +1025,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.k = e->t.k;
 	ra.ctaps = e->ctaps;
 	ra.notch = e->notch;
-	ra.chroma = e->d_chroma;
+	ra.chroma = e->t.k.rawbb ? e->d_raw : e->d_chroma;
 	ra.vbi_sym = (const int *) e->d_vbi_sym;
 	ra.vbi_val = (const int16_t *) e->d_vbi_val;
 	ra.vbi_ops = e->d_ops;

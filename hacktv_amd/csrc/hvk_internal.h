@@ -94,6 +94,8 @@ typedef struct {
 	int32_t vits_line[4];   /* their 0-based line numbers */
 	int32_t vits_pi, vits_pq;   /* chroma phase of the insertion signal, Q15 */
 	int32_t black;          /* black level (WSS blanks part of line 23 to it) */
+	int32_t rawbb;          /* the raster comes from an external baseband stream (--raw-bb-file) */
+	int32_t rawbb_blank, rawbb_range, white;    /* its blanking level and white - blanking; the mode's white level */
 	int32_t s_video;        /* the colour sub-carrier goes to the Q channel (a second raster slab) */
 	int32_t fm_video;       /* the engine's device output is the FM modulator's input (hvk_tail.c does the rest) */
 	int32_t swap_iq, has_offset, has_passthru;   /* complex tail done by hvk_k_tail (not FM video) */

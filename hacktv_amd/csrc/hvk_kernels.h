@@ -21,7 +21,7 @@ typedef struct {
 	hvk_kconst_t k;
 	hvk_packed_taps_t ctaps;
 	hvk_packed_taps_t notch;    /* SECAM luma notch */
-	const int16_t *chroma;      /* SECAM: [nframes][frame_samples] */
+	const int16_t *chroma;      /* SECAM: [nframes][frame_samples]; raw baseband input: [nframes][slab_lines][width] */
 	const int *vbi_sym;         /* VBI data lines: symbol index of every table */
 	const int16_t *vbi_val;
 	const unsigned *vbi_ops;    /* [nframes][HVK_VBI_OPS][HVK_VBI_OPWORDS] */

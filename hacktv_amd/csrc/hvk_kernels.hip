@@ -234,7 +234,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if(vy < 0 || vy >= f.fb_height || !own || !f.fb_valid) vy = -1;
 
 	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
-	const bool active = d.ar > d.al;
+	const bool active = !k.rawbb && d.ar > d.al;    /* raw baseband input: no picture is drawn */
 	const bool has_pix = active && vy >= 0;
 	int ax0 = d.al > px0 ? d.al : px0;                          /* samples that show a source pixel */
 	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
@@ -327,6 +327,22 @@ void hvk_k_raster(const hvk_kconst_t k,
 #pragma unroll
 	for(int i = 0; i < SPL; i++) { s[i] = k.blanking; cq[i] = 0; }
 
+	if(k.rawbb)
+	{
+		/* raw baseband input (src/video.c:2431-2436): the line is taken from the external stream
+		 * (`chroma` holds it, slab layout) and mapped from its levels onto the mode's; C integer
+		 * arithmetic, division truncating */
+		if(x0 < W)
+		{
+			const int16_t *in = chroma + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W + x0;
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				if(x0 + i < W) s[i] = wrap16(k.blanking + (((int) in[i] - k.rawbb_blank) * (k.white - k.blanking)) / k.rawbb_range);
+			}
+		}
+	}
+	else
 	/* sync pulses: this line's own, and the part of the next line's left
 	 * pulse that starts before its sample 0 (src/vbidata.c:211-216) */
 	{

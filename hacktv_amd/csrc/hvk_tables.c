@@ -1409,6 +1409,20 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		t->k.fm_video = 1;
 	}
 
+	/* raw baseband input (src/video.c:2406-2446, :4180-4191): no raster, no colour process, no
+	 * sub-carrier table on the lines (VITS then adds luma only) */
+	if(c->raw_bb)
+	{
+		if(c->raw_bb_white_level == c->raw_bb_blanking_level) return(HVK_ERROR);
+		if(t->k.rs_L || c->s_video) return(HVK_UNSUPPORTED);
+		t->k.rawbb = 1;
+		t->k.rawbb_blank = c->raw_bb_blanking_level;
+		t->k.rawbb_range = c->raw_bb_white_level - c->raw_bb_blanking_level;
+		t->k.white = t->white_level;
+		t->k.colour = 0;
+		t->k.secam = 0;
+	}
+
 	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); the resampler's second channel is not built */
 	if(c->s_video)
 	{

@@ -75,6 +75,7 @@ typedef struct {
 	int32_t *widths;        /* widths of the lines of the frame being handed out (they vary with --pixelrate) */
 	size_t line_at;         /* sample offset of the next line in iq */
 	int16_t *passbuf;
+	int64_t raw_fed;        /* samples of the raw baseband file queued so far */
 	vid_line_t out;
 } shim_t;
 
@@ -100,7 +101,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
-	if(c->raw_bb_file) return(_refuse("raw baseband input"));
+	if(c->raw_bb_file && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->s_video)) return(_refuse("raw baseband input with --pixelrate / --s-video"));
 	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
 	if(c->frame_orientation) return(_refuse("frame orientation"));
 
@@ -159,6 +160,9 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->a2stereo = c->a2stereo;
 	h->vfilter = c->vfilter;
 	h->s_video = c->s_video;
+	h->raw_bb = c->raw_bb_file != NULL;
+	h->raw_bb_blanking_level = c->raw_bb_blanking_level;
+	h->raw_bb_white_level = c->raw_bb_white_level;
 	h->teletext = c->teletext != NULL;
 	h->vits = c->vits;
 	h->vitc = c->vitc;
@@ -249,6 +253,18 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	s->bline = 1;
 	s->processes = (void *) m;
 
+	if(s->conf.raw_bb_file)
+	{
+		/* src/video.c:4180-4188 */
+		s->raw_bb_file = fopen(s->conf.raw_bb_file, "rb");
+		if(!s->raw_bb_file)
+		{
+			perror("fopen");
+			vid_free(s);
+			return(VID_ERROR);
+		}
+	}
+
 	if(s->conf.passthru)
 	{
 		/* src/video.c:4609-4622 */
@@ -280,6 +296,7 @@ void vid_free(vid_t *s)
 
 	if(s->conf.teletext && s->tt.vid) tt_free(&s->tt);
 	if(s->passthru && s->passthru != stdin) fclose(s->passthru);   /* src/video.c:4783-4786 */
+	if(s->raw_bb_file) fclose(s->raw_bb_file);
 
 	if(m && m->worker_on)
 	{
@@ -402,6 +419,31 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 		av_read_audio(&s->av, &a, &an);
 		if(a == NULL || an == 0) break;
 		if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+	}
+
+	/* --raw-bb-file: the lines of these frames and the one after them (the filter looks into it), read
+	 * like src/video.c:2419-2429 -- at the end of the file, start over */
+	if(s->raw_bb_file)
+	{
+		const int64_t want = ((m->frames_pulled * (int64_t) m->info.lines) + 1) * m->info.width;
+		int16_t chunk[4096];
+		int empty = 0;
+
+		while(m->raw_fed < want && empty < 2)
+		{
+			size_t ask = (size_t) (want - m->raw_fed) < 4096 ? (size_t) (want - m->raw_fed) : 4096;
+			size_t r = fread(chunk, sizeof(int16_t), ask, s->raw_bb_file);
+			if(r == 0)
+			{
+				if(!feof(s->raw_bb_file)) break;
+				rewind(s->raw_bb_file);
+				empty++;            /* an empty file would loop for ever */
+				continue;
+			}
+			empty = 0;
+			if(hvk_rawbb_write(m->e, chunk, r) != HVK_OK) return(-1);
+			m->raw_fed += r;
+		}
 	}
 
 	/* --passthru: the lines of these frames (and, once, of the filter's start-up lines) from the

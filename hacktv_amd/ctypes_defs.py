@@ -63,6 +63,9 @@ class HvkConfig(C.Structure):
         ("am_mono_carrier", C.c_double),
         ("a2stereo", C.c_int),
         ("vfilter", C.c_int),
+        ("raw_bb", C.c_int),
+        ("raw_bb_blanking_level", C.c_int),
+        ("raw_bb_white_level", C.c_int),
         ("s_video", C.c_int),
         ("teletext", C.c_int),
         ("wss", C.c_int),

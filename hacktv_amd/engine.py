@@ -17,7 +17,7 @@ SYMBOLS = [
     "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
     "hvk_open", "hvk_open_rates", "hvk_line_widths", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
-    "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect",
+    "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
@@ -64,6 +64,7 @@ def lib():
         L.hvk_passthru_write.argtypes = [vp, vp, C.c_size_t]
         L.hvk_cc608_write.argtypes = [vp, i32, C.c_uint8, C.c_uint8]
         L.hvk_frame_aspect.argtypes = [vp, i32, i64, i64]
+        L.hvk_rawbb_write.argtypes = [vp, vp, C.c_size_t]
         L.hvk_host_offset_stream.argtypes = [vp, i64, i64, vp]
         L.hvk_host_fm_video.argtypes = [vp, vp, i64]
         L.hvk_audio_needed.argtypes = [vp, i32]
@@ -171,6 +172,10 @@ class Engine:
     def audio_write(self, stereo):
         a = np.ascontiguousarray(stereo, np.int16)
         return self._chk("hvk_audio_write", lib().hvk_audio_write(self.h, a.ctypes.data, a.shape[0]))
+
+    def rawbb_write(self, samples):
+        a = np.ascontiguousarray(samples, np.int16)
+        return self._chk("hvk_rawbb_write", lib().hvk_rawbb_write(self.h, a.ctypes.data, a.shape[0]))
 
     def frame_aspect(self, slot, num, den):
         return self._chk("hvk_frame_aspect", lib().hvk_frame_aspect(self.h, slot, num, den))

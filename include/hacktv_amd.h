@@ -153,6 +153,13 @@ int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den
  * without a call carry no teletext. */
 int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask);
 
+/* --raw-bb-file (conf.raw_bb != 0): the next nsamples int16 samples of the external baseband
+ * stream that takes the raster's place (src/video.c:2406-2446), in stream order; a line is `width`
+ * samples. Rendering frame f needs the stream up to sample ((f + 1) * lines + 1) * width (the
+ * filter looks into the line after the frame); what is not queued reads as zeros. Starting the
+ * file over at its end, as the reference does, is the caller's job. */
+int hvk_rawbb_write(hvk_engine_t *e, const int16_t *samples, size_t nsamples);
+
 /* --cc608 (conf.cc608 != 0): the caption byte pair av_read_video() delivered with frame
  * `frame_in_batch` of the NEXT render (av_frame_t.cc608, src/av.h:52; queued by
  * src/video.c:4901-4904, sent on line 22 / 21 by src/cc608.c:188-221). Frames without a call,

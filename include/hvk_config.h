@@ -126,6 +126,12 @@ typedef struct hvk_config_t {
 
 	int vfilter;                /* --filter, src/hacktv.c:1412 */
 
+	int raw_bb;                 /* --raw-bb-file: the raster is not built from frames but taken from an external int16
+	                             * baseband stream, hvk_rawbb_write() (src/video.c:2406-2446); the inserters, filter,
+	                             * sound and modulators still apply */
+	int raw_bb_blanking_level;  /* the stream's blanking and white levels: mapped onto the mode's */
+	int raw_bb_white_level;
+
 	int s_video;                /* --s-video (baseband PAL / NTSC / SECAM only, src/hacktv.c:1136-1148): the colour
 	                             * sub-carrier goes to the Q channel instead of onto the luma (src/video.c:3032, :3219) */
 

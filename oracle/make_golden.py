@@ -80,6 +80,10 @@ CASES = [
     ("pal_sv",        "pal",  16000000, ["--s-video"],               0,                                     False, 2, {"s_video": 1}),
     ("ntsc_sv_f",     "ntsc", 13500000, ["--s-video", "--filter"],   refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
     ("secam_sv",      "secam", 16000000, ["--s-video", "--filter"],  refprobe.FLAG_FILTER,                  False, 2, {"s_video": 1}),
+    # raw baseband input instead of the raster (inserters, filter, sound still apply)
+    ("i_rawbb",       "i",    16000000, ["--filter", "--raw-bb-file", "@RAWBB@", "--raw-bb-blanking", "2000", "--raw-bb-white", "21000", "--vits", "--wss", "16:9"],
+                      refprobe.FLAG_FILTER, False, 3, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000, "vits": 1, "wss": 7}),
+    ("pal_rawbb",     "pal",  16000000, ["--raw-bb-file", "@RAWBB@"], 0,                                   True,  2, {"raw_bb": 1, "raw_bb_blanking_level": 0, "raw_bb_white_level": 32767}),
     # SECAM field identification lines in the vertical interval
     ("l_fid",         "l",    16000000, ["--filter", "--secam-field-id"], refprobe.FLAG_FILTER,            False, 3, {"secam_field_id": 1}),
     ("secam_fid4",    "secam", 16000000, ["--secam-field-id", "--secam-field-id-lines", "4"], 0,            True,  2, {"secam_field_id": 1, "secam_field_id_lines": 4}),
@@ -127,6 +131,8 @@ def main():
     ttraw = os.path.join(GOLD, "ttraw.bin")
     passfile = "/tmp/hvk_passthru.bin"
     util.passthru_signal().tofile(passfile)
+    rawfile = "/tmp/hvk_rawbb.bin"
+    util.rawbb_signal().tofile(rawfile)
     for case in CASES:
         cid, mode, sr, flags, pflags, real, nframes = case[:7]
         extra = case[7] if len(case) > 7 else {}
@@ -152,7 +158,7 @@ def main():
             fs = fs * sr // pixel_rate
             W = fs // L     # the nominal line; where lines vary in width the excerpts are just windows of the stream
         bps = 2 if real else 4
-        data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw).replace("@PASS@", passfile) for f in flags], nframes * fs * bps)
+        data = ref_cli(mode, sr, [f.replace("@TTRAW@", ttraw).replace("@PASS@", passfile).replace("@RAWBB@", rawfile) for f in flags], nframes * fs * bps)
         assert len(data) == nframes * fs * bps, (cid, len(data))
         per_frame = [hashlib.sha256(data[: (i + 1) * fs * bps]).hexdigest() for i in range(nframes)]
 

@@ -122,6 +122,9 @@ struct orc_t {
 	const uint32_t *fb;
 	int fb_width, fb_height, fb_pixel_stride, fb_line_stride, fb_interlaced;
 	long long fb_par_num, fb_par_den;   /* pixel aspect of the source frame, 0: 1:1 */
+	/* --raw-bb-file: the external baseband stream (looped like the reference's rewind at end of file) */
+	const int16_t *rawbb; long rawbb_len;
+
 	/* --interlace: the frame shown by each field; the fields above are set from these per line */
 	struct { const uint32_t *fb; int width, height, pixel_stride, line_stride, interlaced; } field_fb[2];
 

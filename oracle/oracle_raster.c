@@ -156,6 +156,19 @@ void orc_raster_line(orc_t *s, long g)
 		if(ncl) memset(ncl, 0, W * sizeof(int16_t));
 	}
 
+	if(c->raw_bb)
+	{
+		/* _vid_next_line_rawbb, src/video.c:2406-2446: the line is the next `width` samples of the
+		 * external stream (which starts over at its end), mapped from its levels onto the mode's */
+		for(x = 0; x < W; x++)
+		{
+			int in = (s->rawbb && s->rawbb_len > 0) ? s->rawbb[(g * W + x) % s->rawbb_len] : 0;
+			o[x] = s->blanking_level +
+				((in - c->raw_bb_blanking_level) * (s->white_level - s->blanking_level) / (c->raw_bb_white_level - c->raw_bb_blanking_level));
+		}
+		return;
+	}
+
 	/* src/video.c:2884-2895 */
 	vy = _source_row(c->type, line);
 	if(vy >= 0 && c->interlaced != 0 && s->fb_interlaced != c->interlaced) vy += 1;

@@ -233,6 +233,12 @@ void orc_select_frame(orc_t *s, int line)
 	s->fb_interlaced = s->field_fb[f].interlaced;
 }
 
+void orc_set_rawbb(orc_t *s, const int16_t *samples, long nsamples)
+{
+	s->rawbb = samples;
+	s->rawbb_len = nsamples;
+}
+
 void orc_set_audio(orc_t *s, const int16_t *stereo, long nsamples, int loop)
 {
 	s->audio_src = stereo;
@@ -316,7 +322,7 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 		{
 			long g = s->rastered - 2;
 			const c16_t *lut = NULL;
-			if(s->colour_lookup && (s->conf.colour_mode == HVK_PAL || s->conf.colour_mode == HVK_NTSC))
+			if(!s->conf.raw_bb && s->colour_lookup && (s->conf.colour_mode == HVK_PAL || s->conf.colour_mode == HVK_NTSC))   /* rawbb lines have no sub-carrier table (src/video.c:2414) */
 			{
 				/* the table position advances by one line per line (src/video.c:2906-2910) */
 				lut = &s->colour_lookup[(unsigned long) (((unsigned long long) g * s->width) % s->colour_lookup_width)];

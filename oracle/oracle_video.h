@@ -47,6 +47,10 @@ int orc_teletext_packets(orc_t *s, long frame_index, const uint8_t *packets, uin
 /* the pixel aspect ratio of the current source frame (only --wss auto looks at it) */
 void orc_set_frame_aspect(orc_t *s, long long par_num, long long par_den);
 
+/* --raw-bb-file (conf.raw_bb): the external int16 baseband stream, kept by reference; read line by
+ * line, starting over at its end (src/video.c:2419-2429) */
+void orc_set_rawbb(orc_t *s, const int16_t *samples, long nsamples);
+
 /* --cc608: the caption byte pair of a frame (0-based stream frame index); frames without a call send zeros */
 void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2);
 

@@ -32,6 +32,8 @@ def lib():
         L.orc_last_widths.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_frame_aspect.restype = None
         L.orc_set_frame_aspect.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong]
+        L.orc_set_rawbb.restype = None
+        L.orc_set_rawbb.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_cc608.restype = None
         L.orc_set_cc608.argtypes = [C.c_void_p, C.c_long, C.c_uint8, C.c_uint8]
         L.orc_set_passthru.restype = None
@@ -120,6 +122,11 @@ class Oracle:
 
     def set_frame_aspect(self, num, den):
         lib().orc_set_frame_aspect(self.p, num, den)
+
+    def set_rawbb(self, samples):
+        a = np.ascontiguousarray(samples, np.int16)
+        self._keep.append(a)
+        lib().orc_set_rawbb(self.p, a.ctypes.data, a.shape[0])
 
     def set_cc608(self, frame_index, c1, c2):
         lib().orc_set_cc608(self.p, frame_index, c1, c2)

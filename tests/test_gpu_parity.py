@@ -17,6 +17,10 @@ def _render(conf, sr, frame, audio, nframes, batch=None, interlaced=0, teletext=
     with H.Engine(conf, sr, device=0, max_frames=batch, pixel_rate=pixel_rate) as e:
         e.frame_upload(0, frame, interlaced)
         e.frame_aspect(0, 12, 13)        # the test source: 4:3 on 832 x 576 (src/av_test.c:50)
+        if conf.raw_bb:
+            raw = util.rawbb_signal()
+            need = (nframes + 1) * e.info["frame_samples"]
+            e.rawbb_write(np.tile(raw, need // len(raw) + 1))       # the file starts over at its end
         if passthru is not None:
             e.passthru_write(passthru)
         done = 0
@@ -55,7 +59,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
                                   "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv",
-                                  "l_fid", "secam_fid4"])
+                                  "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -236,8 +240,9 @@ def test_dropin_binary_equals_reference_cli(golden):
         return bytes(out)
 
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
+    util.rawbb_signal().tofile("/tmp/hvk_rawbb.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
-                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid"):
+                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid", "i_rawbb"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4

@@ -16,7 +16,7 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
 CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
-CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4"]
+CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass"]
 
 
@@ -32,6 +32,8 @@ def test_oracle_stream_matches_reference_cli(golden, case):
         o.set_audio(golden.audio, True)
         if conf.passthru:
             o.set_passthru(util.passthru_signal())
+        if conf.raw_bb:
+            o.set_rawbb(util.rawbb_signal())
         if c.get("teletext"):
             for f in range(nframes + 1):
                 o.teletext_packets(f, *golden.teletext_rows(f, golden.teletext_skip(case)))

@@ -18,6 +18,17 @@ TABLE_DTYPES = {
 }
 
 
+def rawbb_signal(nsamples=700 * 1024 + 311):
+    """The external baseband stream of the --raw-bb-file cases: a fixed integer pattern (levels 2000 ..
+    21000, with excursions below and above), a little more than one PAL frame, not a whole number of
+    lines -- so the reference's rewind falls inside a line."""
+    n = np.arange(nsamples, dtype=np.int64)
+    v = 2000 + (n * 37) % 19001
+    v[(n % 1024) < 75] = 300          # something like a sync tip
+    v[(n % 4099) == 0] = 32000
+    return v.astype(np.int16)
+
+
 def passthru_signal(nsamples=1600300):
     """The external I/Q signal of the --passthru cases: a fixed integer pattern (int16 pairs), 2.5 PAL
     frames and a bit long so that runs end inside it -- in the middle of a line."""
@@ -83,7 +94,7 @@ class Golden:
 
     def cli_flags(self, case, passfile="/tmp/hvk_passthru.bin"):
         """The reference CLI's flags for the case; passthru cases expect passthru_signal() at `passfile`."""
-        return [f.replace("@TTRAW@", os.path.join(GOLD, "ttraw.bin")).replace("@PASS@", passfile)
+        return [f.replace("@TTRAW@", os.path.join(GOLD, "ttraw.bin")).replace("@PASS@", passfile).replace("@RAWBB@", "/tmp/hvk_rawbb.bin")
                 for f in self.cases[case]["cli_flags"]]
 
 
