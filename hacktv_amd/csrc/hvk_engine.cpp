@@ -1043,6 +1043,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.S = e->d_S;
 	ra.C = e->d_C;
 	ra.nframes = e->staged;
+	ra.secam_fid = e->t.conf.secam_field_id != 0;
 	ra.first_frame = e->staged_first;
 	ra.frame_stride = e->staged_stride;
 

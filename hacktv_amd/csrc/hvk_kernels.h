@@ -38,6 +38,7 @@ typedef struct {
 	int16_t *S;                 /* [nframes][lines + 2][width] */
 	int16_t *C;                 /* --s-video: the sub-carrier, same geometry */
 	int nframes;
+	int secam_fid;              /* SECAM field identification lines are switched on */
 	int64_t first_frame, frame_stride;
 } hvk_raster_args_t;
 

@@ -153,7 +153,7 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
  *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
  *   V  [CL]  a lane's FIR window starts at its own first sample index
  * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
-template<int NT, int SECAM, int SV>
+template<int NT, int SECAM, int SV, int EXTRAS>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
@@ -217,8 +217,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 
 	/* a VBI data line (teletext packet, WSS, VITC: the host lists them per frame), an insertion test signal */
 	int vbi_op = -1, vits_i = -1;
-	if(k.vbi && own) vbi_op = __builtin_amdgcn_readfirstlane((int) vbi_map[(size_t) blockIdx.y * k.lines + line0]);
-	if(k.vits && own)
+	if(EXTRAS && k.vbi && own) vbi_op = __builtin_amdgcn_readfirstlane((int) vbi_map[(size_t) blockIdx.y * k.lines + line0]);
+	if(EXTRAS && k.vits && own)
 	{
 		for(int i = 0; i < 4; i++) if(i < k.vits && line0 == k.vits_line[i]) vits_i = i;
 	}
@@ -234,7 +234,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if(vy < 0 || vy >= f.fb_height || !own || !f.fb_valid) vy = -1;
 
 	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
-	const bool active = !k.rawbb && d.ar > d.al;    /* raw baseband input: no picture is drawn */
+	const bool active = !(EXTRAS && k.rawbb) && d.ar > d.al;    /* raw baseband input: no picture is drawn */
 	const bool has_pix = active && vy >= 0;
 	int ax0 = d.al > px0 ? d.al : px0;                          /* samples that show a source pixel */
 	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
@@ -315,7 +315,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if(pal || has_pix) __syncthreads();
 
 	/* SECAM: picture lines and field identification lines carry the sub-carrier and get the luma notch */
-	const bool sc_line = SECAM && (active || d.secam_fid);
+	const bool sc_line = SECAM && (active || (EXTRAS && d.secam_fid));
 	if(x0 >= W && !sc_line && vbi_op < 0) return;
 
 	/* ---- 8 consecutive samples per lane ---- */
@@ -327,7 +327,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 #pragma unroll
 	for(int i = 0; i < SPL; i++) { s[i] = k.blanking; cq[i] = 0; }
 
-	if(k.rawbb)
+	if(EXTRAS && k.rawbb)
 	{
 		/* raw baseband input (src/video.c:2431-2436): the line is taken from the external stream
 		 * (`chroma` holds it, slab layout) and mapped from its levels onto the mode's; C integer
@@ -1173,17 +1173,28 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-template<int NT, int SECAM, int SV>
-static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
+template<int NT, int SECAM, int SV, int EXTRAS>
+static int _launch_raster1(const hvk_raster_args_t *a, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->C, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+/* The plain kernels carry none of the optional stages (VBI data lines, insertion test signals, raw
+ * baseband input, SECAM field identification): a render that uses none of them -- the benchmark
+ * configuration among them -- does not pay their wave-uniform tests either */
+template<int NT, int SECAM, int SV>
+static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
+{
+	const bool extras = a->k.vbi || a->k.vits || a->k.rawbb || (SECAM && a->secam_fid);
+	if(SV || extras) return(_launch_raster1<NT, SECAM, SV, 1>(a, stream));
+	return(_launch_raster1<NT, SECAM, SV, 0>(a, stream));
 }
 
 extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
