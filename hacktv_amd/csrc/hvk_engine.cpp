@@ -175,7 +175,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	if((r = hvk_tables_build(&e->t, conf, sample_rate, pixel_rate)) != HVK_OK) { hvk_close(e); return(r); }
 
-	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));   /* tools/ablate.py: results are WRONG when set */
+	/* tools/ablate.py: only a library built with ABLATE=1 has the switches in its kernels; results are WRONG when set */
+	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));
 
 	if(e->t.k.colour) _pack_taps(&e->ctaps, e->t.chroma_taps, e->t.k.chroma_ntaps);
 	if(e->t.k.vf_type) _pack_taps(&e->itaps, e->t.vf_itaps, e->t.k.vf_ntaps);

@@ -57,6 +57,13 @@ typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
 
 #define SPL HVK_SPL
+
+/* Profiling switches (tools/ablate.py): stages can be skipped to time the rest -- with WRONG output.
+ * Compiled in only with -DHVK_ENABLE_ABLATE=1 (make -C hacktv_amd/csrc ABLATE=1); a normal build has none. */
+#ifndef HVK_ENABLE_ABLATE
+#define HVK_ENABLE_ABLATE 0
+#endif
+#define ABLATE(bit) (HVK_ENABLE_ABLATE && (k.ablate & (bit)))
 #define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
 #define HVK_TILES_PER_WG 1    /* consecutive filter tiles walked by one workgroup (4 measured 10 % slower: fewer independent workgroups to overlap) */
 
@@ -250,7 +257,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int c[SPL];
 #pragma unroll
 	for(int i = 0; i < SPL; i++) c[i] = 0;
-	if((pal || (vits_i >= 0 && k.colour)) && x0 < W && !(k.ablate & 4))
+	if((pal || (vits_i >= 0 && k.colour)) && x0 < W && !ABLATE(4))
 	{
 		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
 		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
@@ -280,7 +287,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if(has_pix && !(k.ablate & 8))
+	if(has_pix && !ABLATE(8))
 	{
 		/* all row reads are issued before the first table look-up, all look-ups
 		 * before the first LDS write: the two dependent global loads per pixel are
@@ -295,7 +302,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			rgb[i] = x < ax1 ? (row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu) : 0u;
 		}
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = (k.ablate & 1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i]];
+		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i]];
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
@@ -398,7 +405,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		/* zero-history low pass of both channels (src/fir.c:357-375), >> 15 and
 		 * clamp by the saturating pack. All-zero input (no picture on this line)
 		 * only matters where the ghost samples reach. */
-		if((has_pix || x0 + SPL + H > W) && !(k.ablate & 2))
+		if((has_pix || x0 + SPL + H > W) && !ABLATE(2))
 		{
 			constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
 			int du[ND], dv[ND], u[SPL], v[SPL];
@@ -619,7 +626,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		}
 	}
 
-	if((k.ablate & 128) && s[0] != 12345) return;   /* profiling: no store */
+	if(ABLATE(128) && s[0] != 12345) return;   /* profiling: no store */
 	if(x0 + SPL <= W)
 	{
 		int4v o;
@@ -686,7 +693,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	/* four copies of the NICAM pulse table, copy s shifted left by s entries, so that
 	 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts instead of
 	 * the 8-way of dword reads at a 32-byte lane stride); staged once per workgroup */
-	if(k.has_nicam && !(k.ablate & 16))
+	if(k.has_nicam && !ABLATE(16))
 	{
 		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
 	}
@@ -859,7 +866,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		 * that is over (or a slot without a symbol) reads the zero tail of the table:
 		 * no branch. idx >= HVK_NICAM_BACK - 1 by construction. */
 #pragma unroll 1
-		for(int b = 0; b < ((k.ablate & 32) ? 0 : HVK_NICAM_BACK); b++)
+		for(int b = 0; b < (ABLATE(32) ? 0 : HVK_NICAM_BACK); b++)
 		{
 			const int4v en = sym_ent[idx - b];
 			int base = x0 + en.x;                                   /* >= 1 */
@@ -877,7 +884,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
 		else cp %= k.nicam_cc_len;
 		/* mixer: the two rows of the rotation, (i, -q) and (q, i), tabulated */
-		if(!(k.ablate & 64))
+		if(!ABLATE(64))
 		{
 		const int4u a0 = ((const int4u *) (nicam_cca + cp))[0], a1 = ((const int4u *) (nicam_cca + cp))[1];
 		const int4u q0 = ((const int4u *) (nicam_ccb + cp))[0], q1 = ((const int4u *) (nicam_ccb + cp))[1];

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/ablate.py -- per-kernel time of the two kernels for configurations that
-switch stages off (HIP events on the launch stream). Run on the GPU box."""
+switch stages off (HIP events on the launch stream). Run on the GPU box. The stage switches need a
+library built with them: `make -C hacktv_amd/csrc clean all ABLATE=1` (the `modes` table does not)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
