@@ -160,7 +160,7 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
  *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
  *   V  [CL]  a lane's FIR window starts at its own first sample index
  * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
-template<int NT, int SECAM, int SV, int EXTRAS>
+template<int NT, int SECAM, int SV, int EXTRAS, int WC>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
@@ -194,8 +194,11 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if((int) blockIdx.x >= k.slab_lines) return;
 
 	constexpr int H = NT / 2;
-	const int W = k.width;
+	/* WC: the line width when it is known at compile time (1024: PAL at 16 Msps) -- every lane then
+	 * holds 8 samples inside the line and the per-sample range tests fold away */
+	const int W = WC ? WC : k.width;
 	const int t = threadIdx.x;
+	if(WC) __builtin_assume(t * SPL + SPL <= WC);
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
 	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
@@ -660,7 +663,7 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 }
 
 
-template<int NT, int VF, int SV>
+template<int NT, int VF, int SV, int EXACT>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL)
 void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_packed_taps_t itaps,
@@ -718,7 +721,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		for(int i = 0; i < PASSES; i++)
 		{
 			const int q = t + i * (HVK_TILE / HVK_SPL);
-			v[i] = (q < NWIN / 2 && q < limit) ? src[q] : 0;
+			v[i] = (q < NWIN / 2 && (EXACT || q < limit)) ? src[q] : 0;
 		}
 #pragma unroll
 		for(int i = 0; i < PASSES; i++)
@@ -731,7 +734,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	/* the serial-carrier samples of this lane, fetched now so the read overlaps the filter */
 	const int nl = n0 + x0;
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
-	if(k.has_carriers && nl + SPL <= FS)
+	if(k.has_carriers && (EXACT || nl + SPL <= FS))
 	{
 		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
 		car0 = c[0];
@@ -812,7 +815,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		/* no filter: the raster goes straight to I, Q = 0 */
 		const int16_t *p = slab + n;
 #pragma unroll
-		for(int i = 0; i < SPL; i++) o[i] = (n + i < FS) ? ((int) p[i] & 0xFFFF) : 0;
+		for(int i = 0; i < SPL; i++) o[i] = (EXACT || n + i < FS) ? ((int) p[i] & 0xFFFF) : 0;
 	}
 
 	if(SV)
@@ -826,7 +829,9 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	const size_t cbase = (size_t) blockIdx.y * FS + n;
 	const size_t obase = (size_t) blockIdx.y * out_stride * FS + n;
-	const bool whole = n + SPL <= FS;
+	/* EXACT: the frame is a whole number of tiles (and the slab reaches a window's length past it):
+	 * every lane's 8 outputs are inside the frame and the tail handling folds away */
+	const bool whole = EXACT || n + SPL <= FS;
 
 	/* serial carriers (FM / AM sound), computed on the host: a plain add of
 	 * int16 pairs with wrap-around (src/video.c:3431-3432) */
@@ -1180,17 +1185,25 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-template<int NT, int SECAM, int SV, int EXTRAS>
-static int _launch_raster1(const hvk_raster_args_t *a, hipStream_t stream)
+template<int NT, int SECAM, int SV, int EXTRAS, int WC>
+static int _launch_raster2(const hvk_raster_args_t *a, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
 	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->C, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+template<int NT, int SECAM, int SV, int EXTRAS>
+static int _launch_raster1(const hvk_raster_args_t *a, hipStream_t stream)
+{
+	/* the plain PAL kernel at 1024 samples per line gets the width as a constant */
+	if(!SECAM && !SV && !EXTRAS && NT == 13 && a->k.width == 1024) return(_launch_raster2<NT, SECAM, SV, EXTRAS, (!SECAM && !SV && !EXTRAS && NT == 13) ? 1024 : 0>(a, stream));
+	return(_launch_raster2<NT, SECAM, SV, EXTRAS, 0>(a, stream));
 }
 
 /* The plain kernels carry none of the optional stages (VBI data lines, insertion test signals, raw
@@ -1235,14 +1248,23 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	return(HVK_UNSUPPORTED);
 }
 
-template<int NT, int VF, int SV>
-static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
+template<int NT, int VF, int SV, int EXACT>
+static int _launch_filter2(const hvk_filter_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
+	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV, EXACT>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
 	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
 	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, a->C, (int *) a->iq, a->out_stride, tiles);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+template<int NT, int VF, int SV>
+static int _launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
+{
+	/* whole tiles only, and at least a window's length of slab behind the frame */
+	const bool exact = a->k.frame_samples % HVK_TILE == 0 && a->k.s_stride - a->k.s_lead - a->k.frame_samples >= 128;
+	if(exact) return(_launch_filter2<NT, VF, SV, 1>(a, stream));
+	return(_launch_filter2<NT, VF, SV, 0>(a, stream));
 }
 
 extern "C" int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
