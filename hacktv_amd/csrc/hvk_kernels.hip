@@ -373,7 +373,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 				const int idx = x0 + i - off;
 				/* a pulse never crosses into the following line; the part of
 				 * the own left pulse before sample 0 belongs to the previous line */
-				if(idx >= 0 && idx < len && x0 + i < W) s[i] = wrap16(s[i] + v[idx]);
+				/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
+				if(idx >= 0 && idx < len && x0 + i < W) s[i] = SECAM ? wrap16(s[i] + v[idx]) : s[i] + v[idx];
 			}
 		}
 	}
@@ -467,7 +468,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		else
 		{
 #pragma unroll
-			for(int i = 0; i < SPL; i++) s[i] = wrap16(s[i] + (dot2(c[i], vu[i], 0) >> 15));
+			for(int i = 0; i < SPL; i++) s[i] = s[i] + (dot2(c[i], vu[i], 0) >> 15);   /* modulo 2^16 at the store (no SECAM here: pal is 0 there) */
 		}
 	}
 
