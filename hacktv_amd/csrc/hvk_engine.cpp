@@ -178,6 +178,24 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	/* tools/ablate.py: only a library built with ABLATE=1 has the switches in its kernels; results are WRONG when set */
 	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));
 
+	/* the kernels exist for these chroma filter lengths (pixel rates of about 11 to 28 MHz) and for
+	 * the NICAM pulse lengths the LDS table holds: say so now, not at the first render */
+	if(e->t.k.colour)
+	{
+		const int nt = e->t.k.chroma_ntaps;
+		if(nt != 9 && nt != 11 && nt != 13 && nt != 15 && nt != 17 && nt != 21)
+		{
+			fprintf(stderr, "libhvk: no raster kernel for a %d-tap chroma filter (pixel rate %d Hz)\n", nt, e->t.pixel_rate);
+			hvk_close(e);
+			return(HVK_UNSUPPORTED);
+		}
+	}
+	if(e->t.k.has_nicam && HVK_NICAM_LEAD + e->t.k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD)
+	{
+		fprintf(stderr, "libhvk: the NICAM pulse (%d taps at %d Hz) does not fit the kernel's table\n", e->t.k.nicam_ntaps, e->t.sample_rate);
+		hvk_close(e);
+		return(HVK_UNSUPPORTED);
+	}
 	if(e->t.k.colour) _pack_taps(&e->ctaps, e->t.chroma_taps, e->t.k.chroma_ntaps);
 	if(e->t.k.vf_type) _pack_taps(&e->itaps, e->t.vf_itaps, e->t.k.vf_ntaps);
 	if(e->t.k.vf_type == 3) _pack_taps(&e->qtaps, e->t.vf_qtaps, e->t.k.vf_ntaps);

@@ -533,6 +533,17 @@ void hvk_k_raster(const hvk_kconst_t k,
 				else s[i] = wrap16(s[i] + cs);
 			}
 		}
+		else if(own && x0 < W)
+		{
+			/* the last, partial group of a line whose width is not a multiple of 8 */
+			const int16_t *cp = chroma + (size_t) blockIdx.y * k.raster_samples + (size_t) rel * W + x0;
+			for(int i = 0; i < SPL; i++)
+			{
+				if(x0 + i >= W) break;
+				if(SV) cq[i] = cp[i];
+				else s[i] = wrap16(s[i] + cp[i]);
+			}
+		}
 	}
 
 	if(vits_i >= 0 && x0 < W)

@@ -1268,6 +1268,13 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	if(c->colour_mode == HVK_SECAM && (r = _build_secam(t, level)) != HVK_OK) return(r);
 
+	/* SECAM's luma notch runs over the active picture and looks 25 samples past its right edge
+	 * (src/video.c:3206, src/fir.c:365-372). At pixel rates where that reaches beyond the line
+	 * (13.5 MHz: 140 + 702 + 25 > 864) the reference reads behind its line buffer -- whatever the
+	 * heap holds there. There is nothing to be exact to: refused. (S-Video has no notch.) */
+	if(c->colour_mode == HVK_SECAM && !c->s_video && !c->raw_bb &&
+	   t->k.active_left + t->k.active_width + 25 > t->k.width) return(HVK_UNSUPPORTED);
+
 	hvk_tables_default_ghost(t);
 
 	/* video filter (src/video.c:3653-3764) */

@@ -453,3 +453,33 @@ def test_frame_numbers_far_beyond_32_bits_of_samples(golden):
         c = e.fetch(0, 4 * fs)
     assert np.array_equal(b, c)
     assert np.array_equal(a[64:], c[64:]) and not np.array_equal(a[:64], c[:64])
+
+
+@pytest.mark.parametrize("mode,sr", [("i", 17734475), ("m", 14318181), ("l", 17734475),
+                                     ("i", 12000000), ("i", 14000000), ("i", 27000000), ("g", 18000000), ("pal", 15000000),
+                                     ("m", 12272727), ("m", 27000000), ("ntsc", 18000000),
+                                     ("l", 20250000), ("l", 27000000), ("secam", 18000000)])
+def test_odd_line_widths(golden, mode, sr):
+    """A sweep over sample rates: every chroma filter length that has a kernel (9 .. 21 taps), lines from
+    768 to 1728 samples. 4 x the colour sub-carrier gives lines of 1135 (PAL) and 910 (NTSC) samples: odd,
+    or not a multiple of 8; slab rows then start on odd int16 offsets. Device against the oracle (the
+    reference's heap over-read is not modelled for these widths, so this pins the device to the oracle only)."""
+    # at 27 MHz the NICAM pulse is longer than the kernel's table: FM / AM sound only there
+    conf = H.preset(mode, H.FLAG_FILTER | (H.FLAG_NONICAM if sr >= 27000000 else 0))
+    n = 2
+    with oracle.Oracle(conf, sr) as o:
+        w, h, L, W = o.info["active_width"], o.info["active_lines"], o.info["lines"], o.info["width"]
+        rng = np.random.default_rng(W)
+        frame = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+        o.set_frame(frame)
+        o.set_audio(golden.audio, True)
+        want = o.render_lines(n * L)
+    with H.Engine(conf, sr, device=0, max_frames=n) as e:
+        assert e.info["width"] == W
+        e.frame_upload(0, frame)
+        while e.audio_needed(n) > 0:
+            e.audio_write(golden.audio)
+        e.render(n)
+        got = e.fetch(0, n * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "W = %d: first difference at line %d x %d" % (W, bad[0] // W, bad[0] % W)
