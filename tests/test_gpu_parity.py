@@ -483,3 +483,61 @@ def test_odd_line_widths(golden, mode, sr):
         got = e.fetch(0, n * e.info["frame_samples"])
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "W = %d: first difference at line %d x %d" % (W, bad[0] // W, bad[0] % W)
+
+
+@pytest.mark.parametrize("mode,sr,pr,members", [
+    ("i", 13500000, 0, {"vits": 1, "vitc": 1, "wss": 0x0B, "acp": 1, "cc608": 1, "teletext": 1}),
+    ("i", 20250000, 0, {"vits": 1, "vitc": 1, "wss": 0xFF, "acp": 1, "cc608": 1, "teletext": 1}),
+    ("m", 16000000, 0, {"vits": 1, "vitc": 1, "acp": 1, "cc608": 1}),                  # 1017-sample lines
+    ("l", 20250000, 0, {"vits": 1, "vitc": 1, "wss": 0x07, "secam_field_id": 1, "teletext": 1}),
+    ("pal-fm", 20250000, 0, {"offset": 750000, "swap_iq": 1}),
+    ("ntsc-fm", 14318181, 0, {}),
+    ("i", 16000000, 12000000, {"vits": 1, "teletext": 1}),                             # up 4 / 3
+    ("i", 16000000, 18000000, {"wss": 0x08, "vitc": 1}),                               # down 8 / 9
+    ("g", 20250000, 13500000, {"a2stereo": 1}),                                        # up 3 / 2
+    ("secam", 16000000, 20250000, {"secam_field_id": 1, "secam_field_id_lines": 5}),   # down 64 / 81
+    ("pal", 13500000, 0, {"s_video": 1, "vits": 1}),
+    ("i", 14000000, 0, {"interlace": 1, "acp": 1}),
+])
+def test_options_at_other_rates(golden, mode, sr, pr, members):
+    """The optional stages away from 16 MHz (their tables scale with the pixel rate: symbol widths,
+    pulse positions, the resampler's phases) with random pictures and teletext packets: device against
+    the oracle."""
+    conf = H.preset(mode, H.FLAG_FILTER if not mode.endswith("-fm") and not members.get("s_video") else 0)
+    for k, v in members.items():
+        setattr(conf, k, v)
+    n = 2
+    rng = np.random.default_rng(sr % 1000 + len(members))
+    with oracle.Oracle(conf, sr, pr) as o:
+        w, h, L = o.info["active_width"], o.info["active_lines"], o.info["lines"]
+        frames = rng.integers(0, 1 << 24, (4, h, w), dtype=np.uint32)
+        packets = rng.integers(0, 256, (n, 32, 45), dtype=np.int64).astype(np.uint8)
+        masks = [0x00FF00FF, 0xFFFFFFFF]
+        o.set_audio(golden.audio, True)
+        want = []
+        for f in range(n):
+            o.set_frame(frames[2 * f])
+            if members.get("interlace"):
+                o.set_frame2(frames[2 * f + 1])
+            o.set_frame_aspect(16, 11)
+            if members.get("teletext"):
+                o.teletext_packets(f, packets[f], masks[f])
+            o.set_cc608(f, 0x41 + f, 0x62)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=n, pixel_rate=pr) as e:
+        for s_ in range(4):
+            e.frame_upload(s_, frames[s_])
+            e.frame_aspect(s_, 16, 11)
+        while e.audio_needed(n) > 0:
+            e.audio_write(golden.audio)
+        for f in range(n):
+            if members.get("teletext"):
+                e.teletext_packets(f, packets[f], masks[f])
+            if members.get("cc608"):
+                e.cc608_write(f, 0x41 + f, 0x62)
+        e.render(n, slots=[0, 1, 2, 3] if members.get("interlace") else [0, 2])
+        got = e.fetch(0, n * e.info["frame_samples"])
+    assert got.shape == want.shape
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first difference at sample %d of %d (%d differ)" % (bad[0], len(got), bad.size)
