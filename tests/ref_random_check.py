@@ -35,6 +35,12 @@ SETUPS = {
     "i_px_moving": ("i", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {}, 3, 13500000),
     "palfm_loud":  ("pal-fm", 16000000, 0, 0, {}, 2),
     "secamfm_mov": ("secam-fm", 16000000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 2),
+    # away from 16 MHz: the inserters' tables, NICAM and the rasters scale with the rate
+    "i_vbi_135":   ("i", 13500000, R.FLAG_FILTER | R.FLAG_CC608 | R.FLAG_ACP | R.FLAG_VITS | R.FLAG_VITC | R.FLAG_WSS_AUTO, H.FLAG_FILTER,
+                    {"cc608": 1, "acp": 1, "vits": 1, "vitc": 1, "wss": 0xFF}, 2),
+    "m_16m":       ("m", 16000000, R.FLAG_FILTER | R.FLAG_VITS | R.FLAG_VITC, H.FLAG_FILTER, {"vits": 1, "vitc": 1}, 2),    # 1017-sample lines
+    "l_2025":      ("l", 20250000, R.FLAG_FILTER | R.FLAG_VITS, H.FLAG_FILTER, {"vits": 1}, 2),
+    "g_a2_2025":   ("g", 20250000, R.FLAG_FILTER | R.FLAG_A2STEREO, H.FLAG_FILTER, {"a2stereo": 1}, 2),
     # 44 frames: the anti-copy AGC level starts to move at frame 39; time code minutes stay 0 but seconds tick
     "i_acp_long":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_VITC, H.FLAG_NOAUDIO, {"acp": 1, "vitc": 1}, 44),
 }
