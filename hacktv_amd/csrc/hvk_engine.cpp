@@ -82,7 +82,10 @@ struct hvk_engine {
 	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_ccb;
 	/* per batch */
 	uint32_t *d_pool;
-	hvk_framedesc_t *d_fdesc;
+	hvk_framedesc_t *d_fdesc;   /* [max_frames][1 + fields]: the frame before (only its last line is looked at:
+	                             * the halo line in front), then one descriptor per field */
+	/* the last line's source row of the last frame staged, kept behind the slots: the next batch's first halo */
+	hvk_framedesc_t carry; int carry_valid; int64_t carry_frame;
 	int16_t *d_S;
 	int16_t *d_C;           /* --s-video: the sub-carrier slab */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
@@ -294,9 +297,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots));
-	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots));
-	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 2));
+	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4));   /* + the carry row */
+	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4));
+	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.rs_L)
@@ -305,7 +308,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_rs_taps, e->t.rs_taps, sizeof(int16_t) * k.rs_L * k.rs_ataps));
 	}
 	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
-	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames * 2, hipHostMallocDefault));
+	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3, hipHostMallocDefault));
 	OPENHIP(hipHostMalloc((void **) &e->h_frame, frame_px * 4, hipHostMallocDefault));
 
 	if(e->t.k.has_carriers)
@@ -721,7 +724,7 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 		{
 			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where
 			 * VITS holds the line (src/acp.c:93-108); the AGC level moves with the frame number */
-			const int frame = (int) (e->h_fdesc[(size_t) i * t.k.fields].frame_index + 1);
+			const int frame = (int) (e->h_fdesc[(size_t) i * (t.k.fields + 1) + 1].frame_index + 1);
 			const int agc = hvk_acp_agc_level(&t, frame);
 			const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
 			const int count = lines == 625 ? 10 : 8;
@@ -751,7 +754,7 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 
 		if(t.conf.vitc)
 		{
-			const int frame = (int) (e->h_fdesc[(size_t) i * t.k.fields].frame_index + 1);
+			const int frame = (int) (e->h_fdesc[(size_t) i * (t.k.fields + 1) + 1].frame_index + 1);
 			const int vl[4] = { t.vitc_lines[0], t.vitc_lines[0] + 2, t.vitc_lines[1], t.vitc_lines[1] + 2 };
 			for(int q = 0; q < 4; q++)
 			{
@@ -863,7 +866,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 
 	for(int i = 0; i < nframes; i++)
 	{
-		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * fields];
+		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * (fields + 1) + 1];
 		const int slot = slots ? slots[(size_t) i * fields] : 0;
 		const int slot2 = (slots && fields == 2) ? slots[(size_t) i * fields + 1] : slot;
 		if(slot < 0 || slot >= e->frame_slots || slot2 < 0 || slot2 >= e->frame_slots) return(HVK_ERROR);
@@ -976,7 +979,44 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		}
 	}
 
-	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * fields, hipMemcpyHostToDevice, e->stream));
+	/* The frame before each frame: the one staged just before it, the last frame of the batch before
+	 * (its last line's source row was kept), nothing at the start of the stream. A strided render does
+	 * not have the frames in between: it takes the frame's own picture, which is right for a picture
+	 * that does not change and wrong by up to the filter's reach (25 samples) otherwise. */
+	for(int i = 0; i < nframes; i++)
+	{
+		hvk_framedesc_t *p = &e->h_fdesc[(size_t) i * (fields + 1)];
+		const hvk_framedesc_t *own = &e->h_fdesc[(size_t) i * (fields + 1) + fields];
+		if(stride != 1) *p = *own;
+		else if(i > 0) *p = e->h_fdesc[(size_t) (i - 1) * (fields + 1) + fields];
+		else if(e->carry_valid && e->carry_frame + 1 == first_frame) *p = e->carry;
+		else { memset(p, 0, sizeof(*p)); }
+		/* the colour table position the kernel counts lines from is this frame's, also on the halo line */
+		p->clut_off0 = own->clut_off0;
+		p->frame_index = own->frame_index;
+		p->parity = own->parity;
+	}
+	{
+		/* keep what the last frame of this batch shows on its last line */
+		const hvk_framedesc_t *last = &e->h_fdesc[(size_t) (nframes - 1) * (fields + 1) + fields];
+		const hvk_linedesc_t *d = &e->t.desc[(size_t) last->parity * k.lines + k.lines - 1];
+		int vy = d->src_row;
+		if(vy >= 0 && k.interlaced != 0 && last->fb_interlaced != k.interlaced) vy += 1;
+		vy -= last->vframe_y;
+		e->carry = *last;
+		e->carry_frame = last->frame_index;
+		e->carry_valid = 1;
+		if(d->ar > d->al && last->fb_valid && vy >= 0 && vy < last->fb_height)
+		{
+			const size_t carry_off = frame_px * e->frame_slots;
+			HIPCHK(hipMemcpyAsync(e->d_pool + carry_off, e->d_pool + last->fb_offset + (int64_t) vy * last->line_stride,
+			                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
+			e->carry.fb_offset = (int64_t) carry_off;
+			e->carry.line_stride = 0;       /* every row of the kept frame is that one row */
+		}
+		else e->carry.fb_valid = 0;
+	}
+	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
 	if(e->h_ops)
 	{
 		_build_vbi_ops(e, nframes);

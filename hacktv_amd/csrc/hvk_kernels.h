@@ -34,7 +34,7 @@ typedef struct {
 	const int16_t *burst_win;
 	const int16_t *ghost;
 	const uint32_t *pool;
-	const hvk_framedesc_t *fdesc;
+	const hvk_framedesc_t *fdesc;   /* [nframes][1 + fields]: the frame before (its last line is this frame's leading halo), then the fields */
 	int16_t *S;                 /* [nframes][lines + 2][width] */
 	int16_t *C;                 /* --s-video: the sub-carrier, same geometry */
 	int nframes;

@@ -179,7 +179,7 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const int16_t *__restrict__ burst_win,
                   const int16_t *__restrict__ ghost,
                   const uint32_t *__restrict__ pool,
-                  const hvk_framedesc_t *__restrict__ fdesc,
+                  const hvk_framedesc_t *__restrict__ fdesc,   /* [frames][1 + fields]: the frame before, then the fields */
                   int16_t *__restrict__ S,
                   int16_t *__restrict__ Cq,             /* --s-video: the sub-carrier alone, same slab geometry as S */
                   const int64_t first_frame,            /* frame y of the batch is stream frame first_frame + y * frame_stride */
@@ -202,8 +202,10 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
 	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
-	/* one descriptor per frame, or per field with --interlace: the second field shows its own source frame */
-	const hvk_framedesc_t &f = fdesc[blockIdx.y * k.fields + ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 1 : 0)];
+	/* one descriptor per frame, or per field with --interlace: the second field shows its own source
+	 * frame. The halo line in front is the last line of the frame BEFORE: on 525 lines it shows picture,
+	 * whose last samples the filter sees from this frame's first outputs. */
+	const hvk_framedesc_t &f = fdesc[blockIdx.y * (k.fields + 1) + (rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1))];
 	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
 
 	/* which line of which frame, without dividing the global line number */
@@ -241,7 +243,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int vy = d.src_row;
 	if(vy >= 0 && k.interlaced != 0 && f.fb_interlaced != k.interlaced) vy += 1;
 	vy -= f.vframe_y;
-	if(vy < 0 || vy >= f.fb_height || !own || !f.fb_valid) vy = -1;
+	if(vy < 0 || vy >= f.fb_height || !(own || rel < 0) || !f.fb_valid) vy = -1;
 
 	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
 	const bool active = !(EXTRAS && k.rawbb) && d.ar > d.al;    /* raw baseband input: no picture is drawn */
@@ -262,7 +264,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	for(int i = 0; i < SPL; i++) c[i] = 0;
 	if((pal || (vits_i >= 0 && k.colour)) && x0 < W && !ABLATE(4))
 	{
-		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
+		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;   /* (fprev[] carries THIS frame's position) */
 		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
 		const int *cl = clut + coff + x0;
 		if(x0 + SPL <= W)

@@ -541,3 +541,77 @@ def test_options_at_other_rates(golden, mode, sr, pr, members):
     assert got.shape == want.shape
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "first difference at sample %d of %d (%d differ)" % (bad[0], len(got), bad.size)
+
+
+def test_batching_and_striding_with_options(golden):
+    """Frame-number and stream-position dependent options (VITC, ACP's moving level, the offset phasor,
+    passthru, NICAM) rendered in one batch, in uneven batches, and as two engines taking alternate frames
+    (as two GPUs would): the same stream each time."""
+    conf = H.preset("i", H.FLAG_FILTER)
+    conf.vitc = conf.acp = conf.vits = 1
+    conf.offset = 1234567
+    conf.passthru = 1
+    sr, n = 16000000, 6
+    frame = golden.frame("i_full")
+    sig = util.passthru_signal(8 * 640000 + 1024)
+
+    def feed(e):
+        e.frame_upload(0, frame)
+        while e.audio_needed(n) > 0:
+            e.audio_write(golden.audio)
+        e.passthru_write(sig)
+
+    with H.Engine(conf, sr, device=0, max_frames=n) as e:
+        feed(e)
+        e.render(n)
+        fs = e.info["frame_samples"]
+        whole = e.fetch(0, n * fs)
+
+    with H.Engine(conf, sr, device=0, max_frames=3) as e:
+        feed(e)
+        parts = []
+        for b in (1, 3, 2):
+            e.render(b)
+            parts.append(e.fetch(0, b * fs))
+    assert np.array_equal(np.concatenate(parts), whole)
+
+    out = np.zeros_like(whole)
+    for r in range(2):
+        with H.Engine(conf, sr, device=0, max_frames=3) as e:
+            feed(e)
+            e.stage(r, 2, 3)            # frames r, r + 2, r + 4
+            e.launch()
+            mine = e.fetch(0, 3 * fs)
+        for i in range(3):
+            out[(r + 2 * i) * fs:(r + 2 * i + 1) * fs] = mine[i * fs:(i + 1) * fs]
+    assert np.array_equal(out, whole)
+
+
+@pytest.mark.parametrize("mode,sr,pr", [("m", 13500000, 0), ("l", 16000000, 0), ("i", 16000000, 13500000), ("ntsc", 18000000, 0)])
+def test_frame_geometry_in_other_modes(golden, mode, sr, pr):
+    """Small, oversized, one-pixel and missing source frames, progressive and both field orders, strided
+    views (a horizontally flipped and a vertically flipped frame): the centre crop of src/video.c:4887-4897
+    and the field-order row shift of :2888, in NTSC, SECAM and with the resampler, against the oracle."""
+    conf = H.preset(mode, H.FLAG_FILTER if mode in ("m", "l", "i") else 0)
+    rng = np.random.default_rng(sr % 977 + pr % 13)
+    with oracle.Oracle(conf, sr, pr) as o:
+        aw, ah, L = o.info["active_width"], o.info["active_lines"], o.info["lines"]
+        shapes = [(ah, aw, 0), (ah // 3, aw // 2, 0), (ah + 40, aw + 64, 1), (1, 1, 2), None, (ah, aw - 1, 2), (ah - 1, aw, 1)]
+        frames = [None if s is None else rng.integers(0, 1 << 24, s[:2], dtype=np.uint32) for s in shapes]
+        o.set_audio(golden.audio, True)
+        want = []
+        for s, f in zip(shapes, frames):
+            o.set_frame(f, interlaced=s[2] if s else 0)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    n = len(shapes)
+    with H.Engine(conf, sr, device=0, max_frames=n, pixel_rate=pr) as e:
+        for i, (s, f) in enumerate(zip(shapes, frames)):
+            e.frame_upload(i, f, interlaced=s[2] if s else 0)
+        while e.audio_needed(n) > 0:
+            e.audio_write(golden.audio)
+        e.render(n, slots=list(range(n)))
+        got = e.fetch(0, n * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    fs = len(want) // n
+    assert bad.size == 0, "frame %d (shape %s): first difference at sample %d" % (bad[0] // fs, shapes[bad[0] // fs], bad[0] % fs)
