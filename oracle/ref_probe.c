@@ -39,6 +39,18 @@ typedef struct {
 	long rendered;
 } ref_probe_t;
 
+/* Settings main() takes from --gamma / --level / --invert-video / --volume (src/hacktv.c:1179-1184,
+ * :1431-1432), applied by the NEXT ref_open(); 0 leaves the preset's value */
+static struct { double gamma, level; int invert, volume; } _override;
+
+void ref_override(double gamma, double level, int invert, int volume)
+{
+	_override.gamma = gamma;
+	_override.level = level;
+	_override.invert = invert;
+	_override.volume = volume;
+}
+
 ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int pixel_rate, int flags, const char *teletext)
 {
 	const vid_configs_t *vc;
@@ -85,6 +97,11 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 	if(flags & REF_FLAG_VITC) conf.vitc = 1;
 	if(teletext && teletext[0]) conf.teletext = (char *) teletext;
 	conf.volume = 1.0 * 256 + 0.5;
+	if(_override.gamma > 0) conf.gamma = _override.gamma;
+	if(_override.level > 0) conf.level *= _override.level;
+	if(_override.invert) conf.invert_video = 1;
+	if(_override.volume > 0) conf.volume = _override.volume;
+	memset(&_override, 0, sizeof(_override));
 
 	p = calloc(1, sizeof(ref_probe_t));
 	if(!p) return(NULL);

@@ -41,6 +41,10 @@ SETUPS = {
     "m_16m":       ("m", 16000000, R.FLAG_FILTER | R.FLAG_VITS | R.FLAG_VITC, H.FLAG_FILTER, {"vits": 1, "vitc": 1}, 2),    # 1017-sample lines
     "l_2025":      ("l", 20250000, R.FLAG_FILTER | R.FLAG_VITS, H.FLAG_FILTER, {"vits": 1}, 2),
     "g_a2_2025":   ("g", 20250000, R.FLAG_FILTER | R.FLAG_A2STEREO, H.FLAG_FILTER, {"a2stereo": 1}, 2),
+    # --gamma / --level / --invert-video / --volume (8th element: the probe's overrides, mirrored in the members)
+    "i_gamma_lvl": ("i", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {"gamma": 2.2, "level": 0.7, "volume": 700}, 2, 0, {"gamma": 2.2, "level": 0.7, "volume": 700}),
+    "m_invert":    ("m", 13500000, R.FLAG_FILTER, H.FLAG_FILTER, {"invert_video": 1, "volume": 64}, 2, 0, {"invert": 1, "volume": 64}),
+    "l_level":     ("l", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {"level": 0.5, "gamma": 0.45}, 2, 0, {"level": 0.5, "gamma": 0.45}),
     # 44 frames: the anti-copy AGC level starts to move at frame 39; time code minutes stay 0 but seconds tick
     "i_acp_long":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_VITC, H.FLAG_NOAUDIO, {"acp": 1, "vitc": 1}, 44),
 }
@@ -50,12 +54,13 @@ def main():
     name = sys.argv[1]
     mode, sr, pflags, hflags, members, nframes = SETUPS[name][:6]
     pixel_rate = SETUPS[name][6] if len(SETUPS[name]) > 6 else 0
+    override = SETUPS[name][7] if len(SETUPS[name]) > 7 else {}
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
     conf = H.preset(mode, hflags)
     for k, v in members.items():
         setattr(conf, k, v)
 
-    with R.RefProbe(mode, sr, pflags, pixel_rate=pixel_rate) as r:
+    with R.RefProbe(mode, sr, pflags, pixel_rate=pixel_rate, **override) as r:
         info = dict(r.info)
         w, h, L = info["active_width"], info["active_lines"], info["lines"]
         fields = 2 if members.get("interlace") else 1

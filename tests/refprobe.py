@@ -40,6 +40,8 @@ def lib():
         L.ref_open.restype = ctypes.c_void_p
         L.ref_open.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_char_p]
         L.ref_close.argtypes = [ctypes.c_void_p]
+        L.ref_override.restype = None
+        L.ref_override.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
         L.ref_set_source.restype = None
         L.ref_set_source.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
@@ -57,7 +59,9 @@ def lib():
 
 
 class RefProbe:
-    def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None):
+    def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None, gamma=0.0, level=0.0, invert=0, volume=0):
+        if gamma or level or invert or volume:
+            lib().ref_override(gamma, level, invert, volume)
         self.p = lib().ref_open(mode.encode(), sample_rate, pixel_rate, flags,
                                 teletext.encode() if teletext else None)
         if not self.p:

@@ -615,3 +615,84 @@ def test_frame_geometry_in_other_modes(golden, mode, sr, pr):
     bad = np.nonzero((got != want).any(axis=1))[0]
     fs = len(want) // n
     assert bad.size == 0, "frame %d (shape %s): first difference at sample %d" % (bad[0] // fs, shapes[bad[0] // fs], bad[0] % fs)
+
+
+@pytest.mark.parametrize("mode,members", [
+    ("i", {"invert_video": 1}), ("i", {"gamma": 2.2, "level": 0.7}), ("m", {"volume": 1024, "rw_co": 0.2126, "gw_co": 0.7152, "bw_co": 0.0722}),
+    ("l", {"level": 0.5, "volume": 64}), ("pal", {"gamma": 0.45, "invert_video": 1}), ("pal-fm", {"fm_deviation": 8e6, "level": 0.8}),
+])
+def test_level_gamma_volume_settings(golden, mode, members):
+    """--invert-video, --gamma, --level, --volume, --deviation and other luma weights: the tables they
+    change (levels, the 2^24-entry RGB table expanded on the device in FP64, sync pulses, sound levels),
+    with a random picture and loud audio, against the oracle."""
+    conf = H.preset(mode, H.FLAG_FILTER if not mode.endswith("-fm") else 0)
+    for k, v in members.items():
+        setattr(conf, k, v)
+    sr = 13500000 if mode == "m" else 16000000
+    rng = np.random.default_rng(len(mode) + len(members))
+    audio = rng.integers(-32768, 32768, (5000, 2), dtype=np.int64).astype(np.int16)
+    with oracle.Oracle(conf, sr) as o:
+        frame = rng.integers(0, 1 << 24, (o.info["active_lines"], o.info["active_width"]), dtype=np.uint32)
+        L = o.info["lines"]
+        o.set_frame(frame)
+        o.set_audio(audio, True)
+        want = o.render_lines(2 * L)
+        yuv = o.table("yuv", np.int16)
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        assert np.array_equal(e.table("yuv", np.int16), yuv)
+        e.frame_upload(0, frame)
+        while e.audio_needed(2) > 0:
+            e.audio_write(audio)
+        e.render(2)
+        got = e.fetch(0, 2 * e.info["frame_samples"])
+    assert np.array_equal(got, want)
+
+
+def test_audio_that_runs_dry_and_a_custom_ghost(golden):
+    """A source with too little audio (the rest is silence, src/video.c:3299-3304), none at all, and an
+    embedder's own over-read values (hvk_set_chroma_ghost): against the oracle."""
+    conf, sr = golden.conf("i_full")
+    frame = golden.frame("i_full")
+    L = golden.cases["i_full"]["lines"]
+    ghost = (np.arange(32, dtype=np.int16) * 997 - 12000).astype(np.int16)
+    for audio in (golden.audio[:900], None):
+        with oracle.Oracle(conf, sr) as o:
+            o.set_ghost(ghost)
+            o.set_frame(frame)
+            if audio is not None:
+                o.set_audio(audio, False)
+            want = o.render_lines(2 * L)
+        with H.Engine(conf, sr, device=0, max_frames=2) as e:
+            e.set_chroma_ghost(ghost)
+            e.frame_upload(0, frame)
+            if audio is not None:
+                e.audio_write(audio)
+            e.render(2)
+            got = e.fetch(0, 2 * e.info["frame_samples"])
+        assert np.array_equal(got, want)
+
+
+def test_strided_source_views(golden):
+    """hvk_frame_upload takes pixel and line strides of either sign (what av_hflip_frame / av_vflip_frame
+    leave behind, src/av.c:240-262): a mirrored, an upside-down and a column-subsampled view of one buffer
+    against the oracle given the same pictures as plain arrays."""
+    import ctypes as C
+    conf, sr = golden.conf("i_vsb")
+    base = np.ascontiguousarray(np.random.default_rng(3).integers(0, 1 << 24, (576, 2 * 832), dtype=np.uint32))
+    L = golden.cases["i_vsb"]["lines"]
+    h, w2 = base.shape
+    views = [(base[:, :832][:, ::-1], base.ctypes.data + 4 * 831, 832, h, -1, w2),          # mirrored
+             (base[::-1, :832], base.ctypes.data + 4 * w2 * (h - 1), 832, h, 1, -w2),        # upside down
+             (base[:, ::2], base.ctypes.data, 832, h, 2, w2)]                                 # every other column
+    with oracle.Oracle(conf, sr) as o:
+        want = []
+        for arr, *_ in views:
+            o.set_frame(np.ascontiguousarray(arr))
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=3) as e:
+        for slot, (_, ptr, w, hh, ps, ls) in enumerate(views):
+            assert H.lib().hvk_frame_upload(e.h, slot, C.c_void_p(ptr), w, hh, ps, ls, 0) == 0
+        e.render(3, slots=[0, 1, 2])
+        got = e.fetch(0, 3 * e.info["frame_samples"])
+    assert np.array_equal(got, want)
