@@ -86,6 +86,7 @@ struct hvk_engine {
 	                             * the halo line in front), then one descriptor per field */
 	/* the last line's source row of the last frame staged, kept behind the slots: the next batch's first halo */
 	hvk_framedesc_t carry; int carry_valid; int64_t carry_frame;
+	int carry_row;              /* which of the two kept rows `carry` points at: the batch being staged reads one while the other is written */
 	int16_t *d_S;
 	int16_t *d_C;           /* --s-video: the sub-carrier slab */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
@@ -297,8 +298,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4));   /* + the carry row */
-	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4));
+	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2));   /* + two kept rows */
+	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2));
 	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
@@ -1008,7 +1009,9 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		e->carry_valid = 1;
 		if(d->ar > d->al && last->fb_valid && vy >= 0 && vy < last->fb_height)
 		{
-			const size_t carry_off = frame_px * e->frame_slots;
+			/* not the row this batch's first frame is about to read */
+			e->carry_row ^= 1;
+			const size_t carry_off = frame_px * e->frame_slots + (size_t) e->carry_row * k.active_width;
 			HIPCHK(hipMemcpyAsync(e->d_pool + carry_off, e->d_pool + last->fb_offset + (int64_t) vy * last->line_stride,
 			                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
 			e->carry.fb_offset = (int64_t) carry_off;

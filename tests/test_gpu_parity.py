@@ -696,3 +696,38 @@ def test_strided_source_views(golden):
         e.render(3, slots=[0, 1, 2])
         got = e.fetch(0, 3 * e.info["frame_samples"])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_picture_carried_across_batches_on_525_lines(golden, batch):
+    """NTSC: the last line of a frame is a picture line within the filter's reach of the next frame. When
+    that next frame opens a new batch, the source row has to come from the batch before (whose frame
+    slots have been overwritten by then): field-ordered random pictures, one slot, batches of 1 and 3."""
+    conf = H.preset("m", H.FLAG_FILTER)
+    sr, n = 13500000, 6
+    rng = np.random.default_rng(batch)
+    with oracle.Oracle(conf, sr) as o:
+        aw, ah, L = o.info["active_width"], o.info["active_lines"], o.info["lines"]
+        frames = rng.integers(0, 1 << 24, (n, ah, aw), dtype=np.uint32)
+        o.set_audio(golden.audio, True)
+        want = []
+        for f in range(n):
+            o.set_frame(frames[f], interlaced=1)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    got = []
+    with H.Engine(conf, sr, device=0, max_frames=batch) as e:
+        done = 0
+        while done < n:
+            b = min(batch, n - done)
+            for i in range(b):
+                e.frame_upload(i, frames[done + i], interlaced=1)      # the same slots every batch
+            while e.audio_needed(b) > 0:
+                e.audio_write(golden.audio)
+            e.render(b, slots=list(range(b)))
+            got.append(e.fetch(0, b * e.info["frame_samples"]))
+            done += b
+    got = np.concatenate(got)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    fs = len(want) // n
+    assert bad.size == 0, "frame %d sample %d" % (bad[0] // fs, bad[0] % fs)
