@@ -991,7 +991,8 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		if(stride != 1) *p = *own;
 		else if(i > 0) *p = e->h_fdesc[(size_t) (i - 1) * (fields + 1) + fields];
 		else if(e->carry_valid && e->carry_frame + 1 == first_frame) *p = e->carry;
-		else { memset(p, 0, sizeof(*p)); }
+		else if(first_frame == 0) { memset(p, 0, sizeof(*p)); }     /* nothing before the stream */
+		else *p = *own;                                             /* a jump: like a strided render */
 		/* the colour table position the kernel counts lines from is this frame's, also on the halo line */
 		p->clut_off0 = own->clut_off0;
 		p->frame_index = own->frame_index;

@@ -207,6 +207,11 @@ int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int
  * descriptors, carrier side stream and NICAM symbols; hvk_launch() enqueues
  * the raster and filter kernels for the staged batch (it may be called
  * repeatedly for the same staged batch). */
+/* (On 525 lines the last line of a frame shows picture and lies within the filter's reach of the next
+ * frame's first samples. Consecutive frames -- within a batch or from one call to the next -- are
+ * handled exactly: the engine keeps the source row. A strided call, or one that does not continue where
+ * the last one ended, does not have the frame before: it uses the frame's own picture, which is exact for
+ * a picture that does not change.) */
 int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots);
 int hvk_launch(hvk_engine_t *e, void *d_iq);
 
