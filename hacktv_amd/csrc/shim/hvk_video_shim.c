@@ -49,6 +49,8 @@
 #include "video.h"          /* the reference's */
 #include "hacktv_amd.h"
 
+#define SHIM_AUDIO_RATE 32000    /* HACKTV_AUDIO_SAMPLE_RATE, src/hacktv.h:31 */
+
 typedef struct {
 	hvk_engine_t *e;
 	hvk_info_t info;
@@ -76,8 +78,33 @@ typedef struct {
 	size_t line_at;         /* sample offset of the next line in iq */
 	int16_t *passbuf;
 	int64_t raw_fed;        /* samples of the raw baseband file queued so far */
+	/* caption pairs waiting for a line 21, like src/cc608.c:26-96: 128 pairs, empty ones never queued */
+	uint8_t cc_fifo[256];
+	int cc_in, cc_out, cc_len;
+	int64_t audio_drawn;    /* 32 kHz samples taken from the source when no carrier needs them */
+	int last[2];            /* buffer holds the last frames of the source */
+	int end_drop;           /* lines of the last frame the reference never hands out (see vid_next_line) */
 	vid_line_t out;
 } shim_t;
+
+static void _cc_push(shim_t *m, const uint8_t *pair)
+{
+	if(m->cc_len >= 256 || ((pair[0] | pair[1]) & 0x7F) == 0) return;
+	m->cc_fifo[m->cc_in++] = pair[0];
+	m->cc_fifo[m->cc_in++] = pair[1];
+	if(m->cc_in >= 256) m->cc_in = 0;
+	m->cc_len += 2;
+}
+
+static int _cc_pop(shim_t *m, uint8_t *pair)
+{
+	if(m->cc_len < 2) return(0);
+	pair[0] = m->cc_fifo[m->cc_out++];
+	pair[1] = m->cc_fifo[m->cc_out++];
+	if(m->cc_out >= 256) m->cc_out = 0;
+	m->cc_len -= 2;
+	return(1);
+}
 
 /* vid_t has no spare member; the engine handle rides in a pointer member the
  * caller never touches (`processes` is private to the reference's video.c). */
@@ -190,6 +217,8 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	return(VID_OK);
 }
 
+static int _pipeline_depth(const vid_t *s, int filter_delay);
+
 int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const vid_config_t * const conf)
 {
 	hvk_config_t hc;
@@ -287,6 +316,8 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 		}
 	}
 
+	m->end_drop = _pipeline_depth(s, m->info.delay_lines);
+
 	return(VID_OK);
 }
 
@@ -341,6 +372,38 @@ size_t vid_get_framebuffer_length(vid_t *s)
 	return(sizeof(uint32_t) * s->active_width * s->conf.active_lines);
 }
 
+/* The lines in flight in the reference's line pipeline: vid_init() gives each process a window of
+ * `nlines` output-line buffers in a ring (src/video.c:3578, :4675-4688); two neighbours share one
+ * buffer unless either runs on a thread of its own. The raster writes the middle one of its three
+ * (src/video.c:2873), "output" is the last window, and a buffer takes as many calls of
+ * _vid_next_line() from the one to the other as their positions in the ring differ. That many lines
+ * are handed out late -- and, at the end of the source, not at all (see vid_next_line below). */
+static int _pipeline_depth(const vid_t *s, int filter_delay)
+{
+	int depth = s->raw_bb_file ? 0 : 1;     /* rawbb has one buffer, the raster one ahead of the line it writes */
+	int prev_thread = 0;
+
+#define PROCESS(nlines, thread) do { depth += (nlines) - ((thread) || prev_thread ? 0 : 1); prev_thread = (thread); } while(0)
+	if(!s->raw_bb_file && s->conf.colour_mode == VID_SECAM) PROCESS(1, 1);
+	if(s->conf.vits) PROCESS(1, 0);
+	if(s->conf.wss) PROCESS(1, 0);
+	if(s->conf.acp) PROCESS(1, 0);
+	if(s->conf.vitc) PROCESS(1, 0);
+	if(s->conf.cc608) PROCESS(1, 0);
+	if(s->conf.teletext) PROCESS(1, 0);
+	if(s->pixel_rate != s->sample_rate) PROCESS(2, 1);             /* src/video.c:3648 */
+	if(s->conf.vfilter) PROCESS(1 + filter_delay, 1);              /* src/video.c:3761 */
+	PROCESS(1, 1);                                                 /* audio, always: src/video.c:4561 */
+	if(s->conf.modulation == VID_FM) PROCESS(1, 1);
+	if(s->conf.swap_iq) PROCESS(1, 0);
+	if(s->conf.offset) PROCESS(1, 1);
+	if(s->conf.passthru) PROCESS(1, 0);
+	PROCESS(1, 0);                                                 /* output */
+#undef PROCESS
+
+	return(depth);
+}
+
 /* Pull up to `batch` frames and the audio they need from the source, render them into iq */
 static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 {
@@ -352,29 +415,44 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 
 	while(n < m->batch && n < 256)
 	{
-		av_frame_t f, f2;
+		av_frame_t *f = &s->vframe;
 		const int slot = n * fields;
+		uint8_t cc[2];
+		r64_t par;
 
 		/* src/video.c:4873-4897: end of source is tested at the start of each frame -- and, with
 		 * --interlace, of each field, which shows a frame of its own. (A source that ends between the
 		 * two fields ends the stream with the frame before; the reference would still emit that
 		 * frame's first field.) */
 		if(av_eof(&s->av)) { m->ended = 1; break; }
-		av_read_video(&s->av, &f);
 
-		if(hvk_frame_upload(m->e, slot, f.framebuffer, f.width, f.height, f.pixel_stride, f.line_stride, f.interlaced) != HVK_OK) return(-1);
+		/* like src/video.c:4881: into the vid_t's own frame, so that a source whose video ends before
+		 * its sound shows its last picture once more (the failed read leaves the frame as it was) and
+		 * blank frames from then on (src/av.c:55-59) */
+		av_read_video(&s->av, f);
+
+		if(hvk_frame_upload(m->e, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced) != HVK_OK) return(-1);
 		slots[slot] = slot;
+		par = f->pixel_aspect_ratio;
+
+		/* src/video.c:4899-4903 queues the pair of every picture read; line 21 takes one per frame
+		 * (src/cc608.c:203), before the second field's picture is read */
+		if(s->conf.cc608)
+		{
+			_cc_push(m, f->cc608);
+			if(_cc_pop(m, cc) && hvk_cc608_write(m->e, n, cc[0], cc[1]) != HVK_OK) return(-1);
+		}
 
 		if(fields == 2)
 		{
 			if(av_eof(&s->av)) { m->ended = 1; break; }
-			av_read_video(&s->av, &f2);
-			if(hvk_frame_upload(m->e, slot + 1, f2.framebuffer, f2.width, f2.height, f2.pixel_stride, f2.line_stride, f2.interlaced) != HVK_OK) return(-1);
+			av_read_video(&s->av, f);
+			if(hvk_frame_upload(m->e, slot + 1, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced) != HVK_OK) return(-1);
 			slots[slot + 1] = slot + 1;
+			if(s->conf.cc608) _cc_push(m, f->cc608);
 		}
 
-		if(s->conf.wss && hvk_frame_aspect(m->e, slot, f.pixel_aspect_ratio.num, f.pixel_aspect_ratio.den) != HVK_OK) return(-1);
-		if(s->conf.cc608 && hvk_cc608_write(m->e, n, f.cc608[0], f.cc608[1]) != HVK_OK) return(-1);
+		if(s->conf.wss && hvk_frame_aspect(m->e, slot, par.num, par.den) != HVK_OK) return(-1);
 
 		if(s->conf.teletext)
 		{
@@ -406,20 +484,43 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 		m->frame_in_batch_pull++;
 		m->frames_pulled++;
 		n++;
+
+		/* 32 kHz audio for this frame (src/video.c:3278-3286), pulled frame by frame so that the end
+		 * of the sound is seen by the same av_eof() as in the reference; a source that runs dry
+		 * leaves silence (src/video.c:3299-3304) */
+		if(m->info.has_carriers || m->info.has_nicam)
+		{
+			while(hvk_audio_needed(m->e, n) > 0)
+			{
+				int16_t *a = NULL;
+				size_t an = 0;
+				av_read_audio(&s->av, &a, &an);
+				if(a == NULL || an == 0) break;
+				if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+			}
+		}
+		else
+		{
+			/* no sound carrier: the reference's audio process still draws the source at 32 kHz
+			 * (src/video.c:3272-3286), and a source only ends once its sound has */
+			const int64_t pos = m->frames_pulled * (int64_t) m->info.frame_samples + m->info.startup_samples;
+			const int64_t ticks = pos / m->info.sample_rate * SHIM_AUDIO_RATE
+			                    + pos % m->info.sample_rate * SHIM_AUDIO_RATE / m->info.sample_rate;
+			while(m->audio_drawn < ticks)
+			{
+				int16_t *a = NULL;
+				size_t an = 0;
+				av_read_audio(&s->av, &a, &an);
+				if(a == NULL || an == 0) break;
+				m->audio_drawn += an;
+			}
+		}
 	}
+
+	/* a full batch that used up the source is the last one too */
+	if(!m->ended && av_eof(&s->av)) m->ended = 1;
 
 	if(n == 0) return(0);
-
-	/* 32 kHz audio for these frames (src/video.c:3278-3286); a source that runs dry
-	 * leaves silence (src/video.c:3299-3304) */
-	while(hvk_audio_needed(m->e, n) > 0)
-	{
-		int16_t *a = NULL;
-		size_t an = 0;
-		av_read_audio(&s->av, &a, &an);
-		if(a == NULL || an == 0) break;
-		if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
-	}
 
 	/* --raw-bb-file: the lines of these frames and the one after them (the filter looks into it), read
 	 * like src/video.c:2419-2429 -- at the end of the file, start over */
@@ -497,6 +598,7 @@ static void *_worker(void *arg)
 		n = m->ended ? 0 : _next_batch(s, m, m->buf[b]);
 
 		pthread_mutex_lock(&m->lock);
+		m->last[b] = m->ended;
 		m->count[b] = n;
 		m->ready[b] = 1;
 		pthread_cond_broadcast(&m->cond);
@@ -541,6 +643,15 @@ vid_line_t *vid_next_line(vid_t *s)
 		m->frame_in_batch = 0;
 		m->line = 0;
 		m->line_at = 0;
+	}
+
+	/* The reference tests for the end of the source when it starts a frame (src/video.c:4876), and
+	 * returns NULL there and then: the lines still in its pipeline -- one per two-slot process, the
+	 * resampler and the video filter -- never come out. Nor do they here. */
+	if(m->last[m->cur] && m->frame_in_batch == m->have - 1 && m->line >= m->info.lines - m->end_drop)
+	{
+		m->frame_in_batch = m->have;    /* a further call finds the worker's empty batch */
+		return(NULL);
 	}
 
 	if(m->line == 0)

@@ -255,6 +255,39 @@ def test_dropin_binary_equals_reference_cli(golden):
             assert got == run(ref, flags, nframes * fs * bps), case
 
 
+SHIM_CHECK_CASES = [
+    # mode, sample rate, frames, flags (oracle/shim_check.c), pixel rate
+    ("i", 16000000, 5, 1, 0),            # VSB filter + NICAM + FM; ends in the middle of a batch
+    ("i", 13500000, 4, 0, 0),            # ends on a batch boundary
+    ("pal", 13500000, 3, 2 | 4 | 8, 0),
+    ("m", 13500000, 5, 16 | 32 | 8, 0),
+    ("l", 16000000, 3, 1, 0),
+    ("i", 16000000, 3, 1 | 64, 0),       # --interlace: two pictures per frame
+    ("m", 13500000, 4, 32 | 64, 0),      # captions of both pictures queue up
+    ("i", 20250000, 3, 1 | 4, 13500000),
+    ("pal", 14000000, 3, 2, 13500000),
+    ("g", 13500000, 3, 128, 0),
+]
+
+
+@pytest.mark.parametrize("mode,sr,frames,flags,pr", SHIM_CHECK_CASES)
+def test_shim_equals_reference_engine_line_by_line(mode, sr, frames, flags, pr):
+    """oracle/_ref/shim_check: the video.h shim (GPU) and the reference's engine in ONE process, fed by
+    identical sources that change every frame and END -- every vid_line_t (width, frame, line, samples)
+    and the call on which NULL comes back."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "shim_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check not built (needs /root/reference at build time)")
+    env = dict(os.environ, HVK_BATCH="2")
+    r = subprocess.run([exe, mode, str(sr), str(frames), str(flags)] + ([str(pr)] if pr else []),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.startswith("EQUAL"), out + r.stderr.decode()[-2000:]
+
+
 def test_secam_moving_picture_and_geometry(golden):
     """SECAM-L with a different picture on every frame (the vertical average reaches
     across lines, the IIR across frames), a small centred picture and an empty frame."""
