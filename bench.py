@@ -248,7 +248,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hvk_k_filter<51, 3, 0, 1>",
+                "kernel": "hvk_k_filter<51, 3, 0, 1, 1>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

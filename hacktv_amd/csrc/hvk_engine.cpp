@@ -80,6 +80,8 @@ struct hvk_engine {
 
 	/* constant tables */
 	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_ccb;
+	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
+	int mfma_ci, mfma_cq;
 	/* per batch */
 	uint32_t *d_pool;
 	hvk_framedesc_t *d_fdesc;   /* [max_frames][1 + fields]: the frame before (only its last line is looked at:
@@ -126,6 +128,47 @@ struct hvk_engine {
 #define HIPCHK(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
 	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
 	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
+
+/* The video filter as a matrix product (hvk_k_filter, MF = 1). Eight consecutive outputs of a
+ * segment and both channels make the 16 rows of A, 64 window positions its columns:
+ *
+ *   row m = 4 g + i  ->  output b = 2 g + (i >> 1) of the segment, channel i & 1 (I, Q)
+ *   A[m][t] = h[t - 1 - b]      (window position 0 is the sample 26 before the segment's first)
+ *
+ * int16 x int16 on the int8 matrix unit: the taps are split into signed bytes h = 256 hh + hl
+ * (hl = the low byte read as signed), the samples into x = 256 xh + (xl - 128) + 128, which gives
+ * four int8 products and the constant 128 * sum(h) -- exact modulo 2^32, like the reference's
+ * int32 accumulator. Layout: [hh, hl][lane][16 bytes], lane = 16 * (t / 16) + m, byte = t % 16.
+ * A tap above 32639 has no such split (hh = 128): the caller keeps the VALU kernel then. */
+static bool _mfma_taps(int8_t *a, int *ci, int *cq, const int16_t *hi, const int16_t *hq, int ntaps)
+{
+	int64_t si = 0, sq = 0;
+
+	for(int k = 0; k < ntaps; k++)
+	{
+		si += hi[k];
+		if(hq) sq += hq[k];
+	}
+
+	for(int lane = 0; lane < 64; lane++)
+	{
+		const int g = lane >> 4, m = lane & 15, b = 2 * (m >> 2) + ((m & 3) >> 1), q = m & 1;
+
+		for(int j = 0; j < 16; j++)
+		{
+			const int k = 16 * g + j - 1 - b;
+			const int h = (k >= 0 && k < ntaps) ? (q ? (hq ? hq[k] : 0) : hi[k]) : 0;
+			const int lo = (int) (int8_t) (h & 0xFF), hh = (h - lo) >> 8;
+			if(hh < -128 || hh > 127) return(false);
+			a[(0 * 64 + lane) * 16 + j] = (int8_t) hh;
+			a[(1 * 64 + lane) * 16 + j] = (int8_t) lo;
+		}
+	}
+
+	*ci = (int) (uint32_t) (128 * si);
+	*cq = (int) (uint32_t) (128 * sq);
+	return(true);
+}
 
 static void _pack_taps(hvk_packed_taps_t *p, const int16_t *taps, int ntaps)
 {
@@ -263,6 +306,14 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	e->stream = e->own_stream;
 
 	OPENCHK(_upload(&e->d_yuvparams, &e->t.yuv, sizeof(e->t.yuv)));
+	if(e->t.k.vf_type && e->t.k.vf_ntaps == 51 && !getenv("HVK_NO_MFMA"))
+	{
+		std::vector<int8_t> a(HVK_MFMA_A_BYTES);
+		if(_mfma_taps(a.data(), &e->mfma_ci, &e->mfma_cq, e->t.vf_itaps, e->t.k.vf_type == 3 ? e->t.vf_qtaps : NULL, 51))
+		{
+			OPENCHK(_upload(&e->d_mfma_a, a.data(), a.size()));
+		}
+	}
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
 
@@ -404,7 +455,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw };
+		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -1123,6 +1174,9 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.nicam_tapd = (const int *) e->d_tapd;
 	fa.nicam_cca = (const int *) e->d_cca;
 	fa.nicam_ccb = (const int *) e->d_ccb;
+	fa.mfma_a = e->d_mfma_a;
+	fa.mfma_ci = e->mfma_ci;
+	fa.mfma_cq = e->mfma_cq;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;

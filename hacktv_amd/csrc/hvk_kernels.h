@@ -9,6 +9,7 @@
 #define HVK_CHROMA_LEAD 16   /* int16 of slack either side of a chroma channel in LDS */
 #define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
+#define HVK_MFMA_A_BYTES (2 * 64 * 16)
 #define HVK_NICAM_TAPD  384  /* dwords of the duplicated, zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
@@ -53,6 +54,8 @@ typedef struct {
 	const int *nicam_tapd;      /* HVK_NICAM_TAPD dwords: (tap, tap), zero padded */
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const int *nicam_ccb;       /* nicam_cc_len + 8 dwords: (cc.q,  cc.i) */
+	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
+	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
 	int16_t *iq;
 	int nframes;
 	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */

@@ -65,6 +65,7 @@ typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
 #endif
 #define ABLATE(bit) (HVK_ENABLE_ABLATE && (k.ablate & (bit)))
 #define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
+#define HVK_FILTER_GROUP 4    /* filter tiles a workgroup works on side by side (two waves each): they share the staged NICAM pulse table */
 #define HVK_TILES_PER_WG 1    /* consecutive filter tiles walked by one workgroup (4 measured 10 % slower: fewer independent workgroups to overlap) */
 
 __device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
@@ -677,8 +678,8 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 }
 
 
-template<int NT, int VF, int SV, int EXACT>
-__global__ __launch_bounds__(HVK_TILE / HVK_SPL)
+template<int NT, int VF, int SV, int EXACT, int MF>
+__global__ __launch_bounds__(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP)
 void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_packed_taps_t itaps,
                   const hvk_packed_taps_t qtaps,
@@ -690,6 +691,8 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
                   const int *__restrict__ nicam_ccb,     /* mixer (q,  i) */
                   const int16_t *__restrict__ Cq,        /* --s-video: the Q channel, laid out like S */
+                  const int4v *__restrict__ mfma_a,      /* MF: the taps as A operand, [hh, hl][lane] (hvk_engine.cpp:_mfma_taps) */
+                  const int mfma_ci, const int mfma_cq,  /* MF: 128 * sum of the taps */
                   int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
                   const int64_t out_stride,
                   const int tiles)                       /* 1024-sample tiles per frame */
@@ -697,35 +700,88 @@ void hvk_k_filter(const hvk_kconst_t k,
 	constexpr int H = NT / 2;
 	constexpr int LEAD = H + (H & 1);           /* window lead, even */
 	constexpr int NWIN = HVK_TILE + 2 * LEAD + 16;
-	__shared__ __attribute__((aligned(16))) int16_t win[NWIN];
+	constexpr int NPL = HVK_TILE + 64;          /* MF: window as two byte planes; position 0 is sample n0 - LEAD */
+	static_assert(!MF || (NT == 51 && HVK_TILE / HVK_SPL == 128), "the MFMA filter is laid out for 51 taps and two waves per tile");
+	constexpr int G = HVK_FILTER_GROUP;
+	__shared__ __attribute__((aligned(16))) int16_t win_g[G][MF ? 8 : NWIN];
+	__shared__ __attribute__((aligned(16))) unsigned char xh_g[G][MF ? NPL : 16], xl_g[G][MF ? NPL : 16];
+	__shared__ __attribute__((aligned(16))) int outl_g[G][MF ? HVK_TILE : 4];
 	__shared__ __attribute__((aligned(16))) int tapd[4 * HVK_NICAM_TAPD];
-	__shared__ int sym_st[HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
-	__shared__ __attribute__((aligned(16))) int4v sym_ent[HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
+	__shared__ int sym_st_g[G][HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
+	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[G][HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
 
 	const int FS = k.frame_samples;
-	const int t = threadIdx.x;
+	const int sub = threadIdx.x / (HVK_TILE / HVK_SPL);        /* which of the workgroup's tiles */
+	const int t = threadIdx.x % (HVK_TILE / HVK_SPL);
 	const int x0 = t * SPL;
 	const int16_t *slab = S + (size_t) blockIdx.y * k.s_stride + k.s_lead;    /* frame local sample 0 */
+	int16_t *const win = win_g[sub];
+	unsigned char *const xh = xh_g[sub], *const xl = xl_g[sub];
+	int *const outl = outl_g[sub];
+	int *const sym_st = sym_st_g[sub];
+	int4v *const sym_ent = sym_ent_g[sub];
+	(void) win; (void) xh; (void) xl; (void) outl;
 
 	/* four copies of the NICAM pulse table, copy s shifted left by s entries, so that
 	 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts instead of
 	 * the 8-way of dword reads at a 32-byte lane stride); staged once per workgroup */
 	if(k.has_nicam && !ABLATE(16))
 	{
-		for(int q = t; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
+		for(int q = threadIdx.x; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
+	}
+
+	/* MF: this lane's share of the tap matrix, 16 rows (8 outputs x I, Q) by 64 window positions */
+	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
+	if(MF)
+	{
+		a_hh = mfma_a[t & 63];
+		a_hl = mfma_a[64 + (t & 63)];
 	}
 
 	/* a workgroup walks HVK_TILES_PER_WG consecutive tiles: its fixed costs (kernel
 	 * arguments into SGPRs, the pulse table) are paid once */
 	for(int it = 0; it < HVK_TILES_PER_WG; it++)
 	{
-	const int tile = blockIdx.x * HVK_TILES_PER_WG + it;
-	if(tile >= tiles) break;
+	if((blockIdx.x * HVK_TILES_PER_WG + it) * G >= tiles) break;
+	/* a group that reaches past the frame's last tile does that one again: same values to the same places */
+	const int tile = min((blockIdx.x * HVK_TILES_PER_WG + it) * G + sub, tiles - 1);
 	const int n0 = tile * HVK_TILE;             /* first output sample of the tile, frame local */
 
 	/* stage raster samples [n0 - LEAD, n0 + TILE + LEAD) as dwords; the slab
 	 * keeps one line before and one after the frame */
-	if(VF != 0)
+	if(VF != 0 && MF)
+	{
+		/* The int8 matrix unit multiplies bytes: the window goes to LDS as a plane of high bytes
+		 * (x >> 8, signed) and a plane of low bytes less 128 (x & 255, read as signed after ^ 0x80),
+		 * eight samples per lane and pass, v_perm_b32 picking the bytes out of the sample pairs. */
+		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
+		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
+		constexpr int NG = NPL / 8;
+#pragma unroll
+		for(int i = 0; i < (NG + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL); i++)
+		{
+			const int q = t + i * (HVK_TILE / HVK_SPL);
+			if(q < NG)
+			{
+				int4u d = { 0, 0, 0, 0 };
+				if(EXACT || q * 4 + 3 < limit) d = ((const int4u *) src)[q];
+				else
+				{
+					if(q * 4 + 0 < limit) d.x = src[q * 4 + 0];
+					if(q * 4 + 1 < limit) d.y = src[q * 4 + 1];
+					if(q * 4 + 2 < limit) d.z = src[q * 4 + 2];
+				}
+				int2v ph, pl;
+				ph.x = (int) __builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x07050301u);
+				ph.y = (int) __builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x07050301u);
+				pl.x = (int) (__builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x06040200u) ^ 0x80808080u);
+				pl.y = (int) (__builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x06040200u) ^ 0x80808080u);
+				((int2v *) xh)[q] = ph;
+				((int2v *) xl)[q] = pl;
+			}
+		}
+	}
+	else if(VF != 0)
 	{
 		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
 		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
@@ -790,7 +846,43 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
 
-	if(VF != 0)
+	if(VF != 0 && MF)
+	{
+		/* The FIR as a banded matrix product on the matrix unit. A wave takes 64 segments of 8
+		 * outputs, 16 segments (the columns of B) per v_mfma_i32_16x16x64_i8: lane (g, c) hands over
+		 * window positions 16 g .. 16 g + 15 of segment c, which are 16 consecutive bytes of a plane,
+		 * and gets back rows 4 g .. 4 g + 3 = outputs 2 g, 2 g + 1 of that segment, I and Q. Four
+		 * products (high / low byte of taps and samples), recombined with two shift-adds; the
+		 * constant of the low plane's offset starts the low accumulator. Then >> 15 and the
+		 * saturating pack (src/fir.c:605-608), and through LDS to the lane that owns the 8 outputs. */
+		const int lane = t & 63, g = lane >> 4, c = lane & 15;
+#pragma unroll
+		for(int j = 0; j < 4; j++)
+		{
+			const int seg = (t >> 6) * 64 + j * 16 + c;
+			const int off = seg * 8 + g * 16;
+			int4v bh, bl;
+			bh.xy = *(const int2v *) (xh + off); bh.zw = *(const int2v *) (xh + off + 8);
+			bl.xy = *(const int2v *) (xl + off); bl.zw = *(const int2v *) (xl + off + 8);
+			int4v p_hh = { 0, 0, 0, 0 }, p_m = { 0, 0, 0, 0 }, p_ll = { mfma_ci, mfma_cq, mfma_ci, mfma_cq };
+			p_hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bh, p_hh, 0, 0, 0);
+			p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bh, p_m, 0, 0, 0);
+			p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bl, p_m, 0, 0, 0);
+			p_ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bl, p_ll, 0, 0, 0);
+			int y[4];
+#pragma unroll
+			for(int i = 0; i < 4; i++) y[i] = (int) ((((unsigned) p_hh[i] << 8) + (unsigned) p_m[i]) << 8) + p_ll[i];
+			int2v pk;
+			pk.x = sat_pack16(y[0] >> 15, y[1] >> 15);
+			pk.y = sat_pack16(y[2] >> 15, y[3] >> 15);
+			*(int2v *) (outl + seg * 8 + 2 * g) = pk;
+		}
+		__syncthreads();
+		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
+		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
+		o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
+	}
+	else if(VF != 0)
 	{
 		constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
 		int d[ND];
@@ -1262,14 +1354,24 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	return(HVK_UNSUPPORTED);
 }
 
+template<int NT, int VF, int SV, int EXACT, int MF>
+static int _launch_filter3(const hvk_filter_args_t *a, hipStream_t stream)
+{
+	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+	const int per_wg = HVK_TILES_PER_WG * HVK_FILTER_GROUP;
+	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV, EXACT, MF>), dim3((tiles + per_wg - 1) / per_wg, a->nframes), dim3(HVK_TILE / SPL * HVK_FILTER_GROUP), 0, stream,
+	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
+	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, a->C, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq,
+	                   (int *) a->iq, a->out_stride, tiles);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
 template<int NT, int VF, int SV, int EXACT>
 static int _launch_filter2(const hvk_filter_args_t *a, hipStream_t stream)
 {
-	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV, EXACT>), dim3((tiles + HVK_TILES_PER_WG - 1) / HVK_TILES_PER_WG, a->nframes), dim3(HVK_TILE / SPL), 0, stream,
-	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
-	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, a->C, (int *) a->iq, a->out_stride, tiles);
-	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+	/* the matrix-unit form of the filter whenever the taps have one (hvk_engine.cpp:_mfma_taps) */
+	if(NT == 51 && a->mfma_a) return(_launch_filter3<NT, VF, SV, EXACT, NT == 51>(a, stream));
+	return(_launch_filter3<NT, VF, SV, EXACT, 0>(a, stream));
 }
 
 template<int NT, int VF, int SV>
