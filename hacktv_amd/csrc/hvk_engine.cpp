@@ -324,18 +324,19 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
 	if(k.has_nicam)
 	{
-		/* device forms of the NICAM tables: the pulse with each tap in both
-		 * halves of a dword behind HVK_NICAM_LEAD zeros and zero padded, so a
-		 * packed multiply-add shapes I and Q at once and no bounds test is
-		 * needed; the mixer as the two rows of the rotation matrix,
-		 * (i, -q) and (q, i), extended by 8 entries past the wrap */
-		std::vector<int> tapd(4 * HVK_NICAM_TAPD, 0), cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
+		/* device forms of the NICAM tables: the pulse as int16 behind HVK_NICAM_LEAD
+		 * zeros and zero padded (no bounds test is needed), in four copies of which
+		 * copy s starts s entries later, so that any eight consecutive entries start
+		 * 8-byte aligned in one of them; the mixer as the two rows of the rotation
+		 * matrix, (i, -q) and (q, i), extended by 8 entries past the wrap */
+		std::vector<int16_t> tapd(4 * HVK_NICAM_TAPD, 0);
+		std::vector<int> cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
 		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
 		for(int i = 0; i < k.nicam_ntaps; i++)
 		{
 			const int v = e->t.nicam_taps[i];
 			/* copy s holds entry j + s at position j */
-			for(int sft = 0; sft < 4; sft++) tapd[sft * HVK_NICAM_TAPD + HVK_NICAM_LEAD + i - sft] = (v & 0xFFFF) | (v << 16);
+			for(int sft = 0; sft < 4; sft++) tapd[sft * HVK_NICAM_TAPD + HVK_NICAM_LEAD + i - sft] = (int16_t) v;
 		}
 		for(int i = 0; i < k.nicam_cc_len + 8; i++)
 		{
@@ -343,7 +344,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			cca[i] = ((int) c.i & 0xFFFF) | ((-(int) c.q) << 16);
 			ccb[i] = ((int) c.q & 0xFFFF) | ((int) c.i << 16);
 		}
-		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * 4));
+		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * sizeof(int16_t)));
 		OPENCHK(_upload(&e->d_cca, cca.data(), cca.size() * 4));
 		OPENCHK(_upload(&e->d_ccb, ccb.data(), ccb.size() * 4));
 	}

@@ -10,7 +10,7 @@
 #define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_MFMA_A_BYTES (2 * 64 * 16)
-#define HVK_NICAM_TAPD  384  /* dwords of the duplicated, zero padded NICAM pulse table */
+#define HVK_NICAM_TAPD  384  /* entries of one copy of the zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
  * live in SGPRs (wave-uniform operands of v_dot2c_i32_i16) */
@@ -51,7 +51,7 @@ typedef struct {
 	const int16_t *C;           /* --s-video: the Q channel, laid out like S */
 	const hvk_c16_t *carriers;
 	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
-	const int *nicam_tapd;      /* HVK_NICAM_TAPD dwords: (tap, tap), zero padded */
+	const int *nicam_tapd;      /* 4 x HVK_NICAM_TAPD int16: the pulse, four shifted copies, zero padded */
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const int *nicam_ccb;       /* nicam_cc_len + 8 dwords: (cc.q,  cc.i) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */

@@ -687,7 +687,7 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int16_t *__restrict__ S,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW]: symbols (start << 3 | valid << 2 | dsym), mixer position */
-                  const int *__restrict__ nicam_tapd,    /* pulse taps, each duplicated into both halves of a dword, zero padded */
+                  const int *__restrict__ nicam_tapd,    /* pulse taps: four shifted int16 copies, zero padded (hvk_engine.cpp) */
                   const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
                   const int *__restrict__ nicam_ccb,     /* mixer (q,  i) */
                   const int16_t *__restrict__ Cq,        /* --s-video: the Q channel, laid out like S */
@@ -706,7 +706,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	__shared__ __attribute__((aligned(16))) int16_t win_g[G][MF ? 8 : NWIN];
 	__shared__ __attribute__((aligned(16))) unsigned char xh_g[G][MF ? NPL : 16], xl_g[G][MF ? NPL : 16];
 	__shared__ __attribute__((aligned(16))) int outl_g[G][MF ? HVK_TILE : 4];
-	__shared__ __attribute__((aligned(16))) int tapd[4 * HVK_NICAM_TAPD];
+	__shared__ __attribute__((aligned(16))) int16_t tapd[4 * HVK_NICAM_TAPD];   /* four copies of the pulse, copy s one entry further left */
 	__shared__ int sym_st_g[G][HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
 	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[G][HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
 
@@ -722,12 +722,12 @@ void hvk_k_filter(const hvk_kconst_t k,
 	int4v *const sym_ent = sym_ent_g[sub];
 	(void) win; (void) xh; (void) xl; (void) outl;
 
-	/* four copies of the NICAM pulse table, copy s shifted left by s entries, so that
-	 * any run of 8 entries is two aligned ds_read_b128 (2-way bank conflicts instead of
-	 * the 8-way of dword reads at a 32-byte lane stride); staged once per workgroup */
+	/* four copies of the NICAM pulse table (int16), copy s shifted left by s entries, so that
+	 * any run of 8 entries starts 8-byte aligned in one of them: one ds_read2_b64, lanes side by
+	 * side; staged once per workgroup */
 	if(k.has_nicam && !ABLATE(16))
 	{
-		for(int q = threadIdx.x; q < HVK_NICAM_TAPD; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
+		for(int q = threadIdx.x; q < HVK_NICAM_TAPD / 2; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
 	}
 
 	/* MF: this lane's share of the tap matrix, 16 rows (8 outputs x I, Q) by 64 window positions */
@@ -835,8 +835,10 @@ void hvk_k_filter(const hvk_kconst_t k,
 			 * table a lane needs depends on the symbol only. A slot without a symbol
 			 * gets an offset that clamps into the table's zero tail. */
 			const int rel = HVK_NICAM_LEAD - st;
-			const int sgn = (int) (((cs & 1) ? 0x0001u : 0xFFFFu) | ((cs & 2) ? 0x00010000u : 0xFFFF0000u));
-			sym_ent[t] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgn, 0 }
+			/* +1 or -1 in both halves: the pulse shapes two samples of a channel per packed multiply-add */
+			const int sgi = (cs & 1) ? 0x00010001 : (int) 0xFFFFFFFFu;
+			const int sgq = (cs & 2) ? 0x00010001 : (int) 0xFFFFFFFFu;
+			sym_ent[t] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgi, sgq }
 			                   : (int4v) { 0x10000000, 0, 0, 0 };
 		}
 	}
@@ -969,9 +971,10 @@ void hvk_k_filter(const hvk_kconst_t k,
 		while(idx + 1 < HVK_NICAM_SYMS && sym_st[idx + 1] <= last) idx++;
 		while(idx > 0 && sym_st[idx] > last) idx--;
 
-		int bb[SPL];
+		/* I and Q apart while the pulses are summed: (I[2m], I[2m + 1]) and (Q[2m], Q[2m + 1]) */
+		int bi[SPL / 2], bq[SPL / 2];
 #pragma unroll
-		for(int i = 0; i < SPL; i++) bb[i] = 0;
+		for(int i = 0; i < SPL / 2; i++) bi[i] = bq[i] = 0;
 
 		/* the newest symbol and the six before it: everything older is over. A pulse
 		 * that is over (or a slot without a symbol) reads the zero tail of the table:
@@ -982,13 +985,20 @@ void hvk_k_filter(const hvk_kconst_t k,
 			const int4v en = sym_ent[idx - b];
 			int base = x0 + en.x;                                   /* >= 1 */
 			base = base < HVK_NICAM_TAPD - SPL ? base : HVK_NICAM_TAPD - SPL;
-			const int4v *tp = (const int4v *) (tapd + en.y + (base & ~3));
-			const int4v ta = tp[0], tb = tp[1];
-			const int sg = en.z;
-			bb[0] = pk_mad16(ta.x, sg, bb[0]); bb[1] = pk_mad16(ta.y, sg, bb[1]);
-			bb[2] = pk_mad16(ta.z, sg, bb[2]); bb[3] = pk_mad16(ta.w, sg, bb[3]);
-			bb[4] = pk_mad16(tb.x, sg, bb[4]); bb[5] = pk_mad16(tb.y, sg, bb[5]);
-			bb[6] = pk_mad16(tb.z, sg, bb[6]); bb[7] = pk_mad16(tb.w, sg, bb[7]);
+			const int2v *tp = (const int2v *) (tapd + en.y + (base & ~3));
+			const int2v ta = tp[0], tb = tp[1];
+			bi[0] = pk_mad16(ta.x, en.z, bi[0]); bi[1] = pk_mad16(ta.y, en.z, bi[1]);
+			bi[2] = pk_mad16(tb.x, en.z, bi[2]); bi[3] = pk_mad16(tb.y, en.z, bi[3]);
+			bq[0] = pk_mad16(ta.x, en.w, bq[0]); bq[1] = pk_mad16(ta.y, en.w, bq[1]);
+			bq[2] = pk_mad16(tb.x, en.w, bq[2]); bq[3] = pk_mad16(tb.y, en.w, bq[3]);
+		}
+
+		int bb[SPL];                            /* (I, Q) of each sample */
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++)
+		{
+			bb[2 * m + 0] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x05040100u);
+			bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
 		}
 
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
