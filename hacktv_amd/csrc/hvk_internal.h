@@ -36,7 +36,7 @@ typedef struct {
 	int16_t src_row;        /* source row before centring / field shift, -1: none */
 	int16_t pal;            /* 0 no chroma, +1, -1 (PAL V switch) */
 	int16_t secam_fid;      /* SECAM field identification line: sub-carrier (and luma notch) without a picture */
-} hvk_linedesc_t;
+} __attribute__((aligned(16))) hvk_linedesc_t;      /* 16 bytes, aligned: one scalar load on the device */
 
 /* RGB -> (Y,U,V) level conversion, evaluated in double on the device with
  * contraction off, operation for operation as src/video.c:3912-3958 */

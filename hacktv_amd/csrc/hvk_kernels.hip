@@ -206,7 +206,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	/* one descriptor per frame, or per field with --interlace: the second field shows its own source
 	 * frame. The halo line in front is the last line of the frame BEFORE: on 525 lines it shows picture,
 	 * whose last samples the filter sees from this frame's first outputs. */
-	const hvk_framedesc_t &f = fdesc[blockIdx.y * (k.fields + 1) + (rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1))];
+	const hvk_framedesc_t f = fdesc[__builtin_amdgcn_readfirstlane(blockIdx.y * (k.fields + 1) + (rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1)))];   /* one scalar load of the whole descriptor */
 	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
 
 	/* which line of which frame, without dividing the global line number */
@@ -225,7 +225,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 		return;
 	}
 
-	const hvk_linedesc_t d = desc[par * k.lines + line0];
+	const hvk_linedesc_t d = desc[__builtin_amdgcn_readfirstlane(par * k.lines + line0)];
 	const int pal = k.colour ? d.pal : 0;
 
 	/* a VBI data line (teletext packet, WSS, VITC: the host lists them per frame), an insertion test signal */
@@ -256,6 +256,32 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * right end of the active part (src/video.c:2972-2975): on a left-half line a
 	 * picture narrow enough to start beyond mid-line pushes the black fill past it */
 	const int ar_eff = (px0 > d.al && px0 > d.ar) ? px0 : d.ar;
+
+	/* The loads nothing but the descriptors depends on go out first, longest chain first: the source
+	 * row (its pixels index the level table, whose entries go to LDS), then the samples the reference
+	 * reads past its chroma buffer, then the sub-carrier phasors. All unconditional, at clamped
+	 * positions (ax1 > ax0 when there is a picture): a load under a lane test gets a wait of its own
+	 * from the compiler, and eight round trips in a row. */
+	uint32_t rgb[HVK_PIX_PASSES];
+	{
+		/* without a picture: the pool's first pixel, eight times (never used) -- no branch, no merge */
+		const bool pix = has_pix && !ABLATE(8);
+		const uint32_t *row = pix ? pool + f.fb_offset + (int64_t) vy * f.line_stride : pool;
+		const int64_t ps = pix ? f.pixel_stride : 0;
+#pragma unroll
+		for(int i = 0; i < HVK_PIX_PASSES; i++)
+		{
+			const int x = ax0 + t + i * nth;
+			rgb[i] = row[(int64_t) ((x < ax1 ? x : ax1 - 1) - px0) * ps];
+		}
+	}
+	int ghost_u = 0, ghost_v = 0;
+	if(NT > 1)
+	{
+		const int gt = t < H ? t : H - 1;
+		ghost_u = ghost[2 * gt + 0];
+		ghost_v = ghost[2 * gt + 1];
+	}
 
 	/* sub-carrier phasors of this lane's samples, fetched now so that the read is
 	 * in flight during the picture and filter phases. The table position advances
@@ -288,27 +314,22 @@ void hvk_k_raster(const hvk_kconst_t k,
 		__syncthreads();
 		if(t < H)
 		{
-			U[H + W + t] = ghost[2 * t + 0];
-			V[H + W + t] = ghost[2 * t + 1];
+			U[H + W + t] = (int16_t) ghost_u;
+			V[H + W + t] = (int16_t) ghost_v;
 		}
 	}
 
 	if(has_pix && !ABLATE(8))
 	{
-		/* all row reads are issued before the first table look-up, all look-ups
-		 * before the first LDS write: the two dependent global loads per pixel are
-		 * paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width) */
-		const uint32_t *row = pool + f.fb_offset + (int64_t) vy * f.line_stride;
-		uint32_t rgb[HVK_PIX_PASSES];
+		/* all look-ups are issued before the first LDS write: the two dependent global loads
+		 * per pixel are paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width) */
 		short4v c[HVK_PIX_PASSES];
+		/* the pixels are first needed HERE: keeps the compiler from preparing the table addresses
+		 * (and waiting for the loads) right where they were issued */
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			const int x = ax0 + t + i * nth;
-			rgb[i] = x < ax1 ? (row[(int64_t) (x - px0) * f.pixel_stride] & 0xFFFFFFu) : 0u;
-		}
+		for(int i = 0; i < HVK_PIX_PASSES; i++) asm volatile("" : "+v"(rgb[i]));
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i]];
+		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i] & 0xFFFFFFu];
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
@@ -370,6 +391,15 @@ void hvk_k_raster(const hvk_kconst_t k,
 			const int16_t *v = pulses + k.pulse_start[id];
 			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
 			if(x0 + SPL <= off || x0 >= off + len) continue;
+			/* loads first, at clamped positions, then the range tests: a load under a lane test
+			 * would get a wait of its own, eight round trips in a row */
+			int pv[SPL];
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int idx = x0 + i - off;
+				pv[i] = v[idx < 0 ? 0 : (idx < len ? idx : len - 1)];
+			}
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
 			{
@@ -377,7 +407,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 				/* a pulse never crosses into the following line; the part of
 				 * the own left pulse before sample 0 belongs to the previous line */
 				/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
-				if(idx >= 0 && idx < len && x0 + i < W) s[i] = SECAM ? wrap16(s[i] + v[idx]) : s[i] + v[idx];
+				if(idx >= 0 && idx < len && x0 + i < W) s[i] = SECAM ? wrap16(s[i] + pv[i]) : s[i] + pv[i];
 			}
 		}
 	}

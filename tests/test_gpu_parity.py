@@ -84,6 +84,22 @@ def test_stream_equals_reference_digests(golden, case):
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 
+@pytest.mark.parametrize("case", ["i_full", "pal_bb_filter", "i_20m", "ntsc_sv_f", "pal_px135_s136"])
+def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
+    """The video filter has two forms: the banded matrix product on the int8 matrix unit (default) and
+    the packed dot-product form on the vector unit, kept for taps the byte split cannot express (> 32639).
+    HVK_NO_MFMA=1 forces the second: same digests."""
+    monkeypatch.setenv("HVK_NO_MFMA", "1")
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    nframes = c["frames"]
+    iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2, pixel_rate=c.get("pixel_rate", 0))
+    fs = c.get("frame_samples", c["width"] * c["lines"])
+    for n in range(nframes):
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
+
+
 @pytest.mark.parametrize("case", ["i_full", "m_full"])
 def test_raster_stage_equals_oracle(golden, case):
     """The raster kernel's output (before filter and audio) against the oracle's raster."""
