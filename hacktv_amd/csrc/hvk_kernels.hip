@@ -381,14 +381,24 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * pulse that starts before its sample 0 (src/vbidata.c:211-216) */
 	{
 		const int ids[3] = { d.pulse_left, d.pulse_mid, d.pulse_next };
+		/* where the three pulses are, read together (one wait) rather than one field at a time between branches */
+		int poff[3], plen[3], pst[3];
+#pragma unroll
+		for(int p = 0; p < 3; p++)
+		{
+			const int idc = ids[p] < 0 ? 0 : ids[p];
+			poff[p] = k.pulse_offset[idc];
+			plen[p] = k.pulse_length[idc];
+			pst[p] = k.pulse_start[idc];
+		}
 #pragma unroll
 		for(int p = 0; p < 3; p++)
 		{
 			const int id = ids[p];
 			if(id < 0) continue;
-			const int off = k.pulse_offset[id] + (p == 2 ? W : 0);
-			const int len = k.pulse_length[id];
-			const int16_t *v = pulses + k.pulse_start[id];
+			const int off = poff[p] + (p == 2 ? W : 0);
+			const int len = plen[p];
+			const int16_t *v = pulses + pst[p];
 			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
 			if(x0 + SPL <= off || x0 >= off + len) continue;
 			/* loads first, at clamped positions, then the range tests: a load under a lane test
@@ -416,21 +426,25 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * the picture where the frame covers the line, black elsewhere */
 	if(active && x0 < ar_eff && x0 + SPL > d.al)
 	{
+		/* one 16-byte read of the lane's 8 luma values whether the picture covers them all or not
+		 * (what it does not cover is not used): eight reads under lane tests would each be waited for */
+		const int4v y = *(const int4v *) (Yb + x0);
+		const int yv[SPL] = { (int) (short) (y.x & 0xFFFF), y.x >> 16, (int) (short) (y.y & 0xFFFF), y.y >> 16,
+		                      (int) (short) (y.z & 0xFFFF), y.z >> 16, (int) (short) (y.w & 0xFFFF), y.w >> 16 };
 		if(x0 >= ax0 && x0 + SPL <= ax1)
 		{
-			const int4v y = *(const int4v *) (Yb + x0);
-			s[0] = (int) (short) (y.x & 0xFFFF); s[1] = y.x >> 16;
-			s[2] = (int) (short) (y.y & 0xFFFF); s[3] = y.y >> 16;
-			s[4] = (int) (short) (y.z & 0xFFFF); s[5] = y.z >> 16;
-			s[6] = (int) (short) (y.w & 0xFFFF); s[7] = y.w >> 16;
+#pragma unroll
+			for(int i = 0; i < SPL; i++) s[i] = yv[i];
 		}
 		else
 		{
+			int black_y = k.black_y;
+			asm volatile("" : "+s"(black_y));        /* one scalar load, not one per sample */
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
 			{
 				const int x = x0 + i;
-				if(x >= d.al && x < ar_eff) s[i] = (x >= ax0 && x < ax1) ? (int) Yb[x] : k.black_y;
+				if(x >= d.al && x < ar_eff) s[i] = (x >= ax0 && x < ax1) ? yv[i] : black_y;
 			}
 		}
 	}
@@ -471,13 +485,21 @@ void hvk_k_raster(const hvk_kconst_t k,
 		if(wx1 > k.burst_left && wx0 < k.burst_left + k.burst_width)
 		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
 		{
+			/* window values first, at clamped positions (see the source row above) */
+			int bw[SPL];
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int b = x0 + i - k.burst_left;
+				bw[i] = burst_win[b < 0 ? 0 : (b < k.burst_width ? b : k.burst_width - 1)];
+			}
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
 			{
 				const int b = x0 + i - k.burst_left;
 				if(b >= 0 && b < k.burst_width)
 				{
-					const int w = burst_win[b];
+					const int w = bw[i];
 					vu[i] = (((k.burst_q * w) >> 15) & 0xFFFF) | (((k.burst_i * w) >> 15) << 16);
 				}
 			}
