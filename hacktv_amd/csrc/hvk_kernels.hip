@@ -776,11 +776,12 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	/* four copies of the NICAM pulse table (int16), copy s shifted left by s entries, so that
 	 * any run of 8 entries starts 8-byte aligned in one of them: one ds_read2_b64, lanes side by
-	 * side; staged once per workgroup */
-	if(k.has_nicam && !ABLATE(16))
-	{
-		for(int q = threadIdx.x; q < HVK_NICAM_TAPD / 2; q += blockDim.x) ((int4v *) tapd)[q] = ((const int4v *) nicam_tapd)[q];
-	}
+	 * side; staged once per workgroup. The load goes out here, the LDS write waits until the first
+	 * tile's own loads are on their way. */
+	static_assert(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP >= HVK_NICAM_TAPD / 2, "one pulse-table vector per thread");
+	const bool tap_mine = k.has_nicam && !ABLATE(16) && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	int4v tap_stage = { 0, 0, 0, 0 };
+	if(k.has_nicam && !ABLATE(16)) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
 
 	/* MF: this lane's share of the tap matrix, 16 rows (8 outputs x I, Q) by 64 window positions */
 	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
@@ -801,28 +802,68 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	/* stage raster samples [n0 - LEAD, n0 + TILE + LEAD) as dwords; the slab
 	 * keeps one line before and one after the frame */
+	constexpr int NG = NPL / 8;                 /* MF: groups of 8 window samples */
+	constexpr int WP = (NG + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL);
+	int4u wd[WP];
+
+	/* ---- this tile's loads, in the order their values are needed; none under a lane test where
+	 * it can be helped (such a load is waited for on the spot) ---- */
+	int symv = 0, cc_tile = 0;
+	if(k.has_nicam)
+	{
+		/* one dense row per tile, prepared by the host: HVK_NICAM_SYMS symbol words
+		 * then the mixer position of the tile's first sample -- a single load
+		 * that depends on nothing but the block index */
+		const int *row = tilesyms + ((size_t) blockIdx.y * tiles + tile) * HVK_NICAM_ROW;
+		cc_tile = row[HVK_NICAM_SYMS];
+		symv = row[t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1];
+	}
+	if(VF != 0 && MF)
+	{
+		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
+		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
+#pragma unroll
+		for(int i = 0; i < WP; i++)
+		{
+			const int q = min(t + i * (HVK_TILE / HVK_SPL), NG - 1);
+			int4u d = { 0, 0, 0, 0 };
+			if(EXACT) d = ((const int4u *) src)[q];
+			else if(q * 4 + 3 < limit) d = ((const int4u *) src)[q];
+			else
+			{
+				if(q * 4 + 0 < limit) d.x = src[q * 4 + 0];
+				if(q * 4 + 1 < limit) d.y = src[q * 4 + 1];
+				if(q * 4 + 2 < limit) d.z = src[q * 4 + 2];
+			}
+			wd[i] = d;
+		}
+	}
+	/* the serial-carrier samples of this lane: needed last */
+	const int nl = n0 + x0;
+	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
+	if(k.has_carriers && (EXACT || nl + SPL <= FS))
+	{
+		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
+		car0 = c[0];
+		car1 = c[1];
+	}
+
+	if(it == 0 && tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
+
+	/* stage raster samples [n0 - LEAD, n0 + TILE + LEAD) as dwords; the slab
+	 * keeps one line before and one after the frame */
 	if(VF != 0 && MF)
 	{
 		/* The int8 matrix unit multiplies bytes: the window goes to LDS as a plane of high bytes
 		 * (x >> 8, signed) and a plane of low bytes less 128 (x & 255, read as signed after ^ 0x80),
 		 * eight samples per lane and pass, v_perm_b32 picking the bytes out of the sample pairs. */
-		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
-		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
-		constexpr int NG = NPL / 8;
 #pragma unroll
-		for(int i = 0; i < (NG + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL); i++)
+		for(int i = 0; i < WP; i++)
 		{
 			const int q = t + i * (HVK_TILE / HVK_SPL);
 			if(q < NG)
 			{
-				int4u d = { 0, 0, 0, 0 };
-				if(EXACT || q * 4 + 3 < limit) d = ((const int4u *) src)[q];
-				else
-				{
-					if(q * 4 + 0 < limit) d.x = src[q * 4 + 0];
-					if(q * 4 + 1 < limit) d.y = src[q * 4 + 1];
-					if(q * 4 + 2 < limit) d.z = src[q * 4 + 2];
-				}
+				const int4u d = wd[i];
 				int2v ph, pl;
 				ph.x = (int) __builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x07050301u);
 				ph.y = (int) __builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x07050301u);
@@ -853,30 +894,14 @@ void hvk_k_filter(const hvk_kconst_t k,
 		}
 	}
 
-	/* the serial-carrier samples of this lane, fetched now so the read overlaps the filter */
-	const int nl = n0 + x0;
-	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
-	if(k.has_carriers && (EXACT || nl + SPL <= FS))
-	{
-		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
-		car0 = c[0];
-		car1 = c[1];
-	}
-
-	int cc_tile = 0;
 	if(k.has_nicam)
 	{
 		/* the symbols whose pulses can touch this tile, oldest first: start
 		 * (relative to the tile's first sample) and sign pair. The schedule
 		 * (src/nicam728.c:398-407) is tabulated per frame by the host. */
-		/* one dense row per tile, prepared by the host: HVK_NICAM_SYMS symbol words
-		 * then the mixer position of the tile's first sample -- a single load
-		 * that depends on nothing but the block index */
-		const int *row = tilesyms + ((size_t) blockIdx.y * tiles + tile) * HVK_NICAM_ROW;
-		cc_tile = row[HVK_NICAM_SYMS];
 		if(t < HVK_NICAM_SYMS)
 		{
-			const int v = row[t];
+			const int v = symv;
 			const int st = (v >> 3) - n0;
 			const bool valid = (v & 4) && st < HVK_TILE;
 			/* constellation { 0, 1, 3, 2 }: bit 0 -> +I else -I, bit 1 -> +Q else -Q
@@ -897,6 +922,17 @@ void hvk_k_filter(const hvk_kconst_t k,
 	__syncthreads();
 
 	const int n = n0 + x0;                      /* this lane's first output, frame local; lanes past the frame compute and store nothing */
+
+	/* the mixer rows of this lane's samples: on their way while the filter and the pulse sums run */
+	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 }, mix_q0 = { 0, 0, 0, 0 }, mix_q1 = { 0, 0, 0, 0 };
+	if(k.has_nicam && !ABLATE(64))
+	{
+		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
+		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
+		else cp %= k.nicam_cc_len;
+		mix_a0 = ((const int4u *) (nicam_cca + cp))[0]; mix_a1 = ((const int4u *) (nicam_cca + cp))[1];
+		mix_q0 = ((const int4u *) (nicam_ccb + cp))[0]; mix_q1 = ((const int4u *) (nicam_ccb + cp))[1];
+	}
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
 
@@ -1053,14 +1089,10 @@ void hvk_k_filter(const hvk_kconst_t k,
 			bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
 		}
 
-		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
-		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
-		else cp %= k.nicam_cc_len;
-		/* mixer: the two rows of the rotation, (i, -q) and (q, i), tabulated */
+		/* mixer: the two rows of the rotation, (i, -q) and (q, i), tabulated (loaded before the filter) */
 		if(!ABLATE(64))
 		{
-		const int4u a0 = ((const int4u *) (nicam_cca + cp))[0], a1 = ((const int4u *) (nicam_cca + cp))[1];
-		const int4u q0 = ((const int4u *) (nicam_ccb + cp))[0], q1 = ((const int4u *) (nicam_ccb + cp))[1];
+		const int4u a0 = mix_a0, a1 = mix_a1, q0 = mix_q0, q1 = mix_q1;
 		const int ca[SPL] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 		const int cq[SPL] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
 #pragma unroll
