@@ -16,12 +16,14 @@
  *                      _vid_next_line_raster, src/video.c:2864-3066 -- and
  *                      writes it as int16, 16 bytes per lane.
  *
- *   hvk_k_filter       one workgroup per 1024 output samples (= one PAL line
- *                      at 16 Msps), 8 consecutive outputs per lane. Stages
- *                      1024 + 50 raster samples in LDS, runs the 51-tap
- *                      real->complex VSB filter (or real low-pass) with
- *                      v_dot2c_i32_i16 on packed sample pairs against taps
- *                      held in SGPRs (src/fir.c:564-615, :304-355), adds the
+ *   hvk_k_filter       two waves per 1024 output samples (= one PAL line at 16 Msps),
+ *                      four such tiles per workgroup, 8 consecutive outputs per
+ *                      lane. The 51-tap real->complex VSB filter (or real
+ *                      low-pass) is a banded matrix product on the int8 matrix
+ *                      unit -- taps and samples split into bytes, four
+ *                      v_mfma_i32_16x16x64_i8 per 128 outputs recombined exactly
+ *                      modulo 2^32 (src/fir.c:564-615, :304-355); taps the split
+ *                      cannot express keep the v_dot2c_i32_i16 form. Adds the
  *                      serial-carrier side stream and the NICAM DQPSK signal
  *                      (pulse overlap-add + mixer, src/nicam728.c:342-411),
  *                      and stores interleaved int16 I/Q, 32 bytes per lane.
@@ -39,8 +41,9 @@
  * symbols from one table store; anti-copy pulse runs) listed per frame by the
  * host. S-Video has kernel variants of its own (template parameter).
  *
- * Nothing here is a dense contraction: no MFMA. The work is bounded by VALU
- * issue (dot2 count) and by the 4 B/sample HBM write.
+ * The one dense contraction is the video filter. The raster kernel is bound by VALU
+ * issue, the filter kernel by its HBM streams (2 + 4 B/sample read, 4 B/sample
+ * written) and the NICAM stage.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
