@@ -411,7 +411,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int i = 0; i < SPL; i++)
 			{
 				const int idx = x0 + i - off;
-				pv[i] = v[idx < 0 ? 0 : (idx < len ? idx : len - 1)];
+				pv[i] = v[idx < 0 || len < 1 ? 0 : (idx < len ? idx : len - 1)];
 			}
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
@@ -494,7 +494,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 			for(int i = 0; i < SPL; i++)
 			{
 				const int b = x0 + i - k.burst_left;
-				bw[i] = burst_win[b < 0 ? 0 : (b < k.burst_width ? b : k.burst_width - 1)];
+				bw[i] = burst_win[b < 0 || k.burst_width < 1 ? 0 : (b < k.burst_width ? b : k.burst_width - 1)];
 			}
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
