@@ -43,6 +43,7 @@ struct hvk_slot_t {
 	int width, height;      /* after the centre crop */
 	int interlaced;
 	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
+	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
 };
 
 struct hvk_engine {
@@ -80,6 +81,8 @@ struct hvk_engine {
 
 	/* constant tables */
 	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_ccb;
+	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
+	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
 	int mfma_ci, mfma_cq;
 	/* per batch */
@@ -224,6 +227,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	/* tools/ablate.py: only a library built with ABLATE=1 has the switches in its kernels; results are WRONG when set */
 	if(getenv("HVK_ABLATE")) e->t.k.ablate = atoi(getenv("HVK_ABLATE"));
+	if(getenv("HVK_LEVELS"))
+	{
+		const char *v = getenv("HVK_LEVELS");
+		e->levels_mode = !strcmp(v, "table") ? HVK_LEVELS_TABLE : (!strcmp(v, "compute") ? HVK_LEVELS_COMPUTE : HVK_LEVELS_AUTO);
+	}
 
 	/* the kernels exist for these chroma filter lengths (pixel rates of about 11 to 28 MHz) and for
 	 * the NICAM pulse lengths the LDS table holds: say so now, not at the first render */
@@ -599,6 +607,25 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 		else for(int c = 0; c < w; c++) o[c] = p[(int64_t) c * pixel_stride];
 	}
 
+	/* How many colours? 4096 pixels on a regular grid, counted through a small open hash. Graphics and
+	 * test cards have a few hundred, and the same ones in every frame: their level-table entries stay
+	 * in cache. Camera pictures have tens of thousands per frame: most look-ups would miss. */
+	{
+		enum { SAMPLES = 4096, SLOTS = 8192, MANY = 1024 };
+		static const uint32_t EMPTY = 0xFFFFFFFFu;
+		std::vector<uint32_t> seen(SLOTS, EMPTY);
+		const size_t npx = (size_t) w * h;
+		int distinct = 0;
+		for(int i = 0; i < SAMPLES && npx > 0; i++)
+		{
+			const uint32_t c = e->h_frame[(size_t) ((uint64_t) i * npx / SAMPLES)] & 0xFFFFFFu;
+			uint32_t hsh = (c * 2654435761u) >> 19;      /* 13 bits */
+			while(seen[hsh] != EMPTY && seen[hsh] != c) hsh = (hsh + 1) & (SLOTS - 1);
+			if(seen[hsh] == EMPTY) { seen[hsh] = c; distinct++; }
+		}
+		s->many_colours = distinct > MANY;
+	}
+
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 	if(e->secam)
 	{
@@ -609,6 +636,13 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	}
 	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, e->h_frame, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
+
+extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
+{
+	if(!e || mode < HVK_LEVELS_AUTO || mode > HVK_LEVELS_COMPUTE) return(HVK_ERROR);
+	e->levels_mode = mode;
 	return(HVK_OK);
 }
 
@@ -916,6 +950,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	}
 
 	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
+	int many = 0;
 
 	for(int i = 0; i < nframes; i++)
 	{
@@ -943,6 +978,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 			d->vframe_y = (k.active_lines - d->fb_height) / 2;
 			d->fb_interlaced = ss->interlaced;
 			d->fb_valid = ss->valid;
+			if(ss->valid && ss->many_colours) many = 1;
 			d->parity = (int32_t) ((d->frame_index + 1) & 1);
 			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
 		}
@@ -1103,6 +1139,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
 	}
 
+	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
 	e->staged = nframes;
 	e->staged_first = first_frame;
 	e->staged_stride = stride;
@@ -1150,6 +1187,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
 	ra.yuv = e->d_yuv;
+	ra.yuvparams = e->d_yuvparams;
+	ra.levels_computed = e->levels_computed;
 	ra.clut = (const hvk_c16_t *) e->d_clut;
 	ra.burst_win = (const int16_t *) e->d_burst;
 	ra.ghost = (const int16_t *) e->d_ghost;

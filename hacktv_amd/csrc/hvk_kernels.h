@@ -31,6 +31,8 @@ typedef struct {
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const void *yuv;            /* 2^24 x int16x4 */
+	const void *yuvparams;      /* hvk_yuvparams_t on the device */
+	int levels_computed;        /* this block's pictures have many colours: compute the levels, do not look them up */
 	const hvk_c16_t *clut;
 	const int16_t *burst_win;
 	const int16_t *ghost;

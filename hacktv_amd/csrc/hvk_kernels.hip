@@ -115,13 +115,11 @@ __device__ __forceinline__ void fir8(const int *d, const int *tp, int (&acc)[SPL
 
 /* ------------------------------------------------------------------ */
 
-__global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
+/* RGB -> (Y, U, V) levels of one colour: src/video.c:3917-3958, same order of operations, no
+ * contraction. Used to expand the 2^24-entry table once per engine and, when the pictures have too
+ * many colours for the table's cache lines to be found again (moving video), per pixel. */
+__device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p)
 {
-	const hvk_yuvparams_t &p = *pp;
-	unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-	if(c > 0xFFFFFFu) return;
-
-	/* src/video.c:3917-3958, same order of operations, no contraction */
 	double r = p.glut[(c & 0xFF0000) >> 16];
 	double g = p.glut[(c & 0x00FF00) >> 8];
 	double b = p.glut[(c & 0x0000FF) >> 0];
@@ -154,7 +152,14 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 	o.y = (short) round(u * 32767);
 	o.z = (short) round(v * 32767);
 	o.w = 0;
-	lut[c] = o;
+	return(o);
+}
+
+__global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
+{
+	unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+	if(c > 0xFFFFFFu) return;
+	lut[c] = level_of(c, *pp);
 }
 
 /* ------------------------------------------------------------------ */
@@ -164,7 +169,7 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
  *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
  *   V  [CL]  a lane's FIR window starts at its own first sample index
  * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
-template<int NT, int SECAM, int SV, int EXTRAS, int WC>
+template<int NT, int SECAM, int SV, int EXTRAS, int WC, int LV>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
@@ -179,6 +184,7 @@ void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_linedesc_t *__restrict__ desc,
                   const int16_t *__restrict__ pulses,
                   const short4v *__restrict__ yuv,
+                  const hvk_yuvparams_t *__restrict__ yuvp,   /* LV: what the table is made from */
                   const int *__restrict__ clut,
                   const int16_t *__restrict__ burst_win,
                   const int16_t *__restrict__ ghost,
@@ -332,7 +338,14 @@ void hvk_k_raster(const hvk_kconst_t k,
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++) asm volatile("" : "+v"(rgb[i]));
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i] & 0xFFFFFFu];
+		for(int i = 0; i < HVK_PIX_PASSES; i++)
+		{
+			/* LV: the levels computed from the colour instead of looked up -- the same arithmetic that
+			 * fills the table. A table entry is 8 bytes somewhere in 128 MiB; pictures with many colours
+			 * (moving video) pay an HBM round trip and a 64-byte sector for most pixels. */
+			if(LV) c[i] = level_of(rgb[i] & 0xFFFFFFu, *yuvp);
+			else c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i] & 0xFFFFFFu];
+		}
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
@@ -1388,17 +1401,26 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-template<int NT, int SECAM, int SV, int EXTRAS, int WC>
-static int _launch_raster2(const hvk_raster_args_t *a, hipStream_t stream)
+template<int NT, int SECAM, int SV, int EXTRAS, int WC, int LV>
+static int _launch_raster3(const hvk_raster_args_t *a, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv, (const int *) a->clut,
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC, LV>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv,
+	                   (const hvk_yuvparams_t *) a->yuvparams, (const int *) a->clut,
 	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->C, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+template<int NT, int SECAM, int SV, int EXTRAS, int WC>
+static int _launch_raster2(const hvk_raster_args_t *a, hipStream_t stream)
+{
+	/* levels computed per pixel or looked up: the engine decides per block of frames (hvk_engine.cpp) */
+	if(a->levels_computed) return(_launch_raster3<NT, SECAM, SV, EXTRAS, WC, 1>(a, stream));
+	return(_launch_raster3<NT, SECAM, SV, EXTRAS, WC, 0>(a, stream));
 }
 
 template<int NT, int SECAM, int SV, int EXTRAS>

@@ -19,7 +19,7 @@ SYMBOLS = [
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
-    "hvk_launch_strided_out", "hvk_set_stream",
+    "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
@@ -57,6 +57,7 @@ def lib():
         L.hvk_get_framebuffer_length.argtypes = [vp]
         L.hvk_get_framebuffer_length.restype = C.c_size_t
         L.hvk_set_chroma_ghost.argtypes = [vp, vp, i32]
+        L.hvk_set_levels.argtypes = [vp, i32]
         L.hvk_get_chroma_ghost.argtypes = [vp, vp, i32]
         L.hvk_frame_upload.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32]
         L.hvk_teletext_packets.argtypes = [vp, i32, vp, C.c_uint32]
@@ -259,6 +260,10 @@ class Engine:
 
     def timing_enable(self, on=True):
         return self._chk("hvk_timing_enable", lib().hvk_timing_enable(self.h, 1 if on else 0))
+
+    def set_levels(self, mode):
+        """0 auto, 1 table look-up, 2 computed per pixel (hvk_set_levels)."""
+        return self._chk("hvk_set_levels", lib().hvk_set_levels(self.h, mode))
 
     def timing_read(self, which):
         ms = C.c_double(0)

@@ -294,6 +294,18 @@ void *hvk_output_device_ptr(hvk_engine_t *e);
 /* Average duration in milliseconds of each kernel over the launches since
  * the last reset, measured with HIP events on the engine's stream.
  * which: 0 raster kernel, 1 filter/audio kernel. */
+/* RGB -> level conversion of the raster (src/video.c:3912-3958 builds a 2^24-entry table, :2981-2995
+ * looks every pixel up). The engine has the same table in HBM and the arithmetic that fills it as a
+ * device function; results are identical. Looking up is cheaper while the pictures' colours are few
+ * and recur (test cards, graphics: the entries stay in cache); computing is cheaper for camera
+ * pictures, where most look-ups would be an HBM round trip (measured: DESIGN.md section 6).
+ * AUTO (default; environment HVK_LEVELS=table|compute|auto overrides the default) decides per staged
+ * block from a sample of each uploaded picture's pixels. */
+#define HVK_LEVELS_AUTO    0
+#define HVK_LEVELS_TABLE   1
+#define HVK_LEVELS_COMPUTE 2
+int hvk_set_levels(hvk_engine_t *e, int mode);
+
 int hvk_timing_enable(hvk_engine_t *e, int on);
 int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches);
 

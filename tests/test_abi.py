@@ -88,6 +88,8 @@ def test_bad_arguments_fail_with_codes_not_crashes():
         assert L.hvk_fetch_as(h, buf, 0, 16, 99, 0) == H.HVK_ERROR                    # no such sample type
         assert L.hvk_sync(h) == H.HVK_NO_DEVICE
         assert L.hvk_set_chroma_ghost(h, buf, 1000) == H.HVK_ERROR
+        assert L.hvk_set_levels(h, 3) == H.HVK_ERROR and L.hvk_set_levels(h, -1) == H.HVK_ERROR
+        assert L.hvk_set_levels(h, 2) == H.HVK_OK and L.hvk_set_levels(h, 0) == H.HVK_OK
         assert L.hvk_audio_write(h, None, 0) in (H.HVK_OK, H.HVK_ERROR)
     assert L.hvk_get_info(None, None) == H.HVK_ERROR
     assert L.hvk_render(None, 1, None, None) == H.HVK_ERROR

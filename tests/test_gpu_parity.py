@@ -483,6 +483,36 @@ def test_random_pictures_and_loud_audio(golden, case, members):
     assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // c["width"], bad[0] % c["width"])
 
 
+@pytest.mark.parametrize("case", ["i_full", "m_full", "l_full", "pal_sv"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_levels_looked_up_or_computed(golden, case, mode):
+    """hvk_set_levels(): the RGB -> level conversion by the 2^24-entry table (1) or by the arithmetic
+    that fills it, per pixel (2). AUTO picks by the number of colours, so the other tests see the table
+    with the test card and the arithmetic with random pictures; here each is forced on both."""
+    conf, sr = golden.conf(case)
+    c = golden.cases[case]
+    L = c["lines"]
+    rng = np.random.default_rng(11)
+    frames = [golden.frame(case), rng.integers(0, 1 << 24, golden.frame(case).shape, dtype=np.uint32)]
+    with oracle.Oracle(conf, sr) as o:
+        o.set_audio(golden.audio, True)
+        want = []
+        for fb in frames:
+            o.set_frame(fb)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        e.set_levels(mode)
+        for i, fb in enumerate(frames):
+            e.frame_upload(i, fb)
+        while e.audio_needed(2) > 0:
+            e.audio_write(golden.audio)
+        e.render(2, slots=[0, 1])
+        got = e.fetch(0, 2 * e.info["frame_samples"])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first difference at line %d x %d" % (bad[0] // c["width"], bad[0] % c["width"])
+
+
 def test_frame_numbers_far_beyond_32_bits_of_samples(golden):
     """Without sound the stream has a period of 4 frames at 16 Msps (colour table position, PAL
     sequence): frames 4 000 000 .. 4 000 003 -- 2.56e12 samples in, a month of signal -- must equal frames
