@@ -143,9 +143,10 @@ __device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p
 		v = (v + 4406250.0 - 4328125.0) / 1000000.0;
 	}
 
-	y = y < -1 ? -1 : (y > 1 ? 1 : y);
-	u = u < -1 ? -1 : (u > 1 ? 1 : u);
-	v = v < -1 ? -1 : (v > 1 ? 1 : v);
+	/* limited to [-1, 1] (src/video.c:3954-3956; never NaN): v_max_f64 / v_min_f64 */
+	y = fmin(fmax(y, -1.0), 1.0);
+	u = fmin(fmax(u, -1.0), 1.0);
+	v = fmin(fmax(v, -1.0), 1.0);
 
 	short4v o;
 	o.x = (short) round(y * 32767);
