@@ -748,7 +748,7 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 
 
 template<int NT, int VF, int SV, int EXACT, int MF>
-__global__ __launch_bounds__(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP)
+__global__ __launch_bounds__(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP, MF ? 8 : 1)
 void hvk_k_filter(const hvk_kconst_t k,
                   const hvk_packed_taps_t itaps,
                   const hvk_packed_taps_t qtaps,
