@@ -221,7 +221,7 @@ def main():
         # timing_read() gives the average duration of ONE launch; a step launches each kernel once per chunk
         # of frames (rasters on one stream, filters on another: they overlap)
         kernels = {"filter": ("hvk_k_filter<51, 3, 0, 1, 1>", filter_ms, n_f),
-                   "raster": ("hvk_k_raster<13, 0, 0, 0, 1024>", raster_ms, n_r)}
+                   "raster": ("hvk_k_raster<13, 0, 0, 0, 1024, 0>", raster_ms, n_r)}
         lps = max(1, int(round(n_f / max(1, args.steps))))      # launches per step
         dom = "filter" if filter_ms >= raster_ms else "raster"
         tj = {}
