@@ -17,6 +17,7 @@ extern "C" {
 #define HVK_SPL          8      /* samples per lane in both kernels */
 #define HVK_TILE         1024   /* samples per filter workgroup */
 #define HVK_MAX_VF_TAPS  64
+#define HVK_PULSE_PAD    8      /* zero int16 either side of every sync pulse in the flat value table */
 #define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
 #define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
 #define HVK_VBI_OPS      64     /* VBI lines per frame (32 teletext + WSS + 4 VITC + CC608 + 20 ACP + spare) */

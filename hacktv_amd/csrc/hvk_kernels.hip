@@ -58,6 +58,8 @@ typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 /* four dwords that are only dword aligned: global_load_dwordx4 needs no more */
 typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
+/* ... and four that are only 2-byte aligned (global memory only) */
+typedef int    int4a2  __attribute__((ext_vector_type(4), aligned(2)));
 
 #define SPL HVK_SPL
 
@@ -276,13 +278,13 @@ void hvk_k_raster(const hvk_kconst_t k,
 	{
 		/* without a picture: the pool's first pixel, eight times (never used) -- no branch, no merge */
 		const bool pix = has_pix && !ABLATE(8);
+		/* the pool holds dense pictures (hvk_frame_upload gathers strided and flipped sources): pixel stride 1 */
 		const uint32_t *row = pix ? pool + f.fb_offset + (int64_t) vy * f.line_stride : pool;
-		const int64_t ps = pix ? f.pixel_stride : 0;
 #pragma unroll
 		for(int i = 0; i < HVK_PIX_PASSES; i++)
 		{
 			const int x = ax0 + t + i * nth;
-			rgb[i] = row[(int64_t) ((x < ax1 ? x : ax1 - 1) - px0) * ps];
+			rgb[i] = row[pix ? (x < ax1 ? x : ax1 - 1) - px0 : 0];
 		}
 	}
 	int ghost_u = 0, ghost_v = 0;
@@ -417,25 +419,18 @@ void hvk_k_raster(const hvk_kconst_t k,
 			const int len = plen[p];
 			const int16_t *v = pulses + pst[p];
 			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
-			if(x0 + SPL <= off || x0 >= off + len) continue;
-			/* loads first, at clamped positions, then the range tests: a load under a lane test
-			 * would get a wait of its own, eight round trips in a row */
-			int pv[SPL];
+			/* the lane's 8 values in one 16-byte load (2-byte aligned: global memory takes that): the table
+			 * has HVK_PULSE_PAD zeros either side of every pulse, so a lane before or behind the pulse
+			 * reads zeros and no sample needs a range test. A pulse never crosses into the following
+			 * line; the part of the own left pulse before sample 0 belongs to the previous line. */
+			const int idx0 = x0 - off;
+			const int ic = idx0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (idx0 < len ? idx0 : len);
+			const int4a2 pw = *(const int4a2 *) (v + ic);
+			const int pv[SPL] = { (int) (short) (pw.x & 0xFFFF), pw.x >> 16, (int) (short) (pw.y & 0xFFFF), pw.y >> 16,
+			                      (int) (short) (pw.z & 0xFFFF), pw.z >> 16, (int) (short) (pw.w & 0xFFFF), pw.w >> 16 };
+			/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
 #pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int idx = x0 + i - off;
-				pv[i] = v[idx < 0 || len < 1 ? 0 : (idx < len ? idx : len - 1)];
-			}
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int idx = x0 + i - off;
-				/* a pulse never crosses into the following line; the part of
-				 * the own left pulse before sample 0 belongs to the previous line */
-				/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
-				if(idx >= 0 && idx < len && x0 + i < W) s[i] = SECAM ? wrap16(s[i] + pv[i]) : s[i] + pv[i];
-			}
+			for(int i = 0; i < SPL; i++) if(WC || x0 + i < W) s[i] = SECAM ? wrap16(s[i] + pv[i]) : s[i] + pv[i];
 		}
 	}
 

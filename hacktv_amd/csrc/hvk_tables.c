@@ -1139,7 +1139,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		const double len[5] = { c->hsync_width, c->vsync_short_width, c->vsync_long_width,
 		                        c->vsync_short_width, c->vsync_long_width };
 		double rise = c->sync_rise * EDGE_0_100 * pixel_rate;
-		int total = 0, o = 0, first;
+		int total = HVK_PULSE_PAD, o = 0, first;      /* HVK_PULSE_PAD zeros in front of and behind every pulse: the kernel reads 8 values wherever a lane stands */
 
 		t->k.npulses = 5;
 		for(i = 0; i < 5; i++)
@@ -1147,7 +1147,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			t->k.pulse_length[i] = _quantise_pulse(NULL, &first, at[i] * pixel_rate, len[i] * pixel_rate, rise, (int) sync_amp);
 			t->k.pulse_offset[i] = first;
 			t->k.pulse_start[i] = total;
-			total += t->k.pulse_length[i];
+			total += t->k.pulse_length[i] + HVK_PULSE_PAD;
 
 			/* a pulse must end inside its own line (true for every standard) */
 			if(first + t->k.pulse_length[i] > t->k.width || first < -t->k.width) return(HVK_UNSUPPORTED);
