@@ -80,7 +80,7 @@ struct hvk_engine {
 	hipStream_t own_stream;
 
 	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_ccb;
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca;
 	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
 	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
@@ -335,10 +335,10 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		/* device forms of the NICAM tables: the pulse as int16 behind HVK_NICAM_LEAD
 		 * zeros and zero padded (no bounds test is needed), in four copies of which
 		 * copy s starts s entries later, so that any eight consecutive entries start
-		 * 8-byte aligned in one of them; the mixer as the two rows of the rotation
-		 * matrix, (i, -q) and (q, i), extended by 8 entries past the wrap */
+		 * 8-byte aligned in one of them; the mixer as the first row of the rotation
+		 * matrix, (i, -q), extended by 8 entries past the wrap (the kernel derives the second) */
 		std::vector<int16_t> tapd(4 * HVK_NICAM_TAPD, 0);
-		std::vector<int> cca(k.nicam_cc_len + 8), ccb(k.nicam_cc_len + 8);
+		std::vector<int> cca(k.nicam_cc_len + 8);
 		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
 		for(int i = 0; i < k.nicam_ntaps; i++)
 		{
@@ -350,11 +350,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		{
 			const hvk_c16_t c = e->t.nicam_cc[i % k.nicam_cc_len];
 			cca[i] = ((int) c.i & 0xFFFF) | ((-(int) c.q) << 16);
-			ccb[i] = ((int) c.q & 0xFFFF) | ((int) c.i << 16);
 		}
 		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * sizeof(int16_t)));
 		OPENCHK(_upload(&e->d_cca, cca.data(), cca.size() * 4));
-		OPENCHK(_upload(&e->d_ccb, ccb.data(), ccb.size() * 4));
 	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
@@ -464,7 +462,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
-		                e->d_tapd, e->d_cca, e->d_ccb, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -1213,7 +1211,6 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;
 	fa.nicam_cca = (const int *) e->d_cca;
-	fa.nicam_ccb = (const int *) e->d_ccb;
 	fa.mfma_a = e->d_mfma_a;
 	fa.mfma_ci = e->mfma_ci;
 	fa.mfma_cq = e->mfma_cq;

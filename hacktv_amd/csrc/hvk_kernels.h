@@ -55,7 +55,6 @@ typedef struct {
 	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
 	const int *nicam_tapd;      /* 4 x HVK_NICAM_TAPD int16: the pulse, four shifted copies, zero padded */
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
-	const int *nicam_ccb;       /* nicam_cc_len + 8 dwords: (cc.q,  cc.i) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
 	int16_t *iq;

@@ -753,7 +753,6 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW]: symbols (start << 3 | valid << 2 | dsym), mixer position */
                   const int *__restrict__ nicam_tapd,    /* pulse taps: four shifted int16 copies, zero padded (hvk_engine.cpp) */
                   const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
-                  const int *__restrict__ nicam_ccb,     /* mixer (q,  i) */
                   const int16_t *__restrict__ Cq,        /* --s-video: the Q channel, laid out like S */
                   const int4v *__restrict__ mfma_a,      /* MF: the taps as A operand, [hh, hl][lane] (hvk_engine.cpp:_mfma_taps) */
                   const int mfma_ci, const int mfma_cq,  /* MF: 128 * sum of the taps */
@@ -935,15 +934,14 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	const int n = n0 + x0;                      /* this lane's first output, frame local; lanes past the frame compute and store nothing */
 
-	/* the mixer rows of this lane's samples: on their way while the filter and the pulse sums run */
-	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 }, mix_q0 = { 0, 0, 0, 0 }, mix_q1 = { 0, 0, 0, 0 };
+	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
+	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 };
 	if(k.has_nicam && !ABLATE(64))
 	{
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
 		else cp %= k.nicam_cc_len;
 		mix_a0 = ((const int4u *) (nicam_cca + cp))[0]; mix_a1 = ((const int4u *) (nicam_cca + cp))[1];
-		mix_q0 = ((const int4u *) (nicam_ccb + cp))[0]; mix_q1 = ((const int4u *) (nicam_ccb + cp))[1];
 	}
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
@@ -1101,12 +1099,15 @@ void hvk_k_filter(const hvk_kconst_t k,
 			bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
 		}
 
-		/* mixer: the two rows of the rotation, (i, -q) and (q, i), tabulated (loaded before the filter) */
+		/* mixer: the rotation's first row (i, -q) is tabulated (loaded before the filter) */
 		if(!ABLATE(64))
 		{
-		const int4u a0 = mix_a0, a1 = mix_a1, q0 = mix_q0, q1 = mix_q1;
+		const int4u a0 = mix_a0, a1 = mix_a1;
 		const int ca[SPL] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-		const int cq[SPL] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+		/* the second row (q, i) from the first (i, -q): halves swapped, the low one negated (|q| <= 32767) */
+		int cq[SPL];
+#pragma unroll
+		for(int i = 0; i < SPL; i++) cq[i] = pk_mad16(shift_pair(ca[i], ca[i]), (int) 0x0001FFFFu, 0);
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
@@ -1476,7 +1477,7 @@ static int _launch_filter3(const hvk_filter_args_t *a, hipStream_t stream)
 	const int per_wg = HVK_TILES_PER_WG * HVK_FILTER_GROUP;
 	hipLaunchKernelGGL((hvk_k_filter<NT, VF, SV, EXACT, MF>), dim3((tiles + per_wg - 1) / per_wg, a->nframes), dim3(HVK_TILE / SPL * HVK_FILTER_GROUP), 0, stream,
 	                   a->k, a->itaps, a->qtaps, a->fdesc, a->S, (const int *) a->carriers, a->tilesyms,
-	                   a->nicam_tapd, a->nicam_cca, a->nicam_ccb, a->C, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq,
+	                   a->nicam_tapd, a->nicam_cca, a->C, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq,
 	                   (int *) a->iq, a->out_stride, tiles);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
