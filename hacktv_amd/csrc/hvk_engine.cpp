@@ -364,7 +364,19 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(k.rs_L)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
-		OPENCHK(_upload(&e->d_rs_taps, e->t.rs_taps, sizeof(int16_t) * k.rs_L * k.rs_ataps));
+		/* one 16-byte aligned row of 12 packed dwords per phase: pairs (t[0], t[1]) ... oldest sample
+		 * first; a 21-tap phase gets a zero 22nd (hvk_k_resample stages the rows as they are) */
+		std::vector<int> rows((size_t) k.rs_L * 12, 0);
+		for(int ph = 0; ph < k.rs_L; ph++)
+		{
+			for(int m = 0; m < 12; m++)
+			{
+				const int lo = 2 * m < k.rs_ataps ? e->t.rs_taps[ph * k.rs_ataps + 2 * m] : 0;
+				const int hi = 2 * m + 1 < k.rs_ataps ? e->t.rs_taps[ph * k.rs_ataps + 2 * m + 1] : 0;
+				rows[(size_t) ph * 12 + m] = (lo & 0xFFFF) | (hi << 16);
+			}
+		}
+		OPENCHK(_upload(&e->d_rs_taps, rows.data(), rows.size() * sizeof(int)));
 	}
 	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
 	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3, hipHostMallocDefault));

@@ -1230,7 +1230,7 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
 #define HVK_RS_WIN  (4 * HVK_RS_TILE + 72 + 8)      /* raster samples a tile can need: 1024 D / L + ataps, D <= 4 L */
 #define HVK_RS_NP   11                              /* tap pairs per phase: ataps is 21 or 22 for every L (ntaps = 21 L | 1) */
 #define HVK_RS_ROW  12                              /* dwords per phase row in LDS: 16-byte aligned rows */
-__global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int16_t *__restrict__ taps,
+__global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int *__restrict__ taps,
                                                       int16_t *__restrict__ S2)
 {
 	__shared__ __attribute__((aligned(16))) int win[HVK_RS_WIN / 2];        /* raster samples, two per dword */
@@ -1250,18 +1250,48 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	const long n_hi = (long) (((r0 + HVK_RS_TILE - 1) * D) / L);
 	const int count2 = (int) ((n_hi - n_lo + 2) / 2);           /* dwords */
 
-	/* taps of phase p: pairs (t[0], t[1]) ... oldest sample first; a 21-tap phase gets a zero 22nd */
-	for(int j = t; j < (int) L * HVK_RS_ROW; j += 256)
+	/* Loads first, LDS writes after: a load inside a loop with lane-dependent bounds is waited for in
+	 * every round. The tap rows come packed from the host (hvk_engine.cpp), 3 x 16 bytes per phase;
+	 * the window as two int16 per dword from clamped positions, zero outside the slab. */
+	constexpr int TPASS = (256 * HVK_RS_ROW / 4 + 255) / 256;       /* 3 */
+	constexpr int WPASS = (HVK_RS_WIN / 2 + 255) / 256;
+	int4v trow[TPASS];
+	int wlo[WPASS], whi[WPASS];
+	const int nrows4 = (int) L * (HVK_RS_ROW / 4);
+#pragma unroll
+	for(int i = 0; i < TPASS; i++)
 	{
-		const int p = j / HVK_RS_ROW, m = j % HVK_RS_ROW;
-		const int lo = 2 * m < A ? taps[p * A + 2 * m] : 0, hi = 2 * m + 1 < A ? taps[p * A + 2 * m + 1] : 0;
-		tp[j] = (lo & 0xFFFF) | (hi << 16);
+		const int j = t + i * 256;
+		trow[i] = ((const int4v *) taps)[j < nrows4 ? j : nrows4 - 1];
 	}
-	for(int j = t; j < count2 + 1 && j < HVK_RS_WIN / 2; j += 256)
+#pragma unroll
+	for(int i = 0; i < WPASS; i++)
 	{
-		const long p = n_lo + 2 * j + k.width;                  /* slab position: one halo line in front */
-		const int lo = (p >= 0 && p < slab_in) ? in[p] : 0, hi = (p + 1 >= 0 && p + 1 < slab_in) ? in[p + 1] : 0;
-		win[j] = (lo & 0xFFFF) | (hi << 16);
+		wlo[i] = whi[i] = 0;
+		if(i * 256 < count2 + 1)                                /* the same for every lane */
+		{
+			const long p = n_lo + 2 * (t + i * 256) + k.width;      /* slab position: one halo line in front */
+			const long pa = p < 0 ? 0 : (p < slab_in ? p : slab_in - 1), pb = p + 1 < 0 ? 0 : (p + 1 < slab_in ? p + 1 : slab_in - 1);
+			wlo[i] = in[pa];
+			whi[i] = in[pb];
+		}
+	}
+#pragma unroll
+	for(int i = 0; i < TPASS; i++)
+	{
+		const int j = t + i * 256;
+		if(j < nrows4) ((int4v *) tp)[j] = trow[i];
+	}
+#pragma unroll
+	for(int i = 0; i < WPASS; i++)
+	{
+		const int j = t + i * 256;
+		if(i * 256 < count2 + 1 && j < count2 + 1 && j < HVK_RS_WIN / 2)
+		{
+			const long p = n_lo + 2 * j + k.width;
+			const int lo = (p >= 0 && p < slab_in) ? wlo[i] : 0, hi = (p + 1 >= 0 && p + 1 < slab_in) ? whi[i] : 0;
+			win[j] = (lo & 0xFFFF) | (hi << 16);
+		}
 	}
 	__syncthreads();
 
@@ -1309,7 +1339,7 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream)
 {
 	const int tiles = (k->s_stride + HVK_RS_TILE - 1) / HVK_RS_TILE;
-	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int16_t *) taps, (int16_t *) S2);
+	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
