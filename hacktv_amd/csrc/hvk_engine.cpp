@@ -328,7 +328,12 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENCHK(_upload(&e->d_desc, e->t.desc, sizeof(hvk_linedesc_t) * 2 * k.lines));
 	OPENCHK(_upload(&e->d_pulses, e->t.pulse_values, sizeof(int16_t) * (e->t.pulse_total + 8)));
 	OPENCHK(_upload(&e->d_clut, e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len));
-	OPENCHK(_upload(&e->d_burst, e->t.burst_win, sizeof(int16_t) * k.burst_width));
+	{
+		/* HVK_PULSE_PAD zeros either side: a lane reads its 8 window values in one load wherever it stands */
+		std::vector<int16_t> bw((size_t) k.burst_width + 2 * HVK_PULSE_PAD, 0);
+		for(int i = 0; i < k.burst_width; i++) bw[HVK_PULSE_PAD + i] = e->t.burst_win[i];
+		OPENCHK(_upload(&e->d_burst, bw.data(), bw.size() * sizeof(int16_t)));
+	}
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
 	if(k.has_nicam)
 	{
@@ -1200,7 +1205,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.yuvparams = e->d_yuvparams;
 	ra.levels_computed = e->levels_computed;
 	ra.clut = (const hvk_c16_t *) e->d_clut;
-	ra.burst_win = (const int16_t *) e->d_burst;
+	ra.burst_win = (const int16_t *) e->d_burst + HVK_PULSE_PAD;
 	ra.ghost = (const int16_t *) e->d_ghost;
 	ra.pool = e->d_pool;
 	ra.fdesc = e->d_fdesc;

@@ -497,14 +497,11 @@ void hvk_k_raster(const hvk_kconst_t k,
 		if(wx1 > k.burst_left && wx0 < k.burst_left + k.burst_width)
 		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
 		{
-			/* window values first, at clamped positions (see the source row above) */
-			int bw[SPL];
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int b = x0 + i - k.burst_left;
-				bw[i] = burst_win[b < 0 || k.burst_width < 1 ? 0 : (b < k.burst_width ? b : k.burst_width - 1)];
-			}
+			/* the lane's 8 window values in one 16-byte load from the zero-padded table (see the sync pulses) */
+			const int b0 = x0 - k.burst_left;
+			const int4a2 bwv = *(const int4a2 *) (burst_win + (b0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (b0 < k.burst_width ? b0 : k.burst_width)));
+			const int bw[SPL] = { (int) (short) (bwv.x & 0xFFFF), bwv.x >> 16, (int) (short) (bwv.y & 0xFFFF), bwv.y >> 16,
+			                      (int) (short) (bwv.z & 0xFFFF), bwv.z >> 16, (int) (short) (bwv.w & 0xFFFF), bwv.w >> 16 };
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
 			{
