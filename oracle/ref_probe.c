@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <unistd.h>
 #include "hacktv.h"
+#include "../hacktv_amd/csrc/shim/hvk_shim_depth.h"
 
 #define REF_FLAG_FILTER   (1 << 0)
 #define REF_FLAG_NOAUDIO  (1 << 1)
@@ -223,6 +224,18 @@ void ref_close(ref_probe_t *p)
 		}
 	}
 	else free(p);
+}
+
+/* The lines the reference's pipeline holds back -- the distance in its ring of output lines between the
+ * buffer the raster (or the raw baseband reader) writes and the one handed out (src/video.c:3578,
+ * :4675-4688, :2873, :2408) -- and what the shim's own count says for the same vid_t
+ * (hacktv_amd/csrc/shim/hvk_shim_depth.h). The video filter's delay is one line at every rate in use. */
+int ref_pipeline_depths(ref_probe_t *p, int32_t *reference, int32_t *shim)
+{
+	const vid_t *s = &p->vid;
+	*reference = s->olines - (s->raw_bb_file ? 1 : 2);
+	*shim = hvk_shim_pipeline_depth(s, 1);
+	return(0);
 }
 
 /* Geometry and levels, in a fixed order the python side names */

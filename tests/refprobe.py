@@ -46,6 +46,7 @@ def lib():
         L.ref_set_source.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         L.ref_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ref_pipeline_depths.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.ref_render_lines.restype = ctypes.c_long
         L.ref_render_lines.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         L.ref_table.restype = ctypes.c_long
@@ -78,6 +79,12 @@ class RefProbe:
         self._keep = (f, a, c)
         lib().ref_set_source(self.p, f.ctypes.data, f.shape[0], f.shape[2], f.shape[1], interlaced, par[0], par[1],
                              c.ctypes.data if c is not None else None, a.ctypes.data, a.shape[0])
+
+    def pipeline_depths(self):
+        """(reference, shim): lines held back by the reference's line pipeline, and the shim's count of them."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        lib().ref_pipeline_depths(self.p, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
 
     def table(self, name, dtype):
         n = lib().ref_table(self.p, name.encode(), None, 0)

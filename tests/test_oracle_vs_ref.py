@@ -118,3 +118,24 @@ def test_random_source_through_the_real_reference(setup):
     assert out.returncode == 0 and words, out.stderr[-2000:]
     # "EQUAL-EXCEPT-LINE-ENDS": the heap bytes the reference over-reads changed during its run
     assert words[-1].startswith("EQUAL"), words[-1]
+
+
+@pytest.mark.parametrize("mode,sr,flags,pr", [
+    ("i", 16000000, 0, 0),
+    ("i", 16000000, refprobe.FLAG_FILTER, 0),
+    ("l", 16000000, refprobe.FLAG_FILTER, 0),
+    ("i", 20250000, refprobe.FLAG_FILTER | refprobe.FLAG_VITS, 13500000),
+    ("pal", 14000000, refprobe.FLAG_NOAUDIO, 13500000),
+    ("m", 13500000, refprobe.FLAG_ACP | refprobe.FLAG_CC608 | refprobe.FLAG_VITC, 0),
+    ("pal-fm", 16000000, 0, 0),
+    ("secam-fm", 16000000, 0, 0),
+    ("i", 16000000, refprobe.FLAG_FILTER | refprobe.FLAG_INTERLACE | refprobe.FLAG_WSS_AUTO, 0),
+    ("g", 13500000, refprobe.FLAG_A2STEREO, 0),
+])
+def test_shim_counts_the_lines_in_flight_like_the_reference(mode, sr, flags, pr):
+    """At the end of a source the reference hands out no more lines: what is still in its line pipeline is
+    lost, one line per buffer between the raster's and the output's window in its ring. The
+    video.h shim withholds as many; its count (hvk_shim_depth.h) next to the reference's own ring, same vid_t."""
+    with refprobe.RefProbe(mode, sr, flags, pixel_rate=pr) as r:
+        reference, shim = r.pipeline_depths()
+    assert shim == reference and 3 <= reference <= 8
