@@ -97,3 +97,6 @@ class HvkInfo(C.Structure):
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
 
 HVK_OK, HVK_ERROR, HVK_OUT_OF_MEMORY, HVK_NO_DEVICE, HVK_UNSUPPORTED = 0, -1, -2, -3, -4
+
+# hvk_set_levels()
+LEVELS_AUTO, LEVELS_TABLE, LEVELS_COMPUTE = 0, 1, 2
