@@ -36,6 +36,8 @@
 
 extern "C" {
 int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
+int hvk_fused_supported(const hvk_kconst_t *k, const void *mfma_a);
+int hvk_launch_fused(const hvk_raster_args_t *ra, const hvk_filter_args_t *fa, int run_lines, hipStream_t stream);
 }
 
 struct hvk_slot_t {
@@ -107,7 +109,11 @@ struct hvk_engine {
 	int32_t *h_sym;
 	int32_t *h_tile;
 	uint8_t *sym_tmp;
-	int tiles;
+	int tiles;                  /* NICAM symbol rows per frame: one per filter tile, or one per line for the fused kernel */
+	int tile_len;               /* samples a row covers: HVK_TILE, or the line width */
+	int fused;                  /* this configuration renders in one kernel (hvk_fused.hip) */
+	int run_lines;              /* ... whose workgroups walk this many lines each */
+	int last_fused;             /* the last launch did: the raster slab in HBM was not written */
 	uint32_t *h_frame;
 
 	hvk_slot_t *slots;          /* [frame_slots] */
@@ -325,6 +331,14 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
 
+	/* One kernel for the whole per-sample path where the configuration allows (hvk_fused.hip); HVK_NO_FUSE=1
+	 * keeps the raster and the filter kernel apart (tests run both), HVK_RUN_LINES sets the lines a
+	 * workgroup walks. */
+	e->fused = hvk_fused_supported(&e->t.k, e->d_mfma_a) && !getenv("HVK_NO_FUSE");
+	e->run_lines = getenv("HVK_RUN_LINES") ? atoi(getenv("HVK_RUN_LINES")) : 25;
+	if(e->run_lines < 1) e->run_lines = 1;
+	e->tile_len = e->fused ? k.width : HVK_TILE;
+
 	OPENCHK(_upload(&e->d_desc, e->t.desc, sizeof(hvk_linedesc_t) * 2 * k.lines));
 	OPENCHK(_upload(&e->d_pulses, e->t.pulse_values, sizeof(int16_t) * (e->t.pulse_total + 8)));
 	OPENCHK(_upload(&e->d_clut, e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len));
@@ -395,7 +409,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	if(e->t.k.has_nicam)
 	{
-		e->tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+		e->tiles = (k.frame_samples + e->tile_len - 1) / e->tile_len;
 		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride * 4, hipHostMallocDefault));
 		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4));
@@ -1069,7 +1083,7 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 				while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
 				for(int b = 0; b < e->tiles; b++)
 				{
-					const int64_t pos = (int64_t) b * HVK_TILE;
+					const int64_t pos = (int64_t) b * e->tile_len;
 					int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
 					while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
 					for(int q = 0; q < HVK_NICAM_SYMS; q++)
@@ -1171,23 +1185,10 @@ extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
 	return(HVK_OK);
 }
 
-extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
+/* the kernels' arguments for the staged batch */
+static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride)
 {
-	return(hvk_launch_strided_out(e, d_iq, 1));
-}
-
-extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride)
-{
-	if(!e || out_stride < 1) return(HVK_ERROR);
-	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(e->staged < 1) return(HVK_ERROR);
-	/* FM video: the device buffer holds the modulator's input; the samples exist on the host only (hvk_fetch) */
-	if(e->t.k.fm_video && d_iq != NULL) return(HVK_UNSUPPORTED);
-
-	HIPCHK(hipSetDevice(e->device));
-
-	hvk_raster_args_t ra;
+	hvk_raster_args_t &ra = *pra;
 	memset(&ra, 0, sizeof(ra));
 	ra.k = e->t.k;
 	ra.ctaps = e->ctaps;
@@ -1216,7 +1217,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	ra.first_frame = e->staged_first;
 	ra.frame_stride = e->staged_stride;
 
-	hvk_filter_args_t fa;
+	hvk_filter_args_t &fa = *pfa;
 	memset(&fa, 0, sizeof(fa));
 	fa.k = e->t.k;
 	fa.itaps = e->itaps;
@@ -1235,16 +1236,48 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;
 
+}
+
+extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
+{
+	return(hvk_launch_strided_out(e, d_iq, 1));
+}
+
+extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride)
+{
+	if(!e || out_stride < 1) return(HVK_ERROR);
+	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(e->staged < 1) return(HVK_ERROR);
+	/* FM video: the device buffer holds the modulator's input; the samples exist on the host only (hvk_fetch) */
+	if(e->t.k.fm_video && d_iq != NULL) return(HVK_UNSUPPORTED);
+
+	HIPCHK(hipSetDevice(e->device));
+
+	hvk_raster_args_t ra;
+	hvk_filter_args_t fa;
+	_kernel_args(e, &ra, &fa, d_iq, out_stride);
+
 	const bool timed = e->timing && e->ev_used < HVK_TIMING_SLOTS;
 	hipEvent_t *ev = timed ? e->ev[e->ev_used] : NULL;
 	int r;
 
 	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
-	if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
-	if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->stream)) != HVK_OK) return(r);
-	if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
-	if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
+	if(e->fused)
+	{
+		/* one kernel: its time is reported as the second (filter) kernel's, the first one's is nil */
+		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
+		if((r = hvk_launch_fused(&ra, &fa, e->run_lines, e->stream)) != HVK_OK) return(r);
+	}
+	else
+	{
+		if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->stream)) != HVK_OK) return(r);
+		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
+		if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
+	}
 	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
+	e->last_fused = e->fused;
 	if(!e->t.k.fm_video && (e->t.k.swap_iq || e->d_off || e->d_pass))
 	{
 		if((r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream)) != HVK_OK) return(r);
@@ -1336,6 +1369,17 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 	const size_t FS = k.raster_samples;
 	if(first + count > (size_t) e->last_frames * FS) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
+	if(e->last_fused)
+	{
+		/* the fused kernel keeps the raster in LDS: run the raster kernel (the same device code) over the
+		 * staged batch to have it in HBM */
+		hvk_raster_args_t ra;
+		hvk_filter_args_t fa;
+		if(e->staged != e->last_frames) return(HVK_ERROR);
+		_kernel_args(e, &ra, &fa, NULL, 1);
+		int r = hvk_launch_raster(&ra, e->stream);
+		if(r != HVK_OK) return(r);
+	}
 	HIPCHK(hipStreamSynchronize(e->stream));
 	while(count > 0)
 	{
@@ -1348,6 +1392,32 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 }
 
 extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
+
+/* The kernels hvk_launch() enqueues for this configuration, as rocprofv3 prints them, ';' between
+ * them: the launchers' choice of template arguments restated (hvk_kernels.hip, hvk_fused.hip). */
+extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
+{
+	if(!e || !buf || n < 1) return(HVK_ERROR);
+	const hvk_kconst_t &k = e->t.k;
+	const int nt = k.secam ? 1 : (k.colour ? k.chroma_ntaps : 1);
+	const int lv = e->levels_computed ? 1 : 0;
+	if(e->fused)
+	{
+		const int extras = (k.vbi || k.vits) ? 1 : 0;
+		const int wc = (!extras && nt == 13 && k.width == 1024) ? 1024 : 0;
+		snprintf(buf, n, "hvk_k_fused<%d, %d, %d, %d, %d>", nt, k.vf_type, extras, wc, lv);
+		return(HVK_OK);
+	}
+	const int sv = k.s_video ? 1 : 0;
+	const int extras = (sv || k.vbi || k.vits || k.rawbb || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
+	const int wc = (!k.secam && !sv && !extras && nt == 13 && k.width == 1024) ? 1024 : 0;
+	const int vnt = k.vf_type ? k.vf_ntaps : 1;
+	const int exact = (k.frame_samples % HVK_TILE == 0 && k.s_stride - k.s_lead - k.frame_samples >= 128) ? 1 : 0;
+	const int mf = (vnt == 51 && e->d_mfma_a) ? 1 : 0;
+	snprintf(buf, n, "hvk_k_raster<%d, %d, %d, %d, %d, %d>;%shvk_k_filter<%d, %d, %d, %d, %d>", nt, k.secam ? 1 : 0, sv, extras, wc, lv,
+	         k.rs_L ? "hvk_k_resample;" : "", vnt, k.vf_type, sv, exact, mf);
+	return(HVK_OK);
+}
 
 extern "C" int hvk_timing_enable(hvk_engine_t *e, int on)
 {

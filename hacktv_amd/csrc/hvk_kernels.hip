@@ -50,113 +50,14 @@
 #include "hvk_internal.h"
 #include "hvk_kernels.h"
 
-typedef short  short2v __attribute__((ext_vector_type(2)));
-typedef short  short4v __attribute__((ext_vector_type(4)));
-typedef int    int4v   __attribute__((ext_vector_type(4)));
-typedef int    int2v   __attribute__((ext_vector_type(2)));
-typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-/* four dwords that are only dword aligned: global_load_dwordx4 needs no more */
-typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
-typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
-/* ... and four that are only 2-byte aligned (global memory only) */
-typedef int    int4a2  __attribute__((ext_vector_type(4), aligned(2)));
+#include "hvk_device.h"
 
-#define SPL HVK_SPL
-
-/* Profiling switches (tools/ablate.py): stages can be skipped to time the rest -- with WRONG output.
- * Compiled in only with -DHVK_ENABLE_ABLATE=1 (make -C hacktv_amd/csrc ABLATE=1); a normal build has none. */
-#ifndef HVK_ENABLE_ABLATE
-#define HVK_ENABLE_ABLATE 0
-#endif
-#define ABLATE(bit) (HVK_ENABLE_ABLATE && (k.ablate & (bit)))
-#define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
 #define HVK_FILTER_GROUP 4    /* filter tiles a workgroup works on side by side (two waves each): they share the staged NICAM pulse table */
 #define HVK_TILES_PER_WG 1    /* consecutive filter tiles walked by one workgroup (4 measured 10 % slower: fewer independent workgroups to overlap) */
 
-__device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
-__device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
-__device__ __forceinline__ int dot2(int a, int b, int c)
-{
-	return(__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false));
-}
-/* (lo >> 16) | (hi << 16): the pair of int16 that starts one element later */
-__device__ __forceinline__ int shift_pair(int lo, int hi) { return((int) __builtin_amdgcn_alignbit((unsigned) hi, (unsigned) lo, 16)); }
-/* (sat16(lo) & 0xFFFF) | (sat16(hi) << 16) */
-__device__ __forceinline__ int sat_pack16(int lo, int hi) { return(__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(lo, hi))); }
 __device__ __forceinline__ int floordiv(int a, int b) { int q = a / b; return((a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q); }
 
-/* 8 consecutive FIR outputs from a register window of packed int16 pairs.
- * d[] holds window elements w[0..], two per dword; output i is
- *   sum_k tap[k] * w[START + i + k]
- * with START in {0,1}. tp[] holds the NT taps packed two per dword and zero
- * padded. Outputs whose first element is dword aligned use d[] directly, the
- * others use the pairs shifted by one element. */
-template<int NT, int START>
-__device__ __forceinline__ void fir8(const int *d, const int *tp, int (&acc)[SPL])
-{
-	constexpr int NP = (NT + 1) / 2;
-	constexpr int NS = SPL / 2 + NP;   /* shifted pairs needed */
-	int sh[NS];
-
-#pragma unroll
-	for(int m = 0; m < NS; m++) sh[m] = shift_pair(d[m], d[m + 1]);
-
-#pragma unroll
-	for(int i = 0; i < SPL; i++)
-	{
-		int a = 0;
-		const int e = START + i;        /* first window element of this output */
-#pragma unroll
-		for(int j = 0; j < NP; j++)
-		{
-			a = dot2((e & 1) ? sh[e / 2 + j] : d[e / 2 + j], tp[j], a);
-		}
-		acc[i] = a;
-	}
-}
-
 /* ------------------------------------------------------------------ */
-
-/* RGB -> (Y, U, V) levels of one colour: src/video.c:3917-3958, same order of operations, no
- * contraction. Used to expand the 2^24-entry table once per engine and, when the pictures have too
- * many colours for the table's cache lines to be found again (moving video), per pixel. */
-__device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p)
-{
-	double r = p.glut[(c & 0xFF0000) >> 16];
-	double g = p.glut[(c & 0x00FF00) >> 8];
-	double b = p.glut[(c & 0x0000FF) >> 0];
-	double y, u, v;
-
-	y = r * p.rw + g * p.gw + b * p.bw;
-	u = (b - y) * p.eu;
-	v = (r - y) * p.ev;
-
-	y = (p.black + (y * p.range)) * p.level;
-	if(!p.secam)
-	{
-		u *= p.chroma_scale;
-		v *= p.chroma_scale;
-	}
-	else
-	{
-		/* frequency deviation of the D'b / D'r rest frequencies from the FM centre,
-		 * in units of the 1 MHz full scale (src/video.c:3951-3952, :45-48) */
-		u = (u + 4250000.0 - 4328125.0) / 1000000.0;
-		v = (v + 4406250.0 - 4328125.0) / 1000000.0;
-	}
-
-	/* limited to [-1, 1] (src/video.c:3954-3956; never NaN): v_max_f64 / v_min_f64 */
-	y = fmin(fmax(y, -1.0), 1.0);
-	u = fmin(fmax(u, -1.0), 1.0);
-	v = fmin(fmax(v, -1.0), 1.0);
-
-	short4v o;
-	o.x = (short) round(y * 32767);
-	o.y = (short) round(u * 32767);
-	o.z = (short) round(v * 32767);
-	o.w = 0;
-	return(o);
-}
 
 __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 {
@@ -167,32 +68,14 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 
 /* ------------------------------------------------------------------ */
 
-/* LDS layout of the raster kernel (int16 elements):
- *   Y  [YL]  luma of the picture part of the line, index = sample x
- *   U  [CL]  chroma channels, index j <-> sample x = j - H (H = ntaps / 2), so
- *   V  [CL]  a lane's FIR window starts at its own first sample index
- * YL and CL are multiples of 8 elements: every lane's slice is 16-byte aligned. */
+/* One workgroup per scanline of the slab (hvk_device.h has the steps): the samples go to the raster
+ * slab in HBM, 16 bytes per lane. */
 template<int NT, int SECAM, int SV, int EXTRAS, int WC, int LV>
 __global__ __launch_bounds__(1024)
 void hvk_k_raster(const hvk_kconst_t k,
                   const hvk_packed_taps_t ctaps,
                   const hvk_packed_taps_t notch,        /* SECAM luma notch, 51 taps */
-                  const int16_t *__restrict__ chroma,   /* SECAM: [frames][frame_samples] values to add */
-                  const int *__restrict__ vbi_sym,      /* VBI data lines: every table's symbols, { first sample, length, start } */
-                  const int16_t *__restrict__ vbi_val,  /*   symbol values */
-                  const unsigned *__restrict__ vbi_ops, /*   [frames][HVK_VBI_OPS][16]: symbol base, bits, blank range, -, 12 data words (LSB first) */
-                  const signed char *__restrict__ vbi_map, /* [frames][lines]: op of the line or -1 */
-                  const int16_t *__restrict__ vits_l,   /* VITS: [n][width] luma added */
-                  const int16_t *__restrict__ vits_c,   /*       [n][width] chroma amplitude */
-                  const hvk_linedesc_t *__restrict__ desc,
-                  const int16_t *__restrict__ pulses,
-                  const short4v *__restrict__ yuv,
-                  const hvk_yuvparams_t *__restrict__ yuvp,   /* LV: what the table is made from */
-                  const int *__restrict__ clut,
-                  const int16_t *__restrict__ burst_win,
-                  const int16_t *__restrict__ ghost,
-                  const uint32_t *__restrict__ pool,
-                  const hvk_framedesc_t *__restrict__ fdesc,   /* [frames][1 + fields]: the frame before, then the fields */
+                  const hvk_rptrs_t P,
                   int16_t *__restrict__ S,
                   int16_t *__restrict__ Cq,             /* --s-video: the sub-carrier alone, same slab geometry as S */
                   const int64_t first_frame,            /* frame y of the batch is stream frame first_frame + y * frame_stride */
@@ -206,7 +89,6 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * stay in that XCD's L2 from frame to frame */
 	if((int) blockIdx.x >= k.slab_lines) return;
 
-	constexpr int H = NT / 2;
 	/* WC: the line width when it is known at compile time (1024: PAL at 16 Msps) -- every lane then
 	 * holds 8 samples inside the line and the per-sample range tests fold away */
 	const int W = WC ? WC : k.width;
@@ -215,495 +97,33 @@ void hvk_k_raster(const hvk_kconst_t k,
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
 	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
-	/* one descriptor per frame, or per field with --interlace: the second field shows its own source
-	 * frame. The halo line in front is the last line of the frame BEFORE: on 525 lines it shows picture,
-	 * whose last samples the filter sees from this frame's first outputs. */
-	const hvk_framedesc_t f = fdesc[__builtin_amdgcn_readfirstlane(blockIdx.y * (k.fields + 1) + (rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1)))];   /* one scalar load of the whole descriptor */
 	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
 
-	/* which line of which frame, without dividing the global line number */
-	/* frame number and parity by arithmetic: the descriptor fetch below does not wait for fdesc */
-	const int64_t frame_index = first_frame + (int64_t) blockIdx.y * frame_stride;
-	int line0 = rel, par = (int) ((frame_index + 1) & 1);
-	bool own = true;
-	if(rel < 0) { line0 = k.lines - 1; par ^= 1; own = false; }
-	else if(rel >= k.lines) { line0 = rel - k.lines; par ^= 1; own = false; }
+	const hvk_line_t L = raster_setup<SECAM, EXTRAS>(k, P, (int) blockIdx.y, rel, first_frame, frame_stride);
 
-	if(rel < 0 && frame_index == 0)
+	if(L.zero)
 	{
-		/* before the stream: the filter history is zero, not blanking
-		 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
 		for(int i = 0; i < SPL; i++) if(x0 + i < W) out[x0 + i] = 0;
 		return;
 	}
 
-	const hvk_linedesc_t d = desc[__builtin_amdgcn_readfirstlane(par * k.lines + line0)];
-	const int pal = k.colour ? d.pal : 0;
-
-	/* a VBI data line (teletext packet, WSS, VITC: the host lists them per frame), an insertion test signal */
-	int vbi_op = -1, vits_i = -1;
-	if(EXTRAS && k.vbi && own) vbi_op = __builtin_amdgcn_readfirstlane((int) vbi_map[(size_t) blockIdx.y * k.lines + line0]);
-	if(EXTRAS && k.vits && own)
-	{
-		for(int i = 0; i < 4; i++) if(i < k.vits && line0 == k.vits_line[i]) vits_i = i;
-	}
-
-	const int YL = (W + 8 + 7) & ~7;
-	const int CL = (W + 2 * HVK_CHROMA_LEAD + 7) & ~7;
+	const int YL = raster_YL(W), CL = raster_CL(W);
 	int16_t *Yb = lds, *U = lds + YL, *V = lds + YL + CL;
 
-	/* ---- picture: one pixel per lane per pass, coalesced row reads ---- */
-	int vy = d.src_row;
-	if(vy >= 0 && k.interlaced != 0 && f.fb_interlaced != k.interlaced) vy += 1;
-	vy -= f.vframe_y;
-	if(vy < 0 || vy >= f.fb_height || !(own || rel < 0) || !f.fb_valid) vy = -1;
-
-	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
-	const bool active = !(EXTRAS && k.rawbb) && d.ar > d.al;    /* raw baseband input: no picture is drawn */
-	const bool has_pix = active && vy >= 0;
-	int ax0 = d.al > px0 ? d.al : px0;                          /* samples that show a source pixel */
-	int ax1 = d.ar < px0 + f.fb_width ? d.ar : px0 + f.fb_width;
-	if(!has_pix) ax1 = ax0 = 0;
-	/* the reference fills the border left of the picture without looking at the
-	 * right end of the active part (src/video.c:2972-2975): on a left-half line a
-	 * picture narrow enough to start beyond mid-line pushes the black fill past it */
-	const int ar_eff = (px0 > d.al && px0 > d.ar) ? px0 : d.ar;
-
-	/* The loads nothing but the descriptors depends on go out first, longest chain first: the source
-	 * row (its pixels index the level table, whose entries go to LDS), then the samples the reference
-	 * reads past its chroma buffer, then the sub-carrier phasors. All unconditional, at clamped
-	 * positions (ax1 > ax0 when there is a picture): a load under a lane test gets a wait of its own
-	 * from the compiler, and eight round trips in a row. */
 	uint32_t rgb[HVK_PIX_PASSES];
-	{
-		/* without a picture: the pool's first pixel, eight times (never used) -- no branch, no merge */
-		const bool pix = has_pix && !ABLATE(8);
-		/* the pool holds dense pictures (hvk_frame_upload gathers strided and flipped sources): pixel stride 1 */
-		const uint32_t *row = pix ? pool + f.fb_offset + (int64_t) vy * f.line_stride : pool;
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			const int x = ax0 + t + i * nth;
-			rgb[i] = row[pix ? (x < ax1 ? x : ax1 - 1) - px0 : 0];
-		}
-	}
-	int ghost_u = 0, ghost_v = 0;
-	if(NT > 1)
-	{
-		const int gt = t < H ? t : H - 1;
-		ghost_u = ghost[2 * gt + 0];
-		ghost_v = ghost[2 * gt + 1];
-	}
+	int ghost_u, ghost_v, c[SPL];
+	raster_loads<NT, WC>(k, P, L, t, nth, rgb, ghost_u, ghost_v, c);
 
-	/* sub-carrier phasors of this lane's samples, fetched now so that the read is
-	 * in flight during the picture and filter phases. The table position advances
-	 * by one line per line, colour or not: position relative to the frame's. */
-	int c[SPL];
-#pragma unroll
-	for(int i = 0; i < SPL; i++) c[i] = 0;
-	if((pal || (vits_i >= 0 && k.colour)) && x0 < W && !ABLATE(4))
+	if(L.pal)
 	{
-		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;   /* (fprev[] carries THIS frame's position) */
-		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
-		const int *cl = clut + coff + x0;
-		if(x0 + SPL <= W)
-		{
-			const int4u a = ((const int4u *) cl)[0], b = ((const int4u *) cl)[1];
-			c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-		}
-		else
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) c[i] = (x0 + i < W) ? cl[i] : 0;
-		}
-	}
-
-	if(pal)
-	{
-		/* clear both chroma channels; then the samples the reference reads past
-		 * the end of its buffer */
-		for(int j = t * 8; j < 2 * CL; j += nth * 8) *(int4v *) (U + j) = (int4v) { 0, 0, 0, 0 };
+		raster_clear(L, t, nth, U, CL);
 		__syncthreads();
-		if(t < H)
-		{
-			U[H + W + t] = (int16_t) ghost_u;
-			V[H + W + t] = (int16_t) ghost_v;
-		}
 	}
+	raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, ghost_u, ghost_v, Yb, U, V);
+	if(L.pal || L.has_pix) __syncthreads();
 
-	if(has_pix && !ABLATE(8))
-	{
-		/* all look-ups are issued before the first LDS write: the two dependent global loads
-		 * per pixel are paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width) */
-		short4v c[HVK_PIX_PASSES];
-		/* the pixels are first needed HERE: keeps the compiler from preparing the table addresses
-		 * (and waiting for the loads) right where they were issued */
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) asm volatile("" : "+v"(rgb[i]));
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			/* LV: the levels computed from the colour instead of looked up -- the same arithmetic that
-			 * fills the table. A table entry is 8 bytes somewhere in 128 MiB; pictures with many colours
-			 * (moving video) pay an HBM round trip and a 64-byte sector for most pixels. */
-			if(LV) c[i] = level_of(rgb[i] & 0xFFFFFFu, *yuvp);
-			else c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : yuv[rgb[i] & 0xFFFFFFu];
-		}
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			const int x = ax0 + t + i * nth;
-			if(x < ax1)
-			{
-				Yb[x] = c[i].x;
-				if(pal)
-				{
-					U[H + x] = c[i].y;
-					V[H + x] = c[i].z;
-				}
-			}
-		}
-	}
-
-	if(pal || has_pix) __syncthreads();
-
-	/* SECAM: picture lines and field identification lines carry the sub-carrier and get the luma notch */
-	const bool sc_line = SECAM && (active || (EXTRAS && d.secam_fid));
-	if(x0 >= W && !sc_line && vbi_op < 0) return;
-
-	/* ---- 8 consecutive samples per lane ---- */
-	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
-	const int wx0 = __builtin_amdgcn_readfirstlane(x0);
-	const int wx1 = wx0 + 64 * SPL;
-	int s[SPL];
-	int cq[SPL];                                /* S-Video: the line's Q channel */
-#pragma unroll
-	for(int i = 0; i < SPL; i++) { s[i] = k.blanking; cq[i] = 0; }
-
-	if(EXTRAS && k.rawbb)
-	{
-		/* raw baseband input (src/video.c:2431-2436): the line is taken from the external stream
-		 * (`chroma` holds it, slab layout) and mapped from its levels onto the mode's; C integer
-		 * arithmetic, division truncating */
-		if(x0 < W)
-		{
-			const int16_t *in = chroma + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W + x0;
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				if(x0 + i < W) s[i] = wrap16(k.blanking + (((int) in[i] - k.rawbb_blank) * (k.white - k.blanking)) / k.rawbb_range);
-			}
-		}
-	}
-	else
-	/* sync pulses: this line's own, and the part of the next line's left
-	 * pulse that starts before its sample 0 (src/vbidata.c:211-216) */
-	{
-		const int ids[3] = { d.pulse_left, d.pulse_mid, d.pulse_next };
-		/* where the three pulses are, read together (one wait) rather than one field at a time between branches */
-		int poff[3], plen[3], pst[3];
-#pragma unroll
-		for(int p = 0; p < 3; p++)
-		{
-			const int idc = ids[p] < 0 ? 0 : ids[p];
-			poff[p] = k.pulse_offset[idc];
-			plen[p] = k.pulse_length[idc];
-			pst[p] = k.pulse_start[idc];
-		}
-#pragma unroll
-		for(int p = 0; p < 3; p++)
-		{
-			const int id = ids[p];
-			if(id < 0) continue;
-			const int off = poff[p] + (p == 2 ? W : 0);
-			const int len = plen[p];
-			const int16_t *v = pulses + pst[p];
-			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
-			/* the lane's 8 values in one 16-byte load (2-byte aligned: global memory takes that): the table
-			 * has HVK_PULSE_PAD zeros either side of every pulse, so a lane before or behind the pulse
-			 * reads zeros and no sample needs a range test. A pulse never crosses into the following
-			 * line; the part of the own left pulse before sample 0 belongs to the previous line. */
-			const int idx0 = x0 - off;
-			const int ic = idx0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (idx0 < len ? idx0 : len);
-			const int4a2 pw = *(const int4a2 *) (v + ic);
-			const int pv[SPL] = { (int) (short) (pw.x & 0xFFFF), pw.x >> 16, (int) (short) (pw.y & 0xFFFF), pw.y >> 16,
-			                      (int) (short) (pw.z & 0xFFFF), pw.z >> 16, (int) (short) (pw.w & 0xFFFF), pw.w >> 16 };
-			/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
-#pragma unroll
-			for(int i = 0; i < SPL; i++) if(WC || x0 + i < W) s[i] = SECAM ? wrap16(s[i] + pv[i]) : s[i] + pv[i];
-		}
-	}
-
-	/* luma is assigned over whatever is there (src/video.c:2961-3009):
-	 * the picture where the frame covers the line, black elsewhere */
-	if(active && x0 < ar_eff && x0 + SPL > d.al)
-	{
-		/* one 16-byte read of the lane's 8 luma values whether the picture covers them all or not
-		 * (what it does not cover is not used): eight reads under lane tests would each be waited for */
-		const int4v y = *(const int4v *) (Yb + x0);
-		const int yv[SPL] = { (int) (short) (y.x & 0xFFFF), y.x >> 16, (int) (short) (y.y & 0xFFFF), y.y >> 16,
-		                      (int) (short) (y.z & 0xFFFF), y.z >> 16, (int) (short) (y.w & 0xFFFF), y.w >> 16 };
-		if(x0 >= ax0 && x0 + SPL <= ax1)
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) s[i] = yv[i];
-		}
-		else
-		{
-			int black_y = k.black_y;
-			asm volatile("" : "+s"(black_y));        /* one scalar load, not one per sample */
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int x = x0 + i;
-				if(x >= d.al && x < ar_eff) s[i] = (x >= ax0 && x < ax1) ? yv[i] : black_y;
-			}
-		}
-	}
-
-	if(pal && x0 < W)
-	{
-		int vu[SPL];                            /* (V, U) packed int16: the dot2 operand of the modulator */
-
-		/* zero-history low pass of both channels (src/fir.c:357-375), >> 15 and
-		 * clamp by the saturating pack. All-zero input (no picture on this line)
-		 * only matters where the ghost samples reach. */
-		if((has_pix || x0 + SPL + H > W) && !ABLATE(2))
-		{
-			constexpr int ND = SPL / 2 + (NT + 1) / 2 + 1;
-			int du[ND], dv[ND], u[SPL], v[SPL];
-			const int4v *pu = (const int4v *) (U + x0), *pv = (const int4v *) (V + x0);
-#pragma unroll
-			for(int m = 0; m < (ND + 3) / 4; m++)
-			{
-				const int4v a = pu[m], b = pv[m];
-				if(m * 4 + 0 < ND) { du[m * 4 + 0] = a.x; dv[m * 4 + 0] = b.x; }
-				if(m * 4 + 1 < ND) { du[m * 4 + 1] = a.y; dv[m * 4 + 1] = b.y; }
-				if(m * 4 + 2 < ND) { du[m * 4 + 2] = a.z; dv[m * 4 + 2] = b.z; }
-				if(m * 4 + 3 < ND) { du[m * 4 + 3] = a.w; dv[m * 4 + 3] = b.w; }
-			}
-			fir8<NT, 0>(du, ctaps.p, u);
-			fir8<NT, 0>(dv, ctaps.p, v);
-#pragma unroll
-			for(int i = 0; i < SPL; i++) vu[i] = sat_pack16(v[i] >> 15, u[i] >> 15);
-		}
-		else
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) vu[i] = 0;
-		}
-
-		/* colour burst replaces the filtered samples (src/video.c:3024-3029) */
-		if(wx1 > k.burst_left && wx0 < k.burst_left + k.burst_width)
-		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
-		{
-			/* the lane's 8 window values in one 16-byte load from the zero-padded table (see the sync pulses) */
-			const int b0 = x0 - k.burst_left;
-			const int4a2 bwv = *(const int4a2 *) (burst_win + (b0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (b0 < k.burst_width ? b0 : k.burst_width)));
-			const int bw[SPL] = { (int) (short) (bwv.x & 0xFFFF), bwv.x >> 16, (int) (short) (bwv.y & 0xFFFF), bwv.y >> 16,
-			                      (int) (short) (bwv.z & 0xFFFF), bwv.z >> 16, (int) (short) (bwv.w & 0xFFFF), bwv.w >> 16 };
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int b = x0 + i - k.burst_left;
-				if(b >= 0 && b < k.burst_width)
-				{
-					const int w = bw[i];
-					vu[i] = (((k.burst_q * w) >> 15) & 0xFFFF) | (((k.burst_i * w) >> 15) << 16);
-				}
-			}
-		}
-
-		/* quadrature modulation onto the sub-carrier (src/video.c:3032-3040):
-		 *   s += (lut.i * V * pal + lut.q * U) >> 15
-		 * as one dot2 of the packed table entry (i, q) with (V, U); the PAL switch
-		 * negates lut.i, which never is -32768. */
-		if(pal < 0)
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) c[i] = (c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF);
-		}
-		if(SV)
-		{
-			/* S-Video: onto the (empty) Q channel instead of the luma (src/video.c:3032) */
-#pragma unroll
-			for(int i = 0; i < SPL; i++) cq[i] = wrap16(dot2(c[i], vu[i], 0) >> 15);
-		}
-		else
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) s[i] = s[i] + (dot2(c[i], vu[i], 0) >> 15);   /* modulo 2^16 at the store (no SECAM here: pal is 0 there) */
-		}
-	}
-
-	if(sc_line)
-	{
-		/* SECAM lines with picture (src/video.c:3202-3229): first the luma notch
-		 * over the active picture, a zero-history FIR whose input starts at
-		 * active_left (everything left of it counts as zero) and which looks 25
-		 * samples past the picture's right edge; then the sub-carrier, computed in
-		 * stream order by the host (hvk_secam.c), is added. */
-		constexpr int NH = 25, NLEAD = 26;
-		int16_t *Z = lds + YL;                  /* index j <-> sample x = j - NLEAD */
-
-		if(!SV)                          /* S-Video leaves the luma alone (src/video.c:3206) */
-		{
-		if(t < 4) *(int4v *) (Z + t * 8) = (int4v) { 0, 0, 0, 0 };   /* Z does not overlap the picture's luma in LDS */
-		{
-			int4v z;
-			int w[SPL];
-#pragma unroll
-			for(int i = 0; i < SPL; i++) w[i] = (x0 + i >= k.active_left) ? s[i] : 0;
-			z.x = (w[0] & 0xFFFF) | (w[1] << 16); z.y = (w[2] & 0xFFFF) | (w[3] << 16);
-			z.z = (w[4] & 0xFFFF) | (w[5] << 16); z.w = (w[6] & 0xFFFF) | (w[7] << 16);
-			*(int4u *) (Z + NLEAD + x0) = (int4u) { z.x, z.y, z.z, z.w };
-		}
-		/* windows that run past the line belong to outputs right of the picture, which are not kept */
-		__syncthreads();
-
-		if(x0 + SPL > k.active_left && x0 < k.active_left + k.active_width)
-		{
-			constexpr int ND = SPL / 2 + (51 + 1) / 2 + 1;
-			int dn[ND], a[SPL];
-			const int4v *pz = (const int4v *) (Z + x0);
-#pragma unroll
-			for(int m = 0; m < (ND + 3) / 4; m++)
-			{
-				const int4v v = pz[m];
-				if(m * 4 + 0 < ND) dn[m * 4 + 0] = v.x;
-				if(m * 4 + 1 < ND) dn[m * 4 + 1] = v.y;
-				if(m * 4 + 2 < ND) dn[m * 4 + 2] = v.z;
-				if(m * 4 + 3 < ND) dn[m * 4 + 3] = v.w;
-			}
-			fir8<51, NLEAD - NH>(dn, notch.p, a);
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int x = x0 + i;
-				if(x >= k.active_left && x < k.active_left + k.active_width) s[i] = clamp16(a[i] >> 15);
-			}
-		}
-		}
-
-		if(own && x0 + SPL <= W)
-		{
-			const int4u cv = *(const int4u *) (chroma + (size_t) blockIdx.y * k.raster_samples + (size_t) rel * W + x0);
-			const int cw[4] = { cv.x, cv.y, cv.z, cv.w };
-#pragma unroll
-			for(int i = 0; i < SPL; i++)
-			{
-				const int cs = (i & 1) ? (cw[i / 2] >> 16) : (int) (short) (cw[i / 2] & 0xFFFF);
-				if(SV) cq[i] = cs;
-				else s[i] = wrap16(s[i] + cs);
-			}
-		}
-		else if(own && x0 < W)
-		{
-			/* the last, partial group of a line whose width is not a multiple of 8 */
-			const int16_t *cp = chroma + (size_t) blockIdx.y * k.raster_samples + (size_t) rel * W + x0;
-			for(int i = 0; i < SPL; i++)
-			{
-				if(x0 + i >= W) break;
-				if(SV) cq[i] = cp[i];
-				else s[i] = wrap16(s[i] + cp[i]);
-			}
-		}
-	}
-
-	if(vits_i >= 0 && x0 < W)
-	{
-		/* insertion test signal (src/vits.c:270-311): the line's luma waveform is added; its
-		 * chroma amplitude rides on the line's sub-carrier, rotated to the insertion phase */
-		const int16_t *vl = vits_l + (size_t) vits_i * W + x0, *vc = vits_c + (size_t) vits_i * W + x0;
-#pragma unroll
-		for(int i = 0; i < SPL; i++)
-		{
-			if(x0 + i < W)
-			{
-				s[i] = wrap16(s[i] + vl[i]);
-				if(k.colour)
-				{
-					/* on a V-switched line the chroma stage has negated the table's i half in place */
-					const int li = (pal < 0 ? -1 : 1) * (int) (short) (c[i] & 0xFFFF), lq = c[i] >> 16;
-					s[i] = wrap16(s[i] + ((((k.vits_pi * lq + k.vits_pq * li) >> 15) * (int) vc[i]) >> 15));
-				}
-			}
-		}
-	}
-
-	/* the line's ops, in the reference's process order (an anti-copy line can also carry VITC) */
-	for(int opi = vbi_op; opi >= 0;)
-	{
-		/* One data line = up to 384 shaped symbols, each a run of samples added for every set
-		 * bit (vbidata_render, src/vbidata.c:186-239). Set bits are walked by the whole
-		 * workgroup (the data words are wave-uniform); lane t adds the t-th value of the
-		 * symbol into an int32 line accumulator in LDS. */
-		int *acc = (int *) lds;
-		const unsigned *op = vbi_ops + ((size_t) blockIdx.y * HVK_VBI_OPS + opi) * HVK_VBI_OPWORDS;
-		const int base_next = __builtin_amdgcn_readfirstlane((int) op[0]);
-		const int sym_base = base_next & 0xFFFF;
-		opi = (base_next >> 16) - 1;            /* next op of this line, -1: none */
-		const int bits_mode = __builtin_amdgcn_readfirstlane((int) op[1]);
-		const int nbits = bits_mode & 0xFFFF, mode = bits_mode >> 16;
-		const int blank = __builtin_amdgcn_readfirstlane((int) op[2]);
-		const int blank_lo = blank & 0xFFFF, blank_hi = blank >> 16;
-
-		/* WSS first sets part of the line to black (src/wss.c:176-182) */
-		if(blank_hi > blank_lo)
-		{
-#pragma unroll
-			for(int i = 0; i < SPL; i++) if(x0 + i >= blank_lo && x0 + i < blank_hi) s[i] = k.black;
-		}
-
-		if(mode == 1)
-		{
-			/* anti-copy pulse pairs (src/acp.c:113-126): twelve runs of samples SET to one of two levels */
-			const int lv = __builtin_amdgcn_readfirstlane((int) op[3]);
-			const int la = (int) (short) (lv & 0xFFFF), lb = lv >> 16;
-			for(int q = 0; q < 12; q++)
-			{
-				const int seg = __builtin_amdgcn_readfirstlane((int) op[4 + q]);
-				const int lo = seg & 0xFFFF, hi = (unsigned) seg >> 16;
-#pragma unroll
-				for(int i = 0; i < SPL; i++) if(x0 + i >= lo && x0 + i < hi) s[i] = (q & 1) ? lb : la;
-			}
-		}
-		else if(nbits > 0)
-		{
-			__syncthreads();
-			for(int j = t; j < W; j += nth) acc[j] = 0;
-			__syncthreads();
-
-			/* set bits are dealt round-robin to the workgroup's waves: a symbol is a run of a few
-			 * dozen samples, one wave's worth */
-			const int nwaves = nth >> 6, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-			int turn = 0;
-			for(int w = 0; w * 32 < nbits && w < 12; w++)
-			{
-				unsigned word = __builtin_amdgcn_readfirstlane(op[4 + w]);
-				if(nbits - w * 32 < 32) word &= (1u << (nbits - w * 32)) - 1;
-				while(word)
-				{
-					const int b = sym_base + w * 32 + __builtin_ctz(word);
-					word &= word - 1;
-					if(turn++ % nwaves != wave) continue;
-					const int off = vbi_sym[b * 3 + 0], len = vbi_sym[b * 3 + 1];
-					const int16_t *v = vbi_val + vbi_sym[b * 3 + 2];
-					for(int j = lane; j < len; j += 64)
-					{
-						if(off + j >= 0 && off + j < W) atomicAdd(&acc[off + j], (int) v[j]);
-					}
-				}
-			}
-			__syncthreads();
-
-			if(x0 < W)
-			{
-#pragma unroll
-				for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
-			}
-		}
-	}
+	int s[SPL], cq[SPL];
+	raster_compute<NT, SECAM, SV, EXTRAS, WC>(k, P, L, ctaps, notch, (int) blockIdx.y, (int) blockIdx.x, t, nth, lds, c, s, cq);
 
 	if(ABLATE(128) && s[0] != 12345) return;   /* profiling: no store */
 	if(x0 + SPL <= W)
@@ -728,15 +148,6 @@ void hvk_k_raster(const hvk_kconst_t k,
 }
 
 /* ------------------------------------------------------------------ */
-
-__device__ __forceinline__ int pk_add16(int a, int b)
-{
-	return(__builtin_bit_cast(int, (ushort2v) (__builtin_bit_cast(ushort2v, a) + __builtin_bit_cast(ushort2v, b))));
-}
-__device__ __forceinline__ int pk_mad16(int a, int b, int c)
-{
-	return(__builtin_bit_cast(int, (ushort2v) (__builtin_bit_cast(ushort2v, a) * __builtin_bit_cast(ushort2v, b) + __builtin_bit_cast(ushort2v, c))));
-}
 
 
 template<int NT, int VF, int SV, int EXACT, int MF>
@@ -1425,6 +836,26 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
+extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P)
+{
+	P->chroma = a->chroma;
+	P->vbi_sym = a->vbi_sym;
+	P->vbi_val = a->vbi_val;
+	P->vbi_ops = a->vbi_ops;
+	P->vbi_map = a->vbi_map;
+	P->vits_l = a->vits_l;
+	P->vits_c = a->vits_c;
+	P->desc = a->desc;
+	P->pulses = a->pulses;
+	P->yuv = (const short4v *) a->yuv;
+	P->yuvp = (const hvk_yuvparams_t *) a->yuvparams;
+	P->clut = (const int *) a->clut;
+	P->burst_win = a->burst_win;
+	P->ghost = a->ghost;
+	P->pool = a->pool;
+	P->fdesc = a->fdesc;
+}
+
 template<int NT, int SECAM, int SV, int EXTRAS, int WC, int LV>
 static int _launch_raster3(const hvk_raster_args_t *a, hipStream_t stream)
 {
@@ -1432,10 +863,10 @@ static int _launch_raster3(const hvk_raster_args_t *a, hipStream_t stream)
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
+	hvk_rptrs_t P;
+	hvk_raster_ptrs(a, &P);
 	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC, LV>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->notch, a->chroma, a->vbi_sym, a->vbi_val, a->vbi_ops, a->vbi_map, a->vits_l, a->vits_c, a->desc, a->pulses, (const short4v *) a->yuv,
-	                   (const hvk_yuvparams_t *) a->yuvparams, (const int *) a->clut,
-	                   a->burst_win, a->ghost, a->pool, a->fdesc, a->S, a->C, a->first_frame, a->frame_stride);
+	                   a->k, a->ctaps, a->notch, P, a->S, a->C, a->first_frame, a->frame_stride);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

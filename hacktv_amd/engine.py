@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
-    "hvk_timing_enable", "hvk_timing_read", "hvk_table", "hvk_fetch_raster", "hvk_version",
+    "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def lib():
         L.hvk_output_device_ptr.restype = vp
         L.hvk_timing_enable.argtypes = [vp, i32]
         L.hvk_timing_read.argtypes = [vp, i32, vp, vp]
+        L.hvk_kernel_names.argtypes = [vp, C.c_char_p, i32]
         L.hvk_table.argtypes = [vp, C.c_char_p, vp, C.c_long]
         L.hvk_table.restype = C.c_long
         L.hvk_fetch_raster.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -264,6 +265,12 @@ class Engine:
     def set_levels(self, mode):
         """0 auto, 1 table look-up, 2 computed per pixel (hvk_set_levels)."""
         return self._chk("hvk_set_levels", lib().hvk_set_levels(self.h, mode))
+
+    def kernel_names(self):
+        """The kernels a launch enqueues for this configuration (one when the path is fused)."""
+        buf = C.create_string_buffer(512)
+        self._chk("hvk_kernel_names", lib().hvk_kernel_names(self.h, buf, 512))
+        return buf.value.decode().split(";")
 
     def timing_read(self, which):
         ms = C.c_double(0)

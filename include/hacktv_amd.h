@@ -307,6 +307,11 @@ void *hvk_output_device_ptr(hvk_engine_t *e);
 int hvk_set_levels(hvk_engine_t *e, int mode);
 
 int hvk_timing_enable(hvk_engine_t *e, int on);
+/* The names of the kernels a launch of this configuration enqueues, as a profiler prints them,
+ * separated by ';' -- one name when the whole per-sample path runs as one kernel (the default where
+ * the configuration allows), else raster [; resampler] ; filter. With one kernel
+ * hvk_timing_read() reports its time as kernel 1 and nothing for kernel 0. */
+int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n);
 int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches);
 
 /* ---- host tables (for parity tests): same names as the oracle's ---- */

@@ -1,0 +1,120 @@
+"""Whole bench blocks and BASELINE config 4 as written, on the GPU, against the unmodified reference.
+
+* The metric configuration (`-m i -s 16000000 --filter test`, FM + NICAM on) rendered in blocks of 128
+  frames (what bench.py times) and of 37 (an odd batch), every sample hashed: against the committed
+  digests of the reference CLI (tests/golden/ref_long.json, oracle/make_golden_long.py) and, where the
+  reference binary is present (it travels to the GPU box), against its output produced in the same job.
+* `-m l -s 16000000 --filter --teletext demo.tti` through the drop-in binary (the reference's main(),
+  av_test.c, rf_file.c, teletext.c + the video.h shim + libhvk) with the wall clock pinned for both
+  (oracle/pin_time.c)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import hacktv_amd as H
+import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+LONG = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_long.json")))
+
+
+def _ref_digests(flags, frame_bytes, marks, env=None):
+    """sha256 of the first m frames of the reference CLI's output, for every m in marks (None: no binary)."""
+    exe = os.path.join(REF, "hacktv_ref")
+    if not os.path.exists(exe):
+        return None
+    p = subprocess.Popen([exe] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    h = hashlib.sha256()
+    out, done = {}, 0
+    for m in sorted(marks):
+        want = m * frame_bytes - done
+        while want > 0:
+            chunk = p.stdout.read(min(want, 1 << 22))
+            assert chunk, "reference ended early"
+            h.update(chunk)
+            want -= len(chunk)
+            done += len(chunk)
+        out[m] = h.copy().hexdigest()
+    p.kill()
+    p.wait()
+    return out
+
+
+@pytest.mark.parametrize("batches,nofuse", [((128, 37), False), ((37, 37, 37, 17), False), ((37, 91), True)])
+def test_whole_blocks_equal_the_reference(golden, batches, nofuse, monkeypatch):
+    """Every sample of 128-frame and 37-frame blocks with sound on, one kernel (default) and two."""
+    if nofuse:
+        monkeypatch.setenv("HVK_NO_FUSE", "1")
+    conf, sr = golden.conf("i_full")
+    marks, total = [], 0
+    for b in batches:
+        total += b
+        marks.append(total)
+    want = LONG["i_full"]["sha256_at_frames"]
+    live = _ref_digests(LONG["i_full"]["flags"], LONG["i_full"]["frame_bytes"], marks)
+    h = hashlib.sha256()
+    with H.Engine(conf, sr, device=0, max_frames=max(batches)) as e:
+        e.frame_upload(0, golden.frame("i_full"))
+        fs = e.info["frame_samples"]
+        done = 0
+        for b in batches:
+            while e.audio_needed(b) > 0:
+                e.audio_write(golden.audio)
+            e.render(b)
+            h.update(e.fetch(0, b * fs).tobytes())
+            done += b
+            got = h.copy().hexdigest()
+            if str(done) in want:
+                assert got == want[str(done)], "first %d frames differ from the committed reference digest" % done
+            if live is not None:
+                assert got == live[done], "first %d frames differ from the reference run in this job" % done
+            assert str(done) in want or live is not None
+
+
+def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
+    """BASELINE config 4 as written: the TTI page goes through the reference's own parser and packet
+    scheduler (unchanged, in the drop-in binary), the shim hands the packets to the engine, the device
+    renders them. time() is pinned for both binaries."""
+    hvk = os.path.join(REF, "hacktv_hvk")
+    ref = os.path.join(REF, "hacktv_ref")
+    pin = os.path.join(REF, "pin_time.so")
+    tti = os.path.join(REF, "demo.tti")
+    for f in (hvk, pin, tti):
+        if not os.path.exists(f):
+            pytest.skip("%s not built (needs /root/reference at build time)" % f)
+    env = dict(os.environ, LD_PRELOAD=pin, TZ="UTC", HVK_BATCH="2")
+    env.pop("HVK_PIN_TIME", None)
+    flags = [f.replace("@REF@", REF) for f in LONG["l_tti"]["flags"]]
+    fb = LONG["l_tti"]["frame_bytes"]
+    nframes = 5
+
+    def run(binary):
+        p = subprocess.Popen([binary] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        out = bytearray()
+        while len(out) < nframes * fb:
+            chunk = p.stdout.read(nframes * fb - len(out))
+            if not chunk:
+                break
+            out += chunk
+        p.kill()
+        p.wait()
+        return bytes(out)
+
+    got = run(hvk)
+    assert len(got) == nframes * fb
+    for m, d in LONG["l_tti"]["sha256_at_frames"].items():
+        assert util.sha256(got[: int(m) * fb]) == d, "first %s frames differ from the committed digest of the reference" % m
+    if os.path.exists(ref):
+        want = run(ref)
+        if got != want:
+            a = np.frombuffer(got, np.int16).reshape(-1, 2)
+            b = np.frombuffer(want, np.int16).reshape(-1, 2)
+            bad = np.nonzero((a != b).any(axis=1))[0]
+            raise AssertionError("%d samples differ, first at %d (line %d)" % (bad.size, bad[0], bad[0] // 1024))
