@@ -155,6 +155,7 @@ typedef struct {
 	const int16_t *vits_c;        /*       [n][width] chroma amplitude */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
+	const int16_t *linebase;      /* [rows][k.base_stride]: blanking + sync pulses of every kind of line */
 	const short4v *yuv;
 	const hvk_yuvparams_t *yuvp;  /* LV: what the table is made from */
 	const int *clut;
@@ -164,72 +165,112 @@ typedef struct {
 	const hvk_framedesc_t *fdesc; /* [frames][1 + fields]: the frame before, then the fields */
 } hvk_rptrs_t;
 
+/* What a lane fetches for a line besides pixels and sub-carrier phasors: issued with them, used in raster_compute() */
+typedef struct {
+	int ghost_u, ghost_v;   /* the samples the reference reads past its chroma buffer (lanes < H) */
+	int4v base;             /* the lane's 8 samples of the line's base line (blanking + sync pulses) */
+	int4v bwin;             /* ... of the burst window, zero outside it */
+} hvk_side_t;
+
 /* One line's state: all of it the same for every lane (SGPRs) */
 typedef struct {
 	int rel;                /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
-	int line0, par;
-	bool own, zero;         /* zero: before the stream -- the filter history is zero, not blanking */
+	bool own, zero;         /* own: a line of this frame, not a halo line; zero: before the stream -- the filter history is zero, not blanking */
 	hvk_linedesc_t d;
-	hvk_framedesc_t f;
+	int64_t row_off;        /* the source row in the pool, less the sample of source pixel 0: pixel of sample x at pool[row_off + x] */
+	unsigned coff;          /* colour table position of the line's first sample */
 	int pal, vbi_op, vits_i;
-	int vy, px0, ax0, ax1, ar_eff;
+	int ax0, ax1, ar_eff;   /* samples [ax0, ax1) show a source pixel; luma is assigned up to ar_eff */
 	bool active, has_pix;
 } hvk_line_t;
+
+/* which line of which frame, without dividing the global line number: line of the field table, frame parity,
+ * whether the line belongs to the frame at all (the halo lines do not), whether it lies before the stream */
+__device__ __forceinline__ void raster_line_index(const hvk_kconst_t &k, const int rel, const int64_t frame_index,
+                                                  int &line0, int &par, bool &own, bool &zero)
+{
+	line0 = rel;
+	par = (int) ((frame_index + 1) & 1);
+	own = true;
+	if(rel < 0) { line0 = k.lines - 1; par ^= 1; own = false; }
+	else if(rel >= k.lines) { line0 = rel - k.lines; par ^= 1; own = false; }
+	/* before the stream: the filter history is zero, not blanking
+	 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
+	zero = rel < 0 && frame_index == 0;
+}
+
+/* which of a frame's descriptors a line looks at: one per frame, or per field with --interlace -- the second
+ * field shows its own source frame. The halo line in front is the last line of the frame BEFORE (entry 0): on
+ * 525 lines it shows picture, whose last samples the filter sees from this frame's first outputs. */
+__device__ __forceinline__ int raster_fdesc_of(const hvk_kconst_t &k, const int rel)
+{
+	return(rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1));
+}
+
+template<int SECAM, int EXTRAS>
+__device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_framedesc_t &f, const hvk_linedesc_t &d,
+                                                        const int y, const int rel, const int line0, const bool own, const bool zero);
 
 template<int SECAM, int EXTRAS>
 __device__ __forceinline__ hvk_line_t raster_setup(const hvk_kconst_t &k, const hvk_rptrs_t &P, const int y, const int rel,
                                                    const int64_t first_frame, const int64_t frame_stride)
 {
+	int line0, par;
+	bool own, zero;
+	/* frame number and parity by arithmetic: the line descriptor's fetch does not wait for the frame descriptor's */
+	raster_line_index(k, rel, first_frame + (int64_t) y * frame_stride, line0, par, own, zero);
+	const hvk_framedesc_t f = P.fdesc[__builtin_amdgcn_readfirstlane(y * (k.fields + 1) + raster_fdesc_of(k, rel))];   /* one scalar load of the whole descriptor */
+	const hvk_linedesc_t d = P.desc[__builtin_amdgcn_readfirstlane(par * k.lines + line0)];
+	return(raster_setup_core<SECAM, EXTRAS>(k, P, f, d, y, rel, line0, own, zero));
+}
+
+template<int SECAM, int EXTRAS>
+__device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_framedesc_t &f, const hvk_linedesc_t &d,
+                                                        const int y, const int rel, const int line0, const bool own, const bool zero)
+{
 	hvk_line_t L;
 
 	L.rel = rel;
-	/* one descriptor per frame, or per field with --interlace: the second field shows its own source
-	 * frame. The halo line in front is the last line of the frame BEFORE: on 525 lines it shows picture,
-	 * whose last samples the filter sees from this frame's first outputs. */
-	L.f = P.fdesc[__builtin_amdgcn_readfirstlane(y * (k.fields + 1) + (rel < 0 ? 0 : ((k.fields == 2 && rel >= k.hline - 1 && rel < k.lines) ? 2 : 1)))];   /* one scalar load of the whole descriptor */
-
-	/* which line of which frame, without dividing the global line number */
-	/* frame number and parity by arithmetic: the descriptor fetch below does not wait for fdesc */
-	const int64_t frame_index = first_frame + (int64_t) y * frame_stride;
-	L.line0 = rel;
-	L.par = (int) ((frame_index + 1) & 1);
-	L.own = true;
-	if(rel < 0) { L.line0 = k.lines - 1; L.par ^= 1; L.own = false; }
-	else if(rel >= k.lines) { L.line0 = rel - k.lines; L.par ^= 1; L.own = false; }
-
-	/* before the stream: the filter history is zero, not blanking
-	 * (src/video.c:4665-4667 with src/fir.c:289, :579) */
-	L.zero = rel < 0 && frame_index == 0;
-
-	L.d = P.desc[__builtin_amdgcn_readfirstlane(L.par * k.lines + L.line0)];
+	L.own = own;
+	L.zero = zero;
+	L.d = d;
 	L.pal = k.colour ? L.d.pal : 0;
 
 	/* a VBI data line (teletext packet, WSS, VITC: the host lists them per frame), an insertion test signal */
 	L.vbi_op = -1;
 	L.vits_i = -1;
-	if(EXTRAS && k.vbi && L.own) L.vbi_op = __builtin_amdgcn_readfirstlane((int) P.vbi_map[(size_t) y * k.lines + L.line0]);
+	if(EXTRAS && k.vbi && L.own) L.vbi_op = __builtin_amdgcn_readfirstlane((int) P.vbi_map[(size_t) y * k.lines + line0]);
 	if(EXTRAS && k.vits && L.own)
 	{
-		for(int i = 0; i < 4; i++) if(i < k.vits && L.line0 == k.vits_line[i]) L.vits_i = i;
+		for(int i = 0; i < 4; i++) if(i < k.vits && line0 == k.vits_line[i]) L.vits_i = i;
 	}
 
 	/* ---- picture geometry ---- */
 	int vy = L.d.src_row;
-	if(vy >= 0 && k.interlaced != 0 && L.f.fb_interlaced != k.interlaced) vy += 1;
-	vy -= L.f.vframe_y;
-	if(vy < 0 || vy >= L.f.fb_height || !(L.own || rel < 0) || !L.f.fb_valid) vy = -1;
-	L.vy = vy;
+	if(vy >= 0 && k.interlaced != 0 && f.fb_interlaced != k.interlaced) vy += 1;
+	vy -= f.vframe_y;
+	if(vy < 0 || vy >= f.fb_height || !(L.own || rel < 0) || !f.fb_valid) vy = -1;
 
-	L.px0 = k.active_left + L.f.vframe_x;                       /* sample of source pixel 0 */
+	const int px0 = k.active_left + f.vframe_x;                 /* sample of source pixel 0 */
 	L.active = !(EXTRAS && k.rawbb) && L.d.ar > L.d.al;         /* raw baseband input: no picture is drawn */
 	L.has_pix = L.active && vy >= 0;
-	L.ax0 = L.d.al > L.px0 ? L.d.al : L.px0;                    /* samples that show a source pixel */
-	L.ax1 = L.d.ar < L.px0 + L.f.fb_width ? L.d.ar : L.px0 + L.f.fb_width;
+	L.ax0 = L.d.al > px0 ? L.d.al : px0;                        /* samples that show a source pixel */
+	L.ax1 = L.d.ar < px0 + f.fb_width ? L.d.ar : px0 + f.fb_width;
 	if(!L.has_pix) L.ax1 = L.ax0 = 0;
 	/* the reference fills the border left of the picture without looking at the
 	 * right end of the active part (src/video.c:2972-2975): on a left-half line a
 	 * picture narrow enough to start beyond mid-line pushes the black fill past it */
-	L.ar_eff = (L.px0 > L.d.al && L.px0 > L.d.ar) ? L.px0 : L.d.ar;
+	L.ar_eff = (px0 > L.d.al && px0 > L.d.ar) ? px0 : L.d.ar;
+	/* the pool holds dense pictures (hvk_frame_upload gathers strided and flipped sources): pixel stride 1 */
+	L.row_off = f.fb_offset + (int64_t) vy * f.line_stride - px0;
+
+	/* The sub-carrier table position advances by one line per line, colour or not: position relative
+	 * to the frame's (fprev[] carries THIS frame's position). */
+	{
+		const int W = k.width;
+		unsigned coff = (f.clut_off0 + (unsigned) (rel + 1) * (unsigned) W) % k.clw;
+		L.coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
+	}
 	return(L);
 }
 
@@ -238,44 +279,68 @@ __device__ __forceinline__ hvk_line_t raster_setup(const hvk_kconst_t &k, const 
  * reads past its chroma buffer, then the sub-carrier phasors. All unconditional, at clamped
  * positions (ax1 > ax0 when there is a picture): a load under a lane test gets a wait of its own
  * from the compiler, and eight round trips in a row. */
-template<int NT, int WC>
-__device__ __forceinline__ void raster_loads(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
-                                             uint32_t (&rgb)[HVK_PIX_PASSES], int &ghost_u, int &ghost_v, int (&c)[SPL])
+template<int PASSES = HVK_PIX_PASSES>
+__device__ __forceinline__ void raster_load_rgb(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
+                                                uint32_t (&rgb)[HVK_PIX_PASSES])
+{
+	/* without a picture: the pool's first pixel, eight times (never used) -- no branch, no merge */
+	const bool pix = L.has_pix && !ABLATE(8);
+	const uint32_t *row = pix ? P.pool + L.row_off : P.pool;
+#pragma unroll
+	for(int i = 0; i < PASSES; i++)
+	{
+		const int x = L.ax0 + t + i * nth;
+		rgb[i] = row[pix ? (x < L.ax1 ? x : L.ax1 - 1) : 0];
+	}
+}
+
+/* ALWAYS: every load goes out whatever the line is (at a clamped position where it has no use): no branch
+ * for the compiler to put a wait behind */
+template<int NT, int WC, int ALWAYS = 0>
+__device__ __forceinline__ void raster_load_side(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t,
+                                                 hvk_side_t &sd, int (&c)[SPL])
 {
 	constexpr int H = NT / 2;
 	const int W = WC ? WC : k.width;
 	const int x0 = t * SPL;
 
-	{
-		/* without a picture: the pool's first pixel, eight times (never used) -- no branch, no merge */
-		const bool pix = L.has_pix && !ABLATE(8);
-		/* the pool holds dense pictures (hvk_frame_upload gathers strided and flipped sources): pixel stride 1 */
-		const uint32_t *row = pix ? P.pool + L.f.fb_offset + (int64_t) L.vy * L.f.line_stride : P.pool;
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			const int x = L.ax0 + t + i * nth;
-			rgb[i] = row[pix ? (x < L.ax1 ? x : L.ax1 - 1) - L.px0 : 0];
-		}
-	}
-	ghost_u = ghost_v = 0;
+	sd.ghost_u = sd.ghost_v = 0;
 	if(NT > 1)
 	{
 		const int gt = t < H ? t : H - 1;
-		ghost_u = P.ghost[2 * gt + 0];
-		ghost_v = P.ghost[2 * gt + 1];
+		sd.ghost_u = P.ghost[2 * gt + 0];
+		sd.ghost_v = P.ghost[2 * gt + 1];
+	}
+
+	/* the line's base: one aligned 16-byte load wherever the lane stands (rows are padded) */
+	{
+		const int xb = x0 < k.base_stride - SPL ? x0 : k.base_stride - SPL;
+		sd.base = *(const int4v *) (P.linebase + (size_t) (L.d.secam_fid >> 8) * k.base_stride + xb);
+	}
+	/* the lane's 8 burst window values in one 16-byte load from the zero-padded table (2-byte aligned:
+	 * global memory takes that); lanes away from the burst read zeros */
+	sd.bwin = (int4v) { 0, 0, 0, 0 };
+	if(NT > 1)
+	{
+		const int b0 = x0 - k.burst_left;
+		const int4a2 w = *(const int4a2 *) (P.burst_win + (b0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (b0 < k.burst_width ? b0 : k.burst_width)));
+		sd.bwin = (int4v) { w.x, w.y, w.z, w.w };
 	}
 
 	/* sub-carrier phasors of this lane's samples, fetched now so that the read is
-	 * in flight during the picture and filter phases. The table position advances
-	 * by one line per line, colour or not: position relative to the frame's. */
+	 * in flight during the picture and filter phases */
+	if(ALWAYS && NT > 1)
+	{
+		/* (a lane that straddles the line's end reads on into the table: it is 8 entries longer than it needs to be) */
+		const int4u a = ((const int4u *) (P.clut + L.coff + (x0 < W ? x0 : 0)))[0], b = ((const int4u *) (P.clut + L.coff + (x0 < W ? x0 : 0)))[1];
+		c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+		return;
+	}
 #pragma unroll
 	for(int i = 0; i < SPL; i++) c[i] = 0;
 	if((L.pal || (L.vits_i >= 0 && k.colour)) && x0 < W && !ABLATE(4))
 	{
-		unsigned coff = (L.f.clut_off0 + (unsigned) (L.rel + 1) * (unsigned) W) % k.clw;   /* (fprev[] carries THIS frame's position) */
-		coff = (coff + k.clw - ((unsigned) W % k.clw)) % k.clw;
-		const int *cl = P.clut + coff + x0;
+		const int *cl = P.clut + L.coff + x0;
 		if(x0 + SPL <= W)
 		{
 			const int4u a = ((const int4u *) cl)[0], b = ((const int4u *) cl)[1];
@@ -287,6 +352,14 @@ __device__ __forceinline__ void raster_loads(const hvk_kconst_t &k, const hvk_rp
 			for(int i = 0; i < SPL; i++) c[i] = (x0 + i < W) ? cl[i] : 0;
 		}
 	}
+}
+
+template<int NT, int WC, int PASSES = HVK_PIX_PASSES>
+__device__ __forceinline__ void raster_loads(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
+                                             uint32_t (&rgb)[HVK_PIX_PASSES], hvk_side_t &sd, int (&c)[SPL])
+{
+	raster_load_rgb<PASSES>(k, P, L, t, nth, rgb);
+	raster_load_side<NT, WC>(k, P, L, t, sd, c);
 }
 
 /* LDS layout of the raster (int16 elements):
@@ -306,16 +379,54 @@ __device__ __forceinline__ void raster_clear(const hvk_line_t &L, const int t, c
 	}
 }
 
-template<int NT, int WC, int LV>
-__device__ __forceinline__ void raster_pixels(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
-                                              uint32_t (&rgb)[HVK_PIX_PASSES], const int ghost_u, const int ghost_v,
-                                              int16_t *Yb, int16_t *U, int16_t *V)
+/* RGB -> levels of the pixels loaded by raster_load_rgb(): all look-ups are issued together -- the two
+ * dependent global loads per pixel are paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width).
+ * PASSES: how many passes of nth pixels cover the line's pixels (ax1 - ax0 <= PASSES * nth). */
+template<int LV, int PASSES = HVK_PIX_PASSES, int ALWAYS = 0>
+__device__ __forceinline__ void raster_gather(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L,
+                                              uint32_t (&rgb)[HVK_PIX_PASSES], short4v (&c)[HVK_PIX_PASSES])
+{
+	if(ALWAYS || (L.has_pix && !ABLATE(8)))
+	{
+		/* the pixels are first needed HERE: keeps the compiler from preparing the table addresses
+		 * (and waiting for the loads) right where they were issued */
+#pragma unroll
+		for(int i = 0; i < PASSES; i++) asm volatile("" : "+v"(rgb[i]));
+#pragma unroll
+		for(int i = 0; i < PASSES; i++)
+		{
+			/* LV: the levels computed from the colour instead of looked up -- the same arithmetic that
+			 * fills the table. A table entry is 8 bytes somewhere in 128 MiB; pictures with many colours
+			 * (moving video) pay an HBM round trip and a 64-byte sector for most pixels. */
+			if(LV) c[i] = level_of(rgb[i] & 0xFFFFFFu, *P.yuvp);
+			else c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : P.yuv[rgb[i] & 0xFFFFFFu];
+		}
+	}
+}
+
+/* ... and into the staging area: Y where there is a pixel, U / V likewise. NOCLEAR = 0: the chroma
+ * channels have been cleared (raster_clear() and a barrier); NOCLEAR = 1: the zeros around the
+ * pixels are written here, to addresses no pixel goes to, from `zero_from` on (what is in front of
+ * that is not read: a line of which only the tail is wanted). */
+template<int NT, int WC, int PASSES = HVK_PIX_PASSES, int NOCLEAR = 0>
+__device__ __forceinline__ void raster_stage(const hvk_kconst_t &k, const hvk_line_t &L, const int t, const int nth,
+                                             const short4v (&c)[HVK_PIX_PASSES], const int ghost_u, const int ghost_v,
+                                             int16_t *Yb, int16_t *U, int16_t *V, const int zero_from = 0)
 {
 	constexpr int H = NT / 2;
 	const int W = WC ? WC : k.width;
 
 	if(L.pal)
 	{
+		if(NOCLEAR)
+		{
+			const int CL = raster_CL(W);
+			/* left of the pixels; right of them (without a picture only the ghost samples' surroundings are read) */
+			const int lo_end = L.has_pix ? H + L.ax0 : 0;
+			const int hi_beg = L.has_pix ? H + L.ax1 : (W > 2 * HVK_CHROMA_LEAD ? W - 2 * HVK_CHROMA_LEAD : 0);
+			for(int j = zero_from + t; j < lo_end; j += nth) U[j] = V[j] = 0;
+			for(int j = hi_beg + t; j < CL; j += nth) if(j < H + W || j >= H + W + H) U[j] = V[j] = 0;
+		}
 		/* the samples the reference reads past the end of its buffer */
 		if(t < H)
 		{
@@ -326,24 +437,8 @@ __device__ __forceinline__ void raster_pixels(const hvk_kconst_t &k, const hvk_r
 
 	if(L.has_pix && !ABLATE(8))
 	{
-		/* all look-ups are issued before the first LDS write: the two dependent global loads
-		 * per pixel are paid once per line, not once per pass (nth * HVK_PIX_PASSES >= width) */
-		short4v c[HVK_PIX_PASSES];
-		/* the pixels are first needed HERE: keeps the compiler from preparing the table addresses
-		 * (and waiting for the loads) right where they were issued */
 #pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++) asm volatile("" : "+v"(rgb[i]));
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
-		{
-			/* LV: the levels computed from the colour instead of looked up -- the same arithmetic that
-			 * fills the table. A table entry is 8 bytes somewhere in 128 MiB; pictures with many colours
-			 * (moving video) pay an HBM round trip and a 64-byte sector for most pixels. */
-			if(LV) c[i] = level_of(rgb[i] & 0xFFFFFFu, *P.yuvp);
-			else c[i] = ABLATE(1) ? (short4v) { (short) rgb[i], (short) (rgb[i] >> 8), (short) (rgb[i] >> 12), 0 } : P.yuv[rgb[i] & 0xFFFFFFu];
-		}
-#pragma unroll
-		for(int i = 0; i < HVK_PIX_PASSES; i++)
+		for(int i = 0; i < PASSES; i++)
 		{
 			const int x = L.ax0 + t + i * nth;
 			if(x < L.ax1)
@@ -359,6 +454,16 @@ __device__ __forceinline__ void raster_pixels(const hvk_kconst_t &k, const hvk_r
 	}
 }
 
+template<int NT, int WC, int LV, int PASSES = HVK_PIX_PASSES>
+__device__ __forceinline__ void raster_pixels(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
+                                              uint32_t (&rgb)[HVK_PIX_PASSES], const int ghost_u, const int ghost_v,
+                                              int16_t *Yb, int16_t *U, int16_t *V)
+{
+	short4v c[HVK_PIX_PASSES];
+	raster_gather<LV, PASSES>(k, P, L, rgb, c);
+	raster_stage<NT, WC, PASSES, 0>(k, L, t, nth, c, ghost_u, ghost_v, Yb, U, V);
+}
+
 /* 8 consecutive samples per lane, from the staged picture: s[] receives the line's samples (only their
  * low 16 bits count), cq[] the Q channel of --s-video. `lds` is the raster's whole LDS area (Y, U, V:
  * the SECAM notch and the VBI data lines re-use it). `slab_line`: the line's index in the raw baseband
@@ -367,7 +472,7 @@ template<int NT, int SECAM, int SV, int EXTRAS, int WC>
 __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L,
                                                const hvk_packed_taps_t &ctaps, const hvk_packed_taps_t &notch,
                                                const int y, const int slab_line, const int t, const int nth,
-                                               int16_t *lds, int (&c)[SPL], int (&s)[SPL], int (&cq)[SPL])
+                                               int16_t *lds, const hvk_side_t &sd, int (&c)[SPL], int (&s)[SPL], int (&cq)[SPL])
 {
 	constexpr int H = NT / 2;
 	const int W = WC ? WC : k.width;
@@ -382,19 +487,21 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 	(void) rel; (void) own; (void) V;
 
 	/* SECAM: picture lines and field identification lines carry the sub-carrier and get the luma notch */
-	const bool sc_line = SECAM && (active || (EXTRAS && d.secam_fid));
+	const bool sc_line = SECAM && (active || (EXTRAS && (d.secam_fid & 1)));
 
 	/* the samples this WAVE covers, for wave-uniform (scalar) range tests */
 	const int wx0 = __builtin_amdgcn_readfirstlane(x0);
 	const int wx1 = wx0 + 64 * SPL;
 #pragma unroll
-	for(int i = 0; i < SPL; i++) { s[i] = k.blanking; cq[i] = 0; }
+	for(int i = 0; i < SPL; i++) cq[i] = 0;
 
 	if(EXTRAS && k.rawbb)
 	{
 		/* raw baseband input (src/video.c:2431-2436): the line is taken from the external stream
 		 * (`chroma` holds it, slab layout) and mapped from its levels onto the mode's; C integer
 		 * arithmetic, division truncating */
+#pragma unroll
+		for(int i = 0; i < SPL; i++) s[i] = k.blanking;
 		if(x0 < W)
 		{
 			const int16_t *in = P.chroma + ((size_t) y * k.slab_lines + slab_line) * W + x0;
@@ -406,42 +513,13 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		}
 	}
 	else
-	/* sync pulses: this line's own, and the part of the next line's left
-	 * pulse that starts before its sample 0 (src/vbidata.c:211-216) */
 	{
-		const int ids[3] = { d.pulse_left, d.pulse_mid, d.pulse_next };
-		/* where the three pulses are, read together (one wait) rather than one field at a time between branches */
-		int poff[3], plen[3], pst[3];
-#pragma unroll
-		for(int p = 0; p < 3; p++)
-		{
-			const int idc = ids[p] < 0 ? 0 : ids[p];
-			poff[p] = k.pulse_offset[idc];
-			plen[p] = k.pulse_length[idc];
-			pst[p] = k.pulse_start[idc];
-		}
-#pragma unroll
-		for(int p = 0; p < 3; p++)
-		{
-			const int id = ids[p];
-			if(id < 0) continue;
-			const int off = poff[p] + (p == 2 ? W : 0);
-			const int len = plen[p];
-			const int16_t *v = P.pulses + pst[p];
-			if(wx1 <= off || wx0 >= off + len) continue;       /* scalar: most waves see no pulse */
-			/* the lane's 8 values in one 16-byte load (2-byte aligned: global memory takes that): the table
-			 * has HVK_PULSE_PAD zeros either side of every pulse, so a lane before or behind the pulse
-			 * reads zeros and no sample needs a range test. A pulse never crosses into the following
-			 * line; the part of the own left pulse before sample 0 belongs to the previous line. */
-			const int idx0 = x0 - off;
-			const int ic = idx0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (idx0 < len ? idx0 : len);
-			const int4a2 pw = *(const int4a2 *) (v + ic);
-			const int pv[SPL] = { (int) (short) (pw.x & 0xFFFF), pw.x >> 16, (int) (short) (pw.y & 0xFFFF), pw.y >> 16,
-			                      (int) (short) (pw.z & 0xFFFF), pw.z >> 16, (int) (short) (pw.w & 0xFFFF), pw.w >> 16 };
-			/* sums are taken modulo 2^16; only SECAM's notch looks at the value in between, the store keeps 16 bits */
-#pragma unroll
-			for(int i = 0; i < SPL; i++) if(WC || x0 + i < W) s[i] = SECAM ? wrap16(s[i] + pv[i]) : s[i] + pv[i];
-		}
+		/* blanking level and sync pulses -- this line's own, and the part of the next line's left pulse
+		 * that starts before its sample 0 (src/vbidata.c:211-216) -- summed modulo 2^16 once per kind of
+		 * line by the host (hvk_tables.c:_build_linebase) */
+		const int4v bv = sd.base;
+		s[0] = (int) (short) (bv.x & 0xFFFF); s[1] = bv.x >> 16; s[2] = (int) (short) (bv.y & 0xFFFF); s[3] = bv.y >> 16;
+		s[4] = (int) (short) (bv.z & 0xFFFF); s[5] = bv.z >> 16; s[6] = (int) (short) (bv.w & 0xFFFF); s[7] = bv.w >> 16;
 	}
 
 	/* luma is assigned over whatever is there (src/video.c:2961-3009):
@@ -507,9 +585,7 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		if(wx1 > k.burst_left && wx0 < k.burst_left + k.burst_width)
 		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
 		{
-			/* the lane's 8 window values in one 16-byte load from the zero-padded table (see the sync pulses) */
-			const int b0 = x0 - k.burst_left;
-			const int4a2 bwv = *(const int4a2 *) (P.burst_win + (b0 < -HVK_PULSE_PAD ? -HVK_PULSE_PAD : (b0 < k.burst_width ? b0 : k.burst_width)));
+			const int4v bwv = sd.bwin;
 			const int bw[SPL] = { (int) (short) (bwv.x & 0xFFFF), bwv.x >> 16, (int) (short) (bwv.y & 0xFFFF), bwv.y >> 16,
 			                      (int) (short) (bwv.z & 0xFFFF), bwv.z >> 16, (int) (short) (bwv.w & 0xFFFF), bwv.w >> 16 };
 #pragma unroll

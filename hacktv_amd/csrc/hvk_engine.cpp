@@ -82,7 +82,7 @@ struct hvk_engine {
 	hipStream_t own_stream;
 
 	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca;
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_zeros;
 	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
 	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
@@ -112,7 +112,7 @@ struct hvk_engine {
 	int tiles;                  /* NICAM symbol rows per frame: one per filter tile, or one per line for the fused kernel */
 	int tile_len;               /* samples a row covers: HVK_TILE, or the line width */
 	int fused;                  /* this configuration renders in one kernel (hvk_fused.hip) */
-	int run_lines;              /* ... whose workgroups walk this many lines each */
+	int run_lines;              /* < 0: runs per frame as given (HVK_RUNS); 0: the launcher chooses */
 	int last_fused;             /* the last launch did: the raster slab in HBM was not written */
 	uint32_t *h_frame;
 
@@ -332,16 +332,23 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
 
 	/* One kernel for the whole per-sample path where the configuration allows (hvk_fused.hip); HVK_NO_FUSE=1
-	 * keeps the raster and the filter kernel apart (tests run both), HVK_RUN_LINES sets the lines a
-	 * workgroup walks. */
+	 * keeps the raster and the filter kernel apart (tests run both), HVK_RUNS sets the runs a frame's
+	 * lines are dealt to (one workgroup each). */
 	e->fused = hvk_fused_supported(&e->t.k, e->d_mfma_a) && !getenv("HVK_NO_FUSE");
-	e->run_lines = getenv("HVK_RUN_LINES") ? atoi(getenv("HVK_RUN_LINES")) : 25;
-	if(e->run_lines < 1) e->run_lines = 1;
+	e->run_lines = getenv("HVK_RUNS") ? -atoi(getenv("HVK_RUNS")) : 0;      /* < 0: that many runs per frame; 0: the launcher decides */
 	e->tile_len = e->fused ? k.width : HVK_TILE;
 
 	OPENCHK(_upload(&e->d_desc, e->t.desc, sizeof(hvk_linedesc_t) * 2 * k.lines));
 	OPENCHK(_upload(&e->d_pulses, e->t.pulse_values, sizeof(int16_t) * (e->t.pulse_total + 8)));
-	OPENCHK(_upload(&e->d_clut, e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len));
+	OPENCHK(_upload(&e->d_linebase, e->t.linebase, sizeof(int16_t) * (size_t) e->t.nbase * k.base_stride));
+	if(e->t.colour_lookup_len > 0)
+	{
+		/* 8 entries of slack behind the table: a lane that straddles the end of a line loads 8 entries all the same */
+		std::vector<hvk_c16_t> cl((size_t) e->t.colour_lookup_len + 8);
+		memcpy(cl.data(), e->t.colour_lookup, sizeof(hvk_c16_t) * e->t.colour_lookup_len);
+		memset(cl.data() + e->t.colour_lookup_len, 0, sizeof(hvk_c16_t) * 8);
+		OPENCHK(_upload(&e->d_clut, cl.data(), sizeof(hvk_c16_t) * cl.size()));
+	}
 	{
 		/* HVK_PULSE_PAD zeros either side: a lane reads its 8 window values in one load wherever it stands */
 		std::vector<int16_t> bw((size_t) k.burst_width + 2 * HVK_PULSE_PAD, 0);
@@ -349,6 +356,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_burst, bw.data(), bw.size() * sizeof(int16_t)));
 	}
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
+	OPENHIP(hipMalloc(&e->d_zeros, HVK_ZERO_BYTES));
+	OPENHIP(hipMemset(e->d_zeros, 0, HVK_ZERO_BYTES));
 	if(k.has_nicam)
 	{
 		/* device forms of the NICAM tables: the pulse as int16 behind HVK_NICAM_LEAD
@@ -403,8 +412,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	if(e->t.k.has_carriers)
 	{
-		OPENHIP(hipMalloc((void **) &e->d_car, (size_t) max_frames * FS * 4));
-		OPENHIP(hipMemset(e->d_car, 0, (size_t) max_frames * FS * 4));
+		OPENHIP(hipMalloc((void **) &e->d_car, (size_t) max_frames * FS * 4 + 64));    /* (a lane that straddles the end of the last line loads 8 values all the same) */
+		OPENHIP(hipMemset(e->d_car, 0, (size_t) max_frames * FS * 4 + 64));
 		OPENHIP(hipHostMalloc((void **) &e->h_car, (size_t) max_frames * FS * 4, hipHostMallocDefault));
 	}
 	if(e->t.k.has_nicam)
@@ -492,7 +501,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_clut, e->d_burst, e->d_ghost,
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_zeros,
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
@@ -1202,6 +1211,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	ra.vits_c = (const int16_t *) e->d_vits_c;
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
+	ra.linebase = (const int16_t *) e->d_linebase;
 	ra.yuv = e->d_yuv;
 	ra.yuvparams = e->d_yuvparams;
 	ra.levels_computed = e->levels_computed;
@@ -1232,6 +1242,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	fa.mfma_a = e->d_mfma_a;
 	fa.mfma_ci = e->mfma_ci;
 	fa.mfma_cq = e->mfma_cq;
+	fa.zeros = e->d_zeros;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;
@@ -1405,7 +1416,8 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	{
 		const int extras = (k.vbi || k.vits) ? 1 : 0;
 		const int wc = (!extras && nt == 13 && k.width == 1024) ? 1024 : 0;
-		snprintf(buf, n, "hvk_k_fused<%d, %d, %d, %d, %d>", nt, k.vf_type, extras, wc, lv);
+		if(k.vf_type != 0 && !extras && !getenv("HVK_NO_WAVE_ROLES")) snprintf(buf, n, "hvk_k_fusedw<%d, %d, %d, %d>", nt, k.vf_type, wc, lv);
+		else snprintf(buf, n, "hvk_k_fused<%d, %d, %d, %d, %d>", nt, k.vf_type, extras, wc, lv);
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;

@@ -36,7 +36,8 @@ typedef struct {
 	int16_t al, ar;         /* luma is assigned on [al, ar); al == ar: none */
 	int16_t src_row;        /* source row before centring / field shift, -1: none */
 	int16_t pal;            /* 0 no chroma, +1, -1 (PAL V switch) */
-	int16_t secam_fid;      /* SECAM field identification line: sub-carrier (and luma notch) without a picture */
+	int16_t secam_fid;      /* bit 0: SECAM field identification line -- sub-carrier (and luma notch) without a picture;
+	                         * bits 8..: the line's row of the base-line table (blanking + sync pulses) */
 } __attribute__((aligned(16))) hvk_linedesc_t;      /* 16 bytes, aligned: one scalar load on the device */
 
 /* RGB -> (Y,U,V) level conversion, evaluated in double on the device with
@@ -74,6 +75,7 @@ typedef struct {
 	int32_t pulse_length[HVK_MAX_PULSES];
 	int32_t pulse_start[HVK_MAX_PULSES];   /* index into the flat value array */
 	int32_t black_y;        /* luma of RGB 000000 */
+	int32_t base_stride;    /* int16 entries per row of the base-line table */
 	/* filter / audio stage */
 	int32_t vf_type;        /* 0 none, 1 real, 3 real -> complex */
 	int32_t vf_ntaps;
@@ -126,6 +128,7 @@ typedef struct {
 	hvk_kconst_t k;
 	hvk_yuvparams_t yuv;
 	hvk_linedesc_t *desc;   /* [2][lines] */
+	int16_t *linebase; int32_t nbase;   /* [nbase][k.base_stride]: blanking + sync pulses of every kind of line */
 	int16_t *pulse_values; int32_t pulse_total;
 	int16_t *sync_packed; int32_t sync_packed_len;  /* reference layout, for tests */
 	hvk_c16_t *colour_lookup; int64_t colour_lookup_len;

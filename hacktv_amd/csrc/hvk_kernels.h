@@ -10,6 +10,7 @@
 #define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_MFMA_A_BYTES (2 * 64 * 16)
+#define HVK_ZERO_BYTES  (64 * 1024)
 #define HVK_NICAM_TAPD  384  /* entries of one copy of the zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
@@ -30,6 +31,7 @@ typedef struct {
 	const int16_t *vits_l, *vits_c;
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
+	const int16_t *linebase;    /* [nbase][k.base_stride] */
 	const void *yuv;            /* 2^24 x int16x4 */
 	const void *yuvparams;      /* hvk_yuvparams_t on the device */
 	int levels_computed;        /* this block's pictures have many colours: compute the levels, do not look them up */
@@ -57,6 +59,7 @@ typedef struct {
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
+	const void *zeros;          /* HVK_ZERO_BYTES of zeros: what hvk_k_fusedw reads where a configuration has no carriers / no NICAM */
 	int16_t *iq;
 	int nframes;
 	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */

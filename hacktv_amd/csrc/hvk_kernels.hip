@@ -111,19 +111,20 @@ void hvk_k_raster(const hvk_kconst_t k,
 	int16_t *Yb = lds, *U = lds + YL, *V = lds + YL + CL;
 
 	uint32_t rgb[HVK_PIX_PASSES];
-	int ghost_u, ghost_v, c[SPL];
-	raster_loads<NT, WC>(k, P, L, t, nth, rgb, ghost_u, ghost_v, c);
+	hvk_side_t sd;
+	int c[SPL];
+	raster_loads<NT, WC>(k, P, L, t, nth, rgb, sd, c);
 
 	if(L.pal)
 	{
 		raster_clear(L, t, nth, U, CL);
 		__syncthreads();
 	}
-	raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, ghost_u, ghost_v, Yb, U, V);
+	raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, sd.ghost_u, sd.ghost_v, Yb, U, V);
 	if(L.pal || L.has_pix) __syncthreads();
 
 	int s[SPL], cq[SPL];
-	raster_compute<NT, SECAM, SV, EXTRAS, WC>(k, P, L, ctaps, notch, (int) blockIdx.y, (int) blockIdx.x, t, nth, lds, c, s, cq);
+	raster_compute<NT, SECAM, SV, EXTRAS, WC>(k, P, L, ctaps, notch, (int) blockIdx.y, (int) blockIdx.x, t, nth, lds, sd, c, s, cq);
 
 	if(ABLATE(128) && s[0] != 12345) return;   /* profiling: no store */
 	if(x0 + SPL <= W)
@@ -847,6 +848,7 @@ extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P)
 	P->vits_c = a->vits_c;
 	P->desc = a->desc;
 	P->pulses = a->pulses;
+	P->linebase = a->linebase;
 	P->yuv = (const short4v *) a->yuv;
 	P->yuvp = (const hvk_yuvparams_t *) a->yuvparams;
 	P->clut = (const int *) a->clut;

@@ -285,7 +285,7 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 		if(fb && vy >= 0 && vy < fb_height) row = fb + (size_t) vy * fb_width;
 
 		/* an empty frame (0 x 0, what a source past its end hands out) shows no pixels at all */
-		_line(s, frame, line, picture, right_half, d->secam_fid, row, fb_width, vframe_x, out + (size_t) (line - 1) * k->width);
+		_line(s, frame, line, picture, right_half, d->secam_fid & 1, row, fb_width, vframe_x, out + (size_t) (line - 1) * k->width);
 	}
 
 	s->next_frame++;

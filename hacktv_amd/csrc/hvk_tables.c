@@ -106,6 +106,56 @@ static int _row_of_line(int type, int line)
 	return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
 }
 
+/* The part of a line that only depends on which sync pulses it carries: blanking level plus its own
+ * left and mid pulse plus the part of the NEXT line's left pulse that starts before that line's
+ * sample 0 (src/video.c:2944-2958 with src/vbidata.c:186-239, :211-216), modulo 2^16. A frame has a
+ * handful of such combinations; the kernels start a line from the row of its combination -- one
+ * aligned 16-byte load per lane -- instead of adding up to three pulses under range tests. The
+ * row's index goes into the high byte of the descriptor's secam_fid. */
+static int _build_linebase(hvk_tables_t *t)
+{
+	const int W = t->k.width, n = 2 * t->conf.lines;
+	const int stride = ((W + 7) & ~7) + 8;
+	int key[64][3], nbase = 0, i, b, p, j;
+
+	for(i = 0; i < n; i++)
+	{
+		hvk_linedesc_t *d = &t->desc[i];
+		for(b = 0; b < nbase; b++) if(key[b][0] == d->pulse_left && key[b][1] == d->pulse_mid && key[b][2] == d->pulse_next) break;
+		if(b == nbase)
+		{
+			if(nbase == 64) return(HVK_UNSUPPORTED);
+			key[b][0] = d->pulse_left; key[b][1] = d->pulse_mid; key[b][2] = d->pulse_next;
+			nbase++;
+		}
+		d->secam_fid = (int16_t) ((d->secam_fid & 1) | (b << 8));
+	}
+
+	free(t->linebase);
+	t->linebase = calloc((size_t) nbase * stride, sizeof(int16_t));
+	if(!t->linebase) return(HVK_OUT_OF_MEMORY);
+	t->nbase = nbase;
+	t->k.base_stride = stride;
+
+	for(b = 0; b < nbase; b++)
+	{
+		int16_t *row = t->linebase + (size_t) b * stride;
+		for(j = 0; j < stride; j++) row[j] = (int16_t) t->k.blanking;
+		for(p = 0; p < 3; p++)
+		{
+			const int id = key[b][p];
+			if(id < 0) continue;
+			const int off = t->k.pulse_offset[id] + (p == 2 ? W : 0);
+			const int16_t *v = t->pulse_values + t->k.pulse_start[id];
+			for(j = 0; j < t->k.pulse_length[id]; j++)
+			{
+				if(off + j >= 0 && off + j < W) row[off + j] = (int16_t) (row[off + j] + v[j]);
+			}
+		}
+	}
+	return(HVK_OK);
+}
+
 static int _build_linedesc(hvk_tables_t *t)
 {
 	const hvk_config_t *c = &t->conf;
@@ -150,7 +200,7 @@ static int _build_linedesc(hvk_tables_t *t)
 		}
 	}
 
-	return(HVK_OK);
+	return(_build_linebase(t));
 }
 
 static hvk_c32_t _unit_phasor(double radians);
@@ -1466,6 +1516,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 void hvk_tables_free(hvk_tables_t *t)
 {
 	free(t->desc);
+	free(t->linebase);
 	free(t->pulse_values);
 	free(t->sync_packed);
 	free(t->colour_lookup);

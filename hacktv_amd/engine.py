@@ -11,7 +11,8 @@ import numpy as np
 
 from .ctypes_defs import HvkConfig, HvkInfo
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
+# HVK_LIB: another build of the library (tools/ablate.py uses one with the profiling switches compiled in)
+LIB_PATH = os.environ.get("HVK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
 
 SYMBOLS = [
     "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
