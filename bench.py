@@ -6,8 +6,9 @@ Workload (BASELINE.json configs[1], the one the metric is quoted on):
   16 MHz sample rate, built-in test card, FM mono + NICAM-728 sound on.
 
 A "step" is one pass of the hot path over one block of F whole frames per GPU
-(one fused kernel -- raster, video filter, sound carriers, NICAM -- through the
-C ABI of libhvk; HVK_NO_FUSE=1 runs the raster and the filter kernel apart). The
+(raster kernel + filter/sound kernel through the C ABI of libhvk; HVK_FUSE=1 runs
+the one-kernel form of the same path, hvk_fused.hip, which is not the faster one
+yet). The
 side inputs of the block (source frame, serial-carrier stream, NICAM symbols)
 are staged into HBM before the clock starts; every step re-renders the staged
 block in full (nothing is cached between steps). Before any number is taken

@@ -82,7 +82,7 @@ struct hvk_engine {
 	hipStream_t own_stream;
 
 	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_zeros;
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_zeros, *d_lstate;
 	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
 	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
@@ -331,10 +331,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
 
-	/* One kernel for the whole per-sample path where the configuration allows (hvk_fused.hip); HVK_NO_FUSE=1
-	 * keeps the raster and the filter kernel apart (tests run both), HVK_RUNS sets the runs a frame's
-	 * lines are dealt to (one workgroup each). */
-	e->fused = hvk_fused_supported(&e->t.k, e->d_mfma_a) && !getenv("HVK_NO_FUSE");
+	/* One kernel for the whole per-sample path (hvk_fused.hip) where the configuration allows and the caller asks
+	 * for it -- HVK_FUSE=1 or hvk_set_fused(): measured on MI355X it does not beat the raster + filter kernel pair
+	 * yet (0.40 against 0.37 ms per 82 M samples; DESIGN.md section 4 has the counters), so the pair is the default.
+	 * HVK_RUNS sets the runs a frame's lines are dealt to (one workgroup each). */
+	e->fused = hvk_fused_supported(&e->t.k, e->d_mfma_a) && getenv("HVK_FUSE") != NULL && atoi(getenv("HVK_FUSE")) != 0;
 	e->run_lines = getenv("HVK_RUNS") ? -atoi(getenv("HVK_RUNS")) : 0;      /* < 0: that many runs per frame; 0: the launcher decides */
 	e->tile_len = e->fused ? k.width : HVK_TILE;
 
@@ -356,6 +357,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_burst, bw.data(), bw.size() * sizeof(int16_t)));
 	}
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
+	OPENHIP(hipMalloc(&e->d_lstate, (size_t) max_frames * (k.lines + 2) * 32));
 	OPENHIP(hipMalloc(&e->d_zeros, HVK_ZERO_BYTES));
 	OPENHIP(hipMemset(e->d_zeros, 0, HVK_ZERO_BYTES));
 	if(k.has_nicam)
@@ -501,7 +503,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_zeros,
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_zeros, e->d_lstate,
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
@@ -1243,6 +1245,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	fa.mfma_ci = e->mfma_ci;
 	fa.mfma_cq = e->mfma_cq;
 	fa.zeros = e->d_zeros;
+	fa.lstate = e->d_lstate;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;

@@ -8,17 +8,16 @@
  *
  * hvk_k_fusedw, the kernel of the plain configurations (the benchmark's among them), divides the work
  * between the WAVES of the workgroup -- half of them "sample" waves, half "io" waves, about the same
- * number of vector instructions each, two barriers per line:
+ * number of vector instructions each, ONE barrier per line (the hand-over areas exist twice):
  *
  *        sample waves                                        io waves
- *        line r - 2 through the 51-tap filter on the         line r's pixel levels (looked up during the
- *        matrix unit: planes -> output exchange              last phase) -> Y / U / V staging in LDS;
- *                                                            NICAM symbol table of line r - 2
  *   ------------------------------------ barrier ------------------------------------
- *        8 samples per lane of line r: base line, luma,      look-ups of line r + 1, source row of r + 2
- *        chroma low pass, burst, QAM -> planes; the next     and the carriers / symbols of line r - 1 go
- *        line's base line / burst / phasor loads go out      out; carriers + NICAM onto the filtered
- *                                                            samples of line r - 2, 32-byte stores
+ *        line r - 2 through the 51-tap filter on the         line r + 1's pixel levels (looked up during the
+ *        matrix unit: planes -> output exchange;             last round) -> Y / U / V staging in LDS; look-ups
+ *        8 samples per lane of line r: base line, luma,      of line r + 2 and source row of line r + 3 go out;
+ *        chroma low pass, burst, QAM -> planes; the next     carriers + NICAM onto the filtered samples of line
+ *        line's base line / burst / phasor loads go out      r - 3, 32-byte stores; symbols, mixer row and
+ *                                                            carriers of line r - 2 go out
  *   ------------------------------------ barrier ------------------------------------
  *
  * A wave is in-order: in one wave the raster's and the filter's dependent loads and LDS round trips
@@ -32,7 +31,8 @@
  * barriers inside the raster (VBI data lines, insertion test signals) and those without a video
  * filter, where a lane's raster samples are its outputs and there are no planes.
  *
- * Three plane buffers rotate. Buffer b holds, for its line, the last 32 samples of the line before,
+ * Three plane buffers rotate (four in hvk_k_fusedw, whose waves write a line's planes while others still read
+ * the line two back). Buffer b holds, for its line, the last 32 samples of the line before,
  * the line, and the first 32 samples of the line after (the filter reaches 25 either way): a lane
  * that holds edge samples writes them into the neighbour's buffer as well. The first line of a run
  * needs the tail of the line before the run and the last one the head of the line after it: of those
@@ -64,35 +64,64 @@ typedef struct {
 	 * name a block of zeros and these strides are 0, so that every such load reads its first bytes */
 	int car_frame, car_line;  /* carrier samples per frame, per line (0: none) */
 	int sym_frame, sym_line;  /* symbol row ints per frame, per line (0: none) */
+	const void *lstate;       /* hvk_k_fusedw: the lines' states, [frames][lines + 2] records of 32 bytes (hvk_k_linestate writes them) */
 } hvk_fptrs_t;
 
 /* entries of one copy of the NICAM pulse table in LDS: the lead, the pulse, and a zero tail a lane's 8 samples wide */
 __host__ __device__ __forceinline__ int fused_tapd_len(int nicam_ntaps) { return((HVK_NICAM_LEAD + nicam_ntaps + SPL + 7) & ~7); }
 
-/* the workgroup's LDS */
+/* the workgroup's LDS. hvk_k_fusedw (ws) has its hand-over areas twice -- staging, output exchange, symbol
+ * table: one side fills one while the other side reads the other -- and four plane buffers instead of three */
 typedef struct {
 	int16_t *rlds;            /* raster staging: Y, U, V */
-	unsigned char *planes;    /* [3][hi, lo][PB] */
+	int rstride;              /* int16 from one staging area to the other */
+	unsigned char *planes;    /* [3 or 4][hi, lo][PB] */
 	int PB;
-	int *outl;                /* the filter's outputs on their way to the lane that owns them */
+	int *outl;                /* the filter's outputs on their way to the lane that owns them; ostride ints to the other one */
+	int ostride;
 	int *sym_st;              /* NICAM symbols of the line: start relative to its first sample */
 	int4v *sym_ent;           /*   { LEAD - start, copy offset, sign pair I, sign pair Q } */
+	int sstride;              /* bytes from one symbol table (sym_st + sym_ent) to the other */
 	int16_t *tapd;            /* four copies of the pulse, copy s one entry further left */
 	int TL;                   /* entries of one copy */
 } fused_lds_t;
 
-__device__ __forceinline__ fused_lds_t fused_lds(unsigned char *raw, const int W, const int nth, const int vf, const int nicam_ntaps)
+#define FUSED_SYM_BYTES (HVK_NICAM_SYMS * 4 + HVK_NICAM_SYMS * 16)
+
+__host__ __device__ __forceinline__ size_t fused_lds_layout(const int W, const int nth, const int vf, const int nicam_ntaps, const int ws,
+                                                            int *o_planes, int *o_outl, int *o_sym, int *o_tapd, int *o_PB, int *o_rs)
+{
+	const int YL = (W + 8 + 7) & ~7, CL = (W + 2 * HVK_CHROMA_LEAD + 7) & ~7;
+	const int PB = (nth * SPL + 80 + 15) & ~15;
+	const int rbytes = ((YL + 2 * CL) * 2 + 15) & ~15;
+	size_t n = (size_t) rbytes * (ws ? 2 : 1);
+	*o_rs = rbytes / 2;
+	*o_planes = (int) n;
+	if(vf) n += (size_t) (ws ? 8 : 6) * PB;
+	*o_outl = (int) n;
+	if(vf) n += (size_t) nth * SPL * 4 * (ws ? 2 : 1);
+	*o_sym = (int) n;
+	n += (size_t) FUSED_SYM_BYTES * (ws ? 2 : 1);
+	*o_tapd = (int) n;
+	n += (size_t) 4 * ((HVK_NICAM_LEAD + nicam_ntaps + SPL + 7) & ~7) * 2;
+	*o_PB = PB;
+	return(n);
+}
+
+__device__ __forceinline__ fused_lds_t fused_lds(unsigned char *raw, const int W, const int nth, const int vf, const int nicam_ntaps, const int ws = 0)
 {
 	fused_lds_t l;
-	const int YL = raster_YL(W), CL = raster_CL(W);
-	l.PB = (nth * SPL + 80 + 15) & ~15;
+	int op, oo, os, ot;
+	fused_lds_layout(W, nth, vf, nicam_ntaps, ws, &op, &oo, &os, &ot, &l.PB, &l.rstride);
 	l.TL = fused_tapd_len(nicam_ntaps);
 	l.rlds = (int16_t *) raw;
-	l.planes = raw + (((YL + 2 * CL) * 2 + 15) & ~15);
-	l.outl = (int *) (l.planes + (vf ? 6 * l.PB : 0));
-	l.sym_st = l.outl + (vf ? nth * SPL : 0);
+	l.planes = raw + op;
+	l.outl = (int *) (raw + oo);
+	l.ostride = nth * SPL;
+	l.sym_st = (int *) (raw + os);
 	l.sym_ent = (int4v *) (l.sym_st + HVK_NICAM_SYMS);
-	l.tapd = (int16_t *) (l.sym_ent + HVK_NICAM_SYMS);
+	l.sstride = FUSED_SYM_BYTES;
+	l.tapd = (int16_t *) (raw + ot);
 	return(l);
 }
 
@@ -130,7 +159,8 @@ __device__ __forceinline__ void plane_put_some(unsigned char *p, const int j, co
  * into the line's buffer `rs` and, for edge samples, into the neighbours'. part: 1 / 2 only the tail /
  * head is wanted. */
 template<int WC>
-__device__ __forceinline__ void fused_put_planes(const fused_lds_t &l, const int (&s)[SPL], const int x0, const int W, const int rs, const int part)
+__device__ __forceinline__ void fused_put_planes(const fused_lds_t &l, const int (&s)[SPL], const int x0, const int W, const int rs, const int part,
+                                                 const int nbuf = 3)
 {
 	const unsigned d0 = (s[0] & 0xFFFF) | ((unsigned) s[1] << 16), d1 = (s[2] & 0xFFFF) | ((unsigned) s[3] << 16);
 	const unsigned d2 = (s[4] & 0xFFFF) | ((unsigned) s[5] << 16), d3 = (s[6] & 0xFFFF) | ((unsigned) s[7] << 16);
@@ -141,9 +171,9 @@ __device__ __forceinline__ void fused_put_planes(const fused_lds_t &l, const int
 	pl.y = (int) (__builtin_amdgcn_perm(d3, d2, 0x06040200u) ^ 0x80808080u);
 
 	const int PB = l.PB;
-	unsigned char *bh = l.planes + rs * 2 * PB;               /* line r's buffer */
-	unsigned char *nh = l.planes + ((rs + 1) % 3) * 2 * PB;   /* line r + 1's: wants this line's tail */
-	unsigned char *vh = l.planes + ((rs + 2) % 3) * 2 * PB;   /* line r - 1's: wants this line's head */
+	unsigned char *bh = l.planes + rs * 2 * PB;                                     /* line r's buffer */
+	unsigned char *nh = l.planes + (rs + 1 == nbuf ? 0 : rs + 1) * 2 * PB;          /* line r + 1's: wants this line's tail */
+	unsigned char *vh = l.planes + (rs == 0 ? nbuf - 1 : rs - 1) * 2 * PB;          /* line r - 1's: wants this line's head */
 	if(part) { }                    /* a halo line: only its edge is read */
 	else if(WC || x0 + SPL <= W)
 	{
@@ -192,8 +222,10 @@ __device__ __forceinline__ void fused_put_planes(const fused_lds_t &l, const int
  * outputs, 16 per v_mfma_i32_16x16x64_i8; lane (g, c) hands over window positions 16 g .. 16 g + 15 of
  * segment c and gets back outputs 2 g, 2 g + 1 of it, I and Q. t: lane within the filter's lanes. */
 template<int VF>
-__device__ __forceinline__ void fused_filter(const fused_lds_t &l, const hvk_fptrs_t &Q, const int4v a_hh, const int4v a_hl, const int t, const int buf)
+__device__ __forceinline__ void fused_filter(const fused_lds_t &l, const hvk_fptrs_t &Q, const int4v a_hh, const int4v a_hl, const int t, const int buf,
+                                             int *outl = NULL)
 {
+	if(outl == NULL) outl = l.outl;
 	const unsigned char *xh = l.planes + buf * 2 * l.PB, *xl = xh + l.PB;
 	const int lane = t & 63, g = lane >> 4, cc = lane & 15;
 #pragma unroll
@@ -223,14 +255,17 @@ __device__ __forceinline__ void fused_filter(const fused_lds_t &l, const hvk_fpt
 			pk.x = sat_pack16(yv[0] >> 15, 0);
 			pk.y = sat_pack16(yv[2] >> 15, 0);
 		}
-		*(int2v *) (l.outl + seg * 8 + 2 * g) = pk;
+		*(int2v *) (outl + seg * 8 + 2 * g) = pk;
 	}
 }
 
 /* The symbols whose pulses can touch the line, oldest first: start (relative to the line's first
  * sample) and sign pair, from the row the host tabulated (src/nicam728.c:398-407). Lanes < HVK_NICAM_SYMS. */
-__device__ __forceinline__ void fused_symtab(const fused_lds_t &l, const int t, const int symv, const int n0, const int W)
+__device__ __forceinline__ void fused_symtab(const fused_lds_t &l0_, const int t, const int symv, const int n0, const int W, const int which = 0)
 {
+	fused_lds_t l = l0_;
+	l.sym_st = (int *) ((unsigned char *) l0_.sym_st + which * l0_.sstride);
+	l.sym_ent = (int4v *) ((unsigned char *) l0_.sym_ent + which * l0_.sstride);
 	if(t < HVK_NICAM_SYMS)
 	{
 		const int v = symv;
@@ -263,10 +298,13 @@ __device__ __forceinline__ int fused_mix_pos(const hvk_kconst_t &k, const int cc
  * the symbols in flight summed per channel with int16 wrap-around, mixed, added (src/nicam728.c:350-365,
  * :386-396). x0: the lane's first sample of the line; dst: where it goes. */
 template<int WC>
-__device__ __forceinline__ void fused_finish(const hvk_kconst_t &k, const fused_lds_t &l, int (&o)[SPL], const int x0, const int W,
+__device__ __forceinline__ void fused_finish(const hvk_kconst_t &k, const fused_lds_t &l_, int (&o)[SPL], const int x0, const int W,
                                              const bool whole, const int4u car0, const int4u car1, const int *car_tail,
-                                             const int4u mix_a0, const int4u mix_a1, int *dst, const bool emit = true)
+                                             const int4u mix_a0, const int4u mix_a1, int *dst, const bool emit = true, const int which = 0)
 {
+	fused_lds_t l = l_;
+	l.sym_st = (int *) ((unsigned char *) l_.sym_st + which * l_.sstride);
+	l.sym_ent = (int4v *) ((unsigned char *) l_.sym_ent + which * l_.sstride);
 	if(k.has_carriers)
 	{
 		if(whole || car_tail == NULL)       /* (NULL: the 8 values were loaded from the lane's position whatever it is) */
@@ -411,86 +449,104 @@ __device__ __forceinline__ fused_prep_t fused_prep(const hvk_kconst_t &k, const 
 	return(q);
 }
 
-/* The descriptors a run's lines need, held in the lanes of two registers instead of fetched line by line (a
- * scalar load per line is a round trip to L2 the source row's loads then wait for): lane j of `dd` has the
- * descriptor of line l0 - 1 + j (a run has 61 lines at most), lane i of `fv` dword i of the frame's descriptors (the frame before,
- * the field(s)). v_readlane picks out what a line wants. */
+/* A line's state as hvk_k_linestate tabulates it before the main kernel runs: what raster_setup() derives from
+ * the line's and the frame's descriptors, 32 bytes per line of the slab (line -1 first). The main kernel's
+ * waves keep the records of their run's lines in the lanes of two registers (lane j: line l0 - 1 + j; a run
+ * has 61 lines at most) and pick a line's out with v_readlane: no descriptor fetch, and next to no scalar
+ * arithmetic, per line. */
 typedef struct {
-	int4v dd;
-	int fv;
-} fused_desc_t;
+	int4v a;        /* row_off (lo, hi), coff, ax0 | ax1 << 16 */
+	int4v b;        /* al | ar << 16, ar_eff | base row << 16, flags, - */
+} fused_rec_t;
 
-#define FDW (sizeof(hvk_framedesc_t) / 4)       /* dwords of a frame descriptor */
+#define FREC_PAL_POS 1
+#define FREC_PAL_NEG 2
+#define FREC_ACTIVE  4
+#define FREC_HAS_PIX 8
+#define FREC_OWN     16
+#define FREC_ZERO    32
 
-__device__ __forceinline__ fused_desc_t fused_desc_load(const hvk_kconst_t &k, const hvk_rptrs_t &P, const int y, const int l0, const int l1,
-                                                        const int64_t frame_index, const int lane)
+__global__ __launch_bounds__(64)
+void hvk_k_linestate(const hvk_kconst_t k, const hvk_rptrs_t P, fused_rec_t *__restrict__ out, const int64_t first_frame, const int64_t frame_stride)
 {
-	fused_desc_t D;
-	{
-		int rel = l0 - 1 + lane;
-		if(rel > l1) rel = l1;
-		int line0, par;
-		bool own, zero;
-		raster_line_index(k, rel, frame_index, line0, par, own, zero);
-		D.dd = *(const int4v *) &P.desc[par * k.lines + line0];
-	}
-	const int nf = (int) FDW * (k.fields + 1);
-	D.fv = ((const int *) (P.fdesc + (size_t) y * (k.fields + 1)))[lane < nf ? lane : nf - 1];
-	return(D);
+	const int y = blockIdx.y;
+	const int i = blockIdx.x * 64 + threadIdx.x;        /* slab line: line i - 1 of the frame */
+	if(i >= k.lines + 2) return;
+	const int rel = i - 1;
+	int line0, par;
+	bool own, zero;
+	raster_line_index(k, rel, first_frame + (int64_t) y * frame_stride, line0, par, own, zero);
+	const hvk_framedesc_t f = P.fdesc[y * (k.fields + 1) + raster_fdesc_of(k, rel)];
+	const hvk_linedesc_t d = P.desc[par * k.lines + line0];
+	const hvk_line_t L = raster_setup_core<0, 0>(k, P, f, d, y, rel, line0, own, zero);
+	fused_rec_t r;
+	r.a.x = (int) (uint32_t) (uint64_t) L.row_off;
+	r.a.y = (int) (uint32_t) ((uint64_t) L.row_off >> 32);
+	r.a.z = (int) L.coff;
+	r.a.w = (L.ax0 & 0xFFFF) | (L.ax1 << 16);
+	r.b.x = ((int) d.al & 0xFFFF) | ((int) d.ar << 16);
+	r.b.y = (L.ar_eff & 0xFFFF) | ((d.secam_fid >> 8) << 16);
+	r.b.z = (L.pal > 0 ? FREC_PAL_POS : 0) | (L.pal < 0 ? FREC_PAL_NEG : 0) | (L.active ? FREC_ACTIVE : 0) | (L.has_pix ? FREC_HAS_PIX : 0) |
+	        (L.own ? FREC_OWN : 0) | (L.zero ? FREC_ZERO : 0);
+	r.b.w = 0;
+	out[(size_t) y * (k.lines + 2) + i] = r;
+}
+
+__device__ __forceinline__ fused_rec_t fused_rec_load(const fused_rec_t *lstate, const int lines, const int y, const int l0, const int l1, const int lane)
+{
+	int rel = l0 - 1 + lane;
+	if(rel > l1) rel = l1;
+	const fused_rec_t *p = lstate + (size_t) y * (lines + 2) + rel + 1;
+	fused_rec_t r;
+	r.a = p->a;
+	r.b = p->b;
+	return(r);
 }
 
 template<int NT, int VF, int WC>
-__device__ __forceinline__ fused_prep_t fused_prep_lanes(const hvk_kconst_t &k, const hvk_rptrs_t &P, const fused_desc_t &D, const int y, const int r,
-                                                         const int l0, const int l1, const int64_t frame_index)
+__device__ __forceinline__ fused_prep_t fused_prep_lanes(const hvk_kconst_t &k, const fused_rec_t &D, const int r, const int l0, const int l1)
 {
-	static_assert(sizeof(hvk_linedesc_t) == 16 && sizeof(hvk_framedesc_t) == 56, "descriptor layouts the lane picking relies on");
 	fused_prep_t q;
 	const int W = WC ? WC : k.width;
-	int line0, par;
-	bool own, zero;
-	raster_line_index(k, r, frame_index, line0, par, own, zero);
-
-	/* the line's descriptor out of its lane */
 	const int j = r - (l0 - 1);
-	int4v dv;
-	dv.x = __builtin_amdgcn_readlane(D.dd.x, j); dv.y = __builtin_amdgcn_readlane(D.dd.y, j);
-	dv.z = __builtin_amdgcn_readlane(D.dd.z, j); dv.w = __builtin_amdgcn_readlane(D.dd.w, j);
-	const hvk_linedesc_t d = __builtin_bit_cast(hvk_linedesc_t, dv);
-
-	/* the frame descriptor's members (hvk_internal.h: frame_index, fb_offset, fb_width, fb_height, pixel_stride,
-	 * line_stride, vframe_x, vframe_y, fb_interlaced, fb_valid, clut_off0, parity) */
-	const int b = (int) FDW * raster_fdesc_of(k, r);
-	hvk_framedesc_t f;
-	f.frame_index = 0;
-	f.fb_offset = (int64_t) (((uint64_t) (unsigned) __builtin_amdgcn_readlane(D.fv, b + 3) << 32) | (unsigned) __builtin_amdgcn_readlane(D.fv, b + 2));
-	f.fb_width = __builtin_amdgcn_readlane(D.fv, b + 4);
-	f.fb_height = __builtin_amdgcn_readlane(D.fv, b + 5);
-	f.pixel_stride = 1;
-	f.line_stride = __builtin_amdgcn_readlane(D.fv, b + 7);
-	f.vframe_x = __builtin_amdgcn_readlane(D.fv, b + 8);
-	f.vframe_y = __builtin_amdgcn_readlane(D.fv, b + 9);
-	f.fb_interlaced = __builtin_amdgcn_readlane(D.fv, b + 10);
-	f.fb_valid = __builtin_amdgcn_readlane(D.fv, b + 11);
-	f.clut_off0 = (uint32_t) __builtin_amdgcn_readlane(D.fv, b + 12);
-	f.parity = 0;
+	const int ax = __builtin_amdgcn_readlane(D.a.w, j), aa = __builtin_amdgcn_readlane(D.b.x, j);
+	const int eb = __builtin_amdgcn_readlane(D.b.y, j), fl = __builtin_amdgcn_readlane(D.b.z, j);
+	hvk_line_t &L = q.L;
+	L.rel = r;
+	L.row_off = (int64_t) (((uint64_t) (unsigned) __builtin_amdgcn_readlane(D.a.y, j) << 32) | (unsigned) __builtin_amdgcn_readlane(D.a.x, j));
+	L.coff = (unsigned) __builtin_amdgcn_readlane(D.a.z, j);
+	L.ax0 = ax & 0xFFFF;
+	L.ax1 = (unsigned) ax >> 16;
+	L.ar_eff = eb & 0xFFFF;
+	L.d.pulse_left = L.d.pulse_mid = L.d.pulse_next = -1;
+	L.d.al = (int16_t) (aa & 0xFFFF);
+	L.d.ar = (int16_t) ((unsigned) aa >> 16);
+	L.d.src_row = 0;
+	L.d.pal = 0;
+	L.d.secam_fid = (int16_t) (((unsigned) eb >> 16) << 8);
+	L.pal = (fl & FREC_PAL_POS) ? 1 : ((fl & FREC_PAL_NEG) ? -1 : 0);
+	L.active = (fl & FREC_ACTIVE) != 0;
+	L.has_pix = (fl & FREC_HAS_PIX) != 0;
+	L.own = (fl & FREC_OWN) != 0;
+	L.zero = (fl & FREC_ZERO) != 0;
+	L.vbi_op = L.vits_i = -1;
 
 	q.part = VF ? (r == l0 - 1 ? 1 : (r == l1 ? 2 : 0)) : 0;
-	q.L = raster_setup_core<0, 0>(k, P, f, d, y, r, line0, own, zero);
 	if(q.part == 2)
 	{
-		if((!q.L.active || q.L.d.al >= FEDGE + 16) && (!q.L.pal || k.burst_left >= FEDGE + 16))
+		if((!L.active || L.d.al >= FEDGE + 16) && (!L.pal || k.burst_left >= FEDGE + 16))
 		{
-			q.L.pal = 0;
-			q.L.has_pix = false;
-			q.L.ax0 = q.L.ax1 = 0;
+			L.pal = 0;
+			L.has_pix = false;
+			L.ax0 = L.ax1 = 0;
 		}
 		else q.part = 0;
 	}
-	else if(q.part == 1 && q.L.has_pix)
+	else if(q.part == 1 && L.has_pix)
 	{
 		const int lo = W - FEDGE - NT / 2 - 8;
-		if(q.L.ax0 < lo) q.L.ax0 = lo;
-		if(q.L.ax0 >= q.L.ax1) { q.L.has_pix = false; q.L.ax0 = q.L.ax1 = 0; }
+		if(L.ax0 < lo) L.ax0 = lo;
+		if(L.ax0 >= L.ax1) { L.has_pix = false; L.ax0 = L.ax1 = 0; }
 	}
 	return(q);
 }
@@ -562,11 +618,13 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 	fused_run(k.lines, Q.nruns, l0, l1);
 	if(l1 <= l0) return;
 	const int FS = k.frame_samples;
-	const fused_lds_t l = fused_lds(lds_raw, W, nth, VF, k.has_nicam ? k.nicam_ntaps : 0);
-	const int niter = (l1 - l0) + 3;            /* raster line r = l0 - 1 + it, filtered line fl = r - 2 */
-	const int64_t frame_index = first_frame + (int64_t) y * frame_stride;
-	fused_desc_t D = fused_desc_load(k, P, y, l0, l1, frame_index, t & 63);
-	touch4(D.dd); touch(D.fv);
+	const fused_lds_t l = fused_lds(lds_raw, W, nth, VF, k.has_nicam ? k.nicam_ntaps : 0, 1);
+	/* Round `it`: the sample waves filter line r - 2 and make the samples of line r = l0 - 1 + it; the io
+	 * waves stage line r + 1 and send out line r - 3. One barrier per round: every hand-over area exists
+	 * twice and the plane buffers rotate by four, so what one side writes in a round the other reads in the next. */
+	const int niter = (l1 - l0) + 4;
+	fused_rec_t D = fused_rec_load((const fused_rec_t *) Q.lstate, k.lines, y, l0, l1, t & 63);
+	touch4(D.a); touch4(D.b);
 
 	if(!io)
 	{
@@ -577,7 +635,7 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 		touch4(a_hh); touch4(a_hl);
 
 		/* what line r's samples are made from besides pixels is fetched a line ahead */
-		fused_prep_t q = fused_prep_lanes<NT, VF, WC>(k, P, D, y, l0 - 1, l0, l1, frame_index);
+		fused_prep_t q = fused_prep_lanes<NT, VF, WC>(k, D, l0 - 1, l0, l1);
 		hvk_side_t sd;
 		int c[SPL];
 		raster_load_side<NT, WC, 1>(k, P, q.L, t, sd, c);
@@ -587,15 +645,15 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 		{
 			const int r = l0 - 1 + it;
 			const bool do_r = r <= l1;
-			const int rs = it % 3;                  /* plane buffer of line r; of line r - 2: (rs + 1) % 3 */
-
-			/* ---- line r - 2 through the matrix unit: planes -> output exchange ---- */
-			if(!ABLATE(1024)) fused_filter<VF>(l, Q, a_hh, a_hl, t, (rs + 1) % 3);
+			const int rs = it & 3;                  /* plane buffer of line r; of line r - 2: (rs + 2) & 3 */
 			TS_MARK(0);
 			FUSED_BARRIER();
 			TS_MARK(1);
 
-			/* ---- 8 samples per lane of line r (its pixels' levels are in the staging area by now) -> planes ---- */
+			/* ---- line r - 2 through the matrix unit: planes -> output exchange ---- */
+			if(!ABLATE(1024)) fused_filter<VF>(l, Q, a_hh, a_hl, t, (rs + 2) & 3, l.outl + (it & 1) * l.ostride);
+
+			/* ---- 8 samples per lane of line r (its pixels' levels were staged during the last round) -> planes ---- */
 			touch4(sd.base); touch4(sd.bwin);
 #pragma unroll
 			for(int i = 0; i < SPL; i++) touch(c[i]);
@@ -612,30 +670,27 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 #pragma unroll
 					for(int i = 0; i < SPL; i++) s[i] = c[i];
 				}
-				else raster_compute<NT, 0, 0, 0, WC>(k, P, q.L, ctaps, notch, y, r + 1, t, nth, l.rlds, sd, c, s, cq);
+				else raster_compute<NT, 0, 0, 0, WC>(k, P, q.L, ctaps, notch, y, r + 1, t, nth, l.rlds + (it & 1) * l.rstride, sd, c, s, cq);
 				if(q.L.zero)
 				{
 #pragma unroll
 					for(int i = 0; i < SPL; i++) s[i] = 0;
 				}
-				if(do_r && !ABLATE(65536)) fused_put_planes<WC>(l, s, x0, W, rs, part);
+				if(do_r && !ABLATE(65536)) fused_put_planes<WC>(l, s, x0, W, rs, part, 4);
 			}
 
 			/* ---- the next line's base line, burst window, sub-carrier phasors go out ---- */
-			q = fused_prep_lanes<NT, VF, WC>(k, P, D, y, min(r + 1, l1), l0, l1, frame_index);
+			q = fused_prep_lanes<NT, VF, WC>(k, D, min(r + 1, l1), l0, l1);
 			raster_load_side<NT, WC, 1>(k, P, q.L, t, sd, c);
 			TS_MARK(2);
-			FUSED_BARRIER();
-			TS_MARK(3);
 		}
 		TS_DUMP(0);
 	}
 	else
 	{
-		/* ================= io waves: pixels in (line r), sound and samples out (line r - 2) ================= */
+		/* ================= io waves: pixels in (line r + 1), sound and samples out (line r - 3) ================= */
 		constexpr int H = NT / 2;
 		const int YL = raster_YL(W), CL = raster_CL(W);
-		int16_t *const Yb = l.rlds, *const U = l.rlds + YL, *const V = l.rlds + YL + CL;
 		if(k.has_nicam) fused_stage_tapd(l, Q.nicam_tapd, t, nth);
 		const bool whole = WC || x0 + SPL <= W;
 		const int ccl = k.has_nicam ? k.nicam_cc_len : 0x40000000;     /* (no NICAM: the mixer position stays where the zeros are) */
@@ -649,22 +704,34 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 			ghost_v = P.ghost[2 * gt + 1];
 		}
 
-		/* two lines ahead: the source row of line r + 2 is on its way while the levels of line r + 1 are
-		 * looked up and line r is staged */
+		/* Two lines ahead: the source row of line r + 3 is on its way while the levels of line r + 2 are looked up
+		 * and line r + 1 is staged. Before the first round: line l0 - 1 into the first staging area. */
 		uint32_t rgb[HVK_PIX_PASSES];
 		short4v px[HVK_PIX_PASSES];
-		fused_prep_t q0 = fused_prep_lanes<NT, VF, WC>(k, P, D, y, l0 - 1, l0, l1, frame_index);
-		fused_prep_t q1 = fused_prep_lanes<NT, VF, WC>(k, P, D, y, l0, l0, l1, frame_index);
+		fused_prep_t q0 = fused_prep_lanes<NT, VF, WC>(k, D, l0 - 1, l0, l1);
+		fused_prep_t q1 = fused_prep_lanes<NT, VF, WC>(k, D, l0, l0, l1);
+		fused_prep_t q2 = fused_prep_lanes<NT, VF, WC>(k, D, min(l0 + 1, l1), l0, l1);
 		raster_load_rgb<HVK_PIX_PASSES>(k, P, q0.L, t, nth, rgb);
 		raster_gather<LV, HVK_PIX_PASSES, 1>(k, P, q0.L, rgb, px);
 		raster_load_rgb<HVK_PIX_PASSES>(k, P, q1.L, t, nth, rgb);
+		touch(ghost_u); touch(ghost_v);
+		if(!q0.L.zero && !ABLATE(4096))
+		{
+			const int zf = q0.part == 1 ? max(0, W - FEDGE - 2 * HVK_CHROMA_LEAD) : 0;
+			raster_stage<NT, WC, HVK_PIX_PASSES, 1>(k, q0.L, t, nth, px, ghost_u, ghost_v, l.rlds, l.rlds + YL, l.rlds + YL + CL, zf);
+		}
+		raster_gather<LV, HVK_PIX_PASSES, 1>(k, P, q1.L, rgb, px);
+		raster_load_rgb<HVK_PIX_PASSES>(k, P, q2.L, t, nth, rgb);
+		q0 = q1;            /* q0: the line staged next (r + 1), q1: the line looked up next (r + 2) */
+		q1 = q2;
 
-		/* one line ahead: symbol row, carrier samples, mixer row */
+		/* one line ahead: symbol row, carrier samples, mixer row; the first line's symbol table */
 		const int *const car_base = Q.carriers + (size_t) y * Q.car_frame + xc;
 		const int *const sym_base = Q.tilesyms + (size_t) y * Q.sym_frame + (t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1);
 		int cc_line = 0;
 		if(k.has_nicam) cc_line = __builtin_amdgcn_readfirstlane(Q.tilesyms[(size_t) y * Q.sym_frame + (size_t) l0 * Q.sym_line + HVK_NICAM_SYMS]);
-		int symv = sym_base[(unsigned) (l0 * Q.sym_line)];
+		/* (every round tabulates the symbols of the line that goes out in the NEXT round: the first rounds send nothing out,
+		 * and the round before the first line goes out tabulates it) */
 		int4u mix_a0, mix_a1, car0, car1;
 		{
 			int cp = cc_line + xc;
@@ -674,56 +741,59 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 			car0 = cq[0];
 			car1 = cq[1];
 		}
-		touch(ghost_u); touch(ghost_v);
 
 		TS_DECL;
 		for(int it = 0; it < niter; it++)
 		{
 			const int r = l0 - 1 + it;
-			const int fl = r - 2;
-			const bool do_r = r <= l1;
-			const bool do_f = fl >= l0 && fl < l1;
-			const int n0 = fl * W;                  /* first output sample of line fl, frame local */
+			const int fo = r - 3;                   /* the line that goes out */
+			const bool do_s = r + 1 <= l1;
+			const bool do_f = fo >= l0 && fo < l1;
+			const int n0 = fo * W;                  /* its first output sample, frame local */
+			int16_t *const Yb = l.rlds + ((it + 1) & 1) * l.rstride, *const U = Yb + YL, *const V = U + CL;
 
-			/* ---- line r's pixel levels (looked up during the last phase) into the staging area, with the
-			 * zeros around them; line fl's symbol table ---- */
+			TS_MARK(0);
+			FUSED_BARRIER();
+			TS_MARK(1);
+
+			/* the symbols of the line that goes out next: in at the end of the round, tabulated for the next one */
+			const int fn = min(max(fo + 1, l0), l1 - 1);
+			const int symn = sym_base[(unsigned) (fn * Q.sym_line)];
+
+			/* ---- line r + 1's pixel levels (looked up during the last round) into the staging area the sample waves
+			 * read next round, with the zeros around them ---- */
 #pragma unroll
 			for(int i = 0; i < HVK_PIX_PASSES; i++) touch(px[i]);
-			touch(symv);
-			if(do_r && !q0.L.zero && !ABLATE(4096))
+			if(do_s && !q0.L.zero && !ABLATE(4096))
 			{
 				/* (of the line before the run only the tail is wanted: no zeros in front of what its chroma low pass reaches) */
 				const int zf = q0.part == 1 ? max(0, W - FEDGE - 2 * HVK_CHROMA_LEAD) : 0;
 				raster_stage<NT, WC, HVK_PIX_PASSES, 1>(k, q0.L, t, nth, px, ghost_u, ghost_v, Yb, U, V, zf);
 			}
-			if(k.has_nicam) fused_symtab(l, t, symv, n0, W);
-			TS_MARK(0);
-			FUSED_BARRIER();
-			TS_MARK(1);
 
-			/* ---- look-ups of line r + 1 (its colours came in during the last round), source row of line r + 2,
-			 * symbols / mixer row / carriers of line fl + 1 go out; then sound onto the filtered samples of
-			 * line fl, and out ---- */
+			/* ---- look-ups of line r + 2 (its colours came in during the last round), source row of line r + 3 ---- */
 			touch4(car0); touch4(car1); touch4(mix_a0); touch4(mix_a1);
 #pragma unroll
 			for(int i = 0; i < HVK_PIX_PASSES; i++) touch(rgb[i]);
 			if(!ABLATE(4096)) raster_gather<LV, HVK_PIX_PASSES, 1>(k, P, q1.L, rgb, px);
-			const fused_prep_t q2 = fused_prep_lanes<NT, VF, WC>(k, P, D, y, min(r + 2, l1), l0, l1, frame_index);
+			q2 = fused_prep_lanes<NT, VF, WC>(k, D, min(r + 3, l1), l0, l1);
 			raster_load_rgb<HVK_PIX_PASSES>(k, P, q2.L, t, nth, rgb);
 
+			/* ---- sound onto the filtered samples of line fo (the sample waves left them last round), and out ---- */
 			int o[SPL];                             /* packed (I, Q) int16 */
-			const int4v oa = ((const int4v *) (l.outl + x0))[0], ob = ((const int4v *) (l.outl + x0))[1];
+			const int *ol = l.outl + ((it + 1) & 1) * l.ostride + x0;
+			const int4v oa = ((const int4v *) ol)[0], ob = ((const int4v *) ol)[1];
 			o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
 			o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
 			fused_finish<WC>(k, l, o, x0, W, whole, car0, car1, NULL, mix_a0, mix_a1,
-			                 Q.iq + (size_t) y * Q.out_stride * FS + n0 + x0, do_f);
+			                 Q.iq + (size_t) y * Q.out_stride * FS + n0 + x0, do_f, it & 1);
 
-			/* the next line's symbols, mixer row, carrier samples: they have the coming phase to arrive */
+			/* the next line's symbol table (in the table the next round reads), mixer row, carrier samples: they have a
+			 * round to arrive */
 			{
-				const int fn = min(max(fl + 1, l0), l1 - 1);        /* the next line that goes out */
-				symv = sym_base[(unsigned) (fn * Q.sym_line)];
+				if(k.has_nicam) fused_symtab(l, t, symn, fn * W, W, (it + 1) & 1);
 				/* the mixer position moves on by a line */
-				if(fl + 1 > l0 && fl + 1 < l1)
+				if(fo + 1 > l0 && fo + 1 < l1)
 				{
 					cc_line += W;
 					if(ccl >= W) { if(cc_line >= ccl) cc_line -= ccl; }
@@ -737,8 +807,6 @@ void hvk_k_fusedw(const hvk_kconst_t k,
 				if(!ABLATE(8192)) { car0 = cq[0]; car1 = cq[1]; }
 			}
 			TS_MARK(2);
-			FUSED_BARRIER();
-			TS_MARK(3);
 			q0 = q1;
 			q1 = q2;
 		}
@@ -915,15 +983,11 @@ void hvk_k_fused(const hvk_kconst_t k,
 
 extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P);
 
-extern "C" size_t hvk_fused_lds_bytes(int width, int vf, int nicam_ntaps)
+extern "C" size_t hvk_fused_lds_bytes(int width, int vf, int nicam_ntaps, int ws)
 {
 	const int nth = ((width + SPL - 1) / SPL + 63) / 64 * 64;
-	const int YL = (width + 8 + 7) & ~7, CL = (width + 2 * HVK_CHROMA_LEAD + 7) & ~7;
-	const int PB = (nth * SPL + 80 + 15) & ~15;
-	size_t n = ((size_t) (YL + 2 * CL) * 2 + 15) & ~(size_t) 15;
-	if(vf) n += (size_t) 6 * PB + (size_t) nth * SPL * 4;
-	n += HVK_NICAM_SYMS * 4 + HVK_NICAM_SYMS * 16 + (size_t) 4 * fused_tapd_len(nicam_ntaps) * 2;
-	return(n);
+	int a, b, c, d, e, f;
+	return(fused_lds_layout(width, nth, vf, nicam_ntaps, ws, &a, &b, &c, &d, &e, &f));
 }
 
 template<int NT, int VF, int EXTRAS, int WC, int LV>
@@ -937,7 +1001,7 @@ static int _launch_fused4(const hvk_raster_args_t *ra, const hvk_filter_args_t *
 	const int W = ra->k.width;
 	const int nth = ((W + SPL - 1) / SPL + 63) / 64 * 64;
 	const int threads = ws ? 2 * nth : nth;
-	const size_t lds = hvk_fused_lds_bytes(W, VF, ra->k.has_nicam ? ra->k.nicam_ntaps : 0);
+	const size_t lds = hvk_fused_lds_bytes(W, VF, ra->k.has_nicam ? ra->k.nicam_ntaps : 0, ws);
 	const void *fn = (const void *) hvk_k_fused<NT, VF, EXTRAS, WC, LV>;
 	if constexpr(CAN_WS) { if(ws) fn = (const void *) hvk_k_fusedw<NT, VF, WC, LV>; }
 	if(threads > 512) return(HVK_UNSUPPORTED);
@@ -985,6 +1049,7 @@ static int _launch_fused4(const hvk_raster_args_t *ra, const hvk_filter_args_t *
 	Q.out_stride = fa->out_stride;
 	Q.nruns = runs;
 	Q.car_frame = Q.car_line = Q.sym_frame = Q.sym_line = 0;
+	Q.lstate = NULL;
 	if constexpr(CAN_WS)
 	{
 		if(ws)
@@ -995,6 +1060,10 @@ static int _launch_fused4(const hvk_raster_args_t *ra, const hvk_filter_args_t *
 			else Q.carriers = (const int *) fa->zeros;
 			if(ra->k.has_nicam) { Q.sym_frame = ra->k.lines * HVK_NICAM_ROW; Q.sym_line = HVK_NICAM_ROW; }
 			else { Q.tilesyms = (const int *) fa->zeros; Q.nicam_cca = (const int *) fa->zeros; }
+			if(!fa->lstate) return(HVK_ERROR);
+			Q.lstate = fa->lstate;
+			hipLaunchKernelGGL(hvk_k_linestate, dim3((ra->k.lines + 2 + 63) / 64, ra->nframes), dim3(64), 0, stream,
+			                   ra->k, P, (fused_rec_t *) fa->lstate, ra->first_frame, ra->frame_stride);
 			hipLaunchKernelGGL((hvk_k_fusedw<NT, VF, WC, LV>), dim3(runs, ra->nframes), dim3(threads), lds, stream,
 			                   ra->k, ra->ctaps, P, Q, ra->first_frame, ra->frame_stride);
 			return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);

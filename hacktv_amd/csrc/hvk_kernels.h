@@ -59,6 +59,7 @@ typedef struct {
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
+	void *lstate;               /* hvk_k_fusedw: room for the lines' states, nframes * (lines + 2) * 32 bytes */
 	const void *zeros;          /* HVK_ZERO_BYTES of zeros: what hvk_k_fusedw reads where a configuration has no carriers / no NICAM */
 	int16_t *iq;
 	int nframes;

@@ -47,11 +47,13 @@ def _ref_digests(flags, frame_bytes, marks, env=None):
     return out
 
 
-@pytest.mark.parametrize("batches,nofuse", [((128, 37), False), ((37, 37, 37, 17), False), ((37, 91), True)])
-def test_whole_blocks_equal_the_reference(golden, batches, nofuse, monkeypatch):
-    """Every sample of 128-frame and 37-frame blocks with sound on, one kernel (default) and two."""
-    if nofuse:
-        monkeypatch.setenv("HVK_NO_FUSE", "1")
+@pytest.mark.parametrize("batches,env", [((128, 37), {}), ((37, 37, 37, 17), {}),
+                                         ((128, 37), {"HVK_FUSE": "1"}), ((37, 91), {"HVK_FUSE": "1", "HVK_NO_WAVE_ROLES": "1"})])
+def test_whole_blocks_equal_the_reference(golden, batches, env, monkeypatch):
+    """Every sample of 128-frame and 37-frame blocks with sound on: the raster + filter kernel pair (default)
+    and the one-kernel forms (HVK_FUSE=1: wave roles, or both jobs in every wave)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     conf, sr = golden.conf("i_full")
     marks, total = [], 0
     for b in batches:

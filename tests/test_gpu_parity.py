@@ -100,6 +100,29 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 
+@pytest.mark.parametrize("roles", [True, False])
+@pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
+                                  "pal_bb_filter", "i_20m", "i_tt", "i_offset", "m_offset_pass", "pal_fm", "i_vbi", "i_vbi_tt",
+                                  "m_vbi", "i_acp_cc", "g_a2", "m_a2", "i_wss_auto"])
+def test_one_kernel_forms_equal_reference_digests(golden, case, roles, monkeypatch):
+    """HVK_FUSE=1: raster, video filter and sound in one kernel (hvk_fused.hip) -- with wave roles (hvk_k_fusedw: the
+    plain configurations with a video filter) or with both jobs in every wave (hvk_k_fused: VBI data lines, test
+    signals, no filter; HVK_NO_WAVE_ROLES=1 forces it everywhere). Same digests as the kernel pair."""
+    monkeypatch.setenv("HVK_FUSE", "1")
+    if not roles:
+        monkeypatch.setenv("HVK_NO_WAVE_ROLES", "1")
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    nframes = c["frames"]
+    iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
+                 teletext=(lambda f: golden.teletext_rows(f, golden.teletext_skip(case))) if c.get("teletext") else None,
+                 passthru=util.passthru_signal() if conf.passthru else None, pixel_rate=c.get("pixel_rate", 0))
+    fs = c.get("frame_samples", c["width"] * c["lines"])
+    for n in range(nframes):
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
+
+
 @pytest.mark.parametrize("case", ["i_full", "m_full"])
 def test_raster_stage_equals_oracle(golden, case):
     """The raster kernel's output (before filter and audio) against the oracle's raster."""
