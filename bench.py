@@ -150,57 +150,127 @@ def main():
     stream = torch.cuda.current_stream()
     e.set_stream(ctypes.c_void_p(stream.cuda_stream))
     e.frame_upload(0, g.frame("i_full"))
+    gather = N > 1 and not args.no_gather
+    import hashlib
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
+
+    def ref_sha(first, count):
+        """sha256 of frames [first, first + count) of the unmodified reference CLI's output, run now (None: no binary)."""
+        if not os.path.exists(ref_bin):
+            return None
+        p = subprocess.Popen([ref_bin, "-m", MODE, "-s", str(SAMPLE_RATE), "--filter", "-o", "-", "test"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        skip, left, h = first * FS * 4, count * FS * 4, hashlib.sha256()
+        while skip > 0:
+            skip -= len(p.stdout.read(min(skip, 1 << 22)))
+        while left > 0:
+            chunk = p.stdout.read(min(left, 1 << 22))
+            if not chunk:
+                break
+            h.update(chunk)
+            left -= len(chunk)
+        p.kill()
+        p.wait()
+        return h.hexdigest()
+
+    def feed_audio(upto_frame):
+        while e.audio_needed(upto_frame) > 0:
+            e.audio_write(g.audio)
+
+    # ---- N > 1: the sharded path end to end on short blocks, BEFORE anything is timed: every rank stages, renders and
+    # sends two rounds of 2-frame blocks through the same calls as the timed loop (stage with the predecessor slot,
+    # double-buffered gather), rank 0 hashes the reassembled stream -- block seams and round seams included -- against
+    # the reference CLI's output ----
+    seam_gate = None
+    if N > 1 and not args.noaudio:
+        Fg, rounds = min(2, F), 2
+        bufs = [torch.empty((Fg * FS * 2,), dtype=torch.int16, device=dev) for _ in range(2)]
+        roots = [torch.empty((N, Fg * FS * 2), dtype=torch.int16, device=dev) for _ in range(2)] if rank == 0 else [None, None]
+        host = []
+        works = []
+        for rnd in range(rounds + 1):
+            if rnd < rounds:
+                first = sharding.first_frame_of(rank, N, rnd, Fg)
+                feed_audio(first + Fg)
+                e.stage(first, 1, Fg, prev_slots=[0] * Fg)
+                e.launch(ctypes.c_void_p(bufs[rnd & 1].data_ptr()))
+                torch.cuda.synchronize()
+            if rnd > 0:
+                if dry:
+                    sharding.gather_blocks(bufs[(rnd - 1) & 1], roots[(rnd - 1) & 1], rank, N, via_host=True)
+                else:
+                    sharding.gather_wait(works)
+                if rank == 0:
+                    host.append(roots[(rnd - 1) & 1].cpu().numpy().tobytes())
+            if rnd < rounds and not dry:
+                works = sharding.gather_start(bufs[rnd & 1], roots[rnd & 1], rank, N)
+        if rank == 0:
+            got = hashlib.sha256(b"".join(host)).hexdigest()
+            want = ref_sha(0, rounds * N * Fg)
+            if want is None:
+                k = rounds * N * Fg
+                cum = g.cases["i_full"]["sha256_cumulative"]
+                want = cum[k - 1] if k <= len(cum) else None
+            if want is None:
+                raise SystemExit("seam gate: no reference to compare %d frames with -- refusing to report a number" % (rounds * N * Fg))
+            if got != want:
+                raise SystemExit("seam gate failed: the stream reassembled from %d ranks x %d rounds differs from the reference CLI's output" % (N, rounds))
+            seam_gate = "%d rounds x %d ranks x %d frames reassembled on rank 0: sha256 == reference CLI" % (rounds, N, Fg)
+            log("seam gate ok: " + seam_gate)
+        dist.barrier()
 
     # ---- stage the side inputs of this rank's block (untimed: inputs resident in HBM) ----
     first_frame = sharding.first_frame_of(rank, N, 0, F)   # block-cyclic: block b -> rank b mod N; round 0
+    e.close()
+    e = H.Engine(conf, SAMPLE_RATE, device=local_rank, max_frames=F)     # (a fresh stream position for the audio pre-pass)
+    e.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    e.frame_upload(0, g.frame("i_full"))
     t0 = time.perf_counter()
-    while e.audio_needed(first_frame + F) > 0:
-        e.audio_write(g.audio)
-    e.stage(first_frame, 1, F)
+    feed_audio(first_frame + F)
+    e.stage(first_frame, 1, F, prev_slots=[0] * F)
     e.sync()
     t_stage = time.perf_counter() - t0
     log("rank 0 staged %d frames (host control path + H2D) in %.2f s = %.1f Msamples/s" %
         (F, t_stage, (first_frame + F) * FS / t_stage / 1e6))
 
-    gather = N > 1 and not args.no_gather
+    # two output buffers per rank and two stream buffers on the root: round s is sent while round s + 1 is rendered
+    nbuf = 2 if gather else 1
     if rank == 0 and gather:
-        out = torch.empty((N, F * FS * 2), dtype=torch.int16, device=dev)   # the contiguous stream, block after block
-        mine = out[0]
+        outs = [torch.empty((N, F * FS * 2), dtype=torch.int16, device=dev) for _ in range(nbuf)]   # the contiguous stream, block after block
+        mines = [o[0] for o in outs]
     else:
-        out = None
-        mine = torch.empty((F * FS * 2,), dtype=torch.int16, device=dev)
+        outs = [None] * nbuf
+        mines = [torch.empty((F * FS * 2,), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+    mine = mines[0]
+    pending = []
 
-    def step():
-        e.launch(ctypes.c_void_p(mine.data_ptr()))
+    def step(i=0):
+        """Render this rank's block into buffer i & 1 while the block rendered before travels to rank 0."""
+        b = i % nbuf
+        e.launch(ctypes.c_void_p(mines[b].data_ptr()))
         if gather:
-            # grouped ncclSend/ncclRecv: every peer sends its block straight into its
-            # slot of the root's stream buffer, 7 peers -> 7 xGMI links at once
-            sharding.gather_blocks(mine, out, rank, N, via_host=dry)
+            if dry:
+                torch.cuda.synchronize()
+                sharding.gather_blocks(mines[b], outs[b], rank, N, via_host=True)
+            else:
+                sharding.gather_wait(pending)       # the block before this one has arrived: its buffers are free again
+                # (the communicator's stream waits for the render just enqueued on the current stream before it sends)
+                pending[:] = sharding.gather_start(mines[b], outs[b], rank, N)
+
+    def drain():
+        if gather and not dry:
+            sharding.gather_wait(pending)
+            pending[:] = []
 
     # ---- parity gate before any number: EVERY sample of this rank's block against the unmodified reference ----
-    step()
+    step(0)
+    drain()
     torch.cuda.synchronize()
     if not args.noaudio:
-        import hashlib
-        mine_sha = hashlib.sha256(mine.cpu().numpy().tobytes()).hexdigest()
-        want, how = None, None
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
-        if os.path.exists(ref_bin):
-            # the reference CLI run live in this job: its stream up to this rank's block, the block hashed
-            p = subprocess.Popen([ref_bin, "-m", MODE, "-s", str(SAMPLE_RATE), "--filter", "-o", "-", "test"],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-            skip, left, h = first_frame * FS * 4, F * FS * 4, hashlib.sha256()
-            while skip > 0:
-                skip -= len(p.stdout.read(min(skip, 1 << 22)))
-            while left > 0:
-                chunk = p.stdout.read(min(left, 1 << 22))
-                if not chunk:
-                    break
-                h.update(chunk)
-                left -= len(chunk)
-            p.kill()
-            p.wait()
-            want, how = h.hexdigest(), "hacktv_ref run in this job"
+        mine_sha = hashlib.sha256(mines[0].cpu().numpy().tobytes()).hexdigest()
+        want, how = ref_sha(first_frame, F), None
+        if want is not None:
+            how = "hacktv_ref run in this job"
             if mine_sha != want:
                 raise SystemExit("parity gate failed on rank %d: frames %d..%d differ from the reference CLI's output" % (rank, first_frame, first_frame + F - 1))
         long_file = os.path.join(ROOT, "tests", "golden", "ref_long.json")
@@ -213,36 +283,38 @@ def main():
             raise SystemExit("parity gate: neither oracle/_ref/hacktv_ref nor a committed digest for %d frames -- refusing to report a number" % F)
         gate = "all %d frames x %d samples of rank %d's block sha256 == %s" % (F, FS, rank, how)
         log("parity gate ok: " + gate)
+        if rank == 0 and gather:
+            # ... and the whole round as it arrived on rank 0
+            want = ref_sha(0, N * F)
+            if want is not None and hashlib.sha256(outs[0].cpu().numpy().tobytes()).hexdigest() != want:
+                raise SystemExit("parity gate failed: the %d blocks gathered on rank 0 differ from the reference CLI's output" % N)
     else:
         gate = "skipped (--noaudio is not the metric configuration)"
 
-    if rank == 0 and gather and not args.noaudio:
-        # the reassembled stream: frame 1 of block 1 must continue block 0
-        if F <= 3:
-            k = min(4, N * F)
-            seam = out.reshape(-1)[: k * FS * 2].cpu().numpy().tobytes()
-            if util.sha256(seam) != g.cases["i_full"]["sha256_cumulative"][k - 1]:
-                raise SystemExit("parity gate failed: the gathered stream differs from the reference across the block seam")
-            log("gathered stream ok across the block seam (%d frames sha256 == reference CLI)" % k)
+    for i in range(args.warmup):
+        step(i)
+    drain()
 
-    for _ in range(args.warmup):
-        step()
+    def timed(fn_step, fn_drain):
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn_step(i)
+        fn_drain()
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if N > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    if N > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     e.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if N > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if N > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed(step, drain)
 
     raster_ms, n_r = e.timing_read(0)
     filter_ms, n_f = e.timing_read(1)
@@ -251,6 +323,12 @@ def main():
     samples_per_step = N * F * FS
     value = samples_per_step * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
+
+    # N > 1: the same steps without the reassembly, for the record (the ranks share nothing then)
+    render_only = None
+    if gather:
+        dt2 = timed(lambda i: e.launch(ctypes.c_void_p(mines[i % nbuf].data_ptr())), lambda: None)
+        render_only = samples_per_step * args.steps / dt2 / 1e6
 
     # ---- one FRESH block end to end: host pre-pass + H2D of the side inputs, render, D2H of the samples ----
     e2e = None
@@ -328,9 +406,18 @@ def main():
                 "workload": "-m i -s 16000000 --filter test%s (PAL-I AM-VSB + 51-tap FIR, FM mono + NICAM)" % (" --noaudio" if args.noaudio else ""),
                 "frames_per_gpu_per_step": F,
                 "samples_per_step": samples_per_step,
-                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, ", RCCL gather to rank 0 in the step" if gather else ""),
+                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, ", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else ""),
             },
             "parity_gate": gate,
+            "multi_gpu": None if N == 1 else {
+                "ranks": N, "backend": (args.dry_run_backend + " (dry run: every rank on GPU 0, transport through host memory)") if dry else "nccl (RCCL)",
+                "gather_in_step": bool(gather), "gather_overlaps_render": bool(gather and not dry),
+                "seam_gate": seam_gate,
+                "render_only_Msamples_per_s": None if render_only is None else round(render_only, 1),
+                "note": "value includes the reassembly of the contiguous stream on rank 0 (grouped send/recv, one xGMI link per peer): it is bound by "
+                        "the root's ingest (about 38 Gsamples/s per link), not by the kernels; render_only is the same steps without it. With sound on, a run "
+                        "that also stages every round is bound by the serial host pre-pass (host_prepass), whatever the number of GPUs",
+            },
             "roofline": roof,
             "kernels": kernels,
             "host_prepass": {

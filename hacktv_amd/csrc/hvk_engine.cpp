@@ -966,7 +966,19 @@ extern "C" int hvk_host_fm_video(hvk_engine_t *e, int16_t *iq, int64_t count)
 	return(hvk_tail_fm_apply(e->tail, hvk_tail_fm_position(e->tail), count, iq));
 }
 
+static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots);
+
 extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots)
+{
+	return(_stage(e, first_frame, stride, nframes, slots, NULL));
+}
+
+extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
+{
+	return(_stage(e, first_frame, stride, nframes, slots, prev_slots));
+}
+
+static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
 {
 	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
@@ -1116,11 +1128,25 @@ extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t s
 	{
 		hvk_framedesc_t *p = &e->h_fdesc[(size_t) i * (fields + 1)];
 		const hvk_framedesc_t *own = &e->h_fdesc[(size_t) i * (fields + 1) + fields];
-		if(stride != 1) *p = *own;
-		else if(i > 0) *p = e->h_fdesc[(size_t) (i - 1) * (fields + 1) + fields];
-		else if(e->carry_valid && e->carry_frame + 1 == first_frame) *p = e->carry;
-		else if(first_frame == 0) { memset(p, 0, sizeof(*p)); }     /* nothing before the stream */
-		else *p = *own;                                             /* a jump: like a strided render */
+		const int ps = prev_slots ? prev_slots[i] : -1;
+		if(first_frame + i * stride == 0) { memset(p, 0, sizeof(*p)); }     /* nothing before the stream */
+		else if(stride == 1 && i > 0) *p = e->h_fdesc[(size_t) (i - 1) * (fields + 1) + fields];
+		else if(stride == 1 && e->carry_valid && e->carry_frame + 1 == first_frame) *p = e->carry;
+		else if(ps >= 0 && ps < e->frame_slots)
+		{
+			/* the caller has the frame before in a slot (hvk_stage_strided_prev): its picture on the halo line */
+			const hvk_slot_t *ss = &e->slots[ps];
+			*p = *own;
+			p->fb_offset = (int64_t) ps * frame_px;
+			p->fb_width = ss->valid ? ss->width : 0;
+			p->fb_height = ss->valid ? ss->height : 0;
+			p->line_stride = ss->width;
+			p->vframe_x = (k.active_width - p->fb_width) / 2;
+			p->vframe_y = (k.active_lines - p->fb_height) / 2;
+			p->fb_interlaced = ss->interlaced;
+			p->fb_valid = ss->valid;
+		}
+		else *p = *own;                                             /* a strided render or a jump without it: the frame's own picture */
 		/* the colour table position the kernel counts lines from is this frame's, also on the halo line */
 		p->clut_off0 = own->clut_off0;
 		p->frame_index = own->frame_index;

@@ -19,7 +19,7 @@ SYMBOLS = [
     "hvk_open", "hvk_open_rates", "hvk_line_widths", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
-    "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_launch",
+    "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
@@ -74,6 +74,7 @@ def lib():
         L.hvk_render.argtypes = [vp, i32, vp, vp]
         L.hvk_render_strided.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hvk_stage_strided.argtypes = [vp, i64, i64, i32, vp]
+        L.hvk_stage_strided_prev.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hvk_launch.argtypes = [vp, vp]
         L.hvk_launch_strided_out.argtypes = [vp, vp, i64]
         L.hvk_set_stream.argtypes = [vp, vp]
@@ -226,8 +227,11 @@ class Engine:
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)
         return self._chk("hvk_render", lib().hvk_render(self.h, nframes, s.ctypes.data, d_iq))
 
-    def stage(self, first_frame, stride, nframes, slots=None):
+    def stage(self, first_frame, stride, nframes, slots=None, prev_slots=None):
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)
+        if prev_slots is not None:
+            p = np.ascontiguousarray(prev_slots, np.int32)
+            return self._chk("hvk_stage_strided_prev", lib().hvk_stage_strided_prev(self.h, first_frame, stride, nframes, s.ctypes.data, p.ctypes.data))
         return self._chk("hvk_stage_strided", lib().hvk_stage_strided(self.h, first_frame, stride, nframes, s.ctypes.data))
 
     def launch(self, d_iq=None, out_stride=1):

@@ -8,6 +8,10 @@ gathered to `root` with grouped point-to-point operations: every peer sends its
 block straight into its slot of the root's stream buffer, so on an xGMI node
 each peer uses its own link to the root; no ring.
 
+Limits of the sharded path (the engine refuses what it cannot shard): SECAM colour and FM video are serial chains
+over the whole stream -- those modes render on one rank only. Every rank must be fed the whole
+audio stream: the sound carriers' phasor chain is serial too, and each rank runs it up to its own frames.
+
 This module is transport plumbing over torch.distributed; it works with the
 `nccl` backend (RCCL on ROCm) on GPUs and with `gloo` on CPU tensors, which is
 how tests/test_sharding.py exercises it at world size 2."""
@@ -22,6 +26,26 @@ def block_of(rank, world, round_index):
 def first_frame_of(rank, world, round_index, frames):
     """First frame (0-based) of that block."""
     return block_of(rank, world, round_index) * frames
+
+
+def gather_start(local, root_buf, rank, world, root=0, group=None):
+    """Start reassembling one round of blocks on `root` and return the work handles (wait with gather_wait()):
+    the transfers run on the communicator's own stream, so the caller can launch the next round's render
+    meanwhile -- as long as it writes another buffer than `local` / `root_buf`."""
+    if world == 1:
+        return []
+    if rank == root:
+        if root_buf[root].data_ptr() != local.data_ptr():
+            root_buf[root].copy_(local, non_blocking=True)
+        ops = [dist.P2POp(dist.irecv, root_buf[r], r, group) for r in range(world) if r != root]
+    else:
+        ops = [dist.P2POp(dist.isend, local, root, group)]
+    return dist.batch_isend_irecv(ops)
+
+
+def gather_wait(works):
+    for w in works:
+        w.wait()
 
 
 def gather_blocks(local, root_buf, rank, world, root=0, group=None, via_host=False):

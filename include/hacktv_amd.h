@@ -213,6 +213,14 @@ int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int
  * the last one ended, does not have the frame before: it uses the frame's own picture, which is exact for
  * a picture that does not change.) */
 int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots);
+/* As hvk_stage_strided(), for sharded streams whose pictures change: prev_slots[i] names the frame slot that holds the
+ * picture of the frame BEFORE staged frame i (with conf.interlace: the one its second field shows), -1 if the caller
+ * does not have it. It is looked at where the engine does not have that frame itself -- a stride other than 1, or a
+ * call that does not continue the last one -- and makes such renders exact on 525 lines, where the last line of a
+ * frame shows picture within the video filter's reach of the next frame's first samples (src/video.c:4873-4897 takes a
+ * new frame at line 1; the line pipeline still holds the old frame's last line). */
+int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots,
+                           const int32_t *prev_slots);
 int hvk_launch(hvk_engine_t *e, void *d_iq);
 
 /* As hvk_launch(), but frame i of the batch is written at frame position

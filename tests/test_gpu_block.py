@@ -120,3 +120,29 @@ def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
             b = np.frombuffer(want, np.int16).reshape(-1, 2)
             bad = np.nonzero((a != b).any(axis=1))[0]
             raise AssertionError("%d samples differ, first at %d (line %d)" % (bad.size, bad[0], bad[0] // 1024))
+
+
+def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
+    """bench.py's N > 1 path with the engine in it: two ranks (both on GPU 0, gloo through host memory) stage, render and
+    send block-cyclic blocks; before timing anything rank 0 hashes the stream reassembled from two rounds -- block seams
+    and round seams included -- against the reference CLI run in the same job, every rank hashes its timed block, and
+    rank 0 the gathered round. The JSON line must carry the seam gate's verdict."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    if not os.path.exists(os.path.join(REF, "hacktv_ref")):
+        pytest.skip("oracle/_ref/hacktv_ref not built (needs /root/reference at build time)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+           "--dry-run-backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2
+    assert d["multi_gpu"]["seam_gate"] and "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
+    assert "sha256 ==" in d["parity_gate"]

@@ -833,3 +833,42 @@ def test_picture_carried_across_batches_on_525_lines(golden, batch):
     bad = np.nonzero((got != want).any(axis=1))[0]
     fs = len(want) // n
     assert bad.size == 0, "frame %d sample %d" % (bad[0] // fs, bad[0] % fs)
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("world,block", [(2, 1), (3, 2)])
+def test_sharded_525_line_stream_with_changing_pictures_is_exact(golden, world, block, fuse, monkeypatch):
+    """Frames dealt to several engines ('ranks': round-robin for block = 1, block-cyclic otherwise), NTSC, a different
+    random picture on every frame: a rank does not render the frame before its own, but the last line of that frame
+    shows picture within the video filter's reach. With the predecessor's slot named (hvk_stage_strided_prev) the
+    interleaved stream equals the single-engine stream sample for sample; the oracle is the judge."""
+    if fuse:
+        monkeypatch.setenv("HVK_FUSE", "1")
+    conf = H.preset("m", H.FLAG_FILTER)
+    sr, n = 13500000, world * block * 2
+    rng = np.random.default_rng(world * 10 + block)
+    with oracle.Oracle(conf, sr) as o:
+        aw, ah, L = o.info["active_width"], o.info["active_lines"], o.info["lines"]
+        frames = rng.integers(0, 1 << 24, (n, ah, aw), dtype=np.uint32)
+        o.set_audio(golden.audio, True)
+        want = []
+        for f in range(n):
+            o.set_frame(frames[f], interlaced=1)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    fs = len(want) // n
+    got = np.zeros_like(want)
+    for rank in range(world):
+        with H.Engine(conf, sr, device=0, max_frames=n) as e:
+            for f in range(n):
+                e.frame_upload(f, frames[f], interlaced=1)
+            while e.audio_needed(n) > 0:            # the audio pre-pass is one chain over the whole stream: every rank is fed all of it
+                e.audio_write(golden.audio)
+            for rnd in range(n // (world * block)):
+                first = (rnd * world + rank) * block
+                e.stage(first, 1, block, slots=list(range(first, first + block)),
+                        prev_slots=[first + i - 1 for i in range(block)])
+                e.launch()
+                got[first * fs:(first + block) * fs] = e.fetch(0, block * fs)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "%d samples differ, first in frame %d at sample %d" % (bad.size, bad[0] // fs, bad[0] % fs)
