@@ -74,6 +74,8 @@ struct hvk_engine {
 	int64_t fm_batch_pos;       /* output position of the staged batch's first sample */
 	size_t fm_done;             /* samples of the batch modulated so far */
 	int fm_launched;            /* the staged batch has been rendered and is not fully modulated yet */
+	int fm_prime_pending;       /* FM video with the video filter: the phasor has yet to run over the pipeline's start-up samples */
+	int16_t *fm_prime_car;      /*   their sound carrier samples (out_prime int16 pairs) */
 	int device;             /* -1: host tables only */
 	int max_frames;
 	int frame_slots;
@@ -512,6 +514,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	}
 
 	free(e->sym_tmp);
+	free(e->fm_prime_car);
 	free(e->cc_pairs);
 	delete e->raw_q;
 	if(e->host_frames) { for(int i = 0; i < e->frame_slots; i++) free(e->host_frames[i]); free(e->host_frames); }
@@ -1004,6 +1007,23 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
 	int many = 0;
 
+	if(k.fm_video && k.vf_type && first_frame == 0 && k.out_prime > 0)
+	{
+		/* The line pipeline's never-emitted start-up samples pass through the FM modulator as well
+		 * (src/video.c:4936-4952 drops them only at the output): what the sound carriers add to them is
+		 * wanted now, before the audio chain moves on to the first frame (hvk_launch does the rest) */
+		free(e->fm_prime_car);
+		e->fm_prime_car = (int16_t *) calloc((size_t) k.out_prime * 2, sizeof(int16_t));
+		if(!e->fm_prime_car) return(HVK_OUT_OF_MEMORY);
+		if(e->audio && k.has_carriers)
+		{
+			int64_t k0 = 0;
+			int n = hvk_audio_generate(e->audio, 0, k.out_prime, e->fm_prime_car, e->sym_tmp, e->sym_tmp ? e->symbol_stride : 0, &k0);
+			if(n < 0) return(n);
+		}
+		e->fm_prime_pending = 1;
+	}
+
 	for(int i = 0; i < nframes; i++)
 	{
 		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * (fields + 1) + 1];
@@ -1325,6 +1345,34 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 
 	e->last_frames = e->staged;
 	e->fm_launched = e->t.k.fm_video;
+
+	if(e->fm_prime_pending)
+	{
+		/* The modulator's input over the start-up samples: the video filter's output while its history is still
+		 * zero -- nothing but its last ntaps / 2 outputs, whose windows reach the stream's first samples -- plus the
+		 * sound carriers. The stream's first raster samples come from the slab just rendered. */
+		const hvk_kconst_t &k = e->t.k;
+		const int nt = k.vf_ntaps, H = nt / 2, P = k.out_prime;
+		std::vector<int16_t> x(H), in((size_t) P);
+		HIPCHK(hipMemcpyAsync(x.data(), e->d_S + (size_t) k.width, (size_t) H * 2, hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipStreamSynchronize(e->stream));
+		for(int n = 0; n < P; n++)
+		{
+			int32_t acc = 0;
+			const int m = n - P;                    /* stream position of this output: -P .. -1 */
+			for(int kk = 0; kk < nt; kk++)
+			{
+				const int xi = m - H + kk;
+				if(xi >= 0 && xi < H) acc += (int32_t) e->t.vf_itaps[kk] * x[xi];
+			}
+			acc >>= 15;
+			acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+			in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);     /* int16 wrap-around add, src/video.c:3431 */
+		}
+		r = hvk_tail_fm_prime(e->tail, in.data(), P);
+		if(r != HVK_OK) return(r);
+		e->fm_prime_pending = 0;
+	}
 	return(HVK_OK);
 }
 

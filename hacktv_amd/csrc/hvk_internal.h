@@ -16,7 +16,7 @@ extern "C" {
 #define HVK_GHOST_LEN    32
 #define HVK_SPL          8      /* samples per lane in both kernels */
 #define HVK_TILE         1024   /* samples per filter workgroup */
-#define HVK_MAX_VF_TAPS  64
+#define HVK_MAX_VF_TAPS  72     /* (51 for the designed filters; the FM pre-emphasis tables have 67 and 71) */
 #define HVK_PULSE_PAD    8      /* zero int16 either side of every sync pulse in the flat value table */
 #define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
 #define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
@@ -215,6 +215,8 @@ int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_
 /* FM video: the whole tail on the host, in place, for output positions [first, first + count);
  * strictly sequential */
 int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq);
+/* ... before that, once: the modulator's input over the never-emitted start-up samples (with the video filter on) */
+int hvk_tail_fm_prime(hvk_tail_t *s, const int16_t *input, int64_t count);
 int64_t hvk_tail_fm_position(const hvk_tail_t *s);
 
 /* Host audio-rate control path (hvk_audio.c) */

@@ -968,6 +968,9 @@ extern "C" int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 		return(HVK_UNSUPPORTED);
 	}
 	if(a->k.vf_type == 0) return(_launch_filter<1, 0, 0>(a, stream));
+	/* the FM video pre-emphasis tables: real, 67 or 71 taps (vector-unit form) */
+	if(a->k.vf_type == 1 && a->k.vf_ntaps == 67) return(_launch_filter<67, 1, 0>(a, stream));
+	if(a->k.vf_type == 1 && a->k.vf_ntaps == 71) return(_launch_filter<71, 1, 0>(a, stream));
 	if(a->k.vf_ntaps != 51) return(HVK_UNSUPPORTED);
 	if(a->k.vf_type == 1) return(_launch_filter<51, 1, 0>(a, stream));
 	if(a->k.vf_type == 3) return(_launch_filter<51, 3, 0>(a, stream));

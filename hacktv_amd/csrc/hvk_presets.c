@@ -26,19 +26,26 @@ static void _raster_625(hvk_config_t *c, double sync_rise)
 	c->sync_rise = sync_rise;
 }
 
+static void _raster_525w(hvk_config_t *c, double active_width, double sync_rise);
+
 static void _raster_525(hvk_config_t *c)
+{
+	_raster_525w(c, 0.00005290, 0.00000025);     /* 52.90 us */
+}
+
+static void _raster_525w(hvk_config_t *c, double active_width, double sync_rise)
 {
 	c->type = HVK_RASTER_525;
 	c->frame_rate = (hvk_rational_t) { 30000, 1001 };
 	c->lines = 525;
 	c->interlaced = 1;
 	c->active_lines = 480;
-	c->active_width = 0.00005290;        /* 52.90 us */
+	c->active_width = active_width;
 	c->active_left = 0.00000920;         /*  9.20 us */
 	c->hsync_width = 0.00000470;
 	c->vsync_short_width = 0.00000230;
 	c->vsync_long_width = 0.00002710;
-	c->sync_rise = 0.00000025;
+	c->sync_rise = sync_rise;
 }
 
 /* ---- colour systems ---- */
@@ -54,6 +61,16 @@ static void _colour_pal(hvk_config_t *c)
 	c->colour_bw = 1.4e6;
 	c->ev_co = 0.877;
 	c->eu_co = 0.493;
+}
+
+/* PAL on the American rasters' sub-carriers (src/video.c:316-455): burst 2.52 us at 5.3 us, 33 / 73 */
+static void _colour_pal_mn(hvk_config_t *c, int64_t num, int64_t den)
+{
+	_colour_pal(c);
+	c->burst_width = 0.00000252;
+	c->burst_left = 0.00000530;
+	c->burst_level = 33.0 / 73.0;
+	c->colour_carrier = (hvk_rational_t) { num, den };
 }
 
 static void _colour_ntsc(hvk_config_t *c)
@@ -153,6 +170,19 @@ static const struct {
 	{ "pal-fm",   "PAL colour, 25 fps, 625 lines, FM (complex), 6.5 MHz FM audio" },
 	{ "secam-fm", "SECAM colour, 25 fps, 625 lines, FM (complex), 6.5 MHz FM audio" },
 	{ "ntsc-fm",  "NTSC colour, 30/1.001 fps, 525 lines, FM (complex), 6.5 MHz FM audio" },
+	{ "pal-d",    "PAL colour, 25 fps, 625 lines, AM (complex), 6.5 MHz FM audio" },
+	{ "pal-k",    "PAL colour, 25 fps, 625 lines, AM (complex), 6.5 MHz FM audio" },
+	{ "pal-m",    "PAL colour, 30/1.001 fps, 525 lines, AM (complex), 4.5 MHz FM audio" },
+	{ "pal-n",    "PAL colour, 25 fps, 625 lines, AM (complex), 4.5 MHz FM audio" },
+	{ "525pal",   "PAL colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
+	{ "d",        "SECAM colour, 25 fps, 625 lines, AM (complex), 6.5 MHz FM audio" },
+	{ "k",        "SECAM colour, 25 fps, 625 lines, AM (complex), 6.5 MHz FM audio" },
+	{ "secam-i",  "SECAM colour, 25 fps, 625 lines, AM (complex), 6.0 MHz FM audio" },
+	{ "secam-b",  "SECAM colour, 25 fps, 625 lines, AM (complex), 5.5 MHz FM audio" },
+	{ "secam-g",  "SECAM colour, 25 fps, 625 lines, AM (complex), 5.5 MHz FM audio" },
+	{ "ntsc-i",   "NTSC colour, 30/1.001 fps, 525 lines, AM (complex), 6.0 MHz FM audio" },
+	{ "pal60-i",  "PAL colour, 30/1.001 fps, 525 lines, AM (complex), 6.0 MHz FM audio" },
+	{ "pal60",    "PAL colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
 	{ NULL, NULL },
 };
 
@@ -255,6 +285,90 @@ int hvk_config_preset(hvk_config_t *c, const char *id)
 		_raster_525(c);
 		_colour_ntsc(c);
 		_fm_sound(c, 0.05, 6500000, 85000, HVK_50US);
+	}
+	else if(strcmp(id, "pal-d") == 0 || strcmp(id, "pal-k") == 0)
+	{
+		/* src/video.c:158-211 */
+		_vsb(c, 5500000, 750000, 0.70, 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000020);
+		_colour_pal(c);
+		_fm_sound(c, 0.20, 6500000, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 5850000, 0.4);
+	}
+	else if(strcmp(id, "pal-m") == 0)
+	{
+		/* src/video.c:316-364 */
+		_vsb(c, 4200000, 750000, 0.77, 0.2000, 0.7280, 0.7712, 1.0000);
+		_raster_525w(c, 0.00005280, 0.00000020);
+		_colour_pal_mn(c, 511312500, 143);        /* 3575611.888... Hz */
+		_fm_sound(c, 0.15, 4500000, 25000, HVK_75US);
+	}
+	else if(strcmp(id, "pal-n") == 0)
+	{
+		/* src/video.c:366-413 (no sync rise time in the preset) */
+		_vsb(c, 4200000, 750000, 0.77, 0.2000, 0.7280, 0.7712, 1.0000);
+		_raster_625(c, 0);
+		_colour_pal_mn(c, 14328225, 4);           /* 3582056.25 Hz */
+		_fm_sound(c, 0.15, 4500000, 25000, HVK_75US);
+	}
+	else if(strcmp(id, "525pal") == 0)
+	{
+		/* src/video.c:415-455 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		_raster_525w(c, 0.00005280, 0.00000020);
+		_colour_pal_mn(c, 511312500, 143);
+	}
+	else if(strcmp(id, "d") == 0 || strcmp(id, "k") == 0)
+	{
+		/* src/video.c:506-555 */
+		_vsb(c, 5500000, 750000, 0.70, 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000020);
+		_colour_secam(c);
+		_fm_sound(c, 0.20, 6500000, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 5850000, 0.4);
+	}
+	else if(strcmp(id, "secam-i") == 0)
+	{
+		/* src/video.c:557-606 */
+		_vsb(c, 5500000, 1250000, 0.71, 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000025);
+		_colour_secam(c);
+		_fm_sound(c, 0.15, 6000000 - 400, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 6552000, 1.0);
+	}
+	else if(strcmp(id, "secam-b") == 0 || strcmp(id, "secam-g") == 0)
+	{
+		/* src/video.c:608-657 */
+		_vsb(c, 5000000, 750000, 0.80 * (100.0 / 124.0), 0.20, 0.76, 0.76, 1.00);
+		_raster_625(c, 0.00000020);
+		_colour_secam(c);
+		_fm_sound(c, 0.15, 5500000, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 5850000, 0.4);
+	}
+	else if(strcmp(id, "ntsc-i") == 0)
+	{
+		/* src/video.c:805-857 */
+		_vsb(c, 5500000, 1250000, 0.71, 0.200000, 0.728571, 0.771428, 1.000000);
+		_raster_525(c);
+		_colour_ntsc(c);
+		_fm_sound(c, 0.22, 6000000 - 400, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 6552000, 1.0);
+	}
+	else if(strcmp(id, "pal60-i") == 0)
+	{
+		/* src/video.c:1010-1062 */
+		_vsb(c, 5500000, 1250000, 0.71, 0.20, 0.76, 0.76, 1.00);
+		_raster_525(c);
+		_colour_pal(c);
+		_fm_sound(c, 0.22, 6000000 - 400, 50000, HVK_50US);
+		_nicam(c, 0.07 / 2, 6552000, 1.0);
+	}
+	else if(strcmp(id, "pal60") == 0)
+	{
+		/* src/video.c:1064-1103 (no sync rise time in the preset) */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		_raster_525w(c, 0.00005290, 0);
+		_colour_pal(c);
 	}
 	else
 	{

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <math.h>
 #include "hvk_internal.h"
+#include "hvk_fm_taps.h"
 
 #define EDGE_0_100 2.0738786   /* 10-90 % rise time -> full width of an integrated raised-cosine edge (src/common.h:28) */
 
@@ -1128,9 +1129,6 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 	/* what the engine renders */
 	if(c->type != HVK_RASTER_625 && c->type != HVK_RASTER_525) return(HVK_UNSUPPORTED);
-	/* FM video with --filter uses fixed pre-emphasis tap tables designed outside the reference
-	 * (src/video.c:2017-2113); they are not reproduced here */
-	if(c->modulation == HVK_FM && c->vfilter) return(HVK_UNSUPPORTED);
 	if(c->modulation == HVK_FM && (c->fm_level <= 0 || c->fm_deviation <= 0)) return(HVK_ERROR);
 	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
@@ -1332,10 +1330,25 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->k.delay_lines = 0;
 	if(c->vfilter)
 	{
-		const int ntaps = 51;
+		int ntaps = 51;
 		const int fw = round((double) sample_rate * line_s);   /* the line width at the sample rate, src/video.c:3660 */
 
-		if(c->modulation == HVK_VSB)
+		if(c->modulation == HVK_FM)
+		{
+			/* FM video: a fixed pre-emphasis filter picked by line count and sample rate
+			 * (src/video.c:3690-3730; hvk_fm_taps.h has the tables), real, in front of the modulator */
+			const hvk_fm_taps_t *f = hvk_fm_taps;
+			int k;
+			while(f->lines && !(f->lines == c->lines && (f->sample_rate == (int) sample_rate || f->sample_rate == 0))) f++;
+			if(!f->lines || f->ntaps > HVK_MAX_VF_TAPS) return(HVK_UNSUPPORTED);
+			ntaps = f->ntaps;
+			t->k.vf_type = 1;
+			t->k.vf_ntaps = ntaps;
+			t->vf_itaps = calloc(ntaps, sizeof(int16_t));
+			if(!t->vf_itaps) return(HVK_OUT_OF_MEMORY);
+			for(k = 0; k < ntaps; k++) t->vf_itaps[k] = f->q15[ntaps - 1 - k];      /* applied order: the design reversed (src/fir.c:279-286) */
+		}
+		else if(c->modulation == HVK_VSB)
 		{
 			/* complex band pass = low pass of half the pass band rotated to the
 			 * band centre; the rotation phase is ACCUMULATED tap by tap

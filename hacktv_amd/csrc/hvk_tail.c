@@ -26,7 +26,8 @@
  * processes delay_lines never-emitted lines of full width before the first real
  * one (src/video.c:3235-3248 sets their width); the offset phasor advances over
  * them and the passthru source loses its first delay_lines * width samples.
- * FM video never runs with the filter here (hvk_tables.c refuses it).
+ * The FM video phasor runs over them too -- over the video filter's output while its history fills, plus
+ * the sound carriers of those samples: hvk_tail_fm_prime().
  */
 #include <stdlib.h>
 #include <string.h>
@@ -208,6 +209,27 @@ int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_
 int64_t hvk_tail_fm_position(const hvk_tail_t *s)
 {
 	return(s->fm_pos);
+}
+
+/* The never-emitted start-up samples of the line pipeline (src/video.c:3235-3248, :4936-4952: slots whose line
+ * number is 0 are dropped at the output, after every process has run over them): the FM phasor advances over
+ * their modulator input -- count values, before the first call of hvk_tail_fm_apply(). */
+int hvk_tail_fm_prime(hvk_tail_t *s, const int16_t *input, int64_t count)
+{
+	const hvk_c32_t *lut = s->t->fmv_lut;
+	int64_t n;
+
+	if(!lut || s->fm_pos != 0 || count < 0) return(HVK_ERROR);
+	for(n = 0; n < count; n++)
+	{
+		s->fm_phase = _mul(s->fm_phase, lut[input[n] - INT16_MIN]);
+		if(--s->fm_counter == 0)
+		{
+			s->fm_phase = _renormalise(s->fm_phase);
+			s->fm_counter = INT16_MAX;
+		}
+	}
+	return(HVK_OK);
 }
 
 int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)

@@ -52,6 +52,21 @@ CASES = [
     ("secam_bb",      "secam", 16000000, [],                       0,                                      True,  3),
     ("l_raster",      "l",    16000000, ["--noaudio"],             refprobe.FLAG_NOAUDIO,                  False, 2),
     ("l_full",        "l",    16000000, ["--filter"],              refprobe.FLAG_FILTER,                   False, 4),
+    # the other 625 / 525-line presets of src/video.c:1956-2008
+    ("pald_full",     "pal-d",   16000000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("palm_full",     "pal-m",   13500000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("paln_full",     "pal-n",   16000000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("pal525_bb",     "525pal",  13500000, [],                     0,                                      True,  2),
+    ("d_full",        "d",       16000000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("secami_full",   "secam-i", 16000000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("secamb_raster", "secam-b", 16000000, ["--noaudio"],          refprobe.FLAG_NOAUDIO,                  False, 2),
+    ("ntsci_full",    "ntsc-i",  13500000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("pal60i_full",   "pal60-i", 13500000, ["--filter"],           refprobe.FLAG_FILTER,                   False, 2),
+    ("pal60_bb",      "pal60",   13500000, [],                     0,                                      True,  2),
+    # FM video with its pre-emphasis filter (fixed tap tables, src/video.c:2017-2113, picked by :3690-3730)
+    ("palfm_f14",     "pal-fm",   14000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
+    ("ntscfm_f18",    "ntsc-fm",  18000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
+    ("secamfm_f2025", "secam-fm", 20250000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     # teletext from a raw packet file (tests/golden/ttraw.bin: 42-byte records, no wall clock involved)
     ("i_tt",          "i",    16000000, ["--noaudio", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO,  False, 3),
     ("l_tt",          "l",    16000000, ["--filter", "--teletext", "raw:@TTRAW@"],  refprobe.FLAG_FILTER,   False, 3),

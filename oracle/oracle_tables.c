@@ -11,6 +11,7 @@
 #include <string.h>
 #include <math.h>
 #include "oracle_internal.h"
+#include "oracle_fm_taps.h"
 
 double orc_i_zero(double x);
 void orc_kaiser(double *taps, int ntaps, double beta);
@@ -429,6 +430,26 @@ int orc_build_tables(orc_t *s)
 			s->vf_ntaps = ntaps;
 			s->vf_itaps = _quantise_reversed(ct + 0, ntaps, 2);
 			s->vf_qtaps = _quantise_reversed(ct + 1, ntaps, 2);
+		}
+		else if(c->modulation == HVK_FM)
+		{
+			/* src/video.c:3690-3730: a fixed pre-emphasis table by line count and sample rate */
+			const double *tab;
+			if(c->lines == 525)
+			{
+				if(s->sample_rate == 18000000) { tab = orc_fm_525_18_taps; ntaps = sizeof(orc_fm_525_18_taps) / sizeof(double); }
+				else { tab = orc_fm_525_2025_taps; ntaps = sizeof(orc_fm_525_2025_taps) / sizeof(double); }
+			}
+			else
+			{
+				if(s->sample_rate == 14000000) { tab = orc_fm_625_14_taps; ntaps = sizeof(orc_fm_625_14_taps) / sizeof(double); }
+				else if(s->sample_rate == 20000000) { tab = orc_fm_625_20_taps; ntaps = sizeof(orc_fm_625_20_taps) / sizeof(double); }
+				else if(s->sample_rate == 28000000) { tab = orc_fm_625_28_taps; ntaps = sizeof(orc_fm_625_28_taps) / sizeof(double); }
+				else { tab = orc_fm_625_2025_taps; ntaps = sizeof(orc_fm_625_2025_taps) / sizeof(double); }
+			}
+			s->vf_type = 1;
+			s->vf_ntaps = ntaps;
+			s->vf_itaps = _quantise_reversed(tab, ntaps, 1);
 		}
 		else if(c->modulation == HVK_AM || c->modulation == HVK_NONE)
 		{

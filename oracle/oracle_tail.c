@@ -32,9 +32,6 @@ int orc_tail_init(orc_t *s)
 
 	if(c->modulation == HVK_FM)
 	{
-		/* the fixed FM pre-emphasis tap tables (src/video.c:2017-2113) are not restated */
-		if(c->vfilter) return(-1);
-
 		/* src/video.c:4566, :2218-2243: frequency 0 */
 		s->fm_video.on = 1;
 		s->fm_video.level = round(INT16_MAX * (c->fm_level * c->level));

@@ -35,7 +35,10 @@ def test_presets_match_the_reference_mode_ids():
     while H.lib().hvk_preset_id(i):
         ids.append(H.lib().hvk_preset_id(i).decode())
         i += 1
-    assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc", "pal-fm", "secam-fm", "ntsc-fm"]
+    # every 625 / 525-line mode of the reference's vid_configs[] (src/video.c:1956-2008) but ntsc-bs (DANCE digital audio)
+    assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc", "pal-fm", "secam-fm", "ntsc-fm",
+                   "pal-d", "pal-k", "pal-m", "pal-n", "525pal", "d", "k", "secam-i", "secam-b", "secam-g", "ntsc-i",
+                   "pal60-i", "pal60"]
     assert H.lib().hvk_config_preset(ctypes.byref(H.HvkConfig()), b"nope") == -1
 
 
@@ -56,7 +59,6 @@ def test_unsupported_configurations_are_refused():
     """Configurations outside the engine's scope fail at open with HVK_UNSUPPORTED."""
     bad = []
     c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
-    c = H.preset("pal-fm", H.FLAG_FILTER); bad.append((c, 16000000))          # FM video with the fixed pre-emphasis tap tables
     c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster other than 625 / 525
     for conf, sr in bad:
         try:
