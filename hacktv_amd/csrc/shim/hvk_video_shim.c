@@ -33,7 +33,11 @@
  * variable, default 8) and read back into a host buffer the lines point into;
  * a worker thread prepares the next batch (source pulls, host pre-passes, render,
  * read-back) while the lines of the current one are handed out.
- * line->audio is always NULL (the file sink has no audio path).
+ * line->audio / audio_len (src/video.c:3445-3447; what a sink with rf_write_audio() is handed, src/hacktv.c:1586): the
+ * reference's audio process writes every 32 kHz stereo sample it has drawn, after the volume control, into a FIFO of
+ * 320-sample blocks and reads that FIFO once per line -- a block can be read once the writer has left it, i.e. from the
+ * line on which the 321st, 641st, ... sample is drawn (src/fifo.c:230-290). The shim keeps the drawn samples and hands
+ * out the same blocks on the same lines.
  *
  * Teletext: which packet goes on which line -- the TTI page store, the magazine
  * scheduler, the wall clock (src/teletext.c:489-990) -- is host control logic and
@@ -51,6 +55,7 @@
 #include "hvk_shim_depth.h"
 
 #define SHIM_AUDIO_RATE 32000    /* HACKTV_AUDIO_SAMPLE_RATE, src/hacktv.h:31 */
+#define SHIM_AUDIO_BLOCK 320     /* stereo samples per block of the reference's audio FIFO, src/video.c:4342 */
 
 typedef struct {
 	hvk_engine_t *e;
@@ -85,8 +90,40 @@ typedef struct {
 	int64_t audio_drawn;    /* 32 kHz samples taken from the source when no carrier needs them */
 	int last[2];            /* buffer holds the last frames of the source */
 	int end_drop;           /* lines of the last frame the reference never hands out (see vid_next_line) */
+	/* line->audio: the 32 kHz samples drawn so far after the volume control (pairs; aud[0] is pair aud_base), the stream
+	 * position the audio process has reached when a line goes out, the blocks handed out */
+	int16_t *aud;
+	size_t aud_len, aud_cap;
+	int64_t aud_base;
+	int volume;
+	int64_t out_pos;
+	int64_t aud_blocks_read;
+	int16_t aud_out[SHIM_AUDIO_BLOCK * 2];
 	vid_line_t out;
 } shim_t;
+
+/* keep what av_read_audio() delivered, scaled like src/video.c:3293-3298 (worker side) */
+static int _aud_append(shim_t *m, const int16_t *a, size_t pairs)
+{
+	size_t i;
+	pthread_mutex_lock(&m->lock);
+	if(m->aud_len + pairs > m->aud_cap)
+	{
+		size_t cap = (m->aud_len + pairs) * 2 + 4096;
+		int16_t *p = realloc(m->aud, cap * 2 * sizeof(int16_t));
+		if(!p) { pthread_mutex_unlock(&m->lock); return(-1); }
+		m->aud = p;
+		m->aud_cap = cap;
+	}
+	for(i = 0; i < pairs * 2; i++)
+	{
+		const int32_t v = ((int32_t) a[i] * m->volume + 128) >> 8;
+		m->aud[m->aud_len * 2 + i] = (int16_t) (v < INT16_MIN ? INT16_MIN : (v > INT16_MAX ? INT16_MAX : v));
+	}
+	m->aud_len += pairs;
+	pthread_mutex_unlock(&m->lock);
+	return(0);
+}
 
 static void _cc_push(shim_t *m, const uint8_t *pair)
 {
@@ -123,7 +160,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
 	if(c->modulation == VID_FM && c->fm_energy_dispersal) return(_refuse("FM energy dispersal"));
-	if(c->modulation == VID_FM && c->vfilter) return(_refuse("the FM video pre-emphasis filter (--filter with an FM mode)"));
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
@@ -247,6 +283,8 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	}
 
 	hvk_get_info(m->e, &m->info);
+	m->out_pos = m->info.startup_samples;
+	m->volume = conf->volume;
 
 	m->buf[0] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
 	m->buf[1] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
@@ -349,6 +387,7 @@ void vid_free(vid_t *s)
 		pthread_cond_destroy(&m->cond);
 		free(m->widths);
 		free(m->passbuf);
+		free(m->aud);
 		free(m);
 	}
 
@@ -464,6 +503,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 				av_read_audio(&s->av, &a, &an);
 				if(a == NULL || an == 0) break;
 				if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+				if(_aud_append(m, a, an) != 0) return(-1);
 			}
 		}
 		else
@@ -480,6 +520,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 				av_read_audio(&s->av, &a, &an);
 				if(a == NULL || an == 0) break;
 				m->audio_drawn += an;
+				if(_aud_append(m, a, an) != 0) return(-1);
 			}
 		}
 	}
@@ -637,6 +678,41 @@ vid_line_t *vid_next_line(vid_t *s)
 	l->vbialloc = 0;
 	l->audio = NULL;
 	l->audio_len = 0;
+	{
+		/* 32 kHz samples the audio process has drawn once it is through with this line (one every sample_rate / 32000
+		 * output samples, src/video.c:3272-3274; it is startup_samples ahead of the output); a block goes out on the
+		 * first line that finds it complete, one block per line at most */
+		int64_t ticks, avail;
+		m->out_pos += l->width;
+		ticks = m->out_pos / m->info.sample_rate * SHIM_AUDIO_RATE + m->out_pos % m->info.sample_rate * SHIM_AUDIO_RATE / m->info.sample_rate;
+		avail = ticks >= 1 ? (ticks - 1) / SHIM_AUDIO_BLOCK : 0;
+		if(m->aud_blocks_read < avail)
+		{
+			const int64_t first = m->aud_blocks_read * SHIM_AUDIO_BLOCK;
+			int i;
+			pthread_mutex_lock(&m->lock);
+			for(i = 0; i < SHIM_AUDIO_BLOCK; i++)
+			{
+				/* a source that has run dry leaves silence (src/video.c:3299-3304) */
+				const int64_t at = first + i - m->aud_base;
+				const int have = at >= 0 && at < (int64_t) m->aud_len;
+				m->aud_out[i * 2 + 0] = have ? m->aud[at * 2 + 0] : 0;
+				m->aud_out[i * 2 + 1] = have ? m->aud[at * 2 + 1] : 0;
+			}
+			/* what has gone out is dropped now and then */
+			if(first + SHIM_AUDIO_BLOCK - m->aud_base >= 65536 && first + SHIM_AUDIO_BLOCK - m->aud_base <= (int64_t) m->aud_len)
+			{
+				const size_t drop = (size_t) (first + SHIM_AUDIO_BLOCK - m->aud_base);
+				memmove(m->aud, m->aud + drop * 2, (m->aud_len - drop) * 2 * sizeof(int16_t));
+				m->aud_len -= drop;
+				m->aud_base += drop;
+			}
+			pthread_mutex_unlock(&m->lock);
+			m->aud_blocks_read++;
+			l->audio = m->aud_out;
+			l->audio_len = SHIM_AUDIO_BLOCK * 2;
+		}
+	}
 	l->previous = l->next = l;
 
 	s->frame = l->frame;

@@ -92,7 +92,7 @@ int main(int argc, char *argv[])
 	static src_t sa, sb;
 	unsigned int sr, pr = 0;
 	int frames, flags, colour_tail;
-	long lines = 0, bad_lines = 0, compared = 0;
+	long lines = 0, bad_lines = 0, compared = 0, audio_blocks = 0;
 
 	if(argc < 5) { fprintf(stderr, "usage: shim_check <mode> <sample rate> <frames> <flags> [pixel rate]\n"); return(2); }
 	sr = atoi(argv[2]);
@@ -150,6 +150,16 @@ int main(int argc, char *argv[])
 			_exit(1);
 		}
 
+		/* the line's share of the 32 kHz sound (src/video.c:3445-3447: what rf_write_audio() sinks are handed) */
+		if(la->audio_len != lb->audio_len || (la->audio == NULL) != (lb->audio == NULL) ||
+		   (la->audio && memcmp(la->audio, lb->audio, la->audio_len * sizeof(int16_t)) != 0))
+		{
+			printf("DIFFERENT: frame %d line %d: line->audio (%zu samples in the reference, %zu in the shim)\n", la->frame, la->line, la->audio_len, lb->audio_len);
+			fflush(stdout);
+			_exit(1);
+		}
+		if(la->audio) audio_blocks++;
+
 		x1 = la->width;
 		if(colour_tail) { x0 = 32; x1 = la->width - 40; }   /* H2: see the header */
 		for(x = x0; x < x1; x++)
@@ -168,7 +178,7 @@ int main(int argc, char *argv[])
 		lines++;
 	}
 
-	printf("%s: %ld lines, %ld samples compared, %ld lines differ; both ended on the same call\n", bad_lines ? "DIFFERENT" : "EQUAL", lines, compared, bad_lines);
+	printf("%s: %ld lines, %ld samples compared, %ld lines differ; %ld blocks of line->audio equal; both ended on the same call\n", bad_lines ? "DIFFERENT" : "EQUAL", lines, compared, bad_lines, audio_blocks);
 	fflush(stdout);
 	_exit(bad_lines ? 1 : 0);       /* the reference's vid_free() can hang on its thread shutdown (see ref_probe.c) */
 }
