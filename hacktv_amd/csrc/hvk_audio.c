@@ -279,6 +279,7 @@ static void _nicam_build_frame(_nicam_t *n)
 
 struct hvk_audio {
 	const hvk_tables_t *t;
+	int oom;                /* an allocation failed: the symbol store is incomplete, every later request fails */
 	int width;
 	int sample_rate;
 
@@ -479,7 +480,9 @@ static void _sym_append(hvk_audio_t *a, uint8_t v)
 	if(a->sym_len == a->sym_cap)
 	{
 		size_t cap = a->sym_cap ? a->sym_cap * 2 : 65536;
-		a->sym = realloc(a->sym, cap);
+		uint8_t *p = realloc(a->sym, cap);
+		if(!p) { a->oom = 1; return; }       /* hvk_audio_generate() reports it */
+		a->sym = p;
 		a->sym_cap = cap;
 	}
 	a->sym[a->sym_len++] = v;
@@ -649,6 +652,7 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 
 	/* the chains cannot be rewound: a request may start inside the line generated last, not before it */
 	if(first < (a->last_w ? a->last_pos : a->pos)) return(HVK_ERROR);
+	if(a->oom) return(HVK_OUT_OF_MEMORY);
 
 	for(;;)
 	{
@@ -693,6 +697,7 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 	}
 	else if(k0) *k0 = 0;
 
+	if(a->oom) return(HVK_OUT_OF_MEMORY);
 	return(nsym);
 }
 

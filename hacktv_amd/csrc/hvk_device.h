@@ -36,6 +36,7 @@ typedef int    int4u   __attribute__((ext_vector_type(4), aligned(4)));
 typedef int    int2u   __attribute__((ext_vector_type(2), aligned(4)));
 /* ... and four that are only 2-byte aligned (global memory only) */
 typedef int    int4a2  __attribute__((ext_vector_type(4), aligned(2)));
+typedef int    int_a2  __attribute__((aligned(2)));
 
 #define SPL HVK_SPL
 

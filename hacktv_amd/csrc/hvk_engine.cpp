@@ -127,6 +127,7 @@ struct hvk_engine {
 	int64_t staged_first, staged_stride;
 	int last_frames;        /* frames of the last launch (for fetch) */
 	int ghost_dirty;
+	int poisoned;           /* a stage failed after the serial chains had moved on: the stream is out of step, nothing more is rendered */
 
 	/* kernel timing with HIP events on the engine's stream */
 	int timing;
@@ -985,6 +986,16 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 {
 	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
+	/* A stage that fails half way has moved the serial chains (sound carriers, SECAM colour, offset, passthru, FM
+	 * video) forward for the frames before the failure; they cannot be rewound, so the stream would go on out of step
+	 * without anyone noticing. Everything that can be checked is checked before the first of them is touched, and a
+	 * failure after that point poisons the engine: every later call fails too. */
+	if(e->poisoned) return(HVK_ERROR);
+	for(int i = 0; i < nframes * e->t.k.fields; i++)
+	{
+		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
+	}
+	if(e->secam && (stride != 1 || first_frame != e->secam_next)) return(HVK_UNSUPPORTED);   /* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
 
 	const hvk_kconst_t &k = e->t.k;
 	const int64_t FS = k.frame_samples;
@@ -1057,8 +1068,6 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 
 		if(e->secam)
 		{
-			/* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
-			if(f->frame_index != e->secam_next) return(HVK_UNSUPPORTED);
 			const hvk_slot_t *s2 = &e->slots[slot2];
 			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
 			                        f->fb_width, f->fb_height, s->interlaced,
@@ -1086,12 +1095,12 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(e->h_off)
 		{
 			int r = hvk_tail_offset_stream(e->tail, f->frame_index * FS, FS, e->h_off + (size_t) i * FS * 2);
-			if(r != HVK_OK) return(r);
+			if(r != HVK_OK) { e->poisoned = 1; return(r); }
 		}
 		if(e->h_pass)
 		{
 			int r = hvk_tail_passthru_stream(e->tail, f->frame_index * FS, FS, e->h_pass + (size_t) i * FS * 2);
-			if(r != HVK_OK) return(r);
+			if(r != HVK_OK) { e->poisoned = 1; return(r); }
 		}
 
 		if(e->audio)
@@ -1101,7 +1110,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			int n = hvk_audio_generate(e->audio, m0, FS,
 				e->h_car ? e->h_car + (size_t) i * FS * 2 : NULL,
 				e->sym_tmp, e->symbol_stride, &k0);
-			if(n < 0) return(n);
+			if(n < 0) { e->poisoned = 1; return(n); }
 
 			if(k.has_nicam)
 			{

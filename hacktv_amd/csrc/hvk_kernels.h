@@ -11,7 +11,7 @@
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_MFMA_A_BYTES (2 * 64 * 16)
 #define HVK_ZERO_BYTES  (64 * 1024)
-#define HVK_NICAM_TAPD  384  /* entries of one copy of the zero padded NICAM pulse table */
+#define HVK_NICAM_TAPD  512  /* entries of one copy of the zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
  * live in SGPRs (wave-uniform operands of v_dot2c_i32_i16) */

@@ -240,15 +240,17 @@ void hvk_k_filter(const hvk_kconst_t k,
 	}
 	if(VF != 0 && MF)
 	{
-		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
+		/* (2-byte aligned only: a line can have an odd number of samples -- 1135 at 4 f_sc -- and then every other
+		 * frame's slab starts on an odd sample; global memory takes the dword loads all the same) */
+		const int_a2 *src = (const int_a2 *) (slab + n0 - LEAD);
 		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
 #pragma unroll
 		for(int i = 0; i < WP; i++)
 		{
 			const int q = min(t + i * (HVK_TILE / HVK_SPL), NG - 1);
 			int4u d = { 0, 0, 0, 0 };
-			if(EXACT) d = ((const int4u *) src)[q];
-			else if(q * 4 + 3 < limit) d = ((const int4u *) src)[q];
+			if(EXACT) { const int4a2 w = ((const int4a2 *) src)[q]; d = (int4u) { w.x, w.y, w.z, w.w }; }
+			else if(q * 4 + 3 < limit) { const int4a2 w = ((const int4a2 *) src)[q]; d = (int4u) { w.x, w.y, w.z, w.w }; }
 			else
 			{
 				if(q * 4 + 0 < limit) d.x = src[q * 4 + 0];
@@ -296,7 +298,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	}
 	else if(VF != 0)
 	{
-		const int *src = (const int *) (slab + n0 - LEAD);   /* 4-byte aligned: W, TILE, LEAD even */
+		const int_a2 *src = (const int_a2 *) (slab + n0 - LEAD);   /* (2-byte aligned only, see above) */
 		const int limit = (k.s_stride - k.s_lead - (n0 - LEAD)) / 2;   /* dwords available in the slab */
 		constexpr int PASSES = (NWIN / 2 + HVK_TILE / HVK_SPL - 1) / (HVK_TILE / HVK_SPL);
 		int v[PASSES];

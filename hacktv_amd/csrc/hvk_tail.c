@@ -52,6 +52,7 @@ struct hvk_tail {
 	/* passthru queue: q[0] is source sample q_base */
 	int16_t *q;
 	size_t q_len, q_cap;
+	size_t q_head;              /* pairs at the front that have been consumed already (dropped lazily) */
 	int64_t q_base;
 	int ended;                  /* a line found the source short: nothing is added from then on */
 };
@@ -167,12 +168,19 @@ int hvk_tail_passthru_push(hvk_tail_t *s, const int16_t *iq, size_t nsamples)
 /* Drop queued source samples below source index `upto` */
 static void _passthru_discard(hvk_tail_t *s, int64_t upto)
 {
-	int64_t drop = upto - s->q_base;
+	int64_t drop = upto - s->q_base - (int64_t) s->q_head;
 	if(drop <= 0) return;
-	if((size_t) drop > s->q_len) drop = s->q_len;
-	memmove(s->q, s->q + drop * 2, (s->q_len - drop) * 2 * sizeof(int16_t));
-	s->q_len -= drop;
-	s->q_base += drop;
+	if((size_t) drop > s->q_len - s->q_head) drop = s->q_len - s->q_head;
+	/* a read offset moves on; the queue is compacted once more than half of it has been consumed (FM video asks line
+	 * by line: moving the rest of the queue for every line would be quadratic) */
+	s->q_head += (size_t) drop;
+	if(s->q_head * 2 > s->q_len)
+	{
+		memmove(s->q, s->q + s->q_head * 2, (s->q_len - s->q_head) * 2 * sizeof(int16_t));
+		s->q_len -= s->q_head;
+		s->q_base += (int64_t) s->q_head;
+		s->q_head = 0;
+	}
 }
 
 int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out)

@@ -67,6 +67,8 @@ CASES = [
     ("palfm_f14",     "pal-fm",   14000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     ("ntscfm_f18",    "ntsc-fm",  18000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     ("secamfm_f2025", "secam-fm", 20250000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
+    # NICAM at the top of the range of sample rates (its pulse is 373 taps long there)
+    ("i_27m",         "i",        27000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     # teletext from a raw packet file (tests/golden/ttraw.bin: 42-byte records, no wall clock involved)
     ("i_tt",          "i",    16000000, ["--noaudio", "--teletext", "raw:@TTRAW@"], refprobe.FLAG_NOAUDIO,  False, 3),
     ("l_tt",          "l",    16000000, ["--filter", "--teletext", "raw:@TTRAW@"],  refprobe.FLAG_FILTER,   False, 3),
