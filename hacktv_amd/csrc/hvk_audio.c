@@ -499,6 +499,50 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 		return;
 	}
 
+	if(a->fm.on && !a->a2.on && !a->am.on)
+	{
+		/* One FM carrier and nothing else (the common case: every mono FM system): the recurrence with its state
+		 * in registers, in runs that end where the amplitude correction is due. The chain is bound by the latency
+		 * of its dependent multiply -> subtract -> shift; nothing else sits on that path (measured: working the
+		 * output values out in a vectorised second pass gains nothing). */
+		const hvk_c32_t st = a->t->fm_lut[a->fm.sample - INT16_MIN];
+		const int64_t ci = st.i, cq = st.q;
+		const int32_t level = a->fm.level;
+		int32_t pi = a->fm.pi, pq = a->fm.pq;
+		int32_t counter = a->fm.counter;
+
+		x = x0;
+		while(x < x1)
+		{
+			int run = x1 - x, i;
+			int16_t *o = carriers + (size_t) x * 2;
+			if(run > counter) run = counter;
+			for(i = 0; i < run; i++)
+			{
+				const int64_t ni = pi * ci - pq * cq;
+				const int64_t nq = pi * cq + pq * ci;
+				pi = (int32_t) (ni >> 31);
+				pq = (int32_t) (nq >> 31);
+				o[i * 2 + 0] = (int16_t) (((pi >> 16) * level) >> 15);
+				o[i * 2 + 1] = (int16_t) (((pq >> 16) * level) >> 15);
+			}
+			x += run;
+			counter -= run;
+			if(counter == 0)
+			{
+				/* amplitude drift correction every INT16_MAX steps (src/video.c:2266-2275) */
+				const double ra = atan2(pq, pi);
+				pi = lround(cos(ra) * INT32_MAX);
+				pq = lround(sin(ra) * INT32_MAX);
+				counter = INT16_MAX;
+			}
+		}
+		a->fm.pi = pi;
+		a->fm.pq = pq;
+		a->fm.counter = counter;
+		return;
+	}
+
 	{
 		/* the step is constant between two 32 kHz ticks */
 		const hvk_c32_t fm_step = a->fm.on ? a->t->fm_lut[a->fm.sample - INT16_MIN] : (hvk_c32_t) { 0, 0 };

@@ -33,6 +33,7 @@
 #define HVK_MIN_FRAME_SLOTS 4
 #define HVK_MAX_FRAME_SLOTS 256
 #define HVK_TIMING_SLOTS 512
+#define HVK_UPLOAD_RING 8
 
 extern "C" {
 int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
@@ -116,7 +117,12 @@ struct hvk_engine {
 	int fused;                  /* this configuration renders in one kernel (hvk_fused.hip) */
 	int run_lines;              /* < 0: runs per frame as given (HVK_RUNS); 0: the launcher chooses */
 	int last_fused;             /* the last launch did: the raster slab in HBM was not written */
-	uint32_t *h_frame;
+	/* pinned staging for source frames: a small ring, each buffer guarded by an event recorded behind its copy, so that
+	 * hvk_frame_upload() waits for the copy that last used THAT buffer only -- never for the stream */
+	uint32_t *h_frame[HVK_UPLOAD_RING];
+	hipEvent_t up_ev[HVK_UPLOAD_RING];
+	int up_busy[HVK_UPLOAD_RING];
+	int up_next;
 
 	hvk_slot_t *slots;          /* [frame_slots] */
 	hvk_packed_taps_t ctaps, itaps, qtaps;
@@ -413,7 +419,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	OPENHIP(hipMalloc((void **) &e->d_out, (size_t) max_frames * FS * 4));
 	OPENHIP(hipHostMalloc((void **) &e->h_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3, hipHostMallocDefault));
-	OPENHIP(hipHostMalloc((void **) &e->h_frame, frame_px * 4, hipHostMallocDefault));
+	for(int i = 0; i < HVK_UPLOAD_RING; i++)
+	{
+		OPENHIP(hipHostMalloc((void **) &e->h_frame[i], frame_px * 4, hipHostMallocDefault));
+		OPENHIP(hipEventCreateWithFlags(&e->up_ev[i], hipEventDisableTiming));
+	}
 
 	if(e->t.k.has_carriers)
 	{
@@ -509,7 +519,8 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_zeros, e->d_lstate,
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_frame, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
+		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -639,14 +650,18 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	}
 
 	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipStreamSynchronize(e->stream));   /* staging buffer reuse */
+	/* the next staging buffer of the ring; its last copy (HVK_UPLOAD_RING uploads ago) has to be through */
+	const int ub = e->up_next;
+	e->up_next = (e->up_next + 1) % HVK_UPLOAD_RING;
+	if(e->up_busy[ub]) { HIPCHK(hipEventSynchronize(e->up_ev[ub])); e->up_busy[ub] = 0; }
+	uint32_t *const stage = e->h_frame[ub];
 
 	/* gather into a dense w x h image: strides may be negative (flips) */
 	const uint32_t *src = fb + (int64_t) y * line_stride + (int64_t) x * pixel_stride;
 	for(int r = 0; r < h; r++)
 	{
 		const uint32_t *p = src + (int64_t) r * line_stride;
-		uint32_t *o = e->h_frame + (size_t) r * w;
+		uint32_t *o = stage + (size_t) r * w;
 		if(pixel_stride == 1) memcpy(o, p, (size_t) w * 4);
 		else for(int c = 0; c < w; c++) o[c] = p[(int64_t) c * pixel_stride];
 	}
@@ -662,7 +677,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 		int distinct = 0;
 		for(int i = 0; i < SAMPLES && npx > 0; i++)
 		{
-			const uint32_t c = e->h_frame[(size_t) ((uint64_t) i * npx / SAMPLES)] & 0xFFFFFFu;
+			const uint32_t c = stage[(size_t) ((uint64_t) i * npx / SAMPLES)] & 0xFFFFFFu;
 			uint32_t hsh = (c * 2654435761u) >> 19;      /* 13 bits */
 			while(seen[hsh] != EMPTY && seen[hsh] != c) hsh = (hsh + 1) & (SLOTS - 1);
 			if(seen[hsh] == EMPTY) { seen[hsh] = c; distinct++; }
@@ -676,10 +691,12 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 		/* the SECAM pre-pass reads the picture on the host */
 		if(!e->host_frames[slot]) e->host_frames[slot] = (uint32_t *) malloc(frame_px * 4);
 		if(!e->host_frames[slot]) return(HVK_OUT_OF_MEMORY);
-		memcpy(e->host_frames[slot], e->h_frame, (size_t) w * h * 4);
+		memcpy(e->host_frames[slot], stage, (size_t) w * h * 4);
 	}
-	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, e->h_frame, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(hipStreamSynchronize(e->stream));
+	/* on the engine's stream: behind every launch that still reads the slot's old picture, in front of every later one */
+	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, stage, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(hipEventRecord(e->up_ev[ub], e->stream));
+	e->up_busy[ub] = 1;
 	return(HVK_OK);
 }
 
