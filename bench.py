@@ -159,8 +159,11 @@ def main():
         """sha256 of frames [first, first + count) of the unmodified reference CLI's output, run now (None: no binary)."""
         if not os.path.exists(ref_bin):
             return None
+        # a clean environment: under rocprofv3 the child would inherit the profiler's LD_PRELOAD and tool settings
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS", "ROCPROFILER"))}
         p = subprocess.Popen([ref_bin, "-m", MODE, "-s", str(SAMPLE_RATE), "--filter", "-o", "-", "test"],
-                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
         skip, left, h = first * FS * 4, count * FS * 4, hashlib.sha256()
         while skip > 0:
             skip -= len(p.stdout.read(min(skip, 1 << 22)))
