@@ -29,6 +29,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "hvk_internal.h"
 
 #define AUDIO_RATE      32000   /* src/hacktv.h:31 */
@@ -216,27 +219,53 @@ static void _nicam_build_frame(_nicam_t *n)
 	int16_t w[64];
 	int rng[2], x, k, at;
 
-	/* pre-emphasis: the newest sample is written, then the 83 taps sweep
-	 * the ring from the oldest sample (src/nicam728.c:147-162) */
-	for(x = 0; x < 32; x++)
+	/* pre-emphasis: the newest sample is written, then the 83 taps sweep the ring from the oldest sample
+	 * (src/nicam728.c:147-162). Here the history is kept in order, oldest first (n->l / n->r: the last 83
+	 * samples), so output x is the plain dot product of samples x .. x + 82 of history + block with the taps */
 	{
-		int32_t al = 0, ar = 0;
-		int p;
+		static int16_t taps[88];        /* the 83 taps, zero padded to whole vectors */
+		int16_t hl[120], hr[120];
 
-		n->l[n->pos] = n->block[x * 2 + 0];
-		n->r[n->pos] = n->block[x * 2 + 1];
-		n->pos = n->pos == J17_TAPS - 1 ? 0 : n->pos + 1;
+		if(taps[41] == 0) for(k = 0; k < J17_TAPS; k++) taps[k] = _j17[k <= 41 ? k : 82 - k];
 
-		for(k = 0, p = n->pos; k < J17_TAPS; k++)
+		memcpy(hl, n->l + 1, sizeof(int16_t) * (J17_TAPS - 1));
+		memcpy(hr, n->r + 1, sizeof(int16_t) * (J17_TAPS - 1));
+		for(x = 0; x < 32; x++)
 		{
-			int tap = _j17[k <= 41 ? k : 82 - k];
-			al += (int32_t) n->l[p] * tap;
-			ar += (int32_t) n->r[p] * tap;
-			p = p == J17_TAPS - 1 ? 0 : p + 1;
+			hl[J17_TAPS - 1 + x] = n->block[x * 2 + 0];
+			hr[J17_TAPS - 1 + x] = n->block[x * 2 + 1];
+		}
+		memset(hl + J17_TAPS - 1 + 32, 0, sizeof(int16_t) * (120 - (J17_TAPS - 1 + 32)));
+		memset(hr + J17_TAPS - 1 + 32, 0, sizeof(int16_t) * (120 - (J17_TAPS - 1 + 32)));
+
+		for(x = 0; x < 32; x++)
+		{
+			int32_t al = 0, ar = 0;
+#if defined(__SSE2__)
+			__m128i sl = _mm_setzero_si128(), sr = _mm_setzero_si128();
+			int32_t q[4];
+			for(k = 0; k < 88; k += 8)
+			{
+				const __m128i t = _mm_loadu_si128((const __m128i *) (taps + k));
+				sl = _mm_add_epi32(sl, _mm_madd_epi16(_mm_loadu_si128((const __m128i *) (hl + x + k)), t));
+				sr = _mm_add_epi32(sr, _mm_madd_epi16(_mm_loadu_si128((const __m128i *) (hr + x + k)), t));
+			}
+			/* (sums of int32 wrap the same way in any order) */
+			_mm_storeu_si128((__m128i *) q, sl); al = (int32_t) ((uint32_t) q[0] + (uint32_t) q[1] + (uint32_t) q[2] + (uint32_t) q[3]);
+			_mm_storeu_si128((__m128i *) q, sr); ar = (int32_t) ((uint32_t) q[0] + (uint32_t) q[1] + (uint32_t) q[2] + (uint32_t) q[3]);
+#else
+			for(k = 0; k < J17_TAPS; k++)
+			{
+				al += (int32_t) hl[x + k] * taps[k];
+				ar += (int32_t) hr[x + k] * taps[k];
+			}
+#endif
+			w[x * 2 + 0] = (int16_t) (al >> 15);
+			w[x * 2 + 1] = (int16_t) (ar >> 15);
 		}
 
-		w[x * 2 + 0] = (int16_t) (al >> 15);
-		w[x * 2 + 1] = (int16_t) (ar >> 15);
+		memcpy(n->l, hl + 32 - 1, sizeof(int16_t) * J17_TAPS);
+		memcpy(n->r, hr + 32 - 1, sizeof(int16_t) * J17_TAPS);
 	}
 
 	rng[0] = _range_of(w + 0);
@@ -488,6 +517,27 @@ static void _sym_append(hvk_audio_t *a, uint8_t v)
 	a->sym[a->sym_len++] = v;
 }
 
+/* v[i] = (v[i] * level) >> 15 (src/video.c:2263-2264 after the phase's top half has been taken) */
+static void _scale16(int16_t *v, int n, int32_t level)
+{
+	int i = 0;
+#if defined(__SSE2__)
+	if(level >= 0 && level <= INT16_MAX)
+	{
+		const __m128i lv = _mm_set1_epi16((short) level);
+		for(; i + 8 <= n; i += 8)
+		{
+			const __m128i a = _mm_loadu_si128((const __m128i *) (v + i));
+			const __m128i lo = _mm_mullo_epi16(a, lv), hi = _mm_mulhi_epi16(a, lv);
+			const __m128i p0 = _mm_srai_epi32(_mm_unpacklo_epi16(lo, hi), 15);
+			const __m128i p1 = _mm_srai_epi32(_mm_unpackhi_epi16(lo, hi), 15);
+			_mm_storeu_si128((__m128i *) (v + i), _mm_packs_epi32(p0, p1));   /* |product >> 15| < 2^15: nothing saturates */
+		}
+	}
+#endif
+	for(; i < n; i++) v[i] = (int16_t) (((int32_t) v[i] * level) >> 15);
+}
+
 /* Samples [x0, x1) of the current line with the modulating samples in force */
 static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 {
@@ -508,7 +558,11 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 		const hvk_c32_t st = a->t->fm_lut[a->fm.sample - INT16_MIN];
 		const int64_t ci = st.i, cq = st.q;
 		const int32_t level = a->fm.level;
-		int32_t pi = a->fm.pi, pq = a->fm.pq;
+		/* the phase as sign-extended 64-bit values: the reference's (int32_t) cast of the shifted product changes
+		 * nothing while |phase| stays below 2^31 -- always, in practice: a step scales the amplitude by < 1 -- so the
+		 * sign extension comes off the dependent chain (multiply -> subtract -> shift: 5 cycles instead of 6 - 7) and
+		 * a never-taken branch keeps the cast for the case it would matter */
+		int64_t pi = a->fm.pi, pq = a->fm.pq;
 		int32_t counter = a->fm.counter;
 
 		x = x0;
@@ -519,26 +573,35 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 			if(run > counter) run = counter;
 			for(i = 0; i < run; i++)
 			{
-				const int64_t ni = pi * ci - pq * cq;
-				const int64_t nq = pi * cq + pq * ci;
-				pi = (int32_t) (ni >> 31);
-				pq = (int32_t) (nq >> 31);
-				o[i * 2 + 0] = (int16_t) (((pi >> 16) * level) >> 15);
-				o[i * 2 + 1] = (int16_t) (((pq >> 16) * level) >> 15);
+				int64_t ni = (pi * ci - pq * cq) >> 31;
+				int64_t nq = (pi * cq + pq * ci) >> 31;
+				if(__builtin_expect((((uint64_t) ni + 0x80000000ULL) | ((uint64_t) nq + 0x80000000ULL)) >> 32 != 0, 0))
+				{
+					__asm__ volatile("" : "+r" (ni), "+r" (nq));      /* (keeps the compiler from folding the test into the cast) */
+					ni = (int32_t) ni;
+					nq = (int32_t) nq;
+				}
+				pi = ni;
+				pq = nq;
+				/* the top halves now, their scaling by the carrier level below, eight at a time: the recurrence's
+				 * four multiplies are all the one multiplier of a core should see per sample */
+				o[i * 2 + 0] = (int16_t) ((int32_t) pi >> 16);
+				o[i * 2 + 1] = (int16_t) ((int32_t) pq >> 16);
 			}
+			_scale16(o, run * 2, level);
 			x += run;
 			counter -= run;
 			if(counter == 0)
 			{
 				/* amplitude drift correction every INT16_MAX steps (src/video.c:2266-2275) */
-				const double ra = atan2(pq, pi);
+				const double ra = atan2((int32_t) pq, (int32_t) pi);
 				pi = lround(cos(ra) * INT32_MAX);
 				pq = lround(sin(ra) * INT32_MAX);
 				counter = INT16_MAX;
 			}
 		}
-		a->fm.pi = pi;
-		a->fm.pq = pq;
+		a->fm.pi = (int32_t) pi;
+		a->fm.pq = (int32_t) pq;
 		a->fm.counter = counter;
 		return;
 	}

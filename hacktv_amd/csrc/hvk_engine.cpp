@@ -34,6 +34,7 @@
 #define HVK_MAX_FRAME_SLOTS 256
 #define HVK_TIMING_SLOTS 512
 #define HVK_UPLOAD_RING 8
+#define HVK_FETCH_TICKETS 4
 
 extern "C" {
 int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
@@ -123,6 +124,10 @@ struct hvk_engine {
 	hipEvent_t up_ev[HVK_UPLOAD_RING];
 	int up_busy[HVK_UPLOAD_RING];
 	int up_next;
+	hipEvent_t ev_staged;       /* after the last host-to-device copy of a stage: the pinned side buffers are free again */
+	int staged_busy;
+	hipEvent_t fetch_ev[HVK_FETCH_TICKETS];   /* hvk_fetch_async() */
+	int fetch_next;
 
 	hvk_slot_t *slots;          /* [frame_slots] */
 	hvk_packed_taps_t ctaps, itaps, qtaps;
@@ -424,6 +429,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipHostMalloc((void **) &e->h_frame[i], frame_px * 4, hipHostMallocDefault));
 		OPENHIP(hipEventCreateWithFlags(&e->up_ev[i], hipEventDisableTiming));
 	}
+	OPENHIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
+	for(int i = 0; i < HVK_FETCH_TICKETS; i++) OPENHIP(hipEventCreateWithFlags(&e->fetch_ev[i], hipEventDisableTiming));
 
 	if(e->t.k.has_carriers)
 	{
@@ -520,6 +527,8 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
+		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
+		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
@@ -1019,7 +1028,10 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 
 	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipStreamSynchronize(e->stream));   /* pinned staging is reused */
+	/* the pinned side buffers are reused: the copies of the stage before have to be through. (Not the whole stream: a
+	 * read-back queued with hvk_fetch_async() goes on while this stage's host pre-passes run.) */
+	if(k.fm_video) HIPCHK(hipStreamSynchronize(e->stream));
+	else if(e->staged_busy) { HIPCHK(hipEventSynchronize(e->ev_staged)); e->staged_busy = 0; }
 
 	if(k.fm_video)
 	{
@@ -1251,6 +1263,9 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
 	}
 
+	HIPCHK(hipEventRecord(e->ev_staged, e->stream));
+	e->staged_busy = 1;
+
 	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
 	e->staged = nframes;
 	e->staged_first = first_frame;
@@ -1443,6 +1458,48 @@ extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t coun
 	HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
 	return(HVK_OK);
+}
+
+extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_t count)
+{
+	if(!e || !iq) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	HIPCHK(hipSetDevice(e->device));
+	const int t = e->fetch_next;
+	e->fetch_next = (e->fetch_next + 1) % HVK_FETCH_TICKETS;
+	if(e->t.k.fm_video)
+	{
+		/* the FM phasor runs on the host, in this call (see hvk_fetch()) */
+		int r = hvk_fetch(e, iq, first, count);
+		if(r != HVK_OK) return(r);
+	}
+	else HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
+	return(t);
+}
+
+extern "C" int hvk_fetch_wait(hvk_engine_t *e, int ticket)
+{
+	if(!e || ticket < 0 || ticket >= HVK_FETCH_TICKETS) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	HIPCHK(hipEventSynchronize(e->fetch_ev[ticket]));
+	return(HVK_OK);
+}
+
+extern "C" void *hvk_host_alloc(hvk_engine_t *e, size_t bytes)
+{
+	void *p = NULL;
+	if(!e || e->device < 0 || bytes == 0) return(NULL);
+	if(hipSetDevice(e->device) != hipSuccess) return(NULL);
+	if(hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return(NULL);
+	return(p);
+}
+
+extern "C" void hvk_host_free(hvk_engine_t *e, void *p)
+{
+	(void) e;
+	if(p) (void) hipHostFree(p);
 }
 
 extern "C" long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t count, int type, int complex_out)

@@ -50,6 +50,7 @@
 #include <string.h>
 #include <strings.h>
 #include <pthread.h>
+#include <time.h>
 #include "video.h"          /* the reference's */
 #include "hacktv_amd.h"
 #include "hvk_shim_depth.h"
@@ -65,6 +66,12 @@ typedef struct {
 	int have;               /* frames rendered in iq */
 	/* the next batch is pulled, rendered and fetched by a worker thread while this one goes out */
 	int16_t *buf[2];
+	int pinned;             /* buf[] came from hvk_host_alloc() */
+	int ticket[2];          /* hvk_fetch_async() ticket of the buffer's read-back; the consumer waits for it */
+	/* HVK_SHIM_STATS=1: where the time of both threads went, printed by vid_free() */
+	int stats;
+	double t_first;
+	double t_pull, t_audio, t_render, t_fetch, t_worker_idle, t_consumer_wait;
 	int ready[2];           /* 0: free for the worker, 1: filled */
 	int count[2];           /* frames in the buffer; 0: the source has ended, < 0: failure */
 	int cur;                /* buffer being handed out, -1: none yet */
@@ -101,6 +108,13 @@ typedef struct {
 	int16_t aud_out[SHIM_AUDIO_BLOCK * 2];
 	vid_line_t out;
 } shim_t;
+
+static double _now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return(ts.tv_sec + ts.tv_nsec * 1e-9);
+}
 
 /* keep what av_read_audio() delivered, scaled like src/video.c:3293-3298 (worker side) */
 static int _aud_append(shim_t *m, const int16_t *a, size_t pairs)
@@ -286,16 +300,33 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	m->out_pos = m->info.startup_samples;
 	m->volume = conf->volume;
 
-	m->buf[0] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
-	m->buf[1] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+	/* the read-back buffers: page-locked, so that the copy runs at PCIe speed and beside the next batch's host work
+	 * (HVK_SHIM_PAGEABLE=1: plain malloc, for comparison) */
+	m->stats = getenv("HVK_SHIM_STATS") != NULL;
+	if(!getenv("HVK_SHIM_PAGEABLE"))
+	{
+		m->buf[0] = hvk_host_alloc(m->e, sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+		m->buf[1] = hvk_host_alloc(m->e, sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+		m->pinned = m->buf[0] && m->buf[1];
+		if(!m->pinned)
+		{
+			hvk_host_free(m->e, m->buf[0]);
+			hvk_host_free(m->e, m->buf[1]);
+		}
+	}
+	if(!m->pinned)
+	{
+		m->buf[0] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+		m->buf[1] = malloc(sizeof(int16_t) * 2 * (size_t) m->info.frame_samples * m->batch);
+	}
 	m->widths = malloc(sizeof(int32_t) * m->info.lines);
 	m->cur = -1;
 	pthread_mutex_init(&m->lock, NULL);
 	pthread_cond_init(&m->cond, NULL);
 	if(!m->buf[0] || !m->buf[1] || !m->widths)
 	{
-		free(m->buf[0]);
-		free(m->buf[1]);
+		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
+		else { free(m->buf[0]); free(m->buf[1]); }
 		free(m->widths);
 		hvk_close(m->e);
 		free(m);
@@ -380,9 +411,18 @@ void vid_free(vid_t *s)
 
 	if(m)
 	{
+		if(m->stats)
+		{
+			const double el = _now() - m->t_first;
+			fprintf(stderr, "hacktv-amd: %lld frames in %.3f s from the first line on = %.1f Msamples/s\n", (long long) m->frames_done, el,
+				el > 0 ? m->frames_done * (double) m->info.frame_samples / el * 1e-6 : 0.0);
+			fprintf(stderr, "hacktv-amd: worker: source pulls + picture uploads %.3f s, audio pulls %.3f s, stage + launch %.3f s, read-back queueing %.3f s, waiting for a free buffer %.3f s; consumer: waiting for a batch %.3f s (%lld frames)\n",
+				m->t_pull, m->t_audio, m->t_render, m->t_fetch, m->t_worker_idle, m->t_consumer_wait, (long long) m->frames_done);
+		}
+		hvk_sync(m->e);         /* a read-back the consumer never waited for */
+		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
+		else { free(m->buf[0]); free(m->buf[1]); }
 		hvk_close(m->e);
-		free(m->buf[0]);
-		free(m->buf[1]);
 		pthread_mutex_destroy(&m->lock);
 		pthread_cond_destroy(&m->cond);
 		free(m->widths);
@@ -411,8 +451,9 @@ size_t vid_get_framebuffer_length(vid_t *s)
 }
 
 /* Pull up to `batch` frames and the audio they need from the source, render them into iq */
-static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
+static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 {
+	double t0 = m->stats ? _now() : 0, t1;
 	int32_t slots[512];
 	const int fields = (s->conf.interlace && s->conf.interlaced) ? 2 : 1;
 	int n = 0;
@@ -491,6 +532,8 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 		m->frames_pulled++;
 		n++;
 
+		if(m->stats) { t1 = _now(); m->t_pull += t1 - t0; t0 = t1; }
+
 		/* 32 kHz audio for this frame (src/video.c:3278-3286), pulled frame by frame so that the end
 		 * of the sound is seen by the same av_eof() as in the reference; a source that runs dry
 		 * leaves silence (src/video.c:3299-3304) */
@@ -523,6 +566,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 				if(_aud_append(m, a, an) != 0) return(-1);
 			}
 		}
+		if(m->stats) { t1 = _now(); m->t_audio += t1 - t0; t0 = t1; }
 	}
 
 	/* a full batch that used up the source is the last one too */
@@ -580,8 +624,14 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq)
 		if(hvk_passthru_write(m->e, m->passbuf, got) != HVK_OK) return(-1);
 	}
 
+	if(m->stats) t0 = _now();
 	if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);
-	if(hvk_fetch(m->e, iq, 0, (size_t) n * m->info.frame_samples) != HVK_OK) return(-1);
+	if(m->stats) { t1 = _now(); m->t_render += t1 - t0; t0 = t1; }
+	/* the read-back is queued behind the render; the consumer waits for it (vid_next_line) while this thread goes
+	 * on with the next batch's pulls and host pre-passes */
+	*ticket = hvk_fetch_async(m->e, iq, 0, (size_t) n * m->info.frame_samples);
+	if(*ticket < 0) return(-1);
+	if(m->stats) { t1 = _now(); m->t_fetch += t1 - t0; }
 
 	return(n);
 }
@@ -598,16 +648,21 @@ static void *_worker(void *arg)
 	{
 		int n;
 
+		int ticket = -1;
+		double t0 = m->stats ? _now() : 0;
+
 		pthread_mutex_lock(&m->lock);
 		while(m->ready[b] && !m->stop) pthread_cond_wait(&m->cond, &m->lock);
 		if(m->stop) { pthread_mutex_unlock(&m->lock); break; }
 		pthread_mutex_unlock(&m->lock);
+		if(m->stats) m->t_worker_idle += _now() - t0;
 
-		n = m->ended ? 0 : _next_batch(s, m, m->buf[b]);
+		n = m->ended ? 0 : _next_batch(s, m, m->buf[b], &ticket);
 
 		pthread_mutex_lock(&m->lock);
 		m->last[b] = m->ended;
 		m->count[b] = n;
+		m->ticket[b] = ticket;
 		m->ready[b] = 1;
 		pthread_cond_broadcast(&m->cond);
 		pthread_mutex_unlock(&m->lock);
@@ -635,16 +690,22 @@ vid_line_t *vid_next_line(vid_t *s)
 			/* started on the first line, once main() has filled in s->av (src/hacktv.c:1493) */
 			if(pthread_create(&m->worker, NULL, _worker, s) != 0) return(NULL);
 			m->worker_on = 1;
+			m->t_first = _now();
 		}
 
-		/* hand the finished buffer back, wait for the next one */
+		/* hand the finished buffer back, wait for the next one and for its read-back */
+		double t0 = m->stats ? _now() : 0;
+		int ticket;
 		pthread_mutex_lock(&m->lock);
 		if(m->cur >= 0) { m->ready[m->cur] = 0; pthread_cond_broadcast(&m->cond); }
 		while(!m->ready[nb]) pthread_cond_wait(&m->cond, &m->lock);
 		n = m->count[nb];
+		ticket = m->ticket[nb];
 		pthread_mutex_unlock(&m->lock);
 
 		if(n <= 0) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
+		if(hvk_fetch_wait(m->e, ticket) != HVK_OK) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
+		if(m->stats) m->t_consumer_wait += _now() - t0;
 		m->cur = nb;
 		m->iq = m->buf[nb];
 		m->have = n;

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from .ctypes_defs import HvkConfig, HvkInfo
+from .ctypes_defs import HvkConfig, HvkInfo, HVK_OUT_OF_MEMORY
 
 # HVK_LIB: another build of the library (tools/ablate.py uses one with the profiling switches compiled in)
 LIB_PATH = os.environ.get("HVK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhvk.so")
@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_as", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -82,6 +82,12 @@ def lib():
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.hvk_fetch_async.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.hvk_fetch_wait.argtypes = [vp, i32]
+        L.hvk_host_alloc.argtypes = [vp, C.c_size_t]
+        L.hvk_host_alloc.restype = vp
+        L.hvk_host_free.argtypes = [vp, vp]
+        L.hvk_host_free.restype = None
         L.hvk_fetch_as.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, i32]
         L.hvk_fetch_as.restype = C.c_long
         L.hvk_output_device_ptr.argtypes = [vp]
@@ -115,6 +121,7 @@ class Engine:
         if r != 0:
             self.h = None
             raise HvkError("hvk_open", r)
+        self._host_bufs = []
         info = HvkInfo()
         lib().hvk_get_info(self.h, C.byref(info))
         self.info = info.as_dict()
@@ -127,6 +134,9 @@ class Engine:
 
     def close(self):
         if self.h:
+            for p in self._host_bufs:
+                lib().hvk_host_free(self.h, p)
+            self._host_bufs = []
             lib().hvk_close(self.h)
             self.h = None
 
@@ -249,6 +259,22 @@ class Engine:
         out = np.zeros((count, 2), np.int16)
         self._chk("hvk_fetch", lib().hvk_fetch(self.h, out.ctypes.data, first, count))
         return out
+
+    def host_buffer(self, count):
+        """(count, 2) int16 array over page-locked memory (hvk_host_alloc); released with the engine's close()."""
+        p = lib().hvk_host_alloc(self.h, count * 4)
+        if not p:
+            raise HvkError("hvk_host_alloc", HVK_OUT_OF_MEMORY)
+        self._host_bufs.append(p)
+        return np.ctypeslib.as_array((C.c_int16 * (count * 2)).from_address(p)).reshape(count, 2)
+
+    def fetch_async(self, out, first, count):
+        """Queue the read-back of samples [first, first + count) into `out` (an int16 array, best from host_buffer());
+        returns the ticket for fetch_wait()."""
+        return self._chk("hvk_fetch_async", lib().hvk_fetch_async(self.h, out.ctypes.data, first, count))
+
+    def fetch_wait(self, ticket):
+        return self._chk("hvk_fetch_wait", lib().hvk_fetch_wait(self.h, ticket))
 
     FILE_TYPES = {"uint8": (0, np.uint8), "int8": (1, np.int8), "uint16": (2, np.uint16),
                   "int16": (3, np.int16), "int32": (4, np.int32), "float": (5, np.float32)}

@@ -279,6 +279,19 @@ int hvk_sync(hvk_engine_t *e);
  * never fetched are modulated when the next batch is staged. */
 int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
 
+/* hvk_fetch() without the wait: the copy is queued behind the render and the call returns a ticket (0 .. 3, reused in
+ * turn; negative: an HVK_* code); iq may be read once hvk_fetch_wait() has returned for that ticket. With iq in page-locked
+ * memory (hvk_host_alloc()) the copy runs at PCIe speed beside the host pre-passes of the next hvk_stage() -- how the
+ * shim keeps the reference's serial sound chain (src/video.c:2249-2289, the slowest stage of the drop-in) busy all the
+ * time. hvk_fetch_wait() may be called from another thread than the one that renders. */
+int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
+int hvk_fetch_wait(hvk_engine_t *e, int ticket);
+
+/* Page-locked host memory for hvk_fetch() / hvk_fetch_async() targets (a pageable target is copied through the runtime's
+ * bounce buffers at a fraction of the PCIe rate). NULL: no device or out of memory. */
+void *hvk_host_alloc(hvk_engine_t *e, size_t bytes);
+void hvk_host_free(hvk_engine_t *e, void *p);
+
 /* Sample formats of the reference's file sink (src/rf.h:31-36) */
 #define HVK_UINT8  0
 #define HVK_INT8   1

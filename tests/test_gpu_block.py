@@ -146,3 +146,35 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
     assert d["n_gpus"] == 2
     assert d["multi_gpu"]["seam_gate"] and "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
     assert "sha256 ==" in d["parity_gate"]
+
+
+def test_queued_read_back_into_page_locked_memory(golden):
+    """hvk_fetch_async() / hvk_fetch_wait() / hvk_host_alloc(): batches read back behind the next batch's staging
+    are the same samples hvk_fetch() hands over, and the reference's."""
+    FS = 640000
+    c = H.preset("i", H.FLAG_FILTER)
+    with H.Engine(c, 16000000, max_frames=3) as e, H.Engine(c, 16000000, max_frames=3) as plain:
+        bufs = [e.host_buffer(3 * FS), e.host_buffer(3 * FS)]
+        for eng in (e, plain):
+            eng.frame_upload(0, golden.frame("i_full"))
+        tickets, got, want = [None, None], [], []
+        for b in range(4):
+            for eng in (e, plain):
+                while eng.audio_needed(3 * (b + 1)) > 0:
+                    eng.audio_write(golden.audio)
+            if tickets[b & 1] is not None:
+                e.fetch_wait(tickets[b & 1])
+                got.append(bufs[b & 1].copy())
+            e.stage(3 * b, 1, 3)                 # host pre-passes of batch b while batch b - 1 is still on its way
+            e.launch()
+            tickets[b & 1] = e.fetch_async(bufs[b & 1], 0, 3 * FS)
+            plain.render(3)
+            want.append(plain.fetch(0, 3 * FS))
+        for b in (2, 3):
+            e.fetch_wait(tickets[b & 1])
+            got.append(bufs[b & 1].copy())
+        for b in range(4):
+            assert np.array_equal(got[b], want[b]), "batch %d" % b
+        # and the reference's first frame (committed digest of the reference CLI's output)
+        assert hashlib.sha256(got[0][:FS].tobytes()).hexdigest() == LONG["i_full"]["sha256_at_frames"]["1"]
+    assert e.h is None
