@@ -57,6 +57,15 @@ struct hvk_engine {
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
+	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
+	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
+	hvk_secam_args_t sa;
+	void *d_secam[10];          /* what sa points into (freed at close) */
+	int *h_secam_count;         /* pinned: failures of the last check */
+	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
+	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
+	int64_t secam_counts[4];
+	int32_t *staged_slots2;     /* [max_frames] the slot of the second field's picture */
 	uint32_t *h_tt_pk;          /* teletext packets queued for the next batch: [max_frames][32][12] */
 	uint32_t *h_tt_mask;        /* [max_frames] rows present */
 	/* VBI data lines (teletext, WSS, VITC): symbol store, per-frame op list and line map */
@@ -241,7 +250,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	e->slots = (hvk_slot_t *) calloc(e->frame_slots, sizeof(hvk_slot_t));
 	e->staged_slots = (int32_t *) calloc(max_frames, sizeof(int32_t));
-	if(!e->slots || !e->staged_slots) { free(e->slots); free(e->staged_slots); free(e); return(HVK_OUT_OF_MEMORY); }
+	e->staged_slots2 = (int32_t *) calloc(max_frames, sizeof(int32_t));
+	if(!e->slots || !e->staged_slots || !e->staged_slots2) { free(e->slots); free(e->staged_slots); free(e->staged_slots2); free(e); return(HVK_OUT_OF_MEMORY); }
 
 	if((r = hvk_tables_build(&e->t, conf, sample_rate, pixel_rate)) != HVK_OK) { hvk_close(e); return(r); }
 
@@ -488,6 +498,77 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * RS * 2));
 		OPENHIP(hipMemset(e->d_chroma, 0, (size_t) max_frames * RS * 2));
 		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * RS * 2, hipHostMallocDefault));
+
+		/* the device's own chain (HVK_SECAM_HOST=1: everything through the host's, as before). It needs whole
+		 * 8-sample chunks, the FM loop's overhang within the low pass's reach, and no picture that close to the
+		 * line's start */
+		const int n0 = hvk_secam_tasks(&e->t, 0, NULL, 0), n1 = hvk_secam_tasks(&e->t, 1, NULL, 0);
+		const int over = k.burst_left + k.burst_width - k.width;
+		if(!getenv("HVK_SECAM_HOST") && k.width % 8 == 0 && k.width <= 2048 && over <= HVK_SECAM_TAIL && k.active_left >= 8 && n0 > 0 && n1 > 0)
+		{
+			hvk_secam_args_t &a = e->sa;
+			memset(&a, 0, sizeof(a));
+			a.C.W = k.width;
+			a.C.sl = k.burst_left;
+			a.C.level = e->t.secam_level;
+			for(int i = 0; i < 2; i++) { a.C.dmin[i] = e->t.secam_dmin[i]; a.C.dmax[i] = e->t.secam_dmax[i]; }
+			for(int i = 0; i < 15; i++) a.C.fir[i] = e->t.secam_fir[i];
+			a.lines = k.lines; a.hline = e->t.conf.hline; a.fields = k.fields; a.interlaced = k.interlaced;
+			a.active_left = k.active_left; a.active_width = k.active_width; a.active_lines = k.active_lines;
+			a.burst_left = k.burst_left; a.burst_width = k.burst_width;
+			a.ntasks = 2 + (n0 > n1 ? n0 : n1);
+			a.tpad = (max_frames * a.ntasks + 63) & ~63;
+			a.K = HVK_SECAM_WARMUP;
+			if(getenv("HVK_SECAM_WARMUP")) a.K = atoi(getenv("HVK_SECAM_WARMUP"));
+			if(a.K < 0) a.K = 0;
+			a.raster_samples = (int64_t) RS;
+
+			std::vector<hvk_secam_task_t> tasks((size_t) 2 * a.ntasks);
+			memset(tasks.data(), 0, tasks.size() * sizeof(hvk_secam_task_t));
+			hvk_secam_tasks(&e->t, 0, tasks.data() + 2, n0);
+			hvk_secam_tasks(&e->t, 1, tasks.data() + a.ntasks + 2, n1);
+			std::vector<int16_t> fid((size_t) 2 * k.width);
+			{
+				/* rest values of RGB 000000: the level table's first entry, computed like the table (hvk_secam.c) */
+				std::vector<int16_t> q(4);
+				if(hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(q.data(), e->d_yuv, 8, hipMemcpyDeviceToHost) != hipSuccess) { hvk_close(e); return(HVK_ERROR); }
+				hvk_secam_fid_row(&e->t, 0, q[1], fid.data());
+				hvk_secam_fid_row(&e->t, 1, q[2], fid.data() + k.width);
+			}
+			OPENCHK(_upload(&e->d_secam[0], tasks.data(), tasks.size() * sizeof(hvk_secam_task_t)));
+			OPENCHK(_upload(&e->d_secam[1], fid.data(), fid.size() * 2));
+			OPENCHK(_upload(&e->d_secam[2], e->t.secam_lut, 65536 * sizeof(hvk_c32_t)));
+			OPENCHK(_upload(&e->d_secam[3], e->t.secam_bell, 65536 * sizeof(hvk_c16_t)));
+			OPENHIP(hipMalloc(&e->d_secam[4], (size_t) a.tpad * k.width * 2));
+			OPENHIP(hipMalloc(&e->d_secam[5], (size_t) a.tpad * 32));
+			OPENHIP(hipMalloc(&e->d_secam[6], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
+			OPENHIP(hipMalloc(&e->d_secam[7], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
+			OPENHIP(hipMalloc(&e->d_secam[8], sizeof(hvk_secam_state_t) + 64));
+			OPENHIP(hipMalloc(&e->d_secam[9], (size_t) a.tpad * 4 + 64));
+			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.tpad * k.width * 2));
+			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.tpad * 32));
+			OPENHIP(hipMemset(e->d_secam[8], 0, sizeof(hvk_secam_state_t) + 64));
+			OPENHIP(hipHostMalloc((void **) &e->h_secam_count, 64, hipHostMallocDefault));
+			OPENHIP(hipHostMalloc((void **) &e->h_secam_carry, sizeof(hvk_secam_state_t), hipHostMallocDefault));
+			memset(e->h_secam_carry, 0, sizeof(hvk_secam_state_t));
+			a.tasks = (const hvk_secam_task_t *) e->d_secam[0];
+			a.fid_rows = (const int16_t *) e->d_secam[1];
+			a.lut = (const hvk_secam_c32_t *) e->d_secam[2];
+			a.bell = (const hvk_secam_c16_t *) e->d_secam[3];
+			a.F = (int16_t *) e->d_secam[4];
+			a.acc = (int32_t *) e->d_secam[5];
+			a.entry = (hvk_secam_state_t *) e->d_secam[6];
+			a.exit = (hvk_secam_state_t *) e->d_secam[7];
+			a.carry = (hvk_secam_state_t *) e->d_secam[8];
+			a.flags = (int *) e->d_secam[9];
+			a.count = a.flags + a.tpad;
+			a.desc = (const hvk_linedesc_t *) e->d_desc;
+			a.pool = e->d_pool;
+			a.yuv = e->d_yuv;
+			a.burst_win = (const int16_t *) e->d_burst + HVK_PULSE_PAD;
+			a.chroma = e->d_chroma;
+			e->secam_dev = 1;
+		}
 	}
 
 	if(e->t.k.fm_video)
@@ -527,6 +608,9 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
+		for(void *p : e->d_secam) if(p) (void) hipFree(p);
+		if(e->h_secam_count) (void) hipHostFree(e->h_secam_count);
+		if(e->h_secam_carry) (void) hipHostFree(e->h_secam_carry);
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
@@ -543,6 +627,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	hvk_tail_free(e->tail);
 	free(e->slots);
 	free(e->staged_slots);
+	free(e->staged_slots2);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
 	free(e);
@@ -813,6 +898,16 @@ extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int wi
 	return(r);
 }
 
+extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
+{
+	if(!e || !counts) return(HVK_ERROR);
+	if(!e->secam) return(HVK_UNSUPPORTED);
+	hvk_secam_counters(e->secam, &counts[0], &counts[1], &counts[2]);
+	counts[3] = 0;
+	if(e->secam_dev) for(int i = 0; i < 4; i++) counts[i] = e->secam_counts[i];
+	return(HVK_OK);
+}
+
 /* ---- render ---- */
 
 /* The VBI data lines of the staged frames (h_fdesc holds their stream frame numbers): per
@@ -1008,6 +1103,61 @@ extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int6
 	return(_stage(e, first_frame, stride, nframes, slots, prev_slots));
 }
 
+/* SECAM: the sub-carrier of the staged frames on the device (hvk_secam.hip) -- every line at once from derived entry
+ * states, then check / redo rounds until every line started from the state the line before it left. The frame
+ * descriptors and pictures are on their way to the device (same stream). */
+static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
+{
+	const hvk_kconst_t &k = e->t.k;
+	hvk_secam_args_t &a = e->sa;
+	int r, rounds = 0;
+
+	a.nframes = nframes;
+	a.total = nframes * a.ntasks;
+	a.first_frame = first_frame;
+	a.fdesc = e->d_fdesc;
+	e->secam_start = *e->h_secam_carry;
+
+	HIPCHK(hipMemsetAsync(e->d_chroma, 0, (size_t) nframes * k.raster_samples * 2, e->stream));
+	if((r = hvk_launch_secam_cells_chain(&a, e->stream)) != HVK_OK) return(r);
+	e->secam_counts[0] += a.total;
+
+	for(;;)
+	{
+		if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
+		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipStreamSynchronize(e->stream));
+		const int bad = *e->h_secam_count;
+		if(bad == 0) break;
+		if(rounds == 0) e->secam_counts[1] += bad;
+		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
+		{
+			/* the host's chain takes the batch over from the state it began with */
+			hvk_secam_set_state(e->secam, &e->secam_start, first_frame);
+			for(int i = 0; i < nframes; i++)
+			{
+				const int slot = e->staged_slots[i], slot2 = e->staged_slots2[i];
+				const hvk_slot_t *s = &e->slots[slot], *s2 = &e->slots[slot2];
+				r = hvk_secam_frame(e->secam, first_frame + i, s->valid ? e->host_frames[slot] : NULL, s->valid ? s->width : 0, s->valid ? s->height : 0, s->interlaced,
+				                    s2->valid ? e->host_frames[slot2] : NULL, s2->valid ? s2->width : 0, s2->valid ? s2->height : 0, s2->interlaced,
+				                    e->h_chroma + (size_t) i * k.raster_samples);
+				if(r != HVK_OK) return(r);
+			}
+			hvk_secam_get_state(e->secam, e->h_secam_carry, NULL);
+			HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
+			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
+			e->secam_counts[3] += nframes;
+			return(HVK_OK);
+		}
+		e->secam_counts[2] += bad;
+		if((r = hvk_launch_secam_redo(&a, e->stream)) != HVK_OK) return(r);
+	}
+
+	if((r = hvk_launch_secam_carry(&a, e->stream)) != HVK_OK) return(r);
+	HIPCHK(hipMemcpyAsync(e->h_secam_carry, a.carry, sizeof(hvk_secam_state_t), hipMemcpyDeviceToHost, e->stream));
+	return(HVK_OK);
+}
+
 static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
 {
 	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
@@ -1072,6 +1222,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(slot < 0 || slot >= e->frame_slots || slot2 < 0 || slot2 >= e->frame_slots) return(HVK_ERROR);
 		const hvk_slot_t *s = &e->slots[slot];
 		e->staged_slots[i] = slot;
+		e->staged_slots2[i] = slot2;
 
 		for(int fld = 0; fld < fields; fld++)
 		{
@@ -1095,7 +1246,8 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
 		}
 
-		if(e->secam)
+		if(e->secam && e->secam_dev) e->secam_next++;
+		else if(e->secam)
 		{
 			const hvk_slot_t *s2 = &e->slots[slot2];
 			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
@@ -1254,7 +1406,12 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			e->raw_base += drop;
 		}
 	}
-	if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
+	if(e->secam_dev)
+	{
+		int r = _secam_on_device(e, first_frame, nframes);
+		if(r != HVK_OK) { e->poisoned = 1; return(r); }
+	}
+	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_pass) HIPCHK(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));

@@ -195,9 +195,16 @@ int hvk_acp_agc_level(const hvk_tables_t *t, int frame);
 void hvk_cc608_bits(uint8_t c1, uint8_t c2, uint8_t data[3]);
 
 /* Host SECAM colour pre-pass (hvk_secam.c) */
+#include "hvk_secam_chain.h"
 typedef struct hvk_secam hvk_secam_t;
 hvk_secam_t *hvk_secam_new(const hvk_tables_t *t);
 void hvk_secam_free(hvk_secam_t *s);
+/* the lines of a frame of this parity the process works on (out NULL: just the count) */
+int hvk_secam_tasks(const hvk_tables_t *t, int parity, hvk_secam_task_t *out, int max);
+void hvk_secam_fid_row(const hvk_tables_t *t, int dr, int16_t level, int16_t *row);
+void hvk_secam_counters(const hvk_secam_t *s, int64_t *tasks, int64_t *mismatches, int64_t *repaired);
+void hvk_secam_get_state(const hvk_secam_t *s, hvk_secam_state_t *st, int64_t *next_frame);
+void hvk_secam_set_state(hvk_secam_t *s, const hvk_secam_state_t *st, int64_t next_frame);
 /* fb2 .. : the frame the second field shows (--interlace); pass the first field's again otherwise */
 int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb, int fb_width, int fb_height,
                     int fb_interlaced, const uint32_t *fb2, int fb2_width, int fb2_height, int fb2_interlaced, int16_t *out);

@@ -66,10 +66,44 @@ typedef struct {
 	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */
 } hvk_filter_args_t;
 
+/* SECAM colour sub-carrier on the device (hvk_secam.hip) */
+#define HVK_SECAM_WARMUP 12     /* lines walked before a task's own to find its entry state */
+#define HVK_SECAM_ROUNDS 16     /* check / redo rounds before the batch goes through the host's chain */
+typedef struct {
+	hvk_secam_consts_t C;
+	int lines, hline, fields, interlaced, active_left, active_width, active_lines, burst_left, burst_width;
+	int ntasks;                 /* task slots per frame: the two fill slots, then the longer of the two parities' lists */
+	int nframes, total;         /* frames of the batch, nframes * ntasks */
+	int tpad;                   /* tasks the transposed stores are laid out for (>= total) */
+	int K;
+	int64_t first_frame;
+	int64_t raster_samples;
+	const hvk_secam_task_t *tasks;      /* [2][ntasks] */
+	const hvk_linedesc_t *desc;
+	const hvk_framedesc_t *fdesc;
+	const uint32_t *pool;
+	const void *yuv;
+	const int16_t *fid_rows;    /* [2][W] */
+	const hvk_secam_c32_t *lut;
+	const hvk_secam_c16_t *bell;
+	const int16_t *burst_win;
+	int16_t *F;                 /* [W / 8][tpad][8] */
+	int32_t *acc;               /* [tpad][8] */
+	hvk_secam_state_t *entry, *exit;    /* [tpad] */
+	hvk_secam_state_t *carry;   /* the state the batch starts from; after hvk_launch_secam_carry(): the next batch's */
+	int *flags;                 /* [tpad] */
+	int *count;
+	int16_t *chroma;            /* [nframes][raster_samples] */
+} hvk_secam_args_t;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
+int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream_t stream);
+int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream);
+int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream);
+int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);

@@ -1,0 +1,376 @@
+/* hvk_secam.hip -- the SECAM colour sub-carrier on the device (gfx950).
+ *
+ * The reference computes it line after line (src/video.c:3068-3233): what a line leaves behind -- the pre-emphasis
+ * IIR's two doubles and the values behind the line's end, hvk_secam_state_t -- is the next line's start, for ever.
+ * The arithmetic of a line is hvk_secam_chain.h, the same source the host's serial chain compiles (hvk_secam.c,
+ * pinned against the reference on the CPU). Here the lines of a batch ("tasks": hvk_secam_tasks()) are worked on
+ * all at once:
+ *
+ *   hvk_k_secam_cells   one workgroup per task, 8 samples per lane: the line's colour-difference cells (its own
+ *                       pixels and the line above's through the level table) and the 15-tap low pass, without the
+ *                       share of what lies behind the line; written transposed, 8 samples of one task per 16 bytes,
+ *                       tasks side by side, so that a wave of the next kernel reads its 64 lines with one load
+ *   hvk_k_secam_chain   one LANE per task: the serial walk over the line (IIR, FM phasor) -- after K warm-up lines,
+ *                       the K tasks before it walked from a state of nothing, which leaves the lane with the state
+ *                       its own line starts from in all but a few cases per ten thousand (the influence of a
+ *                       line's start state on its end state shrinks by a factor of ~3 per line; K = 12). Tasks
+ *                       whose warm-up reaches back to the batch's first task start from the true state carried
+ *                       over from the batch before. Every lane records the state it assumed and the state it left
+ *   hvk_k_secam_check   entry state of task t == exit state of task t - 1, bit for bit? By induction from the
+ *                       carried state every task that passes is exact
+ *   hvk_k_secam_redo    the tasks that failed walk their line again from the exit state of the task before; then
+ *                       the check again, until nothing fails (a run of r wrong tasks takes r rounds; the engine gives
+ *                       up after HVK_SECAM_ROUNDS and sends the batch through the host's chain)
+ *
+ * Doubles: the IIR is evaluated term by term with contraction off (this file is compiled with -ffp-contract=off),
+ * like the reference's x86-64 build. */
+#include <hip/hip_runtime.h>
+#include "hvk_kernels.h"
+#include "hvk_secam_chain.h"
+
+#define SPL 8
+
+typedef struct { short x, y, z, w; } lvl_t;    /* a level-table entry: (Y, U, V, -) */
+
+/* task t of the batch -> its record; NULL state of affairs (a padding slot, the priming slots of any frame but the
+ * stream's first) comes back as valid = false */
+struct task_view {
+	bool valid, clear, fid;
+	int frame;          /* frame of the batch */
+	int64_t fnum;       /* frame number counted from 1 */
+	int line, prev_line, sr, dr, phase_pos;
+};
+
+__device__ __forceinline__ task_view task_of(const hvk_secam_args_t &a, const int t)
+{
+	task_view v;
+	const int i = t / a.ntasks, slot = t - i * a.ntasks;
+	const int64_t findex = a.first_frame + i;
+	const int parity = (int) ((findex + 1) & 1);
+	const hvk_secam_task_t q = a.tasks[parity * a.ntasks + slot];
+	v.frame = i;
+	v.fnum = findex + 1;
+	v.valid = (q.flags & HVK_SECAM_TASK_VALID) != 0;
+	if(slot < 2)
+	{
+		/* the pipeline's two fill slots before the stream's first line (hvk_secam.c): frame 1, line 0, no picture */
+		v.valid = findex == 0;
+		v.line = 0;
+		v.prev_line = 0;
+		v.sr = a.burst_left + a.burst_width;
+		v.clear = false;
+		v.fid = false;
+	}
+	else
+	{
+		v.line = q.line;
+		v.prev_line = q.prev_line;
+		v.sr = q.sr;
+		v.clear = (q.flags & HVK_SECAM_TASK_CLEAR) != 0;
+		v.fid = (q.flags & HVK_SECAM_TASK_FID) != 0;
+	}
+	{
+		/* (frame * lines + line) as the reference's int */
+		const int n = (int) v.fnum * a.lines + v.line;
+		v.dr = n & 1;
+		v.phase_pos = n % 3 == 0;
+	}
+	return(v);
+}
+
+/* ------------------------------------------------------------------ */
+
+__global__ __launch_bounds__(256)
+void hvk_k_secam_cells(const hvk_secam_args_t a)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 8 zeros */
+	const int W = a.C.W;
+	const int slot = blockIdx.x, i = blockIdx.y;
+	const int t = i * a.ntasks + slot;
+	const task_view v = task_of(a, t);
+	const int lane = threadIdx.x, x0 = lane * SPL;
+
+	if(!v.valid) return;
+
+	int16_t c[SPL];
+
+	if(v.fid)
+	{
+		for(int j = 0; j < SPL; j++) c[j] = x0 + j < W ? a.fid_rows[v.dr * W + x0 + j] : 0;
+	}
+	else
+	{
+		const lvl_t *yuv = (const lvl_t *) a.yuv;
+		const int comp = v.dr ? 1 : 0;
+		int pcomp, have_prev;
+		bool prime = slot < 2;
+		/* geometry of the field's frame: like the raster's (hvk_device.h raster_setup_core) */
+		const int second = a.fields == 2 && v.line >= a.hline;
+		const hvk_framedesc_t f = a.fdesc[i * (a.fields + 1) + 1 + (second ? 1 : 0)];
+		int fbw = prime ? a.active_width : (f.fb_valid ? f.fb_width : 0);
+		int p0 = a.active_left + (prime ? 0 : (a.active_width - fbw) / 2);
+		int64_t row = -1, prow = -1;
+
+		if(prime)
+		{
+			have_prev = slot == 1;
+			pcomp = v.dr ? 0 : 1;       /* the first fill slot's OTHER component */
+		}
+		else
+		{
+			const int fbh = f.fb_valid ? f.fb_height : 0;
+			const int vframe_y = (a.active_lines - fbh) / 2;
+			const int parity = (int) (v.fnum & 1);
+			int vy = a.desc[parity * a.lines + v.line - 1].src_row;
+			if(vy >= 0 && a.interlaced != 0 && f.fb_interlaced != a.interlaced) vy += 1;
+			vy -= vframe_y;
+			if(f.fb_valid && vy >= 0 && vy < fbh) row = f.fb_offset + (int64_t) vy * f.line_stride;
+			have_prev = v.prev_line != 0;
+			{
+				const int pn = (int) v.fnum * a.lines + v.prev_line;
+				pcomp = (pn & 1) ? 0 : 1;
+			}
+			if(have_prev)
+			{
+				int py = a.desc[parity * a.lines + v.prev_line - 1].src_row;
+				if(py >= 0 && a.interlaced != 0 && f.fb_interlaced != a.interlaced) py += 1;
+				py -= vframe_y;
+				if(f.fb_valid && py >= 0 && py < fbh) prow = f.fb_offset + (int64_t) py * f.line_stride;
+			}
+		}
+
+		const lvl_t black = yuv[0];
+		const int16_t rest = comp ? black.z : black.y;
+		for(int j = 0; j < SPL; j++)
+		{
+			const int x = x0 + j;
+			int16_t cell = rest;
+			if(x >= p0 && x < p0 + fbw)
+			{
+				const uint32_t rgb = row >= 0 ? (a.pool[row + (x - p0)] & 0xFFFFFF) : 0;
+				const lvl_t m = yuv[rgb];
+				int held = 0;
+				if(have_prev)
+				{
+					const uint32_t prgb = prow >= 0 ? (a.pool[prow + (x - p0)] & 0xFFFFFF) : 0;
+					const lvl_t pm = yuv[prgb];
+					held = pcomp ? pm.z : pm.y;
+				}
+				cell = (int16_t) (((int) (comp ? m.z : m.y) + held) / 2);
+			}
+			c[j] = x < W ? cell : 0;
+		}
+	}
+
+	if(lane == 0) for(int j = 0; j < 8; j++) { lds[j] = 0; lds[8 + W + j] = 0; }
+	for(int j = 0; j < SPL; j++) if(x0 + j < W) lds[8 + x0 + j] = c[j];
+	__syncthreads();
+
+	if(x0 >= W) return;
+
+	int32_t acc[SPL];
+	for(int j = 0; j < SPL; j++)
+	{
+		int32_t s = 0;
+		for(int k = 0; k < 15; k++) s += (int32_t) lds[8 + x0 + j - 7 + k] * a.C.fir[k];
+		acc[j] = s;
+	}
+
+	/* 8 outputs of one task in 16 bytes, tasks side by side */
+	{
+		int16_t o[SPL];
+		for(int j = 0; j < SPL; j++)
+		{
+			int32_t s = acc[j] >> 15;
+			o[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+		}
+		int4 pk;
+		pk.x = (uint16_t) o[0] | ((uint32_t) (uint16_t) o[1] << 16);
+		pk.y = (uint16_t) o[2] | ((uint32_t) (uint16_t) o[3] << 16);
+		pk.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
+		pk.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
+		((int4 *) a.F)[(size_t) lane * a.tpad + t] = pk;
+	}
+	/* the last 7 outputs also as they are before the shift: the share of what lies behind the line comes later */
+	if(x0 + SPL >= W)
+	{
+		for(int j = 0; j < SPL; j++)
+		{
+			const int x = x0 + j;
+			if(x >= W - HVK_SECAM_TAIL && x < W) a.acc[(size_t) t * 8 + (x - (W - HVK_SECAM_TAIL))] = acc[j];
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+
+/* One line's walk by one lane: hvk_secam_chain_line() with the low pass read 8 at a time from the transposed store
+ * and the output written 8 at a time. */
+__device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
+{
+	const int W = a.C.W, sl = a.C.sl;
+	const int16_t dmin = a.C.dmin[v.dr], dmax = a.C.dmax[v.dr];
+	const int32_t level = a.C.level;
+	const int fm_end = v.sr < W ? v.sr : W;
+	double ix = S.ix, iy = S.iy;
+	int32_t pi = v.phase_pos ? INT32_MAX : -INT32_MAX, pq = 0;
+	const int4 *F = (const int4 *) a.F + m;
+	const int chunks = W / SPL;
+
+	for(int ch = 0; ch < chunks; ch++)
+	{
+		const int4 pk = F[(size_t) ch * a.tpad];
+		int16_t f8[SPL], o8[SPL];
+		f8[0] = (int16_t) pk.x; f8[1] = (int16_t) (pk.x >> 16);
+		f8[2] = (int16_t) pk.y; f8[3] = (int16_t) (pk.y >> 16);
+		f8[4] = (int16_t) pk.z; f8[5] = (int16_t) (pk.z >> 16);
+		f8[6] = (int16_t) pk.w; f8[7] = (int16_t) (pk.w >> 16);
+
+		if(ch == chunks - 1)
+		{
+			/* the last 7: add what lies behind the line (output x reads tail[i] through tap W + 7 + i - x) */
+			for(int j = 1; j < SPL; j++)
+			{
+				const int x = ch * SPL + j;
+				int32_t s = a.acc[(size_t) m * 8 + (j - 1)];
+				for(int i = 0; i < HVK_SECAM_TAIL; i++)
+				{
+					const int k = W + 7 + i - x;
+					if(k <= 14) s += (int32_t) S.tail[i] * a.C.fir[k];
+				}
+				s >>= 15;
+				f8[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+			}
+		}
+
+#pragma unroll
+		for(int j = 0; j < SPL; j++)
+		{
+			const int x = ch * SPL + j;
+			const double in = (double) f8[j];
+			const double t0 = in * 2.90456054;
+			const double t1 = ix * -2.80912108;
+			const double t2 = iy * -0.90456054;
+			int16_t vv = 0;
+			iy = (t0 + t1) - t2;
+			ix = in;
+			const int16_t y = (int16_t) hvk_secam_round_away(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
+			if(x >= sl && x < fm_end)
+			{
+				vv = hvk_secam_fm_step(a.lut, a.bell, y, dmin, dmax, level, &pi, &pq);
+				vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
+			}
+			o8[j] = vv;
+		}
+
+		if(out)
+		{
+			int4 po;
+			po.x = (uint16_t) o8[0] | ((uint32_t) (uint16_t) o8[1] << 16);
+			po.y = (uint16_t) o8[2] | ((uint32_t) (uint16_t) o8[3] << 16);
+			po.z = (uint16_t) o8[4] | ((uint32_t) (uint16_t) o8[5] << 16);
+			po.w = (uint16_t) o8[6] | ((uint32_t) (uint16_t) o8[7] << 16);
+			*(int4 *) (out + ch * SPL) = po;
+		}
+	}
+
+	S.ix = ix;
+	S.iy = iy;
+	for(int x = W; x < v.sr; x++) S.tail[x - W] = hvk_secam_fm_step(a.lut, a.bell, S.tail[x - W], dmin, dmax, level, &pi, &pq);
+}
+
+__device__ __forceinline__ int16_t *out_of(const hvk_secam_args_t &a, const task_view &v)
+{
+	if(v.line < 1) return(NULL);        /* the fill slots are never seen */
+	return(a.chroma + (size_t) v.frame * a.raster_samples + (size_t) (v.line - 1) * a.C.W);
+}
+
+__device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit)
+{
+	const task_view v = task_of(a, m);
+	if(!v.valid) return;
+	if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
+	walk_line(a, m, v, S, emit ? out_of(a, v) : NULL);
+}
+
+__global__ __launch_bounds__(64)
+void hvk_k_secam_chain(const hvk_secam_args_t a)
+{
+	const int t = blockIdx.x * 64 + threadIdx.x;
+	if(t >= a.total) return;
+
+	hvk_secam_state_t S;
+	int m = t - a.K;
+	if(m <= 0) { m = 0; S = *a.carry; }
+	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
+
+	for(; m < t; m++) run_task(a, m, S, false);
+	a.entry[t] = S;
+	run_task(a, t, S, true);
+	a.exit[t] = S;
+}
+
+__device__ __forceinline__ bool same_state(const hvk_secam_state_t &p, const hvk_secam_state_t &q)
+{
+	bool same = __double_as_longlong(p.ix) == __double_as_longlong(q.ix) && __double_as_longlong(p.iy) == __double_as_longlong(q.iy);
+	for(int i = 0; i < HVK_SECAM_TAIL; i++) same = same && p.tail[i] == q.tail[i];
+	return(same);
+}
+
+/* flags[t] = task t started from a state the task before did not leave; count[0] += failures */
+__global__ void hvk_k_secam_check(const hvk_secam_args_t a)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if(t >= a.total) return;
+	const hvk_secam_state_t want = t ? a.exit[t - 1] : *a.carry;
+	const bool bad = !same_state(a.entry[t], want);
+	a.flags[t] = bad;
+	if(bad) atomicAdd(a.count, 1);
+}
+
+/* the failed tasks again, from the exit state of the task before */
+__global__ __launch_bounds__(64)
+void hvk_k_secam_redo(const hvk_secam_args_t a)
+{
+	const int t = blockIdx.x * 64 + threadIdx.x;
+	if(t >= a.total || !a.flags[t]) return;
+	hvk_secam_state_t S = t ? a.exit[t - 1] : *a.carry;
+	a.entry[t] = S;
+	run_task(a, t, S, true);
+	a.exit[t] = S;
+}
+
+/* the batch is through: its last exit state is the next batch's start */
+__global__ void hvk_k_secam_carry(const hvk_secam_args_t a)
+{
+	if(threadIdx.x == 0 && blockIdx.x == 0) *a.carry = a.exit[a.total - 1];
+}
+
+extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream_t stream)
+{
+	const int lanes = (a->C.W + SPL - 1) / SPL;
+	const int threads = (lanes + 63) & ~63;
+	if(threads > 256 || (a->C.W % SPL) != 0) return(HVK_UNSUPPORTED);
+	hipLaunchKernelGGL(hvk_k_secam_cells, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
+	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->total + 63) / 64), dim3(64), 0, stream, *a);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream)
+{
+	if(hipMemsetAsync(a->count, 0, sizeof(int), stream) != hipSuccess) return(HVK_ERROR);
+	hipLaunchKernelGGL(hvk_k_secam_check, dim3((a->total + 255) / 256), dim3(256), 0, stream, *a);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(hvk_k_secam_redo, dim3((a->total + 63) / 64), dim3(64), 0, stream, *a);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(hvk_k_secam_carry, dim3(1), dim3(64), 0, stream, *a);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}

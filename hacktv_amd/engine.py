@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -80,6 +80,7 @@ def lib():
         L.hvk_set_stream.argtypes = [vp, vp]
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.hvk_secam_stats.argtypes = [vp, vp]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_fetch_async.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -232,6 +233,11 @@ class Engine:
             r = lib().hvk_host_secam_stream(self.h, fb.ctypes.data, w, h, interlaced, out.ctypes.data)
         self._chk("hvk_host_secam_stream", r)
         return out
+
+    def secam_stats(self):
+        c = (C.c_int64 * 4)()
+        self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
+        return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
 
     def render(self, nframes, slots=None, d_iq=None):
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)

@@ -251,6 +251,13 @@ int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
  * hvk_render(). Needs no device. */
 int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int height, int interlaced, int16_t *out);
 
+/* SECAM: how the colour sub-carrier's line-to-line chain went so far. Lines are worked on independently, each from
+ * an entry state derived by running a few lines before it from nothing; the derived states are then checked against
+ * the true ones (the exit states of the lines before) and lines that started wrong are redone in order.
+ * counts[0] lines worked on speculatively, [1] lines whose derived entry state was wrong, [2] lines redone in order
+ * because of them, [3] frames that went through the host's serial chain instead. */
+int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4]);
+
 /* --offset, host half on its own: the values the offset process multiplies
  * output samples [first, first + count) by (src/video.c:3482-3515): count int16
  * pairs, the free-running Q31 phasor >> 16, advanced over the pipeline's

@@ -357,6 +357,56 @@ def test_secam_moving_picture_and_geometry(golden):
     assert np.array_equal(np.concatenate(got), np.concatenate(want))
 
 
+def _secam_noisy(n, seed=11):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:576, 0:832]
+    out = []
+    for i in range(n):
+        r = (xx * 255 // 831 + i * 17) % 256
+        g = (yy * 255 // 575 + i * 5) % 256
+        b = ((xx + yy + i * 29) // 3) % 256
+        p = (r.astype(np.uint32) << 16) | (g.astype(np.uint32) << 8) | b.astype(np.uint32)
+        noise = rng.integers(0, 1 << 24, p.shape, dtype=np.uint32)
+        out.append(np.where(rng.random(p.shape) < 0.3, noise, p).astype(np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("env,expect", [({}, "device"), ({"HVK_SECAM_WARMUP": "5"}, "redo"),
+                                        ({"HVK_SECAM_WARMUP": "1", "HVK_SECAM_FORCE_FALLBACK": "1"}, "fallback")])
+def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypatch, env, expect):
+    """The SECAM colour sub-carrier computed line-parallel on the device (hvk_secam.hip: derived entry states,
+    check, redo rounds) against the host's serial chain (HVK_SECAM_HOST=1, itself pinned against the reference on
+    the CPU), over 3 batches of 3 moving noisy pictures + field identification lines: every sample equal; with the
+    default warm-up next to nothing needs redoing, with a short one the redo rounds do the work, and a forced
+    fall-back hands the batch to the host's chain and takes the chain back afterwards."""
+    conf = H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO)
+    conf.secam_field_id = 1
+    pics = _secam_noisy(8) + [None]
+    def run():
+        out = []
+        with H.Engine(conf, 16000000, device=0, max_frames=3) as e:
+            for b in range(3):
+                for s_ in range(3):
+                    e.frame_upload(s_, pics[b * 3 + s_])
+                e.render(3, slots=[0, 1, 2])
+                out.append(e.fetch(0, 3 * 640000))
+            return np.concatenate(out), e.secam_stats()
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, st_host = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    got, st = run()
+    assert np.array_equal(got, want)
+    assert st["tasks"] >= 9 * 570
+    if expect == "device":
+        assert st["host_frames"] == 0 and st["mismatches"] <= st["tasks"] // 200, st
+    elif expect == "redo":
+        assert st["host_frames"] == 0 and st["redone"] > 0, st
+    else:
+        assert st["host_frames"] > 0, st
+
+
 @pytest.mark.parametrize("case", ["i_full", "pal_bb"])
 def test_sink_formats_on_device(golden, case):
     """hvk_fetch_as(): the file sink's sample-format conversion done on the GPU, against

@@ -128,6 +128,28 @@ def test_secam_host_prepass_equals_oracle(golden):
     assert not got[:, :82].any()
 
 
+def test_secam_lines_from_derived_entry_states(golden, monkeypatch):
+    """What the device does (hvk_secam.hip), run by the host code that shares its arithmetic (hvk_secam_chain.h,
+    HVK_SECAM_SPEC=K): every line on its own from an entry state derived by walking K lines before it from nothing,
+    then checked against the true chain. The result equals the serial chain's whatever K is (wrong starts are
+    found and redone); with 12 warm-up lines next to none are wrong, with 4 most are."""
+    frames = [golden.frame("l_raster")]
+    rng = np.random.default_rng(3)
+    frames += [rng.integers(0, 1 << 24, size=(576, 832), dtype=np.uint32) for _ in range(2)]
+    conf = H.preset("l", H.FLAG_NOAUDIO)
+
+    def run():
+        with H.Engine(conf, 16000000, device=-1) as e:
+            return np.concatenate([e.host_secam_stream(f) for f in frames]), e.secam_stats()
+    want, _ = run()
+    monkeypatch.setenv("HVK_SECAM_SPEC", "12")
+    got, st = run()
+    assert np.array_equal(got, want) and st["tasks"] > 1700 and st["mismatches"] <= 5, st
+    monkeypatch.setenv("HVK_SECAM_SPEC", "4")
+    got, st = run()
+    assert np.array_equal(got, want) and st["mismatches"] > st["tasks"] // 2, st
+
+
 # ---- the complex tail: offset phasor, passthru queue, FM video (hvk_tail.c) ----
 
 def _oracle_frames(golden, conf, sr, case, nlines, passthru=False):
