@@ -51,6 +51,9 @@
 #include <strings.h>
 #include <pthread.h>
 #include <time.h>
+#include <signal.h>
+#include <execinfo.h>
+#include <unistd.h>
 #include "video.h"          /* the reference's */
 #include "hacktv_amd.h"
 #include "hvk_shim_depth.h"
@@ -109,6 +112,89 @@ typedef struct {
 	vid_line_t out;
 } shim_t;
 
+/* HVK_SHIM_STATS: SIGUSR1 shows where the worker thread is (a diagnostic for a drop-in that does not leave) */
+static pthread_t _dbg_worker;
+static volatile int _dbg_have_worker;
+static void _dbg_usr1(int sig)
+{
+	void *bt[48];
+	(void) sig;
+	if(_dbg_have_worker && !pthread_equal(pthread_self(), _dbg_worker)) { pthread_kill(_dbg_worker, SIGUSR1); return; }
+	backtrace_symbols_fd(bt, backtrace(bt, 48), 2);
+}
+
+/* The reference's main() closes the source -- av_close(), src/hacktv.c:1596 -- as soon as its line loop ends (end of
+ * the source, or a signal), BEFORE vid_free(); its own vid_next_line() reads the source only inside the call, so that
+ * is safe there. Here a worker thread reads ahead: it has to be off the source before the source's close callback
+ * frees what it reads (a test card freed under the worker's copy is a segmentation fault -- which hacktv's handler
+ * turns into an endless loop). The shim therefore puts its own close callback in front of the source's: it stops the
+ * worker, then lets the source close. A source opened afterwards (hacktv plays its arguments one after the other)
+ * starts a new worker on the next vid_next_line(). */
+#define SHIM_HOOKS 8
+static struct { void *ctx; vid_t *s; av_close_t close; } _hooks[SHIM_HOOKS];
+static pthread_mutex_t _hooks_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void _worker_stop(vid_t *s);
+
+static int _hooked_close(void *ctx)
+{
+	av_close_t orig = NULL;
+	vid_t *s = NULL;
+	int i;
+
+	pthread_mutex_lock(&_hooks_lock);
+	for(i = 0; i < SHIM_HOOKS; i++)
+	{
+		if(_hooks[i].s && _hooks[i].ctx == ctx)
+		{
+			orig = _hooks[i].close;
+			s = _hooks[i].s;
+			_hooks[i].s = NULL;
+			break;
+		}
+	}
+	pthread_mutex_unlock(&_hooks_lock);
+
+	if(s) _worker_stop(s);
+	return(orig ? orig(ctx) : AV_OK);
+}
+
+static int _hook_source(vid_t *s)
+{
+	int i, r = -1;
+	if(s->av.close == _hooked_close) return(0);
+	pthread_mutex_lock(&_hooks_lock);
+	for(i = 0; i < SHIM_HOOKS; i++)
+	{
+		if(!_hooks[i].s)
+		{
+			_hooks[i].s = s;
+			_hooks[i].ctx = s->av.av_source_ctx;
+			_hooks[i].close = s->av.close;
+			s->av.close = _hooked_close;
+			r = 0;
+			break;
+		}
+	}
+	pthread_mutex_unlock(&_hooks_lock);
+	return(r);
+}
+
+static void _unhook_source(vid_t *s)
+{
+	int i;
+	pthread_mutex_lock(&_hooks_lock);
+	for(i = 0; i < SHIM_HOOKS; i++)
+	{
+		if(_hooks[i].s == s)
+		{
+			if(s->av.close == _hooked_close) s->av.close = _hooks[i].close;
+			_hooks[i].s = NULL;
+		}
+	}
+	pthread_mutex_unlock(&_hooks_lock);
+}
+
 static double _now(void)
 {
 	struct timespec ts;
@@ -161,6 +247,26 @@ static int _cc_pop(shim_t *m, uint8_t *pair)
 /* vid_t has no spare member; the engine handle rides in a pointer member the
  * caller never touches (`processes` is private to the reference's video.c). */
 static shim_t *_shim(vid_t *s) { return((shim_t *) s->processes); }
+
+/* Stop the read-ahead: the worker leaves the source and the engine alone from here on. What it had rendered and not
+ * handed out is dropped (the caller is leaving, or -- at the end of a source -- there is nothing left) */
+static void _worker_stop(vid_t *s)
+{
+	shim_t *m = _shim(s);
+	if(!m || !m->worker_on) return;
+	pthread_mutex_lock(&m->lock);
+	m->stop = 1;
+	pthread_cond_broadcast(&m->cond);
+	pthread_mutex_unlock(&m->lock);
+	pthread_join(m->worker, NULL);
+	m->worker_on = 0;
+	m->stop = 0;
+	m->ready[0] = m->ready[1] = 0;
+	m->cur = -1;
+	m->have = 0;
+	m->frame_in_batch = 0;
+	m->ended = 0;
+}
 
 static int _refuse(const char *what)
 {
@@ -397,15 +503,8 @@ void vid_free(vid_t *s)
 	if(s->passthru && s->passthru != stdin) fclose(s->passthru);   /* src/video.c:4783-4786 */
 	if(s->raw_bb_file) fclose(s->raw_bb_file);
 
-	if(m && m->worker_on)
-	{
-		/* the worker is the only caller of the engine and the source: stop it first */
-		pthread_mutex_lock(&m->lock);
-		m->stop = 1;
-		pthread_cond_broadcast(&m->cond);
-		pthread_mutex_unlock(&m->lock);
-		pthread_join(m->worker, NULL);
-	}
+	/* the worker is the only caller of the engine and the source: stop it first */
+	if(m) { _unhook_source(s); _worker_stop(s); }
 
 	av_close(&s->av);       /* src/video.c:4711 */
 
@@ -688,9 +787,11 @@ vid_line_t *vid_next_line(vid_t *s)
 		if(!m->worker_on)
 		{
 			/* started on the first line, once main() has filled in s->av (src/hacktv.c:1493) */
+			if(_hook_source(s) != 0) return(NULL);
 			if(pthread_create(&m->worker, NULL, _worker, s) != 0) return(NULL);
 			m->worker_on = 1;
 			m->t_first = _now();
+			if(m->stats) { _dbg_worker = m->worker; _dbg_have_worker = 1; signal(SIGUSR1, _dbg_usr1); }
 		}
 
 		/* hand the finished buffer back, wait for the next one and for its read-back */
