@@ -549,21 +549,23 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 		return;
 	}
 
-	if(a->fm.on && !a->a2.on && !a->am.on)
+	if((a->fm.on && !a->a2.on && !a->am.on) || (a->am.on && !a->fm.on && !a->a2.on))
 	{
-		/* One FM carrier and nothing else (the common case: every mono FM system): the recurrence with its state
-		 * in registers, in runs that end where the amplitude correction is due. The chain is bound by the latency
-		 * of its dependent multiply -> subtract -> shift; nothing else sits on that path (measured: working the
-		 * output values out in a vectorised second pass gains nothing). */
-		const hvk_c32_t st = a->t->fm_lut[a->fm.sample - INT16_MIN];
+		/* One carrier and nothing else (the common cases: every mono FM system; system L's AM sound): the recurrence
+		 * with its state in registers, in runs that end where the amplitude correction is due. The chain is bound
+		 * by the latency of its dependent multiply -> subtract -> shift; nothing else sits on that path. */
+		_phasor_t *const ph = a->fm.on ? &a->fm : &a->am;
+		const hvk_c32_t st = a->fm.on ? a->t->fm_lut[a->fm.sample - INT16_MIN] : a->t->am_delta;
 		const int64_t ci = st.i, cq = st.q;
-		const int32_t level = a->fm.level;
+		const int32_t level = ph->level;
+		/* AM: the carrier is scaled by the sound first (src/video.c:3386-3392) */
+		const int32_t am_s = ((int32_t) a->am.sample - INT16_MIN) / 2;
 		/* the phase as sign-extended 64-bit values: the reference's (int32_t) cast of the shifted product changes
 		 * nothing while |phase| stays below 2^31 -- always, in practice: a step scales the amplitude by < 1 -- so the
 		 * sign extension comes off the dependent chain (multiply -> subtract -> shift: 5 cycles instead of 6 - 7) and
 		 * a never-taken branch keeps the cast for the case it would matter */
-		int64_t pi = a->fm.pi, pq = a->fm.pq;
-		int32_t counter = a->fm.counter;
+		int64_t pi = ph->pi, pq = ph->pq;
+		int32_t counter = ph->counter;
 
 		x = x0;
 		while(x < x1)
@@ -583,11 +585,12 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 				}
 				pi = ni;
 				pq = nq;
-				/* the top halves now, their scaling by the carrier level below, eight at a time: the recurrence's
-				 * four multiplies are all the one multiplier of a core should see per sample */
+				/* the top halves now, their scaling below, eight at a time: the recurrence's four multiplies are
+				 * all the one multiplier of a core should see per sample */
 				o[i * 2 + 0] = (int16_t) ((int32_t) pi >> 16);
 				o[i * 2 + 1] = (int16_t) ((int32_t) pq >> 16);
 			}
+			if(a->am.on) _scale16(o, run * 2, am_s);
 			_scale16(o, run * 2, level);
 			x += run;
 			counter -= run;
@@ -600,9 +603,9 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 				counter = INT16_MAX;
 			}
 		}
-		a->fm.pi = (int32_t) pi;
-		a->fm.pq = (int32_t) pq;
-		a->fm.counter = counter;
+		ph->pi = (int32_t) pi;
+		ph->pq = (int32_t) pq;
+		ph->counter = counter;
 		return;
 	}
 
