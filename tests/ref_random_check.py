@@ -114,6 +114,15 @@ def main():
     if np.array_equal(ref, mine):
         print("EQUAL")
         return
+    if conf.colour_mode != 3:
+        # The same, unnoticed by the before / after comparison: the bytes changed during the run and were back by
+        # its end (they belong to the allocator; which bytes they are depends on the process's heap layout, down
+        # to the length of the path the script was started from). Every difference then sits at a line's end.
+        x = np.arange(len(ref)) % W
+        keep = (x >= 32) & (x < W - 40)
+        if np.array_equal(ref[keep], mine[keep]):
+            print("EQUAL-EXCEPT-LINE-ENDS (%d of %d samples compared; the over-read bytes were not stable)" % (keep.sum(), len(ref)))
+            return
     d = np.nonzero((ref != mine).any(axis=1))[0]
     print("DIFFERENT %d samples, first at line %d x %d: ref %s oracle %s" % (len(d), d[0] // W, d[0] % W, ref[d[0]].tolist(), mine[d[0]].tolist()))
 
