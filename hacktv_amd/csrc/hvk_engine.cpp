@@ -62,6 +62,7 @@ struct hvk_engine {
 	hvk_secam_args_t sa;
 	void *d_secam[10];          /* what sa points into (freed at close) */
 	int *h_secam_count;         /* pinned: failures of the last check */
+	int secam_lanes;            /* lanes of four waves per SIMD */
 	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
 	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
 	int64_t secam_counts[4];
@@ -504,7 +505,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		 * line's start */
 		const int n0 = hvk_secam_tasks(&e->t, 0, NULL, 0), n1 = hvk_secam_tasks(&e->t, 1, NULL, 0);
 		const int over = k.burst_left + k.burst_width - k.width;
-		if(!getenv("HVK_SECAM_HOST") && k.width % 8 == 0 && k.width <= 2048 && over <= HVK_SECAM_TAIL && k.active_left >= 8 && n0 > 0 && n1 > 0)
+		if(!getenv("HVK_SECAM_HOST") && k.width % 16 == 0 && k.width <= 2048 && over <= HVK_SECAM_TAIL && k.active_left >= 8 && n0 > 0 && n1 > 0)
 		{
 			hvk_secam_args_t &a = e->sa;
 			memset(&a, 0, sizeof(a));
@@ -567,6 +568,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.yuv = e->d_yuv;
 			a.burst_win = (const int16_t *) e->d_burst + HVK_PULSE_PAD;
 			a.chroma = e->d_chroma;
+			{
+				hipDeviceProp_t prop;
+				e->secam_lanes = 1024 * 64 * 4;
+				if(hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->secam_lanes = prop.multiProcessorCount * 4 * 64 * 4;
+			}
 			e->secam_dev = 1;
 		}
 	}
@@ -1116,6 +1122,15 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	a.total = nframes * a.ntasks;
 	a.first_frame = first_frame;
 	a.fdesc = e->d_fdesc;
+	a.levels_computed = e->levels_computed;
+	a.yuvp = e->d_yuvparams;
+	/* A lane's walk is a chain of dependent operations: a SIMD interleaves a few waves of it for free (measured: 1156
+	 * waves on 1024 SIMDs take as long as 578). Longer runs per lane only when the batch has more lines than four
+	 * waves per SIMD hold. */
+	a.R = (a.total + e->secam_lanes - 1) / e->secam_lanes;
+	if(a.R < 1) a.R = 1;
+	if(getenv("HVK_SECAM_RUN")) a.R = atoi(getenv("HVK_SECAM_RUN")) > 0 ? atoi(getenv("HVK_SECAM_RUN")) : 1;
+	a.nruns = (a.total + a.R - 1) / a.R;
 	e->secam_start = *e->h_secam_carry;
 
 	HIPCHK(hipMemsetAsync(e->d_chroma, 0, (size_t) nframes * k.raster_samples * 2, e->stream));
@@ -1129,7 +1144,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		HIPCHK(hipStreamSynchronize(e->stream));
 		const int bad = *e->h_secam_count;
 		if(bad == 0) break;
-		if(rounds == 0) e->secam_counts[1] += bad;
+		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;
 		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
 		{
 			/* the host's chain takes the batch over from the state it began with */
@@ -1149,7 +1164,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			e->secam_counts[3] += nframes;
 			return(HVK_OK);
 		}
-		e->secam_counts[2] += bad;
+		e->secam_counts[2] += (int64_t) bad * a.R;
 		if((r = hvk_launch_secam_redo(&a, e->stream)) != HVK_OK) return(r);
 	}
 
@@ -1406,6 +1421,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			e->raw_base += drop;
 		}
 	}
+	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
 	if(e->secam_dev)
 	{
 		int r = _secam_on_device(e, first_frame, nframes);

@@ -76,6 +76,9 @@ typedef struct {
 	int nframes, total;         /* frames of the batch, nframes * ntasks */
 	int tpad;                   /* tasks the transposed stores are laid out for (>= total) */
 	int K;
+	int R, nruns;               /* tasks per lane of the chain kernel, ceil(total / R) */
+	int levels_computed;        /* this batch's pictures have many colours: compute the levels, do not look them up */
+	const void *yuvp;           /* hvk_yuvparams_t on the device */
 	int64_t first_frame;
 	int64_t raster_samples;
 	const hvk_secam_task_t *tasks;      /* [2][ntasks] */

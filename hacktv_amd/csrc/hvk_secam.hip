@@ -25,12 +25,26 @@
  * Doubles: the IIR is evaluated term by term with contraction off (this file is compiled with -ffp-contract=off),
  * like the reference's x86-64 build. */
 #include <hip/hip_runtime.h>
+#include "hvk_device.h"         /* level_of(): a colour's levels computed instead of looked up */
 #include "hvk_kernels.h"
 #include "hvk_secam_chain.h"
 
-#define SPL 8
-
 typedef struct { short x, y, z, w; } lvl_t;    /* a level-table entry: (Y, U, V, -) */
+
+/* (-, U, V) of a colour: from the 2^24-entry table, or -- pictures with too many colours for the table's lines to
+ * be found in the caches again -- worked out on the spot like the table's entries (src/video.c:3917-3958) */
+template<int LV>
+__device__ __forceinline__ lvl_t lvl_of(const hvk_secam_args_t &a, const uint32_t rgb)
+{
+	if(LV)
+	{
+		const short4v q = level_of(rgb, *(const hvk_yuvparams_t *) a.yuvp);
+		lvl_t r;
+		r.x = q.x; r.y = q.y; r.z = q.z; r.w = 0;
+		return(r);
+	}
+	return(((const lvl_t *) a.yuv)[rgb]);
+}
 
 /* task t of the batch -> its record; NULL state of affairs (a padding slot, the priming slots of any frame but the
  * stream's first) comes back as valid = false */
@@ -80,6 +94,7 @@ __device__ __forceinline__ task_view task_of(const hvk_secam_args_t &a, const in
 
 /* ------------------------------------------------------------------ */
 
+template<int LV>
 __global__ __launch_bounds__(256)
 void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
@@ -100,7 +115,6 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 	}
 	else
 	{
-		const lvl_t *yuv = (const lvl_t *) a.yuv;
 		const int comp = v.dr ? 1 : 0;
 		int pcomp, have_prev;
 		bool prime = slot < 2;
@@ -139,7 +153,7 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 			}
 		}
 
-		const lvl_t black = yuv[0];
+		const lvl_t black = ((const lvl_t *) a.yuv)[0];
 		const int16_t rest = comp ? black.z : black.y;
 		for(int j = 0; j < SPL; j++)
 		{
@@ -148,12 +162,12 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 			if(x >= p0 && x < p0 + fbw)
 			{
 				const uint32_t rgb = row >= 0 ? (a.pool[row + (x - p0)] & 0xFFFFFF) : 0;
-				const lvl_t m = yuv[rgb];
+				const lvl_t m = lvl_of<LV>(a, rgb);
 				int held = 0;
 				if(have_prev)
 				{
 					const uint32_t prgb = prow >= 0 ? (a.pool[prow + (x - p0)] & 0xFFFFFF) : 0;
-					const lvl_t pm = yuv[prgb];
+					const lvl_t pm = lvl_of<LV>(a, prgb);
 					held = pcomp ? pm.z : pm.y;
 				}
 				cell = (int16_t) (((int) (comp ? m.z : m.y) + held) / 2);
@@ -204,8 +218,30 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 
 /* ------------------------------------------------------------------ */
 
-/* One line's walk by one lane: hvk_secam_chain_line() with the low pass read 8 at a time from the transposed store
- * and the output written 8 at a time. */
+/* One line's walk by one lane: hvk_secam_chain_line() in chunks of CH samples -- the low pass read 8 at a time from
+ * the transposed store (the next chunk's loads go out before this chunk's arithmetic), the IIR over the whole
+ * chunk first, then all of the chunk's table reads at once (the bell-filter gain and the FM step of every sample:
+ * 2 x CH loads in flight instead of one round trip per sample), then the FM recurrence, then the output 8 at a
+ * time. Same arithmetic, same order per sample. */
+#define CH 16
+__device__ __forceinline__ void unpack8(const int4 pk, int16_t *f)
+{
+	f[0] = (int16_t) pk.x; f[1] = (int16_t) (pk.x >> 16);
+	f[2] = (int16_t) pk.y; f[3] = (int16_t) (pk.y >> 16);
+	f[4] = (int16_t) pk.z; f[5] = (int16_t) (pk.z >> 16);
+	f[6] = (int16_t) pk.w; f[7] = (int16_t) (pk.w >> 16);
+}
+
+__device__ __forceinline__ int4 pack8(const int16_t *o)
+{
+	int4 po;
+	po.x = (uint16_t) o[0] | ((uint32_t) (uint16_t) o[1] << 16);
+	po.y = (uint16_t) o[2] | ((uint32_t) (uint16_t) o[3] << 16);
+	po.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
+	po.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
+	return(po);
+}
+
 __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
 {
 	const int W = a.C.W, sl = a.C.sl;
@@ -215,62 +251,91 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 	double ix = S.ix, iy = S.iy;
 	int32_t pi = v.phase_pos ? INT32_MAX : -INT32_MAX, pq = 0;
 	const int4 *F = (const int4 *) a.F + m;
-	const int chunks = W / SPL;
+	const int chunks = W / CH;          /* W is a multiple of 16 (checked by the launcher) */
 
+	int4 nx0 = F[0], nx1 = F[(size_t) a.tpad];
 	for(int ch = 0; ch < chunks; ch++)
 	{
-		const int4 pk = F[(size_t) ch * a.tpad];
-		int16_t f8[SPL], o8[SPL];
-		f8[0] = (int16_t) pk.x; f8[1] = (int16_t) (pk.x >> 16);
-		f8[2] = (int16_t) pk.y; f8[3] = (int16_t) (pk.y >> 16);
-		f8[4] = (int16_t) pk.z; f8[5] = (int16_t) (pk.z >> 16);
-		f8[6] = (int16_t) pk.w; f8[7] = (int16_t) (pk.w >> 16);
+		int16_t f[CH], y[CH], o[CH];
+		unpack8(nx0, f);
+		unpack8(nx1, f + 8);
+		if(ch + 1 < chunks)
+		{
+			nx0 = F[(size_t) (2 * ch + 2) * a.tpad];
+			nx1 = F[(size_t) (2 * ch + 3) * a.tpad];
+		}
 
 		if(ch == chunks - 1)
 		{
 			/* the last 7: add what lies behind the line (output x reads tail[i] through tap W + 7 + i - x) */
-			for(int j = 1; j < SPL; j++)
+			for(int j = CH - HVK_SECAM_TAIL; j < CH; j++)
 			{
-				const int x = ch * SPL + j;
-				int32_t s = a.acc[(size_t) m * 8 + (j - 1)];
+				const int x = ch * CH + j;
+				int32_t s = a.acc[(size_t) m * 8 + (j - (CH - HVK_SECAM_TAIL))];
 				for(int i = 0; i < HVK_SECAM_TAIL; i++)
 				{
 					const int k = W + 7 + i - x;
 					if(k <= 14) s += (int32_t) S.tail[i] * a.C.fir[k];
 				}
 				s >>= 15;
-				f8[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+				f[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
 			}
 		}
 
 #pragma unroll
-		for(int j = 0; j < SPL; j++)
+		for(int j = 0; j < CH; j++)
 		{
-			const int x = ch * SPL + j;
-			const double in = (double) f8[j];
+			const double in = (double) f[j];
 			const double t0 = in * 2.90456054;
 			const double t1 = ix * -2.80912108;
 			const double t2 = iy * -0.90456054;
-			int16_t vv = 0;
 			iy = (t0 + t1) - t2;
 			ix = in;
-			const int16_t y = (int16_t) hvk_secam_round_away(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
-			if(x >= sl && x < fm_end)
+			y[j] = (int16_t) hvk_secam_round_away(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
+		}
+
+		const int x0 = ch * CH;
+		if(x0 + CH > sl && x0 < fm_end)
+		{
+			hvk_secam_c16_t g[CH];
+			hvk_secam_c32_t st[CH];
+#pragma unroll
+			for(int j = 0; j < CH; j++)
 			{
-				vv = hvk_secam_fm_step(a.lut, a.bell, y, dmin, dmax, level, &pi, &pq);
-				vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
+				const int16_t c = y[j] < dmin ? dmin : (y[j] > dmax ? dmax : y[j]);
+				g[j] = a.bell[(uint16_t) c];
+				st[j] = a.lut[(int32_t) c + 32768];
 			}
-			o8[j] = vv;
+#pragma unroll
+			for(int j = 0; j < CH; j++)
+			{
+				const int x = x0 + j;
+				int16_t vv = 0;
+				if(x >= sl && x < fm_end)
+				{
+					/* hvk_secam_fm_step() with the table entries already here */
+					const int64_t ni = (int64_t) pi * st[j].i - (int64_t) pq * st[j].q;
+					const int64_t nq = (int64_t) pi * st[j].q + (int64_t) pq * st[j].i;
+					pi = (int32_t) (ni >> 31);
+					pq = (int32_t) (nq >> 31);
+					const int32_t vi = ((pi >> 16) * level) >> 15;
+					const int32_t vq = ((pq >> 16) * level) >> 15;
+					vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
+					vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
+				}
+				o[j] = vv;
+			}
+		}
+		else
+		{
+#pragma unroll
+			for(int j = 0; j < CH; j++) o[j] = 0;
 		}
 
 		if(out)
 		{
-			int4 po;
-			po.x = (uint16_t) o8[0] | ((uint32_t) (uint16_t) o8[1] << 16);
-			po.y = (uint16_t) o8[2] | ((uint32_t) (uint16_t) o8[3] << 16);
-			po.z = (uint16_t) o8[4] | ((uint32_t) (uint16_t) o8[5] << 16);
-			po.w = (uint16_t) o8[6] | ((uint32_t) (uint16_t) o8[7] << 16);
-			*(int4 *) (out + ch * SPL) = po;
+			*(int4 *) (out + x0) = pack8(o);
+			*(int4 *) (out + x0 + 8) = pack8(o + 8);
 		}
 	}
 
@@ -293,21 +358,24 @@ __device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m,
 	walk_line(a, m, v, S, emit ? out_of(a, v) : NULL);
 }
 
+/* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than four waves per SIMD hold:
+ * then the warm-up is shared by the run's lines) */
 __global__ __launch_bounds__(64)
 void hvk_k_secam_chain(const hvk_secam_args_t a)
 {
-	const int t = blockIdx.x * 64 + threadIdx.x;
-	if(t >= a.total) return;
+	const int r = blockIdx.x * 64 + threadIdx.x;
+	if(r >= a.nruns) return;
+	const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
 
 	hvk_secam_state_t S;
-	int m = t - a.K;
+	int m = t0 - a.K;
 	if(m <= 0) { m = 0; S = *a.carry; }
 	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
 
-	for(; m < t; m++) run_task(a, m, S, false);
-	a.entry[t] = S;
-	run_task(a, t, S, true);
-	a.exit[t] = S;
+	for(; m < t0; m++) run_task(a, m, S, false);
+	a.entry[r] = S;
+	for(; m < t1; m++) run_task(a, m, S, true);
+	a.exit[r] = S;
 }
 
 __device__ __forceinline__ bool same_state(const hvk_secam_state_t &p, const hvk_secam_state_t &q)
@@ -317,55 +385,57 @@ __device__ __forceinline__ bool same_state(const hvk_secam_state_t &p, const hvk
 	return(same);
 }
 
-/* flags[t] = task t started from a state the task before did not leave; count[0] += failures */
+/* flags[r] = run r started from a state the run before did not leave; count[0] += failures */
 __global__ void hvk_k_secam_check(const hvk_secam_args_t a)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if(t >= a.total) return;
-	const hvk_secam_state_t want = t ? a.exit[t - 1] : *a.carry;
-	const bool bad = !same_state(a.entry[t], want);
-	a.flags[t] = bad;
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= a.nruns) return;
+	const hvk_secam_state_t want = r ? a.exit[r - 1] : *a.carry;
+	const bool bad = !same_state(a.entry[r], want);
+	a.flags[r] = bad;
 	if(bad) atomicAdd(a.count, 1);
 }
 
-/* the failed tasks again, from the exit state of the task before */
+/* the failed runs again, from the exit state of the run before */
 __global__ __launch_bounds__(64)
 void hvk_k_secam_redo(const hvk_secam_args_t a)
 {
-	const int t = blockIdx.x * 64 + threadIdx.x;
-	if(t >= a.total || !a.flags[t]) return;
-	hvk_secam_state_t S = t ? a.exit[t - 1] : *a.carry;
-	a.entry[t] = S;
-	run_task(a, t, S, true);
-	a.exit[t] = S;
+	const int r = blockIdx.x * 64 + threadIdx.x;
+	if(r >= a.nruns || !a.flags[r]) return;
+	const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
+	hvk_secam_state_t S = r ? a.exit[r - 1] : *a.carry;
+	a.entry[r] = S;
+	for(int m = t0; m < t1; m++) run_task(a, m, S, true);
+	a.exit[r] = S;
 }
 
 /* the batch is through: its last exit state is the next batch's start */
 __global__ void hvk_k_secam_carry(const hvk_secam_args_t a)
 {
-	if(threadIdx.x == 0 && blockIdx.x == 0) *a.carry = a.exit[a.total - 1];
+	if(threadIdx.x == 0 && blockIdx.x == 0) *a.carry = a.exit[a.nruns - 1];
 }
 
 extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream_t stream)
 {
 	const int lanes = (a->C.W + SPL - 1) / SPL;
 	const int threads = (lanes + 63) & ~63;
-	if(threads > 256 || (a->C.W % SPL) != 0) return(HVK_UNSUPPORTED);
-	hipLaunchKernelGGL(hvk_k_secam_cells, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
-	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->total + 63) / 64), dim3(64), 0, stream, *a);
+	if(threads > 256 || (a->C.W % 16) != 0) return(HVK_UNSUPPORTED);
+	if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
+	else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
+	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream)
 {
 	if(hipMemsetAsync(a->count, 0, sizeof(int), stream) != hipSuccess) return(HVK_ERROR);
-	hipLaunchKernelGGL(hvk_k_secam_check, dim3((a->total + 255) / 256), dim3(256), 0, stream, *a);
+	hipLaunchKernelGGL(hvk_k_secam_check, dim3((a->nruns + 255) / 256), dim3(256), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream)
 {
-	hipLaunchKernelGGL(hvk_k_secam_redo, dim3((a->total + 63) / 64), dim3(64), 0, stream, *a);
+	hipLaunchKernelGGL(hvk_k_secam_redo, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

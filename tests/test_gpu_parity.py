@@ -371,7 +371,8 @@ def _secam_noisy(n, seed=11):
     return out
 
 
-@pytest.mark.parametrize("env,expect", [({}, "device"), ({"HVK_SECAM_WARMUP": "5"}, "redo"),
+@pytest.mark.parametrize("env,expect", [({}, "device"), ({"HVK_SECAM_RUN": "3"}, "device"), ({"HVK_SECAM_WARMUP": "5"}, "redo"),
+                                        ({"HVK_LEVELS": "compute"}, "device"),
                                         ({"HVK_SECAM_WARMUP": "1", "HVK_SECAM_FORCE_FALLBACK": "1"}, "fallback")])
 def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypatch, env, expect):
     """The SECAM colour sub-carrier computed line-parallel on the device (hvk_secam.hip: derived entry states,
