@@ -406,6 +406,48 @@ def main():
         }
         em.close()
 
+    # ---- SECAM-L (BASELINE config 4's mode): the colour sub-carrier's line-to-line chain runs on the device when a
+    # block is staged (hvk_secam.hip), so here a step is stage + launch of a fresh block; beside it the host's serial
+    # chain on one short block ----
+    secam = None
+    if N == 1 and not args.no_moving:
+        Fs = F
+        es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
+        es.frame_upload(0, g.frame("l_full"))
+        for k in range(2):
+            es.stage(k * Fs, 1, Fs)
+            es.launch()
+        es.sync()
+        ksteps = 5
+        t0 = time.perf_counter()
+        for k in range(ksteps):
+            es.stage((2 + k) * Fs, 1, Fs)
+            es.launch()
+        es.sync()
+        t_dev = (time.perf_counter() - t0) / ksteps
+        st = es.secam_stats()
+        names_s = es.kernel_names()
+        es.close()
+        os.environ["HVK_SECAM_HOST"] = "1"
+        eh = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=8)
+        eh.frame_upload(0, g.frame("l_full"))
+        t0 = time.perf_counter()
+        eh.stage(0, 1, 8)
+        eh.launch()
+        eh.sync()
+        t_host = time.perf_counter() - t0
+        eh.close()
+        del os.environ["HVK_SECAM_HOST"]
+        secam = {
+            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % Fs,
+            "Msamples_per_s": round(Fs * FS / t_dev / 1e6, 1),
+            "ms_per_step": round(t_dev * 1e3, 3),
+            "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
+            "lines": st,
+            "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
+            "note": "lines: worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain",
+        }
+
     if rank == 0:
         names = e.kernel_names()
         fused = len(names) == 1
@@ -488,6 +530,8 @@ def main():
             res["end_to_end"] = e2e
         if moving:
             res["moving_pictures"] = moving
+        if secam:
+            res["secam_l"] = secam
         if not args.no_cpu_baseline and N == 1:
             res["cpu_baseline"] = cpu_baseline(log)
         print(json.dumps(res), flush=True)

@@ -11,7 +11,7 @@ if [ -n "${STEADY:-}" ]; then
   for flags in "-m i -s 16000000 --filter" "-m i -s 16000000 --filter --noaudio" "-m l -s 16000000 --filter"; do
     for extra in "" "HVK_SHIM_PAGEABLE=1"; do
       echo "== hacktv_hvk $flags $extra"
-      env HVK_BATCH=32 HVK_SHIM_STATS=1 $extra timeout -s INT ${STEADY} oracle/_ref/hacktv_hvk $flags -o /dev/null test 2>&1 | grep "hacktv-amd"
+      env HVK_BATCH=32 HVK_SHIM_STATS=1 $extra timeout -k 5 -s INT ${STEADY} oracle/_ref/hacktv_hvk $flags -o /dev/null test 2>&1 | grep "hacktv-amd"
     done
   done
   exit 0

@@ -3,6 +3,7 @@
 (profiling build, HVK_ABLATE bit 16384: WRONG output). Run on the GPU box."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["HVK_FUSE"] = "1"
 os.environ.setdefault("HVK_LIB", os.path.join(ROOT, "hacktv_amd", "libhvk_ablate.so"))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
