@@ -357,7 +357,6 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 		/* the device's way: every task by itself, K warm-up lines from nothing (or from the frame's true entry state
 		 * when they reach back that far), then the check */
 		const int K = s->spec_k;
-		int bad = 0;
 
 		for(i = 0; i < n; i++)
 		{
