@@ -67,52 +67,83 @@ static int32_t _fir65(_fir65_t *f, int32_t in)
 	return((int32_t) acc);
 }
 
-/* ---- look-ahead soft limiter (src/fir.c:748-870), width 21 ---- */
+/* ---- look-ahead soft limiter, 21 samples wide ----
+ * What the reference's limiter_process() computes (src/fir.c:748-870, called with the same sample on all three
+ * inputs, src/video.c:3322): the sample goes through two 65-tap FIRs -- "flat" (clipped to the ceiling on the spot)
+ * and pre-emphasised, of which only the excess over the flat branch is kept. Ten samples later the pair is looked at
+ * again: if flat + excess would overshoot the ceiling, the share of the excess that has to go is worked out and,
+ * shaped by a 21-point window centred there, raises the cut of the 21 samples around it. What leaves is the oldest
+ * sample: flat + excess x (1 - cut). All integer, every rounding as in the reference; laid out here as one ring
+ * of (flat, excess, cut) slots with the three steps as functions of their own. */
+#define LIM_SPAN 21
 typedef struct {
-	_fir65_t vfir, ffir;
-	const int16_t *shape;
-	int32_t level;
-	int16_t att[21];
-	int32_t fix[21], var[21];
-	int p, h;
+	int32_t flat, excess;
+	int32_t cut;                /* Q15 share of the excess to take away, 0 .. 32767 */
+} _lim_slot_t;
+
+typedef struct {
+	_fir65_t pre, flat;         /* the two branches' filters */
+	const int16_t *shape;       /* the window a cut is spread with */
+	int32_t ceiling;
+	_lim_slot_t ring[LIM_SPAN];
+	int oldest;                 /* slot that leaves next (and is overwritten by the newcomer) */
+	int centre;                 /* slot LIM_SPAN / 2 samples behind the newcomer */
 } _limiter_t;
+
+static inline int _lim_next(int i) { return(i + 1 == LIM_SPAN ? 0 : i + 1); }
+
+/* the newcomer takes the place of the sample that left last time */
+static void _lim_take(_limiter_t *l, int16_t in)
+{
+	_lim_slot_t *s = &l->ring[l->oldest];
+	const int32_t pre = _fir65(&l->pre, in);
+	int32_t flat = _fir65(&l->flat, in);
+
+	if(flat < -l->ceiling) flat = -l->ceiling;
+	else if(flat > l->ceiling) flat = l->ceiling;
+
+	s->flat = flat;
+	s->excess = pre - flat;
+	s->cut = 0;
+
+	l->oldest = _lim_next(l->oldest);
+	l->centre = _lim_next(l->centre);
+}
+
+/* does the sample in the middle of the ring overshoot? Then every slot's cut is raised to what the window, centred
+ * there, asks of it (slot `oldest` is the window's first point) */
+static void _lim_look_ahead(_limiter_t *l)
+{
+	const _lim_slot_t *c = &l->ring[l->centre];
+	const int32_t mag = abs(c->excess + c->flat);
+	int32_t need;
+	int i, at;
+
+	if(mag <= l->ceiling) return;
+
+	need = INT16_MAX - (l->ceiling + abs(c->excess) - mag) * INT16_MAX / abs(c->excess);
+	for(i = 0, at = l->oldest; i < LIM_SPAN; i++, at = _lim_next(at))
+	{
+		const int32_t want = (need * l->shape[i]) >> 15;
+		if(want > l->ring[at].cut) l->ring[at].cut = want;
+	}
+}
+
+static int16_t _lim_give(const _limiter_t *l)
+{
+	const _lim_slot_t *s = &l->ring[l->oldest];
+	/* the cut is held as the reference's int16 */
+	int32_t v = s->flat + (int32_t) (((int64_t) s->excess * (INT16_MAX - (int16_t) s->cut)) >> 15);
+	if(v < -l->ceiling) v = -l->ceiling;
+	else if(v > l->ceiling) v = l->ceiling;
+	return((int16_t) v);
+}
 
 static int16_t _limit(_limiter_t *l, int16_t in)
 {
-	const int W = 21;
-	int32_t a, b;
-	int j;
-
-	/* the same sample feeds the variable (pre-emphasised) and the fixed
-	 * (flat) branch: limiter_process(&lim, &s, &s, &s, 1, 1), src/video.c:3322 */
-	l->var[l->p] = _fir65(&l->vfir, in);
-	l->fix[l->p] = _fir65(&l->ffir, in);
-	l->att[l->p] = 0;
-
-	if(l->fix[l->p] < -l->level) l->fix[l->p] = -l->level;
-	else if(l->fix[l->p] > l->level) l->fix[l->p] = l->level;
-	l->var[l->p] -= l->fix[l->p];
-
-	if(++l->p == W) l->p = 0;
-	if(++l->h == W) l->h = 0;
-
-	a = abs(l->var[l->h] + l->fix[l->h]);
-	if(a > l->level)
-	{
-		a = INT16_MAX - (l->level + abs(l->var[l->h]) - a) * INT16_MAX / abs(l->var[l->h]);
-		for(j = 0; j < W; j++)
-		{
-			b = (a * l->shape[j]) >> 15;
-			if(b > l->att[l->p]) l->att[l->p] = b;
-			if(++l->p == W) l->p = 0;
-		}
-	}
-
-	a = l->fix[l->p] + (int32_t) (((int64_t) l->var[l->p] * (INT16_MAX - l->att[l->p])) >> 15);
-	if(a < -l->level) a = -l->level;
-	else if(a > l->level) a = l->level;
-
-	return((int16_t) a);
+	_lim_take(l, in);
+	_lim_look_ahead(l);
+	return(_lim_give(l));
 }
 
 /* ---- carrier phasor ---- */
@@ -358,11 +389,11 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		if(t->has_limiter)
 		{
 			a->has_lim = 1;
-			a->lim.vfir.taps = t->limiter_vtaps;
-			a->lim.ffir.taps = t->limiter_ftaps;
+			a->lim.pre.taps = t->limiter_vtaps;
+			a->lim.flat.taps = t->limiter_ftaps;
 			a->lim.shape = t->limiter_shape;
-			a->lim.level = INT16_MAX;
-			a->lim.h = 21 / 2;
+			a->lim.ceiling = INT16_MAX;
+			a->lim.centre = LIM_SPAN / 2;
 		}
 	}
 
@@ -374,11 +405,11 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		a->a2.level = t->a2_level;
 		if(t->has_limiter)
 		{
-			a->a2_lim.vfir.taps = t->limiter_vtaps;
-			a->a2_lim.ffir.taps = t->limiter_ftaps;
+			a->a2_lim.pre.taps = t->limiter_vtaps;
+			a->a2_lim.flat.taps = t->limiter_ftaps;
 			a->a2_lim.shape = t->limiter_shape;
-			a->a2_lim.level = INT16_MAX;
-			a->a2_lim.h = 21 / 2;
+			a->a2_lim.ceiling = INT16_MAX;
+			a->a2_lim.centre = LIM_SPAN / 2;
 		}
 		a->a2_pilot.pi = a->a2_signal.pi = INT32_MAX;
 		a->a2_pilot.counter = a->a2_signal.counter = INT16_MAX;
