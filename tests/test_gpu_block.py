@@ -178,3 +178,32 @@ def test_queued_read_back_into_page_locked_memory(golden):
         # and the reference's first frame (committed digest of the reference CLI's output)
         assert hashlib.sha256(got[0][:FS].tobytes()).hexdigest() == LONG["i_full"]["sha256_at_frames"]["1"]
     assert e.h is None
+
+
+@pytest.mark.parametrize("flags", [["-m", "i", "-s", "16000000", "--filter"],
+                                   ["-m", "l", "-s", "16000000", "--filter", "--vits", "--vitc"]])
+def test_dropin_resident_set_does_not_grow_with_the_run(flags):
+    """60 s of signal through the drop-in binary: its queues (32 kHz sound kept for line->audio, NICAM symbols,
+    the SECAM chain's stores, the read-back ring) are emptied as the stream goes by -- the resident set at the end of
+    the run is what it was a third of the way in."""
+    psutil = pytest.importorskip("psutil")
+    exe = os.path.join(REF, "hacktv_hvk")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hacktv_hvk not built")
+    S = 60
+    n = S * 16000000 * 4
+    p = subprocess.Popen([exe] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         env=dict(os.environ, HVK_BATCH="16"))
+    try:
+        ps = psutil.Process(p.pid)
+        got, rss = 0, []
+        while got < n:
+            chunk = p.stdout.read(min(1 << 24, n - got))
+            assert chunk, "the drop-in ended early"
+            got += len(chunk)
+            if len(rss) < got // (n // 8 + 1) + 1:
+                rss.append(ps.memory_info().rss >> 20)
+    finally:
+        p.kill()
+        p.wait()
+    assert len(rss) == 8 and rss[-1] <= rss[2] + 16, rss
