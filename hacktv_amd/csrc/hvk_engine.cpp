@@ -1045,6 +1045,37 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 	}
 }
 
+/* Which lines of a frame the inserters other than teletext write to -- the lines on which the reference's
+ * vid_line_t.vbialloc is set by the time the teletext process sees them (src/teletext.c:1219; the processes run in the
+ * order VITS, WSS, ACP, VITC, CC608, ..., teletext, src/video.c:4234-4358). From the same tables the op list above is
+ * built from, so that a caller who schedules teletext packets (the shim) does not keep a list of its own. */
+extern "C" int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlines)
+{
+	if(!e || !held || nlines < e->t.k.lines) return(HVK_ERROR);
+	const hvk_tables_t &t = e->t;
+	const int lines = t.k.lines;
+	memset(held, 0, (size_t) nlines);
+	auto hold = [&](int line1) { if(line1 >= 1 && line1 <= lines) held[line1 - 1] = 1; };
+
+	for(int q = 0; q < t.k.vits; q++) hold(t.k.vits_line[q] + 1);
+	if(t.conf.wss) hold(23);
+	if(t.conf.acp)
+	{
+		const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
+		const int count = lines == 625 ? 10 : 8;
+		for(int fld = 0; fld < 2; fld++) for(int l = first[fld]; l < first[fld] + count; l++) hold(l);
+	}
+	if(t.conf.vitc)
+	{
+		hold(t.vitc_lines[0]); hold(t.vitc_lines[0] + 2);
+		hold(t.vitc_lines[1]); hold(t.vitc_lines[1] + 2);
+	}
+	if(t.conf.cc608) hold(t.cc608_line);
+	/* SECAM field identification lines carry the sub-carrier ramp (src/video.c:3101-3103, :4132-4137) */
+	for(int l = 1; l <= lines; l++) if(t.desc[l - 1].secam_fid & 1) hold(l);
+	return(HVK_OK);
+}
+
 /* FM video: bring the host copy of the current batch up to `upto` samples -- fetch the
  * modulator's input from the device and run the serial tail over it (hvk_tail.c) */
 static int _fm_upto(hvk_engine *e, size_t upto)

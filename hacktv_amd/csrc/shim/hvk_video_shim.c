@@ -90,6 +90,7 @@ typedef struct {
 	int ended;              /* source has ended: no more batches */
 	int frame_in_batch_pull;
 	int passthru_primed;    /* the start-up line's share of the passthru source has been queued */
+	uint8_t held[1250];     /* lines the inserters other than teletext write to (hvk_vbi_lines_held) */
 	int32_t *widths;        /* widths of the lines of the frame being handed out (they vary with --pixelrate) */
 	size_t line_at;         /* sample offset of the next line in iq */
 	int16_t *passbuf;
@@ -244,9 +245,36 @@ static int _cc_pop(shim_t *m, uint8_t *pair)
 	return(1);
 }
 
-/* vid_t has no spare member; the engine handle rides in a pointer member the
- * caller never touches (`processes` is private to the reference's video.c). */
-static shim_t *_shim(vid_t *s) { return((shim_t *) s->processes); }
+/* vid_t has no member for an engine handle (src/video.h:358-508), and its private ones are the reference engine's to
+ * use: the shim keeps its state beside the vid_t, in a small table of (vid_t, state) pairs. */
+#define SHIM_INSTANCES 8
+static struct { vid_t *s; shim_t *m; } _instances[SHIM_INSTANCES];
+static pthread_mutex_t _instances_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static shim_t *_shim(vid_t *s)
+{
+	int i;
+	for(i = 0; i < SHIM_INSTANCES; i++) if(_instances[i].s == s) return(_instances[i].m);
+	return(NULL);
+}
+
+static int _shim_register(vid_t *s, shim_t *m)
+{
+	int i, r = -1;
+	pthread_mutex_lock(&_instances_lock);
+	for(i = 0; i < SHIM_INSTANCES; i++) if(_instances[i].s == s) { _instances[i].m = m; r = 0; break; }
+	for(i = 0; r != 0 && i < SHIM_INSTANCES; i++) if(!_instances[i].s) { _instances[i].m = m; _instances[i].s = s; r = 0; }
+	pthread_mutex_unlock(&_instances_lock);
+	return(r);
+}
+
+static void _shim_unregister(vid_t *s)
+{
+	int i;
+	pthread_mutex_lock(&_instances_lock);
+	for(i = 0; i < SHIM_INSTANCES; i++) if(_instances[i].s == s) { _instances[i].s = NULL; _instances[i].m = NULL; }
+	pthread_mutex_unlock(&_instances_lock);
+}
 
 /* Stop the read-ahead: the worker leaves the source and the engine alone from here on. What it had rendered and not
  * handed out is dropped (the caller is leaving, or -- at the end of a source -- there is nothing left) */
@@ -403,6 +431,12 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	}
 
 	hvk_get_info(m->e, &m->info);
+	if(m->info.lines > (int) sizeof(m->held) || hvk_vbi_lines_held(m->e, m->held, (int) sizeof(m->held)) != HVK_OK)
+	{
+		hvk_close(m->e);
+		free(m);
+		return(VID_ERROR);
+	}
 	m->out_pos = m->info.startup_samples;
 	m->volume = conf->volume;
 
@@ -454,7 +488,16 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	s->sync_level = m->info.sync_level;
 	s->bframe = 1;
 	s->bline = 1;
-	s->processes = (void *) m;
+	if(_shim_register(s, m) != 0)
+	{
+		fprintf(stderr, "hacktv-amd: more than %d engines in one process\n", SHIM_INSTANCES);
+		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
+		else { free(m->buf[0]); free(m->buf[1]); }
+		free(m->widths);
+		hvk_close(m->e);
+		free(m);
+		return(VID_ERROR);
+	}
 
 	if(s->conf.raw_bb_file)
 	{
@@ -529,6 +572,7 @@ void vid_free(vid_t *s)
 		free(m->aud);
 		free(m);
 	}
+	_shim_unregister(s);
 
 	memset(s, 0, sizeof(vid_t));
 }
@@ -610,18 +654,10 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 			for(row = 0; row < 32; row++)
 			{
 				int line = row < 16 ? 7 + row : 320 + row - 16;
-				/* a line another inserter holds is left alone and the packet kept for the
-				 * next one (vbialloc, src/teletext.c:1219): VITS 17/18/330/331, VITC 19/21/332/334 */
-				if(s->conf.vits && (line == 17 || line == 18 || line == 330 || line == 331)) continue;
-				if(s->conf.vitc && (line == 19 || line == 21 || line == 332 || line == 334)) continue;
-				if(s->conf.acp && ((line >= 9 && line <= 18) || (line >= 321 && line <= 330))) continue;
-				if(s->conf.cc608 && line == 22) continue;
-				if(s->conf.colour_mode == VID_SECAM && s->conf.secam_field_id)
-				{
-					/* src/video.c:3101-3103, :4132-4137 */
-					int nl = (s->conf.secam_field_id_lines < 1 || s->conf.secam_field_id_lines > 9) ? 9 : s->conf.secam_field_id_lines;
-					if((line >= 7 && line < 7 + nl) || (line >= 320 && line < 320 + nl)) continue;
-				}
+				/* a line another inserter holds is left alone and the packet kept for the next one (vbialloc,
+				 * src/teletext.c:1219): the engine says which (hvk_vbi_lines_held(): from the tables it
+				 * renders those inserters with) */
+				if(m->held[line - 1]) continue;
 				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
 			}
 			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);

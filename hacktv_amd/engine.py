@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -81,6 +81,7 @@ def lib():
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_secam_stats.argtypes = [vp, vp]
+        L.hvk_vbi_lines_held.argtypes = [vp, vp, i32]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_fetch_async.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -233,6 +234,13 @@ class Engine:
             r = lib().hvk_host_secam_stream(self.h, fb.ctypes.data, w, h, interlaced, out.ctypes.data)
         self._chk("hvk_host_secam_stream", r)
         return out
+
+    def vbi_lines_held(self):
+        """1-based numbers of the lines the inserters other than teletext write to"""
+        n = self.info["lines"]
+        held = np.zeros(n, np.uint8)
+        self._chk("hvk_vbi_lines_held", lib().hvk_vbi_lines_held(self.h, held.ctypes.data, n))
+        return [i + 1 for i in range(n) if held[i]]
 
     def secam_stats(self):
         c = (C.c_int64 * 4)()

@@ -153,6 +153,12 @@ int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den
  * without a call carry no teletext. */
 int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask);
 
+/* Which lines (held[line - 1] != 0) the configuration's other inserters -- VITS, WSS, ACP, VITC, CC608, SECAM field
+ * identification -- write to: the lines on which the reference's vid_line_t.vbialloc is already set when its
+ * teletext process looks (src/teletext.c:1219), where a packet must not go and is kept for the next free line.
+ * nlines >= the mode's line count. Needs no device. */
+int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlines);
+
 /* --raw-bb-file (conf.raw_bb != 0): the next nsamples int16 samples of the external baseband
  * stream that takes the raster's place (src/video.c:2406-2446), in stream order; a line is `width`
  * samples. Rendering frame f needs the stream up to sample ((f + 1) * lines + 1) * width (the

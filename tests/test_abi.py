@@ -136,3 +136,20 @@ def test_sample_rates_without_a_kernel_are_refused_at_open():
             assert e.info["sample_rate"] == sr
     with H.Engine(H.preset("i"), 27000000, device=-1) as e:      # NICAM's 373-tap pulse at the top of the range
         assert e.info["has_nicam"] == 1
+
+
+def test_lines_held_by_the_other_inserters():
+    """hvk_vbi_lines_held(): where a teletext packet must not go (the reference's vbialloc, src/teletext.c:1219) --
+    the 625-line positions of VITS (src/vits.c), VITC (src/vitc.c), ACP (src/acp.c:93-108), CC608 (src/cc608.c),
+    WSS (line 23) and the SECAM field identification lines."""
+    c = H.preset("i", H.FLAG_NOAUDIO)
+    with H.Engine(c, 16000000, device=-1) as e:
+        assert e.vbi_lines_held() == []
+    c.vits, c.vitc, c.acp, c.cc608, c.wss = 1, 1, 1, 1, 1
+    with H.Engine(c, 16000000, device=-1) as e:
+        want = set([17, 18, 330, 331]) | set([19, 21, 332, 334]) | set(range(9, 19)) | set(range(321, 331)) | set([22, 23])
+        assert set(e.vbi_lines_held()) == want
+    c = H.preset("l", H.FLAG_NOAUDIO)
+    c.secam_field_id, c.secam_field_id_lines = 1, 5
+    with H.Engine(c, 16000000, device=-1) as e:
+        assert e.vbi_lines_held() == list(range(7, 12)) + list(range(320, 325))
