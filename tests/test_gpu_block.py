@@ -183,14 +183,14 @@ def test_queued_read_back_into_page_locked_memory(golden):
 @pytest.mark.parametrize("flags", [["-m", "i", "-s", "16000000", "--filter"],
                                    ["-m", "l", "-s", "16000000", "--filter", "--vits", "--vitc"]])
 def test_dropin_resident_set_does_not_grow_with_the_run(flags):
-    """60 s of signal through the drop-in binary: its queues (32 kHz sound kept for line->audio, NICAM symbols,
-    the SECAM chain's stores, the read-back ring) are emptied as the stream goes by -- the resident set at the end of
-    the run is what it was a third of the way in."""
+    """120 s of signal through the drop-in binary: its queues (32 kHz sound kept for line->audio, NICAM symbols,
+    the SECAM chain's stores, the read-back ring) are emptied as the stream goes by -- after the first half minute of
+    signal (one-off growth of the runtime's pools) the resident set stays where it is."""
     psutil = pytest.importorskip("psutil")
     exe = os.path.join(REF, "hacktv_hvk")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/hacktv_hvk not built")
-    S = 60
+    S = 120
     n = S * 16000000 * 4
     p = subprocess.Popen([exe] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                          env=dict(os.environ, HVK_BATCH="16"))
@@ -206,4 +206,4 @@ def test_dropin_resident_set_does_not_grow_with_the_run(flags):
     finally:
         p.kill()
         p.wait()
-    assert len(rss) == 8 and rss[-1] <= rss[2] + 16, rss
+    assert len(rss) == 8 and rss[-1] <= rss[3] + 16, rss
