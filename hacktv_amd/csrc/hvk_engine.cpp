@@ -720,6 +720,28 @@ extern "C" long hvk_table(const hvk_engine_t *e, const char *name, void *dst, lo
 
 /* ---- inputs ---- */
 
+/* How many colours? 4096 pixels on a regular grid, counted through a small open hash. Graphics and
+ * test cards have a few hundred, and the same ones in every frame: their level-table entries stay
+ * in cache. Camera pictures have tens of thousands per frame: most look-ups would miss.
+ * px: a w x h picture whose rows are `pitch` pixels apart. */
+static bool _many_colours(const uint32_t *px, int pitch, int w, int h)
+{
+	enum { SAMPLES = 4096, SLOTS = 8192, MANY = 1024 };
+	static const uint32_t EMPTY = 0xFFFFFFFFu;
+	std::vector<uint32_t> seen(SLOTS, EMPTY);
+	const size_t npx = (size_t) w * h;
+	int distinct = 0;
+	for(int i = 0; i < SAMPLES && npx > 0; i++)
+	{
+		const size_t at = (size_t) ((uint64_t) i * npx / SAMPLES);
+		const uint32_t c = px[(at / w) * (size_t) pitch + at % w] & 0xFFFFFFu;
+		uint32_t hsh = (c * 2654435761u) >> 19;      /* 13 bits */
+		while(seen[hsh] != EMPTY && seen[hsh] != c) hsh = (hsh + 1) & (SLOTS - 1);
+		if(seen[hsh] == EMPTY) { seen[hsh] = c; distinct++; }
+	}
+	return(distinct > MANY);
+}
+
 extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
                                 int pixel_stride, int line_stride, int interlaced)
 {
@@ -766,24 +788,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 		else for(int c = 0; c < w; c++) o[c] = p[(int64_t) c * pixel_stride];
 	}
 
-	/* How many colours? 4096 pixels on a regular grid, counted through a small open hash. Graphics and
-	 * test cards have a few hundred, and the same ones in every frame: their level-table entries stay
-	 * in cache. Camera pictures have tens of thousands per frame: most look-ups would miss. */
-	{
-		enum { SAMPLES = 4096, SLOTS = 8192, MANY = 1024 };
-		static const uint32_t EMPTY = 0xFFFFFFFFu;
-		std::vector<uint32_t> seen(SLOTS, EMPTY);
-		const size_t npx = (size_t) w * h;
-		int distinct = 0;
-		for(int i = 0; i < SAMPLES && npx > 0; i++)
-		{
-			const uint32_t c = stage[(size_t) ((uint64_t) i * npx / SAMPLES)] & 0xFFFFFFu;
-			uint32_t hsh = (c * 2654435761u) >> 19;      /* 13 bits */
-			while(seen[hsh] != EMPTY && seen[hsh] != c) hsh = (hsh + 1) & (SLOTS - 1);
-			if(seen[hsh] == EMPTY) { seen[hsh] = c; distinct++; }
-		}
-		s->many_colours = distinct > MANY;
-	}
+	s->many_colours = _many_colours(stage, w, w, h);
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 	if(e->secam)
@@ -797,6 +802,43 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, stage, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(hipEventRecord(e->up_ev[ub], e->stream));
 	e->up_busy[ub] = 1;
+	return(HVK_OK);
+}
+
+/* The same for a picture that lies in page-locked memory (hvk_host_alloc()), rows `width` pixels apart: no copy on the
+ * host, the cropped picture goes from where it lies to the slot by one strided DMA. */
+extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height, int interlaced)
+{
+	if(!e || slot < 0 || slot >= e->frame_slots) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	/* SECAM keeps a host copy of every picture for its fall-back chain, and an empty frame has nothing to copy:
+	 * the ordinary way */
+	if(e->secam || fb == NULL) return(hvk_frame_upload(e, slot, fb, width, height, 1, width, interlaced));
+
+	const hvk_kconst_t &k = e->t.k;
+	hvk_slot_t *s = &e->slots[slot];
+	int x = (width - k.active_width) / 2, y = (height - k.active_lines) / 2;
+	int w = k.active_width, h = k.active_lines;
+	if(x < 0) { w += x; x = 0; }
+	if(y < 0) { h += y; y = 0; }
+	if(x + w > width) w = width - x;
+	if(y + h > height) h = height - y;
+	if(w < 0) w = 0;
+	if(h < 0) h = 0;
+
+	s->valid = w > 0 && h > 0;
+	s->width = w;
+	s->height = h;
+	s->interlaced = interlaced;
+	if(!s->valid) return(HVK_OK);
+
+	const uint32_t *src = fb + (size_t) y * width + x;
+	s->many_colours = _many_colours(src, width, w, h);
+
+	HIPCHK(hipSetDevice(e->device));
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	HIPCHK(hipMemcpy2DAsync(e->d_pool + slot * frame_px, (size_t) w * 4, src, (size_t) width * 4, (size_t) w * 4, (size_t) h,
+	                        hipMemcpyHostToDevice, e->stream));
 	return(HVK_OK);
 }
 

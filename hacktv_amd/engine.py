@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_fetch_as", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -86,6 +86,7 @@ def lib():
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_fetch_async.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_fetch_wait.argtypes = [vp, i32]
+        L.hvk_frame_upload_pinned.argtypes = [vp, i32, vp, i32, i32, i32]
         L.hvk_host_alloc.argtypes = [vp, C.c_size_t]
         L.hvk_host_alloc.restype = vp
         L.hvk_host_free.argtypes = [vp, vp]
@@ -273,6 +274,15 @@ class Engine:
         out = np.zeros((count, 2), np.int16)
         self._chk("hvk_fetch", lib().hvk_fetch(self.h, out.ctypes.data, first, count))
         return out
+
+    def host_picture(self, height, width):
+        """(height, width) uint32 array over page-locked memory, for frame_upload_pinned()"""
+        return self.host_buffer(height * width).view(np.uint32).reshape(height, width)
+
+    def frame_upload_pinned(self, slot, fb, interlaced=0):
+        """fb: an array from host_picture(); it must stay unchanged until the copy is through (sync / a later fetch)"""
+        h, w = fb.shape
+        return self._chk("hvk_frame_upload_pinned", lib().hvk_frame_upload_pinned(self.h, slot, fb.ctypes.data, w, h, interlaced))
 
     def host_buffer(self, count):
         """(count, 2) int16 array over page-locked memory (hvk_host_alloc); released with the engine's close()."""

@@ -137,6 +137,13 @@ int hvk_get_chroma_ghost(const hvk_engine_t *e, int16_t *ghost, int n);
 int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height,
                      int pixel_stride, int line_stride, int interlaced);
 
+/* hvk_frame_upload() for a picture in page-locked memory (hvk_host_alloc()), pixels adjacent, rows `width` pixels
+ * apart: nothing is copied on the host, the centre crop goes from where it lies into the slot by one strided DMA queued
+ * on the engine's stream. The picture must stay as it is until that copy is through -- hvk_sync(), or the return of
+ * the hvk_fetch() / hvk_fetch_wait() of a batch staged after this call. (SECAM engines keep a host copy of every
+ * picture and take the ordinary way.) A source that decodes into such memory uploads at PCIe speed. */
+int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height, int interlaced);
+
 /* The pixel aspect ratio of the frame in `slot` (av_frame_t.pixel_aspect_ratio, src/av.h:43):
  * only `--wss auto` (conf.wss == 0xFF) looks at it (src/wss.c:166-179). 1:1 unless set. */
 int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den);

@@ -207,3 +207,22 @@ def test_dropin_resident_set_does_not_grow_with_the_run(flags):
         p.kill()
         p.wait()
     assert len(rss) == 8 and rss[-1] <= rss[3] + 16, rss
+
+
+@pytest.mark.parametrize("shape", [(576, 832), (600, 900), (300, 500)])
+def test_pictures_uploaded_from_page_locked_memory(golden, shape):
+    """hvk_frame_upload_pinned(): a picture that lies in page-locked memory goes to its slot by one strided copy --
+    exact size, larger than the active area (centre crop) and smaller (borders): the same samples as through the
+    ordinary upload."""
+    rng = np.random.default_rng(shape[0])
+    pics = [rng.integers(0, 1 << 24, size=shape, dtype=np.uint32) for _ in range(2)]
+    c = H.preset("i", H.FLAG_FILTER | H.FLAG_NOAUDIO)
+    with H.Engine(c, 16000000, max_frames=2) as a, H.Engine(c, 16000000, max_frames=2) as b:
+        host = [b.host_picture(*shape) for _ in range(2)]
+        for i in range(2):
+            a.frame_upload(i, pics[i])
+            host[i][:] = pics[i]
+            b.frame_upload_pinned(i, host[i])
+        a.render(2, slots=[0, 1])
+        b.render(2, slots=[0, 1])
+        assert np.array_equal(a.fetch(0, 2 * 640000), b.fetch(0, 2 * 640000))
