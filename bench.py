@@ -148,7 +148,12 @@ def main():
     F = args.frames
     e = H.Engine(conf, SAMPLE_RATE, device=local_rank, max_frames=F)
     FS = e.info["frame_samples"]
-    stream = torch.cuda.current_stream()
+    # A stream of our own, made torch's current one: the engine launches on it (a null handle would send the engine
+    # back to its private stream), and RCCL's point-to-point operations order themselves behind torch's CURRENT stream --
+    # the send of a block has to wait for the render that was just enqueued there.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     e.set_stream(ctypes.c_void_p(stream.cuda_stream))
     e.frame_upload(0, g.frame("i_full"))
     gather = N > 1 and not args.no_gather
