@@ -258,6 +258,9 @@ int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)
 		if(!line) return(HVK_OUT_OF_MEMORY);
 	}
 
+	/* the offset phasor has run over the pipeline's start-up samples as well (they pass through every process) */
+	if(offset) while(s->off_steps < s->prime + first) (void) _offset_step(s);
+
 	for(n = 0; n < count; n++)
 	{
 		int16_t i, q;

@@ -67,6 +67,8 @@ CASES = [
     ("palfm_f14",     "pal-fm",   14000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     ("ntscfm_f18",    "ntsc-fm",  18000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     ("secamfm_f2025", "secam-fm", 20250000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
+    # ... and the rest of the tail behind it: the pipeline's start-up samples go through swap, offset and passthru too
+    ("palfm_f14_tail", "pal-fm",  14000000, ["--filter", "--swap-iq", "--offset", "400000", "--passthru", "@PASS@"], refprobe.FLAG_FILTER, False, 3, {"swap_iq": 1, "offset": 400000, "passthru": 1}),
     # NICAM at the top of the range of sample rates (its pulse is 373 taps long there)
     ("i_27m",         "i",        27000000, ["--filter"],          refprobe.FLAG_FILTER,                   False, 2),
     # teletext from a raw packet file (tests/golden/ttraw.bin: 42-byte records, no wall clock involved)
