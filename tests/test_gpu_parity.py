@@ -655,12 +655,29 @@ def test_odd_line_widths(golden, mode, sr):
     ("secam", 16000000, 20250000, {"secam_field_id": 1, "secam_field_id_lines": 5}),   # down 64 / 81
     ("pal", 13500000, 0, {"s_video": 1, "vits": 1}),
     ("i", 14000000, 0, {"interlace": 1, "acp": 1}),
+    # FM video with its pre-emphasis filter and the rest of the tail behind it
+    ("pal-fm", 14000000, 0, {"_filter": 1, "offset": -300000}),
+    ("secam-fm", 20250000, 0, {"_filter": 1, "swap_iq": 1, "offset": 222222}),
+    ("ntsc-fm", 18000000, 0, {"_filter": 1, "offset": 123456}),
+    # the presets added this round, with options on top
+    ("pal-m", 13500000, 0, {"vits": 1, "vitc": 1, "cc608": 1}),
+    ("pal-n", 16000000, 0, {"wss": 0x07, "teletext": 1}),
+    ("secam-b", 16000000, 0, {"secam_field_id": 1, "vits": 1}),
+    ("d", 20250000, 0, {"vitc": 1}),
+    ("k", 14000000, 16000000, {}),                                                    # SECAM through the resampler (down 7 / 8)
+    ("pal60", 13500000, 0, {"acp": 1}),
+    ("525pal", 13500000, 0, {"s_video": 1}),
+    ("secam-i", 18000000, 0, {}),
+    ("i", 27000000, 0, {"teletext": 1, "vits": 1}),                                    # NICAM's longest pulse + VBI
+    ("l", 16000000, 0, {"interlace": 1, "secam_field_id": 1}),                         # the SECAM chain, a picture per field
 ])
 def test_options_at_other_rates(golden, mode, sr, pr, members):
     """The optional stages away from 16 MHz (their tables scale with the pixel rate: symbol widths,
     pulse positions, the resampler's phases) with random pictures and teletext packets: device against
     the oracle."""
-    conf = H.preset(mode, H.FLAG_FILTER if not mode.endswith("-fm") and not members.get("s_video") else 0)
+    members = dict(members)
+    want_filter = members.pop("_filter", 0) or (not mode.endswith("-fm") and not members.get("s_video"))
+    conf = H.preset(mode, H.FLAG_FILTER if want_filter else 0)
     for k, v in members.items():
         setattr(conf, k, v)
     n = 2
