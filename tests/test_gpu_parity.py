@@ -670,6 +670,20 @@ def test_odd_line_widths(golden, mode, sr):
     ("secam-i", 18000000, 0, {}),
     ("i", 27000000, 0, {"teletext": 1, "vits": 1}),                                    # NICAM's longest pulse + VBI
     ("l", 16000000, 0, {"interlace": 1, "secam_field_id": 1}),                         # the SECAM chain, a picture per field
+    # a second round of combinations nothing else covers
+    ("l", 20250000, 16000000, {"interlace": 1}),
+    ("secam", 16000000, 0, {"s_video": 1, "secam_field_id": 1}),
+    ("b", 16000000, 0, {"a2stereo": 1, "vitc": 1}),
+    ("d", 16000000, 0, {"teletext": 1, "wss": 0x0D, "vits": 1, "vitc": 1, "secam_field_id": 1}),
+    ("pal-d", 13500000, 16000000, {"vits": 1}),
+    ("ntsc", 13500000, 0, {"s_video": 1, "vitc": 1, "cc608": 1}),
+    ("m", 20250000, 13500000, {"cc608": 1, "acp": 1}),
+    ("pal-fm", 20250000, 0, {"_filter": 1}),
+    ("ntsc-fm", 14000000, 0, {"_filter": 1, "swap_iq": 1}),
+    ("i", 16000000, 0, {"invert_video": 1, "vits": 1, "offset": 500000}),
+    ("pal60-i", 16000000, 0, {"cc608": 1}),
+    ("i", 12000000, 0, {"wss": 0x08}),
+    ("secam-g", 16000000, 0, {"a2stereo": 1}),
 ])
 def test_options_at_other_rates(golden, mode, sr, pr, members):
     """The optional stages away from 16 MHz (their tables scale with the pixel rate: symbol widths,
