@@ -310,6 +310,12 @@ SHIM_CHECK_CASES = [
     ("i", 20250000, 3, 1 | 4, 13500000),
     ("pal", 14000000, 3, 2, 13500000),
     ("g", 13500000, 3, 128, 0),
+    ("secam-b", 16000000, 3, 1 | 64, 0), # the SECAM chain on the device, a picture per field, the source ends
+    ("l", 20250000, 4, 1 | 4, 16000000),
+    ("pal-m", 13500000, 3, 1 | 4 | 8 | 32, 0),
+    ("pal-fm", 14000000, 3, 1, 0),       # FM video with its pre-emphasis filter
+    ("d", 16000000, 3, 1, 0),
+    ("ntsc-i", 13500000, 3, 1, 0),
 ]
 
 
