@@ -30,7 +30,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
-#include <stdio.h>
 #include "hvk_internal.h"
 #include "hvk_secam_chain.h"
 
@@ -378,9 +377,6 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 			for(i = 0; i < n; i++)
 			{
 				if(_same_state(&s->entry[i], &st)) { st = s->exit[i]; continue; }
-				if(getenv("HVK_SECAM_DEBUG") && s->n_mismatch < 12)
-					fprintf(stderr, "task %d (line %d): entry ix %.17g iy %.17g tail %d %d | true ix %.17g iy %.17g tail %d %d\n", i, i < nprime ? 0 : T[i - nprime].line,
-						s->entry[i].ix, s->entry[i].iy, s->entry[i].tail[0], s->entry[i].tail[1], st.ix, st.iy, st.tail[0], st.tail[1]);
 				s->n_mismatch++;
 				s->n_repaired++;
 				TASK_RUN(i, &st, TASK_OUT(i));
