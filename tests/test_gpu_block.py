@@ -226,3 +226,36 @@ def test_pictures_uploaded_from_page_locked_memory(golden, shape):
         a.render(2, slots=[0, 1])
         b.render(2, slots=[0, 1])
         assert np.array_equal(a.fetch(0, 2 * 640000), b.fetch(0, 2 * 640000))
+
+
+def test_two_minutes_in_the_stream_still_equals_the_reference():
+    """Frames 3350 .. 3361 of `-m i -s 16000000 --filter test` -- where the sample index passes 2^31, after 65 000
+    re-normalisations of the sound phasor and 134 000 NICAM frames -- from the drop-in binary and from the unmodified
+    reference CLI: the same bytes."""
+    ref, hvk = os.path.join(REF, "hacktv_ref"), os.path.join(REF, "hacktv_hvk")
+    if not (os.path.exists(ref) and os.path.exists(hvk)):
+        pytest.skip("oracle/_ref binaries not built")
+    flags = ["-m", "i", "-s", "16000000", "--filter", "-o", "-", "test"]
+    skip, take = 3350 * 2560000, 12 * 2560000
+
+    def digest(exe, env=None):
+        p = subprocess.Popen([exe] + flags, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        try:
+            left = skip
+            while left > 0:
+                n = len(p.stdout.read(min(left, 1 << 24)))
+                assert n, "ended early"
+                left -= n
+            h, left = hashlib.sha256(), take
+            while left > 0:
+                chunk = p.stdout.read(min(left, 1 << 24))
+                assert chunk, "ended early"
+                h.update(chunk)
+                left -= len(chunk)
+            return h.hexdigest()
+        finally:
+            p.kill()
+            p.wait()
+
+    got = digest(hvk, dict(os.environ, HVK_BATCH="32"))
+    assert got == digest(ref)
