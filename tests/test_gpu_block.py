@@ -228,15 +228,17 @@ def test_pictures_uploaded_from_page_locked_memory(golden, shape):
         assert np.array_equal(a.fetch(0, 2 * 640000), b.fetch(0, 2 * 640000))
 
 
-def test_two_minutes_in_the_stream_still_equals_the_reference():
+@pytest.mark.parametrize("mode,first", [("i", 3350), ("l", 1000)])
+def test_two_minutes_in_the_stream_still_equals_the_reference(mode, first):
     """Frames 3350 .. 3361 of `-m i -s 16000000 --filter test` -- where the sample index passes 2^31, after 65 000
     re-normalisations of the sound phasor and 134 000 NICAM frames -- from the drop-in binary and from the unmodified
-    reference CLI: the same bytes."""
+    reference CLI: the same bytes. And frames 1000 .. 1011 of SECAM-L: 578 000 lines into the colour sub-carrier's
+    chain, batch after batch on the device."""
     ref, hvk = os.path.join(REF, "hacktv_ref"), os.path.join(REF, "hacktv_hvk")
     if not (os.path.exists(ref) and os.path.exists(hvk)):
         pytest.skip("oracle/_ref binaries not built")
-    flags = ["-m", "i", "-s", "16000000", "--filter", "-o", "-", "test"]
-    skip, take = 3350 * 2560000, 12 * 2560000
+    flags = ["-m", mode, "-s", "16000000", "--filter", "-o", "-", "test"]
+    skip, take = first * 2560000, 12 * 2560000
 
     def digest(exe, env=None):
         p = subprocess.Popen([exe] + flags, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
