@@ -69,6 +69,7 @@ typedef struct {
 	int have;               /* frames rendered in iq */
 	/* the next batch is pulled, rendered and fetched by a worker thread while this one goes out */
 	int16_t *buf[2];
+	int source_closed;      /* main() has closed a source: the stream ends there (see _hooked_close) */
 	int pinned;             /* buf[] came from hvk_host_alloc() */
 	int ticket[2];          /* hvk_fetch_async() ticket of the buffer's read-back; the consumer waits for it */
 	/* HVK_SHIM_STATS=1: where the time of both threads went, printed by vid_free() */
@@ -129,13 +130,17 @@ static void _dbg_usr1(int sig)
  * is safe there. Here a worker thread reads ahead: it has to be off the source before the source's close callback
  * frees what it reads (a test card freed under the worker's copy is a segmentation fault -- which hacktv's handler
  * turns into an endless loop). The shim therefore puts its own close callback in front of the source's: it stops the
- * worker, then lets the source close. A source opened afterwards (hacktv plays its arguments one after the other)
- * starts a new worker on the next vid_next_line(). */
+ * worker, then lets the source close.
+ * hacktv plays its arguments one after the other (and over again with --repeat), and the reference's line pipeline
+ * carries the last lines of one source over into the next (the lines vid_next_line() withholds at the end, src/video.c
+ * :4876). That hand-over is not reproduced: the stream ends with the first source, and vid_next_line() says so once if
+ * it is asked for more. */
 #define SHIM_HOOKS 8
 static struct { void *ctx; vid_t *s; av_close_t close; } _hooks[SHIM_HOOKS];
 static pthread_mutex_t _hooks_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void _worker_stop(vid_t *s);
+static void _source_closed(vid_t *s);
 
 static int _hooked_close(void *ctx)
 {
@@ -156,7 +161,11 @@ static int _hooked_close(void *ctx)
 	}
 	pthread_mutex_unlock(&_hooks_lock);
 
-	if(s) _worker_stop(s);
+	if(s)
+	{
+		_worker_stop(s);
+		_source_closed(s);
+	}
 	return(orig ? orig(ctx) : AV_OK);
 }
 
@@ -294,6 +303,12 @@ static void _worker_stop(vid_t *s)
 	m->have = 0;
 	m->frame_in_batch = 0;
 	m->ended = 0;
+}
+
+static void _source_closed(vid_t *s)
+{
+	shim_t *m = _shim(s);
+	if(m) m->source_closed = 1;
 }
 
 static int _refuse(const char *what)
@@ -815,6 +830,13 @@ vid_line_t *vid_next_line(vid_t *s)
 	vid_line_t *l;
 
 	if(!m) return(NULL);
+
+	if(m->source_closed)
+	{
+		if(m->source_closed == 1) fprintf(stderr, "hacktv-amd: one source per run (the next one would start in the middle of the reference's line pipeline); stopping here\n");
+		m->source_closed = 2;
+		return(NULL);
+	}
 
 	if(m->frame_in_batch >= m->have)
 	{
