@@ -242,6 +242,9 @@ __device__ __forceinline__ int4 pack8(const int16_t *o)
 	return(po);
 }
 
+/* EMIT = false: a warm-up line -- only the state it leaves matters, so the output half of an FM step (level, bell-filter
+ * gain and its table read, burst window) is left out */
+template<bool EMIT>
 __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
 {
 	const int W = a.C.W, sl = a.C.sl;
@@ -291,11 +294,45 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			const double t2 = iy * -0.90456054;
 			iy = (t0 + t1) - t2;
 			ix = in;
-			y[j] = (int16_t) hvk_secam_round_away(iy < INT16_MIN ? INT16_MIN : (iy > INT16_MAX ? INT16_MAX : iy));
+			{
+				/* clamp-then-round (src/fir.c:729-733) == round-then-clamp: the bounds are whole numbers and rounding is
+				 * monotone; |iy| stays far below 2^31 (int16 in, a gain of a few tens), and the clamp is one v_med3_i32 */
+				const int32_t r = hvk_secam_round_away(iy);
+				y[j] = (int16_t) (r < INT16_MIN ? INT16_MIN : (r > INT16_MAX ? INT16_MAX : r));
+			}
 		}
 
 		const int x0 = ch * CH;
-		if(x0 + CH > sl && x0 < fm_end)
+		if(__all(x0 >= sl && x0 + CH <= fm_end))
+		{
+			/* the chunk lies inside the sub-carrier window of every line of the wave (all but the chunks at the window's
+			 * ends, and half lines): the same steps without a test per sample */
+			hvk_secam_c16_t g[CH];
+			hvk_secam_c32_t st[CH];
+#pragma unroll
+			for(int j = 0; j < CH; j++)
+			{
+				const int16_t c = y[j] < dmin ? dmin : (y[j] > dmax ? dmax : y[j]);
+				if(EMIT) g[j] = a.bell[(uint16_t) c];
+				st[j] = a.lut[(int32_t) c + 32768];
+			}
+#pragma unroll
+			for(int j = 0; j < CH; j++)
+			{
+				const int64_t ni = (int64_t) pi * st[j].i - (int64_t) pq * st[j].q;
+				const int64_t nq = (int64_t) pi * st[j].q + (int64_t) pq * st[j].i;
+				pi = (int32_t) (ni >> 31);
+				pq = (int32_t) (nq >> 31);
+				if(EMIT)
+				{
+					const int32_t vi = ((pi >> 16) * level) >> 15;
+					const int32_t vq = ((pq >> 16) * level) >> 15;
+					const int16_t vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
+					o[j] = (int16_t) ((vv * a.burst_win[x0 + j - sl]) >> 15);
+				}
+			}
+		}
+		else if(x0 + CH > sl && x0 < fm_end)
 		{
 			hvk_secam_c16_t g[CH];
 			hvk_secam_c32_t st[CH];
@@ -303,7 +340,7 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			for(int j = 0; j < CH; j++)
 			{
 				const int16_t c = y[j] < dmin ? dmin : (y[j] > dmax ? dmax : y[j]);
-				g[j] = a.bell[(uint16_t) c];
+				if(EMIT) g[j] = a.bell[(uint16_t) c];
 				st[j] = a.lut[(int32_t) c + 32768];
 			}
 #pragma unroll
@@ -318,10 +355,13 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 					const int64_t nq = (int64_t) pi * st[j].q + (int64_t) pq * st[j].i;
 					pi = (int32_t) (ni >> 31);
 					pq = (int32_t) (nq >> 31);
-					const int32_t vi = ((pi >> 16) * level) >> 15;
-					const int32_t vq = ((pq >> 16) * level) >> 15;
-					vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
-					vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
+					if(EMIT)
+					{
+						const int32_t vi = ((pi >> 16) * level) >> 15;
+						const int32_t vq = ((pq >> 16) * level) >> 15;
+						vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
+						vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
+					}
 				}
 				o[j] = vv;
 			}
@@ -332,7 +372,7 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			for(int j = 0; j < CH; j++) o[j] = 0;
 		}
 
-		if(out)
+		if(EMIT && out)
 		{
 			*(int4 *) (out + x0) = pack8(o);
 			*(int4 *) (out + x0 + 8) = pack8(o + 8);
@@ -355,7 +395,8 @@ __device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m,
 	const task_view v = task_of(a, m);
 	if(!v.valid) return;
 	if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
-	walk_line(a, m, v, S, emit ? out_of(a, v) : NULL);
+	if(emit) walk_line<true>(a, m, v, S, out_of(a, v));
+	else walk_line<false>(a, m, v, S, NULL);
 }
 
 /* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than four waves per SIMD hold:
