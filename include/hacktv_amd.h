@@ -31,7 +31,14 @@
  *                         buffers the reference hands to rf_write()
  *                         (src/hacktv.c:1579-1587).
  *   hvk_fetch()           copies rendered samples to a host buffer for a
- *                         host-side rf_* sink.
+ *                         host-side rf_* sink; hvk_fetch_async() /
+ *                         hvk_fetch_wait() queue that copy behind the render
+ *                         (page-locked buffers: hvk_host_alloc()) so that it
+ *                         runs beside the next batch's host work.
+ *
+ * SECAM's colour sub-carrier -- in the reference one chain over every line of
+ * the stream -- is computed on the device as well, every line from a derived
+ * entry state that is then checked bit for bit (hvk_secam_stats()).
  *
  * All entry points return HVK_OK (0) or a negative HVK_* code, like the
  * reference's VID_OK / VID_ERROR / VID_OUT_OF_MEMORY (src/video.h:45-47).
