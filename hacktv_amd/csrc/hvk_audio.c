@@ -640,6 +640,91 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 		return;
 	}
 
+	if(a->fm.on && a->a2.on && !a->am.on)
+	{
+		/* Zweikanalton: four recurrences per sample -- the first carrier, the identification tone, the pilot it
+		 * modulates, and the second carrier whose step follows right channel + pilot (src/video.c:3402-3424). They
+		 * depend on one another only through values, not through state: with all four phases in registers the core
+		 * works on them side by side. Same operations, same order per phasor as the general loop below. */
+		const hvk_tables_t *t = a->t;
+		const hvk_c32_t fm_step = t->fm_lut[a->fm.sample - INT16_MIN];
+		const hvk_c32_t sg_step = t->a2_signal_delta, pl_step = t->a2_pilot_delta;
+		const int16_t m0 = t->a2_system_m ? (int16_t) (a->fm.sample - a->a2.sample) : a->a2.sample;
+		const int32_t fm_level = a->fm.level, a2_level = a->a2.level, sg_level = a->a2_signal.level, pl_level = a->a2_pilot.level;
+		int32_t fi = a->fm.pi, fq = a->fm.pq, si = a->a2_signal.pi, sq = a->a2_signal.pq;
+		int32_t li = a->a2_pilot.pi, lq = a->a2_pilot.pq, ci = a->a2.pi, cq = a->a2.pq;
+		int32_t fc = a->fm.counter, sc = a->a2_signal.counter, lc = a->a2_pilot.counter, cc = a->a2.counter;
+
+#define A2_MUL(pi_, pq_, st_) \
+	do { \
+		const int64_t ni_ = (int64_t) (pi_) * (st_).i - (int64_t) (pq_) * (st_).q; \
+		const int64_t nq_ = (int64_t) (pi_) * (st_).q + (int64_t) (pq_) * (st_).i; \
+		(pi_) = (int32_t) (ni_ >> 31); \
+		(pq_) = (int32_t) (nq_ >> 31); \
+	} while(0)
+#define A2_FIX(pi_, pq_, cnt_) \
+	do { \
+		if((cnt_) == 0) \
+		{ \
+			const double ra_ = atan2((pq_), (pi_)); \
+			(pi_) = lround(cos(ra_) * INT32_MAX); \
+			(pq_) = lround(sin(ra_) * INT32_MAX); \
+			(cnt_) = INT16_MAX; \
+		} \
+	} while(0)
+
+		x = x0;
+		while(x < x1)
+		{
+			int run = x1 - x, i;
+			int16_t *o = carriers + (size_t) x * 2;
+			if(run > fc) run = fc;
+			if(run > sc) run = sc;
+			if(run > lc) run = lc;
+			if(run > cc) run = cc;
+			for(i = 0; i < run; i++)
+			{
+				int32_t tone, pilot;
+				int16_t m, ai, aq;
+				hvk_c32_t st;
+
+				A2_MUL(fi, fq, fm_step);
+				ai = (int16_t) (((fi >> 16) * fm_level) >> 15);
+				aq = (int16_t) (((fq >> 16) * fm_level) >> 15);
+
+				A2_MUL(si, sq, sg_step);
+				tone = (int16_t) (((((si >> 16) * 16384) >> 15) * sg_level) >> 15);
+
+				A2_MUL(li, lq, pl_step);
+				pilot = (int16_t) (((((li >> 16) * ((tone - INT16_MIN) / 2)) >> 15) * pl_level) >> 15);
+
+				m = (int16_t) (m0 + pilot);
+				st = t->a2_lut[m - INT16_MIN];
+				A2_MUL(ci, cq, st);
+				ai += (int16_t) (((ci >> 16) * a2_level) >> 15);
+				aq += (int16_t) (((cq >> 16) * a2_level) >> 15);
+
+				o[i * 2 + 0] = ai;
+				o[i * 2 + 1] = aq;
+			}
+			x += run;
+			fc -= run; sc -= run; lc -= run; cc -= run;
+			/* amplitude drift correction every INT16_MAX steps of a phasor (src/video.c:2266-2275) */
+			A2_FIX(fi, fq, fc);
+			A2_FIX(si, sq, sc);
+			A2_FIX(li, lq, lc);
+			A2_FIX(ci, cq, cc);
+		}
+#undef A2_MUL
+#undef A2_FIX
+
+		a->fm.pi = fi; a->fm.pq = fq; a->fm.counter = fc;
+		a->a2_signal.pi = si; a->a2_signal.pq = sq; a->a2_signal.counter = sc;
+		a->a2_pilot.pi = li; a->a2_pilot.pq = lq; a->a2_pilot.counter = lc;
+		a->a2.pi = ci; a->a2.pq = cq; a->a2.counter = cc;
+		return;
+	}
+
 	{
 		/* the step is constant between two 32 kHz ticks */
 		const hvk_c32_t fm_step = a->fm.on ? a->t->fm_lut[a->fm.sample - INT16_MIN] : (hvk_c32_t) { 0, 0 };
