@@ -628,8 +628,8 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		/* SECAM lines with picture (src/video.c:3202-3229): first the luma notch
 		 * over the active picture, a zero-history FIR whose input starts at
 		 * active_left (everything left of it counts as zero) and which looks 25
-		 * samples past the picture's right edge; then the sub-carrier, computed in
-		 * stream order by the host (hvk_secam.c), is added. */
+		 * samples past the picture's right edge; then the sub-carrier -- the colour chain's
+		 * output, hvk_secam.hip (or the host's hvk_secam.c) -- is added. */
 		constexpr int NH = 25, NLEAD = 26;
 		int16_t *Z = lds + YL;                  /* index j <-> sample x = j - NLEAD */
 

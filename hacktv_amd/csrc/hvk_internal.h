@@ -90,7 +90,7 @@ typedef struct {
 	int32_t out_prime;      /* samples of the never-emitted start-up lines the audio / tail processes run over */
 	int32_t rs_L, rs_D, rs_ataps;   /* --pixelrate poly-phase resampler: interpolation, decimation, taps per phase; rs_L == 0: none */
 	int32_t rs_shift;       /* resampled-stream index (frame local) of output sample 0's filter centre */
-	int32_t secam;          /* SECAM: luma notch + host-computed chroma side stream */
+	int32_t secam;          /* SECAM: luma notch + the FM sub-carrier stream (hvk_secam.hip; hvk_secam.c where the device does not take it) */
 	int32_t teletext;       /* teletext symbol table present */
 	int32_t vbi;            /* VBI data lines (teletext / WSS / VITC ops) may be present */
 	int32_t vits;           /* insertion test signals: 0 none, else the number of VITS lines (2 or 4) */
@@ -194,7 +194,7 @@ int hvk_acp_agc_level(const hvk_tables_t *t, int frame);
 /* CC608: the 17 bits of a caption byte pair, LSB first (src/cc608.c:170-186) */
 void hvk_cc608_bits(uint8_t c1, uint8_t c2, uint8_t data[3]);
 
-/* Host SECAM colour pre-pass (hvk_secam.c) */
+/* SECAM colour sub-carrier on the host: the serial chain (hvk_secam.c; the device has its own way, hvk_secam.hip) */
 #include "hvk_secam_chain.h"
 typedef struct hvk_secam hvk_secam_t;
 hvk_secam_t *hvk_secam_new(const hvk_tables_t *t);

@@ -36,7 +36,7 @@
  *   hvk_k_convert      the file sink's sample formats (src/rf_file.c:34-277).
  *
  * Inside hvk_k_raster, behind wave-uniform tests that cost the plain path a
- * scalar compare each: SECAM (luma notch + the host's FM sub-carrier stream),
+ * scalar compare each: SECAM (luma notch + the FM sub-carrier stream of hvk_secam.hip),
  * insertion test signals, and the VBI data lines (teletext, WSS, VITC, CC608
  * symbols from one table store; anti-copy pulse runs) listed per frame by the
  * host. S-Video has kernel variants of its own (template parameter).
