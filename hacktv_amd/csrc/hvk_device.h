@@ -297,7 +297,7 @@ __device__ __forceinline__ void raster_load_rgb(const hvk_kconst_t &k, const hvk
 
 /* ALWAYS: every load goes out whatever the line is (at a clamped position where it has no use): no branch
  * for the compiler to put a wait behind */
-template<int NT, int WC, int ALWAYS = 0>
+template<int NT, int WC, int ALWAYS = 0, int NOCLUT = 0>
 __device__ __forceinline__ void raster_load_side(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t,
                                                  hvk_side_t &sd, int (&c)[SPL])
 {
@@ -339,6 +339,7 @@ __device__ __forceinline__ void raster_load_side(const hvk_kconst_t &k, const hv
 	}
 #pragma unroll
 	for(int i = 0; i < SPL; i++) c[i] = 0;
+	if(NOCLUT) return;                      /* the picture planes are made without the sub-carrier (hvk_k_prep) */
 	if((L.pal || (L.vits_i >= 0 && k.colour)) && x0 < W && !ABLATE(4))
 	{
 		const int *cl = P.clut + L.coff + x0;
@@ -355,12 +356,12 @@ __device__ __forceinline__ void raster_load_side(const hvk_kconst_t &k, const hv
 	}
 }
 
-template<int NT, int WC, int PASSES = HVK_PIX_PASSES>
+template<int NT, int WC, int PASSES = HVK_PIX_PASSES, int NOCLUT = 0>
 __device__ __forceinline__ void raster_loads(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const int t, const int nth,
                                              uint32_t (&rgb)[HVK_PIX_PASSES], hvk_side_t &sd, int (&c)[SPL])
 {
 	raster_load_rgb<PASSES>(k, P, L, t, nth, rgb);
-	raster_load_side<NT, WC>(k, P, L, t, sd, c);
+	raster_load_side<NT, WC, 0, NOCLUT>(k, P, L, t, sd, c);
 }
 
 /* LDS layout of the raster (int16 elements):
@@ -469,7 +470,9 @@ __device__ __forceinline__ void raster_pixels(const hvk_kconst_t &k, const hvk_r
  * low 16 bits count), cq[] the Q channel of --s-video. `lds` is the raster's whole LDS area (Y, U, V:
  * the SECAM notch and the VBI data lines re-use it). `slab_line`: the line's index in the raw baseband
  * slab (hvk_k_raster's blockIdx.x). Lanes at or beyond the line's end take part in the barriers. */
-template<int NT, int SECAM, int SV, int EXTRAS, int WC>
+/* PREP: the line WITHOUT its sub-carrier, for the picture planes (hvk_k_prep): s[] is what the chroma
+ * is added to, c[] receives the (V, U) pairs the modulator multiplies the phasors by (burst included). */
+template<int NT, int SECAM, int SV, int EXTRAS, int WC, int PREP = 0>
 __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L,
                                                const hvk_packed_taps_t &ctaps, const hvk_packed_taps_t &notch,
                                                const int y, const int slab_line, const int t, const int nth,
@@ -605,12 +608,18 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		 *   s += (lut.i * V * pal + lut.q * U) >> 15
 		 * as one dot2 of the packed table entry (i, q) with (V, U); the PAL switch
 		 * negates lut.i, which never is -32768. */
-		if(pal < 0)
+		if(PREP)
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) c[i] = vu[i];
+		}
+		else if(pal < 0)
 		{
 #pragma unroll
 			for(int i = 0; i < SPL; i++) c[i] = (c[i] & 0xFFFF0000) | ((0 - c[i]) & 0xFFFF);
 		}
-		if(SV)
+		if(PREP) { }
+		else if(SV)
 		{
 			/* S-Video: onto the (empty) Q channel instead of the luma (src/video.c:3032) */
 #pragma unroll
@@ -791,6 +800,140 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 				for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
 			}
 		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* stages of a filter tile shared by hvk_k_filter and hvk_k_direct     */
+
+/* One NICAM symbol slot of a tile's table (src/nicam728.c:33, :386-407): `v` is the host's word for
+ * the slot (start << 3 | valid << 2 | value), n0 the tile's first sample. sym_st gets the start
+ * relative to the tile, sym_ent { LEAD - start, offset of the shifted pulse copy, sign pair I, sign pair Q }. */
+__device__ __forceinline__ void nicam_symbol_slot(const int v, const int n0, int *sym_st, int4v *sym_ent, const int slot)
+{
+	const int st = (v >> 3) - n0;
+	const bool valid = (v & 4) && st < HVK_TILE;
+	/* constellation { 0, 1, 3, 2 }: bit 0 -> +I else -I, bit 1 -> +Q else -Q
+	 * (src/nicam728.c:33, :386-396) */
+	const int cs = (0x2310 >> ((v & 3) * 4)) & 3;
+	sym_st[slot] = valid ? st : 0x3FFFFFFF;
+	/* x0 is a multiple of 8, so which of the four shifted copies of the pulse
+	 * table a lane needs depends on the symbol only. A slot without a symbol
+	 * gets an offset that clamps into the table's zero tail. */
+	const int rel = HVK_NICAM_LEAD - st;
+	/* +1 or -1 in both halves: the pulse shapes two samples of a channel per packed multiply-add */
+	const int sgi = (cs & 1) ? 0x00010001 : (int) 0xFFFFFFFFu;
+	const int sgq = (cs & 2) ? 0x00010001 : (int) 0xFFFFFFFFu;
+	sym_ent[slot] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgi, sgq }
+	                      : (int4v) { 0x10000000, 0, 0, 0 };
+}
+
+/* NICAM onto a lane's 8 packed (I, Q) outputs: sum the pulses of the symbols in flight (int16
+ * wrap-around per channel, both channels in one packed multiply-add), mix, add
+ * (src/nicam728.c:350-365, :386-396). mix_a0 / mix_a1: the mixer row (i, -q) of the lane's samples. */
+__device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, const int *sym_st, const int4v *sym_ent, const int16_t *tapd,
+                                          const int4u mix_a0, const int4u mix_a1, int (&o)[SPL])
+{
+	const int last = x0 + SPL - 1;          /* relative to the tile's first sample */
+	/* newest symbol that has started by this lane's last sample; slot
+	 * HVK_NICAM_BACK - 1 holds the newest one at the tile's first sample */
+	int idx = HVK_NICAM_BACK - 1 + (int) ((float) last * (1.0f / (float) k.nicam_sps));
+	if(idx > HVK_NICAM_SYMS - 2) idx = HVK_NICAM_SYMS - 2;
+	while(idx + 1 < HVK_NICAM_SYMS && sym_st[idx + 1] <= last) idx++;
+	while(idx > 0 && sym_st[idx] > last) idx--;
+
+	/* I and Q apart while the pulses are summed: (I[2m], I[2m + 1]) and (Q[2m], Q[2m + 1]) */
+	int bi[SPL / 2], bq[SPL / 2];
+#pragma unroll
+	for(int i = 0; i < SPL / 2; i++) bi[i] = bq[i] = 0;
+
+	/* the newest symbol and the six before it: everything older is over. A pulse
+	 * that is over (or a slot without a symbol) reads the zero tail of the table:
+	 * no branch. idx >= HVK_NICAM_BACK - 1 by construction. */
+#pragma unroll 1
+	for(int b = 0; b < (ABLATE(32) ? 0 : HVK_NICAM_BACK); b++)
+	{
+		const int4v en = sym_ent[idx - b];
+		int base = x0 + en.x;                                   /* >= 1 */
+		base = base < HVK_NICAM_TAPD - SPL ? base : HVK_NICAM_TAPD - SPL;
+		const int2v *tp = (const int2v *) (tapd + en.y + (base & ~3));
+		const int2v ta = tp[0], tb = tp[1];
+		bi[0] = pk_mad16(ta.x, en.z, bi[0]); bi[1] = pk_mad16(ta.y, en.z, bi[1]);
+		bi[2] = pk_mad16(tb.x, en.z, bi[2]); bi[3] = pk_mad16(tb.y, en.z, bi[3]);
+		bq[0] = pk_mad16(ta.x, en.w, bq[0]); bq[1] = pk_mad16(ta.y, en.w, bq[1]);
+		bq[2] = pk_mad16(tb.x, en.w, bq[2]); bq[3] = pk_mad16(tb.y, en.w, bq[3]);
+	}
+
+	int bb[SPL];                            /* (I, Q) of each sample */
+#pragma unroll
+	for(int m = 0; m < SPL / 2; m++)
+	{
+		bb[2 * m + 0] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x05040100u);
+		bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
+	}
+
+	/* mixer: the rotation's first row (i, -q) is tabulated (loaded before the filter) */
+	if(!ABLATE(64))
+	{
+		const int ca[SPL] = { mix_a0.x, mix_a0.y, mix_a0.z, mix_a0.w, mix_a1.x, mix_a1.y, mix_a1.z, mix_a1.w };
+		/* the second row (q, i) from the first (i, -q): halves swapped, the low one negated (|q| <= 32767) */
+		int cq[SPL];
+#pragma unroll
+		for(int i = 0; i < SPL; i++) cq[i] = pk_mad16(shift_pair(ca[i], ca[i]), (int) 0x0001FFFFu, 0);
+#pragma unroll
+		for(int i = 0; i < SPL; i++)
+		{
+			const int mi = dot2(bb[i], ca[i], 0);           /* bb.i * cc.i - bb.q * cc.q */
+			const int mq = dot2(bb[i], cq[i], 0);           /* bb.i * cc.q + bb.q * cc.i */
+			/* ((mi >> 15) & 0xFFFF) | ((mq >> 15) << 16) */
+			const int pk = (int) ((((unsigned) mq << 1) & 0xFFFF0000u) | (((unsigned) mi >> 15) & 0xFFFFu));
+			o[i] = pk_add16(o[i], pk);
+		}
+	}
+}
+
+/* A lane's 8 window samples (four dwords of int16 pairs) as 8 bytes of the high-byte plane and 8 of the
+ * low-byte plane (low bytes less 128: read as signed after ^ 0x80) -- the operands of the int8 matrix unit */
+__device__ __forceinline__ void split_planes(const int4u d, int2v &ph, int2v &pl)
+{
+	ph.x = (int) __builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x07050301u);
+	ph.y = (int) __builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x07050301u);
+	pl.x = (int) (__builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x06040200u) ^ 0x80808080u);
+	pl.y = (int) (__builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x06040200u) ^ 0x80808080u);
+}
+
+/* The 51-tap filter of one wave's 512 outputs as a banded matrix product on the matrix unit. A wave takes
+ * 64 segments of 8 outputs, 16 segments (the columns of B) per v_mfma_i32_16x16x64_i8: lane (g, c) hands
+ * over window positions 16 g .. 16 g + 15 of segment c, which are 16 consecutive bytes of a plane, and gets
+ * back rows 4 g .. 4 g + 3 = outputs 2 g, 2 g + 1 of that segment, I and Q. Four products (high / low byte
+ * of taps and samples), recombined with two shift-adds; the constant of the low plane's offset starts the
+ * low accumulator. Then >> 15 and the saturating pack (src/fir.c:605-608), into `outl` (packed I/Q, indexed
+ * by output) for the lane that owns the 8 outputs. xh / xl: the planes, position 0 = 26 samples before the
+ * tile's first output; t: lane of the tile (0 .. 127). */
+__device__ __forceinline__ void mfma_filter(const unsigned char *xh, const unsigned char *xl, int *outl, const int t,
+                                            const int4v a_hh, const int4v a_hl, const int mfma_ci, const int mfma_cq)
+{
+	const int lane = t & 63, g = lane >> 4, c = lane & 15;
+#pragma unroll
+	for(int j = 0; j < 4; j++)
+	{
+		const int seg = (t >> 6) * 64 + j * 16 + c;
+		const int off = seg * 8 + g * 16;
+		int4v bh, bl;
+		bh.xy = *(const int2v *) (xh + off); bh.zw = *(const int2v *) (xh + off + 8);
+		bl.xy = *(const int2v *) (xl + off); bl.zw = *(const int2v *) (xl + off + 8);
+		int4v p_hh = { 0, 0, 0, 0 }, p_m = { 0, 0, 0, 0 }, p_ll = { mfma_ci, mfma_cq, mfma_ci, mfma_cq };
+		p_hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bh, p_hh, 0, 0, 0);
+		p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bh, p_m, 0, 0, 0);
+		p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bl, p_m, 0, 0, 0);
+		p_ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bl, p_ll, 0, 0, 0);
+		int y[4];
+#pragma unroll
+		for(int i = 0; i < 4; i++) y[i] = (int) ((((unsigned) p_hh[i] << 8) + (unsigned) p_m[i]) << 8) + p_ll[i];
+		int2v pk;
+		pk.x = sat_pack16(y[0] >> 15, y[1] >> 15);
+		pk.y = sat_pack16(y[2] >> 15, y[3] >> 15);
+		*(int2v *) (outl + seg * 8 + 2 * g) = pk;
 	}
 }
 

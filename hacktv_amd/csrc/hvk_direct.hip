@@ -1,0 +1,434 @@
+/* hvk_direct.hip -- the plain configurations' render in ONE kernel, from picture planes.
+ *
+ * What the reference does per scanline in _vid_next_line_raster (src/video.c:2864-3066) falls into two
+ * parts. Everything up to the modulator depends on the PICTURE and the line's place in the frame only:
+ * sync pulses, the RGB -> level look-ups, the chroma low pass with its over-read, the burst. The
+ * modulator -- multiplying (V, U) by the sub-carrier phasor of the sample's position in the STREAM --
+ * and all that follows (video filter, sound carriers, NICAM) depends on where in the stream the frame
+ * stands. The engine therefore does the first part once per uploaded picture:
+ *
+ *   hvk_k_prep     one workgroup per scanline of a picture (the raster stages of hvk_device.h):
+ *                  L plane  int16 [lines][width]  the line without its sub-carrier
+ *                  C plane  int32 [lines][width]  (V, U) after the low pass, burst written over it
+ *                  (parity independent: a frame's parity only decides the phasor's sign and whether a
+ *                  line carries chroma at all -- hvk_linedesc_t.pal)
+ *
+ * and the second part for every frame rendered:
+ *
+ *   hvk_k_direct   two waves per 1024 output samples, four such tiles per workgroup, 8 samples per
+ *                  lane. The raster sample at stream position p of line l, sample x is
+ *                      L[l][x] + ((i * V * pal + q * U) >> 15)   modulo 2^16, (i, q) = colour_lookup[coff(l) + x]
+ *                  (src/video.c:3032-3040): three vector loads and 8 x (v_dot2c_i32_i16, shift, pack,
+ *                  add) per lane. The samples go to LDS as the two byte planes of the int8 matrix
+ *                  unit -- ONE pair of planes for the workgroup's 4096 + 64 window positions, so that
+ *                  a tile's filter reach into its neighbour is the neighbour's own work --, then the
+ *                  51-tap filter (mfma_filter), sound carriers, NICAM and the 32-byte stores exactly
+ *                  as in hvk_k_filter. The raster slab in HBM and its 2 + 2 B/sample do not exist.
+ *
+ * A lane's 8 window positions start 26 samples before a multiple of 8 and may straddle the end of a
+ * line: L and C are read where the first position's line has them (rows follow each other in the
+ * planes), then the lane reads once more with the next line's parameters -- another picture at a
+ * frame's end, the other sign of the V switch, the colour table position after a wrap -- and keeps
+ * the samples from the boundary on. A window touches at most three lines (width >= 544).
+ *
+ * Exactness: the planes hold what raster_compute() computes (the same device code, PREP = 1), the
+ * arithmetic above is raster_compute()'s modulator; tests/ compare with the raster + filter kernel
+ * pair (HVK_DIRECT=0) and with the reference's digests.
+ */
+#include "hvk_device.h"
+
+#define DG    4                     /* tiles per workgroup */
+#define DLEAD 26                    /* window position 0 is this many samples before the tile's first output (_mfma_taps) */
+
+/* ------------------------------------------------------------------ */
+
+template<int NT, int WC, int LV>
+__global__ __launch_bounds__(1024)
+void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
+                int16_t *__restrict__ Lp, int *__restrict__ Cp)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
+
+	if((int) blockIdx.x >= k.lines) return;
+	const int W = WC ? WC : k.width;
+	const int t = threadIdx.x;
+	if(WC) __builtin_assume(t * SPL + SPL <= WC);
+	const int nth = blockDim.x;
+	const int x0 = t * SPL;
+	const int rel = (int) blockIdx.x;
+	const int pic = (int) blockIdx.y;
+
+	const hvk_framedesc_t f = P.fdesc[__builtin_amdgcn_readfirstlane(pic)];
+	hvk_linedesc_t d = P.desc[__builtin_amdgcn_readfirstlane(rel)];
+	{
+		/* chroma wherever a frame of either parity has it: the parity decides at render time */
+		const hvk_linedesc_t d1 = P.desc[__builtin_amdgcn_readfirstlane(k.lines + rel)];
+		d.pal = (int16_t) ((d.pal | d1.pal) ? 1 : 0);
+	}
+	const hvk_line_t L = raster_setup_core<0, 0>(k, P, f, d, pic, rel, rel, true, false);
+
+	const int YL = raster_YL(W), CL = raster_CL(W);
+	int16_t *Yb = lds, *U = lds + YL, *V = lds + YL + CL;
+
+	uint32_t rgb[HVK_PIX_PASSES];
+	hvk_side_t sd;
+	int c[SPL];
+	raster_loads<NT, WC, HVK_PIX_PASSES, 1>(k, P, L, t, nth, rgb, sd, c);
+
+	if(L.pal)
+	{
+		raster_clear(L, t, nth, U, CL);
+		__syncthreads();
+	}
+	raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, sd.ghost_u, sd.ghost_v, Yb, U, V);
+	if(L.pal || L.has_pix) __syncthreads();
+
+	int s[SPL], cq[SPL];
+	raster_compute<NT, 0, 0, 0, WC, 1>(k, P, L, ctaps, ctaps, pic, rel, t, nth, lds, sd, c, s, cq);
+
+	const size_t at = ((size_t) f.plane_row0 + rel) * W + x0;
+	if(x0 + SPL <= W)
+	{
+		int4v o;
+		o.x = (s[0] & 0xFFFF) | (s[1] << 16);
+		o.y = (s[2] & 0xFFFF) | (s[3] << 16);
+		o.z = (s[4] & 0xFFFF) | (s[5] << 16);
+		o.w = (s[6] & 0xFFFF) | (s[7] << 16);
+		*(int4a2 *) (Lp + at) = (int4a2) { o.x, o.y, o.z, o.w };
+		if(NT > 1)
+		{
+			((int4u *) (Cp + at))[0] = (int4u) { c[0], c[1], c[2], c[3] };
+			((int4u *) (Cp + at))[1] = (int4u) { c[4], c[5], c[6], c[7] };
+		}
+	}
+	else
+	{
+		for(int i = 0; i < SPL; i++)
+		{
+			if(x0 + i >= W) break;
+			Lp[at + i] = (int16_t) s[i];
+			if(NT > 1) Cp[at + i] = c[i];
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+
+/* A line of the window: where window position w finds its L / C entry and its phasor -- at index lb + w, cb + w */
+typedef struct { int lb, cb; } dline_t;
+
+template<int COLOUR>
+__device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const hvk_framedesc_t &fp, const hvk_framedesc_t &fo,
+                                               const int rel, const int wstart)
+{
+	/* (raster_line_index(): the line before the frame is the last line of the frame before, of the other
+	 * parity; the lines behind it the first ones of the next frame -- no picture there in any mode, so the
+	 * frame's own planes have them) */
+	int line0 = rel, par = fo.parity, row0 = fo.plane_row0;
+	if(rel < 0) { line0 = k.lines - 1; par ^= 1; row0 = fp.plane_row0; }
+	else if(rel >= k.lines) { line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; par ^= 1; }
+	/* before the stream: the filter history is zero, not blanking (src/video.c:4665-4667 with src/fir.c:289, :579) */
+	const bool zero = rel < 0 && fo.frame_index == 0;
+
+	dline_t l;
+	l.lb = (zero ? D.zero_row : row0 + line0) * k.width - wstart;
+	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
+	if(COLOUR && !zero)
+	{
+		const int pal = D.desc[par * k.lines + line0].pal;
+		/* the sub-carrier table position advances by one line per line, colour or not (raster_setup_core()) */
+		unsigned coff = (fo.clut_off0 + (unsigned) (rel + 1) * (unsigned) k.width) % k.clw;
+		coff = (coff + k.clw - ((unsigned) k.width % k.clw)) % k.clw;
+		if(pal > 0) l.cb = (int) coff - wstart;
+		else if(pal < 0) l.cb = D.creg + (int) coff - wstart;       /* PAL V switch: the table with i negated */
+	}
+	return(l);
+}
+
+/* 8 raster samples (int16 pairs) at window position w of a line */
+template<int COLOUR>
+__device__ __forceinline__ int4u direct_eval(const hvk_dptrs_t &D, const int lb, const int cb, const int w)
+{
+	const int4a2 lv = *(const int4a2 *) (D.Lp + (lb + w));         /* (2-byte aligned where the width is odd) */
+	int4u s = { lv.x, lv.y, lv.z, lv.w };
+	if(COLOUR)
+	{
+		const int4u *cp = (const int4u *) (D.Cp + (lb + w));
+		const int4u *kp = (const int4u *) (D.clut3 + (cb + w));
+		const int4u c0 = cp[0], c1 = cp[1], k0 = kp[0], k1 = kp[1];
+		const int C[SPL] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+		const int K[SPL] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
+		int pr[SPL / 2];
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++)
+		{
+			/* (i * V * pal + q * U) >> 15 as one dot2 of the packed table entry with (V, U); modulo 2^16 at the add */
+			const int t0 = dot2(K[2 * m], C[2 * m], 0) >> 15, t1 = dot2(K[2 * m + 1], C[2 * m + 1], 0) >> 15;
+			pr[m] = (int) __builtin_amdgcn_perm((unsigned) t1, (unsigned) t0, 0x05040100u);
+		}
+		s.x = pk_add16(s.x, pr[0]); s.y = pk_add16(s.y, pr[1]); s.z = pk_add16(s.z, pr[2]); s.w = pk_add16(s.w, pr[3]);
+	}
+	return(s);
+}
+
+/* ... whichever lines they lie in: lA from window position 0, lB from b1, lC from b2 */
+template<int COLOUR>
+__device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_t lA, const dline_t lB, const dline_t lC,
+                                              const int b1, const int b2, const int w)
+{
+	const bool inB = w >= b1, inC = w >= b2;
+	int4u s = direct_eval<COLOUR>(D, inC ? lC.lb : (inB ? lB.lb : lA.lb), inC ? lC.cb : (inB ? lB.cb : lA.cb), w);
+
+	/* a line ends inside the group: the samples from there on with the next line's parameters */
+	const int d1 = b1 - w, d2 = b2 - w;
+	const bool s1 = d1 > 0 && d1 < SPL, s2 = d2 > 0 && d2 < SPL;
+	if(s1 || s2)
+	{
+		const int split = s1 ? d1 : d2;
+		const int4u r = direct_eval<COLOUR>(D, s1 ? lB.lb : lC.lb, s1 ? lB.cb : lC.cb, w);
+		const int sv[4] = { s.x, s.y, s.z, s.w }, rv[4] = { r.x, r.y, r.z, r.w };
+		int o[4];
+#pragma unroll
+		for(int m = 0; m < 4; m++)
+		{
+			const int keep = split - 2 * m;             /* samples of this pair that lie before the boundary */
+			const unsigned mask = keep <= 0 ? 0u : (keep == 1 ? 0xFFFFu : 0xFFFFFFFFu);
+			o[m] = (int) (((unsigned) sv[m] & mask) | ((unsigned) rv[m] & ~mask));
+		}
+		s = (int4u) { o[0], o[1], o[2], o[3] };
+	}
+	return(s);
+}
+
+template<int VF, int COLOUR, int EXACT>
+__global__ __launch_bounds__(HVK_TILE / HVK_SPL * DG, 8)
+void hvk_k_direct(const hvk_kconst_t k,
+                  const hvk_dptrs_t D,
+                  const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
+                  const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW] */
+                  const int *__restrict__ nicam_tapd,
+                  const int *__restrict__ nicam_cca,
+                  const int4v *__restrict__ mfma_a,
+                  const int mfma_ci, const int mfma_cq,
+                  int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
+                  const int64_t out_stride,
+                  const int tiles)
+{
+	constexpr int LEAD = VF ? DLEAD : 0;
+	constexpr int NP = DG * HVK_TILE + 64;      /* window positions of the workgroup: its tiles follow each other in the stream */
+	constexpr int TL = HVK_TILE / HVK_SPL;      /* lanes of a tile */
+	__shared__ __attribute__((aligned(16))) unsigned char xh[VF ? NP : 16], xl[VF ? NP : 16];
+	__shared__ __attribute__((aligned(16))) int outl_g[DG][VF ? HVK_TILE : 4];
+	__shared__ __attribute__((aligned(16))) int16_t tapd[4 * HVK_NICAM_TAPD];
+	__shared__ int sym_st_g[DG][HVK_NICAM_SYMS];
+	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[DG][HVK_NICAM_SYMS];
+
+	const int FS = k.frame_samples, W = k.width;
+	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
+	const int t = threadIdx.x % TL;
+	const int x0 = t * SPL;
+	const int y = (int) blockIdx.y;
+	/* a workgroup that reaches past the frame's last tile still fills its planes (the last tile's filter looks into
+	 * them); nothing of such a tile is stored */
+	const int tile_raw = (int) blockIdx.x * DG + sub;
+	const bool tile_valid = tile_raw < tiles;
+	const int tile = tile_valid ? tile_raw : tiles - 1;
+	const int n0 = tile_raw * HVK_TILE;         /* first output sample of the tile, frame local */
+	int *const outl = outl_g[sub];
+	int *const sym_st = sym_st_g[sub];
+	int4v *const sym_ent = sym_ent_g[sub];
+	(void) outl;
+
+	/* the NICAM pulse table, staged once per workgroup (hvk_k_filter has the layout) */
+	static_assert(TL * DG >= HVK_NICAM_TAPD / 2, "one pulse-table vector per thread");
+	const bool tap_mine = k.has_nicam && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	int4v tap_stage = { 0, 0, 0, 0 };
+	if(k.has_nicam) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
+
+	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
+	if(VF)
+	{
+		a_hh = mfma_a[t & 63];
+		a_hl = mfma_a[64 + (t & 63)];
+	}
+
+	/* ---- the lines this tile's window lies in (all scalar) ---- */
+	const hvk_framedesc_t fp = D.fdesc[2 * y], fo = D.fdesc[2 * y + 1];
+	const int p0 = n0 - LEAD;                                   /* stream position (frame local) of window position 0 */
+	const int lineA = p0 < 0 ? -1 : (int) ((unsigned) p0 / (unsigned) W);
+	const int xA0 = p0 - lineA * W;
+	const int b1 = W - xA0, b2 = b1 + W;                        /* window positions at which the next two lines begin */
+	const dline_t lA = direct_line<COLOUR>(k, D, fp, fo, lineA, -xA0);
+	const dline_t lB = direct_line<COLOUR>(k, D, fp, fo, lineA + 1, b1);
+	const dline_t lC = direct_line<COLOUR>(k, D, fp, fo, lineA + 2, b2);
+
+	/* ---- loads ---- */
+	int symv = 0, cc_tile = 0;
+	if(k.has_nicam)
+	{
+		const int *row = tilesyms + ((size_t) y * tiles + tile) * HVK_NICAM_ROW;
+		cc_tile = row[HVK_NICAM_SYMS];
+		symv = row[t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1];
+	}
+
+	const int n = n0 + x0;                      /* this lane's first output, frame local */
+	/* the lane's 8 outputs are inside the frame (EXACT: the frame is a whole number of tiles) */
+	const bool whole = tile_valid && (EXACT || n + SPL <= FS);
+
+	const int4u g0 = direct_group<COLOUR>(D, lA, lB, lC, b1, b2, x0);
+
+	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
+	if(k.has_carriers && whole)
+	{
+		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + n);
+		car0 = c[0];
+		car1 = c[1];
+	}
+
+	if(tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
+
+	int o[SPL];                                 /* packed (I, Q) int16 */
+
+	if(VF)
+	{
+		int2v ph, pl;
+		split_planes(g0, ph, pl);
+		((int2v *) (xh + sub * HVK_TILE))[t] = ph;
+		((int2v *) (xl + sub * HVK_TILE))[t] = pl;
+		if(sub == DG - 1 && t < 8)
+		{
+			/* the 64 positions behind the workgroup's last tile */
+			const int4u g1 = direct_group<COLOUR>(D, lA, lB, lC, b1, b2, HVK_TILE + x0);
+			split_planes(g1, ph, pl);
+			((int2v *) (xh + DG * HVK_TILE))[t] = ph;
+			((int2v *) (xl + DG * HVK_TILE))[t] = pl;
+		}
+	}
+	else
+	{
+		/* no filter: the raster goes straight to I, Q = 0 */
+		o[0] = g0.x & 0xFFFF; o[1] = (int) ((unsigned) g0.x >> 16); o[2] = g0.y & 0xFFFF; o[3] = (int) ((unsigned) g0.y >> 16);
+		o[4] = g0.z & 0xFFFF; o[5] = (int) ((unsigned) g0.z >> 16); o[6] = g0.w & 0xFFFF; o[7] = (int) ((unsigned) g0.w >> 16);
+	}
+
+	if(k.has_nicam && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
+	__syncthreads();
+
+	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
+	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 };
+	if(k.has_nicam)
+	{
+		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
+		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
+		else cp %= k.nicam_cc_len;
+		mix_a0 = ((const int4u *) (nicam_cca + cp))[0]; mix_a1 = ((const int4u *) (nicam_cca + cp))[1];
+	}
+
+	if(VF)
+	{
+		mfma_filter(xh + sub * HVK_TILE, xl + sub * HVK_TILE, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
+		__syncthreads();
+		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
+		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
+		o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
+	}
+
+	/* serial carriers (FM / AM sound), computed on the host: a plain add of int16 pairs with wrap-around
+	 * (src/video.c:3431-3432) */
+	if(k.has_carriers)
+	{
+		if(whole)
+		{
+			o[0] = pk_add16(o[0], car0.x); o[1] = pk_add16(o[1], car0.y); o[2] = pk_add16(o[2], car0.z); o[3] = pk_add16(o[3], car0.w);
+			o[4] = pk_add16(o[4], car1.x); o[5] = pk_add16(o[5], car1.y); o[6] = pk_add16(o[6], car1.z); o[7] = pk_add16(o[7], car1.w);
+		}
+		else if(tile_valid)
+		{
+			const int *c = carriers + (size_t) y * FS + n;
+#pragma unroll
+			for(int i = 0; i < SPL; i++) if(n + i < FS) o[i] = pk_add16(o[i], c[i]);
+		}
+	}
+
+	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix_a0, mix_a1, o);
+
+	/* interleaved int16 I/Q, 32 bytes per lane */
+	int *dst = iq + (size_t) y * out_stride * FS + n;
+	if(whole)
+	{
+		((int4u *) dst)[0] = (int4u) { o[0], o[1], o[2], o[3] };
+		((int4u *) dst)[1] = (int4u) { o[4], o[5], o[6], o[7] };
+	}
+	else if(tile_valid)
+	{
+#pragma unroll
+		for(int i = 0; i < SPL; i++) if(n + i < FS) dst[i] = o[i];
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* launchers                                                           */
+
+extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P);
+
+template<int NT>
+static int _launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
+{
+	const int W = a->k.width;
+	int threads = (W + SPL - 1) / SPL;
+	threads = (threads + 63) / 64 * 64;
+	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
+	hvk_rptrs_t P;
+	hvk_raster_ptrs(a, &P);
+	const dim3 grid((a->k.lines + 7) & ~7, npics), block(threads);
+#define PREP(WCV, LVV) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV>), grid, block, lds, stream, a->k, a->ctaps, P, Lp, Cp)
+	if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1); else PREP((NT == 13 ? 1024 : 0), 0); }
+	else { if(a->levels_computed) PREP(0, 1); else PREP(0, 0); }
+#undef PREP
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
+{
+	if(npics < 1) return(HVK_OK);
+	switch(a->k.colour ? a->k.chroma_ntaps : 1)
+	{
+	case 1:  return(_launch_prep<1>(a, npics, Lp, Cp, stream));
+	case 9:  return(_launch_prep<9>(a, npics, Lp, Cp, stream));
+	case 11: return(_launch_prep<11>(a, npics, Lp, Cp, stream));
+	case 13: return(_launch_prep<13>(a, npics, Lp, Cp, stream));
+	case 15: return(_launch_prep<15>(a, npics, Lp, Cp, stream));
+	case 17: return(_launch_prep<17>(a, npics, Lp, Cp, stream));
+	case 21: return(_launch_prep<21>(a, npics, Lp, Cp, stream));
+	}
+	return(HVK_UNSUPPORTED);
+}
+
+/* Which configurations render this way: the plain ones -- PAL / NTSC / monochrome at the sample rate, one
+ * picture per frame, no inserters -- with the matrix-unit filter or none */
+extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a)
+{
+	if(k->secam || k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->fields != 1 || k->fm_video) return(0);
+	if(k->vf_type != 0 && !(k->vf_ntaps == 51 && mfma_a && (k->vf_type == 1 || k->vf_type == 3))) return(0);
+	if(k->width < 544) return(0);               /* a tile's window within three lines */
+	return(1);
+}
+
+template<int VF, int COLOUR>
+static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
+{
+	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+	const dim3 grid((tiles + DG - 1) / DG, a->nframes), block(HVK_TILE / SPL * DG);
+#define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, a->D, (const int *) a->carriers, a->tilesyms, \
+	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles)
+	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);
+#undef DIRECT
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream)
+{
+	const int vf = a->k.vf_type ? 1 : 0;
+	if(a->k.colour) return(vf ? _launch_direct2<1, 1>(a, stream) : _launch_direct2<0, 1>(a, stream));
+	return(vf ? _launch_direct2<1, 0>(a, stream) : _launch_direct2<0, 0>(a, stream));
+}

@@ -38,8 +38,6 @@
 
 extern "C" {
 int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
-int hvk_fused_supported(const hvk_kconst_t *k, const void *mfma_a);
-int hvk_launch_fused(const hvk_raster_args_t *ra, const hvk_filter_args_t *fa, int run_lines, hipStream_t stream);
 }
 
 struct hvk_slot_t {
@@ -48,6 +46,7 @@ struct hvk_slot_t {
 	int interlaced;
 	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
 	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
+	int plane_dirty;            /* the picture planes (hvk_direct.hip) have not been made from this picture yet */
 };
 
 struct hvk_engine {
@@ -96,7 +95,7 @@ struct hvk_engine {
 	hipStream_t own_stream;
 
 	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca, *d_zeros, *d_lstate;
+	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca;
 	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
 	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
@@ -123,11 +122,15 @@ struct hvk_engine {
 	int32_t *h_sym;
 	int32_t *h_tile;
 	uint8_t *sym_tmp;
-	int tiles;                  /* NICAM symbol rows per frame: one per filter tile, or one per line for the fused kernel */
-	int tile_len;               /* samples a row covers: HVK_TILE, or the line width */
-	int fused;                  /* this configuration renders in one kernel (hvk_fused.hip) */
-	int run_lines;              /* < 0: runs per frame as given (HVK_RUNS); 0: the launcher chooses */
-	int last_fused;             /* the last launch did: the raster slab in HBM was not written */
+	int tiles;                  /* NICAM symbol rows per frame: one per filter tile */
+	int direct;                 /* this configuration renders in one kernel from picture planes (hvk_direct.hip) */
+	int last_direct;            /* the last launch did: the raster slab in HBM was not written */
+	/* picture planes: [plane_rows][width] each, 16 entries of slack in front; rows: lines per frame slot, two kept
+	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
+	int16_t *d_Lp; int *d_Cp; int *d_clut3;
+	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
+	hvk_framedesc_t *d_pdesc, *h_pdesc;     /* [frame_slots]: the pictures a prep launch works on */
+	int64_t prep_count;         /* pictures the planes were made from so far */
 	/* pinned staging for source frames: a small ring, each buffer guarded by an event recorded behind its copy, so that
 	 * hvk_frame_upload() waits for the copy that last used THAT buffer only -- never for the stream */
 	uint32_t *h_frame[HVK_UPLOAD_RING];
@@ -356,13 +359,18 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
 
-	/* One kernel for the whole per-sample path (hvk_fused.hip) where the configuration allows and the caller asks
-	 * for it -- HVK_FUSE=1 or hvk_set_fused(): measured on MI355X it does not beat the raster + filter kernel pair
-	 * yet (0.40 against 0.37 ms per 82 M samples; DESIGN.md section 4 has the counters), so the pair is the default.
-	 * HVK_RUNS sets the runs a frame's lines are dealt to (one workgroup each). */
-	e->fused = hvk_fused_supported(&e->t.k, e->d_mfma_a) && getenv("HVK_FUSE") != NULL && atoi(getenv("HVK_FUSE")) != 0;
-	e->run_lines = getenv("HVK_RUNS") ? -atoi(getenv("HVK_RUNS")) : 0;      /* < 0: that many runs per frame; 0: the launcher decides */
-	e->tile_len = e->fused ? k.width : HVK_TILE;
+	/* One kernel from picture planes (hvk_direct.hip) for the plain configurations; HVK_DIRECT=0 keeps the raster +
+	 * filter kernel pair (the parity tests run both). The planes do not depend on a frame's parity: the two
+	 * descriptor sets may differ in nothing but `pal`; and the line after a frame must not show picture (its
+	 * planes are taken from the frame's own picture). */
+	e->direct = hvk_direct_supported(&e->t.k, e->d_mfma_a) && !(getenv("HVK_DIRECT") && atoi(getenv("HVK_DIRECT")) == 0);
+	for(int l = 0; l < k.lines && e->direct; l++)
+	{
+		hvk_linedesc_t a = e->t.desc[l], b = e->t.desc[k.lines + l];
+		a.pal = b.pal = 0;
+		if(memcmp(&a, &b, sizeof(a)) != 0) e->direct = 0;
+	}
+	if(e->t.desc[0].ar > e->t.desc[0].al || e->t.desc[k.lines].ar > e->t.desc[k.lines].al) e->direct = 0;
 
 	OPENCHK(_upload(&e->d_desc, e->t.desc, sizeof(hvk_linedesc_t) * 2 * k.lines));
 	OPENCHK(_upload(&e->d_pulses, e->t.pulse_values, sizeof(int16_t) * (e->t.pulse_total + 8)));
@@ -382,9 +390,33 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_burst, bw.data(), bw.size() * sizeof(int16_t)));
 	}
 	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
-	OPENHIP(hipMalloc(&e->d_lstate, (size_t) max_frames * (k.lines + 2) * 32));
-	OPENHIP(hipMalloc(&e->d_zeros, HVK_ZERO_BYTES));
-	OPENHIP(hipMemset(e->d_zeros, 0, HVK_ZERO_BYTES));
+	if(e->direct)
+	{
+		e->plane_rows = e->frame_slots * k.lines + 3;
+		e->plane_carry_row = e->frame_slots * k.lines;
+		e->plane_zero_row = e->plane_carry_row + 2;
+		const size_t pn = (size_t) e->plane_rows * k.width + 32;
+		OPENHIP(hipMalloc((void **) &e->d_Lp, pn * 2));
+		OPENHIP(hipMemset(e->d_Lp, 0, pn * 2));
+		if(k.colour)
+		{
+			OPENHIP(hipMalloc((void **) &e->d_Cp, pn * 4));
+			OPENHIP(hipMemset(e->d_Cp, 0, pn * 4));
+			/* the phasors as they are, with i negated (the PAL switch; i never is -32768), and zeros (a line without
+			 * chroma): regions of clw + width + 16 entries, 16 of slack in front */
+			e->clut_reg = (int) e->t.colour_lookup_len + 16;
+			std::vector<int> c3((size_t) 3 * e->clut_reg + 32, 0);
+			for(int64_t i = 0; i < e->t.colour_lookup_len; i++)
+			{
+				const hvk_c16_t c = e->t.colour_lookup[i];
+				c3[16 + (size_t) i] = ((int) c.i & 0xFFFF) | ((int) c.q << 16);
+				c3[16 + (size_t) e->clut_reg + i] = ((-(int) c.i) & 0xFFFF) | ((int) c.q << 16);
+			}
+			OPENCHK(_upload((void **) &e->d_clut3, c3.data(), c3.size() * 4));
+		}
+		OPENHIP(hipMalloc((void **) &e->d_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots));
+		OPENHIP(hipHostMalloc((void **) &e->h_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots, hipHostMallocDefault));
+	}
 	if(k.has_nicam)
 	{
 		/* device forms of the NICAM tables: the pulse as int16 behind HVK_NICAM_LEAD
@@ -451,7 +483,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	if(e->t.k.has_nicam)
 	{
-		e->tiles = (k.frame_samples + e->tile_len - 1) / e->tile_len;
+		e->tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 		OPENHIP(hipMalloc((void **) &e->d_sym, (size_t) max_frames * e->symbol_stride * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride * 4, hipHostMallocDefault));
 		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4));
@@ -610,7 +642,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_zeros, e->d_lstate,
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc,
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
@@ -619,7 +651,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->h_secam_carry) (void) hipHostFree(e->h_secam_carry);
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -680,6 +712,7 @@ extern "C" int hvk_set_chroma_ghost(hvk_engine_t *e, const int16_t *ghost, int n
 	memset(e->t.ghost, 0, sizeof(e->t.ghost));
 	if(ghost) memcpy(e->t.ghost, ghost, n * sizeof(int16_t));
 	else hvk_tables_default_ghost(&e->t);
+	for(int i = 0; i < e->frame_slots; i++) e->slots[i].plane_dirty = 1;     /* the chroma low pass reads them */
 	if(e->device >= 0 && e->d_ghost)
 	{
 		HIPCHK(hipSetDevice(e->device));
@@ -765,6 +798,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->width = fb ? w : 0;
 	s->height = fb ? h : 0;
 	s->interlaced = interlaced;
+	s->plane_dirty = 1;
 	if(fb == NULL)
 	{
 		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
@@ -830,6 +864,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->width = w;
 	s->height = h;
 	s->interlaced = interlaced;
+	s->plane_dirty = 1;
 	if(!s->valid) return(HVK_OK);
 
 	const uint32_t *src = fb + (size_t) y * width + x;
@@ -846,6 +881,7 @@ extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
 {
 	if(!e || mode < HVK_LEVELS_AUTO || mode > HVK_LEVELS_COMPUTE) return(HVK_ERROR);
 	e->levels_mode = mode;
+	for(int i = 0; i < e->frame_slots; i++) e->slots[i].plane_dirty = 1;     /* (identical either way; made again all the same, so that a test of the mode tests it) */
 	return(HVK_OK);
 }
 
@@ -1171,6 +1207,7 @@ extern "C" int hvk_host_fm_video(hvk_engine_t *e, int16_t *iq, int64_t count)
 }
 
 static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots);
+static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride);
 
 extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots)
 {
@@ -1331,6 +1368,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			d->fb_valid = ss->valid;
 			if(ss->valid && ss->many_colours) many = 1;
 			d->parity = (int32_t) ((d->frame_index + 1) & 1);
+			d->plane_row0 = sl * k.lines;
 			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
 		}
 
@@ -1404,7 +1442,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 				while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
 				for(int b = 0; b < e->tiles; b++)
 				{
-					const int64_t pos = (int64_t) b * e->tile_len;
+					const int64_t pos = (int64_t) b * HVK_TILE;
 					int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
 					while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
 					for(int q = 0; q < HVK_NICAM_SYMS; q++)
@@ -1443,12 +1481,56 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			p->vframe_y = (k.active_lines - p->fb_height) / 2;
 			p->fb_interlaced = ss->interlaced;
 			p->fb_valid = ss->valid;
+			p->plane_row0 = ps * k.lines;
 		}
 		else *p = *own;                                             /* a strided render or a jump without it: the frame's own picture */
 		/* the colour table position the kernel counts lines from is this frame's, also on the halo line */
 		p->clut_off0 = own->clut_off0;
 		p->frame_index = own->frame_index;
 		p->parity = own->parity;
+	}
+	if(e->direct)
+	{
+		/* the picture planes of every picture this batch shows that is new since its planes were made: one prep
+		 * launch for those whose levels are looked up, one for those whose levels are computed */
+		int np[2] = { 0, 0 };
+		for(int i = 0; i < nframes + (prev_slots ? nframes : 0); i++)
+		{
+			const int sl = i < nframes ? e->staged_slots[i] : prev_slots[i - nframes];
+			if(sl < 0 || sl >= e->frame_slots) continue;
+			hvk_slot_t *ss = &e->slots[sl];
+			if(!ss->plane_dirty) continue;
+			const int lv = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours);
+			/* looked-up pictures from the list's front, computed ones from its end: a slot is in one of them, once */
+			hvk_framedesc_t *d = &e->h_pdesc[lv ? e->frame_slots - 1 - np[1] : np[0]];
+			np[lv]++;
+			memset(d, 0, sizeof(*d));
+			d->fb_offset = (int64_t) sl * frame_px;
+			d->fb_width = ss->valid ? ss->width : 0;
+			d->fb_height = ss->valid ? ss->height : 0;
+			d->pixel_stride = 1;
+			d->line_stride = ss->width;
+			d->vframe_x = (k.active_width - d->fb_width) / 2;
+			d->vframe_y = (k.active_lines - d->fb_height) / 2;
+			d->fb_interlaced = ss->interlaced;
+			d->fb_valid = ss->valid;
+			d->plane_row0 = sl * k.lines;
+			ss->plane_dirty = 0;
+		}
+		for(int lv = 0; lv < 2; lv++)
+		{
+			if(np[lv] == 0) continue;
+			const int at = lv ? e->frame_slots - np[1] : 0;
+			hvk_raster_args_t ra;
+			hvk_filter_args_t fa;
+			HIPCHK(hipMemcpyAsync(e->d_pdesc + at, e->h_pdesc + at, sizeof(hvk_framedesc_t) * np[lv], hipMemcpyHostToDevice, e->stream));
+			_kernel_args(e, &ra, &fa, NULL, 1);
+			ra.fdesc = e->d_pdesc + at;
+			ra.levels_computed = lv;
+			int r = hvk_launch_prep(&ra, np[lv], e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, e->stream);
+			if(r != HVK_OK) { e->poisoned = 1; return(r); }
+			e->prep_count += np[lv];
+		}
 	}
 	{
 		/* keep what the last frame of this batch shows on its last line */
@@ -1469,6 +1551,14 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
 			e->carry.fb_offset = (int64_t) carry_off;
 			e->carry.line_stride = 0;       /* every row of the kept frame is that one row */
+			if(e->direct)
+			{
+				/* ... and its planes' last row: the slot may hold another picture by then */
+				const size_t W = k.width, from = ((size_t) last->plane_row0 + k.lines - 1) * W + 16, to = ((size_t) e->plane_carry_row + e->carry_row) * W + 16;
+				HIPCHK(hipMemcpyAsync(e->d_Lp + to, e->d_Lp + from, W * 2, hipMemcpyDeviceToDevice, e->stream));
+				if(e->d_Cp) HIPCHK(hipMemcpyAsync(e->d_Cp + to, e->d_Cp + from, W * 4, hipMemcpyDeviceToDevice, e->stream));
+				e->carry.plane_row0 = e->plane_carry_row + e->carry_row - (k.lines - 1);
+			}
 		}
 		else e->carry.fb_valid = 0;
 	}
@@ -1577,8 +1667,6 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	fa.mfma_a = e->d_mfma_a;
 	fa.mfma_ci = e->mfma_ci;
 	fa.mfma_cq = e->mfma_cq;
-	fa.zeros = e->d_zeros;
-	fa.lstate = e->d_lstate;
 	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
 	fa.nframes = e->staged;
 	fa.out_stride = out_stride;
@@ -1610,11 +1698,31 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	int r;
 
 	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
-	if(e->fused)
+	if(e->direct)
 	{
 		/* one kernel: its time is reported as the second (filter) kernel's, the first one's is nil */
 		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
-		if((r = hvk_launch_fused(&ra, &fa, e->run_lines, e->stream)) != HVK_OK) return(r);
+		hvk_direct_args_t da;
+		memset(&da, 0, sizeof(da));
+		da.k = e->t.k;
+		da.D.Lp = e->d_Lp + 16;
+		da.D.Cp = e->d_Cp ? e->d_Cp + 16 : NULL;
+		da.D.clut3 = e->d_clut3 ? e->d_clut3 + 16 : NULL;
+		da.D.creg = e->clut_reg;
+		da.D.zero_row = e->plane_zero_row;
+		da.D.desc = (const hvk_linedesc_t *) e->d_desc;
+		da.D.fdesc = e->d_fdesc;
+		da.carriers = fa.carriers;
+		da.tilesyms = fa.tilesyms;
+		da.nicam_tapd = fa.nicam_tapd;
+		da.nicam_cca = fa.nicam_cca;
+		da.mfma_a = fa.mfma_a;
+		da.mfma_ci = fa.mfma_ci;
+		da.mfma_cq = fa.mfma_cq;
+		da.iq = fa.iq;
+		da.nframes = fa.nframes;
+		da.out_stride = out_stride;
+		if((r = hvk_launch_direct(&da, e->stream)) != HVK_OK) return(r);
 	}
 	else
 	{
@@ -1624,7 +1732,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
 	}
 	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
-	e->last_fused = e->fused;
+	e->last_direct = e->direct;
 	if(!e->t.k.fm_video && (e->t.k.swap_iq || e->d_off || e->d_pass))
 	{
 		if((r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream)) != HVK_OK) return(r);
@@ -1786,10 +1894,10 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 	const size_t FS = k.raster_samples;
 	if(first + count > (size_t) e->last_frames * FS) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
-	if(e->last_fused)
+	if(e->last_direct)
 	{
-		/* the fused kernel keeps the raster in LDS: run the raster kernel (the same device code) over the
-		 * staged batch to have it in HBM */
+		/* the one-kernel render keeps the raster in LDS: run the raster kernel over the staged batch to have
+		 * it in HBM */
 		hvk_raster_args_t ra;
 		hvk_filter_args_t fa;
 		if(e->staged != e->last_frames) return(HVK_ERROR);
@@ -1811,19 +1919,16 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
 
 /* The kernels hvk_launch() enqueues for this configuration, as rocprofv3 prints them, ';' between
- * them: the launchers' choice of template arguments restated (hvk_kernels.hip, hvk_fused.hip). */
+ * them: the launchers' choice of template arguments restated (hvk_kernels.hip, hvk_direct.hip). */
 extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 {
 	if(!e || !buf || n < 1) return(HVK_ERROR);
 	const hvk_kconst_t &k = e->t.k;
 	const int nt = k.secam ? 1 : (k.colour ? k.chroma_ntaps : 1);
 	const int lv = e->levels_computed ? 1 : 0;
-	if(e->fused)
+	if(e->direct)
 	{
-		const int extras = (k.vbi || k.vits) ? 1 : 0;
-		const int wc = (!extras && nt == 13 && k.width == 1024) ? 1024 : 0;
-		if(k.vf_type != 0 && !extras && !getenv("HVK_NO_WAVE_ROLES")) snprintf(buf, n, "hvk_k_fusedw<%d, %d, %d, %d>", nt, k.vf_type, wc, lv);
-		else snprintf(buf, n, "hvk_k_fused<%d, %d, %d, %d, %d>", nt, k.vf_type, extras, wc, lv);
+		snprintf(buf, n, "hvk_k_direct<%d, %d, %d>", k.vf_type ? 1 : 0, k.colour ? 1 : 0, k.frame_samples % HVK_TILE == 0 ? 1 : 0);
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;

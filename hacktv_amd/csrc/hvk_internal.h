@@ -116,6 +116,8 @@ typedef struct {
 	int32_t fb_valid;       /* 0: no pixels (black) */
 	uint32_t clut_off0;     /* colour table position of the frame's first line: (frame_index * lines * width) mod clw */
 	int32_t parity;         /* (frame number) & 1 with frames counted from 1: (frame_index + 1) & 1 */
+	int32_t plane_row0;     /* picture planes (hvk_direct.hip): the row of this picture's line 0; line l is row plane_row0 + l */
+	int32_t pad;
 } hvk_framedesc_t;
 
 /* Host-built tables (hvk_tables.c) */

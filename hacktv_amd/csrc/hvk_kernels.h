@@ -10,7 +10,6 @@
 #define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_MFMA_A_BYTES (2 * 64 * 16)
-#define HVK_ZERO_BYTES  (64 * 1024)
 #define HVK_NICAM_TAPD  512  /* entries of one copy of the zero padded NICAM pulse table */
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
@@ -59,12 +58,34 @@ typedef struct {
 	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
-	void *lstate;               /* hvk_k_fusedw: room for the lines' states, nframes * (lines + 2) * 32 bytes */
-	const void *zeros;          /* HVK_ZERO_BYTES of zeros: what hvk_k_fusedw reads where a configuration has no carriers / no NICAM */
 	int16_t *iq;
 	int nframes;
 	int64_t out_stride;         /* frame i goes to frame slot i * out_stride of iq */
 } hvk_filter_args_t;
+
+/* The picture planes and the one-kernel render from them (hvk_direct.hip) */
+typedef struct {
+	const int16_t *Lp;          /* [rows][width]: a line without its sub-carrier -- blanking, sync pulses, luma */
+	const int *Cp;              /* [rows][width]: (V, U) after the chroma low pass, burst included: what the phasors are multiplied by */
+	const int *clut3;           /* sub-carrier phasors (i, q), the same with i negated (PAL V switch), zeros: `creg` entries each */
+	int creg;
+	int zero_row;               /* a plane row of zeros: what lies before the stream's first sample */
+	const hvk_linedesc_t *desc;
+	const hvk_framedesc_t *fdesc;   /* [nframes][2]: the frame before, the frame */
+} hvk_dptrs_t;
+
+typedef struct {
+	hvk_kconst_t k;
+	hvk_dptrs_t D;
+	const hvk_c16_t *carriers;
+	const int *tilesyms;
+	const int *nicam_tapd, *nicam_cca;
+	const void *mfma_a;
+	int mfma_ci, mfma_cq;
+	int16_t *iq;
+	int nframes;
+	int64_t out_stride;
+} hvk_direct_args_t;
 
 /* SECAM colour sub-carrier on the device (hvk_secam.hip) */
 #define HVK_SECAM_WARMUP 12     /* lines walked before a task's own to find its entry state */
@@ -110,6 +131,10 @@ int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
+/* picture planes of `npics` pictures: a->fdesc holds one descriptor per picture (plane_row0 says where its rows go) */
+int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
+int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a);
+int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
 int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
                     int nframes, hipStream_t stream);

@@ -285,12 +285,8 @@ void hvk_k_filter(const hvk_kconst_t k,
 			const int q = t + i * (HVK_TILE / HVK_SPL);
 			if(q < NG)
 			{
-				const int4u d = wd[i];
 				int2v ph, pl;
-				ph.x = (int) __builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x07050301u);
-				ph.y = (int) __builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x07050301u);
-				pl.x = (int) (__builtin_amdgcn_perm((unsigned) d.y, (unsigned) d.x, 0x06040200u) ^ 0x80808080u);
-				pl.y = (int) (__builtin_amdgcn_perm((unsigned) d.w, (unsigned) d.z, 0x06040200u) ^ 0x80808080u);
+				split_planes(wd[i], ph, pl);
 				((int2v *) xh)[q] = ph;
 				((int2v *) xl)[q] = pl;
 			}
@@ -321,25 +317,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		/* the symbols whose pulses can touch this tile, oldest first: start
 		 * (relative to the tile's first sample) and sign pair. The schedule
 		 * (src/nicam728.c:398-407) is tabulated per frame by the host. */
-		if(t < HVK_NICAM_SYMS)
-		{
-			const int v = symv;
-			const int st = (v >> 3) - n0;
-			const bool valid = (v & 4) && st < HVK_TILE;
-			/* constellation { 0, 1, 3, 2 }: bit 0 -> +I else -I, bit 1 -> +Q else -Q
-			 * (src/nicam728.c:33, :386-396) */
-			const int cs = (0x2310 >> ((v & 3) * 4)) & 3;
-			sym_st[t] = valid ? st : 0x3FFFFFFF;
-			/* x0 is a multiple of 8, so which of the four shifted copies of the pulse
-			 * table a lane needs depends on the symbol only. A slot without a symbol
-			 * gets an offset that clamps into the table's zero tail. */
-			const int rel = HVK_NICAM_LEAD - st;
-			/* +1 or -1 in both halves: the pulse shapes two samples of a channel per packed multiply-add */
-			const int sgi = (cs & 1) ? 0x00010001 : (int) 0xFFFFFFFFu;
-			const int sgq = (cs & 2) ? 0x00010001 : (int) 0xFFFFFFFFu;
-			sym_ent[t] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgi, sgq }
-			                   : (int4v) { 0x10000000, 0, 0, 0 };
-		}
+		if(t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
 	}
 	__syncthreads();
 
@@ -359,35 +337,8 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	if(VF != 0 && MF)
 	{
-		/* The FIR as a banded matrix product on the matrix unit. A wave takes 64 segments of 8
-		 * outputs, 16 segments (the columns of B) per v_mfma_i32_16x16x64_i8: lane (g, c) hands over
-		 * window positions 16 g .. 16 g + 15 of segment c, which are 16 consecutive bytes of a plane,
-		 * and gets back rows 4 g .. 4 g + 3 = outputs 2 g, 2 g + 1 of that segment, I and Q. Four
-		 * products (high / low byte of taps and samples), recombined with two shift-adds; the
-		 * constant of the low plane's offset starts the low accumulator. Then >> 15 and the
-		 * saturating pack (src/fir.c:605-608), and through LDS to the lane that owns the 8 outputs. */
-		const int lane = t & 63, g = lane >> 4, c = lane & 15;
-#pragma unroll
-		for(int j = 0; j < 4; j++)
-		{
-			const int seg = (t >> 6) * 64 + j * 16 + c;
-			const int off = seg * 8 + g * 16;
-			int4v bh, bl;
-			bh.xy = *(const int2v *) (xh + off); bh.zw = *(const int2v *) (xh + off + 8);
-			bl.xy = *(const int2v *) (xl + off); bl.zw = *(const int2v *) (xl + off + 8);
-			int4v p_hh = { 0, 0, 0, 0 }, p_m = { 0, 0, 0, 0 }, p_ll = { mfma_ci, mfma_cq, mfma_ci, mfma_cq };
-			p_hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bh, p_hh, 0, 0, 0);
-			p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bh, p_m, 0, 0, 0);
-			p_m  = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hh, bl, p_m, 0, 0, 0);
-			p_ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bl, p_ll, 0, 0, 0);
-			int y[4];
-#pragma unroll
-			for(int i = 0; i < 4; i++) y[i] = (int) ((((unsigned) p_hh[i] << 8) + (unsigned) p_m[i]) << 8) + p_ll[i];
-			int2v pk;
-			pk.x = sat_pack16(y[0] >> 15, y[1] >> 15);
-			pk.y = sat_pack16(y[2] >> 15, y[3] >> 15);
-			*(int2v *) (outl + seg * 8 + 2 * g) = pk;
-		}
+		/* the FIR as a banded matrix product on the matrix unit (hvk_device.h), then through LDS to the lane that owns the 8 outputs */
+		mfma_filter(xh, xl, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
 		__syncthreads();
 		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
 		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
@@ -467,69 +418,8 @@ void hvk_k_filter(const hvk_kconst_t k,
 		}
 	}
 
-	/* NICAM: sum the pulses of the symbols in flight (int16 wrap-around per
-	 * channel, both channels in one packed multiply-add), mix, add
-	 * (src/nicam728.c:350-365, :386-396) */
-	if(k.has_nicam)
-	{
-		const int last = x0 + SPL - 1;          /* relative to the tile's first sample */
-		/* newest symbol that has started by this lane's last sample; slot
-		 * HVK_NICAM_BACK - 1 holds the newest one at the tile's first sample */
-		int idx = HVK_NICAM_BACK - 1 + (int) ((float) last * (1.0f / (float) k.nicam_sps));
-		if(idx > HVK_NICAM_SYMS - 2) idx = HVK_NICAM_SYMS - 2;
-		while(idx + 1 < HVK_NICAM_SYMS && sym_st[idx + 1] <= last) idx++;
-		while(idx > 0 && sym_st[idx] > last) idx--;
-
-		/* I and Q apart while the pulses are summed: (I[2m], I[2m + 1]) and (Q[2m], Q[2m + 1]) */
-		int bi[SPL / 2], bq[SPL / 2];
-#pragma unroll
-		for(int i = 0; i < SPL / 2; i++) bi[i] = bq[i] = 0;
-
-		/* the newest symbol and the six before it: everything older is over. A pulse
-		 * that is over (or a slot without a symbol) reads the zero tail of the table:
-		 * no branch. idx >= HVK_NICAM_BACK - 1 by construction. */
-#pragma unroll 1
-		for(int b = 0; b < (ABLATE(32) ? 0 : HVK_NICAM_BACK); b++)
-		{
-			const int4v en = sym_ent[idx - b];
-			int base = x0 + en.x;                                   /* >= 1 */
-			base = base < HVK_NICAM_TAPD - SPL ? base : HVK_NICAM_TAPD - SPL;
-			const int2v *tp = (const int2v *) (tapd + en.y + (base & ~3));
-			const int2v ta = tp[0], tb = tp[1];
-			bi[0] = pk_mad16(ta.x, en.z, bi[0]); bi[1] = pk_mad16(ta.y, en.z, bi[1]);
-			bi[2] = pk_mad16(tb.x, en.z, bi[2]); bi[3] = pk_mad16(tb.y, en.z, bi[3]);
-			bq[0] = pk_mad16(ta.x, en.w, bq[0]); bq[1] = pk_mad16(ta.y, en.w, bq[1]);
-			bq[2] = pk_mad16(tb.x, en.w, bq[2]); bq[3] = pk_mad16(tb.y, en.w, bq[3]);
-		}
-
-		int bb[SPL];                            /* (I, Q) of each sample */
-#pragma unroll
-		for(int m = 0; m < SPL / 2; m++)
-		{
-			bb[2 * m + 0] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x05040100u);
-			bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
-		}
-
-		/* mixer: the rotation's first row (i, -q) is tabulated (loaded before the filter) */
-		if(!ABLATE(64))
-		{
-		const int4u a0 = mix_a0, a1 = mix_a1;
-		const int ca[SPL] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-		/* the second row (q, i) from the first (i, -q): halves swapped, the low one negated (|q| <= 32767) */
-		int cq[SPL];
-#pragma unroll
-		for(int i = 0; i < SPL; i++) cq[i] = pk_mad16(shift_pair(ca[i], ca[i]), (int) 0x0001FFFFu, 0);
-#pragma unroll
-		for(int i = 0; i < SPL; i++)
-		{
-			const int mi = dot2(bb[i], ca[i], 0);           /* bb.i * cc.i - bb.q * cc.q */
-			const int mq = dot2(bb[i], cq[i], 0);           /* bb.i * cc.q + bb.q * cc.i */
-			/* ((mi >> 15) & 0xFFFF) | ((mq >> 15) << 16) */
-			const int pk = (int) ((((unsigned) mq << 1) & 0xFFFF0000u) | (((unsigned) mi >> 15) & 0xFFFFu));
-			o[i] = pk_add16(o[i], pk);
-		}
-		}
-	}
+	/* NICAM: pulse sums of the symbols in flight, mixer, add (hvk_device.h; src/nicam728.c:350-365, :386-396) */
+	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix_a0, mix_a1, o);
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + obase;

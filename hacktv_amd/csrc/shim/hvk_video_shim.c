@@ -603,6 +603,15 @@ void vid_info(vid_t *s)
 	fprintf(stderr, "Engine: %s, %d frame(s) per launch\n", hvk_version(), _shim(s) ? _shim(s)->batch : 0);
 }
 
+/* The engine behind a vid_t, for an embedder that needs an engine-level call the video.h interface has no
+ * place for -- hvk_set_chroma_ghost() with what ITS heap holds behind the reference's chrominance buffer
+ * (SURVEY.md H2), before the first vid_next_line(). NULL: not one of the shim's. */
+hvk_engine_t *hvk_shim_engine(vid_t *s)
+{
+	shim_t *m = _shim(s);
+	return(m ? m->e : NULL);
+}
+
 size_t vid_get_framebuffer_length(vid_t *s)
 {
 	return(sizeof(uint32_t) * s->active_width * s->conf.active_lines);

@@ -12,9 +12,11 @@
  * into one program. Usage: shim_check <mode> <sample rate> <frames> <flags> [pixel rate]
  *   flags: 1 --filter, 2 --noaudio, 4 --vits, 8 --vitc, 16 --acp, 32 --cc608, 64 --interlace, 128 --a2stereo
  *
- * The reference's chroma filter over-reads its heap; here the two engines see different
- * bytes there (the shim models the CLI's heap), so on PAL / NTSC the last samples of colour lines and
- * the filter's reach around them are left out of the comparison.
+ * The reference's chroma filter over-reads its heap: the shim's engine is given the bytes
+ * that follow the reference's chrominance buffer in THIS process (hvk_set_chroma_ghost(); the shim's default
+ * models the CLI's heap) -- with FM video a difference there would stay in the modulator's phase for good.
+ * Should those bytes change while the run lasts, only the last samples of colour lines and the filter's
+ * reach around them could differ: they stay out of the comparison on PAL / NTSC.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +26,9 @@
 
 extern int ref_vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const vid_config_t * const conf);
 extern vid_line_t *ref_vid_next_line(vid_t *s);
+/* the shim's engine (hvk_video_shim.c) and the one engine-level call made here (include/hacktv_amd.h) */
+extern void *hvk_shim_engine(vid_t *s);
+extern int hvk_set_chroma_ghost(void *e, const int16_t *ghost, int n);
 
 typedef struct {
 	uint32_t *fb;
@@ -129,6 +134,10 @@ int main(int argc, char *argv[])
 	}
 
 	colour_tail = (conf.colour_mode == VID_PAL || conf.colour_mode == VID_NTSC);
+	if(colour_tail && a.chrominance_buffer)
+	{
+		if(hvk_set_chroma_ghost(hvk_shim_engine(&b), a.chrominance_buffer + 2 * a.width, 32) != 0) { printf("hvk_set_chroma_ghost failed\n"); return(1); }
+	}
 
 	for(;;)
 	{

@@ -48,10 +48,10 @@ def _ref_digests(flags, frame_bytes, marks, env=None):
 
 
 @pytest.mark.parametrize("batches,env", [((128, 37), {}), ((37, 37, 37, 17), {}),
-                                         ((128, 37), {"HVK_FUSE": "1"}), ((37, 91), {"HVK_FUSE": "1", "HVK_NO_WAVE_ROLES": "1"})])
+                                         ((128, 37), {"HVK_DIRECT": "0"}), ((37, 91), {"HVK_DIRECT": "0"})])
 def test_whole_blocks_equal_the_reference(golden, batches, env, monkeypatch):
-    """Every sample of 128-frame and 37-frame blocks with sound on: the raster + filter kernel pair (default)
-    and the one-kernel forms (HVK_FUSE=1: wave roles, or both jobs in every wave)."""
+    """Every sample of 128-frame and 37-frame blocks with sound on: the one-kernel render from picture planes
+    (default) and the raster + filter kernel pair (HVK_DIRECT=0)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     conf, sr = golden.conf("i_full")

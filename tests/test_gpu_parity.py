@@ -103,27 +103,32 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 
-@pytest.mark.parametrize("roles", [True, False])
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
-                                  "pal_bb_filter", "i_20m", "i_tt", "i_offset", "m_offset_pass", "pal_fm", "i_vbi", "i_vbi_tt",
-                                  "m_vbi", "i_acp_cc", "g_a2", "m_a2", "i_wss_auto"])
-def test_one_kernel_forms_equal_reference_digests(golden, case, roles, monkeypatch):
-    """HVK_FUSE=1: raster, video filter and sound in one kernel (hvk_fused.hip) -- with wave roles (hvk_k_fusedw: the
-    plain configurations with a video filter) or with both jobs in every wave (hvk_k_fused: VBI data lines, test
-    signals, no filter; HVK_NO_WAVE_ROLES=1 forces it everywhere). Same digests as the kernel pair."""
-    monkeypatch.setenv("HVK_FUSE", "1")
-    if not roles:
-        monkeypatch.setenv("HVK_NO_WAVE_ROLES", "1")
+                                  "pal_bb_filter", "i_20m", "i_offset", "m_offset_pass", "g_a2", "m_a2", "i_27m", "d_full", "palm_full",
+                                  "pal60_bb"])
+def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
+    """The plain configurations render in one kernel from picture planes (hvk_direct.hip) by default -- that is what
+    the digest tests above run. HVK_DIRECT=0 keeps the raster + filter kernel pair for them: same digests."""
+    monkeypatch.setenv("HVK_DIRECT", "0")
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     nframes = c["frames"]
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        assert not e.kernel_names()[0].startswith("hvk_k_direct")
     iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
-                 teletext=(lambda f: golden.teletext_rows(f, golden.teletext_skip(case))) if c.get("teletext") else None,
                  passthru=util.passthru_signal() if conf.passthru else None, pixel_rate=c.get("pixel_rate", 0))
     fs = c.get("frame_samples", c["width"] * c["lines"])
     for n in range(nframes):
         got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
+
+
+@pytest.mark.parametrize("case", ["pal_bb", "i_full", "i_mono", "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "i_27m"])
+def test_plain_configurations_render_from_picture_planes(golden, case):
+    """... and that the default really is the one-kernel form for them."""
+    conf, sr = golden.conf(case)
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        assert e.kernel_names()[0].startswith("hvk_k_direct"), e.kernel_names()
 
 
 @pytest.mark.parametrize("case", ["i_full", "m_full"])
@@ -927,15 +932,15 @@ def test_picture_carried_across_batches_on_525_lines(golden, batch):
     assert bad.size == 0, "frame %d sample %d" % (bad[0] // fs, bad[0] % fs)
 
 
-@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("direct", [True, False])
 @pytest.mark.parametrize("world,block", [(2, 1), (3, 2)])
-def test_sharded_525_line_stream_with_changing_pictures_is_exact(golden, world, block, fuse, monkeypatch):
+def test_sharded_525_line_stream_with_changing_pictures_is_exact(golden, world, block, direct, monkeypatch):
     """Frames dealt to several engines ('ranks': round-robin for block = 1, block-cyclic otherwise), NTSC, a different
     random picture on every frame: a rank does not render the frame before its own, but the last line of that frame
     shows picture within the video filter's reach. With the predecessor's slot named (hvk_stage_strided_prev) the
     interleaved stream equals the single-engine stream sample for sample; the oracle is the judge."""
-    if fuse:
-        monkeypatch.setenv("HVK_FUSE", "1")
+    if not direct:
+        monkeypatch.setenv("HVK_DIRECT", "0")
     conf = H.preset("m", H.FLAG_FILTER)
     sr, n = 13500000, world * block * 2
     rng = np.random.default_rng(world * 10 + block)
