@@ -36,6 +36,7 @@
  * pair (HVK_DIRECT=0) and with the reference's digests.
  */
 #include "hvk_device.h"
+#include <stddef.h>
 
 #define DG    4                     /* tiles per workgroup */
 #define DLEAD 26                    /* window position 0 is this many samples before the tile's first output (_mfma_taps) */
@@ -135,10 +136,14 @@ __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_
 	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
 	if(COLOUR && !zero)
 	{
-		const int pal = D.desc[par * k.lines + line0].pal;
-		/* the sub-carrier table position advances by one line per line, colour or not (raster_setup_core()) */
-		unsigned coff = (fo.clut_off0 + (unsigned) (rel + 1) * (unsigned) k.width) % k.clw;
-		coff = (coff + k.clw - ((unsigned) k.width % k.clw)) % k.clw;
+		/* hvk_linedesc_t.pal, as the low half of the descriptor's fourth dword: a scalar load (an int16 member would be
+		 * fetched by the vector unit, and waited for three times per tile) */
+		static_assert(offsetof(hvk_linedesc_t, pal) == 12 && sizeof(hvk_linedesc_t) == 16, "hvk_linedesc_t layout");
+		const int pal = (int) (short) (((const int *) D.desc)[(par * k.lines + line0) * 4 + 3] & 0xFFFF);
+		/* the sub-carrier table position advances by one line per line, colour or not (raster_setup_core():
+		 * (clut_off0 + rel * width) mod clw); the line's share is tabulated, so no division here */
+		unsigned coff = fo.clut_off0 + D.lineoff[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+		if(coff >= k.clw) coff -= k.clw;
 		if(pal > 0) l.cb = (int) coff - wstart;
 		else if(pal < 0) l.cb = D.creg + (int) coff - wstart;       /* PAL V switch: the table with i negated */
 	}
@@ -223,6 +228,11 @@ void hvk_k_direct(const hvk_kconst_t k,
 	__shared__ int sym_st_g[DG][HVK_NICAM_SYMS];
 	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[DG][HVK_NICAM_SYMS];
 
+	/* the grid's x extent is padded to a multiple of 8: with workgroups dealt round-robin to the 8 XCDs, the same
+	 * lines of EVERY frame then run on the same XCD, whose L2 keeps their plane rows (a picture that stays) and
+	 * their slices of the colour table (the same again every few frames) */
+	if((int) blockIdx.x * DG >= tiles) return;
+
 	const int FS = k.frame_samples, W = k.width;
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
 	const int t = threadIdx.x % TL;
@@ -255,7 +265,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	/* ---- the lines this tile's window lies in (all scalar) ---- */
 	const hvk_framedesc_t fp = D.fdesc[2 * y], fo = D.fdesc[2 * y + 1];
 	const int p0 = n0 - LEAD;                                   /* stream position (frame local) of window position 0 */
-	const int lineA = p0 < 0 ? -1 : (int) ((unsigned) p0 / (unsigned) W);
+	const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
 	const int xA0 = p0 - lineA * W;
 	const int b1 = W - xA0, b2 = b1 + W;                        /* window positions at which the next two lines begin */
 	const dline_t lA = direct_line<COLOUR>(k, D, fp, fo, lineA, -xA0);
@@ -418,7 +428,7 @@ template<int VF, int COLOUR>
 static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-	const dim3 grid((tiles + DG - 1) / DG, a->nframes), block(HVK_TILE / SPL * DG);
+	const dim3 grid(((tiles + DG - 1) / DG + 7) & ~7, a->nframes), block(HVK_TILE / SPL * DG);
 #define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, a->D, (const int *) a->carriers, a->tilesyms, \
 	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);

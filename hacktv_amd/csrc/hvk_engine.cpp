@@ -127,9 +127,10 @@ struct hvk_engine {
 	int last_direct;            /* the last launch did: the raster slab in HBM was not written */
 	/* picture planes: [plane_rows][width] each, 16 entries of slack in front; rows: lines per frame slot, two kept
 	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
-	int16_t *d_Lp; int *d_Cp; int *d_clut3;
+	int16_t *d_Lp; int *d_Cp; int *d_clut3; uint32_t *d_lineoff; uint32_t inv_w;
 	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
 	hvk_framedesc_t *d_pdesc, *h_pdesc;     /* [frame_slots]: the pictures a prep launch works on */
+	hipEvent_t ev_pdesc; int pdesc_busy;    /* behind the list's last copy to the device */
 	int64_t prep_count;         /* pictures the planes were made from so far */
 	/* pinned staging for source frames: a small ring, each buffer guarded by an event recorded behind its copy, so that
 	 * hvk_frame_upload() waits for the copy that last used THAT buffer only -- never for the stream */
@@ -414,6 +415,22 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			}
 			OPENCHK(_upload((void **) &e->d_clut3, c3.data(), c3.size() * 4));
 		}
+		{
+			/* what the kernel would divide for: a window position's line by a multiplication (exact up to the
+			 * last position a tile can ask for -- checked here), a line's colour table position from a table */
+			std::vector<uint32_t> lo((size_t) k.lines + 4, 0);
+			for(int j = 0; j < k.lines + 4 && k.colour; j++) lo[j] = (uint32_t) ((((int64_t) (j - 1) * k.width) % k.clw + k.clw) % k.clw);
+			OPENCHK(_upload((void **) &e->d_lineoff, lo.data(), lo.size() * 4));
+			e->inv_w = (uint32_t) (((1ULL << 32) + k.width - 1) / k.width);
+			/* (the quotient can only go wrong next to a multiple of the width: those and their neighbours are tried) */
+			const uint32_t qmax = (uint32_t) ((k.frame_samples + 8 * HVK_TILE) / k.width + 1);
+			for(uint32_t q = 0; q <= qmax && e->direct; q++)
+			{
+				const uint32_t n0 = q * (uint32_t) k.width, n1 = n0 + (uint32_t) k.width - 1;
+				if((uint32_t) (((uint64_t) n0 * e->inv_w) >> 32) != q || (uint32_t) (((uint64_t) n1 * e->inv_w) >> 32) != q) e->direct = 0;
+			}
+		}
+		if(!e->direct) fprintf(stderr, "libhvk: no exact reciprocal of the line width %d: the raster + filter kernel pair renders\n", k.width);
 		OPENHIP(hipMalloc((void **) &e->d_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots));
 		OPENHIP(hipHostMalloc((void **) &e->h_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots, hipHostMallocDefault));
 	}
@@ -473,6 +490,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipEventCreateWithFlags(&e->up_ev[i], hipEventDisableTiming));
 	}
 	OPENHIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
+	OPENHIP(hipEventCreateWithFlags(&e->ev_pdesc, hipEventDisableTiming));
 	for(int i = 0; i < HVK_FETCH_TICKETS; i++) OPENHIP(hipEventCreateWithFlags(&e->fetch_ev[i], hipEventDisableTiming));
 
 	if(e->t.k.has_carriers)
@@ -642,7 +660,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc,
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
 		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
@@ -650,6 +668,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->h_secam_count) (void) hipHostFree(e->h_secam_count);
 		if(e->h_secam_carry) (void) hipHostFree(e->h_secam_carry);
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
+		if(e->ev_pdesc) (void) hipEventDestroy(e->ev_pdesc);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc };
 		for(void *p : host) if(p) (void) hipHostFree(p);
@@ -1283,6 +1302,74 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	return(HVK_OK);
 }
 
+/* The picture planes (hvk_direct.hip) of those of the named slots whose picture is new since its planes were made: one
+ * prep launch for the pictures whose levels are looked up, one for those whose levels are computed. On the engine's
+ * stream: behind the pictures' uploads, in front of every later render. */
+static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n)
+{
+	const hvk_kconst_t &k = e->t.k;
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	int np[2] = { 0, 0 };
+
+	for(int i = 0; i < n; i++)
+	{
+		const int sl = slots[i];
+		if(sl < 0 || sl >= e->frame_slots) continue;
+		hvk_slot_t *ss = &e->slots[sl];
+		if(!ss->plane_dirty) continue;
+		if(np[0] + np[1] == 0 && e->pdesc_busy) { HIPCHK(hipEventSynchronize(e->ev_pdesc)); e->pdesc_busy = 0; }    /* the list's last copy has left it */
+		const int lv = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours);
+		/* looked-up pictures from the list's front, computed ones from its end: a slot is in one of them, once */
+		hvk_framedesc_t *d = &e->h_pdesc[lv ? e->frame_slots - 1 - np[1] : np[0]];
+		np[lv]++;
+		memset(d, 0, sizeof(*d));
+		d->fb_offset = (int64_t) sl * frame_px;
+		d->fb_width = ss->valid ? ss->width : 0;
+		d->fb_height = ss->valid ? ss->height : 0;
+		d->pixel_stride = 1;
+		d->line_stride = ss->width;
+		d->vframe_x = (k.active_width - d->fb_width) / 2;
+		d->vframe_y = (k.active_lines - d->fb_height) / 2;
+		d->fb_interlaced = ss->interlaced;
+		d->fb_valid = ss->valid;
+		d->plane_row0 = sl * k.lines;
+		ss->plane_dirty = 0;
+	}
+	for(int lv = 0; lv < 2; lv++)
+	{
+		if(np[lv] == 0) continue;
+		const int at = lv ? e->frame_slots - np[1] : 0;
+		hvk_raster_args_t ra;
+		hvk_filter_args_t fa;
+		HIPCHK(hipMemcpyAsync(e->d_pdesc + at, e->h_pdesc + at, sizeof(hvk_framedesc_t) * np[lv], hipMemcpyHostToDevice, e->stream));
+		_kernel_args(e, &ra, &fa, NULL, 1);
+		ra.fdesc = e->d_pdesc + at;
+		ra.levels_computed = lv;
+		int r = hvk_launch_prep(&ra, np[lv], e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, e->stream);
+		if(r != HVK_OK) return(r);
+		e->prep_count += np[lv];
+	}
+	if(np[0] + np[1])
+	{
+		HIPCHK(hipEventRecord(e->ev_pdesc, e->stream));
+		e->pdesc_busy = 1;
+	}
+	return(HVK_OK);
+}
+
+/* The planes of the named slots made now -- again, if they exist: what a caller does who wants the per-picture work
+ * inside a clock of its own (bench.py), or out of the way before a stage. */
+extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
+{
+	if(!e || !slots || n < 0) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
+	for(int i = 0; i < n; i++) if(slots[i] < 0 || slots[i] >= e->frame_slots) return(HVK_ERROR);
+	HIPCHK(hipSetDevice(e->device));
+	for(int i = 0; i < n; i++) e->slots[slots[i]].plane_dirty = 1;
+	return(_prep_dirty(e, slots, n));
+}
+
 static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
 {
 	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
@@ -1491,46 +1578,10 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	}
 	if(e->direct)
 	{
-		/* the picture planes of every picture this batch shows that is new since its planes were made: one prep
-		 * launch for those whose levels are looked up, one for those whose levels are computed */
-		int np[2] = { 0, 0 };
-		for(int i = 0; i < nframes + (prev_slots ? nframes : 0); i++)
-		{
-			const int sl = i < nframes ? e->staged_slots[i] : prev_slots[i - nframes];
-			if(sl < 0 || sl >= e->frame_slots) continue;
-			hvk_slot_t *ss = &e->slots[sl];
-			if(!ss->plane_dirty) continue;
-			const int lv = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours);
-			/* looked-up pictures from the list's front, computed ones from its end: a slot is in one of them, once */
-			hvk_framedesc_t *d = &e->h_pdesc[lv ? e->frame_slots - 1 - np[1] : np[0]];
-			np[lv]++;
-			memset(d, 0, sizeof(*d));
-			d->fb_offset = (int64_t) sl * frame_px;
-			d->fb_width = ss->valid ? ss->width : 0;
-			d->fb_height = ss->valid ? ss->height : 0;
-			d->pixel_stride = 1;
-			d->line_stride = ss->width;
-			d->vframe_x = (k.active_width - d->fb_width) / 2;
-			d->vframe_y = (k.active_lines - d->fb_height) / 2;
-			d->fb_interlaced = ss->interlaced;
-			d->fb_valid = ss->valid;
-			d->plane_row0 = sl * k.lines;
-			ss->plane_dirty = 0;
-		}
-		for(int lv = 0; lv < 2; lv++)
-		{
-			if(np[lv] == 0) continue;
-			const int at = lv ? e->frame_slots - np[1] : 0;
-			hvk_raster_args_t ra;
-			hvk_filter_args_t fa;
-			HIPCHK(hipMemcpyAsync(e->d_pdesc + at, e->h_pdesc + at, sizeof(hvk_framedesc_t) * np[lv], hipMemcpyHostToDevice, e->stream));
-			_kernel_args(e, &ra, &fa, NULL, 1);
-			ra.fdesc = e->d_pdesc + at;
-			ra.levels_computed = lv;
-			int r = hvk_launch_prep(&ra, np[lv], e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, e->stream);
-			if(r != HVK_OK) { e->poisoned = 1; return(r); }
-			e->prep_count += np[lv];
-		}
+		/* the picture planes of every picture this batch shows that is new since its planes were made */
+		int r = _prep_dirty(e, e->staged_slots, nframes);
+		if(r == HVK_OK && prev_slots) r = _prep_dirty(e, prev_slots, nframes);
+		if(r != HVK_OK) { e->poisoned = 1; return(r); }
 	}
 	{
 		/* keep what the last frame of this batch shows on its last line */
@@ -1712,6 +1763,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.D.zero_row = e->plane_zero_row;
 		da.D.desc = (const hvk_linedesc_t *) e->d_desc;
 		da.D.fdesc = e->d_fdesc;
+		da.D.lineoff = e->d_lineoff;
+		da.D.inv_w = e->inv_w;
 		da.carriers = fa.carriers;
 		da.tilesyms = fa.tilesyms;
 		da.nicam_tapd = fa.nicam_tapd;

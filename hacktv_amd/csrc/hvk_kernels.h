@@ -72,6 +72,8 @@ typedef struct {
 	int zero_row;               /* a plane row of zeros: what lies before the stream's first sample */
 	const hvk_linedesc_t *desc;
 	const hvk_framedesc_t *fdesc;   /* [nframes][2]: the frame before, the frame */
+	const uint32_t *lineoff;    /* [lines + 4]: ((j - 1) * width) mod clw -- the colour table position of line j - 1 of a frame that starts at position 0 */
+	uint32_t inv_w;             /* ceil(2^32 / width): n / width == (n * inv_w) >> 32 for every n a frame's window positions take (checked by the host) */
 } hvk_dptrs_t;
 
 typedef struct {

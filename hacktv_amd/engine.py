@@ -20,7 +20,7 @@ SYMBOLS = [
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
-    "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels",
+    "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels", "hvk_planes_refresh",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
@@ -96,6 +96,7 @@ def lib():
         L.hvk_output_device_ptr.argtypes = [vp]
         L.hvk_output_device_ptr.restype = vp
         L.hvk_timing_enable.argtypes = [vp, i32]
+        L.hvk_planes_refresh.argtypes = [vp, vp, i32]
         L.hvk_timing_read.argtypes = [vp, i32, vp, vp]
         L.hvk_kernel_names.argtypes = [vp, C.c_char_p, i32]
         L.hvk_table.argtypes = [vp, C.c_char_p, vp, C.c_long]
@@ -321,8 +322,13 @@ class Engine:
         """0 auto, 1 table look-up, 2 computed per pixel (hvk_set_levels)."""
         return self._chk("hvk_set_levels", lib().hvk_set_levels(self.h, mode))
 
+    def planes_refresh(self, slots):
+        """Make the picture planes of these slots now (hvk_planes_refresh)."""
+        arr = (C.c_int32 * len(slots))(*slots)
+        return self._chk("hvk_planes_refresh", lib().hvk_planes_refresh(self.h, arr, len(slots)))
+
     def kernel_names(self):
-        """The kernels a launch enqueues for this configuration (one when the path is fused)."""
+        """The kernels a launch enqueues for this configuration (one where it renders from picture planes)."""
         buf = C.create_string_buffer(512)
         self._chk("hvk_kernel_names", lib().hvk_kernel_names(self.h, buf, 512))
         return buf.value.decode().split(";")

@@ -354,11 +354,21 @@ void *hvk_output_device_ptr(hvk_engine_t *e);
 #define HVK_LEVELS_COMPUTE 2
 int hvk_set_levels(hvk_engine_t *e, int mode);
 
+/* The plain configurations (PAL / NTSC / monochrome at the sample rate, one picture per frame, no inserters) render
+ * from PICTURE PLANES: what src/video.c:2864-3030 computes of a scanline before the sub-carrier is modulated -- sync
+ * pulses, the levels of the pixels, the low-passed chroma, the burst -- depends on the picture alone and is made once
+ * per uploaded picture, by the first hvk_stage_strided() / hvk_render() that shows it (a picture that stays is not
+ * worked on again). hvk_planes_refresh() makes the planes of the named slots now -- again, if
+ * they exist -- on the engine's stream: for a caller that wants that work inside a clock of its own. HVK_OK and
+ * nothing done where the configuration renders straight from the pictures. */
+int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n);
+
 int hvk_timing_enable(hvk_engine_t *e, int on);
 /* The names of the kernels a launch of this configuration enqueues, as a profiler prints them,
- * separated by ';' -- one name when the whole per-sample path runs as one kernel (the default where
- * the configuration allows), else raster [; resampler] ; filter. With one kernel
- * hvk_timing_read() reports its time as kernel 1 and nothing for kernel 0. */
+ * separated by ';' -- one name where the per-sample path runs as one kernel from picture planes (the
+ * plain configurations; HVK_DIRECT=0 in the environment keeps the kernel pair), else raster
+ * [; resampler] ; filter. With one kernel hvk_timing_read() reports its time as kernel 1 and nothing
+ * for kernel 0. */
 int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n);
 int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches);
 

@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
     acc = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0]
-        if not name.startswith(("hvk_k_raster", "hvk_k_filter", "hvk_k_fused", "void hvk_k_raster", "void hvk_k_filter", "void hvk_k_fused")):
+        if not name.replace("void ", "").startswith(("hvk_k_raster", "hvk_k_filter", "hvk_k_direct", "hvk_k_prep", "hvk_k_secam")):
             continue
         name = name.replace("void ", "")
         acc.setdefault((name, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
@@ -37,7 +37,7 @@ t = {"frames": frames,
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), averages per launch of bench.py --steps 3. "
              "Units KiB. FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md (HBM section); WRITE_SIZE as reported."}
 for name, c in counters.items():
-    key = "hvk_k_fused" if "fused" in name else ("hvk_k_filter" if "filter" in name else "hvk_k_raster")
+    key = name.split("<")[0]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         t[key + "_fetch_KiB_raw"] = c["FETCH_SIZE"]
         t[key + "_write_KiB"] = c["WRITE_SIZE"]

@@ -35,6 +35,25 @@ __global__ void k(const int *in, int *out, int s0, int s1)
 			if(OP == 10) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(y), "v"(x));
 			if(OP == 11) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(y), "v"(x));
 			if(OP == 12) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(*(long long *) &a[i & ~1]) : "v"(y), "v"(x) : "vcc");
+			if(OP == 13) asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(a[i]) : "v"(y));
+			if(OP == 14) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(y));
+			if(OP == 15) asm volatile("v_perm_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(y), "v"(x));
+			if(OP == 16) asm volatile("v_ashrrev_i32 %0, 15, %0" : "+v"(a[i]));
+			if(OP == 17) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(y));
+			if(OP == 18) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(a[i]) : "v"(y));
+			if(OP == 19) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(y), "v"(x));
+			if(OP == 20) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(y));
+			if(OP == 21) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(a[i]));
+			if(OP == 22) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(y) : "vcc");
+			if(OP == 23) asm volatile("v_lshl_add_u32 %0, %0, 8, %1" : "+v"(a[i]) : "v"(y));
+			if(OP == 24) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(y), "v"(x));
+			if(OP == 25) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(y), "v"(x));
+			if(OP == 26) asm volatile("v_pk_mul_lo_u16 %0, %1, %0" : "+v"(a[i]) : "v"(y));
+			if(OP == 27) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(y), "v"(x));
+			if(OP == 28) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % UNROLL]));
+			if(OP == 29) asm volatile("v_pk_add_i16 %0, %1, %0" : "+v"(a[i]) : "v"(y));
+			if(OP == 30) asm volatile("v_lshlrev_b32 %0, 8, %0" : "+v"(a[i]));
+			if(OP == 31) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(y));
 		}
 	}
 	int r = 0;
@@ -48,7 +67,7 @@ static void run(const char *name, int *din, int *dout)
 {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	for(int wps = 1; wps <= 8; wps *= 2)
+	for(int wps = 4; wps <= 8; wps *= 2)
 	{
 		// 256 CUs, 4 SIMDs each: blocks of 256 threads = 1 wave per SIMD; wps blocks per CU
 		int blocks = 256 * wps;
@@ -82,5 +101,24 @@ int main()
 	run<9>("v_dot4_i32_i8", din, dout);
 	run<10>("v_fma_f32", din, dout);
 	run<12>("v_mad_i64_i32", din, dout);
+	run<13>("v_pk_add_u16", din, dout);
+	run<14>("v_pk_sub_u16", din, dout);
+	run<29>("v_pk_add_i16", din, dout);
+	run<25>("v_pk_mad_u16", din, dout);
+	run<26>("v_pk_mul_lo_u16", din, dout);
+	run<15>("v_perm_b32", din, dout);
+	run<16>("v_ashrrev_i32", din, dout);
+	run<30>("v_lshlrev_b32", din, dout);
+	run<17>("v_xor_b32", din, dout);
+	run<18>("v_lshl_or_b32", din, dout);
+	run<19>("v_and_or_b32", din, dout);
+	run<20>("v_cvt_pk_i16_i32", din, dout);
+	run<21>("v_bfe_i32", din, dout);
+	run<22>("v_cndmask_b32", din, dout);
+	run<23>("v_lshl_add_u32", din, dout);
+	run<24>("v_add3_u32", din, dout);
+	run<27>("v_bfi_b32", din, dout);
+	run<28>("v_mov_b32", din, dout);
+	run<31>("v_sub_u32", din, dout);
 	return 0;
 }
