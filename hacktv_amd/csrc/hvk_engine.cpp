@@ -62,6 +62,7 @@ struct hvk_engine {
 	void *d_secam[10];          /* what sa points into (freed at close) */
 	int *h_secam_count;         /* pinned: failures of the last check */
 	int secam_lanes;            /* lanes of four waves per SIMD */
+	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
 	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
 	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
 	int64_t secam_counts[4];
@@ -141,6 +142,7 @@ struct hvk_engine {
 	hipEvent_t ev_staged;       /* after the last host-to-device copy of a stage: the pinned side buffers are free again */
 	int staged_busy;
 	hipEvent_t fetch_ev[HVK_FETCH_TICKETS];   /* hvk_fetch_async() */
+	int fetch_busy[HVK_FETCH_TICKETS];        /* handed out and not waited for yet */
 	int fetch_next;
 
 	hvk_slot_t *slots;          /* [frame_slots] */
@@ -162,6 +164,10 @@ struct hvk_engine {
 	int64_t t_n[2];
 };
 
+/* ... after the serial chains have moved on for a batch: the failure leaves the stream out of step for good */
+#define HIPCHK_P(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
+	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+	e->poisoned = 1; return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
 #define HIPCHK(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
 	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
 	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
@@ -570,6 +576,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.ntasks = 2 + (n0 > n1 ? n0 : n1);
 			a.tpad = (max_frames * a.ntasks + 63) & ~63;
 			a.K = HVK_SECAM_WARMUP;
+			e->secam_adapt = getenv("HVK_SECAM_WARMUP") == NULL;
 			if(getenv("HVK_SECAM_WARMUP")) a.K = atoi(getenv("HVK_SECAM_WARMUP"));
 			if(a.K < 0) a.K = 0;
 			a.raster_samples = (int64_t) RS;
@@ -1272,6 +1279,15 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
 		HIPCHK(hipStreamSynchronize(e->stream));
 		const int bad = *e->h_secam_count;
+		if(rounds == 0 && e->secam_adapt)
+		{
+			/* How many warm-up lines a start state needs depends on the pictures (flat colours: a line or two; noise: ten
+			 * and more) and costs a walk each. Exactness never rests on it -- the check does -- so the number follows
+			 * what the last batch showed: down by a third while nothing fails, up by two when more than one start
+			 * in a thousand was wrong. */
+			if(bad == 0) a.K = a.K * 2 / 3 > 2 ? a.K * 2 / 3 : 2;
+			else if((int64_t) bad * 1000 > a.nruns) a.K = a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP;
+		}
 		if(bad == 0) break;
 		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;
 		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
@@ -1288,7 +1304,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 				if(r != HVK_OK) return(r);
 			}
 			hvk_secam_get_state(e->secam, e->h_secam_carry, NULL);
-			HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
+			HIPCHK_P(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
 			e->secam_counts[3] += nframes;
 			return(HVK_OK);
@@ -1421,7 +1437,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		{
 			int64_t k0 = 0;
 			int n = hvk_audio_generate(e->audio, 0, k.out_prime, e->fm_prime_car, e->sym_tmp, e->sym_tmp ? e->symbol_stride : 0, &k0);
-			if(n < 0) return(n);
+			if(n < 0) { e->poisoned = 1; return(n); }
 		}
 		e->fm_prime_pending = 1;
 	}
@@ -1613,19 +1629,19 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		}
 		else e->carry.fb_valid = 0;
 	}
-	HIPCHK(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
+	HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
 	if(e->h_ops)
 	{
 		_build_vbi_ops(e, nframes);
-		HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipMemcpyHostToDevice, e->stream));
-		HIPCHK(hipMemcpyAsync(e->d_map, e->h_map, (size_t) nframes * k.lines, hipMemcpyHostToDevice, e->stream));
+		HIPCHK_P(hipMemcpyAsync(e->d_ops, e->h_ops, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipMemcpyHostToDevice, e->stream));
+		HIPCHK_P(hipMemcpyAsync(e->d_map, e->h_map, (size_t) nframes * k.lines, hipMemcpyHostToDevice, e->stream));
 		/* teletext packets and caption pairs are consumed by the batch they were queued for */
 		if(e->h_tt_mask) memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
 		if(e->cc_pairs) memset(e->cc_pairs, 0, (size_t) e->max_frames * 3);
 	}
 	if(e->h_raw)
 	{
-		HIPCHK(hipMemcpyAsync(e->d_raw, e->h_raw, (size_t) nframes * k.slab_lines * k.width * 2, hipMemcpyHostToDevice, e->stream));
+		HIPCHK_P(hipMemcpyAsync(e->d_raw, e->h_raw, (size_t) nframes * k.slab_lines * k.width * 2, hipMemcpyHostToDevice, e->stream));
 		/* what no later frame can need goes: everything before the last line of the last frame staged */
 		const int64_t keep = ((first_frame + (int64_t) (nframes - 1) * stride + 1) * k.lines - 1) * k.width;
 		if(keep > e->raw_base)
@@ -1642,15 +1658,15 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
-	if(e->h_car) HIPCHK(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_off) HIPCHK(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_pass) HIPCHK(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
 	{
-		HIPCHK(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
+		HIPCHK_P(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
 	}
 
-	HIPCHK(hipEventRecord(e->ev_staged, e->stream));
+	HIPCHK_P(hipEventRecord(e->ev_staged, e->stream));
 	e->staged_busy = 1;
 
 	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
@@ -1818,7 +1834,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 			in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);     /* int16 wrap-around add, src/video.c:3431 */
 		}
 		r = hvk_tail_fm_prime(e->tail, in.data(), P);
-		if(r != HVK_OK) return(r);
+		if(r != HVK_OK) { e->poisoned = 1; return(r); }      /* the sound chain is past these samples: the stream cannot go on */
 		e->fm_prime_pending = 0;
 	}
 	return(HVK_OK);
@@ -1874,6 +1890,9 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
 	const int t = e->fetch_next;
+	/* a ticket goes out again only when its last copy has been waited for: a caller with more than HVK_FETCH_TICKETS
+	 * copies in flight would otherwise wait on the wrong one */
+	if(e->fetch_busy[t]) return(HVK_ERROR);
 	e->fetch_next = (e->fetch_next + 1) % HVK_FETCH_TICKETS;
 	if(e->t.k.fm_video)
 	{
@@ -1883,6 +1902,7 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 	}
 	else HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
+	e->fetch_busy[t] = 1;
 	return(t);
 }
 
@@ -1890,7 +1910,9 @@ extern "C" int hvk_fetch_wait(hvk_engine_t *e, int ticket)
 {
 	if(!e || ticket < 0 || ticket >= HVK_FETCH_TICKETS) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(!e->fetch_busy[ticket]) return(HVK_ERROR);
 	HIPCHK(hipEventSynchronize(e->fetch_ev[ticket]));
+	e->fetch_busy[ticket] = 0;
 	return(HVK_OK);
 }
 

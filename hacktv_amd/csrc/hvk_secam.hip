@@ -437,17 +437,31 @@ __global__ void hvk_k_secam_check(const hvk_secam_args_t a)
 	if(bad) atomicAdd(a.count, 1);
 }
 
-/* the failed runs again, from the exit state of the run before */
+/* The runs that failed, again. A lane takes the FIRST run of a stretch of failed ones -- its start is the exit state of
+ * a run that passed, which nobody writes in this launch -- and walks on from there, run after run, for as long as the
+ * state it leaves is not the one the next run had started from (whether that run had failed the check or not: a
+ * corrected exit state makes the next run's start wrong too). It stops in front of a run that passed and is followed
+ * by a failed one: that run's exit state is what another lane of this launch starts from. Whatever is left
+ * inconsistent -- that case, hvk_k_secam_check finds it -- is next round's. */
 __global__ __launch_bounds__(64)
 void hvk_k_secam_redo(const hvk_secam_args_t a)
 {
-	const int r = blockIdx.x * 64 + threadIdx.x;
-	if(r >= a.nruns || !a.flags[r]) return;
-	const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
-	hvk_secam_state_t S = r ? a.exit[r - 1] : *a.carry;
-	a.entry[r] = S;
-	for(int m = t0; m < t1; m++) run_task(a, m, S, true);
-	a.exit[r] = S;
+	const int r0 = blockIdx.x * 64 + threadIdx.x;
+	if(r0 >= a.nruns || !a.flags[r0] || (r0 > 0 && a.flags[r0 - 1])) return;
+
+	hvk_secam_state_t S = r0 ? a.exit[r0 - 1] : *a.carry;
+	for(int r = r0; r < a.nruns; r++)
+	{
+		const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
+		if(r > r0)
+		{
+			if(same_state(S, a.entry[r])) break;                                  /* from here on everything stands */
+			if(!a.flags[r] && r + 1 < a.nruns && a.flags[r + 1]) break;           /* its exit state is another lane's start */
+		}
+		a.entry[r] = S;
+		for(int m = t0; m < t1; m++) run_task(a, m, S, true);
+		a.exit[r] = S;
+	}
 }
 
 /* the batch is through: its last exit state is the next batch's start */

@@ -199,7 +199,7 @@ int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_
 		 * (src/video.c:3522-3533) */
 		const int64_t src = p + s->prime;
 
-		if(src < s->q_base) return(HVK_ERROR);   /* forward only */
+		if(src < s->q_base + (int64_t) s->q_head) return(HVK_ERROR);   /* forward only: what has been consumed is gone, dropped from the queue or not */
 
 		if(src + W > s->q_base + (int64_t) s->q_len)
 		{

@@ -286,7 +286,8 @@ class Engine:
         return self._chk("hvk_frame_upload_pinned", lib().hvk_frame_upload_pinned(self.h, slot, fb.ctypes.data, w, h, interlaced))
 
     def host_buffer(self, count):
-        """(count, 2) int16 array over page-locked memory (hvk_host_alloc); released with the engine's close()."""
+        """(count, 2) int16 array over page-locked memory (hvk_host_alloc). The array is a VIEW of memory that the
+        engine's close() releases: it (and host_picture()'s) must not be touched after that."""
         p = lib().hvk_host_alloc(self.h, count * 4)
         if not p:
             raise HvkError("hvk_host_alloc", HVK_OUT_OF_MEMORY)

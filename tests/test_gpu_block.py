@@ -14,6 +14,7 @@ import subprocess
 
 import numpy as np
 import pytest
+from conftest import require_ref
 
 import hacktv_amd as H
 import util
@@ -54,6 +55,7 @@ def test_whole_blocks_equal_the_reference(golden, batches, env, monkeypatch):
     (default) and the raster + filter kernel pair (HVK_DIRECT=0)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    require_ref(os.path.join(REF, "hacktv_ref"))
     conf, sr = golden.conf("i_full")
     marks, total = [], 0
     for b in batches:
@@ -89,8 +91,7 @@ def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
     pin = os.path.join(REF, "pin_time.so")
     tti = os.path.join(REF, "demo.tti")
     for f in (hvk, pin, tti):
-        if not os.path.exists(f):
-            pytest.skip("%s not built (needs /root/reference at build time)" % f)
+        require_ref(f)
     env = dict(os.environ, LD_PRELOAD=pin, TZ="UTC", HVK_BATCH="2")
     env.pop("HVK_PIN_TIME", None)
     flags = [f.replace("@REF@", REF) for f in LONG["l_tti"]["flags"]]
@@ -133,8 +134,7 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    if not os.path.exists(os.path.join(REF, "hacktv_ref")):
-        pytest.skip("oracle/_ref/hacktv_ref not built (needs /root/reference at build time)")
+    require_ref(os.path.join(REF, "hacktv_ref"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
            "--dry-run-backend", "gloo", "--no-cpu-baseline"]
@@ -188,8 +188,7 @@ def test_dropin_resident_set_does_not_grow_with_the_run(flags):
     signal (one-off growth of the runtime's pools) the resident set stays where it is."""
     psutil = pytest.importorskip("psutil")
     exe = os.path.join(REF, "hacktv_hvk")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/hacktv_hvk not built")
+    require_ref(exe)
     S = 120
     n = S * 16000000 * 4
     p = subprocess.Popen([exe] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
@@ -235,8 +234,8 @@ def test_two_minutes_in_the_stream_still_equals_the_reference(mode, first):
     reference CLI: the same bytes. And frames 1000 .. 1011 of SECAM-L: 578 000 lines into the colour sub-carrier's
     chain, batch after batch on the device."""
     ref, hvk = os.path.join(REF, "hacktv_ref"), os.path.join(REF, "hacktv_hvk")
-    if not (os.path.exists(ref) and os.path.exists(hvk)):
-        pytest.skip("oracle/_ref binaries not built")
+    require_ref(ref)
+    require_ref(hvk)
     flags = ["-m", mode, "-s", "16000000", "--filter", "-o", "-", "test"]
     skip, take = first * 2560000, 12 * 2560000
 

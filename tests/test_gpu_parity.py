@@ -3,6 +3,7 @@ the oracle and with the committed outputs of the unmodified reference.
 Bit-exact: everything on this path is integer arithmetic."""
 import numpy as np
 import pytest
+from conftest import require_ref
 
 import hacktv_amd as H
 import oracle
@@ -269,8 +270,7 @@ def test_dropin_binary_equals_reference_cli(golden):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hvk = os.path.join(root, "oracle", "_ref", "hacktv_hvk")
     ref = os.path.join(root, "oracle", "_ref", "hacktv_ref")
-    if not os.path.exists(hvk):
-        pytest.skip("oracle/_ref/hacktv_hvk not built (needs /root/reference at build time)")
+    require_ref(hvk)
 
     def run(binary, flags, nbytes):
         env = dict(os.environ, HVK_BATCH="2")
@@ -333,8 +333,7 @@ def test_shim_equals_reference_engine_line_by_line(mode, sr, frames, flags, pr):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "oracle", "_ref", "shim_check")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/shim_check not built (needs /root/reference at build time)")
+    require_ref(exe)
     env = dict(os.environ, HVK_BATCH="2")
     r = subprocess.run([exe, mode, str(sr), str(frames), str(flags)] + ([str(pr)] if pr else []),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
