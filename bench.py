@@ -102,6 +102,211 @@ def cpu_baseline(log):
             "sample": "oracle/liboracle.so, 20 frames of -m i --filter on one core"}
 
 
+def ref_stream_sha(mode, sr, cli_flags, first, count, frame_bytes, env_extra=None):
+    """sha256 of frames [first, first + count) of the unmodified reference CLI's output for these flags, run now
+    (None: oracle/_ref/hacktv_ref is not there)."""
+    import hashlib
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
+    if not os.path.exists(ref_bin):
+        return None
+    # a clean environment: under rocprofv3 the child would inherit the profiler's LD_PRELOAD and tool settings
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS", "ROCPROFILER"))}
+    env.update(env_extra or {})
+    p = subprocess.Popen([ref_bin, "-m", mode, "-s", str(sr)] + list(cli_flags) + ["-o", "-", "test"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    skip, left, h = first * frame_bytes, count * frame_bytes, hashlib.sha256()
+    while skip > 0:
+        chunk = p.stdout.read(min(skip, 1 << 22))
+        if not chunk:
+            break
+        skip -= len(chunk)
+    while left > 0:
+        chunk = p.stdout.read(min(left, 1 << 22))
+        if not chunk:
+            break
+        h.update(chunk)
+        left -= len(chunk)
+    p.kill()
+    p.wait()
+    return h.hexdigest() if left == 0 else None
+
+
+def raw_teletext_rows(g, slot_counter):
+    """The packets the reference's `raw:` source hands to the 32 teletext lines of the next frame (tests/golden/ttraw.bin,
+    256 records): it reads on from where it stood, and the read that hits the end of the file yields NO packet before the
+    file starts over (src/teletext.c:1187-1202). slot_counter: [line slots served so far] (updated)."""
+    rec = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "ttraw.bin"), "rb").read(), np.uint8).reshape(-1, 42)
+    n = len(rec)
+    p = np.zeros((32, 45), np.uint8)
+    p[:, 0] = 0x55
+    p[:, 1] = 0x55
+    p[:, 2] = 0x27
+    mask = 0
+    for r in range(32):
+        j = slot_counter[0] % (n + 1)
+        slot_counter[0] += 1
+        if j < n:
+            p[r, 3:] = rec[j]
+            mask |= 1 << r
+    return p, mask
+
+
+def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, stage_every_step=False, teletext=False, fresh_e2e=False):
+    """One BASELINE configuration as a bench section: golden case `case` (its preset edits and CLI flags), F-frame blocks.
+    Gate: every sample of the first block == the unmodified reference CLI's output for the same flags, run in this job.
+    Then `steps` steps: launches of the staged block (inputs resident), or stage + launch of a fresh block each
+    (stage_every_step: SECAM, whose colour chain runs when a block is staged)."""
+    import hashlib
+    import util
+    c = g.cases[case]
+    conf, sr = g.conf(case)
+    real = bool(c["real"])
+    fs = c.get("frame_samples", c["width"] * c["lines"])
+    frame_bytes = fs * (2 if real else 4)
+    e = H.Engine(conf, sr, device=device, max_frames=F)
+    e.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    e.frame_upload(0, g.frame(case))
+    out = torch.empty((F * fs * 2,), dtype=torch.int16, device=torch.device("cuda", device))
+    tt_slots = [0]
+    state = {"next": 0}
+
+    def stage_block():
+        first = state["next"]
+        if teletext:
+            for i in range(F):
+                rows, mask = raw_teletext_rows(g, tt_slots)
+                e.teletext_packets(i, rows, mask)
+        e.stage(first, 1, F)
+        state["next"] = first + F
+
+    def feed(upto_blocks):
+        # audio for the blocks to come (hvk_audio_needed counts from the engine's own next frame, which stage() does not
+        # advance: feed by position instead)
+        need = upto_blocks * F
+        while e.audio_needed(need) > 0:
+            e.audio_write(g.audio)
+
+    nblocks = 1 + ((warmup + steps + 1) if stage_every_step else 0) + (1 if fresh_e2e else 0)
+    feed(nblocks)
+    t0 = time.perf_counter()
+    stage_block()
+    e.sync()
+    t_stage = time.perf_counter() - t0
+    e.launch(ctypes.c_void_p(out.data_ptr()))
+    torch.cuda.synchronize()
+    got = hashlib.sha256(util.stream_bytes(out.cpu().numpy().reshape(-1, 2), real)).hexdigest()
+    flags = g.cli_flags(case)
+    want = ref_stream_sha(c["mode"], sr, flags, 0, F, frame_bytes)
+    if want is None:
+        cum = c["sha256_cumulative"]
+        if F <= len(cum):
+            want = cum[F - 1]
+    if want is None:
+        gate = "no reference to compare %d frames with (oracle/_ref/hacktv_ref missing): NOT gated" % F
+    elif got != want:
+        raise SystemExit("parity gate failed for %s: %d frames differ from the reference CLI's output" % (label, F))
+    else:
+        gate = "all %d frames x %d samples sha256 == hacktv_ref %s run in this job" % (F, fs, " ".join(["-m", c["mode"], "-s", str(sr)] + flags))
+
+    def step():
+        if stage_every_step:
+            stage_block()
+        e.launch(ctypes.c_void_p(out.data_ptr()))
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = {
+        "workload": " ".join(["-m", c["mode"], "-s", str(sr)] + [f if not f.startswith("raw:") else "raw:tests/golden/ttraw.bin" for f in flags] + ["test"]),
+        "frames_per_step": F,
+        "step": "stage (host pre-passes, colour chain on the device) + launch of a fresh block" if stage_every_step else "launch of the staged block (side inputs resident)",
+        "Msamples_per_s": round(F * fs / dt / 1e6, 1),
+        "ms_per_step": round(dt * 1e3, 4),
+        "path_frac": round(BYTES_PER_SAMPLE * F * fs / dt / 1e9 / HBM_PEAK_GBS, 4),
+        "parity_gate": gate,
+        "kernels": e.kernel_names(),
+        "first_block_stage_s": round(t_stage, 4),
+    }
+    try:
+        res["secam_lines"] = e.secam_stats()        # (SECAM only: how the colour chain's speculation went)
+    except Exception:
+        pass
+    if fresh_e2e:
+        host_out = torch.empty((F * fs * 2,), dtype=torch.int16).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stage_block()
+        e.launch(ctypes.c_void_p(out.data_ptr()))
+        host_out.copy_(out, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t0
+        res["fresh_block_end_to_end_Msamples_per_s"] = round(F * fs / t1 / 1e6, 1)
+        res["fresh_block_note"] = "one fresh block, nothing overlapped: stage (host pre-passes + H2D) + render + D2H of the int16 IQ into pinned host memory"
+    e.close()
+    return res
+
+
+def dropin_section(flags, seconds=4, pin_clock=False):
+    """The drop-in binary (the reference's own main(), av_test.c, rf_file.c, teletext.c + the video.h shim + libhvk) on
+    these CLI flags: its first frames against the reference CLI's (both with the wall clock pinned where teletext needs
+    it), then its steady-state rate from two run lengths."""
+    import hashlib
+    ref = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
+    hvk = os.path.join(ROOT, "oracle", "_ref", "hacktv_hvk")
+    pin = os.path.join(ROOT, "oracle", "_ref", "pin_time.so")
+    if not (os.path.exists(ref) and os.path.exists(hvk)):
+        return None
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS", "ROCPROFILER"))}
+    env["HVK_BATCH"] = "32"
+    if pin_clock:
+        env["LD_PRELOAD"] = pin
+        env["TZ"] = "UTC"
+    flags = [f.replace("@REF@", os.path.join(ROOT, "oracle", "_ref")) for f in flags]
+
+    def run(binary, nbytes, digest=False):
+        t = time.perf_counter()
+        p = subprocess.Popen([binary] + flags + ["-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        left, h = nbytes, hashlib.sha256()
+        while left > 0:
+            chunk = p.stdout.read(min(left, 1 << 22))
+            if not chunk:
+                break
+            if digest:
+                h.update(chunk)
+            left -= len(chunk)
+        dt = time.perf_counter() - t
+        p.kill()
+        p.wait()
+        return dt, (h.hexdigest() if digest and left == 0 else None)
+
+    fb = 640000 * 4
+    nfr = 40
+    _, a = run(ref, nfr * fb, True)
+    _, b = run(hvk, nfr * fb, True)
+    if a is None or b is None or a != b:
+        raise SystemExit("drop-in gate failed: hacktv_hvk %s differs from hacktv_ref within the first %d frames" % (" ".join(flags), nfr))
+    sr = 16000000
+    t1, _ = run(hvk, 1 * sr * 4)
+    t2, _ = run(hvk, (1 + seconds) * sr * 4)
+    r1, _ = run(ref, 1 * sr * 4)
+    r2, _ = run(ref, 3 * sr * 4)
+    return {
+        "workload": "hacktv_hvk " + " ".join(os.path.basename(f) if f.endswith(".tti") else f for f in flags) + " -o - test" + (" (time() pinned for both binaries: oracle/pin_time.c)" if pin_clock else ""),
+        "parity_gate": "first %d frames of the drop-in binary's output sha256 == the reference CLI's, both run in this job" % nfr,
+        "Msamples_per_s": round(seconds * sr / (t2 - t1) / 1e6, 1),
+        "reference_cli_Msamples_per_s": round(2 * sr / (r2 - r1) / 1e6, 1),
+        "note": "end to end through a pipe: the reference's main() and file sink, the shim's read-ahead worker (host sound pre-pass, uploads), "
+                "render, D2H; (t[%d s of signal] - t[1 s]) / %d s" % (1 + seconds, seconds),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,9 +314,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL reassembly out of the step")
+    ap.add_argument("--walk-rounds", action="store_true",
+                    help="every step takes the NEXT round of blocks: sound chains handed from rank to rank, host pre-pass, H2D and render of a fresh block inside the timed loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--noaudio", action="store_true", help="render the --noaudio variant instead")
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-picture section")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sections for BASELINE configs 1, 3, 4 and --noaudio")
     ap.add_argument("--dry-run-backend", default=None, help="gloo: dry-run the N > 1 path with every rank on GPU 0 (no RCCL peers needed)")
     args = ap.parse_args()
 
@@ -143,9 +351,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group(args.dry_run_backend)
+            hostg = None                    # the default group is a host-side one already
         else:
             dist.init_process_group("nccl", device_id=dev)
+            hostg = dist.new_group(backend="gloo")      # the sound chains' state travels between the ranks' hosts
 
+    if N == 1:
+        hostg = None
     g = util.Golden()
     flags = H.FLAG_FILTER | (H.FLAG_NOAUDIO if args.noaudio else 0)
     conf = H.preset(MODE, flags)
@@ -186,9 +398,24 @@ def main():
         p.wait()
         return h.hexdigest()
 
-    def feed_audio(upto_frame):
+    def feed_audio(upto_frame, source_pos=None):
+        """32 kHz source samples up to frame `upto_frame`; source_pos: the engine has just taken over another rank's sound
+        chains and its (empty) queue goes on at that position of the source -- the test tone is a loop."""
+        if source_pos is not None:
+            e.audio_write(g.audio[source_pos % len(g.audio):])
         while e.audio_needed(upto_frame) > 0:
             e.audio_write(g.audio)
+
+    def stage_block(block, Fb, last=False):
+        """Stage block `block` (Fb frames) on the rank it belongs to: take the sound chains over from the rank that staged the
+        block before, run them over this block's frames only, hand them on."""
+        first = block * Fb
+        pos = None if args.noaudio else sharding.sound_state_recv(e, N, block, hostg)
+        if not args.noaudio:
+            feed_audio(first + Fb, pos)
+        e.stage(first, 1, Fb, prev_slots=[0] * Fb)
+        if not args.noaudio:
+            sharding.sound_state_send(e, N, block, hostg, last=last)
 
     # ---- N > 1: the sharded path end to end on short blocks, BEFORE anything is timed: every rank stages, renders and
     # sends two rounds of 2-frame blocks through the same calls as the timed loop (stage with the predecessor slot,
@@ -203,9 +430,7 @@ def main():
         works = []
         for rnd in range(rounds + 1):
             if rnd < rounds:
-                first = sharding.first_frame_of(rank, N, rnd, Fg)
-                feed_audio(first + Fg)
-                e.stage(first, 1, Fg, prev_slots=[0] * Fg)
+                stage_block(sharding.block_of(rank, N, rnd), Fg, last=(rnd == rounds - 1 and rank == N - 1))
                 e.launch(ctypes.c_void_p(bufs[rnd & 1].data_ptr()))
                 torch.cuda.synchronize()
             if rnd > 0:
@@ -239,12 +464,10 @@ def main():
     e.set_stream(ctypes.c_void_p(stream.cuda_stream))
     e.frame_upload(0, g.frame("i_full"))
     t0 = time.perf_counter()
-    feed_audio(first_frame + F)
-    e.stage(first_frame, 1, F, prev_slots=[0] * F)
+    stage_block(sharding.block_of(rank, N, 0), F, last=(rank == N - 1 and not args.walk_rounds))
     e.sync()
     t_stage = time.perf_counter() - t0
-    log("rank 0 staged %d frames (host control path + H2D) in %.2f s = %.1f Msamples/s" %
-        (F, t_stage, (first_frame + F) * FS / t_stage / 1e6))
+    log("rank 0 staged %d frames (host control path + H2D) in %.2f s = %.1f Msamples/s" % (F, t_stage, F * FS / t_stage / 1e6))
 
     # two output buffers per rank and two stream buffers on the root: round s is sent while round s + 1 is rendered
     nbuf = 2 if gather else 1
@@ -257,9 +480,16 @@ def main():
     mine = mines[0]
     pending = []
 
+    walk = {"round": 0, "last_round": None}
+
     def step(i=0):
-        """Render this rank's block into buffer i & 1 while the block rendered before travels to rank 0."""
+        """Render this rank's block into buffer i & 1 while the block rendered before travels to rank 0. --walk-rounds:
+        every step is the NEXT round's block -- sound chains from the rank before, host pre-pass, H2D, then the render."""
         b = i % nbuf
+        if args.walk_rounds and walk["round"] > 0:
+            stage_block(sharding.block_of(rank, N, walk["round"]), F, last=(walk["round"] == walk["last_round"] and rank == N - 1))
+        if args.walk_rounds:
+            walk["round"] += 1
         e.launch(ctypes.c_void_p(mines[b].data_ptr()))
         if gather:
             if dry:
@@ -276,6 +506,9 @@ def main():
             pending[:] = []
 
     # ---- parity gate before any number: EVERY sample of this rank's block against the unmodified reference ----
+    # (--walk-rounds: rounds 0 [this gate], then warm-up and timed steps one round each, then nothing: the last rank of the
+    # last round keeps the chains' state to itself)
+    walk["last_round"] = args.warmup + args.steps if args.walk_rounds else 0
     step(0)
     drain()
     torch.cuda.synchronize()
@@ -326,12 +559,34 @@ def main():
             dt = float(tt.item())
         return dt
 
-    e.timing_enable(True)
-    dt = timed(step, drain)
+    walk_gate = None
+    if args.walk_rounds:
+        # one pass: every step stages and renders the next round (the events' cost is nothing beside a stage)
+        e.timing_enable(True)
+        dt = timed(step, drain)
+        raster_ms, n_r = e.timing_read(0)
+        filter_ms, n_f = e.timing_read(1)
+        e.timing_enable(False)
+        if not args.noaudio:
+            # ... and the LAST round walked is the reference's too: this rank's block of it, every sample
+            lastb = sharding.block_of(rank, N, walk["last_round"])
+            got = hashlib.sha256(mines[(args.warmup + args.steps - 1) % nbuf].cpu().numpy().tobytes()).hexdigest()
+            want = ref_sha(lastb * F, F)
+            if want is not None and got != want:
+                raise SystemExit("parity gate failed on rank %d: block %d (round %d of the walk) differs from the reference CLI's output" % (rank, lastb, walk["last_round"]))
+            walk_gate = None if want is None else "round %d (frames %d..%d on rank %d) sha256 == reference CLI" % (walk["last_round"], lastb * F, lastb * F + F - 1, rank)
+            log("walk gate: %s" % walk_gate)
+    else:
+        # the timed region: K steps, nothing but launches (and the gather at N > 1) between the barriers
+        dt = timed(step, drain)
 
-    raster_ms, n_r = e.timing_read(0)
-    filter_ms, n_f = e.timing_read(1)
-    e.timing_enable(False)
+        # the kernels' own time, for the roofline object: the same steps once more with HIP events recorded around every
+        # launch on the launch stream (their recording costs a little: not inside the region `value` comes from)
+        e.timing_enable(True)
+        timed(step, drain)
+        raster_ms, n_r = e.timing_read(0)
+        filter_ms, n_f = e.timing_read(1)
+        e.timing_enable(False)
 
     samples_per_step = N * F * FS
     value = samples_per_step * args.steps / dt / 1e6
@@ -339,13 +594,13 @@ def main():
 
     # N > 1: the same steps without the reassembly, for the record (the ranks share nothing then)
     render_only = None
-    if gather:
+    if gather and not args.walk_rounds:
         dt2 = timed(lambda i: e.launch(ctypes.c_void_p(mines[i % nbuf].data_ptr())), lambda: None)
         render_only = samples_per_step * args.steps / dt2 / 1e6
 
     # ---- one FRESH block end to end: host pre-pass + H2D of the side inputs, render, D2H of the samples ----
     e2e = None
-    if N == 1:
+    if N == 1 and not args.walk_rounds:
         host_out = torch.empty((F * FS * 2,), dtype=torch.int16).pin_memory()
         nxt = first_frame + F
         t0 = time.perf_counter()
@@ -447,23 +702,26 @@ def main():
     # chain on one short block ----
     secam = None
     if N == 1 and not args.no_moving:
-        Fs = F
-        es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
-        es.frame_upload(0, g.frame("l_full"))
-        for k in range(2):
-            es.stage(k * Fs, 1, Fs)
-            es.launch()
-        es.sync()
-        ksteps = 5
-        t0 = time.perf_counter()
-        for k in range(ksteps):
-            es.stage((2 + k) * Fs, 1, Fs)
-            es.launch()
-        es.sync()
-        t_dev = (time.perf_counter() - t0) / ksteps
-        st = es.secam_stats()
-        names_s = es.kernel_names()
-        es.close()
+        def secam_run(Fs, ksteps):
+            es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
+            es.frame_upload(0, g.frame("l_full"))
+            for k in range(3):
+                es.stage(k * Fs, 1, Fs)
+                es.launch()
+            es.sync()
+            t0 = time.perf_counter()
+            for k in range(ksteps):
+                es.stage((3 + k) * Fs, 1, Fs)
+                es.launch()
+            es.sync()
+            t_dev = (time.perf_counter() - t0) / ksteps
+            st = es.secam_stats()
+            names_s = es.kernel_names()
+            es.close()
+            return t_dev, st, names_s
+
+        t_dev, st, names_s = secam_run(F, 5)
+        t_big, st_big, _ = secam_run(4 * F, 3)
         os.environ["HVK_SECAM_HOST"] = "1"
         eh = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=8)
         eh.frame_upload(0, g.frame("l_full"))
@@ -475,14 +733,34 @@ def main():
         eh.close()
         del os.environ["HVK_SECAM_HOST"]
         secam = {
-            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % Fs,
-            "Msamples_per_s": round(Fs * FS / t_dev / 1e6, 1),
+            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % F,
+            "Msamples_per_s": round(F * FS / t_dev / 1e6, 1),
             "ms_per_step": round(t_dev * 1e3, 3),
+            "blocks_of_%d_frames" % (4 * F): {"Msamples_per_s": round(4 * F * FS / t_big / 1e6, 1), "ms_per_step": round(t_big * 1e3, 3), "lines": st_big,
+                                               "note": "the chain is one lane per line and bound by the latency of its dependent steps: four times the lines keep four waves per SIMD busy"},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
             "lines": st,
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
-            "note": "lines: worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain",
+            "note": "lines: worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; the number of "
+                    "warm-up lines per start state follows the pictures (test card: 2; exactness rests on the check, not on it)",
         }
+
+    configs = None
+    if N == 1 and not args.no_configs:
+        ksteps = max(10, min(args.steps, 100))
+        configs = {
+            "1_pal_baseband": case_section(H, g, torch, "pal_bb", F, ksteps, 3, local_rank, stream, "config 1"),
+            "3_ntsc_m": case_section(H, g, torch, "m_full", F, ksteps, 3, local_rank, stream, "config 3"),
+            "4_secam_l_teletext_device": case_section(H, g, torch, "l_tt", F, 5, 2, local_rank, stream, "config 4 (raw packets)",
+                                                      stage_every_step=True, teletext=True),
+            "4_secam_l_teletext_demo_tti_dropin": dropin_section(["-m", "l", "-s", "16000000", "--filter", "--teletext", "@REF@/demo.tti"], pin_clock=True),
+            "2_noaudio": case_section(H, g, torch, "i_vsb", F, ksteps, 3, local_rank, stream, "config 2 --noaudio", fresh_e2e=True),
+            "2_noaudio_dropin": dropin_section(["-m", "i", "-s", "16000000", "--filter", "--noaudio"]),
+            "2_dropin": dropin_section(["-m", "i", "-s", "16000000", "--filter"]),
+        }
+        for k2, v2 in configs.items():
+            if v2:
+                log("%s: %s Msamples/s" % (k2, v2.get("Msamples_per_s")))
 
     if rank == 0:
         names = e.kernel_names()
@@ -535,7 +813,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int16 data, int32 accumulate",
-            "data": "synthetic: built-in test card + 1 kHz tone (hacktv test source); every step renders all frames of the staged block again. "
+            "data": "synthetic: built-in test card + 1 kHz tone (hacktv test source); " + ("every step stages (sound chains, host pre-pass, H2D) and renders the NEXT round of blocks. " if args.walk_rounds else "every step renders all frames of the staged block again. ") +
                     "The test card's picture planes (levels, low-passed chroma, burst: per-picture work, hvk_k_prep) are made once when the picture "
                     "is uploaded, OUTSIDE the timed loop, like the other side inputs; with a new picture on every frame that work is per frame: "
                     "moving_pictures.pictures_resident_planes_made_every_step",
@@ -547,7 +825,11 @@ def main():
             },
             "parity_gate": gate,
             "multi_gpu": None if N == 1 else {
-                "ranks": N, "backend": (args.dry_run_backend + " (dry run: every rank on GPU 0, transport through host memory)") if dry else "nccl (RCCL)",
+                "ranks": N, "world_size": dist.get_world_size(),
+                "backend": (args.dry_run_backend + " (dry run: every rank on GPU 0, transport through host memory)") if dry else "nccl (RCCL); the sound chains' state between hosts: gloo",
+                "walk_rounds": bool(args.walk_rounds), "walk_gate": walk_gate,
+                "gathered_Msamples_per_s": round(value, 1) if gather else None,
+                "sound_chains": "handed from rank to rank (hvk_sound_state_export / _import): every rank runs them over its own frames only",
                 "gather_in_step": bool(gather), "gather_overlaps_render": bool(gather and not dry),
                 "seam_gate": seam_gate,
                 "render_only_Msamples_per_s": None if render_only is None else round(render_only, 1),
@@ -560,7 +842,7 @@ def main():
             "host_prepass": {
                 "note": "staging one block before the clock: host audio control path (serial FM phasor chain on one core) and H2D of the side streams",
                 "stage_s": round(t_stage, 3),
-                "Msamples_per_s": round((first_frame + F) * FS / t_stage / 1e6, 1),
+                "Msamples_per_s": round(F * FS / t_stage / 1e6, 1),
             },
         }
         if other:
@@ -571,6 +853,8 @@ def main():
             res["moving_pictures"] = moving
         if secam:
             res["secam_l"] = secam
+        if configs:
+            res["baseline_configs"] = configs
         if not args.no_cpu_baseline and N == 1:
             res["cpu_baseline"] = cpu_baseline(log)
         print(json.dumps(res), flush=True)

@@ -346,6 +346,8 @@ struct hvk_audio {
 	/* 32 kHz stereo source queue */
 	int16_t *src;
 	size_t src_len, src_cap, src_pos;
+	int64_t src_base;       /* position of src[0] in the 32 kHz source stream */
+	int64_t generated;      /* stream samples the chains have worked through on THIS engine (not counting an imported start) */
 
 	int interp;             /* 32 kHz tick accumulator (src/video.c:3273-3276) */
 	int64_t pos;            /* stream samples generated so far (always a line boundary) */
@@ -450,7 +452,7 @@ int64_t hvk_audio_position(const hvk_audio_t *a) { return(a->pos); }
 
 int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples)
 {
-	if(a->src_pos > 0 && a->src_pos == a->src_len) a->src_pos = a->src_len = 0;
+	if(a->src_pos > 0 && a->src_pos == a->src_len) { a->src_base += (int64_t) a->src_pos; a->src_pos = a->src_len = 0; }
 
 	if(a->src_len + nsamples > a->src_cap)
 	{
@@ -459,6 +461,7 @@ int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples)
 		{
 			memmove(a->src, a->src + a->src_pos * 2, (a->src_len - a->src_pos) * 2 * sizeof(int16_t));
 			a->src_len -= a->src_pos;
+			a->src_base += (int64_t) a->src_pos;
 			a->src_pos = 0;
 		}
 		if(a->src_len + nsamples > a->src_cap)
@@ -854,6 +857,7 @@ static void _line(hvk_audio_t *a, int16_t *carriers, const int W)
 	}
 
 	a->pos += W;
+	a->generated += W;
 	a->line_no++;
 }
 
@@ -925,6 +929,108 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 
 	if(a->oom) return(HVK_OUT_OF_MEMORY);
 	return(nsym);
+}
+
+/* ---- the chains' state, to be carried to another engine ----
+ *
+ * The sound chains are one recurrence over the whole stream: an engine that renders frames f .. can only
+ * start where the engine that rendered up to f - 1 stopped. This is everything it stopped with -- the phasors (phase,
+ * steps to the next amplitude correction, sample in force), the 32 kHz tick accumulator, both limiters (filter
+ * histories, look-ahead ring), the NICAM framer (J.17 history, the block being filled, the frame being sent and the bit
+ * it stands at, the differential phase, the symbol schedule) and the last symbols, whose pulses reach into the next
+ * samples -- as one flat block; pointers inside it are set again by the importer. Both ends are the same build. */
+#define STATE_MAGIC  0x48564B41u    /* "HVKA" */
+#define STATE_SYMS   256
+typedef struct {
+	uint32_t magic, bytes;
+	int32_t width, sample_rate;
+	int32_t interp;
+	int32_t has_lim, nicam_on;
+	int64_t pos, line_no;
+	int64_t source_pos;         /* 32 kHz source samples consumed so far */
+	_phasor_t fm, am, a2, a2_pilot, a2_signal;
+	_limiter_t lim, a2_lim;
+	_nicam_t nicam;
+	int64_t sym_first;          /* symbol index of sym[0] */
+	int32_t nsym;
+	uint8_t sym[STATE_SYMS];
+} _audio_state_t;
+
+size_t hvk_audio_state_bytes(void) { return(sizeof(_audio_state_t)); }
+
+int64_t hvk_audio_generated(const hvk_audio_t *a) { return(a ? a->generated : 0); }
+
+int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes)
+{
+	_audio_state_t *st = buf;
+	size_t n;
+
+	if(!a || !buf || bytes < sizeof(*st)) return(HVK_ERROR);
+	memset(st, 0, sizeof(*st));
+	st->magic = STATE_MAGIC;
+	st->bytes = (uint32_t) sizeof(*st);
+	st->width = a->width;
+	st->sample_rate = a->sample_rate;
+	st->interp = a->interp;
+	st->has_lim = a->has_lim;
+	st->nicam_on = a->nicam_on;
+	st->pos = a->pos;
+	st->line_no = a->line_no;
+	st->source_pos = a->src_base + (int64_t) a->src_pos;
+	st->fm = a->fm; st->am = a->am; st->a2 = a->a2; st->a2_pilot = a->a2_pilot; st->a2_signal = a->a2_signal;
+	st->lim = a->lim;
+	st->a2_lim = a->a2_lim;
+	st->nicam = a->nicam;
+	n = a->sym_len < STATE_SYMS ? a->sym_len : STATE_SYMS;
+	st->nsym = (int32_t) n;
+	st->sym_first = a->sym_k0 + (int64_t) (a->sym_len - n);
+	if(n) memcpy(st->sym, a->sym + (a->sym_len - n), n);
+	return(HVK_OK);
+}
+
+/* *source_pos receives the position in the 32 kHz source stream the chains go on from. A queue that holds it keeps its
+ * later samples; otherwise the queue is emptied and the NEXT hvk_audio_push() is taken to start there. */
+int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_t *source_pos)
+{
+	const _audio_state_t *st = buf;
+
+	if(!a || !buf || bytes < sizeof(*st) || st->magic != STATE_MAGIC || st->bytes != sizeof(*st)) return(HVK_ERROR);
+	if(st->width != a->width || st->sample_rate != a->sample_rate || st->has_lim != a->has_lim || st->nicam_on != a->nicam_on) return(HVK_ERROR);
+	if(st->fm.on != a->fm.on || st->am.on != a->am.on || st->a2.on != a->a2.on) return(HVK_ERROR);   /* another configuration's state */
+	if(st->nsym < 0 || st->nsym > STATE_SYMS) return(HVK_ERROR);
+
+	a->interp = st->interp;
+	a->pos = st->pos;
+	a->line_no = st->line_no;
+	a->last_w = 0;
+	a->fm = st->fm; a->am = st->am; a->a2 = st->a2; a->a2_pilot = st->a2_pilot; a->a2_signal = st->a2_signal;
+	{
+		/* the tables the filters and the look-ahead window point at are this engine's own */
+		const int32_t *vt = a->lim.pre.taps, *ft = a->lim.flat.taps, *vt2 = a->a2_lim.pre.taps, *ft2 = a->a2_lim.flat.taps;
+		const int16_t *sh = a->lim.shape, *sh2 = a->a2_lim.shape;
+		a->lim = st->lim;
+		a->a2_lim = st->a2_lim;
+		a->lim.pre.taps = vt; a->lim.flat.taps = ft; a->lim.shape = sh;
+		a->a2_lim.pre.taps = vt2; a->a2_lim.flat.taps = ft2; a->a2_lim.shape = sh2;
+	}
+	a->nicam = st->nicam;
+
+	a->sym_len = 0;
+	a->sym_k0 = st->sym_first;
+	for(int i = 0; i < st->nsym; i++) _sym_append(a, st->sym[i]);
+	if(a->oom) return(HVK_OUT_OF_MEMORY);
+
+	if(st->source_pos >= a->src_base + (int64_t) a->src_pos && st->source_pos <= a->src_base + (int64_t) a->src_len)
+	{
+		a->src_pos = (size_t) (st->source_pos - a->src_base);
+	}
+	else
+	{
+		a->src_pos = a->src_len = 0;
+		a->src_base = st->source_pos;
+	}
+	if(source_pos) *source_pos = st->source_pos;
+	return(HVK_OK);
 }
 
 /* The newest NICAM symbol whose pulse has started by stream sample m, and

@@ -968,6 +968,33 @@ extern "C" int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t ns
 	return(hvk_audio_push(e->audio, stereo, nsamples));
 }
 
+/* The serial sound chains' state (hvk_audio.c): what an engine that renders the frames after this engine's last staged
+ * one has to start from, and how much of the stream this engine's chains have worked through themselves. */
+extern "C" size_t hvk_sound_state_size(const hvk_engine_t *e)
+{
+	return((e && e->audio) ? hvk_audio_state_bytes() : 0);
+}
+
+extern "C" int hvk_sound_state_export(hvk_engine_t *e, void *buf, size_t bytes)
+{
+	if(!e || !buf) return(HVK_ERROR);
+	if(!e->audio) return(HVK_UNSUPPORTED);
+	if(e->poisoned) return(HVK_ERROR);
+	return(hvk_audio_state_export(e->audio, buf, bytes));
+}
+
+extern "C" int hvk_sound_state_import(hvk_engine_t *e, const void *buf, size_t bytes, int64_t *source_position)
+{
+	if(!e || !buf) return(HVK_ERROR);
+	if(!e->audio) return(HVK_UNSUPPORTED);
+	return(hvk_audio_state_import(e->audio, buf, bytes, source_position));
+}
+
+extern "C" int64_t hvk_sound_samples_generated(const hvk_engine_t *e)
+{
+	return((e && e->audio) ? hvk_audio_generated(e->audio) : 0);
+}
+
 extern "C" size_t hvk_audio_needed(const hvk_engine_t *e, int nframes)
 {
 	if(!e || !e->audio) return(0);
@@ -1400,6 +1427,24 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
 	}
 	if(e->secam && (stride != 1 || first_frame != e->secam_next)) return(HVK_UNSUPPORTED);   /* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
+	{
+		/* Where the last line of a frame shows picture (525 lines) it lies within the video filter's reach of the next
+		 * frame's first samples: a frame whose predecessor the engine does not have -- a stride, a jump -- needs the
+		 * caller to name the slot that holds it (hvk_stage_strided_prev(); the frame's own slot where the picture stays).
+		 * Exact or refused: no "nearly". */
+		const hvk_linedesc_t *dl = &e->t.desc[e->t.k.lines - 1];
+		if(dl->ar > dl->al && !e->t.k.rawbb)
+		{
+			for(int i = 0; i < nframes; i++)
+			{
+				if(first_frame + i * stride == 0) continue;
+				if(stride == 1 && i > 0) continue;
+				if(stride == 1 && e->carry_valid && e->carry_frame + 1 == first_frame) continue;
+				if(prev_slots && prev_slots[i] >= 0 && prev_slots[i] < e->frame_slots) continue;
+				return(HVK_UNSUPPORTED);
+			}
+		}
+	}
 
 	const hvk_kconst_t &k = e->t.k;
 	const int64_t FS = k.frame_samples;

@@ -21,6 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels", "hvk_planes_refresh",
+    "hvk_sound_state_size", "hvk_sound_state_export", "hvk_sound_state_import", "hvk_sound_samples_generated",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
@@ -97,6 +98,12 @@ def lib():
         L.hvk_output_device_ptr.restype = vp
         L.hvk_timing_enable.argtypes = [vp, i32]
         L.hvk_planes_refresh.argtypes = [vp, vp, i32]
+        L.hvk_sound_state_size.argtypes = [vp]
+        L.hvk_sound_state_size.restype = C.c_size_t
+        L.hvk_sound_state_export.argtypes = [vp, vp, C.c_size_t]
+        L.hvk_sound_state_import.argtypes = [vp, vp, C.c_size_t, vp]
+        L.hvk_sound_samples_generated.argtypes = [vp]
+        L.hvk_sound_samples_generated.restype = C.c_int64
         L.hvk_timing_read.argtypes = [vp, i32, vp, vp]
         L.hvk_kernel_names.argtypes = [vp, C.c_char_p, i32]
         L.hvk_table.argtypes = [vp, C.c_char_p, vp, C.c_long]
@@ -322,6 +329,25 @@ class Engine:
     def set_levels(self, mode):
         """0 auto, 1 table look-up, 2 computed per pixel (hvk_set_levels)."""
         return self._chk("hvk_set_levels", lib().hvk_set_levels(self.h, mode))
+
+    def sound_state_size(self):
+        return lib().hvk_sound_state_size(self.h)
+
+    def sound_state_export(self):
+        """The serial sound chains' state after the last frame staged (bytes; hvk_sound_state_export)."""
+        n = lib().hvk_sound_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        self._chk("hvk_sound_state_export", lib().hvk_sound_state_export(self.h, buf, n))
+        return buf.raw
+
+    def sound_state_import(self, state):
+        """... into this engine; returns the position in the 32 kHz source stream the chains go on from."""
+        pos = C.c_int64(0)
+        self._chk("hvk_sound_state_import", lib().hvk_sound_state_import(self.h, state, len(state), C.byref(pos)))
+        return pos.value
+
+    def sound_samples_generated(self):
+        return lib().hvk_sound_samples_generated(self.h)
 
     def planes_refresh(self, slots):
         """Make the picture planes of these slots now (hvk_planes_refresh)."""

@@ -9,8 +9,10 @@ block straight into its slot of the root's stream buffer, so on an xGMI node
 each peer uses its own link to the root; no ring.
 
 Limits of the sharded path (the engine refuses what it cannot shard): SECAM colour and FM video are serial chains
-over the whole stream -- those modes render on one rank only. Every rank must be fed the whole
-audio stream: the sound carriers' phasor chain is serial too, and each rank runs it up to its own frames.
+over the whole stream -- those modes render on one rank only. The sound carriers' chain is
+serial too, but its state is small: the rank that staged block b - 1 hands it to the rank that stages block b
+(sound_state_send / sound_state_recv, a few kilobytes through a host-side group), so every rank runs the chain over
+its OWN frames only -- one after the other, as the recurrence demands, but nobody twice.
 
 This module is transport plumbing over torch.distributed; it works with the
 `nccl` backend (RCCL on ROCm) on GPUs and with `gloo` on CPU tensors, which is
@@ -83,3 +85,25 @@ def gather_blocks(local, root_buf, rank, world, root=0, group=None, via_host=Fal
     for w in works:
         w.wait()
     return works
+
+
+def sound_state_send(engine, world, block, group=None, last=False):
+    """After staging block `block`: hand the sound chains' state to the rank that stages block + 1
+    (hvk_sound_state_export). `group`: a host-side (gloo) group -- the state travels as a CPU byte tensor.
+    last: nobody stages a block after this one."""
+    import torch
+    if world == 1 or last:
+        return
+    st = bytearray(engine.sound_state_export())
+    dist.send(torch.frombuffer(st, dtype=torch.uint8), (block + 1) % world, group)
+
+
+def sound_state_recv(engine, world, block, group=None):
+    """Before staging block `block` (> 0): take the chains over from the rank that staged block - 1. Returns the
+    position in the 32 kHz source stream the chains go on from (feed the engine's audio queue from there), or None."""
+    import torch
+    if world == 1 or block == 0:
+        return None
+    buf = torch.empty(engine.sound_state_size(), dtype=torch.uint8)
+    dist.recv(buf, (block - 1) % world, group)
+    return engine.sound_state_import(buf.numpy().tobytes())

@@ -193,6 +193,21 @@ int hvk_audio_write(hvk_engine_t *e, const int16_t *stereo, size_t nsamples);
  * rendered with audio (0 when the mode has no audio sub-carriers). */
 size_t hvk_audio_needed(const hvk_engine_t *e, int nframes);
 
+/* Sharded streams with sound. The FM / AM carrier phasors, the limiter and the NICAM framer are ONE chain over the whole
+ * stream (src/video.c:2259-2276, :3261-3450; src/fir.c:758-870; src/nicam728.c:140-249): an engine that renders frames
+ * f, f + 1, ... has to start where the engine that rendered up to frame f - 1 stopped. hvk_sound_state_export() writes
+ * that state -- everything the chains carry from one line to the next, hvk_sound_state_size() bytes, valid between
+ * engines of the same build and configuration -- as it stands after the last frame staged;
+ * hvk_sound_state_import() puts it into an engine that has staged nothing of those frames yet. *source_position
+ * (may be NULL) receives the position in the 32 kHz source stream the chains go on from: an engine whose audio queue
+ * does not hold it drops what it holds and takes the next hvk_audio_write() to start there. With it a rank of a
+ * sharded render runs the chains over its own frames only (hvk_sound_samples_generated() says over how many samples
+ * it did) instead of over the whole stream up to them. */
+size_t hvk_sound_state_size(const hvk_engine_t *e);
+int hvk_sound_state_export(hvk_engine_t *e, void *buf, size_t bytes);
+int hvk_sound_state_import(hvk_engine_t *e, const void *buf, size_t bytes, int64_t *source_position);
+int64_t hvk_sound_samples_generated(const hvk_engine_t *e);
+
 /* --passthru (conf.passthru != 0): the next nsamples int16 I/Q pairs of the
  * external signal that is added to the output (src/video.c:3517-3541), in
  * stream order from the source's first sample. Like the reference the engine
@@ -230,8 +245,9 @@ int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int
 /* (On 525 lines the last line of a frame shows picture and lies within the filter's reach of the next
  * frame's first samples. Consecutive frames -- within a batch or from one call to the next -- are
  * handled exactly: the engine keeps the source row. A strided call, or one that does not continue where
- * the last one ended, does not have the frame before: it uses the frame's own picture, which is exact for
- * a picture that does not change.) */
+ * the last one ended, does not have the frame before: on those modes it is refused with HVK_UNSUPPORTED --
+ * hvk_stage_strided_prev() takes the slot that holds the frame before, the frame's own slot where the
+ * picture does not change.) */
 int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots);
 /* As hvk_stage_strided(), for sharded streams whose pictures change: prev_slots[i] names the frame slot that holds the
  * picture of the frame BEFORE staged frame i (with conf.interlace: the one its second field shows), -1 if the caller

@@ -123,9 +123,10 @@ def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
             raise AssertionError("%d samples differ, first at %d (line %d)" % (bad.size, bad[0], bad[0] // 1024))
 
 
-def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
+@pytest.mark.parametrize("walk", [False, True])
+def test_two_ranks_on_one_gpu_reassemble_the_reference_stream(walk):
     """bench.py's N > 1 path with the engine in it: two ranks (both on GPU 0, gloo through host memory) stage, render and
-    send block-cyclic blocks; before timing anything rank 0 hashes the stream reassembled from two rounds -- block seams
+    send block-cyclic blocks -- the serial sound chains handed from rank to rank, each running them over its own frames only; before timing anything rank 0 hashes the stream reassembled from two rounds -- block seams
     and round seams included -- against the reference CLI run in the same job, every rank hashes its timed block, and
     rank 0 the gathered round. The JSON line must carry the seam gate's verdict."""
     import socket
@@ -137,7 +138,7 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
     require_ref(os.path.join(REF, "hacktv_ref"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
-           "--dry-run-backend", "gloo", "--no-cpu-baseline"]
+           "--dry-run-backend", "gloo", "--no-cpu-baseline"] + (["--walk-rounds"] if walk else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
@@ -146,6 +147,11 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream():
     assert d["n_gpus"] == 2
     assert d["multi_gpu"]["seam_gate"] and "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
     assert "sha256 ==" in d["parity_gate"]
+    assert d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["walk_rounds"] == walk
+    if walk:
+        # every step staged and rendered the next round, the sound chains went from rank to rank, and the last round
+        # walked (round 3: frames 18 .. 20 on rank 0) still is the reference's
+        assert "sha256 == reference CLI" in d["multi_gpu"]["walk_gate"]
 
 
 def test_queued_read_back_into_page_locked_memory(golden):

@@ -968,3 +968,29 @@ def test_sharded_525_line_stream_with_changing_pictures_is_exact(golden, world, 
                 got[first * fs:(first + block) * fs] = e.fetch(0, block * fs)
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "%d samples differ, first in frame %d at sample %d" % (bad.size, bad[0] // fs, bad[0] % fs)
+
+
+def test_a_gap_on_525_lines_needs_the_frame_before(golden):
+    """The last line of a 525-line frame shows picture within the video filter's reach of the next frame: a strided or
+    jumping render whose caller does not name the slot of the frame before is refused -- exact or not at all --, with
+    the slot it renders (bit-exact: test_sharded_525_line_stream_...), and 625-line modes never need it."""
+    conf, sr = golden.conf("m_full")
+    with H.Engine(conf, sr, device=0, max_frames=4) as e:
+        e.frame_upload(0, golden.frame("m_full"))
+        while e.audio_needed(12) > 0:
+            e.audio_write(golden.audio)
+        with pytest.raises(H.HvkError) as ex:
+            e.stage(1, 2, 3)                                  # frames 1, 3, 5: none of them has its predecessor
+        assert ex.value.code == H.HVK_UNSUPPORTED
+        e.stage(0, 1, 2)                                      # from the stream's start: fine
+        e.stage(2, 1, 2)                                      # continues the last stage: the engine kept the row
+        with pytest.raises(H.HvkError) as ex:
+            e.stage(8, 1, 2)                                  # a jump
+        assert ex.value.code == H.HVK_UNSUPPORTED
+        e.stage(8, 1, 2, prev_slots=[0, 0])                   # ... with the slot named
+    conf, sr = golden.conf("i_full")
+    with H.Engine(conf, sr, device=0, max_frames=4) as e:
+        e.frame_upload(0, golden.frame("i_full"))
+        while e.audio_needed(8) > 0:
+            e.audio_write(golden.audio)
+        e.stage(1, 2, 3)
