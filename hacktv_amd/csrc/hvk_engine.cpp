@@ -63,6 +63,7 @@ struct hvk_engine {
 	int *h_secam_count;         /* pinned: failures of the last check */
 	int secam_lanes;            /* lanes of four waves per SIMD */
 	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
+	int secam_clean, secam_patience;    /* batches without a wrong start in a row; how many of them before a line less is tried */
 	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
 	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
 	int64_t secam_counts[4];
@@ -577,6 +578,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.tpad = (max_frames * a.ntasks + 63) & ~63;
 			a.K = HVK_SECAM_WARMUP;
 			e->secam_adapt = getenv("HVK_SECAM_WARMUP") == NULL;
+			e->secam_patience = 4;
 			if(getenv("HVK_SECAM_WARMUP")) a.K = atoi(getenv("HVK_SECAM_WARMUP"));
 			if(a.K < 0) a.K = 0;
 			a.raster_samples = (int64_t) RS;
@@ -1308,12 +1310,20 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		const int bad = *e->h_secam_count;
 		if(rounds == 0 && e->secam_adapt)
 		{
-			/* How many warm-up lines a start state needs depends on the pictures (flat colours: a line or two; noise: ten
-			 * and more) and costs a walk each. Exactness never rests on it -- the check does -- so the number follows
-			 * what the last batch showed: down by a third while nothing fails, up by two when more than one start
-			 * in a thousand was wrong. */
-			if(bad == 0) a.K = a.K * 2 / 3 > 2 ? a.K * 2 / 3 : 2;
-			else if((int64_t) bad * 1000 > a.nruns) a.K = a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP;
+			/* How many warm-up lines a start state needs depends on the pictures and costs a walk each. Exactness never
+			 * rests on it -- the check does -- so the number follows what the batches show, carefully: a wrong start costs
+			 * a redo round, which is dearer than the walk it saved. One line fewer after a run of clean batches (a run
+			 * twice as long after every attempt that failed), two more as soon as anything fails. */
+			if(bad == 0)
+			{
+				if(++e->secam_clean >= e->secam_patience && a.K > 2) { a.K--; e->secam_clean = 0; }
+			}
+			else
+			{
+				a.K = a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP;
+				e->secam_patience = e->secam_patience * 2 < 64 ? e->secam_patience * 2 : 64;
+				e->secam_clean = 0;
+			}
 		}
 		if(bad == 0) break;
 		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;

@@ -98,7 +98,7 @@ template<int LV>
 __global__ __launch_bounds__(256)
 void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
-	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 8 zeros */
+	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 24 zeros */
 	const int W = a.C.W;
 	const int slot = blockIdx.x, i = blockIdx.y;
 	const int t = i * a.ntasks + slot;
@@ -155,39 +155,77 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 
 		const lvl_t black = ((const lvl_t *) a.yuv)[0];
 		const int16_t rest = comp ? black.z : black.y;
+		/* all of the lane's pixels first (at clamped positions: no load under a lane test, which would be waited for
+		 * on the spot), then all of their level look-ups, then the cells */
+		uint32_t rgb[SPL], prgb[SPL];
+		lvl_t m[SPL], pm[SPL];
+#pragma unroll
+		for(int j = 0; j < SPL; j++)
+		{
+			int xi = x0 + j - p0;
+			xi = xi < 0 ? 0 : (xi < fbw ? xi : (fbw > 0 ? fbw - 1 : 0));
+			rgb[j] = (row >= 0 && fbw > 0) ? (a.pool[row + xi] & 0xFFFFFF) : 0;
+			prgb[j] = (have_prev && prow >= 0 && fbw > 0) ? (a.pool[prow + xi] & 0xFFFFFF) : 0;
+		}
+#pragma unroll
+		for(int j = 0; j < SPL; j++)
+		{
+			m[j] = lvl_of<LV>(a, rgb[j]);
+			pm[j] = lvl_of<LV>(a, prgb[j]);
+		}
+#pragma unroll
 		for(int j = 0; j < SPL; j++)
 		{
 			const int x = x0 + j;
 			int16_t cell = rest;
 			if(x >= p0 && x < p0 + fbw)
 			{
-				const uint32_t rgb = row >= 0 ? (a.pool[row + (x - p0)] & 0xFFFFFF) : 0;
-				const lvl_t m = lvl_of<LV>(a, rgb);
-				int held = 0;
-				if(have_prev)
-				{
-					const uint32_t prgb = prow >= 0 ? (a.pool[prow + (x - p0)] & 0xFFFFFF) : 0;
-					const lvl_t pm = lvl_of<LV>(a, prgb);
-					held = pcomp ? pm.z : pm.y;
-				}
-				cell = (int16_t) (((int) (comp ? m.z : m.y) + held) / 2);
+				const int held = have_prev ? (pcomp ? pm[j].z : pm[j].y) : 0;
+				cell = (int16_t) (((int) (comp ? m[j].z : m[j].y) + held) / 2);
 			}
 			c[j] = x < W ? cell : 0;
 		}
 	}
 
-	if(lane == 0) for(int j = 0; j < 8; j++) { lds[j] = 0; lds[8 + W + j] = 0; }
-	for(int j = 0; j < SPL; j++) if(x0 + j < W) lds[8 + x0 + j] = c[j];
+	/* the cells in LDS behind 8 zeros (and in front of 24: the last lane's window), element 8 + x = cell x */
+	if(lane == 0)
+	{
+		*(int4 *) lds = make_int4(0, 0, 0, 0);
+		for(int j = 0; j < 24; j += 8) *(int4 *) (lds + 8 + W + j) = make_int4(0, 0, 0, 0);
+	}
+	if(x0 + SPL <= W)
+	{
+		int4 pk;
+		pk.x = (uint16_t) c[0] | ((uint32_t) (uint16_t) c[1] << 16);
+		pk.y = (uint16_t) c[2] | ((uint32_t) (uint16_t) c[3] << 16);
+		pk.z = (uint16_t) c[4] | ((uint32_t) (uint16_t) c[5] << 16);
+		pk.w = (uint16_t) c[6] | ((uint32_t) (uint16_t) c[7] << 16);
+		*(int4 *) (lds + 8 + x0) = pk;
+	}
+	else for(int j = 0; j < SPL; j++) if(x0 + j < W) lds[8 + x0 + j] = c[j];
 	__syncthreads();
 
 	if(x0 >= W) return;
 
+	/* 15-tap low pass, zero history (src/video.c:3207): output x reads cells x - 7 .. x + 7 = elements x + 1 .. x + 15 --
+	 * the lane's window starts one element behind its 16-byte aligned slice; packed pairs and v_dot2c_i32_i16 */
 	int32_t acc[SPL];
-	for(int j = 0; j < SPL; j++)
 	{
-		int32_t s = 0;
-		for(int k = 0; k < 15; k++) s += (int32_t) lds[8 + x0 + j - 7 + k] * a.C.fir[k];
-		acc[j] = s;
+		constexpr int ND = SPL / 2 + (15 + 1) / 2 + 1;
+		int d[ND], tp[8];
+		const int4v *pw = (const int4v *) (lds + x0);
+#pragma unroll
+		for(int q = 0; q < (ND + 3) / 4; q++)
+		{
+			const int4v w = pw[q];
+			if(q * 4 + 0 < ND) d[q * 4 + 0] = w.x;
+			if(q * 4 + 1 < ND) d[q * 4 + 1] = w.y;
+			if(q * 4 + 2 < ND) d[q * 4 + 2] = w.z;
+			if(q * 4 + 3 < ND) d[q * 4 + 3] = w.w;
+		}
+#pragma unroll
+		for(int q = 0; q < 8; q++) tp[q] = ((int) a.C.fir[2 * q] & 0xFFFF) | ((q < 7 ? (int) a.C.fir[2 * q + 1] : 0) << 16);
+		fir8<15, 1>(d, tp, acc);
 	}
 
 	/* 8 outputs of one task in 16 bytes, tasks side by side */
@@ -242,6 +280,15 @@ __device__ __forceinline__ int4 pack8(const int16_t *o)
 	return(po);
 }
 
+/* hvk_secam_round_away() without its branches (a lane test per sample would cost an exec-mask round trip each):
+ * truncate, then look at the exactly representable rest; halves go away from zero */
+__device__ __forceinline__ int32_t round_away_nb(const double x)
+{
+	const int32_t i = (int32_t) x;
+	const double f = x - (double) i;
+	return(i + (int32_t) (f >= 0.5) - (int32_t) (f <= -0.5));
+}
+
 /* EMIT = false: a warm-up line -- only the state it leaves matters, so the output half of an FM step (level, bell-filter
  * gain and its table read, burst window) is left out */
 template<bool EMIT>
@@ -249,6 +296,7 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 {
 	const int W = a.C.W, sl = a.C.sl;
 	const int16_t dmin = a.C.dmin[v.dr], dmax = a.C.dmax[v.dr];
+	const int32_t dmin32 = dmin, dmax32 = dmax;
 	const int32_t level = a.C.level;
 	const int fm_end = v.sr < W ? v.sr : W;
 	double ix = S.ix, iy = S.iy;
@@ -259,7 +307,7 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 	int4 nx0 = F[0], nx1 = F[(size_t) a.tpad];
 	for(int ch = 0; ch < chunks; ch++)
 	{
-		int16_t f[CH], y[CH], o[CH];
+		int16_t f[CH], o[CH];
 		unpack8(nx0, f);
 		unpack8(nx1, f + 8);
 		if(ch + 1 < chunks)
@@ -285,6 +333,11 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			}
 		}
 
+		/* (u[j]: the table index of sample j -- the IIR's output rounded, limited to int16 (src/fir.c:729-733:
+		 * clamp-then-round == round-then-clamp, the bounds are whole numbers and rounding is monotone; |iy| stays far
+		 * below 2^31) and then to the line's deviation range (src/video.c:3215-3216), which lies inside int16: ONE
+		 * v_med3_i32 does both) */
+		unsigned u[CH];
 #pragma unroll
 		for(int j = 0; j < CH; j++)
 		{
@@ -294,12 +347,9 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			const double t2 = iy * -0.90456054;
 			iy = (t0 + t1) - t2;
 			ix = in;
-			{
-				/* clamp-then-round (src/fir.c:729-733) == round-then-clamp: the bounds are whole numbers and rounding is
-				 * monotone; |iy| stays far below 2^31 (int16 in, a gain of a few tens), and the clamp is one v_med3_i32 */
-				const int32_t r = hvk_secam_round_away(iy);
-				y[j] = (int16_t) (r < INT16_MIN ? INT16_MIN : (r > INT16_MAX ? INT16_MAX : r));
-			}
+			const int32_t r = round_away_nb(iy);
+			const int32_t c = r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+			u[j] = (unsigned) (c + 32768);
 		}
 
 		const int x0 = ch * CH;
@@ -312,9 +362,9 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 #pragma unroll
 			for(int j = 0; j < CH; j++)
 			{
-				const int16_t c = y[j] < dmin ? dmin : (y[j] > dmax ? dmax : y[j]);
-				if(EMIT) g[j] = a.bell[(uint16_t) c];
-				st[j] = a.lut[(int32_t) c + 32768];
+				/* (unsigned indices: the loads take the tables' addresses from scalar registers) */
+				if(EMIT) g[j] = a.bell[(u[j] - 32768u) & 0xFFFFu];
+				st[j] = a.lut[u[j]];
 			}
 #pragma unroll
 			for(int j = 0; j < CH; j++)
@@ -339,9 +389,9 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 #pragma unroll
 			for(int j = 0; j < CH; j++)
 			{
-				const int16_t c = y[j] < dmin ? dmin : (y[j] > dmax ? dmax : y[j]);
-				if(EMIT) g[j] = a.bell[(uint16_t) c];
-				st[j] = a.lut[(int32_t) c + 32768];
+				/* (unsigned indices: the loads take the tables' addresses from scalar registers) */
+				if(EMIT) g[j] = a.bell[(u[j] - 32768u) & 0xFFFFu];
+				st[j] = a.lut[u[j]];
 			}
 #pragma unroll
 			for(int j = 0; j < CH; j++)
@@ -475,8 +525,8 @@ extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream
 	const int lanes = (a->C.W + SPL - 1) / SPL;
 	const int threads = (lanes + 63) & ~63;
 	if(threads > 256 || (a->C.W % 16) != 0) return(HVK_UNSUPPORTED);
-	if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
-	else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 16) * 2, stream, *a);
+	if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+	else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
 	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
