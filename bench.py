@@ -570,7 +570,7 @@ def main():
         if not args.noaudio:
             # ... and the LAST round walked is the reference's too: this rank's block of it, every sample
             lastb = sharding.block_of(rank, N, walk["last_round"])
-            got = hashlib.sha256(mines[(args.warmup + args.steps - 1) % nbuf].cpu().numpy().tobytes()).hexdigest()
+            got = hashlib.sha256(mines[(args.steps - 1) % nbuf].cpu().numpy().tobytes()).hexdigest()   # (the timed loop counts its steps from 0)
             want = ref_sha(lastb * F, F)
             if want is not None and got != want:
                 raise SystemExit("parity gate failed on rank %d: block %d (round %d of the walk) differs from the reference CLI's output" % (rank, lastb, walk["last_round"]))
