@@ -351,10 +351,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group(args.dry_run_backend)
-            hostg = None                    # the default group is a host-side one already
         else:
             dist.init_process_group("nccl", device_id=dev)
-            hostg = dist.new_group(backend="gloo")      # the sound chains' state travels between the ranks' hosts
+        # the sound chains' state travels between the ranks' hosts, in a group of its own: its messages must not queue up
+        # between the blocks of the gather (a rank hands the chains on BEFORE it renders and sends its block)
+        hostg = dist.new_group(backend="gloo")
 
     if N == 1:
         hostg = None
@@ -733,16 +734,17 @@ def main():
         eh.close()
         del os.environ["HVK_SECAM_HOST"]
         secam = {
-            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % F,
-            "Msamples_per_s": round(F * FS / t_dev / 1e6, 1),
-            "ms_per_step": round(t_dev * 1e3, 3),
-            "blocks_of_%d_frames" % (4 * F): {"Msamples_per_s": round(4 * F * FS / t_big / 1e6, 1), "ms_per_step": round(t_big * 1e3, 3), "lines": st_big,
-                                               "note": "the chain is one lane per line and bound by the latency of its dependent steps: four times the lines keep four waves per SIMD busy"},
+            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % (4 * F),
+            "Msamples_per_s": round(4 * F * FS / t_big / 1e6, 1),
+            "ms_per_step": round(t_big * 1e3, 3),
+            "lines": st_big,
+            "blocks_of_%d_frames" % F: {"Msamples_per_s": round(F * FS / t_dev / 1e6, 1), "ms_per_step": round(t_dev * 1e3, 3), "lines": st,
+                                         "note": "the block size of the PAL-I headline: a quarter of the lines, and the chain -- one lane per line, bound by the latency "
+                                                 "of its dependent steps -- takes nearly as long: about one wave per SIMD instead of four"},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
-            "lines": st,
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
             "note": "lines: worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; the number of "
-                    "warm-up lines per start state follows the pictures (test card: 2; exactness rests on the check, not on it)",
+                    "warm-up lines per start state follows the pictures (exactness rests on the check, not on it)",
         }
 
     configs = None
