@@ -73,6 +73,7 @@ class HvkConfig(C.Structure):
         ("vitc", C.c_int),
         ("acp", C.c_int),
         ("cc608", C.c_int),
+        ("sis", C.c_int),
         ("fm_level", C.c_double),
         ("fm_deviation", C.c_double),
         ("swap_iq", C.c_int),

@@ -150,6 +150,12 @@ typedef struct hvk_config_t {
 	int acp;                    /* --acp: P-sync / AGC pulse pairs on lines 9-18, 321-330 (625) or 12-19, 275-282 (525) */
 	int cc608;                  /* --cc608: CEA/EIA-608 caption line 22 (625) / 21 (525); the byte pairs are supplied
 	                             * per frame with hvk_cc608_write(), zeros otherwise */
+	int sis;                    /* --sis dcsis: sound-in-syncs -- a NICAM-728 stream of its own as 4-level symbols inside every
+	                             * line's sync pulse (src/sis.c). 0 none, 1 "dcsis". The reference hands the 32-sample audio
+	                             * blocks from its audio thread to this process without a lock (src/sis.c:217-221,
+	                             * src/video.c:3370-3373); the engine's reading: a NICAM frame carries the newest block handed
+	                             * over in an EARLIER step of the line pipeline -- what the reference CLI does on its test
+	                             * source */
 
 	/* FM video (modulation == HVK_FM), src/video.h:141-142 */
 	double fm_level;

@@ -276,6 +276,29 @@ static void _nicam_encode_frame(orc_nicam_t *n)
 	n->frame_no++;
 }
 
+/* the encoder without a modulator: what sound-in-syncs has (src/sis.c:141, src/nicam728.c:96-126) */
+void orc_nicam_encoder_init(orc_nicam_t *n, uint8_t mode, uint8_t reserve)
+{
+	int x, poly = 0x1FF;
+	memset(n, 0, sizeof(*n));
+	n->mode = mode;
+	n->reserve = reserve;
+	for(x = 0; x < 90; x++)
+	{
+		int i;
+		n->prn[x] = 0;
+		for(i = 0; i < 8; i++)
+		{
+			uint8_t b = (poly & 1) ^ ((poly >> 4) & 1);
+			poly >>= 1;
+			poly |= b << 8;
+			n->prn[x] = (n->prn[x] << 1) | b;
+		}
+	}
+}
+
+void orc_nicam_encode(orc_nicam_t *n) { _nicam_encode_frame(n); }
+
 static double _rrc(double x, double b, double t)
 {
 	/* src/common.c:259-283 */

@@ -159,6 +159,19 @@ struct orc_t {
 	int pass_eof;
 	int16_t *passline;
 
+	/* sound-in-syncs (oracle_sis.c) */
+	orc_pulse_t *sis_lut;       /* 50 half symbols */
+	int16_t *sis_packed;        /* ... as the reference packs them */
+	long sis_pos[50];           /* where an entry's values start in it */
+	int16_t sis_heap[8];        /* the 16 bytes in front of the reference's table on its heap */
+	int sis_blank_left, sis_blank_width;
+	int16_t *sis_blank_win;
+	orc_nicam_t sis_nicam;
+	uint8_t sis_frame[91];
+	int sis_frame_bit, sis_re;
+	long sis_calls;
+	int sis_visible;            /* samples of the step's audio line the audio thread is taken to have behind it (0: none) */
+
 	/* SECAM colour process (oracle_secam.c) */
 	int16_t sc_level;
 	c32_t *sc_lut;
@@ -231,7 +244,15 @@ int orc_tail_init(orc_t *s);
 void orc_tail_free(orc_t *s);
 void orc_tail_line(orc_t *s, int16_t *iq, int width);
 
+/* oracle_sis.c */
+int orc_sis_init(orc_t *s);
+void orc_sis_free(orc_t *s);
+void orc_sis_line(orc_t *s, long g, int first_line);
+
 /* oracle_audio.c */
+/* a NICAM-728 frame encoder on its own (src/nicam728.c:96-126, :195-249): n->audio in, n->frame out */
+void orc_nicam_encoder_init(orc_nicam_t *n, uint8_t mode, uint8_t reserve);
+void orc_nicam_encode(orc_nicam_t *n);
 int orc_audio_init(orc_t *s);
 void orc_audio_free(orc_t *s);
 void orc_audio_line(orc_t *s, int16_t *iq, int width, int16_t *carrier_tap);

@@ -50,7 +50,7 @@ orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsign
 	if(conf->s_video && (conf->output_type != HVK_INT16_REAL || conf->colour_mode == HVK_MONOCHROME ||
 	                     (pixel_rate && pixel_rate != sample_rate))) { free(s); return(NULL); }
 
-	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0 || orc_vbi_init(s) != 0)
+	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0 || orc_vbi_init(s) != 0 || orc_sis_init(s) != 0)
 	{
 		orc_close(s);
 		return(NULL);
@@ -73,6 +73,7 @@ void orc_close(orc_t *s)
 	orc_audio_free(s);
 	orc_tail_free(s);
 	orc_vbi_free(s);
+	orc_sis_free(s);
 	orc_teletext_free(s);
 	free(s->S);
 	free(s->C);
@@ -328,6 +329,19 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 				lut = &s->colour_lookup[(unsigned long) (((unsigned long long) g * s->width) % s->colour_lookup_width)];
 			}
 			orc_vbi_line(s, g, (int) (g / s->conf.lines) + 1, (int) (g % s->conf.lines) + 1, lut);
+		}
+
+		/* sound-in-syncs: behind CC608, in front of teletext (src/video.c:4330-4338); its first invocation works on the
+		 * never-emitted slot in front of line 1 */
+		if(s->conf.sis)
+		{
+			if(s->rastered == 1)
+			{
+				const int dummies = s->conf.colour_mode == HVK_SECAM ? 3 : 1;
+				int d;
+				for(d = 1; d <= dummies; d++) orc_sis_line(s, -1, d == dummies);
+			}
+			else orc_sis_line(s, s->rastered - 2, 0);
 		}
 
 		/* teletext comes after the colour process and before the filter

@@ -54,6 +54,10 @@ void orc_set_rawbb(orc_t *s, const int16_t *samples, long nsamples);
 /* --cc608: the caption byte pair of a frame (0-based stream frame index); frames without a call send zeros */
 void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2);
 
+/* --sis: how many samples of a step's audio line the reference's audio thread is taken to have behind it when its SiS
+ * process looks for the newest audio block (oracle_sis.c; 0: none -- the default) */
+void orc_set_sis_visible(orc_t *s, int samples);
+
 /* --passthru: the external int16 I/Q signal (kept by reference), from its first sample */
 void orc_set_passthru(orc_t *s, const int16_t *iq, long nsamples);
 

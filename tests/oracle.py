@@ -36,6 +36,8 @@ def lib():
         L.orc_set_rawbb.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_cc608.restype = None
         L.orc_set_cc608.argtypes = [C.c_void_p, C.c_long, C.c_uint8, C.c_uint8]
+        L.orc_set_sis_visible.restype = None
+        L.orc_set_sis_visible.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_passthru.restype = None
         L.orc_set_passthru.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_render_lines.restype = C.c_long
@@ -130,6 +132,11 @@ class Oracle:
 
     def set_cc608(self, frame_index, c1, c2):
         lib().orc_set_cc608(self.p, frame_index, c1, c2)
+
+    def set_sis_visible(self, samples):
+        """--sis: samples of a step's audio line the reference's audio thread is taken to have behind it when the SiS
+        process picks its block (oracle_sis.c); 0: none."""
+        lib().orc_set_sis_visible(self.p, samples)
 
     def set_passthru(self, iq):
         a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)

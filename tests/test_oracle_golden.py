@@ -20,10 +20,12 @@ CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_f
 # the other 625 / 525-line presets; FM video with its pre-emphasis filter
 CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster", "ntsci_full",
                  "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m"]
+# sound-in-syncs: a NICAM stream of its own inside every sync pulse (oracle/make_golden_sis.py: ten runs of the reference, one output)
+CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass", "palfm_f14_tail"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)

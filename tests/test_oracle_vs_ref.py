@@ -139,3 +139,37 @@ def test_shim_counts_the_lines_in_flight_like_the_reference(mode, sr, flags, pr)
     with refprobe.RefProbe(mode, sr, flags, pixel_rate=pr) as r:
         reference, shim = r.pipeline_depths()
     assert shim == reference and 3 <= reference <= 8
+
+
+def test_sound_in_syncs_block_hand_over_as_the_reference_does_it(golden):
+    """--sis: the reference's audio thread hands 32-sample blocks to the SiS process on the main thread without a lock
+    (src/sis.c:217-221, src/video.c:3370-3373). Frame encodes and hand-overs both happen exactly 1000 times a second, so
+    they meet in the same step of the line pipeline for ever; which block a frame gets depends on how far the audio
+    thread is -- one number, `visible`, in the oracle. The reference CLI run here equals the oracle for every value up
+    to the first hand-over's place in its line (sample 639 at 16 Msps: the main thread is there before the audio thread)
+    and differs for larger ones; the product's reading is 0 (hand-overs of earlier steps only). The test tone's blocks
+    are all alike but for the first (silence before it), which is why the reference's output is the same on every run."""
+    import hashlib
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hacktv_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hacktv_ref not built")
+    nfr = 3
+    p = subprocess.Popen([exe, "-m", "i", "-s", "16000000", "--sis", "dcsis", "-o", "-", "test"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    data = bytearray()
+    while len(data) < nfr * 2560000:
+        data += p.stdout.read(nfr * 2560000 - len(data))
+    p.kill()
+    p.wait()
+    ref = hashlib.sha256(bytes(data)).hexdigest()
+    conf, sr = golden.conf("i_sis")
+    got = {}
+    for visible in (0, 300, 639, 640, 1024):
+        with oracle.Oracle(conf, sr) as o:
+            o.set_frame(golden.frame("i_sis"))
+            o.set_audio(golden.audio, True)
+            o.set_sis_visible(visible)
+            got[visible] = hashlib.sha256(o.render_lines(625 * nfr).tobytes()).hexdigest()
+    assert got[0] == got[300] == got[639] == ref
+    assert got[640] == got[1024] != ref
