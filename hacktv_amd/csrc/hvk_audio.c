@@ -191,6 +191,7 @@ typedef struct {
 	int64_t k;              /* index of the next symbol to be created */
 	int64_t next_start;     /* its first sample */
 	int sps, dsl, decimation, ds;
+	int reserve;            /* control bit C4: 1 on the NICAM carrier (src/video.c:4524), 0 in sound-in-syncs (src/video.c:4332) */
 } _nicam_t;
 
 /* J.17 pre-emphasis taps at 32 kHz (src/nicam728.c:37-44), first half */
@@ -205,6 +206,7 @@ static void _nicam_reset(_nicam_t *n, const hvk_tables_t *t)
 	int x, i, lfsr = 0x1FF;
 
 	memset(n, 0, sizeof(*n));
+	n->reserve = 1;
 
 	/* 9-bit LFSR x^9 + x^4 + 1, all ones start (src/nicam728.c:96-126) */
 	for(x = 0; x < 90; x++)
@@ -317,7 +319,7 @@ static void _nicam_build_frame(_nicam_t *n)
 	 * mode = stereo, reserve flag = 1: src/video.c:4524), AD bits zero */
 	memset(n->bits, 0, sizeof(n->bits));
 	n->bits[0] = 0x4E;
-	n->bits[1] = ((((~n->frame_no) >> 3) & 1) << 7) | (1 << 3);
+	n->bits[1] = ((((~n->frame_no) >> 3) & 1) << 7) | ((n->reserve & 1) << 3);
 
 	/* 704 sound bits, 11 per sample LSB first, interleaved 16 apart (:221-240) */
 	for(x = 0, at = 0; x < 64; x++)
@@ -334,6 +336,31 @@ static void _nicam_build_frame(_nicam_t *n)
 
 	n->frame_no++;
 }
+
+/* ---- sound-in-syncs (src/sis.c:155-221) ----
+ *
+ * Every line carries 23 or 25 four-level symbols of a NICAM-728 stream of its own inside its sync pulse. The framing
+ * runs here, in step with the sound chains: one invocation per line of the line pipeline, the never-emitted slots in
+ * front of line 1 included (they move the rate counter and the bit position on). A frame is encoded when the bit
+ * position runs out, from the newest 32-sample block the audio process has handed over -- in the reference an unlocked
+ * hand-over between two threads (src/video.c:3370-3373): the engine's reading is "the newest block completed in an
+ * EARLIER step of the pipeline", i.e. before the audio line that runs beside this invocation. */
+#define KEPT_LINES 4
+typedef struct {
+	int on;
+	int dummies;            /* invocations in front of line 1: 1, or 3 behind a threaded colour process (hvk_tables.c) */
+	int re, frame_bit;
+	int64_t calls;          /* invocations so far */
+	_nicam_t enc;           /* the encoder: J.17 history, frame counter, scrambler; enc.bits is the frame being sent */
+	int16_t fill[64];       /* the block being filled by the 32 kHz ticks */
+	int fill_len;
+	int16_t newest[64];     /* the last block handed over */
+	int have_block;
+	/* the lines' bursts made so far: rec[(g - rec_g0) * 8] = the 7 burst bytes (MSB first) and the number of bits */
+	uint8_t *rec;
+	int64_t rec_g0;
+	size_t rec_len, rec_cap;
+} _sis_t;
 
 /* ---- the path ---- */
 
@@ -352,8 +379,6 @@ struct hvk_audio {
 	int interp;             /* 32 kHz tick accumulator (src/video.c:3273-3276) */
 	int64_t pos;            /* stream samples generated so far (always a line boundary) */
 	int64_t line_no;        /* lines generated so far */
-	int64_t last_pos;       /* first sample of the line held in `scratch` */
-	int last_w;             /* its width; 0: none yet */
 
 	_phasor_t fm, am;
 	_limiter_t lim;
@@ -369,8 +394,18 @@ struct hvk_audio {
 	int64_t sym_k0;
 	size_t sym_len, sym_cap;
 
-	int16_t *scratch;       /* the carriers of the last line generated */
+	/* the carriers of the last lines generated, newest in slot `kept_at`: a request may start inside them, and with
+	 * sound-in-syncs behind a threaded colour process (SECAM) the chains run two lines ahead of the requests */
+	int16_t *kept[KEPT_LINES];
+	int64_t kept_pos[KEPT_LINES];
+	int kept_w[KEPT_LINES];
+	int kept_at;
+	int ahead;              /* lines */
+
+	_sis_t sis;
 };
+
+static void _sis_invocation(hvk_audio_t *a);
 
 hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 {
@@ -433,8 +468,21 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		_nicam_reset(&a->nicam, t);
 	}
 
-	a->scratch = malloc(sizeof(int16_t) * 2 * t->max_width);
-	if(!a->scratch) { free(a); return(NULL); }
+	for(int i = 0; i < KEPT_LINES; i++)
+	{
+		a->kept[i] = malloc(sizeof(int16_t) * 2 * t->max_width);
+		if(!a->kept[i]) { hvk_audio_free(a); return(NULL); }
+	}
+
+	if(t->k.sis)
+	{
+		a->sis.on = 1;
+		a->sis.dummies = t->k.sis_dummies;
+		_nicam_reset(&a->sis.enc, t);
+		a->sis.enc.reserve = 0;
+		a->ahead = a->sis.dummies - 1;      /* invocation t needs the audio lines before t - 1 complete; line g is invocation g + 1 + dummies */
+		_sis_invocation(a);                 /* the first one runs before any audio line has */
+	}
 
 	return(a);
 }
@@ -444,7 +492,8 @@ void hvk_audio_free(hvk_audio_t *a)
 	if(!a) return;
 	free(a->src);
 	free(a->sym);
-	free(a->scratch);
+	for(int i = 0; i < KEPT_LINES; i++) free(a->kept[i]);
+	free(a->sis.rec);
 	free(a);
 }
 
@@ -483,7 +532,7 @@ int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples)
  * position upto_pos: ticks fire when the accumulator crosses sample_rate */
 size_t hvk_audio_source_needed(const hvk_audio_t *a, int64_t upto_pos)
 {
-	int64_t n = upto_pos - a->pos;
+	int64_t n = upto_pos + (int64_t) a->ahead * a->width - a->pos;
 	int64_t ticks, have;
 	if(n <= 0) return(0);
 	ticks = ((int64_t) a->interp + n * AUDIO_RATE) / a->sample_rate;
@@ -536,7 +585,74 @@ static void _tick(hvk_audio_t *a)
 			n->fill_len = 0;
 		}
 	}
+
+	if(a->sis.on)
+	{
+		/* the same blocks go to the sound-in-syncs encoder (src/video.c:3353-3373) */
+		_sis_t *q = &a->sis;
+		q->fill[q->fill_len++] = s[0];
+		q->fill[q->fill_len++] = s[1];
+		if(q->fill_len == 64)
+		{
+			memcpy(q->newest, q->fill, sizeof(q->newest));
+			q->have_block = 1;
+			q->fill_len = 0;
+		}
+	}
 }
+
+/* One invocation of the sound-in-syncs process (src/sis.c:155-201): the burst's bits. Called once when the engine is
+ * made and then after every audio line: invocation t sees the blocks handed over in audio lines 0 .. t - 2. */
+static void _sis_invocation(hvk_audio_t *a)
+{
+	static const uint8_t gc[2][4] = { { 3, 0, 2, 1 }, { 0, 3, 1, 2 } };
+	_sis_t *q = &a->sis;
+	uint8_t vbi[8];
+	int x, nb = 50;
+	int64_t g;
+
+	q->calls++;
+	/* rate: 48 bits on most lines, 44 on 44 of every 125 (728 bits a millisecond) */
+	if((q->re += 44) >= 125)
+	{
+		nb -= 4;
+		q->re -= 125;
+	}
+
+	memset(vbi, 0, sizeof(vbi));
+	vbi[0] = 0xC0;
+	for(x = 2; x < nb; x += 2, q->frame_bit += 2)
+	{
+		uint8_t sym;
+		if(q->frame_bit >= NICAM_FRAME_BITS)
+		{
+			if(q->have_block) memcpy(q->enc.block, q->newest, sizeof(q->enc.block));
+			else memset(q->enc.block, 0, sizeof(q->enc.block));
+			_nicam_build_frame(&q->enc);
+			q->frame_bit = 0;
+		}
+		/* (before the first frame the store is all zeros, src/sis.c:88) */
+		sym = (q->enc.bits[q->frame_bit >> 3] >> (6 - (q->frame_bit & 7))) & 3;
+		sym = gc[(x & 4) ? 1 : 0][sym];
+		vbi[x >> 3] |= sym << (6 - (x & 7));
+	}
+	vbi[7] = (uint8_t) nb;
+
+	g = q->calls - 1 - q->dummies;
+	if(g < 0) return;
+	if(q->rec_len == 0) q->rec_g0 = g;
+	if(q->rec_len + 8 > q->rec_cap)
+	{
+		size_t cap = q->rec_cap ? q->rec_cap * 2 : 65536;
+		uint8_t *p = realloc(q->rec, cap);
+		if(!p) { a->oom = 1; return; }
+		q->rec = p;
+		q->rec_cap = cap;
+	}
+	memcpy(q->rec + q->rec_len, vbi, 8);
+	q->rec_len += 8;
+}
+
 
 static void _sym_append(hvk_audio_t *a, uint8_t v)
 {
@@ -859,6 +975,7 @@ static void _line(hvk_audio_t *a, int16_t *carriers, const int W)
 	a->pos += W;
 	a->generated += W;
 	a->line_no++;
+	if(a->sis.on) _sis_invocation(a);
 }
 
 /* Index of the symbol whose pulse starts at or before sample m (>= 0) */
@@ -880,25 +997,38 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 	int64_t end = first + count;
 	int nsym = 0;
 
-	/* the chains cannot be rewound: a request may start inside the line generated last, not before it */
-	if(first < (a->last_w ? a->last_pos : a->pos)) return(HVK_ERROR);
+	/* the chains cannot be rewound: a request may start inside the lines kept, not before them */
+	{
+		int64_t oldest = a->pos;
+		for(int i = 0; i < KEPT_LINES; i++) if(a->kept_w[i] && a->kept_pos[i] < oldest) oldest = a->kept_pos[i];
+		if(first < oldest) return(HVK_ERROR);
+	}
 	if(a->oom) return(HVK_OUT_OF_MEMORY);
 
-	for(;;)
+	/* the part of the request the kept lines cover */
+	if(carriers)
 	{
-		/* the part of the line in `scratch` that the request covers */
-		if(a->last_w && carriers)
+		for(int i = 0; i < KEPT_LINES; i++)
 		{
-			const int64_t lo = first > a->last_pos ? first : a->last_pos;
-			const int64_t hi = end < a->last_pos + a->last_w ? end : a->last_pos + a->last_w;
-			if(hi > lo) memcpy(carriers + (lo - first) * 2, a->scratch + (lo - a->last_pos) * 2, (hi - lo) * 2 * sizeof(int16_t));
+			const int64_t lo = first > a->kept_pos[i] ? first : a->kept_pos[i];
+			const int64_t hi = end < a->kept_pos[i] + a->kept_w[i] ? end : a->kept_pos[i] + a->kept_w[i];
+			if(a->kept_w[i] && hi > lo) memcpy(carriers + (lo - first) * 2, a->kept[i] + (lo - a->kept_pos[i]) * 2, (hi - lo) * 2 * sizeof(int16_t));
 		}
+	}
 
-		if(a->pos >= end) break;
-
-		a->last_pos = a->pos;
-		a->last_w = _line_width(a, a->line_no);
-		_line(a, a->scratch, a->last_w);
+	/* ... and new lines up to its end (and `ahead` lines past it) */
+	while(a->pos < end + (int64_t) a->ahead * a->width)
+	{
+		const int i = a->kept_at = (a->kept_at + 1) % KEPT_LINES;
+		a->kept_pos[i] = a->pos;
+		a->kept_w[i] = _line_width(a, a->line_no);
+		_line(a, a->kept[i], a->kept_w[i]);
+		if(carriers)
+		{
+			const int64_t lo = first > a->kept_pos[i] ? first : a->kept_pos[i];
+			const int64_t hi = end < a->kept_pos[i] + a->kept_w[i] ? end : a->kept_pos[i] + a->kept_w[i];
+			if(hi > lo) memcpy(carriers + (lo - first) * 2, a->kept[i] + (lo - a->kept_pos[i]) * 2, (hi - lo) * 2 * sizeof(int16_t));
+		}
 	}
 
 	if(a->nicam_on && symbols)
@@ -931,6 +1061,38 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 	return(nsym);
 }
 
+/* Run the chains on to stream position `end` (and the lines they keep ahead of it) without handing anything out */
+int hvk_audio_advance(hvk_audio_t *a, int64_t end)
+{
+	while(a->pos < end + (int64_t) a->ahead * a->width)
+	{
+		const int i = a->kept_at = (a->kept_at + 1) % KEPT_LINES;
+		a->kept_pos[i] = a->pos;
+		a->kept_w[i] = _line_width(a, a->line_no);
+		_line(a, a->kept[i], a->kept_w[i]);
+	}
+	return(a->oom ? HVK_OUT_OF_MEMORY : HVK_OK);
+}
+
+/* The sound-in-syncs bursts of lines [g_first, g_first + count) of the stream (8 bytes a line: 7 bytes of bits, MSB first,
+ * then their number); the sound chains have to have been run over the lines' frames. Earlier lines are dropped. */
+int hvk_audio_sis_fetch(hvk_audio_t *a, int64_t g_first, int count, uint8_t *out)
+{
+	_sis_t *q = &a->sis;
+	if(!q->on || count < 0) return(HVK_ERROR);
+	if(a->oom) return(HVK_OUT_OF_MEMORY);
+	if(g_first < q->rec_g0 || (size_t) (g_first - q->rec_g0 + count) * 8 > q->rec_len) return(HVK_ERROR);
+	memcpy(out, q->rec + (size_t) (g_first - q->rec_g0) * 8, (size_t) count * 8);
+	if(g_first > q->rec_g0)
+	{
+		const size_t drop = (size_t) (g_first - q->rec_g0) * 8;
+		memmove(q->rec, q->rec + drop, q->rec_len - drop);
+		q->rec_len -= drop;
+		q->rec_g0 = g_first;
+	}
+	return(HVK_OK);
+}
+
 /* ---- the chains' state, to be carried to another engine ----
  *
  * The sound chains are one recurrence over the whole stream: an engine that renders frames f .. can only
@@ -951,6 +1113,7 @@ typedef struct {
 	_phasor_t fm, am, a2, a2_pilot, a2_signal;
 	_limiter_t lim, a2_lim;
 	_nicam_t nicam;
+	_sis_t sis;                 /* (its record store stays behind: the importer makes its own lines' bursts) */
 	int64_t sym_first;          /* symbol index of sym[0] */
 	int32_t nsym;
 	uint8_t sym[STATE_SYMS];
@@ -966,6 +1129,7 @@ int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes)
 	size_t n;
 
 	if(!a || !buf || bytes < sizeof(*st)) return(HVK_ERROR);
+	if(a->ahead) return(HVK_UNSUPPORTED);    /* the chains stand past the last request (SECAM with sound-in-syncs: one engine renders such a stream anyway) */
 	memset(st, 0, sizeof(*st));
 	st->magic = STATE_MAGIC;
 	st->bytes = (uint32_t) sizeof(*st);
@@ -981,6 +1145,8 @@ int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes)
 	st->lim = a->lim;
 	st->a2_lim = a->a2_lim;
 	st->nicam = a->nicam;
+	st->sis = a->sis;
+	st->sis.rec = NULL; st->sis.rec_len = st->sis.rec_cap = 0;
 	n = a->sym_len < STATE_SYMS ? a->sym_len : STATE_SYMS;
 	st->nsym = (int32_t) n;
 	st->sym_first = a->sym_k0 + (int64_t) (a->sym_len - n);
@@ -996,13 +1162,14 @@ int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_
 
 	if(!a || !buf || bytes < sizeof(*st) || st->magic != STATE_MAGIC || st->bytes != sizeof(*st)) return(HVK_ERROR);
 	if(st->width != a->width || st->sample_rate != a->sample_rate || st->has_lim != a->has_lim || st->nicam_on != a->nicam_on) return(HVK_ERROR);
-	if(st->fm.on != a->fm.on || st->am.on != a->am.on || st->a2.on != a->a2.on) return(HVK_ERROR);   /* another configuration's state */
+	if(st->fm.on != a->fm.on || st->am.on != a->am.on || st->a2.on != a->a2.on || st->sis.on != a->sis.on) return(HVK_ERROR);   /* another configuration's state */
+	if(a->ahead) return(HVK_UNSUPPORTED);
 	if(st->nsym < 0 || st->nsym > STATE_SYMS) return(HVK_ERROR);
 
 	a->interp = st->interp;
 	a->pos = st->pos;
 	a->line_no = st->line_no;
-	a->last_w = 0;
+	for(int i = 0; i < KEPT_LINES; i++) a->kept_w[i] = 0;
 	a->fm = st->fm; a->am = st->am; a->a2 = st->a2; a->a2_pilot = st->a2_pilot; a->a2_signal = st->a2_signal;
 	{
 		/* the tables the filters and the look-ahead window point at are this engine's own */
@@ -1014,6 +1181,12 @@ int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_
 		a->a2_lim.pre.taps = vt2; a->a2_lim.flat.taps = ft2; a->a2_lim.shape = sh2;
 	}
 	a->nicam = st->nicam;
+	{
+		uint8_t *rec = a->sis.rec;
+		const size_t cap = a->sis.rec_cap;
+		a->sis = st->sis;
+		a->sis.rec = rec; a->sis.rec_cap = cap; a->sis.rec_len = 0;
+	}
 
 	a->sym_len = 0;
 	a->sym_k0 = st->sym_first;

@@ -154,6 +154,10 @@ typedef struct {
 	const signed char *vbi_map;   /* [frames][lines]: op of the line or -1 */
 	const int16_t *vits_l;        /* VITS: [n][width] luma added */
 	const int16_t *vits_c;        /*       [n][width] chroma amplitude */
+	const int16_t *sis_dense;     /* sound-in-syncs: [50][HVK_SIS_SPAN] the half symbols as dense rows */
+	const int16_t *sis_win;       /*   the blanking window, k.sis_width values from sample k.sis_left */
+	const int16_t *sis_first;     /*   [HVK_SIS_SPAN] what the last never-emitted invocation leaves on the stream's first line */
+	const unsigned *sis_bits;     /*   [frames][lines][2]: a line's burst -- 7 bytes of bits (MSB first), their number in the eighth */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const int16_t *linebase;      /* [rows][k.base_stride]: blanking + sync pulses of every kind of line */
@@ -183,6 +187,7 @@ typedef struct {
 	int pal, vbi_op, vits_i;
 	int ax0, ax1, ar_eff;   /* samples [ax0, ax1) show a source pixel; luma is assigned up to ar_eff */
 	bool active, has_pix;
+	bool stream_first;      /* line 1 of the stream's first frame */
 } hvk_line_t;
 
 /* which line of which frame, without dividing the global line number: line of the field table, frame parity,
@@ -234,6 +239,7 @@ __device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, c
 	L.rel = rel;
 	L.own = own;
 	L.zero = zero;
+	L.stream_first = own && rel == 0 && f.frame_index == 0;
 	L.d = d;
 	L.pal = k.colour ? L.d.pal : 0;
 
@@ -799,6 +805,52 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 #pragma unroll
 				for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + acc[x0 + i]);
 			}
+		}
+	}
+
+	/* Sound-in-syncs (src/sis.c:155-215; behind CC608, in front of teletext, whose symbols lie elsewhere on the line): the
+	 * sync area blanked to the sync level through a window, then the burst's half symbols added -- 46 or 50 bits, most
+	 * significant first, bit b shaped by entry 50 - nb + b (vbidata_render() passes over the first 50 - nb). All of it
+	 * lies in the line's first HVK_SIS_SPAN samples: the first wave's business. */
+	if(EXTRAS && k.sis && own && wx0 < HVK_SIS_SPAN)
+	{
+		const unsigned *rec = P.sis_bits + ((size_t) y * k.lines + rel) * 2;
+		const unsigned w0 = __builtin_amdgcn_readfirstlane(rec[0]), w1 = __builtin_amdgcn_readfirstlane(rec[1]);
+		const int nb = (int) (w1 >> 24);
+		if(x0 < HVK_SIS_SPAN)
+		{
+			int v[SPL];
+#pragma unroll
+			for(int i = 0; i < SPL; i++) v[i] = wrap16(s[i]);
+			if(L.stream_first)
+			{
+				/* what the process left here when it ran on the never-emitted slot in front of this line (hvk_tables.c:_build_sis) */
+				const int4v f4 = *(const int4v *) (P.sis_first + x0);
+				const int fv[SPL] = { (int) (short) (f4.x & 0xFFFF), f4.x >> 16, (int) (short) (f4.y & 0xFFFF), f4.y >> 16,
+				                      (int) (short) (f4.z & 0xFFFF), f4.z >> 16, (int) (short) (f4.w & 0xFFFF), f4.w >> 16 };
+#pragma unroll
+				for(int i = 0; i < SPL; i++) v[i] = wrap16(v[i] + fv[i]);
+			}
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int x = x0 + i - k.sis_left;
+				if(x >= 0 && x < k.sis_width)
+				{
+					const int w = P.sis_win[x];
+					v[i] = wrap16((v[i] * (32767 - w) + k.sis_sync * w) >> 15);
+				}
+			}
+			for(int b = 0; b < nb; b++)
+			{
+				const unsigned word = b < 32 ? w0 : w1;
+				if(!((word >> (((b >> 3) & 3) * 8 + 7 - (b & 7))) & 1)) continue;       /* (the same for the whole wave) */
+				const int4v q = *(const int4v *) (P.sis_dense + (size_t) (50 - nb + b) * HVK_SIS_SPAN + x0);
+				v[0] += (int) (short) (q.x & 0xFFFF); v[1] += q.x >> 16; v[2] += (int) (short) (q.y & 0xFFFF); v[3] += q.y >> 16;
+				v[4] += (int) (short) (q.z & 0xFFFF); v[5] += q.z >> 16; v[6] += (int) (short) (q.w & 0xFFFF); v[7] += q.w >> 16;
+			}
+#pragma unroll
+			for(int i = 0; i < SPL; i++) s[i] = wrap16(v[i]);
 		}
 	}
 }

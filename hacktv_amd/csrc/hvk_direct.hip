@@ -418,7 +418,7 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *L
  * picture per frame, no inserters -- with the matrix-unit filter or none */
 extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a)
 {
-	if(k->secam || k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->fields != 1 || k->fm_video) return(0);
+	if(k->secam || k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->sis || k->fields != 1 || k->fm_video) return(0);
 	if(k->vf_type != 0 && !(k->vf_ntaps == 51 && mfma_a && (k->vf_type == 1 || k->vf_type == 3))) return(0);
 	if(k->width < 544) return(0);               /* a tile's window within three lines */
 	return(1);

@@ -75,6 +75,8 @@ struct hvk_engine {
 	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	int8_t *d_map, *h_map;      /* [max_frames][lines] */
 	void *d_vits_l, *d_vits_c;
+	void *d_sis_dense, *d_sis_win, *d_sis_first;    /* sound-in-syncs tables */
+	uint32_t *d_sis_bits, *h_sis_bits;              /* [max_frames][lines][2]: the lines' bursts */
 	/* --raw-bb-file: queued stream (raw_q[0] is sample raw_base) and its per-batch slab */
 	std::vector<int16_t> *raw_q; int64_t raw_base;
 	int16_t *d_raw, *h_raw;
@@ -297,7 +299,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(e->t.k.vf_type) _pack_taps(&e->itaps, e->t.vf_itaps, e->t.k.vf_ntaps);
 	if(e->t.k.vf_type == 3) _pack_taps(&e->qtaps, e->t.vf_qtaps, e->t.k.vf_ntaps);
 
-	if(e->t.k.has_carriers || e->t.k.has_nicam)
+	if(e->t.k.has_carriers || e->t.k.has_nicam || e->t.k.sis)
 	{
 		e->audio = hvk_audio_new(&e->t);
 		if(!e->audio) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
@@ -543,6 +545,15 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_vits_c, e->t.vits_c, sizeof(int16_t) * k.vits * k.width));
 	}
 
+	if(k.sis)
+	{
+		OPENCHK(_upload(&e->d_sis_dense, e->t.sis_dense, sizeof(int16_t) * 50 * HVK_SIS_SPAN));
+		OPENCHK(_upload(&e->d_sis_win, e->t.sis_win, sizeof(int16_t) * k.sis_width));
+		OPENCHK(_upload(&e->d_sis_first, e->t.sis_first, sizeof(int16_t) * HVK_SIS_SPAN));
+		OPENHIP(hipMalloc((void **) &e->d_sis_bits, (size_t) max_frames * k.lines * 8));
+		OPENHIP(hipHostMalloc((void **) &e->h_sis_bits, (size_t) max_frames * k.lines * 8, hipHostMallocDefault));
+	}
+
 	if(k.rawbb)
 	{
 		const size_t bytes = (size_t) max_frames * k.slab_lines * k.width * 2;
@@ -670,7 +681,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -679,7 +690,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		if(e->ev_pdesc) (void) hipEventDestroy(e->ev_pdesc);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -1011,6 +1022,16 @@ extern "C" int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t cou
 	if(!e) return(HVK_ERROR);
 	if(!e->audio) return(0);
 	return(hvk_audio_generate(e->audio, first, count, carriers, symbols, max_symbols, k0));
+}
+
+/* sound-in-syncs, host half on its own: the bursts of stream lines [first_line, first_line + nlines), forward only */
+extern "C" int hvk_host_sis_bursts(hvk_engine_t *e, int64_t first_line, int nlines, uint8_t *out)
+{
+	if(!e || !out || first_line < 0 || nlines < 0) return(HVK_ERROR);
+	if(!e->t.k.sis || !e->audio) return(HVK_UNSUPPORTED);
+	int r = hvk_audio_advance(e->audio, (first_line + nlines) * (int64_t) e->t.k.width);
+	if(r != HVK_OK) return(r);
+	return(hvk_audio_sis_fetch(e->audio, first_line, nlines, out));
 }
 
 extern "C" int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int height, int interlaced, int16_t *out)
@@ -1577,6 +1598,13 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 				e->sym_tmp, e->symbol_stride, &k0);
 			if(n < 0) { e->poisoned = 1; return(n); }
 
+			if(k.sis)
+			{
+				/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
+				int r = hvk_audio_sis_fetch(e->audio, f->frame_index * k.lines, k.lines, (uint8_t *) (e->h_sis_bits + (size_t) i * k.lines * 2));
+				if(r != HVK_OK) { e->poisoned = 1; return(r); }
+			}
+
 			if(k.has_nicam)
 			{
 				/* tabulate the symbol schedule for the frame (src/nicam728.c:398-407):
@@ -1713,6 +1741,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
+	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * k.lines * 8, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
@@ -1756,6 +1785,10 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	ra.vbi_map = (const signed char *) e->d_map;
 	ra.vits_l = (const int16_t *) e->d_vits_l;
 	ra.vits_c = (const int16_t *) e->d_vits_c;
+	ra.sis_dense = (const int16_t *) e->d_sis_dense;
+	ra.sis_win = (const int16_t *) e->d_sis_win;
+	ra.sis_first = (const int16_t *) e->d_sis_first;
+	ra.sis_bits = e->d_sis_bits;
 	ra.desc = (const hvk_linedesc_t *) e->d_desc;
 	ra.pulses = (const int16_t *) e->d_pulses;
 	ra.linebase = (const int16_t *) e->d_linebase;
@@ -2062,7 +2095,7 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;
-	const int extras = (sv || k.vbi || k.vits || k.rawbb || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
+	const int extras = (sv || k.vbi || k.vits || k.rawbb || k.sis || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
 	const int wc = (!k.secam && !sv && !extras && nt == 13 && k.width == 1024) ? 1024 : 0;
 	const int vnt = k.vf_type ? k.vf_ntaps : 1;
 	const int exact = (k.frame_samples % HVK_TILE == 0 && k.s_stride - k.s_lead - k.frame_samples >= 128) ? 1 : 0;

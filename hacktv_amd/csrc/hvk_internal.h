@@ -22,6 +22,7 @@ extern "C" {
 #define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
 #define HVK_VBI_OPS      64     /* VBI lines per frame (32 teletext + WSS + 4 VITC + CC608 + 20 ACP + spare) */
 #define HVK_VBI_OPWORDS  16     /* dwords per op: sym_base, nbits, blank range, spare, 12 data words */
+#define HVK_SIS_SPAN     128    /* samples at a line's start the sound-in-syncs burst and its window lie in */
 #define HVK_VBI_LUTS     4      /* 0 teletext, 1 WSS, 2 VITC, 3 CC608 (32 bit cells + the clock run-in as a 33rd symbol) */
 
 typedef struct { int16_t i, q; } hvk_c16_t;
@@ -102,6 +103,9 @@ typedef struct {
 	int32_t s_video;        /* the colour sub-carrier goes to the Q channel (a second raster slab) */
 	int32_t fm_video;       /* the engine's device output is the FM modulator's input (hvk_tail.c does the rest) */
 	int32_t swap_iq, has_offset, has_passthru;   /* complex tail done by hvk_k_tail (not FM video) */
+	int32_t sis;            /* sound-in-syncs: every line's sync area blanked through a window and carrying 4-level symbols */
+	int32_t sis_left, sis_width, sis_sync;  /* the window's first sample, its length, the level it blanks to */
+	int32_t sis_dummies;    /* never-emitted invocations before line 1: 1, or 3 behind a threaded colour process (SECAM) */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;
 
@@ -165,6 +169,11 @@ typedef struct {
 	int32_t acp_left[6], acp_psync_width, acp_pagc_width, acp_psync_level;
 	int32_t grey_y[256];        /* luma level of RGB (i, i, i): what ACP's AGC pulse follows */
 	int16_t *vits_l, *vits_c;   /* [vits][width]: luma added, chroma amplitude */
+	/* sound-in-syncs (src/sis.c): the 50 half symbols as dense rows over the line's first HVK_SIS_SPAN samples, the
+	 * blanking window, and what the last never-emitted invocation leaves on the stream's first line */
+	int16_t *sis_dense;         /* [50][HVK_SIS_SPAN] */
+	int16_t *sis_win;           /* [sis_width] */
+	int16_t *sis_first;         /* [HVK_SIS_SPAN] */
 	/* SECAM (src/video.c:4075-4162) */
 	int32_t secam_level;
 	hvk_c32_t *secam_lut;       /* 65536 FM steps at the pixel rate */
@@ -249,6 +258,9 @@ size_t hvk_audio_state_bytes(void);
 int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes);
 int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_t *source_pos);
 int64_t hvk_audio_generated(const hvk_audio_t *a);
+/* sound-in-syncs: the bursts of stream lines [g_first, g_first + count), 8 bytes a line (7 bytes of bits MSB first, their number) */
+int hvk_audio_sis_fetch(hvk_audio_t *a, int64_t g_first, int count, uint8_t *out);
+int hvk_audio_advance(hvk_audio_t *a, int64_t end);
 
 #ifdef __cplusplus
 }

@@ -1114,6 +1114,116 @@ static int _build_vits(hvk_tables_t *t)
 
 /* ------------------------------------------------------------------ */
 
+/* ---- sound-in-syncs (src/sis.c:36-153) ---- */
+
+static double _sis_rc(double x)
+{
+	if(x <= -1 || x >= 1) return(0);
+	return((1.0 + cos(M_PI * x)) / 2);
+}
+
+static int _build_sis(hvk_tables_t *t)
+{
+	const int W = t->k.width;
+	const double bwidth = (double) W / 382, offset = (double) W / 382 * 3.32;      /* (the offset: "measured", src/sis.c:113) */
+	const double left = 0.2e-6, rise = 80e-9, width = 4.56e-6;
+	int levels[2], b, x, off[50], len[50];
+	int16_t *packed;
+	long pos[50], n = 0;
+
+	{
+		const int level = (int) round((double) (t->white_level - t->black_level));
+		levels[0] = level / 2 / 0.75;
+		levels[1] = level / 4 / 0.75;
+	}
+
+	t->sis_dense = calloc((size_t) 50 * HVK_SIS_SPAN, sizeof(int16_t));
+	packed = calloc((size_t) 50 * (W + 2) + 1, sizeof(int16_t));
+	if(!t->sis_dense || !packed) { free(packed); return(HVK_OUT_OF_MEMORY); }
+
+	/* entry b shapes bit b of the burst: bits 2 n and 2 n + 1 share a place and weigh 2 : 1. Kept twice: as dense rows
+	 * for the kernel, and packed the reference's way ([length][offset][values], from the first non-zero value to
+	 * the last: vbidata_update(), src/vbidata.c:36-60) for what follows */
+	for(b = 0; b < 50; b++)
+	{
+		const double tt = -bwidth * (b / 2) - offset;
+		off[b] = len[b] = 0;
+		pos[b] = n + 2;
+		for(x = 0; x < W; x++)
+		{
+			const int v = (int) round(_sis_rc((tt + x) / bwidth) * levels[b & 1]);
+			if(v == 0) continue;
+			if(len[b] == 0) off[b] = x;
+			while(len[b] < x - off[b]) packed[pos[b] + len[b]++] = 0;
+			packed[pos[b] + len[b]++] = (int16_t) v;
+			if(x >= HVK_SIS_SPAN) { free(packed); return(HVK_UNSUPPORTED); }       /* (a burst longer than the kernel looks at: not at any rate hvk_open takes) */
+			t->sis_dense[(size_t) b * HVK_SIS_SPAN + x] = (int16_t) v;
+		}
+		packed[n] = (int16_t) len[b];
+		packed[n + 1] = (int16_t) off[b];
+		n = pos[b] + len[b];
+	}
+	packed[n++] = -1;
+
+	/* the blanking window */
+	t->k.sis_left = (int) floor(t->pixel_rate * (left - rise / 2));
+	t->k.sis_width = (int) ceil(t->pixel_rate * (width + rise));
+	if(t->k.sis_left < 0 || t->k.sis_left + t->k.sis_width > HVK_SIS_SPAN) { free(packed); return(HVK_UNSUPPORTED); }
+	t->sis_win = calloc(t->k.sis_width, sizeof(int16_t));
+	t->sis_first = calloc(HVK_SIS_SPAN, sizeof(int16_t));
+	if(!t->sis_win || !t->sis_first) { free(packed); return(HVK_OUT_OF_MEMORY); }
+	for(x = t->k.sis_left; x < t->k.sis_left + t->k.sis_width; x++)
+	{
+		t->sis_win[x - t->k.sis_left] = (int16_t) round(_window(1.0 / t->pixel_rate * x, left, width, rise) * INT16_MAX);
+	}
+	t->k.sis_sync = t->sync_level;
+
+	/* The process runs on the never-emitted slots in front of line 1 as well -- one, or three where the colour process
+	 * is a thread between the raster and it (SECAM, src/video.c:4211 with :3543-3583). The last of them has no width
+	 * and line 1's slot behind it: vbidata_render() then draws every set symbol into LINE 1, from its sample 0 on, with a
+	 * negative index into the symbol's values (src/vbidata.c:211-217) -- the symbol lands in its place and the samples
+	 * in front of it get what the packed table holds in front of the values: earlier entries, the entry's own header,
+	 * and for the first entries the 16 bytes in front of the table on the reference's heap (glibc: the chunk's size
+	 * word, zeros before it). Line 1's own invocation blanks most of it away; the stream's first samples keep it.
+	 * The burst of those invocations is known: the frame store is still all zeros. */
+	t->k.sis_dummies = t->conf.colour_mode == HVK_SECAM ? 3 : 1;
+	{
+		static const uint8_t gc[2][4] = { { 3, 0, 2, 1 }, { 0, 3, 1, 2 } };
+		int re = 0, nb = 50, call;
+		uint8_t vbi[7];
+		int16_t heap[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		const unsigned long chunk = (((unsigned long) n * 2 + 8 + 15) & ~15UL) | 1;
+		heap[4] = (int16_t) (chunk & 0xFFFF);
+		heap[5] = (int16_t) ((chunk >> 16) & 0xFFFF);
+
+		for(call = 1; call <= t->k.sis_dummies; call++)
+		{
+			nb = 50;
+			if((re += 44) >= 125) { nb -= 4; re -= 125; }
+		}
+		memset(vbi, 0, sizeof(vbi));
+		vbi[0] = 0xC0;
+		for(x = 2; x < nb; x += 2) vbi[x >> 3] |= gc[(x & 4) ? 1 : 0][0] << (6 - (x & 7));
+
+		for(b = 0; b < nb; b++)
+		{
+			const int e = 50 - nb + b;
+			int i, at;
+			if(!((vbi[b >> 3] >> (7 - (b & 7))) & 1)) continue;
+			for(i = -off[e], at = 0; i < len[e] && at < HVK_SIS_SPAN; i++, at++)
+			{
+				const long q = pos[e] + i;
+				const int16_t v = q >= 0 ? packed[q] : (q >= -8 ? heap[q + 8] : 0);
+				t->sis_first[at] = (int16_t) (t->sis_first[at] + v);
+			}
+		}
+	}
+
+	free(packed);
+	t->k.sis = 1;
+	return(HVK_OK);
+}
+
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate)
 {
 	hvk_config_t *c;
@@ -1526,12 +1636,22 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->vits && (r = _build_vits(t)) != HVK_OK) return(r);
 	if(c->acp) _build_acp(t);
 	t->k.vbi = t->vbi_nsym > 0 || c->acp;
+	if(c->sis)
+	{
+		/* (the burst is laid out in pixels of the raster; behind the resampler the audio process's lines vary in width,
+		 * which the block hand-over's timing goes by: not combined. Nor with a raster that is not built from pictures) */
+		if(c->sis != 1 || t->k.rs_L || c->raw_bb || c->s_video) return(HVK_UNSUPPORTED);
+		if((r = _build_sis(t)) != HVK_OK) return(r);
+	}
 
 	return(_build_linedesc(t));
 }
 
 void hvk_tables_free(hvk_tables_t *t)
 {
+	free(t->sis_dense);
+	free(t->sis_win);
+	free(t->sis_first);
 	free(t->desc);
 	free(t->linebase);
 	free(t->pulse_values);

@@ -326,7 +326,9 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
-	   c->systercnr || c->sis || c->eurocrypt) return(_refuse("a VBI inserter / scrambler"));
+	   c->systercnr || c->eurocrypt) return(_refuse("a scrambler"));
+	if(c->sis && strcmp(c->sis, "dcsis") != 0) return(_refuse("this sound-in-syncs mode"));      /* (so does the reference, src/sis.c:95-103) */
+	if(c->sis && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->raw_bb_file || c->s_video)) return(_refuse("sound-in-syncs with --pixelrate / raw baseband input / S-Video"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->s_video)) return(_refuse("raw baseband input with --pixelrate / --s-video"));
 	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
@@ -395,6 +397,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->vitc = c->vitc;
 	h->acp = c->acp;
 	h->cc608 = c->cc608;
+	h->sis = c->sis ? 1 : 0;
 	if(c->wss)
 	{
 		/* mode name -> the aspect ratio group of ETSI EN 300 294 with its odd parity bit, as src/wss.c:33-44 */

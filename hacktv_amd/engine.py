@@ -21,7 +21,7 @@ SYMBOLS = [
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels", "hvk_planes_refresh",
-    "hvk_sound_state_size", "hvk_sound_state_export", "hvk_sound_state_import", "hvk_sound_samples_generated",
+    "hvk_host_sis_bursts", "hvk_sound_state_size", "hvk_sound_state_export", "hvk_sound_state_import", "hvk_sound_samples_generated",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
@@ -98,6 +98,7 @@ def lib():
         L.hvk_output_device_ptr.restype = vp
         L.hvk_timing_enable.argtypes = [vp, i32]
         L.hvk_planes_refresh.argtypes = [vp, vp, i32]
+        L.hvk_host_sis_bursts.argtypes = [vp, C.c_int64, i32, vp]
         L.hvk_sound_state_size.argtypes = [vp]
         L.hvk_sound_state_size.restype = C.c_size_t
         L.hvk_sound_state_export.argtypes = [vp, vp, C.c_size_t]
@@ -232,6 +233,11 @@ class Engine:
         n = self._chk("hvk_host_side_streams", lib().hvk_host_side_streams(
             self.h, first, count, car.ctypes.data, sym.ctypes.data, len(sym), C.byref(k0)))
         return car, sym[:n], k0.value
+
+    def host_sis_bursts(self, first_line, nlines):
+        out = np.zeros((nlines, 8), np.uint8)
+        self._chk("hvk_host_sis_bursts", lib().hvk_host_sis_bursts(self.h, first_line, nlines, out.ctypes.data))
+        return out
 
     def host_secam_stream(self, fb, interlaced=0):
         out = np.zeros(self.info["frame_samples"], np.int16)

@@ -280,6 +280,13 @@ int hvk_set_stream(hvk_engine_t *e, void *hip_stream);
 int hvk_host_side_streams(hvk_engine_t *e, int64_t first, int64_t count,
                           int16_t *carriers, uint8_t *symbols, int max_symbols, int64_t *k0);
 
+/* --sis (conf.sis), host half on its own: the sound-in-syncs bursts of stream lines [first_line, first_line + nlines),
+ * lines counted from 0 over the whole stream -- 8 bytes a line: the burst's bits, most significant first (the two start
+ * bits, then 23 or 25 grey-coded bit pairs of the NICAM-728 stream, src/sis.c:155-201), and in the eighth byte their
+ * number (46 or 50). Runs the sound chains up to the lines' end; forward only; use it instead of, not next to,
+ * hvk_render(). Needs no device. */
+int hvk_host_sis_bursts(hvk_engine_t *e, int64_t first_line, int nlines, uint8_t *out);
+
 /* SECAM only, host half on its own: the value the colour process adds to every
  * sample of the NEXT frame of the stream (frame_samples int16), given the
  * picture shown on it (fb == NULL: an empty frame). Frames are taken in stream

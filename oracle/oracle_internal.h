@@ -170,6 +170,7 @@ struct orc_t {
 	uint8_t sis_frame[91];
 	int sis_frame_bit, sis_re;
 	long sis_calls;
+	uint8_t *sis_rec; long sis_rec_n, sis_rec_cap;     /* the bursts of the lines made so far, 8 bytes each */
 	int sis_visible;            /* samples of the step's audio line the audio thread is taken to have behind it (0: none) */
 
 	/* SECAM colour process (oracle_secam.c) */

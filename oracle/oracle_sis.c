@@ -111,6 +111,13 @@ int orc_sis_init(orc_t *s)
 	return(0);
 }
 
+long orc_sis_bursts(orc_t *s, long first_line, long nlines, uint8_t *out)
+{
+	if(first_line < 0 || first_line + nlines > s->sis_rec_n) return(-1);
+	memcpy(out, s->sis_rec + first_line * 8, (size_t) nlines * 8);
+	return(nlines);
+}
+
 void orc_set_sis_visible(orc_t *s, int samples) { s->sis_visible = samples < 0 ? 0 : samples; }
 
 void orc_sis_free(orc_t *s)
@@ -120,6 +127,8 @@ void orc_sis_free(orc_t *s)
 	free(s->sis_lut);
 	free(s->sis_blank_win);
 	free(s->sis_packed);
+	free(s->sis_rec);
+	s->sis_rec = NULL;
 	s->sis_packed = NULL;
 	s->sis_lut = NULL;
 	s->sis_blank_win = NULL;
@@ -199,6 +208,20 @@ void orc_sis_line(orc_t *s, long g, int first_line)
 		sym = (s->sis_frame[s->sis_frame_bit >> 3] >> (6 - (s->sis_frame_bit & 7))) & 3;
 		sym = gc[(x & 4) ? 1 : 0][sym];
 		vbi[x >> 3] |= sym << (6 - (x & 7));
+	}
+
+	if(g >= 0)
+	{
+		/* kept for tests: what the host half of the product has to come up with (orc_sis_bursts()) */
+		if(g >= s->sis_rec_cap)
+		{
+			s->sis_rec_cap = s->sis_rec_cap ? s->sis_rec_cap * 2 : 4096;
+			while(g >= s->sis_rec_cap) s->sis_rec_cap *= 2;
+			s->sis_rec = realloc(s->sis_rec, (size_t) s->sis_rec_cap * 8);
+		}
+		memcpy(s->sis_rec + g * 8, vbi, 7);
+		s->sis_rec[g * 8 + 7] = (uint8_t) nb;
+		if(g + 1 > s->sis_rec_n) s->sis_rec_n = g + 1;
 	}
 
 	if(g < 0 && !first_line) return;        /* a slot without width whose successor has none either: nothing is drawn (src/vbidata.c:219-225) */

@@ -57,6 +57,8 @@ void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2);
 /* --sis: how many samples of a step's audio line the reference's audio thread is taken to have behind it when its SiS
  * process looks for the newest audio block (oracle_sis.c; 0: none -- the default) */
 void orc_set_sis_visible(orc_t *s, int samples);
+/* ... the bursts of the lines rendered so far (8 bytes a line: 7 bytes of bits, MSB first, and their number); -1: not made yet */
+long orc_sis_bursts(orc_t *s, long first_line, long nlines, uint8_t *out);
 
 /* --passthru: the external int16 I/Q signal (kept by reference), from its first sample */
 void orc_set_passthru(orc_t *s, const int16_t *iq, long nsamples);

@@ -38,6 +38,8 @@ def lib():
         L.orc_set_cc608.argtypes = [C.c_void_p, C.c_long, C.c_uint8, C.c_uint8]
         L.orc_set_sis_visible.restype = None
         L.orc_set_sis_visible.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sis_bursts.restype = C.c_long
+        L.orc_sis_bursts.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p]
         L.orc_set_passthru.restype = None
         L.orc_set_passthru.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_render_lines.restype = C.c_long
@@ -137,6 +139,11 @@ class Oracle:
         """--sis: samples of a step's audio line the reference's audio thread is taken to have behind it when the SiS
         process picks its block (oracle_sis.c); 0: none."""
         lib().orc_set_sis_visible(self.p, samples)
+
+    def sis_bursts(self, first_line, nlines):
+        out = np.zeros((nlines, 8), np.uint8)
+        assert lib().orc_sis_bursts(self.p, first_line, nlines, out.ctypes.data) == nlines
+        return out
 
     def set_passthru(self, iq):
         a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)
