@@ -63,7 +63,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb",
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
-                                  "palfm_f14_tail"])
+                                  "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -995,3 +995,38 @@ def test_a_gap_on_525_lines_needs_the_frame_before(golden):
         while e.audio_needed(8) > 0:
             e.audio_write(golden.audio)
         e.stage(1, 2, 3)
+
+
+def test_sound_in_syncs_through_the_dropin_binary():
+    """`hacktv_hvk -m i -s 16000000 --filter --sis dcsis` (the reference's main(), the video.h shim, libhvk) against the
+    reference CLI run in the same job: 30 frames, every sample. The NICAM stream inside the sync pulses starts with
+    silence (the first frames are encoded before the audio thread has handed a block over) and then carries the tone."""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hvk, ref = os.path.join(root, "oracle", "_ref", "hacktv_hvk"), os.path.join(root, "oracle", "_ref", "hacktv_ref")
+    require_ref(hvk)
+    require_ref(ref)
+    n = 30 * 2560000
+
+    def run(binary):
+        p = subprocess.Popen([binary, "-m", "i", "-s", "16000000", "--filter", "--sis", "dcsis", "-o", "-", "test"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, env=dict(os.environ, HVK_BATCH="4"))
+        out = bytearray()
+        while len(out) < n:
+            chunk = p.stdout.read(n - len(out))
+            if not chunk:
+                break
+            out += chunk
+        p.kill()
+        p.wait()
+        return bytes(out)
+
+    got, want = run(hvk), run(ref)
+    assert len(got) == n == len(want)
+    if got != want:
+        a = np.frombuffer(got, np.int16).reshape(-1, 2)
+        b = np.frombuffer(want, np.int16).reshape(-1, 2)
+        bad = np.nonzero((a != b).any(axis=1))[0]
+        raise AssertionError("%d samples differ, first in frame %d line %d sample %d" % (bad.size, bad[0] // 640000, bad[0] % 640000 // 1024, bad[0] % 1024))
