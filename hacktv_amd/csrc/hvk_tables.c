@@ -1598,7 +1598,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->raw_bb)
 	{
 		if(c->raw_bb_white_level == c->raw_bb_blanking_level) return(HVK_ERROR);
-		if(t->k.rs_L || c->s_video) return(HVK_UNSUPPORTED);
+		if(c->s_video) return(HVK_UNSUPPORTED);
 		t->k.rawbb = 1;
 		t->k.rawbb_blank = c->raw_bb_blanking_level;
 		t->k.rawbb_range = c->raw_bb_white_level - c->raw_bb_blanking_level;

@@ -330,7 +330,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->sis && strcmp(c->sis, "dcsis") != 0) return(_refuse("this sound-in-syncs mode"));      /* (so does the reference, src/sis.c:95-103) */
 	if(c->sis && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->raw_bb_file || c->s_video)) return(_refuse("sound-in-syncs with --pixelrate / raw baseband input / S-Video"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
-	if(c->raw_bb_file && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->s_video)) return(_refuse("raw baseband input with --pixelrate / --s-video"));
+	if(c->raw_bb_file && c->s_video) return(_refuse("raw baseband input with --s-video"));
 	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
 	if(c->frame_orientation) return(_refuse("frame orientation"));
 
@@ -740,7 +740,8 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 	 * like src/video.c:2419-2429 -- at the end of the file, start over */
 	if(s->raw_bb_file)
 	{
-		const int64_t want = ((m->frames_pulled * (int64_t) m->info.lines) + 1) * m->info.width;
+		/* (behind the resampler the engine looks one raster line further: its chunks lag the raster by a slot) */
+		const int64_t want = ((m->frames_pulled * (int64_t) m->info.lines) + 1 + (m->info.pixel_rate != m->info.sample_rate ? 1 : 0)) * m->info.width;
 		int16_t chunk[4096];
 		int empty = 0;
 

@@ -175,8 +175,9 @@ int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlines);
 
 /* --raw-bb-file (conf.raw_bb != 0): the next nsamples int16 samples of the external baseband
  * stream that takes the raster's place (src/video.c:2406-2446), in stream order; a line is `width`
- * samples. Rendering frame f needs the stream up to sample ((f + 1) * lines + 1) * width (the
- * filter looks into the line after the frame); what is not queued reads as zeros. Starting the
+ * samples (of the pixel rate). Rendering frame f needs the stream up to sample ((f + 1) * lines + 1) * width (the
+ * filter looks into the line after the frame; with --pixelrate one line more: the resampler's chunks lag the raster
+ * by a slot); what is not queued reads as zeros. Starting the
  * file over at its end, as the reference does, is the caller's job. */
 int hvk_rawbb_write(hvk_engine_t *e, const int16_t *samples, size_t nsamples);
 
