@@ -113,6 +113,7 @@ struct hvk_engine {
 	int carry_row;              /* which of the two kept rows `carry` points at: the batch being staged reads one while the other is written */
 	int16_t *d_S;
 	int16_t *d_C;           /* --s-video: the sub-carrier slab */
+	int16_t *d_C2;          /* --s-video with --pixelrate: the resampled sub-carrier (the resampler's second channel) */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
 	int16_t *d_car;
 	int32_t *d_sym;
@@ -477,6 +478,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(k.rs_L)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
+		if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C2, (size_t) max_frames * k.s_stride * 2 + 256));
 		/* one 16-byte aligned row of 12 packed dwords per phase: pairs (t[0], t[1]) ... oldest sample
 		 * first; a 21-tap phase gets a zero 22nd (hvk_k_resample stages the rows as they are) */
 		std::vector<int> rows((size_t) k.rs_L * 12, 0);
@@ -681,7 +683,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -1814,7 +1816,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	fa.qtaps = e->qtaps;
 	fa.fdesc = e->d_fdesc;
 	fa.S = e->t.k.rs_L ? e->d_S2 : e->d_S;
-	fa.C = e->d_C;
+	fa.C = e->t.k.rs_L ? e->d_C2 : e->d_C;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
 	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;
@@ -1885,6 +1887,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	{
 		if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
 		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.rs_L && e->t.k.s_video && (r = hvk_launch_resample(&e->t.k, e->d_C, e->d_rs_taps, e->d_C2, e->staged, e->stream)) != HVK_OK) return(r);
 		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
 		if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
 	}

@@ -1607,10 +1607,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		t->k.secam = 0;
 	}
 
-	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); the resampler's second channel is not built */
+	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); behind the resampler the sub-carrier has a channel of its own (src/video.c:4361-4367) */
 	if(c->s_video)
 	{
-		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME || t->k.rs_L) return(HVK_UNSUPPORTED);
+		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME) return(HVK_UNSUPPORTED);
 		t->k.s_video = 1;
 	}
 

@@ -331,7 +331,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->sis && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->raw_bb_file || c->s_video)) return(_refuse("sound-in-syncs with --pixelrate / raw baseband input / S-Video"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file && c->s_video) return(_refuse("raw baseband input with --s-video"));
-	if(c->s_video && pixel_rate != 0 && pixel_rate != sample_rate) return(_refuse("S-Video with --pixelrate"));
 	if(c->frame_orientation) return(_refuse("frame orientation"));
 
 	h->output_type = c->output_type;

@@ -110,6 +110,8 @@ struct orc_t {
 	int rs_L, rs_D, rs_ataps, rs_d;
 	int16_t *rs_taps;           /* [L][ataps], the order they are applied in; NULL: no resampler */
 	int16_t *rs_win;
+	int16_t *rs_win2; int rs_d2;    /* the resampler's second channel (--s-video) */
+	int16_t *prev_q;            /* its last chunks */
 	int max_width;              /* widest chunk the pipeline can emit */
 
 	/* pipeline state (oracle_video.c) */

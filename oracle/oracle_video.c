@@ -46,9 +46,8 @@ orc_t *orc_open_rates(const hvk_config_t *conf, unsigned int sample_rate, unsign
 	s->sample_rate = sample_rate;
 	s->pixel_rate = pixel_rate ? pixel_rate : sample_rate;   /* src/video.c:3839 */
 
-	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); the two-channel resampler is not restated */
-	if(conf->s_video && (conf->output_type != HVK_INT16_REAL || conf->colour_mode == HVK_MONOCHROME ||
-	                     (pixel_rate && pixel_rate != sample_rate))) { free(s); return(NULL); }
+	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148) */
+	if(conf->s_video && (conf->output_type != HVK_INT16_REAL || conf->colour_mode == HVK_MONOCHROME)) { free(s); return(NULL); }
 
 	if(orc_build_tables(s) != 0 || orc_audio_init(s) != 0 || orc_tail_init(s) != 0 || orc_vbi_init(s) != 0 || orc_sis_init(s) != 0)
 	{
@@ -84,6 +83,8 @@ void orc_close(orc_t *s)
 	free(s->ciq);
 	free(s->ccar);
 	free(s->prev_r);
+	free(s->prev_q);
+	free(s->rs_win2);
 	free(s->prev_w);
 	free(s);
 }
@@ -378,30 +379,36 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 
 /* the poly-phase resampler of src/fir.c:304-355 (fir_int16_process with interpolation L,
  * decimation D): returns the number of samples made from `n` inputs */
-static int _resample(orc_t *s, const int16_t *in, int n, int16_t *out)
+static int _resample_ch(orc_t *s, int *pd, int16_t *win, const int16_t *in, int n, int16_t *out)
 {
-	int x = 0, i, y;
+	int x = 0, i, y, d = *pd;
 
 	for(i = 0; i < n;)
 	{
-		if(s->rs_d >= s->rs_L)
+		if(d >= s->rs_L)
 		{
-			s->rs_d -= s->rs_L;
-			memmove(s->rs_win, s->rs_win + 1, (s->rs_ataps - 1) * sizeof(int16_t));
-			s->rs_win[s->rs_ataps - 1] = in[i++];
+			d -= s->rs_L;
+			memmove(win, win + 1, (s->rs_ataps - 1) * sizeof(int16_t));
+			win[s->rs_ataps - 1] = in[i++];
 		}
 
-		for(; s->rs_d < s->rs_L; s->rs_d += s->rs_D)
+		for(; d < s->rs_L; d += s->rs_D)
 		{
-			const int16_t *taps = &s->rs_taps[s->rs_d * s->rs_ataps];
+			const int16_t *taps = &s->rs_taps[d * s->rs_ataps];
 			int32_t a = 0;
-			for(y = 0; y < s->rs_ataps; y++) a += (int32_t) s->rs_win[y] * taps[y];
+			for(y = 0; y < s->rs_ataps; y++) a += (int32_t) win[y] * taps[y];
 			a >>= 15;
 			out[x++] = a < INT16_MIN ? INT16_MIN : (a > INT16_MAX ? INT16_MAX : a);
 		}
 	}
 
+	*pd = d;
 	return(x);
+}
+
+static int _resample(orc_t *s, const int16_t *in, int n, int16_t *out)
+{
+	return(_resample_ch(s, &s->rs_d, s->rs_win, in, n, out));
 }
 
 /* the video filter as the reference runs it (src/fir.c:304-355 real, :564-615 real -> complex):
@@ -503,7 +510,27 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 
 		/* S-Video: the filter leaves the Q channel alone, and the slot it writes the luma of
 		 * line c - delay_lines into is that line's own: Q is its sub-carrier (src/video.c:3235-3248) */
-		if(s->conf.s_video)
+		if(s->conf.s_video && s->rs_taps)
+		{
+			/* ... behind the resampler, which has a second channel for it (src/video.c:4361-4367: an instance of the same
+			 * filter, fed the Q channel of the same slots): the sub-carrier of chunk c - delay_lines, resampled */
+			const int16_t *cl = orc_cline_ptr(s, c);
+			int16_t *zero = NULL;
+			int wq, back;
+			if(!s->prev_q)
+			{
+				s->prev_q = calloc((size_t) (s->delay_lines + 1) * s->max_width, sizeof(int16_t));
+				s->rs_win2 = calloc(s->rs_ataps, sizeof(int16_t));
+				s->rs_d2 = s->rs_L;
+			}
+			if(!cl) cl = zero = calloc(W, sizeof(int16_t));
+			wq = _resample_ch(s, &s->rs_d2, s->rs_win2, cl, W, s->prev_q + (size_t) slot * s->max_width);
+			free(zero);
+			(void) wq;      /* == w: both channels consume the same inputs from the same phase */
+			back = (int) ((c - s->delay_lines + (s->delay_lines + 1)) % (s->delay_lines + 1));
+			for(x = 0; x < w; x++) s->ciq[x * 2 + 1] = c >= s->delay_lines ? s->prev_q[(size_t) back * s->max_width + x] : 0;
+		}
+		else if(s->conf.s_video)
 		{
 			const int16_t *cq = orc_cline_ptr(s, c - s->delay_lines);
 			for(x = 0; x < w; x++) s->ciq[x * 2 + 1] = cq ? cq[x] : 0;
