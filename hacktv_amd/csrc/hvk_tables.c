@@ -1512,8 +1512,6 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 		/* what the device kernel is sized for, and frames of constant length */
 		if(L > 256 || D > 4 * L || ((int64_t) t->k.raster_samples * L) % D != 0) return(HVK_UNSUPPORTED);
-		/* passthru adds whole lines of the width they come out with; not combined with varying widths */
-		if(c->passthru) return(HVK_UNSUPPORTED);
 
 		ntaps = (21 * L) | 1;
 		taps = calloc(ntaps, sizeof(double));

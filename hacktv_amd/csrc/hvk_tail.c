@@ -63,7 +63,7 @@ hvk_tail_t *hvk_tail_new(const hvk_tables_t *t)
 	if(!s) return(NULL);
 
 	s->t = t;
-	s->W = t->k.width;      /* passthru is refused together with the resampler: lines are `width` samples */
+	s->W = t->k.width;
 	s->prime = t->k.out_prime;
 
 	/* src/video.c:4596-4602: the offset phasor starts at INT16_MAX (sic), so
@@ -183,31 +183,62 @@ static void _passthru_discard(hvk_tail_t *s, int64_t upto)
 	}
 }
 
+/* one line of `w` samples at output position p (src/video.c:3522-3533): all of its source samples [p + prime,
+ * p + prime + w) or -- once the source is short -- none, now and ever after */
+static int _passthru_line(hvk_tail_t *s, int64_t p, int w, int16_t *dst)
+{
+	const int64_t src = p + s->prime;
+
+	if(src < s->q_base + (int64_t) s->q_head) return(HVK_ERROR);   /* forward only: what has been consumed is gone, dropped from the queue or not */
+	if(src + w > s->q_base + (int64_t) s->q_len)
+	{
+		s->ended = 1;
+		return(HVK_OK);
+	}
+	memcpy(dst, s->q + (src - s->q_base) * 2, (size_t) w * 2 * sizeof(int16_t));
+	return(HVK_OK);
+}
+
 int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_t *out)
 {
 	const int W = s->W;
 	int64_t p;
+	int r;
 
-	if(first < 0 || count < 0 || first % W || count % W) return(HVK_ERROR);
-
+	if(first < 0 || count < 0) return(HVK_ERROR);
 	memset(out, 0, count * 2 * sizeof(int16_t));
+
+	if(s->t->k.rs_L)
+	{
+		/* behind the resampler the lines the process sees vary in width (hvk_tables_line_widths()): whole frames only,
+		 * whose lines are walked with their own widths -- the source is read on without gaps either way, the widths
+		 * only decide where a short source stops */
+		const int64_t FS = s->t->k.frame_samples;
+		const int lines = s->t->k.lines;
+		int32_t *w;
+		if(first % FS || count % FS) return(HVK_ERROR);
+		w = malloc(sizeof(int32_t) * lines);
+		if(!w) return(HVK_OUT_OF_MEMORY);
+		for(p = first; p < first + count && !s->ended; p += FS)
+		{
+			int64_t at = p;
+			hvk_tables_line_widths(s->t, (p / FS) * lines, lines, w);
+			for(int l = 0; l < lines && !s->ended; l++)
+			{
+				if((r = _passthru_line(s, at, w[l], out + (at - first) * 2)) != HVK_OK) { free(w); return(r); }
+				at += w[l];
+			}
+		}
+		free(w);
+		_passthru_discard(s, first + count + s->prime);
+		return(HVK_OK);
+	}
+
+	if(first % W || count % W) return(HVK_ERROR);
 
 	for(p = first; p < first + count && !s->ended; p += W)
 	{
-		/* the line at output position p takes source samples [p + prime, p + prime + W),
-		 * all of them or -- once the source is short -- none, now and ever after
-		 * (src/video.c:3522-3533) */
-		const int64_t src = p + s->prime;
-
-		if(src < s->q_base + (int64_t) s->q_head) return(HVK_ERROR);   /* forward only: what has been consumed is gone, dropped from the queue or not */
-
-		if(src + W > s->q_base + (int64_t) s->q_len)
-		{
-			s->ended = 1;
-			break;
-		}
-
-		memcpy(out + (p - first) * 2, s->q + (src - s->q_base) * 2, W * 2 * sizeof(int16_t));
+		if((r = _passthru_line(s, p, W, out + (p - first) * 2)) != HVK_OK) return(r);
 	}
 
 	_passthru_discard(s, first + count + s->prime);

@@ -769,11 +769,11 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 
 		if(!m->passthru_primed)
 		{
-			want += (size_t) m->info.delay_lines * m->info.width;
+			want += (size_t) m->info.startup_samples;      /* (delay_lines * width; with --pixelrate the dropped chunks' widths) */
 			m->passthru_primed = 1;
 		}
 
-		if(!m->passbuf) m->passbuf = malloc(sizeof(int16_t) * 2 * ((size_t) m->batch * m->info.frame_samples + (size_t) m->info.delay_lines * m->info.width));
+		if(!m->passbuf) m->passbuf = malloc(sizeof(int16_t) * 2 * ((size_t) m->batch * m->info.frame_samples + (size_t) m->info.startup_samples));
 		if(!m->passbuf) return(-1);
 
 		got = 0;

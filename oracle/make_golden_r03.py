@@ -27,6 +27,9 @@ CASES = [
      {"raw_bb": 1, "raw_bb_blanking_level": 0, "raw_bb_white_level": 32767}),
     ("i_rawbb_px16", "i_full", "i", 13500000, 16000000, ["--filter", "--raw-bb-file", "@RAWBB@", "--raw-bb-blanking", "2000", "--raw-bb-white", "21000", "--pixelrate", "16000000", "--vits"],
      refprobe.FLAG_FILTER, False, 2, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000, "vits": 1}),
+    # --passthru behind the resampler: lines of varying width (870 / 871 at 13.5 -> 13.6 MHz), a source that ends inside frame 3
+    ("i_pass_px135", "i_px135", "i", 16000000, 13500000, ["--filter", "--passthru", "@PASS@", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 4, {"passthru": 1}),
+    ("pal_pass_px135_s136", "pal_px135_s136", "pal", 13600000, 13500000, ["--passthru", "@PASS@", "--pixelrate", "13500000"], 0, True, 4, {"passthru": 1}),
     # S-Video behind the resampler: its second channel (src/video.c:4361-4367)
     ("pal_sv_px135", "pal_sv", "pal", 16000000, 13500000, ["--s-video", "--pixelrate", "13500000"], 0, False, 2, {"s_video": 1}),
     ("ntsc_sv_f_px18", "ntsc_sv_f", "ntsc", 13500000, 18000000, ["--s-video", "--filter", "--pixelrate", "18000000"], refprobe.FLAG_FILTER, False, 2, {"s_video": 1}),

@@ -64,7 +64,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
-                                  "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025"])
+                                  "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -291,7 +291,7 @@ def test_dropin_binary_equals_reference_cli(golden):
     util.rawbb_signal().tofile("/tmp/hvk_rawbb.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
                  "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid", "i_rawbb",
-                 "i_rawbb_px16", "pal_rawbb_px135", "i_sis_filter", "ntsc_sv_f_px18", "palm_full", "d_full", "ntsci_full", "pal60_bb", "palfm_f14", "palfm_f14_tail"):
+                 "i_rawbb_px16", "pal_rawbb_px135", "i_sis_filter", "ntsc_sv_f_px18", "i_pass_px135", "palm_full", "d_full", "ntsci_full", "pal60_bb", "palfm_f14", "palfm_f14_tail"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4
