@@ -480,7 +480,10 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		a->sis.dummies = t->k.sis_dummies;
 		_nicam_reset(&a->sis.enc, t);
 		a->sis.enc.reserve = 0;
-		a->ahead = a->sis.dummies - 1;      /* invocation t needs the audio lines before t - 1 complete; line g is invocation g + 1 + dummies */
+		/* invocation t needs the audio lines before t - 1 complete, line g is invocation g + 1 + dummies: its burst is known
+		 * once audio line g + dummies - 1 is through. A frame's render also wants the burst of the line BEHIND it (the video
+		 * filter looks into that line's first samples): the chains stay `dummies` lines ahead of the requests */
+		a->ahead = a->sis.dummies;
 		_sis_invocation(a);                 /* the first one runs before any audio line has */
 	}
 

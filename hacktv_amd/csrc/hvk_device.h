@@ -157,7 +157,7 @@ typedef struct {
 	const int16_t *sis_dense;     /* sound-in-syncs: [50][HVK_SIS_SPAN] the half symbols as dense rows */
 	const int16_t *sis_win;       /*   the blanking window, k.sis_width values from sample k.sis_left */
 	const int16_t *sis_first;     /*   [HVK_SIS_SPAN] what the last never-emitted invocation leaves on the stream's first line */
-	const unsigned *sis_bits;     /*   [frames][lines][2]: a line's burst -- 7 bytes of bits (MSB first), their number in the eighth */
+	const unsigned *sis_bits;     /*   [frames][lines + 1][2]: a line's burst (the last: the line behind the frame) -- 7 bytes of bits (MSB first), their number in the eighth */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const int16_t *linebase;      /* [rows][k.base_stride]: blanking + sync pulses of every kind of line */
@@ -812,9 +812,10 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 	 * sync area blanked to the sync level through a window, then the burst's half symbols added -- 46 or 50 bits, most
 	 * significant first, bit b shaped by entry 50 - nb + b (vbidata_render() passes over the first 50 - nb). All of it
 	 * lies in the line's first HVK_SIS_SPAN samples: the first wave's business. */
-	if(EXTRAS && k.sis && own && wx0 < HVK_SIS_SPAN)
+	if(EXTRAS && k.sis && (own || rel == k.lines) && wx0 < HVK_SIS_SPAN)
 	{
-		const unsigned *rec = P.sis_bits + ((size_t) y * k.lines + rel) * 2;
+		/* (also on the line behind the frame: the video filter of the frame's last samples looks into its first ones) */
+		const unsigned *rec = P.sis_bits + ((size_t) y * (k.lines + 1) + rel) * 2;
 		const unsigned w0 = __builtin_amdgcn_readfirstlane(rec[0]), w1 = __builtin_amdgcn_readfirstlane(rec[1]);
 		const int nb = (int) (w1 >> 24);
 		if(x0 < HVK_SIS_SPAN)
@@ -882,17 +883,26 @@ __device__ __forceinline__ void nicam_symbol_slot(const int v, const int n0, int
 
 /* NICAM onto a lane's 8 packed (I, Q) outputs: sum the pulses of the symbols in flight (int16
  * wrap-around per channel, both channels in one packed multiply-add), mix, add
- * (src/nicam728.c:350-365, :386-396). mix_a0 / mix_a1: the mixer row (i, -q) of the lane's samples. */
+ * (src/nicam728.c:350-365, :386-396). mix[0..1]: the mixer's first row (i, -q) of the lane's 8 samples,
+ * mix[2..3]: its second row (q, i) -- both tabulated (hvk_engine.cpp). */
 __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, const int *sym_st, const int4v *sym_ent, const int16_t *tapd,
-                                          const int4u mix_a0, const int4u mix_a1, int (&o)[SPL])
+                                          const int4u (&mix)[4], int (&o)[SPL])
 {
 	const int last = x0 + SPL - 1;          /* relative to the tile's first sample */
-	/* newest symbol that has started by this lane's last sample; slot
-	 * HVK_NICAM_BACK - 1 holds the newest one at the tile's first sample */
-	int idx = HVK_NICAM_BACK - 1 + (int) ((float) last * (1.0f / (float) k.nicam_sps));
-	if(idx > HVK_NICAM_SYMS - 2) idx = HVK_NICAM_SYMS - 2;
-	while(idx + 1 < HVK_NICAM_SYMS && sym_st[idx + 1] <= last) idx++;
-	while(idx > 0 && sym_st[idx] > last) idx--;
+	/* The newest symbol that has started by this lane's last sample. Slot HVK_NICAM_BACK - 1 holds the newest one at the
+	 * tile's first sample (start st_b <= 0); the ones behind it follow at sps or sps - 1 samples each (src/nicam728.c:
+	 * 398-407), so j of them have started where j = (last - st_b) / sps at least and, over a tile's length, one more at
+	 * most (1100 * (1 / (sps - 1) - 1 / sps) < 1 for sps >= 34: every rate hvk_open takes): one look at the next slot
+	 * decides. The division is a multiplication by ceil(2^20 / sps), exact below 2^20 / sps. No loop, no lane test. */
+	int idx;
+	{
+		int a = last - sym_st[HVK_NICAM_BACK - 1];
+		a = a > 0 ? a : 0;                      /* (a slot without a symbol: nothing has started) */
+		const int j = (int) (((unsigned) a * (unsigned) k.nicam_inv20) >> 20);
+		int i0 = HVK_NICAM_BACK - 1 + j;
+		i0 = i0 < HVK_NICAM_SYMS - 2 ? i0 : HVK_NICAM_SYMS - 2;
+		idx = i0 + (sym_st[i0 + 1] <= last ? 1 : 0);
+	}
 
 	/* I and Q apart while the pulses are summed: (I[2m], I[2m + 1]) and (Q[2m], Q[2m + 1]) */
 	int bi[SPL / 2], bq[SPL / 2];
@@ -924,14 +934,10 @@ __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, c
 		bb[2 * m + 1] = (int) __builtin_amdgcn_perm((unsigned) bq[m], (unsigned) bi[m], 0x07060302u);
 	}
 
-	/* mixer: the rotation's first row (i, -q) is tabulated (loaded before the filter) */
 	if(!ABLATE(64))
 	{
-		const int ca[SPL] = { mix_a0.x, mix_a0.y, mix_a0.z, mix_a0.w, mix_a1.x, mix_a1.y, mix_a1.z, mix_a1.w };
-		/* the second row (q, i) from the first (i, -q): halves swapped, the low one negated (|q| <= 32767) */
-		int cq[SPL];
-#pragma unroll
-		for(int i = 0; i < SPL; i++) cq[i] = pk_mad16(shift_pair(ca[i], ca[i]), (int) 0x0001FFFFu, 0);
+		const int ca[SPL] = { mix[0].x, mix[0].y, mix[0].z, mix[0].w, mix[1].x, mix[1].y, mix[1].z, mix[1].w };
+		const int cq[SPL] = { mix[2].x, mix[2].y, mix[2].z, mix[2].w, mix[3].x, mix[3].y, mix[3].z, mix[3].w };
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
@@ -942,6 +948,14 @@ __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, c
 			o[i] = pk_add16(o[i], pk);
 		}
 	}
+}
+
+/* the mixer rows of a lane's 8 samples from table position cp: row (i, -q) at nicam_cca[cp ..], row (q, i) at
+ * nicam_cca[rows + cp ..] (`rows` = cc_len + 8 entries each) */
+__device__ __forceinline__ void nicam_mix_rows(const int *nicam_cca, const int rows, const int cp, int4u (&mix)[4])
+{
+	mix[0] = ((const int4u *) (nicam_cca + cp))[0]; mix[1] = ((const int4u *) (nicam_cca + cp))[1];
+	mix[2] = ((const int4u *) (nicam_cca + rows + cp))[0]; mix[3] = ((const int4u *) (nicam_cca + rows + cp))[1];
 }
 
 /* A lane's 8 window samples (four dwords of int16 pairs) as 8 bytes of the high-byte plane and 8 of the

@@ -118,31 +118,50 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_r
 /* A line of the window: where window position w finds its L / C entry and its phasor -- at index lb + w, cb + w */
 typedef struct { int lb, cb; } dline_t;
 
+/* What a tile reads of the tables for one of its lines, all of it issued before any of it is used (the frame's number
+ * and parity come by arithmetic, so nothing here waits for another load): the line's V switch and its share of the
+ * colour table position. The values are the same for the whole wave: through v_readfirstlane into scalar registers,
+ * where the rest is scalar arithmetic. */
+typedef struct { int line0, par, prev, zero; int pal; unsigned off; } dline_in_t;
+
 template<int COLOUR>
-__device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const hvk_framedesc_t &fp, const hvk_framedesc_t &fo,
-                                               const int rel, const int wstart)
+__device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, const hvk_dptrs_t &D, const int par_own, const bool first, const int rel)
 {
 	/* (raster_line_index(): the line before the frame is the last line of the frame before, of the other
 	 * parity; the lines behind it the first ones of the next frame -- no picture there in any mode, so the
 	 * frame's own planes have them) */
-	int line0 = rel, par = fo.parity, row0 = fo.plane_row0;
-	if(rel < 0) { line0 = k.lines - 1; par ^= 1; row0 = fp.plane_row0; }
-	else if(rel >= k.lines) { line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; par ^= 1; }
+	dline_in_t q;
+	q.line0 = rel; q.par = par_own; q.prev = 0;
+	if(rel < 0) { q.line0 = k.lines - 1; q.par ^= 1; q.prev = 1; }
+	else if(rel >= k.lines) { q.line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; q.par ^= 1; }
 	/* before the stream: the filter history is zero, not blanking (src/video.c:4665-4667 with src/fir.c:289, :579) */
-	const bool zero = rel < 0 && fo.frame_index == 0;
-
-	dline_t l;
-	l.lb = (zero ? D.zero_row : row0 + line0) * k.width - wstart;
-	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
-	if(COLOUR && !zero)
+	q.zero = rel < 0 && first;
+	q.pal = 0;
+	q.off = 0;
+	if(COLOUR)
 	{
-		/* hvk_linedesc_t.pal, as the low half of the descriptor's fourth dword: a scalar load (an int16 member would be
-		 * fetched by the vector unit, and waited for three times per tile) */
+		/* hvk_linedesc_t.pal, as the low half of the descriptor's fourth dword */
 		static_assert(offsetof(hvk_linedesc_t, pal) == 12 && sizeof(hvk_linedesc_t) == 16, "hvk_linedesc_t layout");
-		const int pal = (int) (short) (((const int *) D.desc)[(par * k.lines + line0) * 4 + 3] & 0xFFFF);
+		q.pal = ((const int *) D.desc)[(q.par * k.lines + q.line0) * 4 + 3];
 		/* the sub-carrier table position advances by one line per line, colour or not (raster_setup_core():
 		 * (clut_off0 + rel * width) mod clw); the line's share is tabulated, so no division here */
-		unsigned coff = fo.clut_off0 + D.lineoff[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+		q.off = D.lineoff[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+	}
+	return(q);
+}
+
+template<int COLOUR>
+__device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const dline_in_t &q, const int row0_prev, const int row0_own,
+                                               const unsigned clut_off0, const int wstart)
+{
+	dline_t l;
+	const int row0 = q.prev ? row0_prev : row0_own;
+	l.lb = (q.zero ? D.zero_row : row0 + q.line0) * k.width - wstart;
+	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
+	if(COLOUR && !q.zero)
+	{
+		const int pal = (int) (short) (__builtin_amdgcn_readfirstlane(q.pal) & 0xFFFF);
+		unsigned coff = clut_off0 + (unsigned) __builtin_amdgcn_readfirstlane((int) q.off);
 		if(coff >= k.clw) coff -= k.clw;
 		if(pal > 0) l.cb = (int) coff - wstart;
 		else if(pal < 0) l.cb = D.creg + (int) coff - wstart;       /* PAL V switch: the table with i negated */
@@ -208,7 +227,12 @@ __device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_
 template<int VF, int COLOUR, int EXACT>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL * DG, 8)
 void hvk_k_direct(const hvk_kconst_t k,
-                  const hvk_dptrs_t D,
+                  /* (hvk_dptrs_t member by member: as __restrict__ kernel arguments the descriptor tables are known not to alias
+                   * the output, and what this tile reads of them -- uniform addresses -- comes by scalar loads) */
+                  const int16_t *__restrict__ d_Lp, const int *__restrict__ d_Cp, const int *__restrict__ d_clut3,
+                  const int d_creg, const int d_zero_row,
+                  const hvk_linedesc_t *__restrict__ d_desc, const hvk_framedesc_t *__restrict__ d_fdesc,
+                  const uint32_t *__restrict__ d_lineoff, const uint32_t d_inv_w,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW] */
                   const int *__restrict__ nicam_tapd,
@@ -217,7 +241,9 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const int mfma_ci, const int mfma_cq,
                   int *__restrict__ iq,                  /* [frames * out_stride][frame_samples] int16 pairs */
                   const int64_t out_stride,
-                  const int tiles)
+                  const int tiles,
+                  const int64_t first_frame,             /* frame y of the batch is stream frame first_frame + y * frame_stride */
+                  const int64_t frame_stride)
 {
 	constexpr int LEAD = VF ? DLEAD : 0;
 	constexpr int NP = DG * HVK_TILE + 64;      /* window positions of the workgroup: its tiles follow each other in the stream */
@@ -232,6 +258,10 @@ void hvk_k_direct(const hvk_kconst_t k,
 	 * lines of EVERY frame then run on the same XCD, whose L2 keeps their plane rows (a picture that stays) and
 	 * their slices of the colour table (the same again every few frames) */
 	if((int) blockIdx.x * DG >= tiles) return;
+
+	hvk_dptrs_t D;
+	D.Lp = d_Lp; D.Cp = d_Cp; D.clut3 = d_clut3; D.creg = d_creg; D.zero_row = d_zero_row;
+	D.desc = d_desc; D.fdesc = d_fdesc; D.lineoff = d_lineoff; D.inv_w = d_inv_w;
 
 	const int FS = k.frame_samples, W = k.width;
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
@@ -263,14 +293,23 @@ void hvk_k_direct(const hvk_kconst_t k,
 	}
 
 	/* ---- the lines this tile's window lies in (all scalar) ---- */
-	const hvk_framedesc_t fp = D.fdesc[2 * y], fo = D.fdesc[2 * y + 1];
+	const int64_t frame_index = first_frame + (int64_t) y * frame_stride;
+	const int par_own = (int) ((frame_index + 1) & 1);
+	const bool first = frame_index == 0;
 	const int p0 = n0 - LEAD;                                   /* stream position (frame local) of window position 0 */
 	const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
 	const int xA0 = p0 - lineA * W;
 	const int b1 = W - xA0, b2 = b1 + W;                        /* window positions at which the next two lines begin */
-	const dline_t lA = direct_line<COLOUR>(k, D, fp, fo, lineA, -xA0);
-	const dline_t lB = direct_line<COLOUR>(k, D, fp, fo, lineA + 1, b1);
-	const dline_t lC = direct_line<COLOUR>(k, D, fp, fo, lineA + 2, b2);
+	const dline_in_t qA = direct_line_loads<COLOUR>(k, D, par_own, first, lineA);
+	const dline_in_t qB = direct_line_loads<COLOUR>(k, D, par_own, first, lineA + 1);
+	const dline_in_t qC = direct_line_loads<COLOUR>(k, D, par_own, first, lineA + 2);
+	/* (the frame before: the row its LAST line's planes start at less lines - 1; the frame: the row of its line 0) */
+	const int row0_prev = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y].plane_row0);
+	const int row0_own = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].plane_row0);
+	const unsigned clut_off0 = (unsigned) __builtin_amdgcn_readfirstlane((int) D.fdesc[2 * y + 1].clut_off0);
+	const dline_t lA = direct_line<COLOUR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0);
+	const dline_t lB = direct_line<COLOUR>(k, D, qB, row0_prev, row0_own, clut_off0, b1);
+	const dline_t lC = direct_line<COLOUR>(k, D, qC, row0_prev, row0_own, clut_off0, b2);
 
 	/* ---- loads ---- */
 	int symv = 0, cc_tile = 0;
@@ -325,13 +364,13 @@ void hvk_k_direct(const hvk_kconst_t k,
 	__syncthreads();
 
 	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
-	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 };
+	int4u mix[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 	if(k.has_nicam)
 	{
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
 		else cp %= k.nicam_cc_len;
-		mix_a0 = ((const int4u *) (nicam_cca + cp))[0]; mix_a1 = ((const int4u *) (nicam_cca + cp))[1];
+		nicam_mix_rows(nicam_cca, k.nicam_cc_len + 8, cp, mix);
 	}
 
 	if(VF)
@@ -360,7 +399,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 		}
 	}
 
-	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix_a0, mix_a1, o);
+	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + (size_t) y * out_stride * FS + n;
@@ -429,8 +468,9 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	const dim3 grid(((tiles + DG - 1) / DG + 7) & ~7, a->nframes), block(HVK_TILE / SPL * DG);
-#define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, a->D, (const int *) a->carriers, a->tilesyms, \
-	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles)
+#define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, \
+	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, (const int *) a->carriers, a->tilesyms, \
+	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);
 #undef DIRECT
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);

@@ -450,9 +450,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		 * zeros and zero padded (no bounds test is needed), in four copies of which
 		 * copy s starts s entries later, so that any eight consecutive entries start
 		 * 8-byte aligned in one of them; the mixer as the first row of the rotation
-		 * matrix, (i, -q), extended by 8 entries past the wrap (the kernel derives the second) */
+		 * matrix, (i, -q), extended by 8 entries past the wrap, and its second row, (q, i), likewise */
 		std::vector<int16_t> tapd(4 * HVK_NICAM_TAPD, 0);
-		std::vector<int> cca(k.nicam_cc_len + 8);
+		std::vector<int> cca(2 * (size_t) (k.nicam_cc_len + 8));
 		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
 		for(int i = 0; i < k.nicam_ntaps; i++)
 		{
@@ -464,6 +464,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		{
 			const hvk_c16_t c = e->t.nicam_cc[i % k.nicam_cc_len];
 			cca[i] = ((int) c.i & 0xFFFF) | ((-(int) c.q) << 16);
+			cca[(size_t) (k.nicam_cc_len + 8) + i] = ((int) c.q & 0xFFFF) | ((int) c.i << 16);    /* the rotation's second row (|q| <= 32767) */
 		}
 		OPENCHK(_upload(&e->d_tapd, tapd.data(), tapd.size() * sizeof(int16_t)));
 		OPENCHK(_upload(&e->d_cca, cca.data(), cca.size() * 4));
@@ -552,8 +553,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_sis_dense, e->t.sis_dense, sizeof(int16_t) * 50 * HVK_SIS_SPAN));
 		OPENCHK(_upload(&e->d_sis_win, e->t.sis_win, sizeof(int16_t) * k.sis_width));
 		OPENCHK(_upload(&e->d_sis_first, e->t.sis_first, sizeof(int16_t) * HVK_SIS_SPAN));
-		OPENHIP(hipMalloc((void **) &e->d_sis_bits, (size_t) max_frames * k.lines * 8));
-		OPENHIP(hipHostMalloc((void **) &e->h_sis_bits, (size_t) max_frames * k.lines * 8, hipHostMallocDefault));
+		OPENHIP(hipMalloc((void **) &e->d_sis_bits, (size_t) max_frames * (k.lines + 1) * 8));
+		OPENHIP(hipHostMalloc((void **) &e->h_sis_bits, (size_t) max_frames * (k.lines + 1) * 8, hipHostMallocDefault));
 	}
 
 	if(k.rawbb)
@@ -591,7 +592,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.tpad = (max_frames * a.ntasks + 63) & ~63;
 			a.K = HVK_SECAM_WARMUP;
 			e->secam_adapt = getenv("HVK_SECAM_WARMUP") == NULL;
-			e->secam_patience = 4;
+			e->secam_patience = 1;
 			if(getenv("HVK_SECAM_WARMUP")) a.K = atoi(getenv("HVK_SECAM_WARMUP"));
 			if(a.K < 0) a.K = 0;
 			a.raster_samples = (int64_t) RS;
@@ -1603,7 +1604,8 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			if(k.sis)
 			{
 				/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
-				int r = hvk_audio_sis_fetch(e->audio, f->frame_index * k.lines, k.lines, (uint8_t *) (e->h_sis_bits + (size_t) i * k.lines * 2));
+				/* (and the first line's of the frame behind it: the filter of this frame's last samples looks into it) */
+				int r = hvk_audio_sis_fetch(e->audio, f->frame_index * k.lines, k.lines + 1, (uint8_t *) (e->h_sis_bits + (size_t) i * (k.lines + 1) * 2));
 				if(r != HVK_OK) { e->poisoned = 1; return(r); }
 			}
 
@@ -1743,7 +1745,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
-	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * k.lines * 8, hipMemcpyHostToDevice, e->stream));
+	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + 1) * 8, hipMemcpyHostToDevice, e->stream));
 	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
@@ -1881,6 +1883,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.iq = fa.iq;
 		da.nframes = fa.nframes;
 		da.out_stride = out_stride;
+		da.first_frame = e->staged_first;
+		da.frame_stride = e->staged_stride;
 		if((r = hvk_launch_direct(&da, e->stream)) != HVK_OK) return(r);
 	}
 	else

@@ -84,6 +84,7 @@ typedef struct {
 	int32_t has_carriers;
 	int32_t has_nicam;
 	int32_t nicam_ntaps, nicam_sps, nicam_dsl, nicam_decimation, nicam_cc_len;
+	uint32_t nicam_inv20;   /* ceil(2^20 / nicam_sps): a / sps == (a * inv20) >> 20 for a < 2^20 / sps */
 	int32_t frame_samples;  /* OUTPUT samples per frame (sample rate) */
 	int32_t raster_samples; /* width * lines (pixel rate); == frame_samples without the resampler */
 	int32_t slab_lines;     /* raster lines kept per frame: lines + 2, + 1 with the resampler */

@@ -29,7 +29,7 @@ typedef struct {
 	const signed char *vbi_map; /* [nframes][lines] */
 	const int16_t *vits_l, *vits_c;
 	const int16_t *sis_dense, *sis_win, *sis_first;     /* sound-in-syncs tables */
-	const unsigned *sis_bits;   /* [nframes][lines][2] */
+	const unsigned *sis_bits;   /* [nframes][lines + 1][2] */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const int16_t *linebase;    /* [nbase][k.base_stride] */
@@ -57,7 +57,7 @@ typedef struct {
 	const hvk_c16_t *carriers;
 	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
 	const int *nicam_tapd;      /* 4 x HVK_NICAM_TAPD int16: the pulse, four shifted copies, zero padded */
-	const int *nicam_cca;       /* nicam_cc_len + 8 dwords: (cc.i, -cc.q) */
+	const int *nicam_cca;       /* 2 x (nicam_cc_len + 8) dwords: the mixer's rows (cc.i, -cc.q), then (cc.q, cc.i) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
 	int16_t *iq;
@@ -89,6 +89,7 @@ typedef struct {
 	int16_t *iq;
 	int nframes;
 	int64_t out_stride;
+	int64_t first_frame, frame_stride;
 } hvk_direct_args_t;
 
 /* SECAM colour sub-carrier on the device (hvk_secam.hip) */

@@ -324,13 +324,13 @@ void hvk_k_filter(const hvk_kconst_t k,
 	const int n = n0 + x0;                      /* this lane's first output, frame local; lanes past the frame compute and store nothing */
 
 	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
-	int4u mix_a0 = { 0, 0, 0, 0 }, mix_a1 = { 0, 0, 0, 0 };
+	int4u mix[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 	if(k.has_nicam && !ABLATE(64))
 	{
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
 		else cp %= k.nicam_cc_len;
-		mix_a0 = ((const int4u *) (nicam_cca + cp))[0]; mix_a1 = ((const int4u *) (nicam_cca + cp))[1];
+		nicam_mix_rows(nicam_cca, k.nicam_cc_len + 8, cp, mix);
 	}
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
@@ -419,7 +419,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 	}
 
 	/* NICAM: pulse sums of the symbols in flight, mixer, add (hvk_device.h; src/nicam728.c:350-365, :386-396) */
-	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix_a0, mix_a1, o);
+	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + obase;

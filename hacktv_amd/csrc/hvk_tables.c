@@ -501,6 +501,7 @@ static int _build_audio(hvk_tables_t *t, double slevel)
 		g = _gcd_u(sr, 364000);
 		t->k.nicam_decimation = 364000 / g;
 		t->k.nicam_sps = (sr + 364000 - 1) / 364000;
+		t->k.nicam_inv20 = (uint32_t) (((1u << 20) + t->k.nicam_sps - 1) / t->k.nicam_sps);      /* (hvk_device.h:nicam_add()) */
 		t->k.nicam_dsl = (t->k.nicam_sps * t->k.nicam_decimation) % (sr / g);
 
 		g = _gcd_u(sr, freq);

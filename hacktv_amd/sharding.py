@@ -87,15 +87,21 @@ def gather_blocks(local, root_buf, rank, world, root=0, group=None, via_host=Fal
     return works
 
 
+_state_sends = []       # (work, buffer) of the hand-overs on their way: the buffers have to outlive the sends
+
+
 def sound_state_send(engine, world, block, group=None, last=False):
     """After staging block `block`: hand the sound chains' state to the rank that stages block + 1
     (hvk_sound_state_export). `group`: a host-side (gloo) group -- the state travels as a CPU byte tensor.
-    last: nobody stages a block after this one."""
+    last: nobody stages a block after this one. The send does not wait for its receiver: the next rank may be busy
+    receiving THIS rank's rendered block (which this rank has yet to render) before it gets to its next stage."""
     import torch
     if world == 1 or last:
         return
-    st = bytearray(engine.sound_state_export())
-    dist.send(torch.frombuffer(st, dtype=torch.uint8), (block + 1) % world, group)
+    while _state_sends and _state_sends[0][0].is_completed():
+        _state_sends.pop(0)
+    buf = torch.frombuffer(bytearray(engine.sound_state_export()), dtype=torch.uint8)
+    _state_sends.append((dist.isend(buf, (block + 1) % world, group), buf))
 
 
 def sound_state_recv(engine, world, block, group=None):

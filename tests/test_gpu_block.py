@@ -139,7 +139,7 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream(walk):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
            "--dry-run-backend", "gloo", "--no-cpu-baseline"] + (["--walk-rounds"] if walk else [])
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
