@@ -703,26 +703,31 @@ def main():
     # chain on one short block ----
     secam = None
     if N == 1 and not args.no_moving:
-        def secam_run(Fs, ksteps):
+        def secam_run(Fs, ksteps, wsteps=10):
+            # (the warm-up steps also let the number of warm-up LINES per start state settle: it follows the pictures, one
+            # line down per clean block, two up per block with a wrong start -- hvk_engine.cpp)
             es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
             es.frame_upload(0, g.frame("l_full"))
-            for k in range(3):
+            for k in range(wsteps):
                 es.stage(k * Fs, 1, Fs)
                 es.launch()
             es.sync()
+            st0 = es.secam_stats()
             t0 = time.perf_counter()
             for k in range(ksteps):
-                es.stage((3 + k) * Fs, 1, Fs)
+                es.stage((wsteps + k) * Fs, 1, Fs)
                 es.launch()
             es.sync()
             t_dev = (time.perf_counter() - t0) / ksteps
             st = es.secam_stats()
+            st = {kk: st[kk] - st0[kk] for kk in st}        # the timed steps' lines
+            st["warmup_lines_per_start_state"] = es.secam_warmup_lines()
             names_s = es.kernel_names()
             es.close()
             return t_dev, st, names_s
 
         t_dev, st, names_s = secam_run(F, 5)
-        t_big, st_big, _ = secam_run(4 * F, 3)
+        t_big, st_big, _ = secam_run(4 * F, 5)
         os.environ["HVK_SECAM_HOST"] = "1"
         eh = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=8)
         eh.frame_upload(0, g.frame("l_full"))
@@ -743,8 +748,8 @@ def main():
                                                  "of its dependent steps -- takes nearly as long: about one wave per SIMD instead of four"},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
-            "note": "lines: worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; the number of "
-                    "warm-up lines per start state follows the pictures (exactness rests on the check, not on it)",
+            "note": "lines (of the timed steps): worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; "
+                    "the number of warm-up lines per start state follows the pictures (exactness rests on the check, not on it) and has settled over 10 untimed blocks",
         }
 
     configs = None
@@ -766,7 +771,7 @@ def main():
 
     if rank == 0:
         names = e.kernel_names()
-        fused = len(names) == 1
+        one_kernel = len(names) == 1                        # hvk_k_direct (picture planes): the whole render in one kernel
         samples = F * FS                                    # per launch (one launch per kernel per step)
         alg = BYTES_PER_SAMPLE * samples
         tj = {}
@@ -788,13 +793,13 @@ def main():
 
         # the whole step against the same roofline: what the PATH achieves (kernels back to back, launch gaps, the gather)
         path_ach = BYTES_PER_SAMPLE * samples_per_step / (ms_per_step * 1e-3) / 1e9 / N
-        if fused:
+        if one_kernel:
             roof = hbm_roofline(names[0], filter_ms, n_f, "hvk_k_direct_bytes_per_launch")
-            kernels = {"fused": True, names[0]: round(filter_ms, 4)}
+            kernels = {"one_kernel": True, names[0]: round(filter_ms, 4)}
             other = None
         else:
             roof = hbm_roofline(names[-1], filter_ms, n_f, "hvk_k_filter_bytes_per_launch")
-            kernels = {"fused": False, names[0]: round(raster_ms, 4), names[-1]: round(filter_ms, 4),
+            kernels = {"one_kernel": False, names[0]: round(raster_ms, 4), names[-1]: round(filter_ms, 4),
                        "note": "average per launch; the kernels of a step run back to back on one stream"}
             # the raster kernel writes 2 B per sample and is bound by vector-ALU issue, not by HBM: no HBM fraction for it
             other = {"bound": "valu", "kernel": names[0], "avg_launch_ms": round(raster_ms, 4), "launches_timed": int(n_r),

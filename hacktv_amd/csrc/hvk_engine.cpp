@@ -1071,6 +1071,13 @@ extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
 	return(HVK_OK);
 }
 
+extern "C" int hvk_secam_warmup_lines(hvk_engine_t *e)
+{
+	if(!e) return(HVK_ERROR);
+	if(!e->secam || !e->secam_dev) return(HVK_UNSUPPORTED);
+	return(e->sa.K);
+}
+
 /* ---- render ---- */
 
 /* The VBI data lines of the staged frames (h_fdesc holds their stream frame numbers): per

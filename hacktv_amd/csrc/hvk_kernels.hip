@@ -266,8 +266,8 @@ void hvk_k_filter(const hvk_kconst_t k,
 	if(k.has_carriers && (EXACT || nl + SPL <= FS))
 	{
 		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
-		car0 = c[0];
-		car1 = c[1];
+		car0 = __builtin_nontemporal_load(&c[0]);      /* streaming, like the stores below (hvk_direct.hip has the measurement) */
+		car1 = __builtin_nontemporal_load(&c[1]);
 	}
 
 	if(it == 0 && tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
@@ -425,8 +425,8 @@ void hvk_k_filter(const hvk_kconst_t k,
 	int *dst = iq + obase;
 	if(whole)
 	{
-		((int4u *) dst)[0] = (int4u) { o[0], o[1], o[2], o[3] };
-		((int4u *) dst)[1] = (int4u) { o[4], o[5], o[6], o[7] };
+		__builtin_nontemporal_store(((int4u) { o[0], o[1], o[2], o[3] }), &((int4u *) dst)[0]);
+		__builtin_nontemporal_store(((int4u) { o[4], o[5], o[6], o[7] }), &((int4u *) dst)[1]);
 	}
 	else
 	{

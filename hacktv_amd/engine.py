@@ -22,7 +22,7 @@ SYMBOLS = [
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
     "hvk_launch_strided_out", "hvk_set_stream", "hvk_set_levels", "hvk_planes_refresh",
     "hvk_host_sis_bursts", "hvk_sound_state_size", "hvk_sound_state_export", "hvk_sound_state_import", "hvk_sound_samples_generated",
-    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
+    "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_secam_warmup_lines", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
 ]
 
@@ -82,6 +82,7 @@ def lib():
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_secam_stats.argtypes = [vp, vp]
+        L.hvk_secam_warmup_lines.argtypes = [vp]
         L.hvk_vbi_lines_held.argtypes = [vp, vp, i32]
         L.hvk_sync.argtypes = [vp]
         L.hvk_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -261,6 +262,9 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
         return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
+
+    def secam_warmup_lines(self):
+        return self._chk("hvk_secam_warmup_lines", lib().hvk_secam_warmup_lines(self.h))
 
     def render(self, nframes, slots=None, d_iq=None):
         s = np.ascontiguousarray(slots if slots is not None else np.zeros(nframes * 2), np.int32)

@@ -302,6 +302,11 @@ int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int he
  * because of them, [3] frames that went through the host's serial chain instead. */
 int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4]);
 
+/* SECAM: the number of lines a lane walks in front of a line to derive its entry state, as it stands. It follows the
+ * pictures (one less after a block without a wrong start, two more after one with; HVK_SECAM_WARMUP=n in the
+ * environment pins it) and decides only how much is redone, never what comes out. < 0: an HVK_* code. */
+int hvk_secam_warmup_lines(hvk_engine_t *e);
+
 /* --offset, host half on its own: the values the offset process multiplies
  * output samples [first, first + count) by (src/video.c:3482-3515): count int16
  * pairs, the free-running Q31 phasor >> 16, advanced over the pipeline's

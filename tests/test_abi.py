@@ -5,6 +5,7 @@ import os
 import re
 
 import hacktv_amd as H
+import util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -109,14 +110,12 @@ def test_rate_pairs_the_resampler_refuses():
             assert err.code == H.HVK_UNSUPPORTED
         else:
             raise AssertionError("accepted %d / %d" % (sr, pr))
-    c = H.preset("i", 0)
-    c.passthru = 1
-    try:
-        H.Engine(c, 16000000, device=-1, pixel_rate=13500000)
-    except H.HvkError as err:
-        assert err.code == H.HVK_UNSUPPORTED
-    else:
-        raise AssertionError("--pixelrate with --passthru accepted")
+    # together with --passthru, --s-video and --raw-bb-file the resampler is taken since round 3
+    g = util.Golden()
+    for case in ("i_pass_px135", "pal_sv_px135", "pal_rawbb_px135"):
+        conf, sr = g.conf(case)
+        assert conf.passthru or conf.s_video or conf.raw_bb
+        H.Engine(conf, sr, device=-1, pixel_rate=g.cases[case]["pixel_rate"]).close()
     with H.Engine(H.preset("i", 0), 16000000, device=-1, pixel_rate=16000000) as e:   # same rate: no resampler
         assert e.info["max_width"] == 1024 and e.info["startup_samples"] == 0
 
