@@ -703,19 +703,25 @@ def main():
     # chain on one short block ----
     secam = None
     if N == 1 and not args.no_moving:
-        def secam_run(Fs, ksteps, wsteps=10):
+        def secam_run(Fs, ksteps, wsteps=10, pics=None):
             # (the warm-up steps also let the number of warm-up LINES per start state settle: it follows the pictures, one
             # line down per clean block, two up per block with a wrong start -- hvk_engine.cpp)
             es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
-            es.frame_upload(0, g.frame("l_full"))
+            slots = None
+            if pics is None:
+                es.frame_upload(0, g.frame("l_full"))
+            else:
+                for i_, p_ in enumerate(pics):
+                    es.frame_upload(i_, p_)
+                slots = [i_ % len(pics) for i_ in range(Fs)]
             for k in range(wsteps):
-                es.stage(k * Fs, 1, Fs)
+                es.stage(k * Fs, 1, Fs, slots=slots)
                 es.launch()
             es.sync()
             st0 = es.secam_stats()
             t0 = time.perf_counter()
             for k in range(ksteps):
-                es.stage((wsteps + k) * Fs, 1, Fs)
+                es.stage((wsteps + k) * Fs, 1, Fs, slots=slots)
                 es.launch()
             es.sync()
             t_dev = (time.perf_counter() - t0) / ksteps
@@ -728,6 +734,17 @@ def main():
 
         t_dev, st, names_s = secam_run(F, 5)
         t_big, st_big, _ = secam_run(4 * F, 5)
+        # pictures that change: the cells (levels, vertical average, low pass) are every frame's own work again, and
+        # noisy pictures make the walk's table reads scatter
+        rngs = np.random.default_rng(3)
+        yy_, xx_ = np.mgrid[0:576, 0:832]
+        noisy = []
+        for i_ in range(4):
+            p_ = (((xx_ * 255 // 831 + i_ * 17) % 256).astype(np.uint32) << 16) | (((yy_ * 255 // 575) % 256).astype(np.uint32) << 8) | (((xx_ + yy_) // 3 % 256).astype(np.uint32))
+            noisy.append(np.where(rngs.random(p_.shape) < 0.2, rngs.integers(0, 1 << 24, p_.shape, dtype=np.uint32), p_).astype(np.uint32))
+        os.environ["HVK_SECAM_NO_CELL_CACHE"] = "1"
+        t_mov, st_mov, _ = secam_run(4 * F, 3, wsteps=4, pics=noisy)
+        del os.environ["HVK_SECAM_NO_CELL_CACHE"]
         os.environ["HVK_SECAM_HOST"] = "1"
         eh = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=8)
         eh.frame_upload(0, g.frame("l_full"))
@@ -739,13 +756,19 @@ def main():
         eh.close()
         del os.environ["HVK_SECAM_HOST"]
         secam = {
-            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain) and renders a fresh block" % (4 * F),
+            "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain: every line of every frame walked and checked) "
+                        "and renders a fresh block; the test card's low-passed colour cells are made once per frame parity and kept, like the headline's picture planes" % (4 * F),
             "Msamples_per_s": round(4 * F * FS / t_big / 1e6, 1),
             "ms_per_step": round(t_big * 1e3, 3),
             "lines": st_big,
             "blocks_of_%d_frames" % F: {"Msamples_per_s": round(F * FS / t_dev / 1e6, 1), "ms_per_step": round(t_dev * 1e3, 3), "lines": st,
                                          "note": "the block size of the PAL-I headline: a quarter of the lines, and the chain -- one lane per line, bound by the latency "
                                                  "of its dependent steps -- takes nearly as long: about one wave per SIMD instead of four"},
+            "pictures_change_every_frame": {"Msamples_per_s": round(4 * F * FS / t_mov / 1e6, 1), "ms_per_step": round(t_mov * 1e3, 3), "lines": st_mov,
+                                            "note": "noisy pictures (gradients, a fifth of the pixels random colours), resident in HBM, the cells made for EVERY frame "
+                                                    "(HVK_SECAM_NO_CELL_CACHE=1): what a moving source costs on the device. With the test card a picture's cells are "
+                                                    "made once per frame parity and kept (per-picture work, like the picture planes of the PAL-I headline); the walk "
+                                                    "from line to line, the check and the render are every frame's in both"},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
             "note": "lines (of the timed steps): worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; "

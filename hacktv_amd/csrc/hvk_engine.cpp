@@ -47,6 +47,7 @@ struct hvk_slot_t {
 	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
 	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
 	int plane_dirty;            /* the picture planes (hvk_direct.hip) have not been made from this picture yet */
+	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
 };
 
 struct hvk_engine {
@@ -59,7 +60,9 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[10];          /* what sa points into (freed at close) */
+	void *d_secam[11];          /* what sa points into (freed at close) */
+	int *h_secam_rows;          /* [2][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made */
+	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */
 	int *h_secam_count;         /* pinned: failures of the last check */
 	int secam_lanes;            /* lanes of four waves per SIMD */
 	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
@@ -590,6 +593,10 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.burst_left = k.burst_left; a.burst_width = k.burst_width;
 			a.ntasks = 2 + (n0 > n1 ? n0 : n1);
 			a.tpad = (max_frames * a.ntasks + 63) & ~63;
+			/* the cell stores: a set of rows per picture slot and frame parity where a frame shows one picture, else
+			 * (--interlace: two pictures) a set per frame of the batch */
+			e->secam_cell_cache = k.fields == 1 && !getenv("HVK_SECAM_NO_CELL_CACHE");
+			a.cpad = e->secam_cell_cache ? ((e->frame_slots * 2 > max_frames ? e->frame_slots * 2 : max_frames) * a.ntasks + 63) & ~63 : a.tpad;
 			a.K = HVK_SECAM_WARMUP;
 			e->secam_adapt = getenv("HVK_SECAM_WARMUP") == NULL;
 			e->secam_patience = 1;
@@ -613,14 +620,16 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			OPENCHK(_upload(&e->d_secam[1], fid.data(), fid.size() * 2));
 			OPENCHK(_upload(&e->d_secam[2], e->t.secam_lut, 65536 * sizeof(hvk_c32_t)));
 			OPENCHK(_upload(&e->d_secam[3], e->t.secam_bell, 65536 * sizeof(hvk_c16_t)));
-			OPENHIP(hipMalloc(&e->d_secam[4], (size_t) a.tpad * k.width * 2));
-			OPENHIP(hipMalloc(&e->d_secam[5], (size_t) a.tpad * 32));
+			OPENHIP(hipMalloc(&e->d_secam[4], (size_t) a.cpad * k.width * 2));
+			OPENHIP(hipMalloc(&e->d_secam[5], (size_t) a.cpad * 32));
 			OPENHIP(hipMalloc(&e->d_secam[6], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
 			OPENHIP(hipMalloc(&e->d_secam[7], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
 			OPENHIP(hipMalloc(&e->d_secam[8], sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipMalloc(&e->d_secam[9], (size_t) a.tpad * 4 + 64));
-			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.tpad * k.width * 2));
-			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.tpad * 32));
+			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 2 * sizeof(int)));
+			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
+			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
+			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 2 * sizeof(int), hipHostMallocDefault));
 			OPENHIP(hipMemset(e->d_secam[8], 0, sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_count, 64, hipHostMallocDefault));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_carry, sizeof(hvk_secam_state_t), hipHostMallocDefault));
@@ -636,6 +645,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.carry = (hvk_secam_state_t *) e->d_secam[8];
 			a.flags = (int *) e->d_secam[9];
 			a.count = a.flags + a.tpad;
+			a.cbase = (const int *) e->d_secam[10];
+			a.clist = a.cbase + max_frames;
 			a.desc = (const hvk_linedesc_t *) e->d_desc;
 			a.pool = e->d_pool;
 			a.yuv = e->d_yuv;
@@ -693,7 +704,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		if(e->ev_pdesc) (void) hipEventDestroy(e->ev_pdesc);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits, e->h_secam_rows };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -754,7 +765,7 @@ extern "C" int hvk_set_chroma_ghost(hvk_engine_t *e, const int16_t *ghost, int n
 	memset(e->t.ghost, 0, sizeof(e->t.ghost));
 	if(ghost) memcpy(e->t.ghost, ghost, n * sizeof(int16_t));
 	else hvk_tables_default_ghost(&e->t);
-	for(int i = 0; i < e->frame_slots; i++) e->slots[i].plane_dirty = 1;     /* the chroma low pass reads them */
+	for(int i = 0; i < e->frame_slots; i++) e->slots[i].plane_dirty = 1;     /* the chroma low pass reads them (SECAM's cells do not) */
 	if(e->device >= 0 && e->d_ghost)
 	{
 		HIPCHK(hipSetDevice(e->device));
@@ -841,6 +852,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->height = fb ? h : 0;
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
+	s->cells_valid[0] = s->cells_valid[1] = 0;
 	if(fb == NULL)
 	{
 		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
@@ -907,6 +919,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->height = h;
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
+	s->cells_valid[0] = s->cells_valid[1] = 0;
 	if(!s->valid) return(HVK_OK);
 
 	const uint32_t *src = fb + (size_t) y * width + x;
@@ -923,7 +936,11 @@ extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
 {
 	if(!e || mode < HVK_LEVELS_AUTO || mode > HVK_LEVELS_COMPUTE) return(HVK_ERROR);
 	e->levels_mode = mode;
-	for(int i = 0; i < e->frame_slots; i++) e->slots[i].plane_dirty = 1;     /* (identical either way; made again all the same, so that a test of the mode tests it) */
+	for(int i = 0; i < e->frame_slots; i++)     /* (identical either way; made again all the same, so that a test of the mode tests it) */
+	{
+		e->slots[i].plane_dirty = 1;
+		e->slots[i].cells_valid[0] = e->slots[i].cells_valid[1] = 0;
+	}
 	return(HVK_OK);
 }
 
@@ -1329,6 +1346,34 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	a.nruns = (a.total + a.R - 1) / a.R;
 	e->secam_start = *e->h_secam_carry;
 
+	/* Which rows of the cell stores the frames read, and which of them are made now: a picture's cells depend on the
+	 * picture and on the parity of the frame's number only (which of the two colour-difference signals a line carries,
+	 * which picture rows a field shows), so a picture that stays has them made once per parity -- the per-picture
+	 * share of SECAM's work, as the picture planes are PAL's and NTSC's. (The list's last copy is through: every stage
+	 * ends with the check's count read back.) */
+	{
+		int *rows = e->h_secam_rows, *list = rows + e->max_frames;
+		a.ncells = 0;
+		for(int i = 0; i < nframes; i++)
+		{
+			if(!e->secam_cell_cache)
+			{
+				rows[i] = i * a.ntasks;
+				list[a.ncells++] = i;
+				continue;
+			}
+			const int slot = e->staged_slots[i];
+			const int parity = (int) ((first_frame + i + 1) & 1);
+			rows[i] = (slot * 2 + parity) * a.ntasks;
+			if(!e->slots[slot].cells_valid[parity] || first_frame + i == 0)      /* (the stream's first frame has the two fill slots) */
+			{
+				list[a.ncells++] = i;
+				e->slots[slot].cells_valid[parity] = 1;
+			}
+		}
+		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+	}
+
 	HIPCHK(hipMemsetAsync(e->d_chroma, 0, (size_t) nframes * k.raster_samples * 2, e->stream));
 	if((r = hvk_launch_secam_cells_chain(&a, e->stream)) != HVK_OK) return(r);
 	e->secam_counts[0] += a.total;
@@ -1447,8 +1492,9 @@ extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 {
 	if(!e || !slots || n < 0) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
 	for(int i = 0; i < n; i++) if(slots[i] < 0 || slots[i] >= e->frame_slots) return(HVK_ERROR);
+	if(e->secam_dev) for(int i = 0; i < n; i++) e->slots[slots[i]].cells_valid[0] = e->slots[slots[i]].cells_valid[1] = 0;
+	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
 	HIPCHK(hipSetDevice(e->device));
 	for(int i = 0; i < n; i++) e->slots[slots[i]].plane_dirty = 1;
 	return(_prep_dirty(e, slots, n));

@@ -100,7 +100,9 @@ typedef struct {
 	int lines, hline, fields, interlaced, active_left, active_width, active_lines, burst_left, burst_width;
 	int ntasks;                 /* task slots per frame: the two fill slots, then the longer of the two parities' lists */
 	int nframes, total;         /* frames of the batch, nframes * ntasks */
-	int tpad;                   /* tasks the transposed stores are laid out for (>= total) */
+	int tpad;                   /* tasks the state / flag stores are laid out for (>= total) */
+	int cpad;                   /* task rows the cell stores F and acc are laid out for */
+	int ncells;                 /* frames of the batch whose cells are made in this stage (clist) */
 	int K;
 	int R, nruns;               /* tasks per lane of the chain kernel, ceil(total / R) */
 	int levels_computed;        /* this batch's pictures have many colours: compute the levels, do not look them up */
@@ -116,8 +118,13 @@ typedef struct {
 	const hvk_secam_c32_t *lut;
 	const hvk_secam_c16_t *bell;
 	const int16_t *burst_win;
-	int16_t *F;                 /* [W / 8][tpad][8] */
-	int32_t *acc;               /* [tpad][8] */
+	int16_t *F;                 /* [W / 8][cpad][8] */
+	int32_t *acc;               /* [cpad][8] */
+	/* The low-passed cells of a frame depend on its picture and on the parity of its number, not on where in the stream
+	 * it stands: a picture that stays keeps its two sets of rows (the per-picture share of the work, like the picture
+	 * planes of hvk_direct.hip); the walk from line to line is every frame's own. */
+	const int *cbase;           /* [nframes] the row of F / acc at which the frame's tasks begin */
+	const int *clist;           /* [ncells] the frames whose rows are made now */
 	hvk_secam_state_t *entry, *exit;    /* [tpad] */
 	hvk_secam_state_t *carry;   /* the state the batch starts from; after hvk_launch_secam_carry(): the next batch's */
 	int *flags;                 /* [tpad] */

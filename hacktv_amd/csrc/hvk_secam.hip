@@ -9,7 +9,10 @@
  *   hvk_k_secam_cells   one workgroup per task, 8 samples per lane: the line's colour-difference cells (its own
  *                       pixels and the line above's through the level table) and the 15-tap low pass, without the
  *                       share of what lies behind the line; written transposed, 8 samples of one task per 16 bytes,
- *                       tasks side by side, so that a wave of the next kernel reads its 64 lines with one load
+ *                       tasks side by side, so that a wave of the next kernel reads its 64 lines with one load.
+ *                       This much depends on the picture and the parity of the frame's number only: where a frame
+ *                       shows one picture the rows are kept per picture slot and parity (hvk_secam_args_t.cbase) and
+ *                       made again only when the slot gets a new picture (.clist)
  *   hvk_k_secam_chain   one LANE per task: the serial walk over the line (IIR, FM phasor) -- after K warm-up lines,
  *                       the K tasks before it walked from a state of nothing, which leaves the lane with the state
  *                       its own line starts from in all but a few cases per ten thousand (the influence of a
@@ -100,8 +103,9 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 24 zeros */
 	const int W = a.C.W;
-	const int slot = blockIdx.x, i = blockIdx.y;
+	const int slot = blockIdx.x, i = a.clist[blockIdx.y];
 	const int t = i * a.ntasks + slot;
+	const int cm = a.cbase[i] + slot;           /* the task's row in the cell stores */
 	const task_view v = task_of(a, t);
 	const int lane = threadIdx.x, x0 = lane * SPL;
 
@@ -241,7 +245,7 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		pk.y = (uint16_t) o[2] | ((uint32_t) (uint16_t) o[3] << 16);
 		pk.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
 		pk.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
-		((int4 *) a.F)[(size_t) lane * a.tpad + t] = pk;
+		((int4 *) a.F)[(size_t) lane * a.cpad + cm] = pk;
 	}
 	/* the last 7 outputs also as they are before the shift: the share of what lies behind the line comes later */
 	if(x0 + SPL >= W)
@@ -249,7 +253,7 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		for(int j = 0; j < SPL; j++)
 		{
 			const int x = x0 + j;
-			if(x >= W - HVK_SECAM_TAIL && x < W) a.acc[(size_t) t * 8 + (x - (W - HVK_SECAM_TAIL))] = acc[j];
+			if(x >= W - HVK_SECAM_TAIL && x < W) a.acc[(size_t) cm * 8 + (x - (W - HVK_SECAM_TAIL))] = acc[j];
 		}
 	}
 }
@@ -301,10 +305,11 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 	const int fm_end = v.sr < W ? v.sr : W;
 	double ix = S.ix, iy = S.iy;
 	int32_t pi = v.phase_pos ? INT32_MAX : -INT32_MAX, pq = 0;
-	const int4 *F = (const int4 *) a.F + m;
+	const int cm = a.cbase[v.frame] + (m - v.frame * a.ntasks);     /* the task's row in the cell stores */
+	const int4 *F = (const int4 *) a.F + cm;
 	const int chunks = W / CH;          /* W is a multiple of 16 (checked by the launcher) */
 
-	int4 nx0 = F[0], nx1 = F[(size_t) a.tpad];
+	int4 nx0 = F[0], nx1 = F[(size_t) a.cpad];
 	for(int ch = 0; ch < chunks; ch++)
 	{
 		int16_t f[CH], o[CH];
@@ -312,8 +317,8 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 		unpack8(nx1, f + 8);
 		if(ch + 1 < chunks)
 		{
-			nx0 = F[(size_t) (2 * ch + 2) * a.tpad];
-			nx1 = F[(size_t) (2 * ch + 3) * a.tpad];
+			nx0 = F[(size_t) (2 * ch + 2) * a.cpad];
+			nx1 = F[(size_t) (2 * ch + 3) * a.cpad];
 		}
 
 		if(ch == chunks - 1)
@@ -322,7 +327,7 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			for(int j = CH - HVK_SECAM_TAIL; j < CH; j++)
 			{
 				const int x = ch * CH + j;
-				int32_t s = a.acc[(size_t) m * 8 + (j - (CH - HVK_SECAM_TAIL))];
+				int32_t s = a.acc[(size_t) cm * 8 + (j - (CH - HVK_SECAM_TAIL))];
 				for(int i = 0; i < HVK_SECAM_TAIL; i++)
 				{
 					const int k = W + 7 + i - x;
@@ -525,8 +530,11 @@ extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream
 	const int lanes = (a->C.W + SPL - 1) / SPL;
 	const int threads = (lanes + 63) & ~63;
 	if(threads > 256 || (a->C.W % 16) != 0) return(HVK_UNSUPPORTED);
-	if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
-	else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->nframes), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+	if(a->ncells > 0)
+	{
+		if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+		else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+	}
 	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }

@@ -388,8 +388,10 @@ int hvk_set_levels(hvk_engine_t *e, int mode);
  * pulses, the levels of the pixels, the low-passed chroma, the burst -- depends on the picture alone and is made once
  * per uploaded picture, by the first hvk_stage_strided() / hvk_render() that shows it (a picture that stays is not
  * worked on again). hvk_planes_refresh() makes the planes of the named slots now -- again, if
- * they exist -- on the engine's stream: for a caller that wants that work inside a clock of its own. HVK_OK and
- * nothing done where the configuration renders straight from the pictures. */
+ * they exist -- on the engine's stream: for a caller that wants that work inside a clock of its own. SECAM has a
+ * per-picture share of the same kind: the low-passed colour-difference cells of a picture, kept per slot and frame
+ * parity (hvk_secam.hip); for the named slots they are dropped and made again by the next stage that shows them.
+ * HVK_OK and nothing done where the configuration renders straight from the pictures. */
 int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n);
 
 int hvk_timing_enable(hvk_engine_t *e, int on);

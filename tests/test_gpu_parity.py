@@ -421,6 +421,36 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
         assert st["host_frames"] > 0, st
 
 
+def test_secam_cells_of_a_picture_are_kept_and_made_again_when_it_changes(golden, monkeypatch):
+    """SECAM: the low-passed colour cells are kept per picture slot and frame parity (hvk_secam.hip). Pictures that
+    stay over batches of odd length (the parity a slot is shown with changes), slots shown twice in a batch, a slot that
+    gets a new picture between batches and one that is emptied: the same samples as with the cells made for every frame
+    and as the host's serial chain."""
+    conf = H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO)
+    pics = _secam_noisy(3, seed=23) + [golden.frame("l_full")]
+    plan = [([0, 0, 1], None), ([1, 0, 0], None), ([0, 1, 0], (0, 2)), ([1, 1, 0], None), ([0, 0, 0], (0, None)), ([1, 0, 1], (0, 3))]
+    def run():
+        out = []
+        with H.Engine(conf, 16000000, device=0, max_frames=3) as e:
+            e.frame_upload(0, pics[0])
+            e.frame_upload(1, pics[1])
+            for slots, change in plan:
+                if change:
+                    e.frame_upload(change[0], None if change[1] is None else pics[change[1]])
+                e.render(3, slots=slots)
+                out.append(e.fetch(0, 3 * 640000))
+            return np.concatenate(out), e.secam_stats()
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, _ = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    got, st = run()
+    assert np.array_equal(got, want)
+    assert st["host_frames"] == 0
+    monkeypatch.setenv("HVK_SECAM_NO_CELL_CACHE", "1")
+    got2, _ = run()
+    assert np.array_equal(got2, want)
+
+
 @pytest.mark.parametrize("case", ["i_full", "pal_bb"])
 def test_sink_formats_on_device(golden, case):
     """hvk_fetch_as(): the file sink's sample-format conversion done on the GPU, against
