@@ -6,6 +6,7 @@
 # 3. four separate --pmc passes (never combined with trace domains other than
 #    --kernel-trace; TA_/TCP_ derived counters hang on this pool: not used)  -> gpurun_out/TAG/pmcN/
 # 4. tools/pmc_summary.py folds 2-3 into TAG_kernel_stats.csv / TAG_pmc_counters.json / traffic.json
+# 5. rocprofv3 --kernel-trace --stats of tools/secam_blocks.py (card, noisy)  -> TAG_secam_*_kernel_stats.csv
 set -u
 TAG=${1:-r01x}
 BENCH_FLAGS=${BENCH_FLAGS:-}
@@ -14,7 +15,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $PWD/bench.py"
 
-timeout 400 $BENCH $BENCH_FLAGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 $BENCH $BENCH_FLAGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
 
 cd /tmp
@@ -25,6 +26,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
 	i=$((i + 1))
 	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-moving --no-configs > "$OUT/pmc$i.log" 2>&1
 	echo "pmc pass $i ($set): exit $?"
+done
+# 5. the SECAM colour chain (hvk_secam.hip): blocks of 512 frames of the test card, and of noisy pictures with the cells made per frame
+for kind in card noisy; do
+	timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/secam_$kind" -o p -- python $OLDPWD/tools/secam_blocks.py 512 $kind 8 > "$OUT/secam_$kind.log" 2>&1
+	tail -1 "$OUT/secam_$kind.log"
+	f=$(find "$OUT/secam_$kind" -name '*kernel_stats.csv' | head -1)
+	[ -n "$f" ] && cp "$f" "$OUT/${TAG}_secam_${kind}_kernel_stats.csv"
 done
 cd "$OLDPWD"
 python tools/pmc_summary.py "$OUT" "$TAG"
