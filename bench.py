@@ -52,6 +52,43 @@ SAMPLE_RATE = 16000000
 MODE = "i"
 
 
+def a2_prepass(H, pcm):
+    """The host pre-pass of an A2 stereo system (-m g --a2stereo: two FM carriers, pilot, identification tone -- four serial
+    recurrences per sample) on its own, no device: with the tone / pilot pair on a thread of its own (the default) and in
+    one thread (HVK_AUDIO_THREADS=0). Same samples either way (tests/test_host_path.py)."""
+    import ctypes as C
+    from hacktv_amd.engine import lib
+    out = {}
+    for key, env in (("Msamples_per_s", None), ("one_thread_Msamples_per_s", "0")):
+        if env is None:
+            os.environ.pop("HVK_AUDIO_THREADS", None)
+        else:
+            os.environ["HVK_AUDIO_THREADS"] = env
+        conf = H.preset("g", H.FLAG_FILTER)
+        conf.a2stereo = 1
+        best = 0.0
+        for _ in range(3):
+            e = H.Engine(conf, SAMPLE_RATE, device=-1)
+            fs = e.info["frame_samples"]
+            n = 16 * fs
+            while e.audio_needed(20) > 0:
+                e.audio_write(pcm)
+            car = np.ones((n, 2), np.int16)
+            sym = np.zeros(n // 16 + 64, np.uint8)
+            k0 = C.c_int64(0)
+            lib().hvk_host_side_streams(e.h, 0, fs, car.ctypes.data, sym.ctypes.data, len(sym), C.byref(k0))
+            t0 = time.perf_counter()
+            lib().hvk_host_side_streams(e.h, fs, n, car.ctypes.data, sym.ctypes.data, len(sym), C.byref(k0))
+            best = max(best, n / (time.perf_counter() - t0) / 1e6)
+            e.close()
+        out[key] = round(best, 1)
+    os.environ.pop("HVK_AUDIO_THREADS", None)
+    out["note"] = ("-m g --a2stereo --filter, 16 frames of the serial sound chains alone (no device), best of 3: the identification tone and "
+                   "pilot -- constant steps, fed by nothing -- run ahead on a thread of their own; the one-loop form of round 2 measured 215 "
+                   "Msamples/s on this host class (profiles/r03_a2_prepass.txt)")
+    return out
+
+
 def cpu_baseline(log):
     """The reference CLI on the host cores: steady state = (t[21 s of signal] - t[1 s]) / 20 s,
     which strips its ~0.5 s table build."""
@@ -873,6 +910,7 @@ def main():
                 "note": "staging one block before the clock: host audio control path (serial FM phasor chain on one core) and H2D of the side streams",
                 "stage_s": round(t_stage, 3),
                 "Msamples_per_s": round(F * FS / t_stage / 1e6, 1),
+                "a2_stereo": a2_prepass(H, g.audio) if N == 1 and not args.no_moving else None,
             },
         }
         if other:

@@ -29,6 +29,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -384,6 +387,10 @@ struct hvk_audio {
 	_limiter_t lim;
 	int has_lim;
 	_phasor_t a2, a2_pilot, a2_signal;  /* A2 stereo: second FM carrier, pilot and identification tones */
+	struct _pilot_ring *pil;            /* ... the last two on a thread of their own (then a2_pilot / a2_signal stand still until _pilot_settle()) */
+	int pil_off;
+	int thr_lines, thr_slow;            /* lines since the last look; waits for the tone thread in which this one had to step aside */
+	int64_t pil_pos;                    /* pilot values taken from the ring so far */
 	_limiter_t a2_lim;
 
 	int nicam_on;
@@ -490,9 +497,13 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 	return(a);
 }
 
+static void _pilot_stop(hvk_audio_t *a);
+static void _pilot_settle(hvk_audio_t *a);
+
 void hvk_audio_free(hvk_audio_t *a)
 {
 	if(!a) return;
+	_pilot_stop(a);
 	free(a->src);
 	free(a->sym);
 	for(int i = 0; i < KEPT_LINES; i++) free(a->kept[i]);
@@ -691,6 +702,326 @@ static void _scale16(int16_t *v, int n, int32_t level)
 	for(; i < n; i++) v[i] = (int16_t) (((int32_t) v[i] * level) >> 15);
 }
 
+/* v[i] = (int16_t) ((v[i] * w[i]) >> 15), w[i] >= 0 */
+static void _scale16v(int16_t *v, const int16_t *w, int n)
+{
+	int i = 0;
+#if defined(__SSE2__)
+	for(; i + 8 <= n; i += 8)
+	{
+		const __m128i a = _mm_loadu_si128((const __m128i *) (v + i)), b = _mm_loadu_si128((const __m128i *) (w + i));
+		const __m128i lo = _mm_mullo_epi16(a, b), hi = _mm_mulhi_epi16(a, b);
+		const __m128i p0 = _mm_srai_epi32(_mm_unpacklo_epi16(lo, hi), 15);
+		const __m128i p1 = _mm_srai_epi32(_mm_unpackhi_epi16(lo, hi), 15);
+		_mm_storeu_si128((__m128i *) (v + i), _mm_packs_epi32(p0, p1));   /* |product >> 15| <= 2^15 - 1: nothing saturates */
+	}
+#endif
+	for(; i < n; i++) v[i] = (int16_t) (((int32_t) v[i] * w[i]) >> 15);
+}
+
+/* ---- Zweikanalton (A2 stereo) ---- */
+
+#define A2_MUL(pi_, pq_, st_) \
+	do { \
+		const int64_t ni_ = (int64_t) (pi_) * (st_).i - (int64_t) (pq_) * (st_).q; \
+		const int64_t nq_ = (int64_t) (pi_) * (st_).q + (int64_t) (pq_) * (st_).i; \
+		(pi_) = (int32_t) (ni_ >> 31); \
+		(pq_) = (int32_t) (nq_ >> 31); \
+	} while(0)
+/* amplitude drift correction every INT16_MAX steps of a phasor (src/video.c:2266-2275) */
+#define A2_FIX(pi_, pq_, cnt_) \
+	do { \
+		if((cnt_) == 0) \
+		{ \
+			const double ra_ = atan2((pq_), (pi_)); \
+			(pi_) = lround(cos(ra_) * INT32_MAX); \
+			(pq_) = lround(sin(ra_) * INT32_MAX); \
+			(cnt_) = INT16_MAX; \
+		} \
+	} while(0)
+
+/* v[i] = ((uint16) v[i] ^ 0x8000) >> 1 = (v[i] - INT16_MIN) / 2 */
+static void _half_offset16(int16_t *v, int n)
+{
+	int i = 0;
+#if defined(__SSE2__)
+	const __m128i top = _mm_set1_epi16((short) 0x8000);
+	for(; i + 8 <= n; i += 8)
+	{
+		const __m128i a = _mm_loadu_si128((const __m128i *) (v + i));
+		_mm_storeu_si128((__m128i *) (v + i), _mm_srli_epi16(_mm_xor_si128(a, top), 1));
+	}
+#endif
+	for(; i < n; i++) v[i] = (int16_t) (((int32_t) v[i] - INT16_MIN) / 2);
+}
+
+/* v[i] += w[i] (+ c), int16 wrap-around */
+static void _add16(int16_t *v, const int16_t *w, int16_t c, int n)
+{
+	int i = 0;
+#if defined(__SSE2__)
+	const __m128i cc = _mm_set1_epi16(c);
+	for(; i + 8 <= n; i += 8)
+	{
+		__m128i a = _mm_add_epi16(_mm_loadu_si128((const __m128i *) (v + i)), cc);
+		if(w) a = _mm_add_epi16(a, _mm_loadu_si128((const __m128i *) (w + i)));
+		_mm_storeu_si128((__m128i *) (v + i), a);
+	}
+#endif
+	for(; i < n; i++) v[i] = (int16_t) (v[i] + (w ? w[i] : 0) + c);
+}
+
+/* The identification tone and the pilot it modulates (src/video.c:3408-3416): two recurrences with CONSTANT steps that
+ * nothing feeds -- their values are a function of the sample's number in the stream alone. n samples from the state
+ * (si .. lc), pilot values (before the right channel is added) to out; tmp: n + 8 int16 of scratch. */
+typedef struct { int32_t si, sq, li, lq, sc, lc; } _a2_tone_state_t;
+
+static void _a2_pilot_run(const hvk_tables_t *t, int32_t sg_level, int32_t pl_level, _a2_tone_state_t *st, int16_t *out, int16_t *tmp, int n)
+{
+	const hvk_c32_t sg_step = t->a2_signal_delta, pl_step = t->a2_pilot_delta;
+	int32_t si = st->si, sq = st->sq, li = st->li, lq = st->lq, sc = st->sc, lc = st->lc;
+	int done, i;
+
+	for(done = 0; done < n; )
+	{
+		int run = n - done;
+		if(run > sc) run = sc;
+		if(run > lc) run = lc;
+		for(i = done; i < done + run; i++)
+		{
+			A2_MUL(si, sq, sg_step);
+			A2_MUL(li, lq, pl_step);
+			if(out)
+			{
+				tmp[i] = (int16_t) (si >> 16);
+				out[i] = (int16_t) (li >> 16);
+			}
+		}
+		done += run;
+		sc -= run; lc -= run;
+		A2_FIX(si, sq, sc);
+		A2_FIX(li, lq, lc);
+	}
+	st->si = si; st->sq = sq; st->li = li; st->lq = lq; st->sc = sc; st->lc = lc;
+	if(!out) return;
+
+	/* tone = (((si >> 16) * 16384 >> 15) * level) >> 15; pilot = (((li >> 16) * ((tone - INT16_MIN) / 2) >> 15) * level) >> 15 */
+	_scale16(tmp, n, 16384);
+	_scale16(tmp, n, sg_level);
+	_half_offset16(tmp, n);
+	_scale16v(out, tmp, n);
+	_scale16(out, n, pl_level);
+}
+
+/* A thread of their own for those two: it runs ahead of the sound chains through a ring of blocks and leaves the main
+ * thread the two recurrences that do follow the sound (independent carrier chains side by side). Every
+ * block keeps the state it began with, so the state at any sample the consumer stands at -- what
+ * hvk_audio_state_export() hands on -- is a replay of less than a block away. */
+#define PIL_BS 4096
+#define PIL_NB 32
+struct _pilot_ring {
+	pthread_t th;
+	pthread_mutex_t mx;
+	pthread_cond_t cv;
+	int stop;
+	_Atomic int64_t produced, consumed;     /* samples since the thread's start: published / no longer needed (whole blocks) */
+	int16_t ring[PIL_NB * PIL_BS];
+	_a2_tone_state_t start[PIL_NB];         /* a block's state at its first sample */
+	_a2_tone_state_t run;                   /* the producer's */
+	const hvk_tables_t *t;
+	int32_t sg_level, pl_level;
+};
+
+static void *_pilot_thread(void *arg)
+{
+	struct _pilot_ring *r = arg;
+	int16_t tmp[PIL_BS + 8];
+
+	for(;;)
+	{
+		const int64_t p = atomic_load_explicit(&r->produced, memory_order_relaxed);
+		pthread_mutex_lock(&r->mx);
+		while(!r->stop && p + PIL_BS - atomic_load_explicit(&r->consumed, memory_order_acquire) > (int64_t) PIL_NB * PIL_BS)
+			pthread_cond_wait(&r->cv, &r->mx);
+		if(r->stop) { pthread_mutex_unlock(&r->mx); break; }
+		pthread_mutex_unlock(&r->mx);
+
+		const int b = (int) ((p / PIL_BS) % PIL_NB);
+		r->start[b] = r->run;
+		_a2_pilot_run(r->t, r->sg_level, r->pl_level, &r->run, r->ring + (size_t) b * PIL_BS, tmp, PIL_BS);
+		atomic_store_explicit(&r->produced, p + PIL_BS, memory_order_release);
+	}
+	return(NULL);
+}
+
+static void _pilot_stop(hvk_audio_t *a)
+{
+	struct _pilot_ring *r = a->pil;
+	if(!r) return;
+	pthread_mutex_lock(&r->mx);
+	r->stop = 1;
+	pthread_cond_broadcast(&r->cv);
+	pthread_mutex_unlock(&r->mx);
+	pthread_join(r->th, NULL);
+	pthread_cond_destroy(&r->cv);
+	pthread_mutex_destroy(&r->mx);
+	free(r);
+	a->pil = NULL;
+}
+
+/* Starts the thread at the state a->a2_signal / a->a2_pilot hold; false: no thread (HVK_AUDIO_THREADS=0, or none to be had) */
+static int _pilot_start(hvk_audio_t *a)
+{
+	const char *ev = getenv("HVK_AUDIO_THREADS");
+	struct _pilot_ring *r;
+
+	if(a->pil) return(1);
+	if(a->pil_off || (ev && atoi(ev) == 0)) { a->pil_off = 1; return(0); }
+	r = calloc(1, sizeof(*r));
+	if(!r) { a->pil_off = 1; return(0); }
+	r->t = a->t;
+	r->sg_level = a->a2_signal.level; r->pl_level = a->a2_pilot.level;
+	r->run = (_a2_tone_state_t) { a->a2_signal.pi, a->a2_signal.pq, a->a2_pilot.pi, a->a2_pilot.pq, a->a2_signal.counter, a->a2_pilot.counter };
+	pthread_mutex_init(&r->mx, NULL);
+	pthread_cond_init(&r->cv, NULL);
+	if(pthread_create(&r->th, NULL, _pilot_thread, r) != 0)
+	{
+		pthread_cond_destroy(&r->cv);
+		pthread_mutex_destroy(&r->mx);
+		free(r);
+		a->pil_off = 1;
+		return(0);
+	}
+	a->pil = r;
+	a->pil_pos = 0;
+	return(1);
+}
+
+/* (returns whether the wait was long enough for this thread to step aside) */
+static int _pilot_wait(struct _pilot_ring *r, int64_t upto)
+{
+	int spins = 0, yielded = 0;
+	while(atomic_load_explicit(&r->produced, memory_order_acquire) < upto)
+	{
+#if defined(__x86_64__) || defined(__i386__)
+		if(++spins < 100) { __builtin_ia32_pause(); continue; }
+#endif
+		yielded = 1;
+		/* (the producer may be asleep on a full ring only if this thread is behind its bookkeeping: wake it all the same) */
+		pthread_mutex_lock(&r->mx);
+		pthread_cond_signal(&r->cv);
+		pthread_mutex_unlock(&r->mx);
+		sched_yield();
+	}
+	return(yielded);
+}
+
+/* the next n (<= PIL_BS) pilot values */
+static void _pilot_fetch(hvk_audio_t *a, int16_t *dst, int n)
+{
+	struct _pilot_ring *r = a->pil;
+	const int64_t pos = a->pil_pos;
+	const size_t at = (size_t) (pos % ((int64_t) PIL_NB * PIL_BS));
+	const size_t first = (size_t) n < (size_t) PIL_NB * PIL_BS - at ? (size_t) n : (size_t) PIL_NB * PIL_BS - at;
+
+	a->thr_slow += _pilot_wait(r, pos + n);
+	memcpy(dst, r->ring + at, first * sizeof(int16_t));
+	if(first < (size_t) n) memcpy(dst + first, r->ring, ((size_t) n - first) * sizeof(int16_t));
+	a->pil_pos = pos + n;
+	if(a->pil_pos / PIL_BS != pos / PIL_BS)
+	{
+		/* the blocks behind the one this thread stands in are free */
+		atomic_store_explicit(&r->consumed, a->pil_pos / PIL_BS * PIL_BS, memory_order_release);
+		pthread_mutex_lock(&r->mx);
+		pthread_cond_signal(&r->cv);
+		pthread_mutex_unlock(&r->mx);
+	}
+}
+
+/* a->a2_signal / a->a2_pilot brought to where the consumer stands, the thread ended: before the state is read (export),
+ * replaced (import) or the object goes */
+static void _pilot_settle(hvk_audio_t *a)
+{
+	struct _pilot_ring *r = a->pil;
+	_a2_tone_state_t st;
+	if(!r) return;
+	_pilot_wait(r, a->pil_pos / PIL_BS * PIL_BS + PIL_BS);       /* the block the consumer stands in has been begun and finished */
+	st = r->start[(a->pil_pos / PIL_BS) % PIL_NB];
+	_a2_pilot_run(r->t, r->sg_level, r->pl_level, &st, NULL, NULL, (int) (a->pil_pos % PIL_BS));
+	a->a2_signal.pi = st.si; a->a2_signal.pq = st.sq; a->a2_signal.counter = st.sc;
+	a->a2_pilot.pi = st.li; a->a2_pilot.pq = st.lq; a->a2_pilot.counter = st.lc;
+	_pilot_stop(a);
+}
+
+/* Samples [x0, x1) of the line: four recurrences per sample -- the first carrier, the identification tone, the pilot it
+ * modulates, and the second carrier whose step follows right channel + pilot (src/video.c:3402-3424). They depend on one
+ * another only through VALUES, never through state, and everything that is not a recurrence -- the level scalings, the
+ * pilot's modulation, the sums: eight of the reference's 24 multiplies per sample -- works on eight samples at a time.
+ * Tone and pilot come from their own thread (or, without it, from the same function called here); the two carriers'
+ * recurrences run side by side in this one (the second one's step is a table look-up on right channel + pilot). Same
+ * operations on the same values in the same order per phasor as the general loop in _carriers(); the amplitude
+ * corrections fall on the same samples (every phasor counts its own steps). */
+#define A2_SPAN 512
+static void _carriers_a2(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
+{
+	const hvk_tables_t *t = a->t;
+	const hvk_c32_t fm_step = t->fm_lut[a->fm.sample - INT16_MIN];
+	const int16_t m0 = t->a2_system_m ? (int16_t) (a->fm.sample - a->a2.sample) : a->a2.sample;
+	const int32_t fm_level = a->fm.level, a2_level = a->a2.level;
+	int32_t fi = a->fm.pi, fq = a->fm.pq, ci = a->a2.pi, cq = a->a2.pq;
+	int32_t fc = a->fm.counter, cc = a->a2.counter;
+	int16_t tmp[A2_SPAN + 8], pil[A2_SPAN + 8], car2[2 * A2_SPAN + 16];
+	const int threaded = _pilot_start(a);
+	int x;
+
+	for(x = x0; x < x1; )
+	{
+		const int n = x1 - x < A2_SPAN ? x1 - x : A2_SPAN;
+		int16_t *o = carriers + (size_t) x * 2;
+		int i, done;
+
+		if(threaded) _pilot_fetch(a, pil, n);
+		else
+		{
+			_a2_tone_state_t st = { a->a2_signal.pi, a->a2_signal.pq, a->a2_pilot.pi, a->a2_pilot.pq, a->a2_signal.counter, a->a2_pilot.counter };
+			_a2_pilot_run(t, a->a2_signal.level, a->a2_pilot.level, &st, pil, tmp, n);
+			a->a2_signal.pi = st.si; a->a2_signal.pq = st.sq; a->a2_signal.counter = st.sc;
+			a->a2_pilot.pi = st.li; a->a2_pilot.pq = st.lq; a->a2_pilot.counter = st.lc;
+		}
+		/* the second carrier's modulating sample: right channel (L - R on system M) + pilot, int16 wrap-around (src/video.c:3417-3419) */
+		_add16(pil, NULL, m0, n);
+
+		for(done = 0; done < n; )
+		{
+			int run = n - done;
+			if(run > fc) run = fc;
+			if(run > cc) run = cc;
+			for(i = done; i < done + run; i++)
+			{
+				const hvk_c32_t st = t->a2_lut[pil[i] - INT16_MIN];
+				A2_MUL(fi, fq, fm_step);
+				A2_MUL(ci, cq, st);
+				o[i * 2 + 0] = (int16_t) (fi >> 16);
+				o[i * 2 + 1] = (int16_t) (fq >> 16);
+				car2[i * 2 + 0] = (int16_t) (ci >> 16);
+				car2[i * 2 + 1] = (int16_t) (cq >> 16);
+			}
+			done += run;
+			fc -= run; cc -= run;
+			A2_FIX(fi, fq, fc);
+			A2_FIX(ci, cq, cc);
+		}
+
+		_scale16(o, n * 2, fm_level);
+		_scale16(car2, n * 2, a2_level);
+		_add16(o, car2, 0, n * 2);
+		x += n;
+	}
+
+	a->fm.pi = fi; a->fm.pq = fq; a->fm.counter = fc;
+	a->a2.pi = ci; a->a2.pq = cq; a->a2.counter = cc;
+}
+
 /* Samples [x0, x1) of the current line with the modulating samples in force */
 static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 {
@@ -764,86 +1095,7 @@ static void _carriers(hvk_audio_t *a, int16_t *carriers, int x0, int x1)
 
 	if(a->fm.on && a->a2.on && !a->am.on)
 	{
-		/* Zweikanalton: four recurrences per sample -- the first carrier, the identification tone, the pilot it
-		 * modulates, and the second carrier whose step follows right channel + pilot (src/video.c:3402-3424). They
-		 * depend on one another only through values, not through state: with all four phases in registers the core
-		 * works on them side by side. Same operations, same order per phasor as the general loop below. */
-		const hvk_tables_t *t = a->t;
-		const hvk_c32_t fm_step = t->fm_lut[a->fm.sample - INT16_MIN];
-		const hvk_c32_t sg_step = t->a2_signal_delta, pl_step = t->a2_pilot_delta;
-		const int16_t m0 = t->a2_system_m ? (int16_t) (a->fm.sample - a->a2.sample) : a->a2.sample;
-		const int32_t fm_level = a->fm.level, a2_level = a->a2.level, sg_level = a->a2_signal.level, pl_level = a->a2_pilot.level;
-		int32_t fi = a->fm.pi, fq = a->fm.pq, si = a->a2_signal.pi, sq = a->a2_signal.pq;
-		int32_t li = a->a2_pilot.pi, lq = a->a2_pilot.pq, ci = a->a2.pi, cq = a->a2.pq;
-		int32_t fc = a->fm.counter, sc = a->a2_signal.counter, lc = a->a2_pilot.counter, cc = a->a2.counter;
-
-#define A2_MUL(pi_, pq_, st_) \
-	do { \
-		const int64_t ni_ = (int64_t) (pi_) * (st_).i - (int64_t) (pq_) * (st_).q; \
-		const int64_t nq_ = (int64_t) (pi_) * (st_).q + (int64_t) (pq_) * (st_).i; \
-		(pi_) = (int32_t) (ni_ >> 31); \
-		(pq_) = (int32_t) (nq_ >> 31); \
-	} while(0)
-#define A2_FIX(pi_, pq_, cnt_) \
-	do { \
-		if((cnt_) == 0) \
-		{ \
-			const double ra_ = atan2((pq_), (pi_)); \
-			(pi_) = lround(cos(ra_) * INT32_MAX); \
-			(pq_) = lround(sin(ra_) * INT32_MAX); \
-			(cnt_) = INT16_MAX; \
-		} \
-	} while(0)
-
-		x = x0;
-		while(x < x1)
-		{
-			int run = x1 - x, i;
-			int16_t *o = carriers + (size_t) x * 2;
-			if(run > fc) run = fc;
-			if(run > sc) run = sc;
-			if(run > lc) run = lc;
-			if(run > cc) run = cc;
-			for(i = 0; i < run; i++)
-			{
-				int32_t tone, pilot;
-				int16_t m, ai, aq;
-				hvk_c32_t st;
-
-				A2_MUL(fi, fq, fm_step);
-				ai = (int16_t) (((fi >> 16) * fm_level) >> 15);
-				aq = (int16_t) (((fq >> 16) * fm_level) >> 15);
-
-				A2_MUL(si, sq, sg_step);
-				tone = (int16_t) (((((si >> 16) * 16384) >> 15) * sg_level) >> 15);
-
-				A2_MUL(li, lq, pl_step);
-				pilot = (int16_t) (((((li >> 16) * ((tone - INT16_MIN) / 2)) >> 15) * pl_level) >> 15);
-
-				m = (int16_t) (m0 + pilot);
-				st = t->a2_lut[m - INT16_MIN];
-				A2_MUL(ci, cq, st);
-				ai += (int16_t) (((ci >> 16) * a2_level) >> 15);
-				aq += (int16_t) (((cq >> 16) * a2_level) >> 15);
-
-				o[i * 2 + 0] = ai;
-				o[i * 2 + 1] = aq;
-			}
-			x += run;
-			fc -= run; sc -= run; lc -= run; cc -= run;
-			/* amplitude drift correction every INT16_MAX steps of a phasor (src/video.c:2266-2275) */
-			A2_FIX(fi, fq, fc);
-			A2_FIX(si, sq, sc);
-			A2_FIX(li, lq, lc);
-			A2_FIX(ci, cq, cc);
-		}
-#undef A2_MUL
-#undef A2_FIX
-
-		a->fm.pi = fi; a->fm.pq = fq; a->fm.counter = fc;
-		a->a2_signal.pi = si; a->a2_signal.pq = sq; a->a2_signal.counter = sc;
-		a->a2_pilot.pi = li; a->a2_pilot.pq = lq; a->a2_pilot.counter = lc;
-		a->a2.pi = ci; a->a2.pq = cq; a->a2.counter = cc;
+		_carriers_a2(a, carriers, x0, x1);
 		return;
 	}
 
@@ -942,6 +1194,17 @@ static void _line(hvk_audio_t *a, int16_t *carriers, const int W)
 			_carriers(a, carriers, x, x + 1);
 			x++;
 		}
+	}
+	if(a->pil && ++a->thr_lines == 512)
+	{
+		/* A2: where the tone thread keeps this one waiting again and again it does not run BESIDE it -- too few cores to
+		 * go round -- and costs more than it gives: back to one thread (HVK_AUDIO_THREADS=2: never) */
+		if(a->thr_slow > 128 && !(getenv("HVK_AUDIO_THREADS") && atoi(getenv("HVK_AUDIO_THREADS")) > 1))
+		{
+			_pilot_settle(a);
+			a->pil_off = 1;
+		}
+		a->thr_lines = a->thr_slow = 0;
 	}
 
 	/* NICAM: every symbol that starts inside this line is created now, after
@@ -1126,13 +1389,14 @@ size_t hvk_audio_state_bytes(void) { return(sizeof(_audio_state_t)); }
 
 int64_t hvk_audio_generated(const hvk_audio_t *a) { return(a ? a->generated : 0); }
 
-int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes)
+int hvk_audio_state_export(hvk_audio_t *a, void *buf, size_t bytes)
 {
 	_audio_state_t *st = buf;
 	size_t n;
 
 	if(!a || !buf || bytes < sizeof(*st)) return(HVK_ERROR);
 	if(a->ahead) return(HVK_UNSUPPORTED);    /* the chains stand past the last request (SECAM with sound-in-syncs: one engine renders such a stream anyway) */
+	_pilot_settle(a);       /* (A2: the tone thread's state brought to where the chains stand; it starts again with the next line) */
 	memset(st, 0, sizeof(*st));
 	st->magic = STATE_MAGIC;
 	st->bytes = (uint32_t) sizeof(*st);
@@ -1168,6 +1432,7 @@ int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_
 	if(st->fm.on != a->fm.on || st->am.on != a->am.on || st->a2.on != a->a2.on || st->sis.on != a->sis.on) return(HVK_ERROR);   /* another configuration's state */
 	if(a->ahead) return(HVK_UNSUPPORTED);
 	if(st->nsym < 0 || st->nsym > STATE_SYMS) return(HVK_ERROR);
+	_pilot_settle(a);       /* (A2: the tone thread ends; the next line starts it again from the imported state) */
 
 	a->interp = st->interp;
 	a->pos = st->pos;

@@ -256,7 +256,7 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 int64_t hvk_audio_position(const hvk_audio_t *a);
 /* the chains' state as a flat block (hvk_audio.c), for an engine that goes on where another one stopped */
 size_t hvk_audio_state_bytes(void);
-int hvk_audio_state_export(const hvk_audio_t *a, void *buf, size_t bytes);
+int hvk_audio_state_export(hvk_audio_t *a, void *buf, size_t bytes);
 int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_t *source_pos);
 int64_t hvk_audio_generated(const hvk_audio_t *a);
 /* sound-in-syncs: the bursts of stream lines [g_first, g_first + count), 8 bytes a line (7 bytes of bits MSB first, their number) */

@@ -55,6 +55,51 @@ def test_serial_carrier_stream_equals_oracle(golden, case):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("mode,sr", [("g", 16000000), ("m", 13500000)])
+def test_a2_tone_thread_changes_nothing(golden, monkeypatch, mode, sr):
+    """A2 stereo: the identification tone and pilot run ahead on a thread of their own (hvk_audio.c). Loud noise as sound,
+    6 frames (every phasor passes its amplitude correction several times, the ring of blocks wraps): the carriers equal
+    those of the same chains in one thread (HVK_AUDIO_THREADS=0), piecewise requests equal one request, and an engine
+    that takes the state over in the middle -- the thread's state is a replay inside a block -- continues bit for bit."""
+    conf = H.preset(mode, H.FLAG_FILTER)
+    conf.a2stereo = 1
+    rng = np.random.default_rng(17)
+    pcm = (rng.integers(-32768, 32768, size=(32000, 2))).astype(np.int16)
+    def stream(pieces, handover_at=None):
+        out = []
+        e = H.Engine(conf, sr, device=-1)
+        fs, prime = e.info["frame_samples"], e.info["startup_samples"]
+        total = 6 * fs
+        for _ in range(8):
+            e.audio_write(pcm)
+        pos = prime
+        for n in pieces(total):
+            if handover_at is not None and pos - prime >= handover_at:
+                st = e.sound_state_export()
+                e2 = H.Engine(conf, sr, device=-1)
+                src = e2.sound_state_import(st)
+                e.close()
+                e = e2
+                e.audio_write(pcm[src % len(pcm):])
+                for _ in range(8):
+                    e.audio_write(pcm)
+                handover_at = None
+            out.append(e.host_side_streams(pos, n)[0])
+            pos += n
+        e.close()
+        return np.concatenate(out)
+    W = 1024 if mode == "g" else 858
+    whole = lambda total: [total]
+    ragged = lambda total: [70001] * (total // 70001) + ([total % 70001] if total % 70001 else [])
+    lines = lambda total: [67 * W] * (total // (67 * W)) + ([total % (67 * W)] if total % (67 * W) else [])   # (a state goes over between lines)
+    want = stream(whole)
+    assert np.array_equal(stream(ragged), want)
+    assert np.array_equal(stream(lines, handover_at=3 * 67 * W), want)
+    monkeypatch.setenv("HVK_AUDIO_THREADS", "0")
+    assert np.array_equal(stream(whole), want)
+    assert np.array_equal(stream(lines, handover_at=5 * 67 * W), want)
+
+
 def _nicam_from_symbols(e, sym, k0, first, count):
     """numpy model of the filter kernel's NICAM stage (src/nicam728.c:342-411)."""
     taps = e.table("nicam_taps", np.int16).astype(np.int64)
