@@ -3,6 +3,7 @@
 switch stages off (HIP events on the launch stream). Run on the GPU box. The stage switches need a
 library built with them: `make -C hacktv_amd/csrc clean all ABLATE=1` (the `modes` table does not)."""
 import os, sys
+os.environ.setdefault("HVK_DIRECT", "0")     # the stage switches live in the raster + filter kernel pair (the default path since round 3 is hvk_k_direct)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
