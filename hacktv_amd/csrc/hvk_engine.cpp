@@ -48,6 +48,7 @@ struct hvk_slot_t {
 	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
 	int plane_dirty;            /* the picture planes (hvk_direct.hip) have not been made from this picture yet */
 	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
+	int seeds_valid[6];         /* SECAM: the picture has been shown with this frame number modulo 6: its lines' entry states are kept */
 };
 
 struct hvk_engine {
@@ -60,8 +61,10 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[11];          /* what sa points into (freed at close) */
-	int *h_secam_rows;          /* [2][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made */
+	void *d_secam[12];          /* what sa points into (freed at close) */
+	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
+	int secam_seeds;            /* warm-ups start from the states the picture's lines had the last time (kept per row) */
+	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
 	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */
 	int *h_secam_count;         /* pinned: failures of the last check */
 	int secam_lanes;            /* lanes of four waves per SIMD */
@@ -626,10 +629,16 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			OPENHIP(hipMalloc(&e->d_secam[7], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
 			OPENHIP(hipMalloc(&e->d_secam[8], sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipMalloc(&e->d_secam[9], (size_t) a.tpad * 4 + 64));
-			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 2 * sizeof(int)));
+			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 4 * sizeof(int)));
+			e->secam_seeds = e->secam_cell_cache && !getenv("HVK_SECAM_NO_SEEDS");
+			if(e->secam_seeds)
+			{
+				OPENHIP(hipMalloc(&e->d_secam[11], (size_t) 3 * a.cpad * sizeof(hvk_secam_state_t)));
+				OPENHIP(hipMemset(e->d_secam[11], 0, (size_t) 3 * a.cpad * sizeof(hvk_secam_state_t)));    /* (a state of nothing: what every warm-up started from before) */
+			}
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
-			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 2 * sizeof(int), hipHostMallocDefault));
+			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 4 * sizeof(int), hipHostMallocDefault));
 			OPENHIP(hipMemset(e->d_secam[8], 0, sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_count, 64, hipHostMallocDefault));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_carry, sizeof(hvk_secam_state_t), hipHostMallocDefault));
@@ -647,6 +656,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.count = a.flags + a.tpad;
 			a.cbase = (const int *) e->d_secam[10];
 			a.clist = a.cbase + max_frames;
+			a.seed = (hvk_secam_state_t *) e->d_secam[11];
+			a.kf = e->secam_seeds && e->secam_adapt ? a.cbase + 2 * max_frames : NULL;
+			a.sbase = a.cbase + 3 * max_frames;
 			a.desc = (const hvk_linedesc_t *) e->d_desc;
 			a.pool = e->d_pool;
 			a.yuv = e->d_yuv;
@@ -853,6 +865,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
+	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	if(fb == NULL)
 	{
 		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
@@ -920,6 +933,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
+	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	if(!s->valid) return(HVK_OK);
 
 	const uint32_t *src = fb + (size_t) y * width + x;
@@ -940,6 +954,7 @@ extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
 	{
 		e->slots[i].plane_dirty = 1;
 		e->slots[i].cells_valid[0] = e->slots[i].cells_valid[1] = 0;
+		memset(e->slots[i].seeds_valid, 0, sizeof(e->slots[i].seeds_valid));
 	}
 	return(HVK_OK);
 }
@@ -1352,10 +1367,12 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	 * share of SECAM's work, as the picture planes are PAL's and NTSC's. (The list's last copy is through: every stage
 	 * ends with the check's count read back.) */
 	{
-		int *rows = e->h_secam_rows, *list = rows + e->max_frames;
+		int *rows = e->h_secam_rows, *list = rows + e->max_frames, *kf = rows + 2 * e->max_frames, *srows = rows + 3 * e->max_frames;
 		a.ncells = 0;
 		for(int i = 0; i < nframes; i++)
 		{
+			kf[i] = HVK_SECAM_WARMUP;
+			srows[i] = 0;
 			if(!e->secam_cell_cache)
 			{
 				rows[i] = i * a.ntasks;
@@ -1364,14 +1381,28 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			}
 			const int slot = e->staged_slots[i];
 			const int parity = (int) ((first_frame + i + 1) & 1);
+			int fresh = 0;
 			rows[i] = (slot * 2 + parity) * a.ntasks;
 			if(!e->slots[slot].cells_valid[parity] || first_frame + i == 0)      /* (the stream's first frame has the two fill slots) */
 			{
 				list[a.ncells++] = i;
 				e->slots[slot].cells_valid[parity] = 1;
+				fresh = 1;
 			}
+			/* The states kept per row are those the picture's lines had the last time it was shown: good for a picture that
+			 * was here before, behind a frame that was here before. A new picture, and the frame behind one (its first
+			 * lines' warm-ups start in it), take the full number of warm-up lines; the others the number that follows how
+			 * the batches have gone (a.K) */
+			/* (what a line starts from also follows its sub-carrier's start phase, (frame * lines + line) mod 3: with the
+			 * parity, the frame's number modulo 6) */
+			const int ph6 = (int) ((first_frame + i + 1) % 6);
+			srows[i] = (slot * 6 + ph6) * a.ntasks;
+			if(!e->slots[slot].seeds_valid[ph6]) fresh = 1;
+			e->slots[slot].seeds_valid[ph6] = 1;
+			if(!fresh && !e->secam_last_new) kf[i] = a.K;
+			e->secam_last_new = fresh;
 		}
-		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
 	}
 
 	HIPCHK(hipMemsetAsync(e->d_chroma, 0, (size_t) nframes * k.raster_samples * 2, e->stream));
@@ -1389,14 +1420,18 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			/* How many warm-up lines a start state needs depends on the pictures and costs a walk each. Exactness never
 			 * rests on it -- the check does -- so the number follows what the batches show, carefully: a wrong start costs
 			 * a redo round, which is dearer than the walk it saved. One line fewer after a run of clean batches (a run
-			 * twice as long after every attempt that failed), two more as soon as anything fails. */
+			 * twice as long after every attempt that failed), two more as soon as anything fails. With the lines' states
+			 * kept from the picture's last showing (a.seed) a picture that stays ends at NO warm-up line: its lines start
+			 * from what they started from six frames ago, which is what they start from now. */
 			if(bad == 0)
 			{
-				if(++e->secam_clean >= e->secam_patience && a.K > 2) { a.K--; e->secam_clean = 0; }
+				if(++e->secam_clean >= e->secam_patience && a.K > (e->secam_seeds ? 0 : 2)) { a.K--; e->secam_clean = 0; }
 			}
 			else
 			{
-				a.K = a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP;
+				/* a few wrong starts: two lines more; many (a batch at K = 8 can have a quarter of its lines wrong, and the
+				 * redo rounds then cost a hundred times what the warm-up saved): back to the full number at once */
+				a.K = (int64_t) bad * a.R * 500 > a.total ? HVK_SECAM_WARMUP : (a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP);
 				e->secam_patience = e->secam_patience * 2 < 64 ? e->secam_patience * 2 : 64;
 				e->secam_clean = 0;
 			}
@@ -1493,7 +1528,11 @@ extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 	if(!e || !slots || n < 0) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	for(int i = 0; i < n; i++) if(slots[i] < 0 || slots[i] >= e->frame_slots) return(HVK_ERROR);
-	if(e->secam_dev) for(int i = 0; i < n; i++) e->slots[slots[i]].cells_valid[0] = e->slots[slots[i]].cells_valid[1] = 0;
+	if(e->secam_dev) for(int i = 0; i < n; i++)
+	{
+		e->slots[slots[i]].cells_valid[0] = e->slots[slots[i]].cells_valid[1] = 0;
+		memset(e->slots[slots[i]].seeds_valid, 0, sizeof(e->slots[slots[i]].seeds_valid));
+	}
 	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
 	HIPCHK(hipSetDevice(e->device));
 	for(int i = 0; i < n; i++) e->slots[slots[i]].plane_dirty = 1;

@@ -125,6 +125,14 @@ typedef struct {
 	 * planes of hvk_direct.hip); the walk from line to line is every frame's own. */
 	const int *cbase;           /* [nframes] the row of F / acc at which the frame's tasks begin */
 	const int *clist;           /* [ncells] the frames whose rows are made now */
+	/* Where a warm-up starts from. Not from nothing when the picture has been here before: a line's entry state the last
+	 * time this picture slot was shown with this frame parity is kept per row (written by every walk of a task of its
+	 * own), and a picture that stays meets the same states again -- the derived entry state is then right after a line
+	 * or two instead of eleven. A hint, never more: the check decides (hvk_k_secam_check). */
+	hvk_secam_state_t *seed;    /* [3 cpad], NULL: warm-ups start from a state of nothing */
+	const int *sbase;           /* [nframes] the frame's first row in it: per picture slot and frame number modulo 6 (the parity, and the
+	                             * line's sub-carrier start phase, (frame * lines + line) mod 3) */
+	const int *kf;              /* [nframes] warm-up lines of the tasks of a frame (new pictures: the full number), NULL: K */
 	hvk_secam_state_t *entry, *exit;    /* [tpad] */
 	hvk_secam_state_t *carry;   /* the state the batch starts from; after hvk_launch_secam_carry(): the next batch's */
 	int *flags;                 /* [tpad] */

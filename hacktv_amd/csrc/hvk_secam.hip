@@ -454,6 +454,13 @@ __device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m,
 	else walk_line<false>(a, m, v, S, NULL);
 }
 
+/* the row of task m in the store of kept states */
+__device__ __forceinline__ int seed_row(const hvk_secam_args_t &a, const int m)
+{
+	const int i = m / a.ntasks;
+	return(a.sbase[i] + (m - i * a.ntasks));
+}
+
 /* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than four waves per SIMD hold:
  * then the warm-up is shared by the run's lines) */
 __global__ __launch_bounds__(64)
@@ -464,13 +471,18 @@ void hvk_k_secam_chain(const hvk_secam_args_t a)
 	const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
 
 	hvk_secam_state_t S;
-	int m = t0 - a.K;
+	int m = t0 - (a.kf ? a.kf[t0 / a.ntasks] : a.K);
 	if(m <= 0) { m = 0; S = *a.carry; }
+	else if(a.seed) S = a.seed[seed_row(a, m)];
 	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
 
 	for(; m < t0; m++) run_task(a, m, S, false);
 	a.entry[r] = S;
-	for(; m < t1; m++) run_task(a, m, S, true);
+	for(; m < t1; m++)
+	{
+		if(a.seed) a.seed[seed_row(a, m)] = S;
+		run_task(a, m, S, true);
+	}
 	a.exit[r] = S;
 }
 
@@ -514,7 +526,11 @@ void hvk_k_secam_redo(const hvk_secam_args_t a)
 			if(!a.flags[r] && r + 1 < a.nruns && a.flags[r + 1]) break;           /* its exit state is another lane's start */
 		}
 		a.entry[r] = S;
-		for(int m = t0; m < t1; m++) run_task(a, m, S, true);
+		for(int m = t0; m < t1; m++)
+		{
+			if(a.seed) a.seed[seed_row(a, m)] = S;      /* (the hint the chain kernel left here came from the wrong start) */
+			run_task(a, m, S, true);
+		}
 		a.exit[r] = S;
 	}
 }

@@ -451,6 +451,44 @@ def test_secam_cells_of_a_picture_are_kept_and_made_again_when_it_changes(golden
     assert np.array_equal(got2, want)
 
 
+def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch):
+    """SECAM: a warm-up starts from the state the picture's line had the last time the slot was shown with this frame
+    parity, and the number of warm-up lines follows how the batches go (down to 2 for a picture that stays). 36 batches
+    of 2 frames: a picture that stays long enough for that, then another one in the same slot, then two slots taking
+    turns -- every sample equal to the host's serial chain; the warm-up did get short on the way, and got long again."""
+    conf = H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO)
+    pics = _secam_noisy(2, seed=31) + [golden.frame("l_full")]
+    def plan(b):
+        if b < 16: return [0, 0], ((0, 2) if b == 0 else None)          # the test card stays
+        if b < 20: return [0, 0], ((0, 0) if b == 16 else None)         # a noisy picture takes the slot
+        return [0, 1], ((1, 1) if b == 20 else None)                    # two pictures take turns (odd / even frames)
+    def run():
+        out, ks = [], []
+        with H.Engine(conf, 16000000, device=0, max_frames=2) as e:
+            for b in range(36):
+                slots, up = plan(b)
+                if up:
+                    e.frame_upload(up[0], pics[up[1]])
+                e.render(2, slots=slots)
+                out.append(e.fetch(0, 2 * 640000))
+                try:
+                    ks.append(e.secam_warmup_lines())
+                except H.HvkError:
+                    ks.append(-1)
+            return np.concatenate(out), ks, e.secam_stats()
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, _, _ = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    got, ks, st = run()
+    assert np.array_equal(got, want)
+    assert st["host_frames"] == 0
+    assert min(ks[:16]) <= 2, ks          # the card: fewer and fewer lines, in the end none
+    monkeypatch.setenv("HVK_SECAM_NO_SEEDS", "1")
+    got2, ks2, _ = run()
+    assert np.array_equal(got2, want)
+    assert min(ks2) >= 9, ks2             # without the kept states the card needs its 11 lines
+
+
 @pytest.mark.parametrize("case", ["i_full", "pal_bb"])
 def test_sink_formats_on_device(golden, case):
     """hvk_fetch_as(): the file sink's sample-format conversion done on the GPU, against
