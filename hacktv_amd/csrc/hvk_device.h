@@ -687,7 +687,8 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		}
 		}
 
-		if(own && x0 + SPL <= W)
+		if(PREP) { }                   /* (the planes hold the line without its sub-carrier: hvk_k_direct adds the frame's) */
+		else if(own && x0 + SPL <= W)
 		{
 			const int4u cv = *(const int4u *) (P.chroma + (size_t) y * k.raster_samples + (size_t) rel * W + x0);
 			const int cw[4] = { cv.x, cv.y, cv.z, cv.w };

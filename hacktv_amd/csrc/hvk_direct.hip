@@ -43,9 +43,9 @@
 
 /* ------------------------------------------------------------------ */
 
-template<int NT, int WC, int LV>
+template<int NT, int WC, int LV, int SECAM>
 __global__ __launch_bounds__(1024)
-void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
+void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_packed_taps_t notch, const hvk_rptrs_t P,
                 int16_t *__restrict__ Lp, int *__restrict__ Cp)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
@@ -66,7 +66,7 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_r
 		const hvk_linedesc_t d1 = P.desc[__builtin_amdgcn_readfirstlane(k.lines + rel)];
 		d.pal = (int16_t) ((d.pal | d1.pal) ? 1 : 0);
 	}
-	const hvk_line_t L = raster_setup_core<0, 0>(k, P, f, d, pic, rel, rel, true, false);
+	const hvk_line_t L = raster_setup_core<SECAM, 0>(k, P, f, d, pic, rel, rel, true, false);
 
 	const int YL = raster_YL(W), CL = raster_CL(W);
 	int16_t *Yb = lds, *U = lds + YL, *V = lds + YL + CL;
@@ -85,7 +85,7 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_r
 	if(L.pal || L.has_pix) __syncthreads();
 
 	int s[SPL], cq[SPL];
-	raster_compute<NT, 0, 0, 0, WC, 1>(k, P, L, ctaps, ctaps, pic, rel, t, nth, lds, sd, c, s, cq);
+	raster_compute<NT, SECAM, 0, 0, WC, 1>(k, P, L, ctaps, notch, pic, rel, t, nth, lds, sd, c, s, cq);
 
 	const size_t at = ((size_t) f.plane_row0 + rel) * W + x0;
 	if(x0 + SPL <= W)
@@ -122,7 +122,7 @@ typedef struct { int lb, cb; } dline_t;
  * and parity come by arithmetic, so nothing here waits for another load): the line's V switch and its share of the
  * colour table position. The values are the same for the whole wave: through v_readfirstlane into scalar registers,
  * where the rest is scalar arithmetic. */
-typedef struct { int line0, par, prev, zero; int pal; unsigned off; } dline_in_t;
+typedef struct { int line0, par, prev, zero, own; int pal; unsigned off; } dline_in_t;
 
 template<int COLOUR>
 __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, const hvk_dptrs_t &D, const int par_own, const bool first, const int rel)
@@ -132,13 +132,14 @@ __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, c
 	 * frame's own planes have them) */
 	dline_in_t q;
 	q.line0 = rel; q.par = par_own; q.prev = 0;
+	q.own = rel >= 0 && rel < k.lines;
 	if(rel < 0) { q.line0 = k.lines - 1; q.par ^= 1; q.prev = 1; }
 	else if(rel >= k.lines) { q.line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; q.par ^= 1; }
 	/* before the stream: the filter history is zero, not blanking (src/video.c:4665-4667 with src/fir.c:289, :579) */
 	q.zero = rel < 0 && first;
 	q.pal = 0;
 	q.off = 0;
-	if(COLOUR)
+	if(COLOUR == 1)
 	{
 		/* hvk_linedesc_t.pal, as the low half of the descriptor's fourth dword */
 		static_assert(offsetof(hvk_linedesc_t, pal) == 12 && sizeof(hvk_linedesc_t) == 16, "hvk_linedesc_t layout");
@@ -152,13 +153,18 @@ __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, c
 
 template<int COLOUR>
 __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const dline_in_t &q, const int row0_prev, const int row0_own,
-                                               const unsigned clut_off0, const int wstart)
+                                               const unsigned clut_off0, const int wstart, const int y)
 {
 	dline_t l;
 	const int row0 = q.prev ? row0_prev : row0_own;
 	l.lb = (q.zero ? D.zero_row : row0 + q.line0) * k.width - wstart;
 	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
-	if(COLOUR && !q.zero)
+	if(COLOUR == 2)
+	{
+		/* SECAM: the sub-carrier is the colour chain's, a slab per frame of the batch; the lines around a frame have none */
+		l.cb = (q.own && !q.zero ? y * (int) k.raster_samples + q.line0 * k.width : D.chroma_zero) - wstart;
+	}
+	if(COLOUR == 1 && !q.zero)
 	{
 		const int pal = (int) (short) (__builtin_amdgcn_readfirstlane(q.pal) & 0xFFFF);
 		unsigned coff = clut_off0 + (unsigned) __builtin_amdgcn_readfirstlane((int) q.off);
@@ -175,7 +181,12 @@ __device__ __forceinline__ int4u direct_eval(const hvk_dptrs_t &D, const int lb,
 {
 	const int4a2 lv = *(const int4a2 *) (D.Lp + (lb + w));         /* (2-byte aligned where the width is odd) */
 	int4u s = { lv.x, lv.y, lv.z, lv.w };
-	if(COLOUR)
+	if(COLOUR == 2)
+	{
+		const int4a2 cv = *(const int4a2 *) (D.chroma + (cb + w));
+		s.x = pk_add16(s.x, cv.x); s.y = pk_add16(s.y, cv.y); s.z = pk_add16(s.z, cv.z); s.w = pk_add16(s.w, cv.w);
+	}
+	if(COLOUR == 1)
 	{
 		const int4u *cp = (const int4u *) (D.Cp + (lb + w));
 		const int4u *kp = (const int4u *) (D.clut3 + (cb + w));
@@ -233,6 +244,7 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const int d_creg, const int d_zero_row,
                   const hvk_linedesc_t *__restrict__ d_desc, const hvk_framedesc_t *__restrict__ d_fdesc,
                   const uint32_t *__restrict__ d_lineoff, const uint32_t d_inv_w,
+                  const int16_t *__restrict__ d_chroma, const int d_chroma_zero,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW] */
                   const int *__restrict__ nicam_tapd,
@@ -264,6 +276,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	hvk_dptrs_t D;
 	D.Lp = d_Lp; D.Cp = d_Cp; D.clut3 = d_clut3; D.creg = d_creg; D.zero_row = d_zero_row;
 	D.desc = d_desc; D.fdesc = d_fdesc; D.lineoff = d_lineoff; D.inv_w = d_inv_w;
+	D.chroma = d_chroma; D.chroma_zero = d_chroma_zero;
 
 	const int FS = k.frame_samples, W = k.width;
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
@@ -308,9 +321,9 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int row0_prev = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y].plane_row0);
 	const int row0_own = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].plane_row0);
 	const unsigned clut_off0 = (unsigned) __builtin_amdgcn_readfirstlane((int) D.fdesc[2 * y + 1].clut_off0);
-	const dline_t lA = direct_line<COLOUR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0);
-	const dline_t lB = direct_line<COLOUR>(k, D, qB, row0_prev, row0_own, clut_off0, b1);
-	const dline_t lC = direct_line<COLOUR>(k, D, qC, row0_prev, row0_own, clut_off0, b2);
+	const dline_t lA = direct_line<COLOUR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
+	const dline_t lB = direct_line<COLOUR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
+	const dline_t lC = direct_line<COLOUR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
 
 	/* ---- loads ---- */
 	int symv = 0, cc_tile = 0;
@@ -433,9 +446,10 @@ static int _launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int 
 	hvk_rptrs_t P;
 	hvk_raster_ptrs(a, &P);
 	const dim3 grid((a->k.lines + 7) & ~7, npics), block(threads);
-#define PREP(WCV, LVV) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV>), grid, block, lds, stream, a->k, a->ctaps, P, Lp, Cp)
-	if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1); else PREP((NT == 13 ? 1024 : 0), 0); }
-	else { if(a->levels_computed) PREP(0, 1); else PREP(0, 0); }
+#define PREP(WCV, LVV, SC) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV, SC>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp)
+	if(NT == 1 && a->k.secam) { if(a->levels_computed) PREP(0, 1, (NT == 1 ? 1 : 0)); else PREP(0, 0, (NT == 1 ? 1 : 0)); }
+	else if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1, 0); else PREP((NT == 13 ? 1024 : 0), 0, 0); }
+	else { if(a->levels_computed) PREP(0, 1, 0); else PREP(0, 0, 0); }
 #undef PREP
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
@@ -443,7 +457,7 @@ static int _launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int 
 extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
 {
 	if(npics < 1) return(HVK_OK);
-	switch(a->k.colour ? a->k.chroma_ntaps : 1)
+	switch(a->k.colour && !a->k.secam ? a->k.chroma_ntaps : 1)
 	{
 	case 1:  return(_launch_prep<1>(a, npics, Lp, Cp, stream));
 	case 9:  return(_launch_prep<9>(a, npics, Lp, Cp, stream));
@@ -456,11 +470,14 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *L
 	return(HVK_UNSUPPORTED);
 }
 
-/* Which configurations render this way: the plain ones -- PAL / NTSC / monochrome at the sample rate, one
+/* Which configurations render this way: the plain ones -- PAL / NTSC / SECAM / monochrome at the sample rate, one
  * picture per frame, no inserters -- with the matrix-unit filter or none */
-extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a)
+extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames)
 {
-	if(k->secam || k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->sis || k->fields != 1 || k->fm_video) return(0);
+	if(k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->sis || k->fields != 1 || k->fm_video) return(0);
+	/* SECAM: the sub-carrier comes from the colour chain's slab, indexed with 32 bits; the identification lines are the
+	 * raster kernel's optional stages */
+	if(k->secam && (secam_fid || (int64_t) (max_frames + 1) * k->raster_samples >= 0x7FFFFFFF)) return(0);
 	if(k->vf_type != 0 && !(k->vf_ntaps == 51 && mfma_a && (k->vf_type == 1 || k->vf_type == 3))) return(0);
 	if(k->width < 544) return(0);               /* a tile's window within three lines */
 	return(1);
@@ -472,7 +489,7 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	const dim3 grid(((tiles + DG - 1) / DG + 7) & ~7, a->nframes), block(HVK_TILE / SPL * DG);
 #define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, \
-	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, (const int *) a->carriers, a->tilesyms, \
+	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, a->D.chroma, a->D.chroma_zero, (const int *) a->carriers, a->tilesyms, \
 	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);
 #undef DIRECT
@@ -482,6 +499,7 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 extern "C" int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream)
 {
 	const int vf = a->k.vf_type ? 1 : 0;
+	if(a->k.secam) return(vf ? _launch_direct2<1, 2>(a, stream) : _launch_direct2<0, 2>(a, stream));
 	if(a->k.colour) return(vf ? _launch_direct2<1, 1>(a, stream) : _launch_direct2<0, 1>(a, stream));
 	return(vf ? _launch_direct2<1, 0>(a, stream) : _launch_direct2<0, 0>(a, stream));
 }

@@ -58,6 +58,7 @@ struct hvk_engine {
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
+	int16_t *d_chroma_alloc;    /* (d_chroma lies 64 entries inside it: a lane of hvk_k_direct whose 8 samples straddle the start of a frame's first line reads up to 7 entries in front) */
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
@@ -380,7 +381,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	 * filter kernel pair (the parity tests run both). The planes do not depend on a frame's parity: the two
 	 * descriptor sets may differ in nothing but `pal`; and the line after a frame must not show picture (its
 	 * planes are taken from the frame's own picture). */
-	e->direct = hvk_direct_supported(&e->t.k, e->d_mfma_a) && !(getenv("HVK_DIRECT") && atoi(getenv("HVK_DIRECT")) == 0);
+	e->direct = hvk_direct_supported(&e->t.k, e->d_mfma_a, e->t.conf.secam_field_id != 0, max_frames) && !(getenv("HVK_DIRECT") && atoi(getenv("HVK_DIRECT")) == 0);
 	for(int l = 0; l < k.lines && e->direct; l++)
 	{
 		hvk_linedesc_t a = e->t.desc[l], b = e->t.desc[k.lines + l];
@@ -415,7 +416,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		const size_t pn = (size_t) e->plane_rows * k.width + 32;
 		OPENHIP(hipMalloc((void **) &e->d_Lp, pn * 2));
 		OPENHIP(hipMemset(e->d_Lp, 0, pn * 2));
-		if(k.colour)
+		if(k.colour && !k.secam)        /* (SECAM: no (V, U) plane and no phasors -- the sub-carrier is the colour chain's) */
 		{
 			OPENHIP(hipMalloc((void **) &e->d_Cp, pn * 4));
 			OPENHIP(hipMemset(e->d_Cp, 0, pn * 4));
@@ -435,7 +436,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			/* what the kernel would divide for: a window position's line by a multiplication (exact up to the
 			 * last position a tile can ask for -- checked here), a line's colour table position from a table */
 			std::vector<uint32_t> lo((size_t) k.lines + 4, 0);
-			for(int j = 0; j < k.lines + 4 && k.colour; j++) lo[j] = (uint32_t) ((((int64_t) (j - 1) * k.width) % k.clw + k.clw) % k.clw);
+			for(int j = 0; j < k.lines + 4 && k.colour && !k.secam && k.clw > 0; j++) lo[j] = (uint32_t) ((((int64_t) (j - 1) * k.width) % k.clw + k.clw) % k.clw);
 			OPENCHK(_upload((void **) &e->d_lineoff, lo.data(), lo.size() * 4));
 			e->inv_w = (uint32_t) (((1ULL << 32) + k.width - 1) / k.width);
 			/* (the quotient can only go wrong next to a multiple of the width: those and their neighbours are tried) */
@@ -573,8 +574,10 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(e->t.k.secam)
 	{
 		const size_t RS = k.raster_samples;   /* the colour side stream is at the pixel rate */
-		OPENHIP(hipMalloc((void **) &e->d_chroma, (size_t) max_frames * RS * 2));
-		OPENHIP(hipMemset(e->d_chroma, 0, (size_t) max_frames * RS * 2));
+		/* (a line's worth of zeros behind the frames: what hvk_k_direct adds to the lines around a frame) */
+		OPENHIP(hipMalloc((void **) &e->d_chroma_alloc, ((size_t) max_frames * RS + k.width + 128) * 2));
+		OPENHIP(hipMemset(e->d_chroma_alloc, 0, ((size_t) max_frames * RS + k.width + 128) * 2));
+		e->d_chroma = e->d_chroma_alloc + 64;
 		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * RS * 2, hipHostMallocDefault));
 
 		/* the device's own chain (HVK_SECAM_HOST=1: everything through the host's, as before). It needs whole
@@ -707,7 +710,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -1965,6 +1968,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.D.fdesc = e->d_fdesc;
 		da.D.lineoff = e->d_lineoff;
 		da.D.inv_w = e->inv_w;
+		da.D.chroma = e->d_chroma;
+		da.D.chroma_zero = (int) ((size_t) e->max_frames * e->t.k.raster_samples + 16);
 		da.carriers = fa.carriers;
 		da.tilesyms = fa.tilesyms;
 		da.nicam_tapd = fa.nicam_tapd;
@@ -2190,7 +2195,7 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	const int lv = e->levels_computed ? 1 : 0;
 	if(e->direct)
 	{
-		snprintf(buf, n, "hvk_k_direct<%d, %d, %d>", k.vf_type ? 1 : 0, k.colour ? 1 : 0, k.frame_samples % HVK_TILE == 0 ? 1 : 0);
+		snprintf(buf, n, "hvk_k_direct<%d, %d, %d>", k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;

@@ -76,6 +76,8 @@ typedef struct {
 	const hvk_framedesc_t *fdesc;   /* [nframes][2]: the frame before, the frame */
 	const uint32_t *lineoff;    /* [lines + 4]: ((j - 1) * width) mod clw -- the colour table position of line j - 1 of a frame that starts at position 0 */
 	uint32_t inv_w;             /* ceil(2^32 / width): n / width == (n * inv_w) >> 32 for every n a frame's window positions take (checked by the host) */
+	const int16_t *chroma;      /* SECAM: [nframes][raster_samples] the colour chain's sub-carrier (hvk_secam.hip), added to the frame's own lines */
+	int chroma_zero;            /*   index of a run of width + 16 zeros in it: the lines around a frame carry none */
 } hvk_dptrs_t;
 
 typedef struct {
@@ -153,7 +155,7 @@ int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
 /* picture planes of `npics` pictures: a->fdesc holds one descriptor per picture (plane_row0 says where its rows go) */
 int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
-int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a);
+int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames);
 int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
 int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
