@@ -740,7 +740,7 @@ def main():
     # chain on one short block ----
     secam = None
     if N == 1 and not args.no_moving:
-        def secam_run(Fs, ksteps, wsteps=10, pics=None):
+        def secam_run(Fs, ksteps, wsteps=16, pics=None):
             # (the warm-up steps also let the number of warm-up LINES per start state settle: it follows the pictures, one
             # line down per clean block, two up per block with a wrong start -- hvk_engine.cpp)
             es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
@@ -794,7 +794,10 @@ def main():
         del os.environ["HVK_SECAM_HOST"]
         secam = {
             "workload": "-m l -s 16000000 --filter --noaudio test, %d frames per step, every step stages (= runs the colour chain: every line of every frame walked and checked) "
-                        "and renders a fresh block; the test card's low-passed colour cells are made once per frame parity and kept, like the headline's picture planes" % (4 * F),
+                        "and renders a fresh block. Per-picture work is done once per picture, like the headline's picture planes: the test card's low-passed colour cells (per frame parity) "
+                        "and its luma planes; and a line's walk starts from the state the line had the last time the picture was shown with this frame number modulo 6, "
+                        "which for a picture that stays is the state it has now -- no warm-up lines (lines.warmup_lines_per_start_state), every line still walked "
+                        "once and its start state checked bit for bit" % (4 * F),
             "Msamples_per_s": round(4 * F * FS / t_big / 1e6, 1),
             "ms_per_step": round(t_big * 1e3, 3),
             "lines": st_big,
@@ -809,7 +812,7 @@ def main():
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
             "note": "lines (of the timed steps): worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; "
-                    "the number of warm-up lines per start state follows the pictures (exactness rests on the check, not on it) and has settled over 10 untimed blocks",
+                    "the number of warm-up lines per start state follows the pictures (exactness rests on the check, not on it) and has settled over the untimed blocks",
         }
 
     configs = None
