@@ -58,6 +58,7 @@ struct hvk_engine {
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
+	signed char *chroma_par;    /* [max_frames] the frame parity the slab's rows were last written with by the device's chain (-1: clear before use) */
 	int16_t *d_chroma_alloc;    /* (d_chroma lies 64 entries inside it: a lane of hvk_k_direct whose 8 samples straddle the start of a frame's first line reads up to 7 entries in front) */
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
@@ -578,6 +579,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipMalloc((void **) &e->d_chroma_alloc, ((size_t) max_frames * RS + k.width + 128) * 2));
 		OPENHIP(hipMemset(e->d_chroma_alloc, 0, ((size_t) max_frames * RS + k.width + 128) * 2));
 		e->d_chroma = e->d_chroma_alloc + 64;
+		e->chroma_par = (signed char *) malloc((size_t) max_frames);
+		if(!e->chroma_par) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
+		memset(e->chroma_par, -1, (size_t) max_frames);
 		OPENHIP(hipHostMalloc((void **) &e->h_chroma, (size_t) max_frames * RS * 2, hipHostMallocDefault));
 
 		/* the device's own chain (HVK_SECAM_HOST=1: everything through the host's, as before). It needs whole
@@ -725,6 +729,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	}
 
 	free(e->sym_tmp);
+	free(e->chroma_par);
 	free(e->fm_prime_car);
 	free(e->cc_pairs);
 	delete e->raw_q;
@@ -1408,7 +1413,17 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
 	}
 
-	HIPCHK(hipMemsetAsync(e->d_chroma, 0, (size_t) nframes * k.raster_samples * 2, e->stream));
+	/* The chain writes every line on its task list whole and never another; the list follows the frame's parity. A slab
+	 * row that was last written with the same parity has nothing to clear (blocks of even length, one after the other:
+	 * none of them), the others are cleared in runs. */
+	for(int i = 0; i < nframes; )
+	{
+		int j = i;
+		while(j < nframes && e->chroma_par[j] != (signed char) ((first_frame + j + 1) & 1)) j++;
+		if(j > i) HIPCHK(hipMemsetAsync(e->d_chroma + (size_t) i * k.raster_samples, 0, (size_t) (j - i) * k.raster_samples * 2, e->stream));
+		for(int q = i; q < j; q++) e->chroma_par[q] = (signed char) ((first_frame + q + 1) & 1);
+		i = j + 1;
+	}
 	if((r = hvk_launch_secam_cells_chain(&a, e->stream)) != HVK_OK) return(r);
 	e->secam_counts[0] += a.total;
 
@@ -1458,6 +1473,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			HIPCHK_P(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
 			e->secam_counts[3] += nframes;
+			memset(e->chroma_par, -1, (size_t) e->max_frames);      /* (the host's chain wrote the rows) */
 			return(HVK_OK);
 		}
 		e->secam_counts[2] += (int64_t) bad * a.R;
