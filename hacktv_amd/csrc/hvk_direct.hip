@@ -460,12 +460,17 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *L
 	switch(a->k.colour && !a->k.secam ? a->k.chroma_ntaps : 1)
 	{
 	case 1:  return(_launch_prep<1>(a, npics, Lp, Cp, stream));
+	case 5:  return(_launch_prep<5>(a, npics, Lp, Cp, stream));
+	case 7:  return(_launch_prep<7>(a, npics, Lp, Cp, stream));
 	case 9:  return(_launch_prep<9>(a, npics, Lp, Cp, stream));
 	case 11: return(_launch_prep<11>(a, npics, Lp, Cp, stream));
 	case 13: return(_launch_prep<13>(a, npics, Lp, Cp, stream));
 	case 15: return(_launch_prep<15>(a, npics, Lp, Cp, stream));
 	case 17: return(_launch_prep<17>(a, npics, Lp, Cp, stream));
+	case 19: return(_launch_prep<19>(a, npics, Lp, Cp, stream));
 	case 21: return(_launch_prep<21>(a, npics, Lp, Cp, stream));
+	case 23: return(_launch_prep<23>(a, npics, Lp, Cp, stream));
+	case 25: return(_launch_prep<25>(a, npics, Lp, Cp, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

@@ -286,17 +286,26 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		e->levels_mode = !strcmp(v, "table") ? HVK_LEVELS_TABLE : (!strcmp(v, "compute") ? HVK_LEVELS_COMPUTE : HVK_LEVELS_AUTO);
 	}
 
-	/* the kernels exist for these chroma filter lengths (pixel rates of about 11 to 28 MHz) and for
+	/* the kernels exist for these chroma filter lengths (pixel rates of about 6 to 33 MHz) and for
 	 * the NICAM pulse lengths the LDS table holds: say so now, not at the first render */
 	if(e->t.k.colour)
 	{
 		const int nt = e->t.k.chroma_ntaps;
-		if(nt != 9 && nt != 11 && nt != 13 && nt != 15 && nt != 17 && nt != 21)
+		if(nt < 5 || nt > 25 || !(nt & 1))
 		{
 			fprintf(stderr, "libhvk: no raster kernel for a %d-tap chroma filter (pixel rate %d Hz)\n", nt, e->t.pixel_rate);
 			hvk_close(e);
 			return(HVK_UNSUPPORTED);
 		}
+	}
+	if(e->t.k.has_nicam && e->t.sample_rate < 10000000)
+	{
+		/* Below 10 MHz -- where the 6.552 MHz carrier has long left the band -- the symbols get short against a lane's 8
+		 * samples and a tile's 1024: a tile's row of 48 symbol slots and the 7 symbols a lane looks at stop being enough
+		 * (9.5 MHz already differs from the oracle in the GPU sweep). Refused, not approximated. */
+		fprintf(stderr, "libhvk: NICAM symbols of %d samples at %d Hz are too short for the kernel's tables\n", e->t.k.nicam_sps, e->t.sample_rate);
+		hvk_close(e);
+		return(HVK_UNSUPPORTED);
 	}
 	if(e->t.k.has_nicam && HVK_NICAM_LEAD + e->t.k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD)
 	{

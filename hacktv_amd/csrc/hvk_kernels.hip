@@ -803,12 +803,17 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 		if(a->k.secam) return(_launch_raster<1, 1, 1>(a, stream));
 		switch(a->k.colour ? a->k.chroma_ntaps : 1)
 		{
+		case 5:  return(_launch_raster<5, 0, 1>(a, stream));
+		case 7:  return(_launch_raster<7, 0, 1>(a, stream));
 		case 9:  return(_launch_raster<9, 0, 1>(a, stream));
 		case 11: return(_launch_raster<11, 0, 1>(a, stream));
 		case 13: return(_launch_raster<13, 0, 1>(a, stream));
 		case 15: return(_launch_raster<15, 0, 1>(a, stream));
 		case 17: return(_launch_raster<17, 0, 1>(a, stream));
+		case 19: return(_launch_raster<19, 0, 1>(a, stream));
 		case 21: return(_launch_raster<21, 0, 1>(a, stream));
+		case 23: return(_launch_raster<23, 0, 1>(a, stream));
+		case 25: return(_launch_raster<25, 0, 1>(a, stream));
 		}
 		return(HVK_UNSUPPORTED);
 	}
@@ -816,12 +821,17 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	switch(a->k.colour ? a->k.chroma_ntaps : 1)
 	{
 	case 1:  return(_launch_raster<1, 0, 0>(a, stream));   /* monochrome */
+	case 5:  return(_launch_raster<5, 0, 0>(a, stream));
+	case 7:  return(_launch_raster<7, 0, 0>(a, stream));
 	case 9:  return(_launch_raster<9, 0, 0>(a, stream));
 	case 11: return(_launch_raster<11, 0, 0>(a, stream));
 	case 13: return(_launch_raster<13, 0, 0>(a, stream));
 	case 15: return(_launch_raster<15, 0, 0>(a, stream));
 	case 17: return(_launch_raster<17, 0, 0>(a, stream));
+	case 19: return(_launch_raster<19, 0, 0>(a, stream));
 	case 21: return(_launch_raster<21, 0, 0>(a, stream));
+	case 23: return(_launch_raster<23, 0, 0>(a, stream));
+	case 25: return(_launch_raster<25, 0, 0>(a, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

@@ -122,7 +122,7 @@ def test_rate_pairs_the_resampler_refuses():
 
 def test_sample_rates_without_a_kernel_are_refused_at_open():
     """Rates whose chroma filter or NICAM pulse has no kernel fail in hvk_open, not at the first render."""
-    for mode, flags, sr in (("i", H.FLAG_NOAUDIO, 64000000), ("i", 0, 48000000), ("pal", 0, 8000000),
+    for mode, flags, sr in (("i", H.FLAG_NOAUDIO, 64000000), ("i", 0, 48000000), ("pal", 0, 3000000), ("pal", 0, 36000000),
                             ("l", H.FLAG_NOAUDIO, 13500000), ("secam", 0, 14750000)):   # SECAM: the notch would leave the line
         try:
             H.Engine(H.preset(mode, flags), sr, device=-1)
@@ -130,7 +130,7 @@ def test_sample_rates_without_a_kernel_are_refused_at_open():
             assert err.code == H.HVK_UNSUPPORTED
         else:
             raise AssertionError("%s at %d Hz accepted" % (mode, sr))
-    for sr in (12000000, 13500000, 14000000, 16000000, 17734475, 20250000, 27000000):
+    for sr in (7000000, 9000000, 12000000, 13500000, 14000000, 16000000, 17734475, 20250000, 24000000, 27000000, 30000000, 33000000):
         with H.Engine(H.preset("i", H.FLAG_NOAUDIO), sr, device=-1) as e:
             assert e.info["sample_rate"] == sr
     with H.Engine(H.preset("i"), 27000000, device=-1) as e:      # NICAM's 373-tap pulse at the top of the range

@@ -64,7 +64,8 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
-                                  "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136"])
+                                  "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
+                                  "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -107,7 +108,7 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
 
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
                                   "pal_bb_filter", "i_20m", "i_offset", "m_offset_pass", "g_a2", "m_a2", "i_27m", "d_full", "palm_full",
-                                  "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster"])
+                                  "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster", "pal_9m", "i_24m", "m_4fsc"])
 def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
     """The plain configurations render in one kernel from picture planes (hvk_direct.hip) by default -- that is what
     the digest tests above run. HVK_DIRECT=0 keeps the raster + filter kernel pair for them: same digests."""
@@ -695,14 +696,16 @@ def test_frame_numbers_far_beyond_32_bits_of_samples(golden):
 @pytest.mark.parametrize("mode,sr", [("i", 17734475), ("m", 14318181), ("l", 17734475),
                                      ("i", 12000000), ("i", 14000000), ("i", 27000000), ("g", 18000000), ("pal", 15000000),
                                      ("m", 12272727), ("m", 27000000), ("ntsc", 18000000),
-                                     ("l", 20250000), ("l", 27000000), ("secam", 18000000)])
+                                     ("l", 20250000), ("l", 27000000), ("secam", 18000000),
+                                     ("pal", 7000000), ("m", 8000000), ("i", 9000000), ("i", 10000000), ("m", 24000000), ("i", 25000000),
+                                     ("l", 24000000), ("ntsc", 30000000), ("pal", 32000000), ("i", 33000000)])
 def test_odd_line_widths(golden, mode, sr):
-    """A sweep over sample rates: every chroma filter length that has a kernel (9 .. 21 taps), lines from
-    768 to 1728 samples. 4 x the colour sub-carrier gives lines of 1135 (PAL) and 910 (NTSC) samples: odd,
+    """A sweep over sample rates: every chroma filter length that has a kernel (5 .. 25 taps), lines from
+    448 to 2112 samples (below 544 the raster + filter kernel pair renders). 4 x the colour sub-carrier gives lines of 1135 (PAL) and 910 (NTSC) samples: odd,
     or not a multiple of 8; slab rows then start on odd int16 offsets. Device against the oracle (the
     reference's heap over-read is not modelled for these widths, so this pins the device to the oracle only)."""
-    # at 27 MHz the NICAM pulse is longer than the kernel's table: FM / AM sound only there
-    conf = H.preset(mode, H.FLAG_FILTER | (H.FLAG_NONICAM if sr >= 27000000 else 0))
+    # at 27 MHz the NICAM pulse is longer than the kernel's table, below 10 MHz its symbols are too short for it: FM / AM sound only there
+    conf = H.preset(mode, H.FLAG_FILTER | (H.FLAG_NONICAM if sr >= 27000000 or sr < 10000000 else 0))
     n = 2
     with oracle.Oracle(conf, sr) as o:
         w, h, L, W = o.info["active_width"], o.info["active_lines"], o.info["lines"], o.info["width"]

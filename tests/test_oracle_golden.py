@@ -22,10 +22,12 @@ CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "
                  "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m"]
 # sound-in-syncs: a NICAM stream of its own inside every sync pulse (oracle/make_golden_sis.py: ten runs of the reference, one output)
 CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt"]
+# rates outside the first rounds' 11 .. 28 MHz: chroma filters of 7, 19, 23 taps (oracle/make_golden_rates.py)
+CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass", "palfm_f14_tail"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS + CASES_RATES)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
