@@ -162,6 +162,8 @@ struct hvk_engine {
 
 	int64_t next_frame;
 	int staged;             /* frames staged for the next launch */
+	int64_t staged_samples, last_samples;   /* output samples of the staged / the last launched batch (frames x frame_samples; frames of two lengths: what they add up to) */
+	int *h_frec, *d_frec;   /* [max_frames][2] --pixelrate with frames of two lengths: hvk_k_resample's per-frame record */
 	int32_t *staged_slots;  /* [max_frames] the slot each of them shows */
 	int64_t staged_first, staged_stride;
 	int last_frames;        /* frames of the last launch (for fetch) */
@@ -233,6 +235,9 @@ static void _pack_taps(hvk_packed_taps_t *p, const int16_t *taps, int ntaps)
 		p->p[k / 2] |= (k & 1) ? ((int) taps[k] << 16) : ((int) taps[k] & 0xFFFF);
 	}
 }
+
+/* first output sample of stream frame f (frames of two lengths with some --pixelrate pairs: hvk_tables.c) */
+static inline int64_t _fstart(const hvk_engine *e, int64_t f) { return(hvk_tables_frame_start(&e->t, f)); }
 
 static int _upload(void **dst, const void *src, size_t bytes)
 {
@@ -493,6 +498,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
+	if(k.rs_irr)
+	{
+		OPENHIP(hipMalloc((void **) &e->d_frec, (size_t) max_frames * 2 * sizeof(int)));
+		OPENHIP(hipHostMalloc((void **) &e->h_frec, (size_t) max_frames * 2 * sizeof(int), hipHostMallocDefault));
+	}
 	if(k.rs_L)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
@@ -535,7 +545,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipHostMalloc((void **) &e->h_sym, (size_t) max_frames * e->symbol_stride * 4, hipHostMallocDefault));
 		OPENHIP(hipMalloc((void **) &e->d_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_tile, (size_t) max_frames * e->tiles * HVK_NICAM_ROW * 4, hipHostMallocDefault));
-		e->sym_tmp = (uint8_t *) malloc(e->symbol_stride);
+		e->sym_tmp = (uint8_t *) malloc((size_t) e->symbol_stride * (e->t.k.rs_irr ? max_frames : 1));      /* (frames of two lengths: a batch's symbols in one go) */
 		if(!e->sym_tmp) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 
@@ -723,7 +733,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -732,7 +742,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		if(e->ev_pdesc) (void) hipEventDestroy(e->ev_pdesc);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits, e->h_secam_rows };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits, e->h_secam_rows, e->h_frec };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -1064,7 +1074,7 @@ extern "C" size_t hvk_audio_needed(const hvk_engine_t *e, int nframes)
 {
 	if(!e || !e->audio) return(0);
 	const hvk_kconst_t &k = e->t.k;
-	int64_t upto = (e->next_frame + nframes) * (int64_t) k.frame_samples + (int64_t) k.out_prime;
+	int64_t upto = _fstart(e, e->next_frame + nframes) + (int64_t) k.out_prime;
 	return(hvk_audio_source_needed(e->audio, upto));
 }
 
@@ -1118,6 +1128,12 @@ extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
 	counts[3] = 0;
 	if(e->secam_dev) for(int i = 0; i < 4; i++) counts[i] = e->secam_counts[i];
 	return(HVK_OK);
+}
+
+extern "C" int64_t hvk_frame_start(const hvk_engine_t *e, int64_t frame)
+{
+	if(!e || frame < 0) return(HVK_ERROR);
+	return(_fstart(e, frame));
 }
 
 extern "C" int hvk_secam_warmup_lines(hvk_engine_t *e)
@@ -1580,6 +1596,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	{
 		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
 	}
+	if(e->t.k.rs_irr && stride != 1) return(HVK_UNSUPPORTED);        /* frames of two lengths: a batch is one run of samples */
 	if(e->secam && (stride != 1 || first_frame != e->secam_next)) return(HVK_UNSUPPORTED);   /* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
 	{
 		/* Where the last line of a frame shows picture (525 lines) it lies within the video filter's reach of the next
@@ -1641,6 +1658,63 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		e->fm_prime_pending = 1;
 	}
 
+	/* The sound chains over a run of samples: the carriers' side stream, and NICAM's symbol schedule as rows per tile.
+	 * Per frame -- or, with frames of two lengths, once for the batch, which the filter kernel then takes as one long
+	 * frame (tiles counted from the batch's first sample). */
+	auto stage_audio = [&](const int64_t a_pos, const int64_t a_len, const size_t a_off, const int a_row, const int a_symcap, const int a_ntiles, const int64_t a_frame) -> int
+	{
+		const int64_t m0 = a_pos + (int64_t) k.out_prime;
+		int64_t k0 = 0;
+		int n = hvk_audio_generate(e->audio, m0, a_len,
+			e->h_car ? e->h_car + a_off * 2 : NULL,
+			e->sym_tmp, a_symcap, &k0);
+		if(n < 0) { e->poisoned = 1; return(n); }
+
+		if(k.sis)
+		{
+			/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
+			/* (and the first line's of the frame behind it: the filter of this frame's last samples looks into it) */
+			int r = hvk_audio_sis_fetch(e->audio, a_frame * k.lines, k.lines + 1, (uint8_t *) (e->h_sis_bits + (size_t) a_row * (k.lines + 1) * 2));
+			if(r != HVK_OK) { e->poisoned = 1; return(r); }
+		}
+
+		if(k.has_nicam)
+		{
+			/* tabulate the symbol schedule for the frame (src/nicam728.c:398-407):
+			 * symbol k starts at sps * k - floor(k * dsl / decimation); entries are
+			 * (start relative to the frame's first sample) << 3 | valid << 2 | value */
+			int32_t *tab = e->h_sym + (size_t) a_row * e->symbol_stride;
+			int32_t *tile = e->h_tile + (size_t) a_row * e->tiles * HVK_NICAM_ROW;
+			int newest = 0;
+
+			for(int j = 0; j < a_symcap; j++)
+			{
+				const int64_t kk = k0 + j;
+				if(j >= n || kk < 0 || e->sym_tmp[j] == 0xFF) { tab[j] = 0; continue; }
+				const int64_t start = (int64_t) k.nicam_sps * kk - (kk * k.nicam_dsl) / k.nicam_decimation - m0;
+				tab[j] = (int32_t) (start * 8) | 4 | (e->sym_tmp[j] & 3);
+			}
+
+			/* per tile a dense row: the HVK_NICAM_SYMS symbols from 6 before the newest
+			 * one that has started by the tile's first sample, then the mixer table
+			 * position of that sample */
+			while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
+			for(int b = 0; b < a_ntiles; b++)
+			{
+				const int64_t pos = (int64_t) b * HVK_TILE;
+				int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
+				while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
+				for(int q = 0; q < HVK_NICAM_SYMS; q++)
+				{
+					const int j = newest - (HVK_NICAM_BACK - 1) + q;
+					row[q] = (j >= 0 && j < a_symcap) ? tab[j] : 0;
+				}
+				row[HVK_NICAM_SYMS] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
+			}
+		}
+		return(HVK_OK);
+	};
+
 	for(int i = 0; i < nframes; i++)
 	{
 		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * (fields + 1) + 1];
@@ -1701,69 +1775,39 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			}
 		}
 
+		/* where the frame's samples stand in the stream, how many they are, where they go in the batch's side buffers */
+		const int64_t fpos = _fstart(e, f->frame_index), flen = _fstart(e, f->frame_index + 1) - fpos;
+		const size_t foff = k.rs_irr ? (size_t) (fpos - _fstart(e, first_frame)) : (size_t) i * FS;
+		if(k.rs_irr)
+		{
+			/* hvk_k_resample: c = B D - f RS L, and the frame's place in the batch's run */
+			e->h_frec[2 * i + 0] = (int) (fpos * k.rs_D - f->frame_index * (int64_t) k.raster_samples * k.rs_L);
+			e->h_frec[2 * i + 1] = (int) foff;
+		}
+
 		if(e->h_off)
 		{
-			int r = hvk_tail_offset_stream(e->tail, f->frame_index * FS, FS, e->h_off + (size_t) i * FS * 2);
+			int r = hvk_tail_offset_stream(e->tail, fpos, flen, e->h_off + foff * 2);
 			if(r != HVK_OK) { e->poisoned = 1; return(r); }
 		}
 		if(e->h_pass)
 		{
-			int r = hvk_tail_passthru_stream(e->tail, f->frame_index * FS, FS, e->h_pass + (size_t) i * FS * 2);
+			int r = hvk_tail_passthru_stream(e->tail, fpos, flen, e->h_pass + foff * 2);
 			if(r != HVK_OK) { e->poisoned = 1; return(r); }
 		}
 
-		if(e->audio)
+		if(e->audio && !k.rs_irr)
 		{
-			const int64_t m0 = f->frame_index * FS + (int64_t) k.out_prime;
-			int64_t k0 = 0;
-			int n = hvk_audio_generate(e->audio, m0, FS,
-				e->h_car ? e->h_car + (size_t) i * FS * 2 : NULL,
-				e->sym_tmp, e->symbol_stride, &k0);
-			if(n < 0) { e->poisoned = 1; return(n); }
-
-			if(k.sis)
-			{
-				/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
-				/* (and the first line's of the frame behind it: the filter of this frame's last samples looks into it) */
-				int r = hvk_audio_sis_fetch(e->audio, f->frame_index * k.lines, k.lines + 1, (uint8_t *) (e->h_sis_bits + (size_t) i * (k.lines + 1) * 2));
-				if(r != HVK_OK) { e->poisoned = 1; return(r); }
-			}
-
-			if(k.has_nicam)
-			{
-				/* tabulate the symbol schedule for the frame (src/nicam728.c:398-407):
-				 * symbol k starts at sps * k - floor(k * dsl / decimation); entries are
-				 * (start relative to the frame's first sample) << 3 | valid << 2 | value */
-				int32_t *tab = e->h_sym + (size_t) i * e->symbol_stride;
-				int32_t *tile = e->h_tile + (size_t) i * e->tiles * HVK_NICAM_ROW;
-				int newest = 0;
-
-				for(int j = 0; j < e->symbol_stride; j++)
-				{
-					const int64_t kk = k0 + j;
-					if(j >= n || kk < 0 || e->sym_tmp[j] == 0xFF) { tab[j] = 0; continue; }
-					const int64_t start = (int64_t) k.nicam_sps * kk - (kk * k.nicam_dsl) / k.nicam_decimation - m0;
-					tab[j] = (int32_t) (start * 8) | 4 | (e->sym_tmp[j] & 3);
-				}
-
-				/* per tile a dense row: the HVK_NICAM_SYMS symbols from 6 before the newest
-				 * one that has started by the tile's first sample, then the mixer table
-				 * position of that sample */
-				while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
-				for(int b = 0; b < e->tiles; b++)
-				{
-					const int64_t pos = (int64_t) b * HVK_TILE;
-					int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
-					while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
-					for(int q = 0; q < HVK_NICAM_SYMS; q++)
-					{
-						const int j = newest - (HVK_NICAM_BACK - 1) + q;
-						row[q] = (j >= 0 && j < e->symbol_stride) ? tab[j] : 0;
-					}
-					row[HVK_NICAM_SYMS] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
-				}
-			}
+			int r = stage_audio(fpos, flen, foff, i, e->symbol_stride, e->tiles, f->frame_index);
+			if(r != HVK_OK) return(r);
 		}
+	}
+	if(e->audio && k.rs_irr)
+	{
+		const int64_t A0 = _fstart(e, first_frame), T = _fstart(e, first_frame + nframes) - A0;
+		if(T * 8 >= 0x7FFFFFFF) return(HVK_UNSUPPORTED);         /* (symbol starts are kept as 29-bit offsets from the batch's first sample) */
+		int r = stage_audio(A0, T, 0, 0, e->symbol_stride * nframes, (int) ((T + HVK_TILE - 1) / HVK_TILE), first_frame);
+		if(r != HVK_OK) return(r);
 	}
 
 	/* The frame before each frame: the one staged just before it, the last frame of the batch before
@@ -1866,9 +1910,11 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + 1) * 8, hipMemcpyHostToDevice, e->stream));
-	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) nframes * FS * 4, hipMemcpyHostToDevice, e->stream));
+	e->staged_samples = _fstart(e, first_frame + nframes) - _fstart(e, first_frame);     /* (nframes * FS but for frames of two lengths) */
+	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
+	if(e->h_frec) HIPCHK_P(hipMemcpyAsync(e->d_frec, e->h_frec, (size_t) nframes * 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
 	if(e->h_sym)
 	{
 		HIPCHK_P(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
@@ -2012,19 +2058,32 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	else
 	{
 		if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
-		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->stream)) != HVK_OK) return(r);
-		if(e->t.k.rs_L && e->t.k.s_video && (r = hvk_launch_resample(&e->t.k, e->d_C, e->d_rs_taps, e->d_C2, e->staged, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.rs_irr && out_stride != 1) return(HVK_UNSUPPORTED);
+		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.rs_L && e->t.k.s_video && (r = hvk_launch_resample(&e->t.k, e->d_C, e->d_rs_taps, e->d_C2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
 		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
+		if(e->t.k.rs_irr)
+		{
+			/* frames of two lengths: the resampled frames lie one behind the other, and everything from here on -- the
+			 * filter never knew about lines, nor does it need to know about frames -- takes the batch as ONE frame of
+			 * staged_samples samples (64 of halo either side, as every frame has them otherwise) */
+			fa.k.frame_samples = (int32_t) e->staged_samples;
+			fa.k.s_stride = (int32_t) ((e->staged_samples + 2 * 64 + 7) & ~7);
+			fa.nframes = 1;
+		}
 		if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
 	}
 	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
 	e->last_direct = e->direct;
 	if(!e->t.k.fm_video && (e->t.k.swap_iq || e->d_off || e->d_pass))
 	{
-		if((r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.rs_irr) r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, (int) e->staged_samples, 1, 1, e->stream);
+		else r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream);
+		if(r != HVK_OK) return(r);
 	}
 
 	e->last_frames = e->staged;
+	e->last_samples = e->staged_samples;
 	e->fm_launched = e->t.k.fm_video;
 
 	if(e->fm_prime_pending)
@@ -2086,7 +2145,7 @@ extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t coun
 {
 	if(!e || !iq) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
 	if(e->t.k.fm_video)
 	{
@@ -2104,7 +2163,7 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 {
 	if(!e || !iq) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
 	HIPCHK(hipSetDevice(e->device));
 	const int t = e->fetch_next;
 	/* a ticket goes out again only when its last copy has been waited for: a caller with more than HVK_FETCH_TICKETS
@@ -2153,7 +2212,7 @@ extern "C" long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t co
 	if(!e || !dst || type < HVK_UINT8 || type > HVK_FLOAT) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	if(e->t.k.fm_video) return(HVK_UNSUPPORTED);   /* the final samples are not on the device */
-	if(first + count > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
 
 	const size_t unit = (type <= HVK_INT8 ? 1 : (type <= HVK_INT16 ? 2 : 4)) * (complex_out ? 2 : 1);
 	const size_t bytes = count * unit;
@@ -2227,7 +2286,7 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	const int extras = (sv || k.vbi || k.vits || k.rawbb || k.sis || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
 	const int wc = (!k.secam && !sv && !extras && nt == 13 && k.width == 1024) ? 1024 : 0;
 	const int vnt = k.vf_type ? k.vf_ntaps : 1;
-	const int exact = (k.frame_samples % HVK_TILE == 0 && k.s_stride - k.s_lead - k.frame_samples >= 128) ? 1 : 0;
+	const int exact = (!k.rs_irr && k.frame_samples % HVK_TILE == 0 && k.s_stride - k.s_lead - k.frame_samples >= 128) ? 1 : 0;
 	const int mf = (vnt == 51 && e->d_mfma_a) ? 1 : 0;
 	snprintf(buf, n, "hvk_k_raster<%d, %d, %d, %d, %d, %d>;%shvk_k_filter<%d, %d, %d, %d, %d>", nt, k.secam ? 1 : 0, sv, extras, wc, lv,
 	         k.rs_L ? "hvk_k_resample;" : "", vnt, k.vf_type, sv, exact, mf);

@@ -92,6 +92,9 @@ typedef struct {
 	int32_t out_prime;      /* samples of the never-emitted start-up lines the audio / tail processes run over */
 	int32_t rs_L, rs_D, rs_ataps;   /* --pixelrate poly-phase resampler: interpolation, decimation, taps per phase; rs_L == 0: none */
 	int32_t rs_shift;       /* resampled-stream index (frame local) of output sample 0's filter centre */
+	int32_t rs_irr;         /* a raster frame does not resample to a whole number of samples (858 x 525 at 13.5 -> 16 MHz): frames
+	                         * of floor / ceil length, frame f's first output sample ceil(f * raster_samples * L / D); frame_samples is the
+	                         * longer of the two lengths. A staged batch is then ONE run of samples (hvk_engine.cpp) */
 	int32_t secam;          /* SECAM: luma notch + the FM sub-carrier stream (hvk_secam.hip; hvk_secam.c where the device does not take it) */
 	int32_t teletext;       /* teletext symbol table present */
 	int32_t vbi;            /* VBI data lines (teletext / WSS / VITC ops) may be present */
@@ -191,6 +194,7 @@ typedef struct {
 int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate);
 /* widths of output lines [first, first + n) of the stream (they vary with the resampler) */
 void hvk_tables_line_widths(const hvk_tables_t *t, int64_t first, int n, int32_t *widths);
+int64_t hvk_tables_frame_start(const hvk_tables_t *t, int64_t frame);     /* first output sample of a frame, counted from the stream's first */
 void hvk_tables_free(hvk_tables_t *t);
 void hvk_tables_default_ghost(hvk_tables_t *t);
 long hvk_tables_get(const hvk_tables_t *t, const char *name, void *dst, long max_bytes);

@@ -157,7 +157,7 @@ int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
 int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
 int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames);
 int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
-int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream);
+int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
                     int nframes, hipStream_t stream);
 int hvk_launch_convert(const void *iq, size_t count, int type, int cplx, void *dst, hipStream_t stream);

@@ -532,7 +532,11 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
 #define HVK_RS_NP   11                              /* tap pairs per phase: ataps is 21 or 22 for every L (ntaps = 21 L | 1) */
 #define HVK_RS_ROW  12                              /* dwords per phase row in LDS: 16-byte aligned rows */
 __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int *__restrict__ taps,
-                                                      int16_t *__restrict__ S2)
+                                                      int16_t *__restrict__ S2,
+                                                      /* frames of two lengths (k.rs_irr): per frame { c, where its samples go in S2 } -- c = B D - f RS L in (-D, D)
+                                                       * with B the frame's first output sample: output r of the frame is made from raster sample
+                                                       * floor((r D + c) / L) of the frame with the taps of phase (r D + c) mod L. NULL: c = 0, frame y at y * s_stride */
+                                                      const int2v *__restrict__ frec)
 {
 	__shared__ __attribute__((aligned(16))) int win[HVK_RS_WIN / 2];        /* raster samples, two per dword */
 	__shared__ __attribute__((aligned(16))) int tp[256 * HVK_RS_ROW];       /* taps, two per dword, one row per phase */
@@ -542,13 +546,15 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	const int A = k.rs_ataps;
 	const long slab_in = (long) k.slab_lines * k.width;
 	const int16_t *in = Sp + (size_t) blockIdx.y * slab_in;     /* raster line -1 of the frame first */
-	int16_t *out = S2 + (size_t) blockIdx.y * k.s_stride;
+	const int2v fr = frec ? frec[blockIdx.y] : (int2v) { 0, 0 };
+	const unsigned cD = (unsigned) fr.x;         /* (added modulo 2^32: r D >= 2 D > |c|, hvk_tables.c) */
+	int16_t *out = frec ? S2 + fr.y : S2 + (size_t) blockIdx.y * k.s_stride;
 
 	const int q0 = blockIdx.x * HVK_RS_TILE;                    /* first slab sample of the tile */
 	const unsigned r0 = (unsigned) (q0 - k.s_lead + k.rs_shift); /* its resampled-stream index, frame local (>= 0; r D < 2^32, hvk_tables.c) */
 	/* first raster sample staged, frame local, rounded down to an even index so that pairs are dwords */
-	const long n_lo = (((long) ((r0 * D) / L) - (A - 1)) & ~1L);
-	const long n_hi = (long) (((r0 + HVK_RS_TILE - 1) * D) / L);
+	const long n_lo = (((long) ((r0 * D + cD) / L) - (A - 1)) & ~1L);
+	const long n_hi = (long) (((r0 + HVK_RS_TILE - 1) * D + cD) / L);
 	const int count2 = (int) ((n_hi - n_lo + 2) / 2);           /* dwords */
 
 	/* Loads first, LDS writes after: a load inside a loop with lane-dependent bounds is waited for in
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	__syncthreads();
 
 	/* this lane's first output: position and phase by one division, the next three by stepping */
-	unsigned rd = (r0 + t * 4) * D;
+	unsigned rd = (r0 + t * 4) * D + cD;
 	long n = rd / L;
 	unsigned ph = rd - (unsigned) n * L;
 
@@ -637,10 +643,10 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	}
 }
 
-extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, hipStream_t stream)
+extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream)
 {
 	const int tiles = (k->s_stride + HVK_RS_TILE - 1) / HVK_RS_TILE;
-	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2);
+	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2, (const int2v *) frec);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

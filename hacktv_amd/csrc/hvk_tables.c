@@ -1511,8 +1511,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		L = sample_rate / a;
 		D = pixel_rate / a;
 
-		/* what the device kernel is sized for, and frames of constant length */
-		if(L > 256 || D > 4 * L || ((int64_t) t->k.raster_samples * L) % D != 0) return(HVK_UNSUPPORTED);
+		/* what the device kernel is sized for */
+		if(L > 256 || D > 4 * L) return(HVK_UNSUPPORTED);
+		/* frames of constant length, or (525 lines at 13.5 -> 16 MHz: 450450 * 32 / 27) of two lengths one sample apart */
+		t->k.rs_irr = ((int64_t) t->k.raster_samples * L) % D != 0;
 
 		ntaps = (21 * L) | 1;
 		taps = calloc(ntaps, sizeof(double));
@@ -1541,7 +1543,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 
 		/* the kernel's position arithmetic is 32-bit: (frame-local resampled index) * D */
 		if(((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; return(HVK_UNSUPPORTED); }
-		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D);
+		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D) + (t->k.rs_irr ? 1 : 0);
 		t->k.slab_lines = t->k.lines + 3;
 		t->max_width = (int32_t) (((int64_t) t->k.width * L + D - 1) / D);   /* fir_int16_output_size, src/fir.c:376-381 */
 
@@ -1553,7 +1555,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		w1 = ((int64_t) 2 * t->k.width * L + D - 1) / D - w0;
 		t->k.rs_shift = (int32_t) (w0 + (t->k.vf_type ? w1 - round((double) sample_rate * line_s) : 0));
 		t->k.out_prime = (int32_t) (w0 + (t->k.vf_type ? w1 : 0));
-		if(t->k.rs_shift < 64) return(HVK_UNSUPPORTED);
+		if(t->k.rs_shift < 64 + (t->k.rs_irr ? 2 : 0)) return(HVK_UNSUPPORTED);
 	}
 	else
 	{
@@ -1677,6 +1679,19 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->vits_l);
 	free(t->vits_c);
 	memset(t, 0, sizeof(*t));
+}
+
+int64_t hvk_tables_frame_start(const hvk_tables_t *t, int64_t frame)
+{
+	const hvk_kconst_t *k = &t->k;
+	if(!k->rs_irr) return(frame * (int64_t) k->frame_samples);
+	/* where the frame's first EMITTED line begins (hvk_tables_line_widths(): emitted line j is the resampler's chunk
+	 * j + s, chunk g begins at ceil(g W L / D)) */
+	{
+		const int64_t s = 1 + (k->vf_type ? k->delay_lines : 0);
+		const int64_t g = frame * k->lines + s;
+		return((g * k->width * k->rs_L + k->rs_D - 1) / k->rs_D - (s * k->width * k->rs_L + k->rs_D - 1) / k->rs_D);
+	}
 }
 
 void hvk_tables_line_widths(const hvk_tables_t *t, int64_t first, int n, int32_t *widths)

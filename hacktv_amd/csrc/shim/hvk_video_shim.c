@@ -714,7 +714,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 		{
 			/* no sound carrier: the reference's audio process still draws the source at 32 kHz
 			 * (src/video.c:3272-3286), and a source only ends once its sound has */
-			const int64_t pos = m->frames_pulled * (int64_t) m->info.frame_samples + m->info.startup_samples;
+			const int64_t pos = hvk_frame_start(m->e, m->frames_pulled) + m->info.startup_samples;
 			const int64_t ticks = pos / m->info.sample_rate * SHIM_AUDIO_RATE
 			                    + pos % m->info.sample_rate * SHIM_AUDIO_RATE / m->info.sample_rate;
 			while(m->audio_drawn < ticks)
@@ -765,7 +765,8 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 	 * external signal (src/video.c:3517-3541); a short source simply ends */
 	if(s->passthru)
 	{
-		size_t want = (size_t) n * m->info.frame_samples, got;
+		/* (the samples of these n frames: n * frame_samples but for rate pairs with frames of two lengths) */
+		size_t want = (size_t) (hvk_frame_start(m->e, m->frames_pulled) - hvk_frame_start(m->e, m->frames_pulled - n)), got;
 
 		if(!m->passthru_primed)
 		{
@@ -791,7 +792,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 	if(m->stats) { t1 = _now(); m->t_render += t1 - t0; t0 = t1; }
 	/* the read-back is queued behind the render; the consumer waits for it (vid_next_line) while this thread goes
 	 * on with the next batch's pulls and host pre-passes */
-	*ticket = hvk_fetch_async(m->e, iq, 0, (size_t) n * m->info.frame_samples);
+	*ticket = hvk_fetch_async(m->e, iq, 0, (size_t) (hvk_frame_start(m->e, m->frames_pulled) - hvk_frame_start(m->e, m->frames_pulled - n)));
 	if(*ticket < 0) return(-1);
 	if(m->stats) { t1 = _now(); m->t_fetch += t1 - t0; }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HVK_LIB") or os.path.join(os.path.dirname(os.path.abs
 
 SYMBOLS = [
     "hvk_config_preset", "hvk_config_apply_flags", "hvk_preset_id", "hvk_preset_desc",
-    "hvk_open", "hvk_open_rates", "hvk_line_widths", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
+    "hvk_open", "hvk_open_rates", "hvk_line_widths", "hvk_frame_start", "hvk_close", "hvk_get_info", "hvk_get_framebuffer_length",
     "hvk_set_chroma_ghost", "hvk_get_chroma_ghost", "hvk_frame_upload", "hvk_teletext_packets", "hvk_audio_write",
     "hvk_passthru_write", "hvk_host_offset_stream", "hvk_host_fm_video", "hvk_cc608_write", "hvk_frame_aspect", "hvk_rawbb_write",
     "hvk_audio_needed", "hvk_render", "hvk_render_strided", "hvk_stage_strided", "hvk_stage_strided_prev", "hvk_launch",
@@ -82,6 +82,8 @@ def lib():
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_secam_stats.argtypes = [vp, vp]
+        L.hvk_frame_start.argtypes = [vp, C.c_int64]
+        L.hvk_frame_start.restype = C.c_int64
         L.hvk_secam_warmup_lines.argtypes = [vp]
         L.hvk_vbi_lines_held.argtypes = [vp, vp, i32]
         L.hvk_sync.argtypes = [vp]
@@ -262,6 +264,10 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
         return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
+
+    def frame_start(self, frame):
+        """First output sample of a stream frame (frame * frame_samples but for rate pairs with frames of two lengths)."""
+        return lib().hvk_frame_start(self.h, frame)
 
     def secam_warmup_lines(self):
         return self._chk("hvk_secam_warmup_lines", lib().hvk_secam_warmup_lines(self.h))

@@ -122,6 +122,14 @@ int hvk_open_rates(hvk_engine_t **e, const hvk_config_t *conf, unsigned int samp
  * vid_next_line() puts in vid_line_t.width): always info.width without the resampler. */
 int hvk_line_widths(const hvk_engine_t *e, int64_t first_line, int nlines, int32_t *widths);
 
+/* The first output sample of stream frame `frame`, counted from the stream's first: frame * frame_samples -- but for
+ * --pixelrate pairs at which a raster frame does not resample to a whole number of samples (525 lines, 13.5 -> 16 MHz:
+ * 450450 * 32 / 27). Frames then have two lengths one sample apart, hvk_info_t.frame_samples is the longer, a render of n
+ * frames from frame f yields hvk_frame_start(f + n) - hvk_frame_start(f) samples without gaps (what hvk_fetch() counts
+ * in), and such a stream renders in order on one engine: no strides, no interleaved output slots. The lines keep the
+ * widths hvk_line_widths() gives (src/video.c:3246): they never depended on where a frame is cut. */
+int64_t hvk_frame_start(const hvk_engine_t *e, int64_t frame);
+
 /* vid_free(): src/video.c:4706 */
 void hvk_close(hvk_engine_t *e);
 

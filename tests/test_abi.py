@@ -100,10 +100,14 @@ def test_bad_arguments_fail_with_codes_not_crashes():
 
 
 def test_rate_pairs_the_resampler_refuses():
-    """--pixelrate: only rate pairs that keep frames a whole number of samples (and small L / D)."""
+    """--pixelrate: small L / D only. (A pair at which a raster frame is not a whole number of samples -- 450450 * 32 / 27 --
+    is taken since round 3: frames of two lengths, hvk_frame_start().)"""
     c = H.preset("m", 0)
-    for sr, pr in ((16000000, 13500000),      # 450450 * 32 / 27 is not whole
-                   (16000001, 13500000)):     # L = 16000001
+    with H.Engine(c, 16000000, device=-1, pixel_rate=13500000) as e:
+        assert e.info["frame_samples"] == 533867 and [e.frame_start(i) for i in range(4)] == [0, 533867, 1067734, 1601600]
+    with H.Engine(c, 13500000, device=-1) as e:
+        assert [e.frame_start(i) for i in range(3)] == [0, 450450, 900900]
+    for sr, pr in ((16000001, 13500000),):     # L = 16000001
         try:
             H.Engine(c, sr, device=-1, pixel_rate=pr)
         except H.HvkError as err:

@@ -14,7 +14,7 @@ HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_gho
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt",
                                   "pal_fm", "ntsc_fm", "secam_fm_tail", "i_px135", "i_px2025", "l_px2025", "pal_px16_s14",
-                                  "m_px135_s27", "pal_px135_s136"])
+                                  "m_px135_s27", "pal_px135_s136", "m_px135_s16", "ntsc_px16_s135"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
     pr = golden.cases[case].get("pixel_rate", 0)
@@ -35,6 +35,9 @@ def test_host_tables_equal_oracle(golden, case):
             w = o.last_widths()
             assert np.array_equal(e.line_widths(0, 700), w)
             assert np.array_equal(e.line_widths(650, 50), w[650:])
+            # a frame begins where its first line begins (frames of two lengths with some rate pairs)
+            L = e.info["lines"]
+            assert e.frame_start(1) == int(np.sum(w[:L])) and e.frame_start(0) == 0
 
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full", "g_a2", "m_a2"])
