@@ -801,6 +801,11 @@ def test_odd_line_widths(golden, mode, sr):
     ("pal60-i", 16000000, 0, {"cc608": 1}),
     ("i", 12000000, 0, {"wss": 0x08}),
     ("secam-g", 16000000, 0, {"a2stereo": 1}),
+    # rate pairs with frames of two lengths (525 lines, 13.5 <-> 16 MHz) under the stages that ride on the resampler
+    ("ntsc", 16000000, 13500000, {"s_video": 1}),
+    ("m", 16000000, 13500000, {"vits": 1, "vitc": 1, "acp": 1, "cc608": 1, "a2stereo": 1}),
+    ("pal60", 13500000, 16000000, {"offset": 300000, "swap_iq": 1}),
+    ("pal-m", 16000000, 13500000, {"interlace": 1}),
 ])
 def test_options_at_other_rates(golden, mode, sr, pr, members):
     """The optional stages away from 16 MHz (their tables scale with the pixel rate: symbol widths,
@@ -842,7 +847,7 @@ def test_options_at_other_rates(golden, mode, sr, pr, members):
             if members.get("cc608"):
                 e.cc608_write(f, 0x41 + f, 0x62)
         e.render(n, slots=[0, 1, 2, 3] if members.get("interlace") else [0, 2])
-        got = e.fetch(0, n * e.info["frame_samples"])
+        got = e.fetch(0, e.frame_start(n))
     assert got.shape == want.shape
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "first difference at sample %d of %d (%d differ)" % (bad[0], len(got), bad.size)
