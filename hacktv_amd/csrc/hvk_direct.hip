@@ -122,9 +122,9 @@ typedef struct { int lb, cb; } dline_t;
  * and parity come by arithmetic, so nothing here waits for another load): the line's V switch and its share of the
  * colour table position. The values are the same for the whole wave: through v_readfirstlane into scalar registers,
  * where the rest is scalar arithmetic. */
-typedef struct { int line0, par, prev, zero, own; int pal; unsigned off; } dline_in_t;
+typedef struct { int line0, par, prev, zero, own; int pal; unsigned off; int ovr; } dline_in_t;
 
-template<int COLOUR>
+template<int COLOUR, int OVR>
 __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, const hvk_dptrs_t &D, const int par_own, const bool first, const int rel)
 {
 	/* (raster_line_index(): the line before the frame is the last line of the frame before, of the other
@@ -139,6 +139,8 @@ __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, c
 	q.zero = rel < 0 && first;
 	q.pal = 0;
 	q.off = 0;
+	q.ovr = -1;
+	if(OVR && q.own) q.ovr = D.ovr_idx[q.line0];        /* a line the optional stages can write to: the frame's own row of it */
 	if(COLOUR == 1)
 	{
 		/* hvk_linedesc_t.pal, as the low half of the descriptor's fourth dword */
@@ -151,7 +153,7 @@ __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, c
 	return(q);
 }
 
-template<int COLOUR>
+template<int COLOUR, int OVR>
 __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const dline_in_t &q, const int row0_prev, const int row0_own,
                                                const unsigned clut_off0, const int wstart, const int y)
 {
@@ -159,6 +161,17 @@ __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_
 	const int row0 = q.prev ? row0_prev : row0_own;
 	l.lb = (q.zero ? D.zero_row : row0 + q.line0) * k.width - wstart;
 	l.cb = 2 * D.creg - wstart;                                     /* no chroma: phasors of zero */
+	if(OVR)
+	{
+		const int oi = (int) (short) (__builtin_amdgcn_readfirstlane(q.ovr) & 0xFFFF);
+		if(oi >= 0)
+		{
+			/* rendered whole by the raster kernel for this frame (VBI data, test signals, their sub-carrier): nothing to add */
+			l.lb = (D.ovr_row0 + y * D.ovr_n + oi) * k.width - wstart;
+			if(COLOUR == 2) l.cb = D.chroma_zero - wstart;
+			return(l);
+		}
+	}
 	if(COLOUR == 2)
 	{
 		/* SECAM: the sub-carrier is the colour chain's, a slab per frame of the batch; the lines around a frame have none */
@@ -235,7 +248,7 @@ __device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_
 	return(s);
 }
 
-template<int VF, int COLOUR, int EXACT>
+template<int VF, int COLOUR, int EXACT, int OVR>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL * DG, 8)
 void hvk_k_direct(const hvk_kconst_t k,
                   /* (hvk_dptrs_t member by member: as __restrict__ kernel arguments the descriptor tables are known not to alias
@@ -245,6 +258,7 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const hvk_linedesc_t *__restrict__ d_desc, const hvk_framedesc_t *__restrict__ d_fdesc,
                   const uint32_t *__restrict__ d_lineoff, const uint32_t d_inv_w,
                   const int16_t *__restrict__ d_chroma, const int d_chroma_zero,
+                  const int16_t *__restrict__ d_ovr_idx, const int d_ovr_row0, const int d_ovr_n,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW] */
                   const int *__restrict__ nicam_tapd,
@@ -277,6 +291,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	D.Lp = d_Lp; D.Cp = d_Cp; D.clut3 = d_clut3; D.creg = d_creg; D.zero_row = d_zero_row;
 	D.desc = d_desc; D.fdesc = d_fdesc; D.lineoff = d_lineoff; D.inv_w = d_inv_w;
 	D.chroma = d_chroma; D.chroma_zero = d_chroma_zero;
+	D.ovr_idx = d_ovr_idx; D.ovr_row0 = d_ovr_row0; D.ovr_n = d_ovr_n;
 
 	const int FS = k.frame_samples, W = k.width;
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
@@ -314,16 +329,16 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
 	const int xA0 = p0 - lineA * W;
 	const int b1 = W - xA0, b2 = b1 + W;                        /* window positions at which the next two lines begin */
-	const dline_in_t qA = direct_line_loads<COLOUR>(k, D, par_own, first, lineA);
-	const dline_in_t qB = direct_line_loads<COLOUR>(k, D, par_own, first, lineA + 1);
-	const dline_in_t qC = direct_line_loads<COLOUR>(k, D, par_own, first, lineA + 2);
+	const dline_in_t qA = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA);
+	const dline_in_t qB = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 1);
+	const dline_in_t qC = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 2);
 	/* (the frame before: the row its LAST line's planes start at less lines - 1; the frame: the row of its line 0) */
 	const int row0_prev = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y].plane_row0);
 	const int row0_own = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].plane_row0);
 	const unsigned clut_off0 = (unsigned) __builtin_amdgcn_readfirstlane((int) D.fdesc[2 * y + 1].clut_off0);
-	const dline_t lA = direct_line<COLOUR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
-	const dline_t lB = direct_line<COLOUR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
-	const dline_t lC = direct_line<COLOUR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
+	const dline_t lA = direct_line<COLOUR, OVR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
+	const dline_t lB = direct_line<COLOUR, OVR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
+	const dline_t lC = direct_line<COLOUR, OVR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
 
 	/* ---- loads ---- */
 	int symv = 0, cc_tile = 0;
@@ -479,7 +494,7 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *L
  * picture per frame, no inserters -- with the matrix-unit filter or none */
 extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames)
 {
-	if(k->s_video || k->rawbb || k->rs_L || k->vbi || k->vits || k->sis || k->fields != 1 || k->fm_video) return(0);
+	if(k->s_video || k->rawbb || k->rs_L || k->sis || k->fields != 1 || k->fm_video) return(0);        /* (VBI data lines and test signals: rows of their own per frame, hvk_dptrs_t.ovr_idx) */
 	/* SECAM: the sub-carrier comes from the colour chain's slab, indexed with 32 bits; the identification lines are the
 	 * raster kernel's optional stages */
 	if(k->secam && (secam_fid || (int64_t) (max_frames + 1) * k->raster_samples >= 0x7FFFFFFF)) return(0);
@@ -493,11 +508,13 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	const dim3 grid(((tiles + DG - 1) / DG + 7) & ~7, a->nframes), block(HVK_TILE / SPL * DG);
-#define DIRECT(EX) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX>), grid, block, 0, stream, a->k, \
-	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, a->D.chroma, a->D.chroma_zero, (const int *) a->carriers, a->tilesyms, \
+#define DIRECT2(EX, OV) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX, OV>), grid, block, 0, stream, a->k, \
+	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, a->D.chroma, a->D.chroma_zero, a->D.ovr_idx, a->D.ovr_row0, a->D.ovr_n, (const int *) a->carriers, a->tilesyms, \
 	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
+#define DIRECT(EX) do { if(a->D.ovr_idx) DIRECT2(EX, 1); else DIRECT2(EX, 0); } while(0)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);
 #undef DIRECT
+#undef DIRECT2
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

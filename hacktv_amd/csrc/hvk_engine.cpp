@@ -142,6 +142,10 @@ struct hvk_engine {
 	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
 	int16_t *d_Lp; int *d_Cp; int *d_clut3; uint32_t *d_lineoff; uint32_t inv_w;
 	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
+	/* ... and behind them, per frame of a batch, a row for every line the optional stages (VBI data, test signals) can
+	 * write to: rendered whole by the raster kernel per frame, taken by hvk_k_direct instead of the planes' rows */
+	int ovr_n, ovr_row0;
+	int16_t *d_ovr_list, *d_ovr_idx;
 	hvk_framedesc_t *d_pdesc, *h_pdesc;     /* [frame_slots]: the pictures a prep launch works on */
 	hipEvent_t ev_pdesc; int pdesc_busy;    /* behind the list's last copy to the device */
 	int64_t prep_count;         /* pictures the planes were made from so far */
@@ -428,7 +432,26 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		e->plane_rows = e->frame_slots * k.lines + 3;
 		e->plane_carry_row = e->frame_slots * k.lines;
 		e->plane_zero_row = e->plane_carry_row + 2;
-		const size_t pn = (size_t) e->plane_rows * k.width + 32;
+		if(k.vbi || k.vits)
+		{
+			std::vector<uint8_t> held((size_t) k.lines, 0);
+			std::vector<int16_t> list, idx((size_t) k.lines, -1);
+			hvk_vbi_lines_held(e, held.data(), k.lines);
+			/* teletext's lines: rows 0 .. 15 on lines 7 .. 22, rows 16 .. 31 on lines 320 .. 335 (src/teletext.c:1211-1236) */
+			if(k.teletext) for(int r = 0; r < 32; r++) { const int l1 = r < 16 ? 7 + r : 320 + r - 16; if(l1 <= k.lines) held[l1 - 1] = 1; }
+			for(int l = 0; l < k.lines; l++) if(held[l]) { idx[l] = (int16_t) list.size(); list.push_back((int16_t) l); }
+			/* (a frame's first lines and its last one are also what the frames next to it look into -- from THEIR planes, which
+			 * have no such rows: no inserter of the reference writes there, and if one did the kernel pair would render) */
+			if(held[0] || held[1] || held[k.lines - 1]) e->direct = 0;
+			if(!list.empty() && e->direct)
+			{
+				e->ovr_n = (int) list.size();
+				e->ovr_row0 = e->plane_rows;
+				OPENCHK(_upload((void **) &e->d_ovr_list, list.data(), list.size() * sizeof(int16_t)));
+				OPENCHK(_upload((void **) &e->d_ovr_idx, idx.data(), idx.size() * sizeof(int16_t)));
+			}
+		}
+		const size_t pn = ((size_t) e->plane_rows + (size_t) e->ovr_n * max_frames) * k.width + 32;
 		OPENHIP(hipMalloc((void **) &e->d_Lp, pn * 2));
 		OPENHIP(hipMemset(e->d_Lp, 0, pn * 2));
 		if(k.colour && !k.secam)        /* (SECAM: no (V, U) plane and no phasors -- the sub-carrier is the colour chain's) */
@@ -733,7 +756,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec };
+		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -2025,7 +2048,16 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
 	if(e->direct)
 	{
-		/* one kernel: its time is reported as the second (filter) kernel's, the first one's is nil */
+		/* one kernel: its time is reported as the second (filter) kernel's; the first one's is nil, or that of the raster
+		 * kernel over the few lines the optional stages write to */
+		if(e->ovr_n)
+		{
+			hvk_raster_args_t rl = ra;
+			rl.linelist = e->d_ovr_list;
+			rl.nlist = e->ovr_n;
+			rl.S = e->d_Lp + 16 + (size_t) e->ovr_row0 * e->t.k.width;
+			if((r = hvk_launch_raster(&rl, e->stream)) != HVK_OK) return(r);
+		}
 		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
 		hvk_direct_args_t da;
 		memset(&da, 0, sizeof(da));
@@ -2040,6 +2072,9 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.D.lineoff = e->d_lineoff;
 		da.D.inv_w = e->inv_w;
 		da.D.chroma = e->d_chroma;
+		da.D.ovr_idx = e->d_ovr_idx;
+		da.D.ovr_row0 = e->ovr_row0;
+		da.D.ovr_n = e->ovr_n;
 		da.D.chroma_zero = (int) ((size_t) e->max_frames * e->t.k.raster_samples + 16);
 		da.carriers = fa.carriers;
 		da.tilesyms = fa.tilesyms;
@@ -2279,7 +2314,8 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	const int lv = e->levels_computed ? 1 : 0;
 	if(e->direct)
 	{
-		snprintf(buf, n, "hvk_k_direct<%d, %d, %d>", k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
+		if(e->ovr_n) snprintf(buf, n, "hvk_k_raster<%d, %d, 0, 1, 0, %d>;hvk_k_direct<%d, %d, %d, 1>", nt, k.secam ? 1 : 0, lv, k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
+		else snprintf(buf, n, "hvk_k_direct<%d, %d, %d, 0>", k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;

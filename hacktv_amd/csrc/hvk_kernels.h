@@ -46,6 +46,10 @@ typedef struct {
 	int nframes;
 	int secam_fid;              /* SECAM field identification lines are switched on */
 	int64_t first_frame, frame_stride;
+	/* Only some lines of every frame, each a row of its own: the lines the optional stages can write to, for the one-kernel
+	 * render (hvk_direct.hip), which takes them instead of the picture planes' rows. NULL: the whole slab */
+	const int16_t *linelist;    /* [nlist] 0-based line numbers; S is then [nframes][nlist][width] */
+	int nlist;
 } hvk_raster_args_t;
 
 typedef struct {
@@ -78,6 +82,10 @@ typedef struct {
 	uint32_t inv_w;             /* ceil(2^32 / width): n / width == (n * inv_w) >> 32 for every n a frame's window positions take (checked by the host) */
 	const int16_t *chroma;      /* SECAM: [nframes][raster_samples] the colour chain's sub-carrier (hvk_secam.hip), added to the frame's own lines */
 	int chroma_zero;            /*   index of a run of width + 16 zeros in it: the lines around a frame carry none */
+	/* Lines that the optional stages (VBI data lines, insertion test signals) can write to are rendered per frame by the
+	 * raster kernel -- whole, sub-carrier and all -- into rows of their own behind the planes' */
+	const int16_t *ovr_idx;     /* [lines] -1, or the line's place among a frame's such rows; NULL: none */
+	int ovr_row0, ovr_n;        /* their first row in Lp; rows per frame */
 } hvk_dptrs_t;
 
 typedef struct {

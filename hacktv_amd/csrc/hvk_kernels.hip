@@ -79,7 +79,9 @@ void hvk_k_raster(const hvk_kconst_t k,
                   int16_t *__restrict__ S,
                   int16_t *__restrict__ Cq,             /* --s-video: the sub-carrier alone, same slab geometry as S */
                   const int64_t first_frame,            /* frame y of the batch is stream frame first_frame + y * frame_stride */
-                  const int64_t frame_stride)
+                  const int64_t frame_stride,
+                  const int16_t *__restrict__ linelist, /* only these lines of every frame, row after row (hvk_raster_args_t.linelist); NULL: the slab */
+                  const int nlist)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
 
@@ -87,7 +89,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	 * dealt round-robin to the 8 XCDs, line x of EVERY frame runs on XCD x % 8:
 	 * the slices of the colour table and of the source frame a line needs then
 	 * stay in that XCD's L2 from frame to frame */
-	if((int) blockIdx.x >= k.slab_lines) return;
+	if((int) blockIdx.x >= (linelist ? nlist : k.slab_lines)) return;
 
 	/* WC: the line width when it is known at compile time (1024: PAL at 16 Msps) -- every lane then
 	 * holds 8 samples inside the line and the per-sample range tests fold away */
@@ -96,8 +98,8 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if(WC) __builtin_assume(t * SPL + SPL <= WC);
 	const int nth = blockDim.x;
 	const int x0 = t * SPL;
-	const int rel = (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
-	int16_t *out = S + ((size_t) blockIdx.y * k.slab_lines + blockIdx.x) * W;
+	const int rel = linelist ? (int) linelist[blockIdx.x] : (int) blockIdx.x - 1;       /* line of the frame; -1 and `lines` (and `lines` + 1 with the resampler) are halo lines */
+	int16_t *out = S + ((size_t) blockIdx.y * (linelist ? nlist : k.slab_lines) + blockIdx.x) * W;
 
 	const hvk_line_t L = raster_setup<SECAM, EXTRAS>(k, P, (int) blockIdx.y, rel, first_frame, frame_stride);
 
@@ -124,7 +126,7 @@ void hvk_k_raster(const hvk_kconst_t k,
 	if(L.pal || L.has_pix) __syncthreads();
 
 	int s[SPL], cq[SPL];
-	raster_compute<NT, SECAM, SV, EXTRAS, WC>(k, P, L, ctaps, notch, (int) blockIdx.y, (int) blockIdx.x, t, nth, lds, sd, c, s, cq);
+	raster_compute<NT, SECAM, SV, EXTRAS, WC>(k, P, L, ctaps, notch, (int) blockIdx.y, rel + 1, t, nth, lds, sd, c, s, cq);
 
 	if(ABLATE(128) && s[0] != 12345) return;   /* profiling: no store */
 	if(x0 + SPL <= W)
@@ -769,8 +771,8 @@ static int _launch_raster3(const hvk_raster_args_t *a, hipStream_t stream)
 	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
 	hvk_rptrs_t P;
 	hvk_raster_ptrs(a, &P);
-	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC, LV>), dim3((a->k.slab_lines + 7) & ~7, a->nframes), dim3(threads), lds, stream,
-	                   a->k, a->ctaps, a->notch, P, a->S, a->C, a->first_frame, a->frame_stride);
+	hipLaunchKernelGGL((hvk_k_raster<NT, SECAM, SV, EXTRAS, WC, LV>), dim3(((a->linelist ? a->nlist : a->k.slab_lines) + 7) & ~7, a->nframes), dim3(threads), lds, stream,
+	                   a->k, a->ctaps, a->notch, P, a->S, a->C, a->first_frame, a->frame_stride, a->linelist, a->nlist);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

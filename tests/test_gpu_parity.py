@@ -109,7 +109,8 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
 
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
                                   "pal_bb_filter", "i_20m", "i_offset", "m_offset_pass", "g_a2", "m_a2", "i_27m", "d_full", "palm_full",
-                                  "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster", "pal_9m", "i_24m", "m_4fsc"])
+                                  "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster", "pal_9m", "i_24m", "m_4fsc",
+                                  "i_tt", "l_tt", "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "i_acp_cc", "m_acp_cc", "i_wss_auto"])
 def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
     """The plain configurations render in one kernel from picture planes (hvk_direct.hip) by default -- that is what
     the digest tests above run. HVK_DIRECT=0 keeps the raster + filter kernel pair for them: same digests."""
@@ -118,8 +119,9 @@ def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
     conf, sr = golden.conf(case)
     nframes = c["frames"]
     with H.Engine(conf, sr, device=0, max_frames=2) as e:
-        assert not e.kernel_names()[0].startswith("hvk_k_direct")
+        assert not any(n.startswith("hvk_k_direct") for n in e.kernel_names())
     iq = _render(conf, sr, golden.frame(case), golden.audio, nframes, batch=2,
+                 teletext=(lambda f: golden.teletext_rows(f, golden.teletext_skip(case))) if c.get("teletext") else None,
                  passthru=util.passthru_signal() if conf.passthru else None, pixel_rate=c.get("pixel_rate", 0))
     fs = c.get("frame_samples", c["width"] * c["lines"])
     ends = c.get("frame_ends") or [(n + 1) * fs for n in range(nframes)]       # (rate pairs with frames of two lengths list them)
