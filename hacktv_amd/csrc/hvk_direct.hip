@@ -495,9 +495,9 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *L
 extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames)
 {
 	if(k->s_video || k->rawbb || k->rs_L || k->sis || k->fields != 1 || k->fm_video) return(0);        /* (VBI data lines and test signals: rows of their own per frame, hvk_dptrs_t.ovr_idx) */
-	/* SECAM: the sub-carrier comes from the colour chain's slab, indexed with 32 bits; the identification lines are the
-	 * raster kernel's optional stages */
-	if(k->secam && (secam_fid || (int64_t) (max_frames + 1) * k->raster_samples >= 0x7FFFFFFF)) return(0);
+	/* SECAM: the sub-carrier comes from the colour chain's slab, indexed with 32 bits */
+	(void) secam_fid;       /* (the identification lines: rows of their own per frame, like the VBI data lines) */
+	if(k->secam && (int64_t) (max_frames + 1) * k->raster_samples >= 0x7FFFFFFF) return(0);
 	if(k->vf_type != 0 && !(k->vf_ntaps == 51 && mfma_a && (k->vf_type == 1 || k->vf_type == 3))) return(0);
 	if(k->width < 544) return(0);               /* a tile's window within three lines */
 	return(1);

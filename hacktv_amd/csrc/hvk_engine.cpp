@@ -432,7 +432,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		e->plane_rows = e->frame_slots * k.lines + 3;
 		e->plane_carry_row = e->frame_slots * k.lines;
 		e->plane_zero_row = e->plane_carry_row + 2;
-		if(k.vbi || k.vits)
+		if(k.vbi || k.vits || (k.secam && e->t.conf.secam_field_id))
 		{
 			std::vector<uint8_t> held((size_t) k.lines, 0);
 			std::vector<int16_t> list, idx((size_t) k.lines, -1);

@@ -110,7 +110,7 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
                                   "pal_bb_filter", "i_20m", "i_offset", "m_offset_pass", "g_a2", "m_a2", "i_27m", "d_full", "palm_full",
                                   "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster", "pal_9m", "i_24m", "m_4fsc",
-                                  "i_tt", "l_tt", "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "i_acp_cc", "m_acp_cc", "i_wss_auto"])
+                                  "i_tt", "l_tt", "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "i_acp_cc", "m_acp_cc", "i_wss_auto", "l_fid", "secam_fid4"])
 def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
     """The plain configurations render in one kernel from picture planes (hvk_direct.hip) by default -- that is what
     the digest tests above run. HVK_DIRECT=0 keeps the raster + filter kernel pair for them: same digests."""
