@@ -733,7 +733,7 @@ def test_frame_numbers_far_beyond_32_bits_of_samples(golden):
                                      ("i", 12000000), ("i", 14000000), ("i", 27000000), ("g", 18000000), ("pal", 15000000),
                                      ("m", 12272727), ("m", 27000000), ("ntsc", 18000000),
                                      ("l", 20250000), ("l", 27000000), ("secam", 18000000),
-                                     ("pal", 7000000), ("m", 8000000), ("i", 9000000), ("i", 10000000), ("m", 24000000), ("i", 25000000),
+                                     ("pal", 5500000), ("ntsc", 6000000), ("pal", 7000000), ("m", 8000000), ("i", 9000000), ("i", 10000000), ("m", 24000000), ("i", 25000000),
                                      ("l", 24000000), ("ntsc", 30000000), ("pal", 32000000), ("i", 33000000)])
 def test_odd_line_widths(golden, mode, sr):
     """A sweep over sample rates: every chroma filter length that has a kernel (5 .. 25 taps), lines from
