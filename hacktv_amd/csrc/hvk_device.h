@@ -49,6 +49,8 @@ typedef int    int_a2  __attribute__((aligned(2)));
 #define HVK_PIX_PASSES 8      /* the raster block has >= width / 8 lanes */
 
 __device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
+/* the middle one of three (v_med3_i32): a clamp when lo <= hi */
+__device__ __forceinline__ int med3i(int v, int lo, int hi) { return(v < lo ? lo : (v > hi ? hi : v)); }
 __device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 __device__ __forceinline__ int dot2(int a, int b, int c)
 {
@@ -103,6 +105,8 @@ __device__ __forceinline__ void fir8(const int *d, const int *tp, int (&acc)[SPL
 /* RGB -> (Y, U, V) levels of one colour: src/video.c:3917-3958, same order of operations, no
  * contraction. Used to expand the 2^24-entry table once per engine and, when the pictures have too
  * many colours for the table's cache lines to be found again (moving video), per pixel. */
+/* SEC: -1 the mode's kind (SECAM or not) is read from the parameters, 0 / 1: known when the kernel is compiled */
+template<int SEC = -1>
 __device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p)
 {
 	double r = p.glut[(c & 0xFF0000) >> 16];
@@ -115,7 +119,7 @@ __device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p
 	v = (r - y) * p.ev;
 
 	y = (p.black + (y * p.range)) * p.level;
-	if(!p.secam)
+	if(SEC < 0 ? !p.secam : !SEC)
 	{
 		u *= p.chroma_scale;
 		v *= p.chroma_scale;

@@ -37,16 +37,40 @@
  */
 #include "hvk_device.h"
 #include <stddef.h>
+#include <stdlib.h>
 
 #define DG    4                     /* tiles per workgroup (2 and 8 measured: 3 % and 6 % slower) */
 #define DLEAD 26                    /* window position 0 is this many samples before the tile's first output (_mfma_taps) */
 
 /* ------------------------------------------------------------------ */
 
+/* A picture's descriptor as the raster stages want it, from the slot it lies in (hvk_prepgeo_t: src/video.c:4887-4897's
+ * centring included) */
+__device__ __forceinline__ hvk_framedesc_t prep_fdesc(const hvk_kconst_t &k, const hvk_prepgeo_t &g, const int pic)
+{
+	hvk_framedesc_t f;
+	const int slot = g.slot0 + pic;
+	f.frame_index = 0;
+	f.fb_offset = (int64_t) slot * g.frame_px;
+	f.fb_width = g.fb_valid ? g.fb_width : 0;
+	f.fb_height = g.fb_valid ? g.fb_height : 0;
+	f.pixel_stride = 1;
+	f.line_stride = g.fb_width;
+	f.vframe_x = (k.active_width - f.fb_width) / 2;
+	f.vframe_y = (k.active_lines - f.fb_height) / 2;
+	f.fb_interlaced = g.fb_interlaced;
+	f.fb_valid = g.fb_valid;
+	f.clut_off0 = 0;
+	f.parity = 0;
+	f.plane_row0 = slot * k.lines;
+	f.pad = 0;
+	return(f);
+}
+
 template<int NT, int WC, int LV, int SECAM>
 __global__ __launch_bounds__(1024)
 void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_packed_taps_t notch, const hvk_rptrs_t P,
-                int16_t *__restrict__ Lp, int *__restrict__ Cp)
+                int16_t *__restrict__ Lp, int *__restrict__ Cp, const hvk_prepgeo_t geo)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
 
@@ -59,7 +83,7 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_p
 	const int rel = (int) blockIdx.x;
 	const int pic = (int) blockIdx.y;
 
-	const hvk_framedesc_t f = P.fdesc[__builtin_amdgcn_readfirstlane(pic)];
+	const hvk_framedesc_t f = prep_fdesc(k, geo, pic);
 	hvk_linedesc_t d = P.desc[__builtin_amdgcn_readfirstlane(rel)];
 	{
 		/* chroma wherever a frame of either parity has it: the parity decides at render time */
@@ -108,6 +132,211 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_p
 		{
 			if(x0 + i >= W) break;
 			Lp[at + i] = (int16_t) s[i];
+			if(NT > 1) Cp[at + i] = c[i];
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+
+/* The same planes for the PAL / NTSC / monochrome modes, 8 PIXELS PER LANE: a lane loads the 8 pixels under its own 8
+ * samples (two 16-byte loads: the pool's pictures are dense), turns them into levels and keeps the luma in registers;
+ * only the two chroma channels pass through LDS, written as one 16-byte vector per lane and channel -- zeros and the
+ * reference's over-read samples included, so there is no clearing pass -- and read back as the low pass's
+ * windows (index j <-> sample j - HVK_CHROMA_LEAD: writes are aligned, a window is read from the aligned chunk in front of
+ * it). One barrier per line. What it computes is raster_compute<..., PREP = 1>'s, stage by stage (hvk_device.h); the parity
+ * tests run every plain configuration through it and through the raster + filter kernel pair.
+ * src/video.c:2961-3029 (luma, chroma, low pass, burst). */
+template<int NT, int WC, int LV>
+__global__ __launch_bounds__(1024)
+void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
+                 int16_t *__restrict__ Lp, int *__restrict__ Cp, const hvk_prepgeo_t geo)
+{
+	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
+	constexpr int H = NT / 2;
+	constexpr int LEAD = HVK_CHROMA_LEAD;
+	constexpr int BACK = H <= 8 ? 8 : 16;       /* a window is read from this many samples in front of the lane's first */
+	static_assert(H <= 16 && LEAD >= 16, "chroma window");
+
+	if((int) blockIdx.x >= k.lines) return;
+	const int W = WC ? WC : k.width;
+	const int t = threadIdx.x;
+	if(WC) __builtin_assume(t * SPL + SPL <= WC);
+	const int x0 = t * SPL;
+	const int rel = (int) blockIdx.x;
+	const int pic = (int) blockIdx.y;
+
+	const hvk_framedesc_t f = prep_fdesc(k, geo, pic);
+	hvk_linedesc_t d = P.desc[__builtin_amdgcn_readfirstlane(rel)];
+	{
+		/* chroma wherever a frame of either parity has it: the parity decides at render time */
+		const hvk_linedesc_t d1 = P.desc[__builtin_amdgcn_readfirstlane(k.lines + rel)];
+		d.pal = (int16_t) ((d.pal | d1.pal) ? 1 : 0);
+	}
+	const hvk_line_t L = raster_setup_core<0, 0>(k, P, f, d, pic, rel, rel, true, false);
+	const bool pal = NT > 1 && L.pal != 0;
+
+	const int CL = raster_CL(W);
+	int16_t *U = lds, *V = lds + CL;
+
+	/* ---- loads: the lane's 8 pixels (the pool's first ones where it has none: never used), the line's base, burst
+	 * window, over-read samples ---- */
+	/* which of the lane's 8 samples show a pixel: [plo, phi); which are assigned luma (or black): [alo, ahi). The 16-bit
+	 * element masks of such runs are tabulated behind the over-read samples (hvk_engine.cpp), [lo * 9 + hi] */
+	const int plo = med3i(L.ax0 - x0, 0, SPL), phi = med3i(L.ax1 - x0, 0, SPL);
+	const int alo = L.active ? med3i(L.d.al - x0, 0, SPL) : 0, ahi = L.active ? med3i(L.ar_eff - x0, 0, SPL) : 0;
+	const bool lane_pix = phi > plo;            /* (no picture on the line: ax0 = ax1 = 0) */
+	const uint32_t *row = lane_pix ? P.pool + L.row_off + x0 : P.pool;
+	const int4u pa = ((const int4u *) row)[0], pb = ((const int4u *) row)[1];
+	const int4v *runs = (const int4v *) ((const char *) P.ghost + HVK_RUNMASK_OFFSET);
+	const int4v mkp = runs[phi > plo ? plo * 9 + phi : 0], mka = runs[ahi > alo ? alo * 9 + ahi : 0];
+	hvk_side_t sd;
+	int c[SPL];
+	raster_load_side<NT, WC, 0, 1>(k, P, L, t, sd, c);         /* (c[]: zeros -- a line without chroma) */
+
+	/* ---- levels, as pairs of int16: luma, and the two chroma channels where the line has a picture ---- */
+	int yp[SPL / 2], up[SPL / 2], vp[SPL / 2];
+	if(L.has_pix)
+	{
+		unsigned px[SPL] = { (unsigned) pa.x, (unsigned) pa.y, (unsigned) pa.z, (unsigned) pa.w, (unsigned) pb.x, (unsigned) pb.y, (unsigned) pb.z, (unsigned) pb.w };
+		int2v lv[SPL];
+		/* the pixels are first needed HERE (the table's addresses are not prepared, and the loads not waited for, where they were issued) */
+#pragma unroll
+		for(int i = 0; i < SPL; i++) asm volatile("" : "+v"(px[i]));
+#pragma unroll
+		for(int i = 0; i < SPL; i++)
+		{
+			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<0>(px[i] & 0xFFFFFFu, *P.yuvp));
+			else lv[i] = ((const int2v *) P.yuv)[px[i] & 0xFFFFFFu];
+		}
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++)
+		{
+			/* an entry is { y | u << 16, v }: the low halves, the high halves of two neighbours' */
+			yp[m] = (int) __builtin_amdgcn_perm((unsigned) lv[2 * m + 1].x, (unsigned) lv[2 * m].x, 0x05040100u);
+			up[m] = (int) __builtin_amdgcn_perm((unsigned) lv[2 * m + 1].x, (unsigned) lv[2 * m].x, 0x07060302u);
+			vp[m] = (int) __builtin_amdgcn_perm((unsigned) lv[2 * m + 1].y, (unsigned) lv[2 * m].y, 0x05040100u);
+		}
+	}
+	else
+	{
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++) yp[m] = up[m] = vp[m] = 0;
+	}
+	const int mp[SPL / 2] = { mkp.x, mkp.y, mkp.z, mkp.w }, ma[SPL / 2] = { mka.x, mka.y, mka.z, mka.w };
+#pragma unroll
+	for(int m = 0; m < SPL / 2; m++) { up[m] &= mp[m]; vp[m] &= mp[m]; }
+
+	/* ---- the chroma channels into LDS ---- */
+	if(pal)
+	{
+		if(x0 < W)
+		{
+			if(!WC && x0 + SPL > W)
+			{
+				/* the lane that straddles the line's end: the over-read samples behind it are this vector's too */
+#pragma unroll
+				for(int i = 0; i < SPL; i++)
+				{
+					const int g = x0 + i - W;
+					if(g >= 0 && g < H)
+					{
+						const int gu = P.ghost[2 * g + 0], gv = P.ghost[2 * g + 1];
+						up[i / 2] = (i & 1) ? ((up[i / 2] & 0xFFFF) | (gu << 16)) : ((up[i / 2] & (int) 0xFFFF0000u) | (gu & 0xFFFF));
+						vp[i / 2] = (i & 1) ? ((vp[i / 2] & 0xFFFF) | (gv << 16)) : ((vp[i / 2] & (int) 0xFFFF0000u) | (gv & 0xFFFF));
+					}
+				}
+			}
+			*(int4v *) (U + LEAD + x0) = (int4v) { up[0], up[1], up[2], up[3] };
+			*(int4v *) (V + LEAD + x0) = (int4v) { vp[0], vp[1], vp[2], vp[3] };
+		}
+		/* what lies in front of the line: zeros (src/fir.c:357-375: no history) */
+		if(t < LEAD / 8) { *(int4v *) (U + t * 8) = (int4v) { 0, 0, 0, 0 }; *(int4v *) (V + t * 8) = (int4v) { 0, 0, 0, 0 }; }
+		/* ... and behind it, from the next multiple of 8 on: the over-read samples */
+		if(t < H)
+		{
+			const int x = W + t;
+			if(x >= ((W + 7) & ~7)) { U[LEAD + x] = (int16_t) sd.ghost_u; V[LEAD + x] = (int16_t) sd.ghost_v; }
+		}
+	}
+	if(pal) __syncthreads();
+
+	/* ---- the line without its sub-carrier: blanking and sync pulses, luma assigned over them -- the picture where the
+	 * frame covers the line, black elsewhere (src/video.c:2961-3009) ---- */
+	int sp[SPL / 2];
+	{
+		const int bs[SPL / 2] = { sd.base.x, sd.base.y, sd.base.z, sd.base.w };
+		const int blk = (k.black_y & 0xFFFF) | (k.black_y << 16);
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++)
+		{
+			const int lum = (yp[m] & mp[m]) | (blk & ~mp[m]);
+			sp[m] = (lum & ma[m]) | (bs[m] & ~ma[m]);
+		}
+	}
+
+	/* ---- (V, U): zero-history low pass (src/fir.c:357-375), burst written over it (src/video.c:3024-3029) ---- */
+	if(pal && x0 < W)
+	{
+		int vu[SPL];
+		if(L.has_pix || x0 + SPL + H > W)
+		{
+			constexpr int NP = (NT + 1) / 2;
+			constexpr int E0 = BACK - H;                    /* the window's first element within the chunks read */
+			constexpr int ND = E0 / 2 + SPL / 2 + NP + 1;   /* dwords fir8 looks at, from the chunks' first */
+			constexpr int NQ = (ND + 3) / 4;
+			int du[NQ * 4], dv[NQ * 4], u[SPL], v[SPL];
+			const int4v *pu = (const int4v *) (U + LEAD - BACK + x0), *pv = (const int4v *) (V + LEAD - BACK + x0);
+#pragma unroll
+			for(int m = 0; m < NQ; m++)
+			{
+				const int4v a = pu[m], b = pv[m];
+				du[m * 4 + 0] = a.x; du[m * 4 + 1] = a.y; du[m * 4 + 2] = a.z; du[m * 4 + 3] = a.w;
+				dv[m * 4 + 0] = b.x; dv[m * 4 + 1] = b.y; dv[m * 4 + 2] = b.z; dv[m * 4 + 3] = b.w;
+			}
+			fir8<NT, E0 & 1>(du + E0 / 2, ctaps.p, u);
+			fir8<NT, E0 & 1>(dv + E0 / 2, ctaps.p, v);
+#pragma unroll
+			for(int i = 0; i < SPL; i++) vu[i] = sat_pack16(v[i] >> 15, u[i] >> 15);
+		}
+		else
+		{
+#pragma unroll
+			for(int i = 0; i < SPL; i++) vu[i] = 0;
+		}
+
+		if(x0 + SPL > k.burst_left && x0 < k.burst_left + k.burst_width)
+		{
+			const int4v bwv = sd.bwin;
+			const int bw[SPL] = { (int) (short) (bwv.x & 0xFFFF), bwv.x >> 16, (int) (short) (bwv.y & 0xFFFF), bwv.y >> 16,
+			                      (int) (short) (bwv.z & 0xFFFF), bwv.z >> 16, (int) (short) (bwv.w & 0xFFFF), bwv.w >> 16 };
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int b = x0 + i - k.burst_left;
+				if(b >= 0 && b < k.burst_width) vu[i] = (((k.burst_q * bw[i]) >> 15) & 0xFFFF) | (((k.burst_i * bw[i]) >> 15) << 16);
+			}
+		}
+#pragma unroll
+		for(int i = 0; i < SPL; i++) c[i] = vu[i];
+	}
+
+	const size_t at = ((size_t) f.plane_row0 + rel) * W + x0;
+	if(x0 + SPL <= W)
+	{
+		*(int4a2 *) (Lp + at) = (int4a2) { sp[0], sp[1], sp[2], sp[3] };
+		if(NT > 1)
+		{
+			((int4u *) (Cp + at))[0] = (int4u) { c[0], c[1], c[2], c[3] };
+			((int4u *) (Cp + at))[1] = (int4u) { c[4], c[5], c[6], c[7] };
+		}
+	}
+	else
+	{
+		for(int i = 0; i < SPL; i++)
+		{
+			if(x0 + i >= W) break;
+			Lp[at + i] = (int16_t) ((i & 1) ? (sp[i / 2] >> 16) : sp[i / 2]);
 			if(NT > 1) Cp[at + i] = c[i];
 		}
 	}
@@ -452,7 +681,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P);
 
 template<int NT>
-static int _launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
+static int _launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
 {
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
@@ -461,31 +690,40 @@ static int _launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int 
 	hvk_rptrs_t P;
 	hvk_raster_ptrs(a, &P);
 	const dim3 grid((a->k.lines + 7) & ~7, npics), block(threads);
-#define PREP(WCV, LVV, SC) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV, SC>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp)
+#define PREP(WCV, LVV, SC) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV, SC>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp, *g)
+#define PREP8(WCV, LVV) hipLaunchKernelGGL((hvk_k_prep8<NT, WCV, LVV>), grid, block, lds, stream, a->k, a->ctaps, P, Lp, Cp, *g)
+	/* (HVK_PREP=1: the one-pixel-per-lane-and-pass kernel built from the raster's stages, kept as the second opinion) */
+	static const int old_prep = getenv("HVK_PREP") ? atoi(getenv("HVK_PREP")) : 0;
 	if(NT == 1 && a->k.secam) { if(a->levels_computed) PREP(0, 1, (NT == 1 ? 1 : 0)); else PREP(0, 0, (NT == 1 ? 1 : 0)); }
-	else if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1, 0); else PREP((NT == 13 ? 1024 : 0), 0, 0); }
-	else { if(a->levels_computed) PREP(0, 1, 0); else PREP(0, 0, 0); }
+	else if(old_prep == 1)
+	{
+		if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1, 0); else PREP((NT == 13 ? 1024 : 0), 0, 0); }
+		else { if(a->levels_computed) PREP(0, 1, 0); else PREP(0, 0, 0); }
+	}
+	else if(NT == 13 && W == 1024) { if(a->levels_computed) PREP8((NT == 13 ? 1024 : 0), 1); else PREP8((NT == 13 ? 1024 : 0), 0); }
+	else { if(a->levels_computed) PREP8(0, 1); else PREP8(0, 0); }
+#undef PREP8
 #undef PREP
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
+extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int npics, int16_t *Lp, int *Cp, hipStream_t stream)
 {
 	if(npics < 1) return(HVK_OK);
 	switch(a->k.colour && !a->k.secam ? a->k.chroma_ntaps : 1)
 	{
-	case 1:  return(_launch_prep<1>(a, npics, Lp, Cp, stream));
-	case 5:  return(_launch_prep<5>(a, npics, Lp, Cp, stream));
-	case 7:  return(_launch_prep<7>(a, npics, Lp, Cp, stream));
-	case 9:  return(_launch_prep<9>(a, npics, Lp, Cp, stream));
-	case 11: return(_launch_prep<11>(a, npics, Lp, Cp, stream));
-	case 13: return(_launch_prep<13>(a, npics, Lp, Cp, stream));
-	case 15: return(_launch_prep<15>(a, npics, Lp, Cp, stream));
-	case 17: return(_launch_prep<17>(a, npics, Lp, Cp, stream));
-	case 19: return(_launch_prep<19>(a, npics, Lp, Cp, stream));
-	case 21: return(_launch_prep<21>(a, npics, Lp, Cp, stream));
-	case 23: return(_launch_prep<23>(a, npics, Lp, Cp, stream));
-	case 25: return(_launch_prep<25>(a, npics, Lp, Cp, stream));
+	case 1:  return(_launch_prep<1>(a, g, npics, Lp, Cp, stream));
+	case 5:  return(_launch_prep<5>(a, g, npics, Lp, Cp, stream));
+	case 7:  return(_launch_prep<7>(a, g, npics, Lp, Cp, stream));
+	case 9:  return(_launch_prep<9>(a, g, npics, Lp, Cp, stream));
+	case 11: return(_launch_prep<11>(a, g, npics, Lp, Cp, stream));
+	case 13: return(_launch_prep<13>(a, g, npics, Lp, Cp, stream));
+	case 15: return(_launch_prep<15>(a, g, npics, Lp, Cp, stream));
+	case 17: return(_launch_prep<17>(a, g, npics, Lp, Cp, stream));
+	case 19: return(_launch_prep<19>(a, g, npics, Lp, Cp, stream));
+	case 21: return(_launch_prep<21>(a, g, npics, Lp, Cp, stream));
+	case 23: return(_launch_prep<23>(a, g, npics, Lp, Cp, stream));
+	case 25: return(_launch_prep<25>(a, g, npics, Lp, Cp, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

@@ -35,6 +35,8 @@
 #define HVK_TIMING_SLOTS 512
 #define HVK_UPLOAD_RING 8
 #define HVK_FETCH_TICKETS 4
+#define HVK_POOL_PAD 4096
+#define HVK_PREP_EVENTS 8
 
 extern "C" {
 int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
@@ -114,6 +116,8 @@ struct hvk_engine {
 	int mfma_ci, mfma_cq;
 	/* per batch */
 	uint32_t *d_pool;
+	uint32_t *d_pool_alloc;     /* (d_pool lies HVK_POOL_PAD pixels inside it and as many lie behind the slots: hvk_k_prep's lanes read the 8 pixels
+	                             * under their 8 samples wherever the line's picture begins and ends, and keep what is picture) */
 	hvk_framedesc_t *d_fdesc;   /* [max_frames][1 + fields]: the frame before (only its last line is looked at:
 	                             * the halo line in front), then one descriptor per field */
 	/* the last line's source row of the last frame staged, kept behind the slots: the next batch's first halo */
@@ -128,6 +132,7 @@ struct hvk_engine {
 	int32_t *d_tile;
 	int16_t *d_out;
 	void *d_conv; size_t conv_bytes;   /* hvk_fetch_as scratch */
+	void *d_sums;               /* hvk_block_sums(): two 64-bit sums */
 
 	/* pinned staging */
 	hvk_framedesc_t *h_fdesc;
@@ -146,8 +151,17 @@ struct hvk_engine {
 	 * write to: rendered whole by the raster kernel per frame, taken by hvk_k_direct instead of the planes' rows */
 	int ovr_n, ovr_row0;
 	int16_t *d_ovr_list, *d_ovr_idx;
-	hvk_framedesc_t *d_pdesc, *h_pdesc;     /* [frame_slots]: the pictures a prep launch works on */
-	hipEvent_t ev_pdesc; int pdesc_busy;    /* behind the list's last copy to the device */
+	/* The planes of the pictures a staged block shows for the first time are made when the block is LAUNCHED, a chunk of
+	 * frames at a time on a stream of their own, each chunk's render behind its planes: hvk_k_prep of chunk c + 1 runs
+	 * beside hvk_k_direct of chunk c (one is bound by memory latency, the other by vector issue), and a chunk's planes
+	 * are read back while they still lie in the 256 MiB Infinity Cache */
+	hipStream_t prep_stream;
+	hipEvent_t ev_fork, ev_prep[HVK_PREP_EVENTS];
+	int prep_chunk;             /* frames per chunk (HVK_PREP_CHUNK) */
+	int prep_streams;           /* 2: the planes on a stream of their own (HVK_PREP_STREAMS) */
+	int prep_pending;           /* the staged block's planes have not been made yet */
+	int32_t *staged_prev;       /* [max_frames] the slot the caller named for the frame before (hvk_stage_strided_prev), -1: none */
+	int carry_copy_pending; size_t carry_from, carry_to;    /* the staged block's last plane row has yet to be kept (525 lines) */
 	int64_t prep_count;         /* pictures the planes were made from so far */
 	/* pinned staging for source frames: a small ring, each buffer guarded by an event recorded behind its copy, so that
 	 * hvk_frame_upload() waits for the copy that last used THAT buffer only -- never for the stream */
@@ -426,7 +440,19 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		for(int i = 0; i < k.burst_width; i++) bw[HVK_PULSE_PAD + i] = e->t.burst_win[i];
 		OPENCHK(_upload(&e->d_burst, bw.data(), bw.size() * sizeof(int16_t)));
 	}
-	OPENCHK(_upload(&e->d_ghost, e->t.ghost, sizeof(e->t.ghost)));
+	{
+		/* the samples the reference reads past its chroma buffer, and behind them (hvk_k_prep8) the masks of runs of a lane's 8
+		 * samples: entry 9 lo + hi has the 16-bit elements lo .. hi - 1 set */
+		std::vector<uint8_t> gb(HVK_RUNMASK_OFFSET + 81 * 16, 0);
+		static_assert(sizeof(e->t.ghost) <= HVK_RUNMASK_OFFSET, "over-read samples in front of the run masks");
+		memcpy(gb.data(), e->t.ghost, sizeof(e->t.ghost));
+		for(int lo = 0; lo <= 8; lo++) for(int hi = lo; hi <= 8; hi++)
+		{
+			uint16_t *m = (uint16_t *) (gb.data() + HVK_RUNMASK_OFFSET + (lo * 9 + hi) * 16);
+			for(int i = lo; i < hi; i++) m[i] = 0xFFFF;
+		}
+		OPENCHK(_upload(&e->d_ghost, gb.data(), gb.size()));
+	}
 	if(e->direct)
 	{
 		e->plane_rows = e->frame_slots * k.lines + 3;
@@ -486,8 +512,14 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			}
 		}
 		if(!e->direct) fprintf(stderr, "libhvk: no exact reciprocal of the line width %d: the raster + filter kernel pair renders\n", k.width);
-		OPENHIP(hipMalloc((void **) &e->d_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots));
-		OPENHIP(hipHostMalloc((void **) &e->h_pdesc, sizeof(hvk_framedesc_t) * e->frame_slots, hipHostMallocDefault));
+		OPENHIP(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
+		OPENHIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+		for(int i = 0; i < HVK_PREP_EVENTS; i++) OPENHIP(hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming));
+		e->prep_chunk = getenv("HVK_PREP_CHUNK") ? atoi(getenv("HVK_PREP_CHUNK")) : 0;
+		e->prep_streams = getenv("HVK_PREP_STREAMS") ? atoi(getenv("HVK_PREP_STREAMS")) : 1;
+		if(e->prep_chunk < 1) e->prep_chunk = max_frames;
+		e->staged_prev = (int32_t *) malloc(sizeof(int32_t) * (size_t) max_frames);
+		if(!e->staged_prev) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
 	}
 	if(k.has_nicam)
 	{
@@ -516,8 +548,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-	OPENHIP(hipMalloc((void **) &e->d_pool, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2));   /* + two kept rows */
-	OPENHIP(hipMemset(e->d_pool, 0, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2));
+	OPENHIP(hipMalloc((void **) &e->d_pool_alloc, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2 + 2 * HVK_POOL_PAD * 4));   /* + two kept rows */
+	OPENHIP(hipMemset(e->d_pool_alloc, 0, frame_px * 4 * e->frame_slots + (size_t) k.active_width * 4 * 2 + 2 * HVK_POOL_PAD * 4));
+	e->d_pool = e->d_pool_alloc + HVK_POOL_PAD;
 	OPENHIP(hipMalloc((void **) &e->d_fdesc, sizeof(hvk_framedesc_t) * max_frames * 3));
 	OPENHIP(hipMalloc((void **) &e->d_S, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
 	if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C, (size_t) max_frames * k.slab_lines * k.width * 2 + 256));
@@ -552,7 +585,6 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipEventCreateWithFlags(&e->up_ev[i], hipEventDisableTiming));
 	}
 	OPENHIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
-	OPENHIP(hipEventCreateWithFlags(&e->ev_pdesc, hipEventDisableTiming));
 	for(int i = 0; i < HVK_FETCH_TICKETS; i++) OPENHIP(hipEventCreateWithFlags(&e->fetch_ev[i], hipEventDisableTiming));
 
 	if(e->t.k.has_carriers)
@@ -755,17 +787,19 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_pdesc, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx };
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_lineoff,
+		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
 		if(e->h_secam_count) (void) hipHostFree(e->h_secam_count);
 		if(e->h_secam_carry) (void) hipHostFree(e->h_secam_carry);
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
-		if(e->ev_pdesc) (void) hipEventDestroy(e->ev_pdesc);
+		if(e->ev_fork) (void) hipEventDestroy(e->ev_fork);
+		for(int i = 0; i < HVK_PREP_EVENTS; i++) if(e->ev_prep[i]) (void) hipEventDestroy(e->ev_prep[i]);
+		if(e->prep_stream) { (void) hipStreamSynchronize(e->prep_stream); (void) hipStreamDestroy(e->prep_stream); }
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
-		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_pdesc, e->h_sis_bits, e->h_secam_rows, e->h_frec };
+		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_sis_bits, e->h_secam_rows, e->h_frec };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
 	}
@@ -781,6 +815,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	free(e->slots);
 	free(e->staged_slots);
 	free(e->staged_slots2);
+	free(e->staged_prev);
 	hvk_audio_free(e->audio);
 	hvk_tables_free(&e->t);
 	free(e);
@@ -1536,60 +1571,93 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 /* The picture planes (hvk_direct.hip) of those of the named slots whose picture is new since its planes were made: one
  * prep launch for the pictures whose levels are looked up, one for those whose levels are computed. On the engine's
  * stream: behind the pictures' uploads, in front of every later render. */
-static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n)
+/* The planes of those of the named slots whose picture is new since its planes were made, on `stream`: runs of
+ * neighbouring slots with pictures of one geometry go into one launch, which gets the run as an argument -- nothing is
+ * copied to the device and nothing waited for. Returns the number of pictures worked on (< 0: failure). */
+static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t stream)
 {
 	const hvk_kconst_t &k = e->t.k;
-	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-	int np[2] = { 0, 0 };
+	std::vector<int> todo;
 
 	for(int i = 0; i < n; i++)
 	{
 		const int sl = slots[i];
-		if(sl < 0 || sl >= e->frame_slots) continue;
-		hvk_slot_t *ss = &e->slots[sl];
-		if(!ss->plane_dirty) continue;
-		if(np[0] + np[1] == 0 && e->pdesc_busy) { HIPCHK(hipEventSynchronize(e->ev_pdesc)); e->pdesc_busy = 0; }    /* the list's last copy has left it */
-		const int lv = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours);
-		/* looked-up pictures from the list's front, computed ones from its end: a slot is in one of them, once */
-		hvk_framedesc_t *d = &e->h_pdesc[lv ? e->frame_slots - 1 - np[1] : np[0]];
-		np[lv]++;
-		memset(d, 0, sizeof(*d));
-		d->fb_offset = (int64_t) sl * frame_px;
-		d->fb_width = ss->valid ? ss->width : 0;
-		d->fb_height = ss->valid ? ss->height : 0;
-		d->pixel_stride = 1;
-		d->line_stride = ss->width;
-		d->vframe_x = (k.active_width - d->fb_width) / 2;
-		d->vframe_y = (k.active_lines - d->fb_height) / 2;
-		d->fb_interlaced = ss->interlaced;
-		d->fb_valid = ss->valid;
-		d->plane_row0 = sl * k.lines;
-		ss->plane_dirty = 0;
+		if(sl < 0 || sl >= e->frame_slots || !e->slots[sl].plane_dirty) continue;
+		e->slots[sl].plane_dirty = 0;
+		todo.push_back(sl);
 	}
-	for(int lv = 0; lv < 2; lv++)
+	if(todo.empty()) return(0);
+	std::sort(todo.begin(), todo.end());
+
+	auto kind = [&](int sl, hvk_prepgeo_t *g) -> int
 	{
-		if(np[lv] == 0) continue;
-		const int at = lv ? e->frame_slots - np[1] : 0;
-		hvk_raster_args_t ra;
-		hvk_filter_args_t fa;
-		HIPCHK(hipMemcpyAsync(e->d_pdesc + at, e->h_pdesc + at, sizeof(hvk_framedesc_t) * np[lv], hipMemcpyHostToDevice, e->stream));
-		_kernel_args(e, &ra, &fa, NULL, 1);
-		ra.fdesc = e->d_pdesc + at;
+		const hvk_slot_t *ss = &e->slots[sl];
+		g->fb_width = ss->valid ? ss->width : 0;
+		g->fb_height = ss->valid ? ss->height : 0;
+		g->fb_interlaced = ss->interlaced;
+		g->fb_valid = ss->valid;
+		return(e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours));
+	};
+
+	hvk_raster_args_t ra;
+	hvk_filter_args_t fa;
+	_kernel_args(e, &ra, &fa, NULL, 1);
+	for(size_t i = 0; i < todo.size();)
+	{
+		hvk_prepgeo_t g, g2;
+		memset(&g, 0, sizeof(g));
+		const int lv = kind(todo[i], &g);
+		size_t j = i + 1;
+		for(; j < todo.size() && todo[j] == todo[j - 1] + 1; j++)
+		{
+			memset(&g2, 0, sizeof(g2));
+			if(kind(todo[j], &g2) != lv || g2.fb_width != g.fb_width || g2.fb_height != g.fb_height || g2.fb_interlaced != g.fb_interlaced || g2.fb_valid != g.fb_valid) break;
+		}
+		g.slot0 = todo[i];
+		g.frame_px = (int64_t) k.active_width * k.active_lines;
 		ra.levels_computed = lv;
-		int r = hvk_launch_prep(&ra, np[lv], e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, e->stream);
+		const int r = hvk_launch_prep(&ra, &g, (int) (j - i), e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, stream);
 		if(r != HVK_OK) return(r);
-		e->prep_count += np[lv];
+		e->prep_count += (int64_t) (j - i);
+		i = j;
 	}
-	if(np[0] + np[1])
-	{
-		HIPCHK(hipEventRecord(e->ev_pdesc, e->stream));
-		e->pdesc_busy = 1;
-	}
+	return((int) todo.size());
+}
+
+/* ... of the staged block's frames [y0, y0 + n) (and of the slots named for the frames before them) */
+static int _prep_staged(hvk_engine *e, int y0, int n, hipStream_t stream)
+{
+	int r = _prep_dirty(e, e->staged_slots + y0, n, stream);
+	if(r < 0) return(r);
+	const int r2 = _prep_dirty(e, e->staged_prev + y0, n, stream);
+	return(r2 < 0 ? r2 : r + r2);
+}
+
+/* the last plane row of the staged block's last frame, kept for the next block's first frame (its slot may hold another
+ * picture by then): behind the launch that made the planes */
+static int _carry_copy(hvk_engine *e)
+{
+	if(!e->carry_copy_pending) return(HVK_OK);
+	const size_t W = e->t.k.width;
+	HIPCHK(hipMemcpyAsync(e->d_Lp + e->carry_to, e->d_Lp + e->carry_from, W * 2, hipMemcpyDeviceToDevice, e->stream));
+	if(e->d_Cp) HIPCHK(hipMemcpyAsync(e->d_Cp + e->carry_to, e->d_Cp + e->carry_from, W * 4, hipMemcpyDeviceToDevice, e->stream));
+	e->carry_copy_pending = 0;
 	return(HVK_OK);
 }
 
-/* The planes of the named slots made now -- again, if they exist: what a caller does who wants the per-picture work
- * inside a clock of its own (bench.py), or out of the way before a stage. */
+/* A block that was staged and never launched: its planes are made all the same (the next block's first frame may look
+ * into its last one's) */
+static int _flush_planes(hvk_engine *e)
+{
+	if(!e->direct || !e->prep_pending) return(HVK_OK);
+	const int r = _prep_staged(e, 0, e->staged, e->stream);
+	if(r < 0) return(r);
+	e->prep_pending = 0;
+	return(_carry_copy(e));
+}
+
+/* The planes of the named slots are made again before the next render shows them: what a caller does who wants the
+ * per-picture work inside a clock of its own (bench.py). */
 extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 {
 	if(!e || !slots || n < 0) return(HVK_ERROR);
@@ -1601,9 +1669,8 @@ extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 		memset(e->slots[slots[i]].seeds_valid, 0, sizeof(e->slots[slots[i]].seeds_valid));
 	}
 	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
-	HIPCHK(hipSetDevice(e->device));
 	for(int i = 0; i < n; i++) e->slots[slots[i]].plane_dirty = 1;
-	return(_prep_dirty(e, slots, n));
+	return(HVK_OK);
 }
 
 static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
@@ -1645,6 +1712,10 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
 
 	HIPCHK(hipSetDevice(e->device));
+	{
+		int r = _flush_planes(e);           /* (a block staged and not launched) */
+		if(r != HVK_OK) return(r);
+	}
 	/* the pinned side buffers are reused: the copies of the stage before have to be through. (Not the whole stream: a
 	 * read-back queued with hvk_fetch_async() goes on while this stage's host pre-passes run.) */
 	if(k.fm_video) HIPCHK(hipStreamSynchronize(e->stream));
@@ -1868,10 +1939,9 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	}
 	if(e->direct)
 	{
-		/* the picture planes of every picture this batch shows that is new since its planes were made */
-		int r = _prep_dirty(e, e->staged_slots, nframes);
-		if(r == HVK_OK && prev_slots) r = _prep_dirty(e, prev_slots, nframes);
-		if(r != HVK_OK) { e->poisoned = 1; return(r); }
+		/* the picture planes of every picture this batch shows that is new since its planes were made: when it is launched */
+		for(int i = 0; i < nframes; i++) e->staged_prev[i] = (prev_slots && prev_slots[i] >= 0 && prev_slots[i] < e->frame_slots) ? prev_slots[i] : -1;
+		e->prep_pending = 1;
 	}
 	{
 		/* keep what the last frame of this batch shows on its last line */
@@ -1895,9 +1965,10 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 			if(e->direct)
 			{
 				/* ... and its planes' last row: the slot may hold another picture by then */
-				const size_t W = k.width, from = ((size_t) last->plane_row0 + k.lines - 1) * W + 16, to = ((size_t) e->plane_carry_row + e->carry_row) * W + 16;
-				HIPCHK(hipMemcpyAsync(e->d_Lp + to, e->d_Lp + from, W * 2, hipMemcpyDeviceToDevice, e->stream));
-				if(e->d_Cp) HIPCHK(hipMemcpyAsync(e->d_Cp + to, e->d_Cp + from, W * 4, hipMemcpyDeviceToDevice, e->stream));
+				const size_t W = k.width;
+				e->carry_from = ((size_t) last->plane_row0 + k.lines - 1) * W + 16;
+				e->carry_to = ((size_t) e->plane_carry_row + e->carry_row) * W + 16;
+				e->carry_copy_pending = 1;         /* (copied behind the launch that makes the planes) */
 				e->carry.plane_row0 = e->plane_carry_row + e->carry_row - (k.lines - 1);
 			}
 		}
@@ -2068,27 +2139,69 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.D.creg = e->clut_reg;
 		da.D.zero_row = e->plane_zero_row;
 		da.D.desc = (const hvk_linedesc_t *) e->d_desc;
-		da.D.fdesc = e->d_fdesc;
 		da.D.lineoff = e->d_lineoff;
 		da.D.inv_w = e->inv_w;
-		da.D.chroma = e->d_chroma;
 		da.D.ovr_idx = e->d_ovr_idx;
-		da.D.ovr_row0 = e->ovr_row0;
 		da.D.ovr_n = e->ovr_n;
-		da.D.chroma_zero = (int) ((size_t) e->max_frames * e->t.k.raster_samples + 16);
-		da.carriers = fa.carriers;
-		da.tilesyms = fa.tilesyms;
 		da.nicam_tapd = fa.nicam_tapd;
 		da.nicam_cca = fa.nicam_cca;
 		da.mfma_a = fa.mfma_a;
 		da.mfma_ci = fa.mfma_ci;
 		da.mfma_cq = fa.mfma_cq;
-		da.iq = fa.iq;
-		da.nframes = fa.nframes;
 		da.out_stride = out_stride;
-		da.first_frame = e->staged_first;
 		da.frame_stride = e->staged_stride;
-		if((r = hvk_launch_direct(&da, e->stream)) != HVK_OK) return(r);
+		/* frames [y0, y0 + n) of the staged block */
+		auto direct_range = [&](const int y0, const int n) -> int
+		{
+			const size_t FS = (size_t) e->t.k.frame_samples;
+			da.D.fdesc = e->d_fdesc + 2 * (size_t) y0;
+			da.D.chroma = e->d_chroma ? e->d_chroma + (size_t) y0 * e->t.k.raster_samples : NULL;
+			da.D.chroma_zero = (int) ((size_t) (e->max_frames - y0) * e->t.k.raster_samples + 16);
+			da.D.ovr_row0 = e->ovr_row0 + y0 * e->ovr_n;
+			da.carriers = fa.carriers ? fa.carriers + (size_t) y0 * FS : NULL;
+			da.tilesyms = fa.tilesyms ? fa.tilesyms + (size_t) y0 * e->tiles * HVK_NICAM_ROW : NULL;
+			da.iq = fa.iq + (size_t) y0 * (size_t) out_stride * FS * 2;
+			da.nframes = n;
+			da.first_frame = e->staged_first + (int64_t) y0 * e->staged_stride;
+			return(hvk_launch_direct(&da, e->stream));
+		};
+		bool dirty = false;
+		for(int i = 0; i < e->staged && e->prep_pending && !dirty; i++)
+		{
+			dirty = e->slots[e->staged_slots[i]].plane_dirty || (e->staged_prev[i] >= 0 && e->slots[e->staged_prev[i]].plane_dirty);
+		}
+		if(!dirty)
+		{
+			if((r = direct_range(0, e->staged)) != HVK_OK) return(r);
+		}
+		else
+		{
+			/* new pictures: their planes chunk by chunk on the second stream (behind everything queued so far: the pictures'
+			 * uploads, the renders that still read the planes' old contents), each chunk's render behind its planes */
+			const bool two = e->prep_streams == 2;
+			hipStream_t ps = two ? e->prep_stream : e->stream;
+			if(two)
+			{
+				HIPCHK_P(hipEventRecord(e->ev_fork, e->stream));
+				HIPCHK_P(hipStreamWaitEvent(e->prep_stream, e->ev_fork, 0));
+			}
+			int ci = 0;
+			for(int y0 = 0; y0 < e->staged; y0 += e->prep_chunk, ci++)
+			{
+				const int n = std::min(e->prep_chunk, e->staged - y0);
+				const int np = _prep_staged(e, y0, n, ps);
+				if(np < 0) { e->poisoned = 1; return(np); }
+				if(np > 0 && two)
+				{
+					hipEvent_t evp = e->ev_prep[ci % HVK_PREP_EVENTS];
+					HIPCHK_P(hipEventRecord(evp, e->prep_stream));
+					HIPCHK_P(hipStreamWaitEvent(e->stream, evp, 0));
+				}
+				if((r = direct_range(y0, n)) != HVK_OK) { e->poisoned = 1; return(r); }
+			}
+		}
+		e->prep_pending = 0;
+		if((r = _carry_copy(e)) != HVK_OK) return(r);
 	}
 	else
 	{
@@ -2303,6 +2416,41 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 }
 
 extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
+extern "C" void *hvk_engine_stream(hvk_engine_t *e) { return(e ? (void *) e->stream : NULL); }
+
+extern "C" int hvk_last_line_shows_picture(const hvk_engine_t *e)
+{
+	if(!e) return(0);
+	const hvk_linedesc_t *dl = &e->t.desc[e->t.k.lines - 1];
+	return(dl->ar > dl->al && !e->t.k.rawbb);
+}
+
+extern "C" int hvk_stream_is_one_chain(const hvk_engine_t *e)
+{
+	if(!e) return(0);
+	const hvk_kconst_t &k = e->t.k;
+	return(k.secam || k.fm_video || k.rs_irr || k.has_passthru || k.rawbb);
+}
+
+/* hvk_k_sums: a grid-stride pass over the words, a lane's two partial sums folded through the wave and one pair of
+ * 64-bit atomic adds per wave (the sums are modulo 2^64: any order gives the same) */
+extern "C" int hvk_launch_sums(const void *iq, size_t count, unsigned long long *sums, hipStream_t stream);
+
+extern "C" int hvk_block_sums(hvk_engine_t *e, size_t first, size_t count, uint64_t sums[2])
+{
+	if(!e || !sums) return(HVK_ERROR);
+	if(e->device < 0) return(HVK_NO_DEVICE);
+	if(e->t.k.fm_video) return(HVK_UNSUPPORTED);
+	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
+	HIPCHK(hipSetDevice(e->device));
+	if(!e->d_sums) HIPCHK(hipMalloc((void **) &e->d_sums, 16));
+	HIPCHK(hipMemsetAsync(e->d_sums, 0, 16, e->stream));
+	int r = hvk_launch_sums(e->d_out + first * 2, count, (unsigned long long *) e->d_sums, e->stream);
+	if(r != HVK_OK) return(r);
+	HIPCHK(hipMemcpyAsync(sums, e->d_sums, 16, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(hipStreamSynchronize(e->stream));
+	return(HVK_OK);
+}
 
 /* The kernels hvk_launch() enqueues for this configuration, as rocprofv3 prints them, ';' between
  * them: the launchers' choice of template arguments restated (hvk_kernels.hip, hvk_direct.hip). */

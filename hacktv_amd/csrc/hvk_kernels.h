@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 #include "hvk_internal.h"
 
+#define HVK_RUNMASK_OFFSET 256 /* bytes into the over-read samples' device buffer: [9 * lo + hi] the 16-bit element masks of a lane's samples lo .. hi - 1 */
 #define HVK_CHROMA_LEAD 16   /* int16 of slack either side of a chroma channel in LDS */
 #define HVK_NICAM_SYMS  48   /* symbol slots per filter tile */
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
@@ -161,8 +162,14 @@ int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
-/* picture planes of `npics` pictures: a->fdesc holds one descriptor per picture (plane_row0 says where its rows go) */
-int hvk_launch_prep(const hvk_raster_args_t *a, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
+/* picture planes of the pictures in slots slot0 .. slot0 + npics - 1, all of one geometry: a kernel argument, nothing is
+ * copied to the device for a launch (a slot's picture lies at slot * frame_px of the pool, its planes' rows at slot * lines) */
+typedef struct {
+	int32_t slot0;
+	int32_t fb_width, fb_height, fb_interlaced, fb_valid;
+	int64_t frame_px;
+} hvk_prepgeo_t;
+int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
 int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames);
 int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
 int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream);

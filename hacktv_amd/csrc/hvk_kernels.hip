@@ -890,3 +890,48 @@ extern "C" int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream)
 	if(a->k.vf_type == 3) return(_launch_filter<51, 3, 0>(a, stream));
 	return(HVK_UNSUPPORTED);
 }
+
+/* ------------------------------------------------------------------ */
+/* hvk_block_sums(): s1 = sum w[i], s2 = sum (i + 1) w[i] modulo 2^64 over the words of a run of I/Q pairs */
+
+__global__ __launch_bounds__(256)
+void hvk_k_sums(const uint32_t *__restrict__ w, const size_t count, unsigned long long *__restrict__ sums)
+{
+	unsigned long long s1 = 0, s2 = 0;
+	const size_t stride = (size_t) gridDim.x * blockDim.x * 4;
+	/* four consecutive words per lane and step (16-byte loads where the run starts 16-byte aligned; the tail word by word) */
+	for(size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += stride)
+	{
+		if(i + 4 <= count)
+		{
+			const int4u v = *(const int4u *) (w + i);
+			const unsigned long long a = (unsigned) v.x, b = (unsigned) v.y, c = (unsigned) v.z, d = (unsigned) v.w;
+			s1 += a + b + c + d;
+			s2 += (unsigned long long) (i + 1) * a + (unsigned long long) (i + 2) * b + (unsigned long long) (i + 3) * c + (unsigned long long) (i + 4) * d;
+		}
+		else
+		{
+			for(size_t j = i; j < count; j++) { s1 += w[j]; s2 += (unsigned long long) (j + 1) * w[j]; }
+		}
+	}
+	for(int o = 32; o > 0; o >>= 1)
+	{
+		s1 += __shfl_down(s1, o, 64);
+		s2 += __shfl_down(s2, o, 64);
+	}
+	if((threadIdx.x & 63) == 0)
+	{
+		atomicAdd(&sums[0], s1);
+		atomicAdd(&sums[1], s2);
+	}
+}
+
+extern "C" int hvk_launch_sums(const void *iq, size_t count, unsigned long long *sums, hipStream_t stream)
+{
+	if(count == 0) return(HVK_OK);
+	size_t blocks = (count / 4 + 255) / 256;
+	if(blocks > 4096) blocks = 4096;
+	if(blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(hvk_k_sums, dim3((unsigned) blocks), dim3(256), 0, stream, (const uint32_t *) iq, count, sums);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}

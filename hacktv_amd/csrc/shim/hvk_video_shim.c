@@ -63,6 +63,12 @@
 
 typedef struct {
 	hvk_engine_t *e;
+	/* HVK_DEVICES=0,1,...: the stream's batches go round a group of engines, one per device named (hvk_group_*): batch b
+	 * on engine b mod N, the sound chains handed on in process, every engine's read-back straight into the batch's
+	 * page-locked buffer -- N devices, N PCIe links into the one host stream the rf_* sink reads. `e` is then engine 0
+	 * (tables, line widths) */
+	hvk_group_t *g;
+	hvk_engine_t *fe[2];    /* the engine that renders (and reads back) the batch in buf[i] */
 	hvk_info_t info;
 	int batch;              /* frames per GPU launch */
 	int16_t *iq;            /* the batch being handed out: batch * frame_samples pairs */
@@ -311,6 +317,14 @@ static void _source_closed(vid_t *s)
 	if(m) m->source_closed = 1;
 }
 
+static void _engine_close(shim_t *m)
+{
+	if(m->g) hvk_group_close(m->g);
+	else hvk_close(m->e);
+	m->g = NULL;
+	m->e = NULL;
+}
+
 static int _refuse(const char *what)
 {
 	fprintf(stderr, "hacktv-amd: %s is not rendered by the MI355X engine (see DESIGN.md, scope)\n", what);
@@ -437,8 +451,34 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	m->batch = 8;
 	if((env = getenv("HVK_BATCH")) && atoi(env) > 0) m->batch = atoi(env);
 	if((env = getenv("HVK_DEVICE"))) device = atoi(env);
-
-	r = hvk_open_rates(&m->e, &hc, sample_rate, pixel_rate, device, m->batch);
+	{
+		/* HVK_DEVICES: a list of device ordinals, one engine each (the same device may be named more than once) */
+		int devs[64], nd = 0;
+		if((env = getenv("HVK_DEVICES")))
+		{
+			const char *p = env;
+			while(*p && nd < 64)
+			{
+				char *end;
+				long v = strtol(p, &end, 10);
+				if(end == p) break;
+				devs[nd++] = (int) v;
+				p = *end == ',' ? end + 1 : end;
+			}
+		}
+		if(nd == 1) device = devs[0];
+		if(nd > 1)
+		{
+			if((conf->interlace && conf->interlaced) || conf->raw_bb_file || conf->passthru)
+			{
+				free(m);
+				return(_refuse("--interlace, --raw-bb-file and --passthru on more than one device (HVK_DEVICES)"));
+			}
+			r = hvk_group_open(&m->g, &hc, sample_rate, pixel_rate, devs, nd, m->batch);
+			if(r == HVK_OK) m->e = hvk_group_engine(m->g, 0);
+		}
+		else r = hvk_open_rates(&m->e, &hc, sample_rate, pixel_rate, device, m->batch);
+	}
 	if(r != HVK_OK)
 	{
 		free(m);
@@ -450,7 +490,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 	hvk_get_info(m->e, &m->info);
 	if(m->info.lines > (int) sizeof(m->held) || hvk_vbi_lines_held(m->e, m->held, (int) sizeof(m->held)) != HVK_OK)
 	{
-		hvk_close(m->e);
+		_engine_close(m);
 		free(m);
 		return(VID_ERROR);
 	}
@@ -485,7 +525,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
 		else { free(m->buf[0]); free(m->buf[1]); }
 		free(m->widths);
-		hvk_close(m->e);
+		_engine_close(m);
 		free(m);
 		return(VID_OUT_OF_MEMORY);
 	}
@@ -511,7 +551,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
 		else { free(m->buf[0]); free(m->buf[1]); }
 		free(m->widths);
-		hvk_close(m->e);
+		_engine_close(m);
 		free(m);
 		return(VID_ERROR);
 	}
@@ -578,10 +618,11 @@ void vid_free(vid_t *s)
 			fprintf(stderr, "hacktv-amd: worker: source pulls + picture uploads %.3f s, audio pulls %.3f s, stage + launch %.3f s, read-back queueing %.3f s, waiting for a free buffer %.3f s; consumer: waiting for a batch %.3f s (%lld frames)\n",
 				m->t_pull, m->t_audio, m->t_render, m->t_fetch, m->t_worker_idle, m->t_consumer_wait, (long long) m->frames_done);
 		}
-		hvk_sync(m->e);         /* a read-back the consumer never waited for */
+		if(m->g) { for(int i = 0; i < hvk_group_size(m->g); i++) hvk_sync(hvk_group_engine(m->g, i)); }
+		else hvk_sync(m->e);    /* a read-back the consumer never waited for */
 		if(m->pinned) { hvk_host_free(m->e, m->buf[0]); hvk_host_free(m->e, m->buf[1]); }
 		else { free(m->buf[0]); free(m->buf[1]); }
-		hvk_close(m->e);
+		_engine_close(m);
 		pthread_mutex_destroy(&m->lock);
 		pthread_cond_destroy(&m->cond);
 		free(m->widths);
@@ -620,9 +661,10 @@ size_t vid_get_framebuffer_length(vid_t *s)
 }
 
 /* Pull up to `batch` frames and the audio they need from the source, render them into iq */
-static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
+static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket, hvk_engine_t **eng)
 {
 	double t0 = m->stats ? _now() : 0, t1;
+	hvk_engine_t *const E = m->g ? hvk_group_block_engine(m->g) : m->e;     /* the engine this batch goes to */
 	int32_t slots[512];
 	const int fields = (s->conf.interlace && s->conf.interlaced) ? 2 : 1;
 	int n = 0;
@@ -647,7 +689,8 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 		 * blank frames from then on (src/av.c:55-59) */
 		av_read_video(&s->av, f);
 
-		if(hvk_frame_upload(m->e, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced) != HVK_OK) return(-1);
+		if((m->g ? hvk_group_frame_upload(m->g, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced)
+		        : hvk_frame_upload(m->e, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced)) != HVK_OK) return(-1);
 		slots[slot] = slot;
 		par = f->pixel_aspect_ratio;
 
@@ -656,7 +699,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 		if(s->conf.cc608)
 		{
 			_cc_push(m, f->cc608);
-			if(_cc_pop(m, cc) && hvk_cc608_write(m->e, n, cc[0], cc[1]) != HVK_OK) return(-1);
+			if(_cc_pop(m, cc) && hvk_cc608_write(E, n, cc[0], cc[1]) != HVK_OK) return(-1);
 		}
 
 		if(fields == 2)
@@ -668,7 +711,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 			if(s->conf.cc608) _cc_push(m, f->cc608);
 		}
 
-		if(s->conf.wss && hvk_frame_aspect(m->e, slot, par.num, par.den) != HVK_OK) return(-1);
+		if(s->conf.wss && hvk_frame_aspect(E, slot, par.num, par.den) != HVK_OK) return(-1);
 
 		if(s->conf.teletext)
 		{
@@ -686,7 +729,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 				if(m->held[line - 1]) continue;
 				if(tt_next_packet(&s->tt, rows[row], frame, line) == TT_OK) mask |= 1u << row;
 			}
-			if(hvk_teletext_packets(m->e, n, &rows[0][0], mask) != HVK_OK) return(-1);
+			if(hvk_teletext_packets(E, n, &rows[0][0], mask) != HVK_OK) return(-1);
 		}
 
 		m->frame_in_batch_pull++;
@@ -700,13 +743,13 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 		 * leaves silence (src/video.c:3299-3304) */
 		if(m->info.has_carriers || m->info.has_nicam)
 		{
-			while(hvk_audio_needed(m->e, n) > 0)
+			while((m->g ? hvk_group_audio_needed(m->g, n) : hvk_audio_needed(m->e, n)) > 0)
 			{
 				int16_t *a = NULL;
 				size_t an = 0;
 				av_read_audio(&s->av, &a, &an);
 				if(a == NULL || an == 0) break;
-				if(hvk_audio_write(m->e, a, an) != HVK_OK) return(-1);
+				if((m->g ? hvk_group_audio_write(m->g, a, an) : hvk_audio_write(m->e, a, an)) != HVK_OK) return(-1);
 				if(_aud_append(m, a, an) != 0) return(-1);
 			}
 		}
@@ -788,11 +831,16 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket)
 	}
 
 	if(m->stats) t0 = _now();
-	if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);
+	if(m->g)
+	{
+		if(hvk_group_stage(m->g, n, slots) != HVK_OK || hvk_group_launch(m->g, NULL) < 0) return(-1);
+	}
+	else if(hvk_render(m->e, n, slots, NULL) != HVK_OK) return(-1);
 	if(m->stats) { t1 = _now(); m->t_render += t1 - t0; t0 = t1; }
 	/* the read-back is queued behind the render; the consumer waits for it (vid_next_line) while this thread goes
 	 * on with the next batch's pulls and host pre-passes */
-	*ticket = hvk_fetch_async(m->e, iq, 0, (size_t) (hvk_frame_start(m->e, m->frames_pulled) - hvk_frame_start(m->e, m->frames_pulled - n)));
+	*eng = E;
+	*ticket = hvk_fetch_async(E, iq, 0, (size_t) (hvk_frame_start(m->e, m->frames_pulled) - hvk_frame_start(m->e, m->frames_pulled - n)));
 	if(*ticket < 0) return(-1);
 	if(m->stats) { t1 = _now(); m->t_fetch += t1 - t0; }
 
@@ -820,9 +868,11 @@ static void *_worker(void *arg)
 		pthread_mutex_unlock(&m->lock);
 		if(m->stats) m->t_worker_idle += _now() - t0;
 
-		n = m->ended ? 0 : _next_batch(s, m, m->buf[b], &ticket);
+		hvk_engine_t *eng = m->e;
+		n = m->ended ? 0 : _next_batch(s, m, m->buf[b], &ticket, &eng);
 
 		pthread_mutex_lock(&m->lock);
+		m->fe[b] = eng;
 		m->last[b] = m->ended;
 		m->count[b] = n;
 		m->ticket[b] = ticket;
@@ -876,7 +926,7 @@ vid_line_t *vid_next_line(vid_t *s)
 		pthread_mutex_unlock(&m->lock);
 
 		if(n <= 0) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
-		if(hvk_fetch_wait(m->e, ticket) != HVK_OK) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
+		if(hvk_fetch_wait(m->fe[nb] ? m->fe[nb] : m->e, ticket) != HVK_OK) { m->have = 0; m->frame_in_batch = 0; return(NULL); }
 		if(m->stats) m->t_consumer_wait += _now() - t0;
 		m->cur = nb;
 		m->iq = m->buf[nb];

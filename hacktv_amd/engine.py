@@ -24,6 +24,9 @@ SYMBOLS = [
     "hvk_host_sis_bursts", "hvk_sound_state_size", "hvk_sound_state_export", "hvk_sound_state_import", "hvk_sound_samples_generated",
     "hvk_host_side_streams", "hvk_host_secam_stream", "hvk_secam_stats", "hvk_secam_warmup_lines", "hvk_vbi_lines_held", "hvk_sync", "hvk_fetch", "hvk_fetch_async", "hvk_fetch_wait", "hvk_host_alloc", "hvk_host_free", "hvk_frame_upload_pinned", "hvk_fetch_as", "hvk_output_device_ptr",
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
+    "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
+    "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
+    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums",
 ]
 
 _lib = None
@@ -114,6 +117,32 @@ def lib():
         L.hvk_table.restype = C.c_long
         L.hvk_fetch_raster.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.hvk_version.restype = C.c_char_p
+        L.hvk_group_open.argtypes = [C.POINTER(vp), vp, C.c_uint, C.c_uint, vp, i32, i32]
+        L.hvk_group_close.argtypes = [vp]
+        L.hvk_group_close.restype = None
+        L.hvk_group_size.argtypes = [vp]
+        L.hvk_group_block_frames.argtypes = [vp]
+        L.hvk_group_engine.argtypes = [vp, i32]
+        L.hvk_group_engine.restype = vp
+        L.hvk_group_block_engine.argtypes = [vp]
+        L.hvk_group_block_engine.restype = vp
+        L.hvk_group_block_index.argtypes = [vp]
+        L.hvk_group_next_frame.argtypes = [vp]
+        L.hvk_group_next_frame.restype = i64
+        L.hvk_group_frame_upload.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32]
+        L.hvk_group_audio_write.argtypes = [vp, vp, C.c_size_t]
+        L.hvk_group_audio_needed.argtypes = [vp, i32]
+        L.hvk_group_audio_needed.restype = C.c_size_t
+        L.hvk_group_stage.argtypes = [vp, i32, vp]
+        L.hvk_group_launch.argtypes = [vp, vp]
+        L.hvk_group_gather.argtypes = [vp, i32, vp, C.c_size_t]
+        L.hvk_group_gather_backend.argtypes = [vp]
+        L.hvk_group_gather_backend.restype = C.c_char_p
+        L.hvk_engine_stream.argtypes = [vp]
+        L.hvk_engine_stream.restype = vp
+        L.hvk_last_line_shows_picture.argtypes = [vp]
+        L.hvk_stream_is_one_chain.argtypes = [vp]
+        L.hvk_block_sums.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
         _lib = L
     return _lib
 
@@ -381,3 +410,95 @@ class Engine:
         n = C.c_int64(0)
         self._chk("hvk_timing_read", lib().hvk_timing_read(self.h, which, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def block_sums(self, first, count):
+        """(sum w[i], sum (i + 1) w[i]) modulo 2^64 over the I/Q pairs [first, first + count) of the last render, on the device."""
+        out = (C.c_uint64 * 2)()
+        self._chk("hvk_block_sums", lib().hvk_block_sums(self.h, first, count, out))
+        return int(out[0]), int(out[1])
+
+
+class _Member(Engine):
+    """An engine that belongs to a group: the group opens and closes it."""
+
+    def __init__(self, handle, device):
+        self.h = C.c_void_p(handle)
+        self._host_bufs = []
+        info = HvkInfo()
+        lib().hvk_get_info(self.h, C.byref(info))
+        self.info = info.as_dict()
+        self.device = device
+
+    def close(self):
+        for p in self._host_bufs:
+            lib().hvk_host_free(self.h, p)
+        self._host_bufs = []
+        self.h = None
+
+
+class Group:
+    """hvk_group_*: one stream rendered by several engines, block b of `block_frames` frames on engine b mod N
+    (include/hacktv_amd.h, hvk_group.cpp). devices: one HIP device ordinal per engine, repeats allowed."""
+
+    def __init__(self, conf, sample_rate, devices, block_frames, pixel_rate=0):
+        self.h = C.c_void_p()
+        self.conf = conf
+        devs = (C.c_int * len(devices))(*devices)
+        r = lib().hvk_group_open(C.byref(self.h), C.byref(conf), sample_rate, pixel_rate, devs, len(devices), block_frames)
+        if r != 0:
+            self.h = None
+            raise HvkError("hvk_group_open", r)
+        self.n = len(devices)
+        self.block = block_frames
+        self.engines = [_Member(lib().hvk_group_engine(self.h, i), devices[i]) for i in range(self.n)]
+        self.info = self.engines[0].info
+
+    def _chk(self, what, r):
+        if r < 0:
+            raise HvkError(what, r)
+        return r
+
+    def close(self):
+        if self.h:
+            for e in self.engines:
+                e.close()
+            lib().hvk_group_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def block_engine(self):
+        return self.engines[lib().hvk_group_block_index(self.h)]
+
+    def next_frame(self):
+        return int(lib().hvk_group_next_frame(self.h))
+
+    def frame_upload(self, frame_in_block, fb, interlaced=0):
+        if fb is None:
+            return self._chk("hvk_group_frame_upload", lib().hvk_group_frame_upload(self.h, frame_in_block, None, 0, 0, 1, 0, interlaced))
+        fb = np.ascontiguousarray(fb, dtype=np.uint32)
+        return self._chk("hvk_group_frame_upload", lib().hvk_group_frame_upload(self.h, frame_in_block, fb.ctypes.data, fb.shape[1], fb.shape[0], 1, fb.shape[1], interlaced))
+
+    def audio_write(self, stereo):
+        a = np.ascontiguousarray(stereo, dtype=np.int16)
+        return self._chk("hvk_group_audio_write", lib().hvk_group_audio_write(self.h, a.ctypes.data, a.size // 2))
+
+    def audio_needed(self, nframes):
+        return int(lib().hvk_group_audio_needed(self.h, nframes))
+
+    def stage(self, nframes, slots=None):
+        s = None if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
+        return self._chk("hvk_group_stage", lib().hvk_group_stage(self.h, nframes, None if s is None else s.ctypes.data))
+
+    def launch(self, d_iq=None):
+        return self._chk("hvk_group_launch", lib().hvk_group_launch(self.h, d_iq))
+
+    def gather(self, root, d_root, samples):
+        return self._chk("hvk_group_gather", lib().hvk_group_gather(self.h, root, d_root, samples))
+
+    def gather_backend(self):
+        return lib().hvk_group_gather_backend(self.h).decode()

@@ -395,8 +395,10 @@ int hvk_set_levels(hvk_engine_t *e, int mode);
  * from PICTURE PLANES: what src/video.c:2864-3030 computes of a scanline before the sub-carrier is modulated -- sync
  * pulses, the levels of the pixels, the low-passed chroma, the burst -- depends on the picture alone and is made once
  * per uploaded picture, by the first hvk_stage_strided() / hvk_render() that shows it (a picture that stays is not
- * worked on again). hvk_planes_refresh() makes the planes of the named slots now -- again, if
- * they exist -- on the engine's stream: for a caller that wants that work inside a clock of its own. SECAM has a
+ * worked on again) -- when that block is LAUNCHED, a chunk of frames at a time on a second stream,
+ * each chunk's render behind its planes, so that the planes of one chunk are made beside the render of the chunk
+ * before. hvk_planes_refresh() has the planes of the named slots made again by the next launch that shows them: for a
+ * caller that wants that work inside a clock of its own. SECAM has a
  * per-picture share of the same kind: the low-passed colour-difference cells of a picture, kept per slot and frame
  * parity (hvk_secam.hip); for the named slots they are dropped and made again by the next stage that shows them.
  * HVK_OK and nothing done where the configuration renders straight from the pictures. */
@@ -419,6 +421,56 @@ long hvk_table(const hvk_engine_t *e, const char *name, void *dst, long max_byte
 int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, size_t count);
 
 const char *hvk_version(void);
+
+/* ---- several devices: one stream rendered by N engines (BASELINE config 5) --------------------------------------
+ *
+ * The reference renders on one CPU and hands every line to one sink (src/hacktv.c:1579-1587 -> rf_write,
+ * src/rf.c:23-31). A group cuts the stream into blocks of `block_frames` frames; block b is rendered by engine
+ * b mod N, each engine on the device named for it (a device may be named more than once: N engines on one GPU). The
+ * serial sound chains are handed from engine to engine in process, the 32 kHz source is kept by the group and dealt to
+ * the engine whose block draws it, and on 525 lines the picture of the frame before a block reaches the block's engine
+ * too (hvk_group.cpp). Configurations that are one chain over every sample of the stream (SECAM colour, FM video,
+ * --pixelrate pairs with frames of two lengths) are refused for N > 1.
+ *
+ * A block: hvk_group_frame_upload() for its pictures (frame i of the block -> slot i of the block's engine),
+ * hvk_group_audio_write() while hvk_group_audio_needed() > 0, anything per frame (teletext packets, caption pairs)
+ * on hvk_group_block_engine(), then hvk_group_stage() and hvk_group_launch(). The stream's samples come back either
+ *   (i)  host-direct: hvk_fetch_async() on the block's engine, straight into the block's place in the caller's
+ *        page-locked stream buffer -- N devices, N PCIe links, the shape a host rf_* sink wants; or
+ *   (ii) gathered on one device: hvk_group_gather() after a round of N blocks -- grouped ncclSend / ncclRecv from C
+ *        (librccl is loaded on first use) between distinct devices, device-to-device copies between engines that share
+ *        one (hvk_group_gather_backend() says which). */
+typedef struct hvk_group hvk_group_t;
+int hvk_group_open(hvk_group_t **g, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
+                   const int *devices, int ndevices, int block_frames);
+void hvk_group_close(hvk_group_t *g);
+int hvk_group_size(const hvk_group_t *g);
+int hvk_group_block_frames(const hvk_group_t *g);
+hvk_engine_t *hvk_group_engine(hvk_group_t *g, int i);
+hvk_engine_t *hvk_group_block_engine(hvk_group_t *g);      /* the engine the next block goes to */
+int hvk_group_block_index(const hvk_group_t *g);           /* ... and its index */
+int64_t hvk_group_next_frame(const hvk_group_t *g);        /* the stream's next frame (frames launched so far) */
+int hvk_group_frame_upload(hvk_group_t *g, int frame_in_block, const uint32_t *fb, int width, int height,
+                           int pixel_stride, int line_stride, int interlaced);
+int hvk_group_audio_write(hvk_group_t *g, const int16_t *stereo, size_t nsamples);
+size_t hvk_group_audio_needed(hvk_group_t *g, int nframes);
+int hvk_group_stage(hvk_group_t *g, int nframes, const int32_t *slots);
+int hvk_group_launch(hvk_group_t *g, void *d_iq);          /* returns the index of the engine that renders the block */
+int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t samples);
+const char *hvk_group_gather_backend(const hvk_group_t *g);
+
+/* What a group asks of an engine: the HIP stream it launches on; whether the last line of a frame shows picture (525
+ * lines: a block's first frame needs the picture of the frame before); whether the stream is one serial chain that
+ * cannot be cut into blocks for several engines. */
+void *hvk_engine_stream(hvk_engine_t *e);
+int hvk_last_line_shows_picture(const hvk_engine_t *e);
+int hvk_stream_is_one_chain(const hvk_engine_t *e);
+
+/* Two 64-bit sums over samples [first, first + count) of the last render, read as little-endian uint32 words w[i]
+ * (an I/Q pair each): sums[0] = sum w[i], sums[1] = sum (i + 1) w[i], modulo 2^64 -- computed on the device, 16 bytes
+ * cross PCIe. A position-sensitive check of a whole block where fetching it to hash it would take longer than
+ * rendering it (the one-hour run of BASELINE config 5: tests/golden/ref_hour.json holds the reference's sums). */
+int hvk_block_sums(hvk_engine_t *e, size_t first, size_t count, uint64_t sums[2]);
 
 #ifdef __cplusplus
 }

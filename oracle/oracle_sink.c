@@ -31,3 +31,21 @@ long orc_sink_convert(const int16_t *iq, long samples, int type, int complex, vo
 
 	return(n * (type <= 1 ? 1 : (type <= 3 ? 2 : 4)));
 }
+
+/* Two 64-bit sums over a block of I/Q pairs read as little-endian uint32 words w[0 .. n):
+ *   s1 = sum w[i], s2 = sum (i + 1) * w[i], both modulo 2^64
+ * -- a position-sensitive check cheap enough to be computed for every block of an hour of signal
+ * (oracle/make_golden_hour.py over the reference's output; hvk_block_sums() over the device's). */
+void orc_block_sums(const uint32_t *w, long n, uint64_t out[2])
+{
+	uint64_t s1 = 0, s2 = 0;
+	long i;
+
+	for(i = 0; i < n; i++)
+	{
+		s1 += w[i];
+		s2 += (uint64_t) (i + 1) * w[i];
+	}
+	out[0] = s1;
+	out[1] = s2;
+}
