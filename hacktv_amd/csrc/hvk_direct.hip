@@ -417,24 +417,36 @@ __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_
 	return(l);
 }
 
-/* 8 raster samples (int16 pairs) at window position w of a line */
+/* 8 raster samples (int16 pairs) at window position w of a line: what is read, and what is made of it */
+typedef struct { int4a2 lv, cv; int4u c0, c1, k0, k1; } dload_t;
+
 template<int COLOUR>
-__device__ __forceinline__ int4u direct_eval(const hvk_dptrs_t &D, const int lb, const int cb, const int w)
+__device__ __forceinline__ dload_t direct_load(const hvk_dptrs_t &D, const int lb, const int cb, const int w)
 {
-	const int4a2 lv = *(const int4a2 *) (D.Lp + (lb + w));         /* (2-byte aligned where the width is odd) */
-	int4u s = { lv.x, lv.y, lv.z, lv.w };
-	if(COLOUR == 2)
-	{
-		const int4a2 cv = *(const int4a2 *) (D.chroma + (cb + w));
-		s.x = pk_add16(s.x, cv.x); s.y = pk_add16(s.y, cv.y); s.z = pk_add16(s.z, cv.z); s.w = pk_add16(s.w, cv.w);
-	}
+	dload_t q;
+	q.lv = *(const int4a2 *) (D.Lp + (lb + w));          /* (2-byte aligned where the width is odd) */
+	if(COLOUR == 2) q.cv = *(const int4a2 *) (D.chroma + (cb + w));
 	if(COLOUR == 1)
 	{
 		const int4u *cp = (const int4u *) (D.Cp + (lb + w));
 		const int4u *kp = (const int4u *) (D.clut3 + (cb + w));
-		const int4u c0 = cp[0], c1 = cp[1], k0 = kp[0], k1 = kp[1];
-		const int C[SPL] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-		const int K[SPL] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
+		q.c0 = cp[0]; q.c1 = cp[1]; q.k0 = kp[0]; q.k1 = kp[1];
+	}
+	return(q);
+}
+
+template<int COLOUR>
+__device__ __forceinline__ int4u direct_make(const dload_t &q)
+{
+	int4u s = { q.lv.x, q.lv.y, q.lv.z, q.lv.w };
+	if(COLOUR == 2)
+	{
+		s.x = pk_add16(s.x, q.cv.x); s.y = pk_add16(s.y, q.cv.y); s.z = pk_add16(s.z, q.cv.z); s.w = pk_add16(s.w, q.cv.w);
+	}
+	if(COLOUR == 1)
+	{
+		const int C[SPL] = { q.c0.x, q.c0.y, q.c0.z, q.c0.w, q.c1.x, q.c1.y, q.c1.z, q.c1.w };
+		const int K[SPL] = { q.k0.x, q.k0.y, q.k0.z, q.k0.w, q.k1.x, q.k1.y, q.k1.z, q.k1.w };
 		int pr[SPL / 2];
 #pragma unroll
 		for(int m = 0; m < SPL / 2; m++)
@@ -448,27 +460,66 @@ __device__ __forceinline__ int4u direct_eval(const hvk_dptrs_t &D, const int lb,
 	return(s);
 }
 
-/* ... whichever lines they lie in: lA from window position 0, lB from b1, lC from b2 */
+/* ... whichever lines they lie in: lA from window position 0, lB from b1, lC from b2. A lane whose 8 positions straddle the
+ * end of a line reads twice -- with the parameters of the line its first position lies in and with the next line's (another
+ * sign of the V switch, another picture at a frame's end) -- and BOTH reads go out before either is used: one round trip,
+ * not two, for the wave that has such a lane (at 1024 samples per line every tile's first wave has one). */
+/* A lane's 8 positions, read: qa with the parameters of the line its first position lies in. Where a line ends inside them
+ * (split: how many lie before the boundary) the rest wants the next line's parameters. Between two lines of one picture
+ * those differ in the sub-carrier only -- the rows follow each other in the planes --, so the second read is the phasors'
+ * (or SECAM's sub-carrier samples') alone and goes out WITH the first; at a frame's ends, before the stream and on rows of
+ * the optional stages the planes differ too (full): read again when the first read has been used (rare: one round more). */
+typedef struct { dload_t qa; int4u kb0, kb1; int split; bool full; int lb2, cb2; } dgroup_t;
+
 template<int COLOUR>
-__device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_t lA, const dline_t lB, const dline_t lC,
-                                              const int b1, const int b2, const int w)
+__device__ __forceinline__ void direct_group_load(const hvk_dptrs_t &D, const dline_t lA, const dline_t lB, const dline_t lC,
+                                                  const int b1, const int b2, const int w, dgroup_t &G)
 {
 	const bool inB = w >= b1, inC = w >= b2;
-	int4u s = direct_eval<COLOUR>(D, inC ? lC.lb : (inB ? lB.lb : lA.lb), inC ? lC.cb : (inB ? lB.cb : lA.cb), w);
-
-	/* a line ends inside the group: the samples from there on with the next line's parameters */
+	const int lb = inC ? lC.lb : (inB ? lB.lb : lA.lb);
+	G.qa = direct_load<COLOUR>(D, lb, inC ? lC.cb : (inB ? lB.cb : lA.cb), w);
 	const int d1 = b1 - w, d2 = b2 - w;
 	const bool s1 = d1 > 0 && d1 < SPL, s2 = d2 > 0 && d2 < SPL;
-	if(s1 || s2)
+	G.split = s1 ? d1 : (s2 ? d2 : 0);
+	G.lb2 = s1 ? lB.lb : lC.lb;
+	G.cb2 = s1 ? lB.cb : lC.cb;
+	G.full = G.split != 0 && G.lb2 != lb;
+	if(G.split != 0 && !G.full)
 	{
-		const int split = s1 ? d1 : d2;
-		const int4u r = direct_eval<COLOUR>(D, s1 ? lB.lb : lC.lb, s1 ? lB.cb : lC.cb, w);
+		if(COLOUR == 1)
+		{
+			const int4u *kp = (const int4u *) (D.clut3 + (G.cb2 + w));
+			G.kb0 = kp[0]; G.kb1 = kp[1];
+		}
+		if(COLOUR == 2)
+		{
+			const int4a2 cv = *(const int4a2 *) (D.chroma + (G.cb2 + w));
+			G.kb0 = (int4u) { cv.x, cv.y, cv.z, cv.w };
+		}
+	}
+}
+
+template<int COLOUR>
+__device__ __forceinline__ int4u direct_group_make(const hvk_dptrs_t &D, const dgroup_t &G, const int w)
+{
+	int4u s = direct_make<COLOUR>(G.qa);
+	if(G.split)
+	{
+		/* a line ends inside the group: the samples from there on with the next line's parameters */
+		dload_t q2 = G.qa;
+		if(!G.full)
+		{
+			if(COLOUR == 1) { q2.k0 = G.kb0; q2.k1 = G.kb1; }
+			if(COLOUR == 2) q2.cv = (int4a2) { G.kb0.x, G.kb0.y, G.kb0.z, G.kb0.w };
+		}
+		else q2 = direct_load<COLOUR>(D, G.lb2, G.cb2, w);
+		const int4u r = direct_make<COLOUR>(q2);
 		const int sv[4] = { s.x, s.y, s.z, s.w }, rv[4] = { r.x, r.y, r.z, r.w };
 		int o[4];
 #pragma unroll
 		for(int m = 0; m < 4; m++)
 		{
-			const int keep = split - 2 * m;             /* samples of this pair that lie before the boundary */
+			const int keep = G.split - 2 * m;           /* samples of this pair that lie before the boundary */
 			const unsigned mask = keep <= 0 ? 0u : (keep == 1 ? 0xFFFFu : 0xFFFFFFFFu);
 			o[m] = (int) (((unsigned) sv[m] & mask) | ((unsigned) rv[m] & ~mask));
 		}
@@ -477,7 +528,18 @@ __device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_
 	return(s);
 }
 
-template<int VF, int COLOUR, int EXACT, int OVR>
+template<int COLOUR>
+__device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_t lA, const dline_t lB, const dline_t lC,
+                                              const int b1, const int b2, const int w)
+{
+	dgroup_t G;
+	direct_group_load<COLOUR>(D, lA, lB, lC, b1, b2, w, G);
+	return(direct_group_make<COLOUR>(D, G, w));
+}
+
+/* SND = 1: the configuration has FM / AM carriers AND NICAM (the metric's), known when the kernel is compiled: no read hangs
+ * under a test at whose merge point it would be waited for */
+template<int VF, int COLOUR, int EXACT, int OVR, int SND, int TR>
 __global__ __launch_bounds__(HVK_TILE / HVK_SPL * DG, 8)
 void hvk_k_direct(const hvk_kconst_t k,
                   /* (hvk_dptrs_t member by member: as __restrict__ kernel arguments the descriptor tables are known not to alias
@@ -488,6 +550,7 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const uint32_t *__restrict__ d_lineoff, const uint32_t d_inv_w,
                   const int16_t *__restrict__ d_chroma, const int d_chroma_zero,
                   const int16_t *__restrict__ d_ovr_idx, const int d_ovr_row0, const int d_ovr_n,
+                  const hvk_tilerec_t *__restrict__ d_tilerec, const int tiles_pad,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW] */
                   const int *__restrict__ nicam_tapd,
@@ -539,9 +602,10 @@ void hvk_k_direct(const hvk_kconst_t k,
 
 	/* the NICAM pulse table, staged once per workgroup (hvk_k_filter has the layout) */
 	static_assert(TL * DG >= HVK_NICAM_TAPD / 2, "one pulse-table vector per thread");
-	const bool tap_mine = k.has_nicam && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	const bool has_car = SND ? true : k.has_carriers != 0, has_nic = SND ? true : k.has_nicam != 0;
+	const bool tap_mine = has_nic && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
 	int4v tap_stage = { 0, 0, 0, 0 };
-	if(k.has_nicam) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
+	if(has_nic) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
 
 	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
 	if(VF)
@@ -554,24 +618,56 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int64_t frame_index = first_frame + (int64_t) y * frame_stride;
 	const int par_own = (int) ((frame_index + 1) & 1);
 	const bool first = frame_index == 0;
-	const int p0 = n0 - LEAD;                                   /* stream position (frame local) of window position 0 */
-	const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
-	const int xA0 = p0 - lineA * W;
-	const int b1 = W - xA0, b2 = b1 + W;                        /* window positions at which the next two lines begin */
-	const dline_in_t qA = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA);
-	const dline_in_t qB = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 1);
-	const dline_in_t qC = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 2);
 	/* (the frame before: the row its LAST line's planes start at less lines - 1; the frame: the row of its line 0) */
 	const int row0_prev = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y].plane_row0);
 	const int row0_own = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].plane_row0);
 	const unsigned clut_off0 = (unsigned) __builtin_amdgcn_readfirstlane((int) D.fdesc[2 * y + 1].clut_off0);
-	const dline_t lA = direct_line<COLOUR, OVR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
-	const dline_t lB = direct_line<COLOUR, OVR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
-	const dline_t lC = direct_line<COLOUR, OVR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
+	int b1, b2;
+	dline_t lA, lB, lC;
+	if(OVR || !TR)
+	{
+		const int p0 = n0 - LEAD;                               /* stream position (frame local) of window position 0 */
+		const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
+		const int xA0 = p0 - lineA * W;
+		b1 = W - xA0; b2 = b1 + W;                              /* window positions at which the next two lines begin */
+		const dline_in_t qA = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA);
+		const dline_in_t qB = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 1);
+		const dline_in_t qC = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 2);
+		lA = direct_line<COLOUR, OVR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
+		lB = direct_line<COLOUR, OVR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
+		lC = direct_line<COLOUR, OVR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
+	}
+	else
+	{
+		/* Which lines the tile's window lies in, where they begin in it, their V switch and their share of the colour table
+		 * position depend on the tile and the frame's parity only: tabulated by the host (hvk_engine.cpp:_tile_records, the
+		 * arithmetic of direct_line_loads() / direct_line()), ONE 64-byte scalar load instead of a dozen dependent ones. What
+		 * is the frame's own -- where its picture's planes lie, its colour table position -- comes from its descriptor. */
+		const hvk_tilerec_t R = d_tilerec[__builtin_amdgcn_readfirstlane(par_own * tiles_pad + tile_raw)];
+		b1 = R.b1; b2 = b1 + W;
+		dline_t l3[3];
+#pragma unroll
+		for(int X = 0; X < 3; X++)
+		{
+			const int meta = R.meta[X];
+			const int line0 = meta & 0xFFFF, prev = (meta >> 16) & 1, own = (meta >> 17) & 1, pal = ((meta >> 18) & 3) - 1;
+			const bool zero = prev && first;        /* before the stream: the filter's history is zero, not blanking */
+			l3[X].lb = zero ? D.zero_row * W + R.nws[X] : (prev ? row0_prev : row0_own) * W + R.lw[X];
+			l3[X].cb = 2 * D.creg + R.nws[X];
+			if(COLOUR == 2) l3[X].cb = (own && !zero ? y * (int) k.raster_samples + line0 * W : D.chroma_zero) + R.nws[X];
+			if(COLOUR == 1 && !zero && pal != 0)
+			{
+				unsigned coff = clut_off0 + R.off[X];
+				if(coff >= k.clw) coff -= k.clw;
+				l3[X].cb = (pal < 0 ? D.creg : 0) + (int) coff + R.nws[X];
+			}
+		}
+		lA = l3[0]; lB = l3[1]; lC = l3[2];
+	}
 
 	/* ---- loads ---- */
 	int symv = 0, cc_tile = 0;
-	if(k.has_nicam)
+	if(has_nic)
 	{
 		const int *row = tilesyms + ((size_t) y * tiles + tile) * HVK_NICAM_ROW;
 		cc_tile = row[HVK_NICAM_SYMS];
@@ -585,9 +681,10 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int4u g0 = direct_group<COLOUR>(D, lA, lB, lC, b1, b2, x0);
 
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
-	if(k.has_carriers && whole)
+	if(has_car && (SND || whole))
 	{
-		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + n);
+		/* (SND: unconditionally -- a lane outside the frame reads the frame's first run instead, and uses nothing of it) */
+		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + (whole ? n : 0));
 		/* read once, like the output is written once: marked as streaming so that neither pushes the plane rows and the
 		 * colour table's slices, which every frame comes back to, out of the XCD's L2 (+5 % on the metric configuration) */
 		car0 = __builtin_nontemporal_load(&c[0]);
@@ -620,12 +717,12 @@ void hvk_k_direct(const hvk_kconst_t k,
 		o[4] = g0.z & 0xFFFF; o[5] = (int) ((unsigned) g0.z >> 16); o[6] = g0.w & 0xFFFF; o[7] = (int) ((unsigned) g0.w >> 16);
 	}
 
-	if(k.has_nicam && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
+	if(has_nic && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
 	__syncthreads();
 
 	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
 	int4u mix[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-	if(k.has_nicam)
+	if(has_nic)
 	{
 		int cp = cc_tile + x0;                  /* mixer position of this lane's first sample */
 		if(k.nicam_cc_len >= HVK_TILE) { if(cp >= k.nicam_cc_len) cp -= k.nicam_cc_len; }
@@ -644,7 +741,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 
 	/* serial carriers (FM / AM sound), computed on the host: a plain add of int16 pairs with wrap-around
 	 * (src/video.c:3431-3432) */
-	if(k.has_carriers)
+	if(has_car)
 	{
 		if(whole)
 		{
@@ -659,7 +756,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 		}
 	}
 
-	if(k.has_nicam) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
+	if(has_nic) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + (size_t) y * out_stride * FS + n;
@@ -746,13 +843,19 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 {
 	const int tiles = (a->k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 	const dim3 grid(((tiles + DG - 1) / DG + 7) & ~7, a->nframes), block(HVK_TILE / SPL * DG);
-#define DIRECT2(EX, OV) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX, OV>), grid, block, 0, stream, a->k, \
-	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, a->D.chroma, a->D.chroma_zero, a->D.ovr_idx, a->D.ovr_row0, a->D.ovr_n, (const int *) a->carriers, a->tilesyms, \
+#define DIRECT4(EX, OV, SN, TRV) hipLaunchKernelGGL((hvk_k_direct<VF, COLOUR, EX, OV, SN, TRV>), grid, block, 0, stream, a->k, \
+	a->D.Lp, a->D.Cp, a->D.clut3, a->D.creg, a->D.zero_row, a->D.desc, a->D.fdesc, a->D.lineoff, a->D.inv_w, a->D.chroma, a->D.chroma_zero, a->D.ovr_idx, a->D.ovr_row0, a->D.ovr_n, \
+	(const hvk_tilerec_t *) a->tilerec, a->tiles_pad, (const int *) a->carriers, a->tilesyms, \
 	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
+/* (no tile records -- HVK_TILEREC=0 -- : the lines of a tile's window worked out by every wave, the second opinion) */
+#define DIRECT3(EX, OV, SN) do { if(OV == 0 && a->tilerec) DIRECT4(EX, OV, SN, (OV == 0 ? 1 : 0)); else DIRECT4(EX, OV, SN, 0); } while(0)
+#define DIRECT2(EX, OV) do { if(VF && OV == 0 && a->k.has_carriers && a->k.has_nicam) DIRECT3(EX, OV, (VF && OV == 0 ? 1 : 0)); else DIRECT3(EX, OV, 0); } while(0)
 #define DIRECT(EX) do { if(a->D.ovr_idx) DIRECT2(EX, 1); else DIRECT2(EX, 0); } while(0)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);
 #undef DIRECT
 #undef DIRECT2
+#undef DIRECT3
+#undef DIRECT4
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

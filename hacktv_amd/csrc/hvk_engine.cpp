@@ -113,6 +113,10 @@ struct hvk_engine {
 	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
 	int levels_computed;        /* what the staged block uses */
 	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
+	void *d_mfma_a28;           /* ... for hvk_k_fused's window (28 samples of lead) */
+	int fused_ok;               /* this configuration can render from the pixels in one kernel (hvk_fused.hip) */
+	int fused_mode;             /* HVK_FUSED: 0 never, 1 always, unset (-1): when at least half of a block's pictures are new */
+	int64_t fused_count;        /* launches that went that way */
 	int mfma_ci, mfma_cq;
 	/* per batch */
 	uint32_t *d_pool;
@@ -146,6 +150,7 @@ struct hvk_engine {
 	/* picture planes: [plane_rows][width] each, 16 entries of slack in front; rows: lines per frame slot, two kept
 	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
 	int16_t *d_Lp; int *d_Cp; int *d_clut3; uint32_t *d_lineoff; uint32_t inv_w;
+	void *d_tilerec; int tiles_pad;     /* hvk_tilerec_t [2][tiles_pad] */
 	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
 	/* ... and behind them, per frame of a batch, a row for every line the optional stages (VBI data, test signals) can
 	 * write to: rendered whole by the raster kernel per frame, taken by hvk_k_direct instead of the planes' rows */
@@ -215,7 +220,7 @@ struct hvk_engine {
  * four int8 products and the constant 128 * sum(h) -- exact modulo 2^32, like the reference's
  * int32 accumulator. Layout: [hh, hl][lane][16 bytes], lane = 16 * (t / 16) + m, byte = t % 16.
  * A tap above 32639 has no such split (hh = 128): the caller keeps the VALU kernel then. */
-static bool _mfma_taps(int8_t *a, int *ci, int *cq, const int16_t *hi, const int16_t *hq, int ntaps)
+static bool _mfma_taps(int8_t *a, int *ci, int *cq, const int16_t *hi, const int16_t *hq, int ntaps, int lead = 26)
 {
 	int64_t si = 0, sq = 0;
 
@@ -231,7 +236,7 @@ static bool _mfma_taps(int8_t *a, int *ci, int *cq, const int16_t *hi, const int
 
 		for(int j = 0; j < 16; j++)
 		{
-			const int k = 16 * g + j - 1 - b;
+			const int k = 16 * g + j - (lead - 25) - b;      /* window position 0 lies `lead` samples before the segment's first output */
 			const int h = (k >= 0 && k < ntaps) ? (q ? (hq ? hq[k] : 0) : hi[k]) : 0;
 			const int lo = (int) (int8_t) (h & 0xFF), hh = (h - lo) >> 8;
 			if(hh < -128 || hh > 127) return(false);
@@ -405,6 +410,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		if(_mfma_taps(a.data(), &e->mfma_ci, &e->mfma_cq, e->t.vf_itaps, e->t.k.vf_type == 3 ? e->t.vf_qtaps : NULL, 51))
 		{
 			OPENCHK(_upload(&e->d_mfma_a, a.data(), a.size()));
+			int ci2, cq2;
+			if(_mfma_taps(a.data(), &ci2, &cq2, e->t.vf_itaps, e->t.k.vf_type == 3 ? e->t.vf_qtaps : NULL, 51, 28)) OPENCHK(_upload(&e->d_mfma_a28, a.data(), a.size()));
 		}
 	}
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
@@ -510,6 +517,36 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				const uint32_t n0 = q * (uint32_t) k.width, n1 = n0 + (uint32_t) k.width - 1;
 				if((uint32_t) (((uint64_t) n0 * e->inv_w) >> 32) != q || (uint32_t) (((uint64_t) n1 * e->inv_w) >> 32) != q) e->direct = 0;
 			}
+		if(e->direct && !e->ovr_n && !(getenv("HVK_TILEREC") && atoi(getenv("HVK_TILEREC")) == 0))
+		{
+			/* per frame parity and tile of 1024 outputs (the tiles of the last, partial workgroup included): the lines its window
+			 * lies in -- the arithmetic of hvk_direct.hip:direct_line_loads() / direct_line(), done once here */
+			const int DGT = 4, lead = k.vf_type ? 26 : 0, W = k.width, tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+			e->tiles_pad = (tiles + DGT - 1) / DGT * DGT;
+			std::vector<hvk_tilerec_t> rec((size_t) 2 * e->tiles_pad);
+			memset(rec.data(), 0, rec.size() * sizeof(hvk_tilerec_t));
+			for(int par_own = 0; par_own < 2; par_own++) for(int tl = 0; tl < e->tiles_pad; tl++)
+			{
+				hvk_tilerec_t &R = rec[(size_t) par_own * e->tiles_pad + tl];
+				const int p0 = tl * HVK_TILE - lead;
+				const int lineA = p0 < 0 ? -1 : p0 / W, xA0 = p0 - lineA * W;
+				R.b1 = W - xA0;
+				for(int X = 0; X < 3; X++)
+				{
+					const int rel = lineA + X, wstart = X == 0 ? -xA0 : (X == 1 ? R.b1 : R.b1 + W);
+					int line0 = rel, par = par_own, prev = 0;
+					const int own = rel >= 0 && rel < k.lines;
+					if(rel < 0) { line0 = k.lines - 1; par ^= 1; prev = 1; }
+					else if(rel >= k.lines) { line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; par ^= 1; }
+					const int pal = (k.colour && !k.secam) ? e->t.desc[(size_t) par * k.lines + line0].pal : 0;
+					R.meta[X] = line0 | (prev << 16) | (own << 17) | ((pal + 1) << 18);
+					R.lw[X] = line0 * W - wstart;
+					R.nws[X] = -wstart;
+					R.off[X] = lo[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+				}
+			}
+			OPENCHK(_upload(&e->d_tilerec, rec.data(), rec.size() * sizeof(hvk_tilerec_t)));
+		}
 		}
 		if(!e->direct) fprintf(stderr, "libhvk: no exact reciprocal of the line width %d: the raster + filter kernel pair renders\n", k.width);
 		OPENHIP(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
@@ -517,6 +554,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		for(int i = 0; i < HVK_PREP_EVENTS; i++) OPENHIP(hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming));
 		e->prep_chunk = getenv("HVK_PREP_CHUNK") ? atoi(getenv("HVK_PREP_CHUNK")) : 0;
 		e->prep_streams = getenv("HVK_PREP_STREAMS") ? atoi(getenv("HVK_PREP_STREAMS")) : 1;
+		e->fused_mode = getenv("HVK_FUSED") ? atoi(getenv("HVK_FUSED")) : -1;
+		e->fused_ok = e->direct && e->d_mfma_a28 && e->d_clut3 && !e->ovr_n && hvk_fused_supported(&e->t.k, e->t.desc);
 		if(e->prep_chunk < 1) e->prep_chunk = max_frames;
 		e->staged_prev = (int32_t *) malloc(sizeof(int32_t) * (size_t) max_frames);
 		if(!e->staged_prev) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
@@ -788,7 +827,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums };
+		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -1649,7 +1688,7 @@ static int _carry_copy(hvk_engine *e)
  * into its last one's) */
 static int _flush_planes(hvk_engine *e)
 {
-	if(!e->direct || !e->prep_pending) return(HVK_OK);
+	if(!e->direct || !e->prep_pending || !e->carry_copy_pending) return(HVK_OK);
 	const int r = _prep_staged(e, 0, e->staged, e->stream);
 	if(r < 0) return(r);
 	e->prep_pending = 0;
@@ -2143,6 +2182,8 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		da.D.inv_w = e->inv_w;
 		da.D.ovr_idx = e->d_ovr_idx;
 		da.D.ovr_n = e->ovr_n;
+		da.tilerec = e->d_tilerec;
+		da.tiles_pad = e->tiles_pad;
 		da.nicam_tapd = fa.nicam_tapd;
 		da.nicam_cca = fa.nicam_cca;
 		da.mfma_a = fa.mfma_a;
@@ -2165,12 +2206,38 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 			da.first_frame = e->staged_first + (int64_t) y0 * e->staged_stride;
 			return(hvk_launch_direct(&da, e->stream));
 		};
-		bool dirty = false;
-		for(int i = 0; i < e->staged && e->prep_pending && !dirty; i++)
+		bool dirty = false, fused_now = false;
+		int ndirty = 0;         /* new pictures among those the block shows (each counted once) */
+		if(e->prep_pending)
 		{
-			dirty = e->slots[e->staged_slots[i]].plane_dirty || (e->staged_prev[i] >= 0 && e->slots[e->staged_prev[i]].plane_dirty);
+			std::vector<uint8_t> seen((size_t) e->frame_slots, 0);
+			for(int i = 0; i < e->staged; i++)
+			{
+				const int sl[2] = { e->staged_slots[i], e->staged_prev[i] };
+				for(int j = 0; j < 2; j++)
+				{
+					if(sl[j] < 0 || !e->slots[sl[j]].plane_dirty || seen[sl[j]]) continue;
+					seen[sl[j]] = 1;
+					dirty = true;
+					ndirty++;
+				}
+			}
 		}
-		if(!dirty)
+		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || 2 * ndirty >= e->staged))
+		{
+			/* most of the block's pictures are new: from the pixels in one kernel (hvk_fused.hip), their planes are not made
+			 * (and stay marked: a later block that shows one of them again makes them then) */
+			da.D.fdesc = e->d_fdesc;
+			da.carriers = fa.carriers;
+			da.tilesyms = fa.tilesyms;
+			da.iq = fa.iq;
+			da.nframes = e->staged;
+			da.first_frame = e->staged_first;
+			if((r = hvk_launch_fused(&ra, &da, e->d_mfma_a28, e->stream)) != HVK_OK) return(r);
+			e->fused_count++;
+			fused_now = true;
+		}
+		else if(!dirty)
 		{
 			if((r = direct_range(0, e->staged)) != HVK_OK) return(r);
 		}
@@ -2200,8 +2267,11 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 				if((r = direct_range(y0, n)) != HVK_OK) { e->poisoned = 1; return(r); }
 			}
 		}
-		e->prep_pending = 0;
-		if((r = _carry_copy(e)) != HVK_OK) return(r);
+		if(!fused_now)
+		{
+			e->prep_pending = 0;
+			if((r = _carry_copy(e)) != HVK_OK) return(r);
+		}
 	}
 	else
 	{
@@ -2417,6 +2487,7 @@ extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, siz
 
 extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
 extern "C" void *hvk_engine_stream(hvk_engine_t *e) { return(e ? (void *) e->stream : NULL); }
+extern "C" int64_t hvk_fused_launches(const hvk_engine_t *e) { return(e ? e->fused_count : 0); }
 
 extern "C" int hvk_last_line_shows_picture(const hvk_engine_t *e)
 {
@@ -2462,8 +2533,11 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	const int lv = e->levels_computed ? 1 : 0;
 	if(e->direct)
 	{
-		if(e->ovr_n) snprintf(buf, n, "hvk_k_raster<%d, %d, 0, 1, 0, %d>;hvk_k_direct<%d, %d, %d, 1>", nt, k.secam ? 1 : 0, lv, k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
-		else snprintf(buf, n, "hvk_k_direct<%d, %d, %d, 0>", k.vf_type ? 1 : 0, k.secam ? 2 : (k.colour ? 1 : 0), k.frame_samples % HVK_TILE == 0 ? 1 : 0);
+		const int exact = k.frame_samples % HVK_TILE == 0 ? 1 : 0, vf = k.vf_type ? 1 : 0, col = k.secam ? 2 : (k.colour ? 1 : 0);
+		char dk[96];
+		snprintf(dk, sizeof(dk), "hvk_k_direct<%d, %d, %d, %d, %d, %d>", vf, col, exact, e->ovr_n ? 1 : 0, (k.has_carriers && k.has_nicam && vf && !e->ovr_n) ? 1 : 0, e->d_tilerec ? 1 : 0);
+		if(e->ovr_n) snprintf(buf, n, "hvk_k_raster<%d, %d, 0, 1, 0, %d>;%s", nt, k.secam ? 1 : 0, lv, dk);
+		else snprintf(buf, n, "%s", dk);
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;

@@ -89,9 +89,24 @@ typedef struct {
 	int ovr_row0, ovr_n;        /* their first row in Lp; rows per frame */
 } hvk_dptrs_t;
 
+/* What hvk_k_direct needs to know of a tile's 1024 + 64 window positions and does not depend on the frame but for its parity
+ * (hvk_engine.cpp:_tile_records): where the two line ends in the window lie, and per line -- the one window position 0 lies in
+ * and the two behind it -- its number in the frame, whose picture's planes show it, its V switch, its share of the colour
+ * table position */
+typedef struct {
+	int32_t b1;                 /* window position at which the second line begins (the third: b1 + width) */
+	int32_t meta[3];            /* line of the frame | the frame before's (also: before the stream's first frame, zeros) << 16 | a line of the frame itself << 17 | (pal + 1) << 18 */
+	int32_t lw[3];              /* line * width - (window position of the line's sample 0): a plane index less the picture's first row's */
+	int32_t nws[3];             /* - (window position of the line's sample 0) */
+	uint32_t off[3];            /* (line * width) mod clw */
+	int32_t pad[3];
+} __attribute__((aligned(64))) hvk_tilerec_t;
+
 typedef struct {
 	hvk_kconst_t k;
 	hvk_dptrs_t D;
+	const void *tilerec;        /* [2][tiles_pad] hvk_tilerec_t, NULL with rows of the optional stages (D.ovr_idx) */
+	int tiles_pad;
 	const hvk_c16_t *carriers;
 	const int *tilesyms;
 	const int *nicam_tapd, *nicam_cca;
@@ -172,6 +187,9 @@ typedef struct {
 int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int npics, int16_t *Lp, int *Cp, hipStream_t stream);
 int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames);
 int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
+/* the whole pipeline from the pixels in one kernel, for pictures that change (hvk_fused.hip); mfma_a28: the filter's A operand for a window that starts 28 samples before a tile */
+int hvk_fused_supported(const hvk_kconst_t *k, const hvk_linedesc_t *desc);
+int hvk_launch_fused(const hvk_raster_args_t *ra, const hvk_direct_args_t *a, const void *mfma_a28, hipStream_t stream);
 int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
                     int nframes, hipStream_t stream);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
-    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums",
+    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches",
 ]
 
 _lib = None
@@ -143,6 +143,8 @@ def lib():
         L.hvk_last_line_shows_picture.argtypes = [vp]
         L.hvk_stream_is_one_chain.argtypes = [vp]
         L.hvk_block_sums.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
+        L.hvk_fused_launches.argtypes = [vp]
+        L.hvk_fused_launches.restype = i64
         _lib = L
     return _lib
 
@@ -410,6 +412,9 @@ class Engine:
         n = C.c_int64(0)
         self._chk("hvk_timing_read", lib().hvk_timing_read(self.h, which, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def fused_launches(self):
+        return int(lib().hvk_fused_launches(self.h))
 
     def block_sums(self, first, count):
         """(sum w[i], sum (i + 1) w[i]) modulo 2^64 over the I/Q pairs [first, first + count) of the last render, on the device."""

@@ -404,6 +404,13 @@ int hvk_set_levels(hvk_engine_t *e, int mode);
  * HVK_OK and nothing done where the configuration renders straight from the pictures. */
 int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n);
 
+/* Pictures that change: where a block shows mostly NEW pictures (at least half of its frames) and the configuration allows
+ * it -- PAL colour at 1024 samples per line with the video filter: the metric configuration's geometry -- the block is
+ * rendered from the pixels in one kernel (hvk_fused.hip) and the planes are not made at all: they would be written once and
+ * read once. HVK_FUSED=0 in the environment keeps the planes, =1 takes the one kernel for every block with a new picture.
+ * hvk_fused_launches(): how many launches went that way. */
+int64_t hvk_fused_launches(const hvk_engine_t *e);
+
 int hvk_timing_enable(hvk_engine_t *e, int on);
 /* The names of the kernels a launch of this configuration enqueues, as a profiler prints them,
  * separated by ';' -- one name where the per-sample path runs as one kernel from picture planes (the

@@ -130,6 +130,84 @@ def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 
+@pytest.mark.parametrize("case", ["i_vsb", "i_full", "g_full", "pal_bb_filter", "i_offset", "i_swap_pass", "g_a2", "pald_full"])
+def test_one_kernel_from_the_pixels_equals_reference_digests(golden, case, monkeypatch):
+    """Blocks that show new pictures render from the pixels in ONE kernel where the configuration allows it (hvk_fused.hip:
+    PAL colour, 1024 samples per line, the video filter) -- no picture planes. HVK_FUSED=1 takes that way for every block
+    with a new picture, the test card's first showing included: the reference's digests."""
+    monkeypatch.setenv("HVK_FUSED", "1")
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    nframes = c["frames"]
+    out, done = [], 0
+    with H.Engine(conf, sr, device=0, max_frames=2) as e:
+        if conf.passthru:
+            e.passthru_write(util.passthru_signal())
+        while done < nframes:
+            n = min(2, nframes - done)
+            e.frame_upload(0, golden.frame(case))           # a "new" picture for every batch
+            while e.audio_needed(n) > 0:
+                e.audio_write(golden.audio)
+            e.render(n)
+            out.append(e.fetch(0, n * e.info["frame_samples"]))
+            done += n
+        assert e.fused_launches() == (nframes + 1) // 2, e.fused_launches()
+    iq = np.concatenate(out)
+    fs = c["width"] * c["lines"]
+    for n in range(nframes):
+        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
+
+
+@pytest.mark.parametrize("levels", [1, 2])
+def test_one_kernel_from_the_pixels_on_pictures_that_change(golden, levels, monkeypatch):
+    """... and on what the test card cannot show: a different picture on every frame -- noise, small pictures that leave a
+    border, a frame without a picture, batches of uneven length -- with sound: the same samples as from the picture
+    planes (HVK_FUSED=0) and from the raster + filter kernel pair (HVK_DIRECT=0)."""
+    conf, sr = golden.conf("i_full")
+    rng = np.random.default_rng(11)
+    base = golden.frame("i_full")
+    pics = []
+    for i in range(7):
+        if i == 2:
+            pics.append(rng.integers(0, 1 << 24, (300, 400), dtype=np.uint32))        # small: borders left, right, above, below
+        elif i == 4:
+            pics.append(None)                                                          # no picture: black
+        elif i == 5:
+            pics.append(rng.integers(0, 1 << 24, (700, 900), dtype=np.uint32))        # larger than the active area: centre crop
+        else:
+            pics.append(np.where(rng.random(base.shape) < 0.4, rng.integers(0, 1 << 24, base.shape, dtype=np.uint32), np.roll(base, 31 * i, axis=1)).astype(np.uint32))
+
+    def run(env):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        out = []
+        with H.Engine(conf, sr, device=0, max_frames=4) as e:
+            e.set_levels(levels)
+            done = 0
+            for n in (3, 4):
+                for i in range(n):
+                    e.frame_upload(i, pics[done + i])
+                while e.audio_needed(n) > 0:
+                    e.audio_write(golden.audio)
+                e.render(n, slots=list(range(n)))
+                out.append(e.fetch(0, n * e.info["frame_samples"]))
+                done += n
+            fused = e.fused_launches()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        return np.concatenate(out), fused
+
+    a, fa = run({})                       # (new pictures on every frame: the one kernel by default)
+    b, fb = run({"HVK_FUSED": "0"})
+    c, fc = run({"HVK_DIRECT": "0"})
+    assert fa == 2 and fb == 0 and fc == 0
+    for other, name in ((b, "the picture planes"), (c, "the kernel pair")):
+        bad = np.nonzero((a != other).any(axis=1))[0]
+        assert bad.size == 0, "%d samples differ from %s, first at %d (frame %d, line %d, sample %d)" % (
+            bad.size, name, bad[0], bad[0] // 640000, bad[0] % 640000 // 1024, bad[0] % 1024)
+
+
 @pytest.mark.parametrize("case", ["pal_bb", "i_full", "i_mono", "m_full", "ntsc_bb", "pal_bb_filter", "i_20m", "i_27m"])
 def test_plain_configurations_render_from_picture_planes(golden, case):
     """... and that the default really is the one-kernel form for them."""

@@ -49,7 +49,7 @@ def classify(op):
 def main():
     want = sys.argv[1:] or DEFAULT
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("hvk_direct.hip", "hvk_kernels.hip", "hvk_secam.hip"):
+        for src in ("hvk_direct.hip", "hvk_fused.hip", "hvk_kernels.hip", "hvk_secam.hip"):
             out = os.path.join(tmp, src + ".s")
             subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I../../include", "-I.",
                             "--cuda-device-only", "-S", src, "-o", out], cwd=SRC, check=True, stderr=subprocess.DEVNULL)
