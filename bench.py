@@ -340,8 +340,12 @@ def dropin_section(flags, seconds=4, pin_clock=False):
     if a is None or b is None or a != b:
         raise SystemExit("drop-in gate failed: hacktv_hvk %s differs from hacktv_ref within the first %d frames" % (" ".join(flags), nfr))
     sr = 16000000
-    t1, _ = run(hvk, 1 * sr * 4)
+    t1 = min(run(hvk, 1 * sr * 4)[0], run(hvk, 1 * sr * 4)[0])
     t2, _ = run(hvk, (1 + seconds) * sr * 4)
+    while t2 - t1 < 0.6 and seconds < 200:
+        # too fast for the difference of two process lifetimes to mean anything: a longer run (the pipe carries 64 MB per second of signal)
+        seconds *= 4
+        t2, _ = run(hvk, (1 + seconds) * sr * 4)
     r1, _ = run(ref, 1 * sr * 4)
     r2, _ = run(ref, 3 * sr * 4)
     return {
@@ -352,6 +356,97 @@ def dropin_section(flags, seconds=4, pin_clock=False):
         "note": "end to end through a pipe: the reference's main() and file sink, the shim's read-ahead worker (host sound pre-pass, uploads), "
                 "render, D2H; (t[%d s of signal] - t[1 s]) / %d s" % (1 + seconds, seconds),
     }
+
+
+def c_group_section(H, g, devices, Fb, rounds, log):
+    """The several-devices path in C (hvk_group_*, hvk_group.cpp): blocks of Fb frames dealt round-robin to one engine per
+    device named, the sound chains handed on in process, and both reassemblies of the contiguous stream -- (i) every engine's
+    block read back into its place in one page-locked host buffer (N PCIe links: the shape a host rf_* sink wants), (ii) the
+    blocks of a round gathered into the root engine's device memory (RCCL between distinct devices, device copies between
+    engines that share one). Gate: the first round's 2 x Fb frames against the reference (committed digest where there is one)."""
+    import hashlib
+    N = len(devices)
+    res = {"devices": list(devices), "engines": N, "block_frames": Fb}
+    for sound in (True, False):
+        conf = H.preset(MODE, H.FLAG_FILTER | (0 if sound else H.FLAG_NOAUDIO))
+        key = "with_sound" if sound else "noaudio"
+        with H.Group(conf, SAMPLE_RATE, devices, Fb) as grp:
+            fs = grp.info["frame_samples"]
+            res["gather_backend"] = grp.gather_backend()
+            host = [grp.engines[0].host_buffer(N * Fb * fs) for _ in range(2)]
+            def one_round(hb, gather_to=None):
+                tk = []
+                for b in range(N):
+                    e = grp.block_engine()
+                    if sound:
+                        while grp.audio_needed(Fb) > 0:
+                            grp.audio_write(g.audio)
+                    grp.stage(Fb, slots=[0] * Fb)
+                    grp.launch()
+                    if gather_to is None:
+                        tk.append((e, e.fetch_async(hb[b * Fb * fs:(b + 1) * Fb * fs], 0, Fb * fs)))
+                if gather_to is not None:
+                    grp.gather(0, gather_to, Fb * fs)
+                return tk
+
+            for e in grp.engines:
+                e.frame_upload(0, g.frame("i_full"))
+            # round 0, host-direct, gated
+            for e, t in one_round(host[0]):
+                e.fetch_wait(t)
+            got = hashlib.sha256(host[0].tobytes()).hexdigest()
+            gate = None
+            if sound:
+                long_file = os.path.join(ROOT, "tests", "golden", "ref_long.json")
+                committed = json.load(open(long_file))["i_full"]["sha256_at_frames"] if os.path.exists(long_file) else {}
+                want = committed.get(str(N * Fb))
+                if want is None:
+                    want = ref_stream_sha(MODE, SAMPLE_RATE, ["--filter"], 0, N * Fb, fs * 4)
+                if want is not None:
+                    if got != want:
+                        raise SystemExit("c_group gate failed: %d engines x %d frames reassembled on the host differ from the reference CLI's output" % (N, Fb))
+                    gate = "round 0 (%d frames over %d engines, sound chains handed on in process) sha256 == reference" % (N * Fb, N)
+            res.setdefault("parity_gate", gate)
+            # host-direct rounds: two host buffers, the read-back of a round runs beside the next round's stage + render
+            t0 = time.perf_counter()
+            pend = []
+            for r in range(rounds):
+                tk = one_round(host[r & 1])
+                for e, t in pend:
+                    e.fetch_wait(t)
+                pend = tk
+            for e, t in pend:
+                e.fetch_wait(t)
+            dt = time.perf_counter() - t0
+            hd = N * Fb * fs * rounds / dt / 1e6
+            # gathered rounds: into the root engine's device memory (a buffer of the test's own would need torch on that device;
+            # the root's output buffer holds a block + a frame, so gather into a scratch allocation of the HIP runtime)
+            import ctypes as C_
+            hip = C_.CDLL("libamdhip64.so")
+            hip.hipMalloc.argtypes = [C_.POINTER(C_.c_void_p), C_.c_size_t]
+            hip.hipFree.argtypes = [C_.c_void_p]
+            hip.hipSetDevice.argtypes = [C_.c_int]
+            hip.hipSetDevice(devices[0])
+            root = C_.c_void_p()
+            gd = None
+            if hip.hipMalloc(C_.byref(root), N * Fb * fs * 4) == 0:
+                one_round(None, gather_to=root)
+                grp.engines[0].sync()
+                t0 = time.perf_counter()
+                for r in range(rounds):
+                    one_round(None, gather_to=root)
+                for e in grp.engines:
+                    e.sync()
+                gd = N * Fb * fs * rounds / (time.perf_counter() - t0) / 1e6
+                hip.hipFree(root)
+            res[key] = {"host_direct_Msamples_per_s": round(hd, 1), "gathered_on_root_device_Msamples_per_s": None if gd is None else round(gd, 1)}
+            log("c_group %s: host-direct %.1f, gathered %s Msamples/s" % (key, hd, gd))
+    res["note"] = ("host code in C inside libhvk (no torch, no Python in the path): HVK_DEVICES=0,1,... makes the drop-in binary take it. WITH SOUND THE CURVE IS FLAT BY "
+                   "CONSTRUCTION: the FM / AM phasor chain is one recurrence over every sample of the stream (src/video.c:2259-2276) -- each engine has to wait for the "
+                   "state of the one before it, so N devices stage at the pace of one host core (about 0.5 Gsamples/s) whatever N is; --noaudio has no such chain and "
+                   "scales with the devices and their PCIe links. Host-direct is the reassembly a host rf_* sink wants (src/hacktv.c:1579-1587 -> rf_write): one xGMI link "
+                   "moves about 38 Gsamples/s, so a gather on one GPU is bound by the root's ingest before the samples have even started towards the host")
+    return res
 
 
 def main():
@@ -367,6 +462,9 @@ def main():
     ap.add_argument("--noaudio", action="store_true", help="render the --noaudio variant instead")
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-picture section")
     ap.add_argument("--no-configs", action="store_true", help="skip the sections for BASELINE configs 1, 3, 4 and --noaudio")
+    ap.add_argument("--hour-sound", action="store_true", help="5_one_hour: also the whole hour WITH sound (two minutes: the host's serial FM chain)")
+    ap.add_argument("--no-hour", action="store_true", help="skip the one-hour section")
+    ap.add_argument("--settle", type=float, default=0.6, help="seconds of untimed launches before the clock starts (sustained clocks)")
     ap.add_argument("--dry-run-backend", default=None, help="gloo: dry-run the N > 1 path with every rank on GPU 0 (no RCCL peers needed)")
     args = ap.parse_args()
 
@@ -588,6 +686,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
+    # ... and, untimed, the same launches for --settle seconds more: a short timed region (20 steps are 5 ms) then sees the
+    # clocks a long run has, not the first milliseconds after an idle period
+    settle_steps = 0
+    if not args.walk_rounds:
+        torch.cuda.synchronize()
+        t_set = time.perf_counter()
+        while time.perf_counter() - t_set < args.settle:
+            for i in range(20):
+                step(settle_steps + i)
+            drain()
+            torch.cuda.synchronize()
+            settle_steps += 20
 
     def timed(fn_step, fn_drain):
         if N > 1:
@@ -639,6 +749,20 @@ def main():
     samples_per_step = N * F * FS
     value = samples_per_step * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
+
+    # the spread: ten more runs of a tenth of the steps each (at least 10), every run between synchronisations
+    sub_ms = []
+    if not args.walk_rounds:
+        nsub = max(10, args.steps // 10)
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            for i in range(nsub):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            sub_ms.append((time.perf_counter() - t_s) / nsub * 1e3)
+        sub_ms.sort()
 
     # N > 1: the same steps without the reassembly, for the record (the ranks share nothing then)
     render_only = None
@@ -730,13 +854,51 @@ def main():
             mstep(4 + 2 * ksteps + k, 2)
         torch.cuda.synchronize()
         t_pin = time.perf_counter() - t0
+        fused_used = em.fused_launches()
+
+        def new_pictures(levels, fused, card):
+            """Fm new pictures per step, resident in HBM: through the picture planes (HVK_FUSED=0: hvk_k_prep8 + hvk_k_direct) or
+            from the pixels in one kernel (hvk_k_fused, what the engine takes by itself when most of a block's pictures are new)."""
+            os.environ["HVK_FUSED"] = "1" if fused else "0"
+            try:
+                ex = H.Engine(H.preset(MODE, H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fm)
+            finally:
+                del os.environ["HVK_FUSED"]
+            ex.set_stream(ctypes.c_void_p(stream.cuda_stream))
+            ex.set_levels(levels)
+            for i in range(Fm):
+                ex.frame_upload(i, np.roll(g.frame("i_full"), 13 * i, axis=1) if card else pics[i % len(pics)])
+            for k in range(2):
+                ex.planes_refresh(slots); ex.stage(k * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm.data_ptr()))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(ksteps * 2):
+                ex.planes_refresh(slots); ex.stage((2 + k) * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm.data_ptr()))
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0) / (ksteps * 2)
+            nf = ex.fused_launches()
+            ex.close()
+            return round(Fm * FS / dt_ / 1e6, 1), nf
+
+        np_tab_f, nf1 = new_pictures(1, True, True)
+        np_tab_p, _ = new_pictures(1, False, True)
+        np_cmp_f, nf2 = new_pictures(2, True, False)
+        np_cmp_p, _ = new_pictures(2, False, False)
         moving = {
+            "new_pictures_every_frame": {
+                "table_levels_Msamples_per_s": max(np_tab_f, np_tab_p), "computed_levels_Msamples_per_s": max(np_cmp_f, np_cmp_p),
+                "one_kernel_from_the_pixels": {"table_levels": np_tab_f, "computed_levels": np_cmp_f, "kernel": "hvk_k_fused<13, LV>", "launches_that_way": [nf1, nf2]},
+                "through_picture_planes": {"table_levels": np_tab_p, "computed_levels": np_cmp_p, "kernels": "hvk_k_prep8<13, 1024, LV> + hvk_k_direct"},
+                "note": "%d pictures resident in HBM, every one NEW in every step (hvk_planes_refresh): table levels = shifted test cards (few colours: the 2^24-entry "
+                        "level table serves from cache), computed levels = gradients + noise (levels by FP64 arithmetic per pixel). The engine takes the one kernel "
+                        "by itself for a block whose pictures are mostly new (HVK_FUSED unset); the first figure of each pair is the faster of the two ways" % Fm,
+            },
             "workload": "-m i -s 16000000 --filter --noaudio, a different 832 x 576 picture on every frame (smooth gradients + noise), %d frames per step" % Fm,
             "with_uploads_Msamples_per_s": round(Fm * FS * ksteps / t_up / 1e6, 1),
             "with_uploads_from_pinned_memory_Msamples_per_s": round(Fm * FS * ksteps / t_pin / 1e6, 1),
             "pictures_resident_Msamples_per_s": round(Fm * FS * ksteps / t_res / 1e6, 1),
             "pictures_resident_planes_made_every_step_Msamples_per_s": round(Fm * FS * ksteps / t_prep / 1e6, 1),
-            "kernels": em.kernel_names(),
+            "kernels": em.kernel_names() + (["hvk_k_fused<13, 1> (%d launches of this engine rendered from the pixels)" % fused_used] if fused_used else []),
             "note": "with uploads: every picture goes host -> pinned ring -> HBM inside the timed loop (1.9 MB per frame over PCIe, plus the copy "
                     "into pinned memory on one host core); from pinned memory: the pictures already lie in page-locked memory "
                     "(hvk_frame_upload_pinned: one DMA per picture, no host copy); resident: the same launches re-using the uploaded pictures AND their planes; planes_made_every_step: the "
@@ -844,6 +1006,30 @@ def main():
             if v2:
                 log("%s: %s Msamples/s" % (k2, v2.get("Msamples_per_s")))
 
+    # ---- the several-devices path in C: at N = 1 two engines on this one device (everything but the second PCIe link is
+    # exercised), at N > 1 rank 0 drives one engine per device of the node after the ranks' own measurement ----
+    cgroup = None
+    if rank == 0 and not args.no_configs and not dry and os.environ.get("HVK_BENCH_CGROUP", "1") != "0":
+        try:
+            cgroup = c_group_section(H, g, [local_rank, local_rank] if N == 1 else list(range(N)), 64, 3, log)
+        except SystemExit:
+            raise
+        except Exception as ex:        # (never lets the headline fall: reported instead)
+            cgroup = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if N > 1:
+        dist.barrier()
+
+    hour = None
+    if rank == 0 and N == 1 and not args.no_hour and not args.no_configs:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import hour as hour_mod
+        hour = {"noaudio": hour_mod.run(H, g.frame("i_full"), g.audio, device=local_rank, sound=False, log=log)}
+        if args.hour_sound:
+            hour["with_sound"] = hour_mod.run(H, g.frame("i_full"), g.audio, device=local_rank, sound=True, log=log)
+        else:
+            hour["with_sound"] = {"not_run": "two minutes (the host's serial FM chain over 57.6 G samples): python bench.py --hour-sound; the run of record, every block's "
+                                             "sums and the cumulative sha256 at 9 000 / 45 000 / 90 000 frames against the reference: profiles/r04_hour_sound_full.json"}
+
     if rank == 0:
         names = e.kernel_names()
         one_kernel = len(names) == 1                        # hvk_k_direct (picture planes): the whole render in one kernel
@@ -883,6 +1069,26 @@ def main():
         roof["path_frac"] = round(path_ach / HBM_PEAK_GBS, 4)
         roof["path_achieved"] = round(path_ach, 1)
         roof["path_note"] = "4 B x samples of a step / ms_per_step / n_gpus against the same 8 TB/s: the fraction the whole path achieves per GPU"
+        # the handful of numbers a reader of the headline wants beside it (their sections below have the detail)
+        def _g(d, *keys):
+            for k_ in keys:
+                if not isinstance(d, dict) or k_ not in d:
+                    return None
+                d = d[k_]
+            return d
+        also = {
+            "new_pictures_every_frame_table_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "table_levels_Msamples_per_s"),
+            "new_pictures_every_frame_computed_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "computed_levels_Msamples_per_s"),
+            "secam_l_test_card_Msamples_per_s": _g(secam, "Msamples_per_s"),
+            "secam_l_pictures_change_every_frame_Msamples_per_s": _g(secam, "pictures_change_every_frame", "Msamples_per_s"),
+            "config1_path_frac": _g(configs, "1_pal_baseband", "path_frac"), "config3_path_frac": _g(configs, "3_ntsc_m", "path_frac"),
+            "config4_noaudio_device_path_frac": _g(configs, "4_secam_l_teletext_noaudio_device", "path_frac"),
+            "config2_noaudio_path_frac": _g(configs, "2_noaudio", "path_frac"),
+            "end_to_end_Msamples_per_s": _g(e2e, "Msamples_per_s"),
+            "dropin_config2_Msamples_per_s": _g(configs, "2_dropin", "Msamples_per_s"), "dropin_config2_noaudio_Msamples_per_s": _g(configs, "2_noaudio_dropin", "Msamples_per_s"),
+            "one_hour_noaudio_wall_s": _g(hour, "noaudio", "wall_s"),
+            "c_group_noaudio_host_direct_Msamples_per_s": _g(cgroup, "noaudio", "host_direct_Msamples_per_s"),
+        }
         res = {
             "metric": "IQ Msamples/s (PAL-I AM-VSB, 16 MHz SR)",
             "value": round(value, 1),
@@ -899,14 +1105,21 @@ def main():
                     "The test card's picture planes (levels, low-passed chroma, burst: per-picture work, hvk_k_prep) are made once when the picture "
                     "is uploaded, OUTSIDE the timed loop, like the other side inputs; with a new picture on every frame that work is per frame: "
                     "moving_pictures.pictures_resident_planes_made_every_step",
+            "ms_per_step_min": round(sub_ms[0], 4) if sub_ms else None,
+            "ms_per_step_median": round(sub_ms[len(sub_ms) // 2], 4) if sub_ms else None,
+            "settle": {"seconds": args.settle, "untimed_steps": settle_steps, "note": "the same launches, untimed, after the warm-up steps and before the clock starts"},
             "config": {
                 "workload": "-m i -s 16000000 --filter test%s (PAL-I AM-VSB + 51-tap FIR, FM mono + NICAM)" % (" --noaudio" if args.noaudio else ""),
                 "frames_per_gpu_per_step": F,
                 "samples_per_step": samples_per_step,
+                "also_measured": also,
                 "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, ", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else ""),
             },
             "parity_gate": gate,
-            "multi_gpu": None if N == 1 else {
+            "multi_gpu": {"ranks": 1, "backend": "none (one process, one device)", "c_group": cgroup,
+                          "reassembly": "host-direct (every engine's block straight into the host stream buffer) and gathered on a root device (hvk_group_gather): both in c_group",
+                          "sound_chains": "one recurrence over every sample of the stream: with sound the scaling curve is flat by construction (about 0.5 Gsamples/s, one host core), only --noaudio scales"} if N == 1 else {
+                "c_group": cgroup,
                 "ranks": N, "world_size": dist.get_world_size(),
                 "backend": (args.dry_run_backend + " (dry run: every rank on GPU 0, transport through host memory)") if dry else "nccl (RCCL); the sound chains' state between hosts: gloo",
                 "walk_rounds": bool(args.walk_rounds), "walk_gate": walk_gate,
@@ -938,6 +1151,8 @@ def main():
             res["secam_l"] = secam
         if configs:
             res["baseline_configs"] = configs
+        if hour:
+            res["5_one_hour"] = hour
         if not args.no_cpu_baseline and N == 1:
             res["cpu_baseline"] = cpu_baseline(log)
         print(json.dumps(res), flush=True)

@@ -49,6 +49,7 @@ struct hvk_slot_t {
 	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
 	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
 	int plane_dirty;            /* the picture planes (hvk_direct.hip) have not been made from this picture yet */
+	int shown;                  /* ... although a block has shown it already (from the pixels, hvk_fused.hip): it stays, so its planes are worth making now */
 	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
 	int seeds_valid[6];         /* SECAM: the picture has been shown with this frame number modulo 6: its lines' entry states are kept */
 };
@@ -988,6 +989,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->height = fb ? h : 0;
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
+	s->shown = 0;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	if(fb == NULL)
@@ -1056,6 +1058,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->height = h;
 	s->interlaced = interlaced;
 	s->plane_dirty = 1;
+	s->shown = 0;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	if(!s->valid) return(HVK_OK);
@@ -1097,10 +1100,8 @@ extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const u
 	if(!e->t.k.teletext) return(HVK_UNSUPPORTED);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 
-	/* the staging buffers may still be in flight from the previous batch */
-	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipStreamSynchronize(e->stream));
-
+	/* (queued in host memory that only the next stage's op lists are built from -- _build_vbi_ops --: nothing of the device's
+	 * is touched and nothing waited for) */
 	uint32_t *dst = e->h_tt_pk + (size_t) frame_in_batch * 32 * 12;
 	for(int r = 0; r < 32; r++)
 	{
@@ -1708,7 +1709,7 @@ extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 		memset(e->slots[slots[i]].seeds_valid, 0, sizeof(e->slots[slots[i]].seeds_valid));
 	}
 	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
-	for(int i = 0; i < n; i++) e->slots[slots[i]].plane_dirty = 1;
+	for(int i = 0; i < n; i++) { e->slots[slots[i]].plane_dirty = 1; e->slots[slots[i]].shown = 0; }
 	return(HVK_OK);
 }
 
@@ -2219,11 +2220,13 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 					if(sl[j] < 0 || !e->slots[sl[j]].plane_dirty || seen[sl[j]]) continue;
 					seen[sl[j]] = 1;
 					dirty = true;
-					ndirty++;
+					if(!e->slots[sl[j]].shown) ndirty++;       /* (a picture that was shown before and is still here: its planes are made now) */
 				}
 			}
 		}
-		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || 2 * ndirty >= e->staged))
+		/* (levels by arithmetic -- pictures of many colours -- cost the one kernel more waves per SIMD than they are worth: 128 registers
+		 * a lane against 76; such blocks go through the planes, whose hvk_k_prep8 holds the arithmetic alone: measured, profiles/README.md) */
+		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || (2 * ndirty >= e->staged && !e->levels_computed)))
 		{
 			/* most of the block's pictures are new: from the pixels in one kernel (hvk_fused.hip), their planes are not made
 			 * (and stay marked: a later block that shows one of them again makes them then) */
@@ -2236,6 +2239,11 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 			if((r = hvk_launch_fused(&ra, &da, e->d_mfma_a28, e->stream)) != HVK_OK) return(r);
 			e->fused_count++;
 			fused_now = true;
+			for(int i = 0; i < e->staged; i++)
+			{
+				e->slots[e->staged_slots[i]].shown = 1;
+				if(e->staged_prev[i] >= 0) e->slots[e->staged_prev[i]].shown = 1;
+			}
 		}
 		else if(!dirty)
 		{

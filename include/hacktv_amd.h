@@ -407,7 +407,7 @@ int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n);
 /* Pictures that change: where a block shows mostly NEW pictures (at least half of its frames) and the configuration allows
  * it -- PAL colour at 1024 samples per line with the video filter: the metric configuration's geometry -- the block is
  * rendered from the pixels in one kernel (hvk_fused.hip) and the planes are not made at all: they would be written once and
- * read once. HVK_FUSED=0 in the environment keeps the planes, =1 takes the one kernel for every block with a new picture.
+ * read once. (Blocks whose levels are computed -- pictures of many colours, hvk_set_levels() -- keep the planes: faster, measured.) HVK_FUSED=0 in the environment keeps the planes, =1 takes the one kernel for every block with a new picture.
  * hvk_fused_launches(): how many launches went that way. */
 int64_t hvk_fused_launches(const hvk_engine_t *e);
 

@@ -198,11 +198,12 @@ def test_one_kernel_from_the_pixels_on_pictures_that_change(golden, levels, monk
             monkeypatch.delenv(k_)
         return np.concatenate(out), fused
 
-    a, fa = run({})                       # (new pictures on every frame: the one kernel by default)
+    a, fa = run({"HVK_FUSED": "1"})
+    d, fd = run({})                       # (new pictures on every frame: the one kernel by itself where the levels come from the table)
     b, fb = run({"HVK_FUSED": "0"})
     c, fc = run({"HVK_DIRECT": "0"})
-    assert fa == 2 and fb == 0 and fc == 0
-    for other, name in ((b, "the picture planes"), (c, "the kernel pair")):
+    assert fa == 2 and fb == 0 and fc == 0 and fd == (2 if levels == 1 else 0)
+    for other, name in ((b, "the picture planes"), (c, "the kernel pair"), (d, "the engine's own choice")):
         bad = np.nonzero((a != other).any(axis=1))[0]
         assert bad.size == 0, "%d samples differ from %s, first at %d (frame %d, line %d, sample %d)" % (
             bad.size, name, bad[0], bad[0] // 640000, bad[0] % 640000 // 1024, bad[0] % 1024)
