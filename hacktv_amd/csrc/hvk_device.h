@@ -158,6 +158,7 @@ typedef struct {
 	const signed char *vbi_map;   /* [frames][lines]: op of the line or -1 */
 	const int16_t *vits_l;        /* VITS: [n][width] luma added */
 	const int16_t *vits_c;        /*       [n][width] chroma amplitude */
+	const int16_t *fsc_rows;      /* field-sequential colour: [2][width] the flag pulses as dense rows */
 	const int16_t *sis_dense;     /* sound-in-syncs: [50][HVK_SIS_SPAN] the half symbols as dense rows */
 	const int16_t *sis_win;       /*   the blanking window, k.sis_width values from sample k.sis_left */
 	const int16_t *sis_first;     /*   [HVK_SIS_SPAN] what the last never-emitted invocation leaves on the stream's first line */
@@ -189,6 +190,8 @@ typedef struct {
 	int64_t row_off;        /* the source row in the pool, less the sample of source pixel 0: pixel of sample x at pool[row_off + x] */
 	unsigned coff;          /* colour table position of the line's first sample */
 	int pal, vbi_op, vits_i;
+	int base_row;           /* the line's row of the base-line table */
+	int fsc, fsc_flag;      /* field-sequential colour: the channel the line shows (bits to shift a pixel right by), the flag row it carries or -1 */
 	int ax0, ax1, ar_eff;   /* samples [ax0, ax1) show a source pixel; luma is assigned up to ar_eff */
 	bool active, has_pix;
 	bool stream_first;      /* line 1 of the stream's first frame */
@@ -254,6 +257,25 @@ __device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, c
 	if(EXTRAS && k.vits && L.own)
 	{
 		for(int i = 0; i < 4; i++) if(i < k.vits && line0 == k.vits_line[i]) L.vits_i = i;
+	}
+
+	/* blanking + sync pulses: the row of the line's kind -- among the stream's first lines the one without what the line
+	 * before would leave behind its end (hvk_kconst_t.spill_lines) */
+	L.base_row = L.d.secam_fid >> 8;
+	if(k.spill_lines && f.frame_index == 0 && own && rel >= 0 && rel < k.spill_lines) L.base_row = (L.d.secam_fid >> 1) & 0x7F;
+
+	/* field-sequential colour: the frame's number counted from 1, two fields a frame (src/video.c:2919-2930); the flag on
+	 * one line of one field of the three (:3043-3063) */
+	L.fsc = 0;
+	L.fsc_flag = -1;
+	if(k.fsc_mode)
+	{
+		const int64_t frame_no = f.frame_index + 1 + (rel < 0 ? -1 : (rel >= k.lines ? 1 : 0));
+		const int line = line0 + 1;
+		const int fsc = (int) ((frame_no * 2 + (line < k.fsc_split ? 0 : 1)) % 3);
+		L.fsc = 8 * fsc;
+		if(k.fsc_mode == 1 && fsc == 1 && (line == 18 || line == 281)) L.fsc_flag = 0;
+		if(k.fsc_mode == 2 && fsc == 2 && (line == 1 || line == 203)) L.fsc_flag = line == 1 ? 0 : 1;
 	}
 
 	/* ---- picture geometry ---- */
@@ -326,7 +348,7 @@ __device__ __forceinline__ void raster_load_side(const hvk_kconst_t &k, const hv
 	/* the line's base: one aligned 16-byte load wherever the lane stands (rows are padded) */
 	{
 		const int xb = x0 < k.base_stride - SPL ? x0 : k.base_stride - SPL;
-		sd.base = *(const int4v *) (P.linebase + (size_t) (L.d.secam_fid >> 8) * k.base_stride + xb);
+		sd.base = *(const int4v *) (P.linebase + (size_t) L.base_row * k.base_stride + xb);
 	}
 	/* the lane's 8 burst window values in one 16-byte load from the zero-padded table (2-byte aligned:
 	 * global memory takes that); lanes away from the burst read zeros */
@@ -404,6 +426,12 @@ __device__ __forceinline__ void raster_gather(const hvk_kconst_t &k, const hvk_r
 		 * (and waiting for the loads) right where they were issued */
 #pragma unroll
 		for(int i = 0; i < PASSES; i++) asm volatile("" : "+v"(rgb[i]));
+		if(k.fsc_mode)
+		{
+			/* one colour channel of the pixel as a grey (src/video.c:2995-3000) */
+#pragma unroll
+			for(int i = 0; i < PASSES; i++) rgb[i] = ((rgb[i] >> L.fsc) & 0xFFu) * 0x010101u;
+		}
 #pragma unroll
 		for(int i = 0; i < PASSES; i++)
 		{
@@ -736,6 +764,14 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 				}
 			}
 		}
+	}
+
+	if(EXTRAS && L.fsc_flag >= 0 && x0 < W)
+	{
+		/* the field-sequential colour flag: a pulse added to the line (src/video.c:3043-3063) */
+		const int16_t *fr = P.fsc_rows + (size_t) L.fsc_flag * W + x0;
+#pragma unroll
+		for(int i = 0; i < SPL; i++) if(x0 + i < W) s[i] = wrap16(s[i] + fr[i]);
 	}
 
 	/* the line's ops, in the reference's process order (an anti-copy line can also carry VITC) */

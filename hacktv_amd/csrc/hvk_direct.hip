@@ -829,7 +829,7 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *
  * picture per frame, no inserters -- with the matrix-unit filter or none */
 extern "C" int hvk_direct_supported(const hvk_kconst_t *k, const void *mfma_a, int secam_fid, int max_frames)
 {
-	if(k->s_video || k->rawbb || k->rs_L || k->sis || k->fields != 1 || k->fm_video) return(0);        /* (VBI data lines and test signals: rows of their own per frame, hvk_dptrs_t.ovr_idx) */
+	if(k->s_video || k->rawbb || k->rs_L || k->sis || k->fields != 1 || k->fm_video || k->fsc_mode || k->spill_lines) return(0);      /* (field-sequential colour: what a picture's line looks like depends on the frame's number) */        /* (VBI data lines and test signals: rows of their own per frame, hvk_dptrs_t.ovr_idx) */
 	/* SECAM: the sub-carrier comes from the colour chain's slab, indexed with 32 bits */
 	(void) secam_fid;       /* (the identification lines: rows of their own per frame, like the VBI data lines) */
 	if(k->secam && (int64_t) (max_frames + 1) * k->raster_samples >= 0x7FFFFFFF) return(0);

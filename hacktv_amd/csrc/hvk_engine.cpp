@@ -85,7 +85,7 @@ struct hvk_engine {
 	void *d_vbi_sym, *d_vbi_val;
 	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	int8_t *d_map, *h_map;      /* [max_frames][lines] */
-	void *d_vits_l, *d_vits_c;
+	void *d_vits_l, *d_vits_c, *d_fsc_rows;
 	void *d_sis_dense, *d_sis_win, *d_sis_first;    /* sound-in-syncs tables */
 	uint32_t *d_sis_bits, *h_sis_bits;              /* [max_frames][lines][2]: the lines' bursts */
 	/* --raw-bb-file: queued stream (raw_q[0] is sample raw_base) and its per-batch slab */
@@ -664,6 +664,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENHIP(hipMalloc((void **) &e->d_map, (size_t) max_frames * k.lines));
 		OPENHIP(hipHostMalloc((void **) &e->h_map, (size_t) max_frames * k.lines, hipHostMallocDefault));
 	}
+	if(e->t.fsc_rows) OPENCHK(_upload(&e->d_fsc_rows, e->t.fsc_rows, sizeof(int16_t) * 2 * (size_t) k.width + 64));
 	if(e->t.k.vits)
 	{
 		OPENCHK(_upload(&e->d_vits_l, e->t.vits_l, sizeof(int16_t) * k.vits * k.width));
@@ -828,7 +829,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec };
+		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -2087,6 +2088,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	ra.vbi_val = (const int16_t *) e->d_vbi_val;
 	ra.vbi_ops = e->d_ops;
 	ra.vbi_map = (const signed char *) e->d_map;
+	ra.fsc_rows = (const int16_t *) e->d_fsc_rows;
 	ra.vits_l = (const int16_t *) e->d_vits_l;
 	ra.vits_c = (const int16_t *) e->d_vits_c;
 	ra.sis_dense = (const int16_t *) e->d_sis_dense;
@@ -2549,7 +2551,7 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 		return(HVK_OK);
 	}
 	const int sv = k.s_video ? 1 : 0;
-	const int extras = (sv || k.vbi || k.vits || k.rawbb || k.sis || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
+	const int extras = (sv || k.vbi || k.vits || k.rawbb || k.sis || k.fsc_mode || (k.secam && e->t.conf.secam_field_id)) ? 1 : 0;
 	const int wc = (!k.secam && !sv && !extras && nt == 13 && k.width == 1024) ? 1024 : 0;
 	const int vnt = k.vf_type ? k.vf_ntaps : 1;
 	const int exact = (!k.rs_irr && k.frame_samples % HVK_TILE == 0 && k.s_stride - k.s_lead - k.frame_samples >= 128) ? 1 : 0;

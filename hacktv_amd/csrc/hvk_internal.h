@@ -38,7 +38,9 @@ typedef struct {
 	int16_t src_row;        /* source row before centring / field shift, -1: none */
 	int16_t pal;            /* 0 no chroma, +1, -1 (PAL V switch) */
 	int16_t secam_fid;      /* bit 0: SECAM field identification line -- sub-carrier (and luma notch) without a picture;
-	                         * bits 8..: the line's row of the base-line table (blanking + sync pulses) */
+	                         * bits 8..: the line's row of the base-line table (blanking + sync pulses);
+	                         * bits 1..7: its row among the stream's first lines (hvk_kconst_t.spill_lines), where a pulse of the
+	                         * line before that runs past its end has NOT reached this one */
 } __attribute__((aligned(16))) hvk_linedesc_t;      /* 16 bytes, aligned: one scalar load on the device */
 
 /* RGB -> (Y,U,V) level conversion, evaluated in double on the device with
@@ -110,6 +112,12 @@ typedef struct {
 	int32_t sis;            /* sound-in-syncs: every line's sync area blanked through a window and carrying 4-level symbols */
 	int32_t sis_left, sis_width, sis_sync;  /* the window's first sample, its length, the level it blanks to */
 	int32_t sis_dummies;    /* never-emitted invocations before line 1: 1, or 3 behind a threaded colour process (SECAM) */
+	int32_t spill_lines;    /* a sync pulse of some line runs on into the next one (Baird's 240 lines: the broad pulse at mid-line is a line long).
+	                         * The reference's renderer stops at a line buffer that has not been used yet (src/vbidata.c:219-236 with
+	                         * src/video.c:4665): for the stream's first `spill_lines` lines the part that runs over is lost. 0: no such pulse */
+	int32_t fsc_mode;       /* field-sequential colour: 0 none, 1 Apollo (525 lines), 2 CBS (405 lines): a line shows ONE colour channel of the
+	                         * picture as grey -- channel (frame * 2 + field) mod 3, frames counted from 1 (src/video.c:2919-2930, :2995-3000) */
+	int32_t fsc_split;      /* first line (1-based) of the second field for that count: 264, 202 */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;
 
@@ -173,6 +181,7 @@ typedef struct {
 	int32_t acp_left[6], acp_psync_width, acp_pagc_width, acp_psync_level;
 	int32_t grey_y[256];        /* luma level of RGB (i, i, i): what ACP's AGC pulse follows */
 	int16_t *vits_l, *vits_c;   /* [vits][width]: luma added, chroma amplitude */
+	int16_t *fsc_rows;          /* field-sequential colour: [2][width] the flag pulse(s) as dense rows (src/video.c:4050-4073) */
 	/* sound-in-syncs (src/sis.c): the 50 half symbols as dense rows over the line's first HVK_SIS_SPAN samples, the
 	 * blanking window, and what the last never-emitted invocation leaves on the stream's first line */
 	int16_t *sis_dense;         /* [50][HVK_SIS_SPAN] */

@@ -29,6 +29,7 @@ typedef struct {
 	const unsigned *vbi_ops;    /* [nframes][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	const signed char *vbi_map; /* [nframes][lines] */
 	const int16_t *vits_l, *vits_c;
+	const int16_t *fsc_rows;    /* field-sequential colour flag pulses */
 	const int16_t *sis_dense, *sis_win, *sis_first;     /* sound-in-syncs tables */
 	const unsigned *sis_bits;   /* [nframes][lines + 1][2] */
 	const hvk_linedesc_t *desc;

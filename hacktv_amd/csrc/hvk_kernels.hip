@@ -746,6 +746,7 @@ extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P)
 	P->vbi_map = a->vbi_map;
 	P->vits_l = a->vits_l;
 	P->vits_c = a->vits_c;
+	P->fsc_rows = a->fsc_rows;
 	P->sis_dense = a->sis_dense;
 	P->sis_win = a->sis_win;
 	P->sis_first = a->sis_first;
@@ -798,7 +799,7 @@ static int _launch_raster1(const hvk_raster_args_t *a, hipStream_t stream)
 template<int NT, int SECAM, int SV>
 static int _launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 {
-	const bool extras = a->k.vbi || a->k.vits || a->k.rawbb || a->k.sis || (SECAM && a->secam_fid);
+	const bool extras = a->k.vbi || a->k.vits || a->k.rawbb || a->k.sis || a->k.fsc_mode || (SECAM && a->secam_fid);
 	if(SV || extras) return(_launch_raster1<NT, SECAM, SV, 1>(a, stream));
 	return(_launch_raster1<NT, SECAM, SV, 0>(a, stream));
 }

@@ -48,6 +48,66 @@ static void _raster_525w(hvk_config_t *c, double active_width, double sync_rise)
 	c->sync_rise = sync_rise;
 }
 
+/* the rasters of src/video.c:1303-1960 other than 625 / 525 lines: their numbers */
+static void _raster(hvk_config_t *c, int type, int64_t fnum, int64_t fden, int lines, int interlaced, int active_lines,
+                    double active_width, double active_left, double hsync, double vshort, double vlong, double sync_rise)
+{
+	c->type = type;
+	c->frame_rate = (hvk_rational_t) { fnum, fden };
+	c->lines = lines;
+	c->interlaced = interlaced;
+	c->active_lines = active_lines;
+	c->active_width = active_width;
+	c->active_left = active_left;
+	c->hsync_width = hsync;
+	c->vsync_short_width = vshort;
+	c->vsync_long_width = vlong;
+	c->sync_rise = sync_rise;
+}
+static void _raster_819(hvk_config_t *c) { _raster(c, HVK_RASTER_819, 25, 1, 819, 1, 720, 0.00003944, 0.00000890, 0.00000250, 0, 0.00002000, 0); }
+static void _raster_405(hvk_config_t *c) { _raster(c, HVK_RASTER_405, 25, 1, 405, 2, 378, 0.00008030, 0.00001680, 0.00000900, 0, 0.00004000, 0.00000025); }
+static void _raster_240(hvk_config_t *c) { _raster(c, HVK_BAIRD_240, 25, 1, 240, 0, 220, 0.00015, 0.000016667, 0.000013333, 0, 0.000166667, 0); }
+static void _raster_30(hvk_config_t *c)  { _raster(c, HVK_BAIRD_30, 25, 2, 30, 0, 30, 0.002666667, 0, 0, 0, 0, 0); c->frame_orientation = HVK_ROTATE_270 | HVK_HFLIP; }
+static void _raster_nbtv(hvk_config_t *c) { _raster(c, HVK_NBTV_32, 25, 2, 32, 0, 32, 2.5e-3 - 0.1e-3, 0.1e-3, 0.1e-3, 0, 0, 0); c->frame_orientation = HVK_ROTATE_270 | HVK_HFLIP; }
+/* (the long pulse is wider than half a line: the short one completes it, src/video.c:1821-1823) */
+static void _raster_apollo(hvk_config_t *c) { _raster(c, HVK_APOLLO_320, 10, 1, 320, 0, 312, 0.00028250, 0.00002500, 0.00002000, 1.0 / 10.0 / 320.0 / 2.0 - 45e-6, 0.00026750, 0); }
+static void _raster_cbs(hvk_config_t *c) { _raster(c, HVK_CBS_405, 72, 1, 405, 1, 376, 0.00002812, 0.00000480, 0.000002743, 0.000001372, 0.000014746, 0); }
+
+/* NTSC on 405 lines (BBC Engineering Division Monograph No. 32, Appendix A; src/video.c:1422-1433, :1538-1550) */
+static void _colour_ntsc405(hvk_config_t *c, double colour_bw)
+{
+	c->colour_mode = HVK_NTSC;
+	c->burst_width = 0.00000339;
+	c->burst_rise = 0.00000030;
+	c->burst_left = 0.00001050;
+	c->burst_level = 3.0 / 7.0;
+	c->colour_carrier = (hvk_rational_t) { 5315625, 2 };   /* 2657812.5 Hz */
+	c->colour_bw = colour_bw;
+	c->ev_co = 0.877;
+	c->eu_co = 0.493;
+}
+
+static void _fsc(hvk_config_t *c, int mode, double width, double left, double level)
+{
+	c->colour_mode = mode;
+	c->fsc_flag_width = width;
+	c->fsc_flag_left = left;
+	c->fsc_flag_level = level;
+}
+
+/* plain AM: the real signal on I (src/video.h:71) */
+static void _am(hvk_config_t *c, double white, double black, double blank, double sync)
+{
+	c->output_type = HVK_INT16_COMPLEX;
+	c->modulation = HVK_AM;
+	c->level = 1.0;
+	c->video_level = 1.0;
+	c->white_level = white;
+	c->black_level = black;
+	c->blanking_level = blank;
+	c->sync_level = sync;
+}
+
 /* ---- colour systems ---- */
 
 static void _colour_pal(hvk_config_t *c)
@@ -183,6 +243,25 @@ static const struct {
 	{ "ntsc-i",   "NTSC colour, 30/1.001 fps, 525 lines, AM (complex), 6.0 MHz FM audio" },
 	{ "pal60-i",  "PAL colour, 30/1.001 fps, 525 lines, AM (complex), 6.0 MHz FM audio" },
 	{ "pal60",    "PAL colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
+	{ "e",             "No colour, 25 fps, 819 lines, AM (complex), 11.15 MHz AM audio" },
+	{ "819",           "No colour, 25 fps, 819 lines, unmodulated (real)" },
+	{ "a",             "No colour, 25 fps, 405 lines, AM (complex), -3.5 MHz AM audio" },
+	{ "ntsc-a",        "NTSC colour, 25 fps, 405 lines, AM (complex), -3.5 MHz AM audio" },
+	{ "405-i",         "No colour, 25 fps, 405 lines, AM (complex), 6.0 MHz FM audio" },
+	{ "405",           "No colour, 25 fps, 405 lines, unmodulated (real)" },
+	{ "ntsc-405",      "NTSC colour, 25 fps, 405 lines, unmodulated (real)" },
+	{ "240-am",        "No colour, 25 fps, 240 lines, AM (complex)" },
+	{ "240",           "No colour, 25 fps, 240 lines, unmodulated (real)" },
+	{ "30-am",         "No colour, 12.5 fps, 30 lines, AM (complex)" },
+	{ "30",            "No colour, 12.5 fps, 30 lines, unmodulated (real)" },
+	{ "nbtv-am",       "No colour, 12.5 fps, 32 lines, AM (complex)" },
+	{ "nbtv",          "No colour, 12.5 fps, 32 lines, unmodulated (real)" },
+	{ "apollo-fsc-fm", "Field sequential colour, 30/1.001 fps, 525 lines, FM (complex), 1.25 MHz FM audio" },
+	{ "apollo-fsc",    "Field sequential colour, 30/1.001 fps, 525 lines, unmodulated (real)" },
+	{ "apollo-fm",     "No colour, 10 fps, 320 lines, FM (complex), 1.25 MHz FM audio" },
+	{ "apollo",        "No colour, 10 fps, 320 lines, unmodulated (real)" },
+	{ "m-cbs405",      "Field sequential colour, 72 fps, 405 lines, VSB (complex), 4.5MHz FM audio" },
+	{ "cbs405",        "Field sequential colour, 72 fps, 405 lines, unmodulated (real)" },
 	{ NULL, NULL },
 };
 
@@ -369,6 +448,145 @@ int hvk_config_preset(hvk_config_t *c, const char *id)
 		_baseband(c, 0.70, 0.00, 0.00, -0.30);
 		_raster_525w(c, 0.00005290, 0);
 		_colour_pal(c);
+	}
+	else if(strcmp(id, "e") == 0)
+	{
+		/* src/video.c:1303-1337: System E, 819 lines; the sound is AM, 11.15 MHz above the vision carrier */
+		_vsb(c, 2000000, 10400000, 0.8, 1.00, 0.35, 0.30, 0.00);
+		_raster_819(c);
+		c->am_audio_level = 0.2;
+		c->am_mono_carrier = 11.15e6;
+	}
+	else if(strcmp(id, "819") == 0)
+	{
+		/* src/video.c:1339-1366 */
+		_baseband(c, 0.70, 0.05, 0.00, -0.30);
+		c->video_bw = 10.4e6;
+		_raster_819(c);
+	}
+	else if(strcmp(id, "a") == 0)
+	{
+		/* src/video.c:1368-1403: System A, 405 lines; AM sound 3.5 MHz BELOW the vision carrier */
+		_vsb(c, 750000, 3000000, 0.8, 1.00, 0.30, 0.30, 0.00);
+		_raster_405(c);
+		c->am_audio_level = 0.2;
+		c->am_mono_carrier = -3500000;
+	}
+	else if(strcmp(id, "ntsc-a") == 0)
+	{
+		/* src/video.c:1405-1451 (video level reduced for NTSC's 122 % overshoot; no chroma low pass in the preset) */
+		_vsb(c, 750000, 3000000, 0.80 / 1.22, 1.00, 0.35, 0.30, 0.00);
+		_raster_405(c);
+		_colour_ntsc405(c, 0);
+		c->am_audio_level = 0.20;
+		c->am_mono_carrier = -3500000;
+	}
+	else if(strcmp(id, "405-i") == 0)
+	{
+		/* src/video.c:1453-1489 */
+		_vsb(c, 5500000, 1250000, 0.80, 0.20, 0.76, 0.76, 1.00);
+		_raster_405(c);
+		_fm_sound(c, 0.19, 6000000 - 400, 50000, HVK_50US);
+	}
+	else if(strcmp(id, "405") == 0)
+	{
+		/* src/video.c:1491-1519 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		c->video_bw = 3.0e6;
+		_raster_405(c);
+	}
+	else if(strcmp(id, "ntsc-405") == 0)
+	{
+		/* src/video.c:1521-1561 */
+		_baseband(c, 0.70, 0.05, 0.00, -0.30);
+		c->video_bw = 3.0e6;
+		_raster_405(c);
+		_colour_ntsc405(c, 1.1e6);
+	}
+	else if(strcmp(id, "240-am") == 0)
+	{
+		/* src/video.c:1563-1589 */
+		_am(c, 1.00, 0.40, 0.40, 0.00);
+		_raster_240(c);
+	}
+	else if(strcmp(id, "240") == 0)
+	{
+		/* src/video.c:1591-1615 (no video bandwidth in the preset) */
+		_baseband(c, 1.00, 0.40, 0.40, 0.00);
+		c->video_bw = 0;
+		_raster_240(c);
+	}
+	else if(strcmp(id, "30-am") == 0)
+	{
+		/* src/video.c:1617-1641: Baird 30 lines, scanned vertically, no sync pulses */
+		_am(c, 1.00, 0.00, 0.00, 0.00);
+		_raster_30(c);
+	}
+	else if(strcmp(id, "30") == 0)
+	{
+		/* src/video.c:1643-1665 */
+		_baseband(c, 1.00, -1.00, -1.00, -1.00);
+		c->video_bw = 0;
+		_raster_30(c);
+	}
+	else if(strcmp(id, "nbtv-am") == 0)
+	{
+		/* src/video.c:1667-1693: NBTV Club standard, negative modulation */
+		_am(c, 0.10, 0.73, 0.73, 1.00);
+		_raster_nbtv(c);
+	}
+	else if(strcmp(id, "nbtv") == 0)
+	{
+		/* src/video.c:1695-1719 */
+		_baseband(c, 1.00, 0.30, 0.30, 0.00);
+		c->video_bw = 0;
+		_raster_nbtv(c);
+	}
+	else if(strcmp(id, "apollo-fsc-fm") == 0)
+	{
+		/* src/video.c:1721-1767: Unified S-Band, Apollo colour: 525 lines, one colour channel per field */
+		_fm_video(c, 2e6, 0.5000, -0.1475, -0.2000, -0.5000);
+		_raster_525(c);
+		_fsc(c, HVK_APOLLO_FSC, 0.00002000, 0.00001470, 0.5000);
+		_fm_sound(c, 0.150, 1250000, 25000, 0);
+	}
+	else if(strcmp(id, "apollo-fsc") == 0)
+	{
+		/* src/video.c:1769-1801 */
+		_baseband(c, 0.70, 0.0525, 0.00, -0.30);
+		c->video_bw = 0;
+		_raster_525(c);
+		_fsc(c, HVK_APOLLO_FSC, 0.00002000, 0.00001470, 0.70);
+	}
+	else if(strcmp(id, "apollo-fm") == 0)
+	{
+		/* src/video.c:1803-1845: Apollo 10 fps, 320 lines */
+		_fm_video(c, 2e6, 0.50, -0.20, -0.20, -0.50);
+		_raster_apollo(c);
+		_fm_sound(c, 0.150, 1250000, 25000, 0);
+	}
+	else if(strcmp(id, "apollo") == 0)
+	{
+		/* src/video.c:1847-1880 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		c->video_bw = 0;
+		_raster_apollo(c);
+	}
+	else if(strcmp(id, "m-cbs405") == 0)
+	{
+		/* src/video.c:1882-1923: CBS field-sequential colour, 405 lines at 72 frames a second */
+		_vsb(c, 4200000, 750000, 0.77, 0.159, 0.595, 0.595, 1.000);
+		_raster_cbs(c);
+		_fsc(c, HVK_CBS_FSC, 0.000001372, 0.000008573, 1.000);
+		_fm_sound(c, 0.15, 4500000, 25000, HVK_75US);
+	}
+	else if(strcmp(id, "cbs405") == 0)
+	{
+		/* src/video.c:1925-1954 */
+		_baseband(c, 0.70, 0.00, 0.00, -0.30);
+		c->video_bw = 0;
+		_raster_cbs(c);
+		_fsc(c, HVK_CBS_FSC, 0.000001372, 0.000008573, -0.30);
 	}
 	else
 	{

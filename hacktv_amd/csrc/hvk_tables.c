@@ -94,17 +94,73 @@ static const _run_t _runs_525[] = {
 	{ 0, 0, 0, 0, 0, 0 },
 };
 
+/* The other rasters of src/video.c:2592-2810. None of them but the 405-line ones ('A' on lines that exist) carries a
+ * colour burst; the mechanical ones have no vertical interval to speak of. */
+static const _run_t _runs_819[] = {
+	{   1,   1, 2, -1, '-', 0 }, {   2,  38, 0, -1, '-', 0 }, {  39, 405, 0, -1, '-', 3 }, { 406, 406, 0, -1, '-', 1 },
+	{ 407, 408, 0, -1, '-', 0 }, { 409, 409, 0,  4, '-', 0 }, { 410, 446, 0, -1, '-', 0 }, { 447, 447, 0, -1, '-', 2 },
+	{ 448, 816, 0, -1, '-', 3 }, { 817, 819, 0, -1, '-', 0 }, { 0, 0, 0, 0, 0, 0 },
+};
+
+static const _run_t _runs_405[] = {
+	{   1,   4, 2,  4, '-', 0 }, {   5,  15, 0, -1, 'A', 0 }, {  16, 202, 0, -1, 'A', 3 }, { 203, 203, 0,  4, 'A', 1 },
+	{ 204, 206, 2,  4, '-', 0 }, { 207, 207, 2, -1, '-', 0 }, { 208, 217, 0, -1, 'A', 0 }, { 218, 218, 0, -1, 'A', 2 },
+	{ 219, 405, 0, -1, 'A', 3 }, { 0, 0, 0, 0, 0, 0 },
+};
+
+static const _run_t _runs_cbs405[] = {
+	{   1,   3, 1,  3, '-', 0 }, {   4,   6, 2,  4, '-', 0 }, {   7,   9, 1,  3, '-', 0 }, {  10,  14, 0, -1, '-', 0 },
+	{  15, 202, 0, -1, '-', 3 }, { 203, 203, 0,  3, '-', 1 }, { 204, 205, 1,  3, '-', 0 }, { 206, 206, 1,  4, '-', 0 },
+	{ 207, 208, 2,  4, '-', 0 }, { 209, 209, 2,  3, '-', 0 }, { 210, 211, 1,  3, '-', 0 }, { 212, 212, 1, -1, '-', 0 },
+	{ 213, 216, 0, -1, '-', 0 }, { 217, 217, 0, -1, '-', 2 }, { 218, 405, 0, -1, '-', 3 }, { 0, 0, 0, 0, 0, 0 },
+};
+
+static const _run_t _runs_apollo320[] = { { 1, 8, 2, 3, '-', 0 }, { 9, 320, 0, -1, '-', 3 }, { 0, 0, 0, 0, 0, 0 } };
+static const _run_t _runs_baird240[] = { { 1, 12, 2, 4, '-', 0 }, { 13, 20, 0, -1, '-', 0 }, { 21, 240, 0, -1, '-', 3 }, { 0, 0, 0, 0, 0, 0 } };
+static const _run_t _runs_baird30[] = { { 1, 30, -1, -1, '-', 3 }, { 0, 0, 0, 0, 0, 0 } };     /* no sync pulses at all */
+static const _run_t _runs_nbtv32[] = { { 1, 1, -1, -1, '-', 3 }, { 2, 32, 0, -1, '-', 3 }, { 0, 0, 0, 0, 0, 0 } };
+
+/* a raster type's runs and its number of lines (0: not a raster this engine renders) */
+static const _run_t *_runs_of(int type, int *lines)
+{
+	switch(type)
+	{
+	case HVK_RASTER_625: *lines = 625; return(_runs_625);
+	case HVK_RASTER_525: *lines = 525; return(_runs_525);
+	case HVK_RASTER_819: *lines = 819; return(_runs_819);
+	case HVK_RASTER_405: *lines = 405; return(_runs_405);
+	case HVK_CBS_405:    *lines = 405; return(_runs_cbs405);
+	case HVK_APOLLO_320: *lines = 320; return(_runs_apollo320);
+	case HVK_BAIRD_240:  *lines = 240; return(_runs_baird240);
+	case HVK_BAIRD_30:   *lines = 30;  return(_runs_baird30);
+	case HVK_NBTV_32:    *lines = 32;  return(_runs_nbtv32);
+	}
+	*lines = 0;
+	return(NULL);
+}
+
 static const _run_t *_find_run(const _run_t *r, int line)
 {
 	for(; r->first; r++) if(line >= r->first && line <= r->last) return(r);
 	return(NULL);
 }
 
-/* First source row of each field (src/video.c:2818-2831) */
+/* The source row a line shows, before centring (src/video.c:2812-2862) */
 static int _row_of_line(int type, int line)
 {
-	if(type == HVK_RASTER_625) return(line < 313 ? (line - 23) * 2 : (line - 336) * 2 + 1);
-	return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
+	switch(type)
+	{
+	case HVK_RASTER_625: return(line < 313 ? (line - 23) * 2 : (line - 336) * 2 + 1);
+	case HVK_RASTER_525: return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
+	case HVK_RASTER_819: return(line < 406 ? (line - 48) * 2 : (line - 457) * 2 + 1);
+	case HVK_RASTER_405: return(line < 210 ? (line - 16) * 2 : (line - 218) * 2 + 1);
+	case HVK_CBS_405:    return(line < 210 ? (line - 16) * 2 : (line - 219) * 2 + 1);
+	case HVK_APOLLO_320: return(line - 9);
+	case HVK_BAIRD_240:  return(line - 20);
+	case HVK_BAIRD_30:   return(line - 1);
+	case HVK_NBTV_32:    return(line - 1);
+	}
+	return(-1);
 }
 
 /* The part of a line that only depends on which sync pulses it carries: blanking level plus its own
@@ -115,21 +171,34 @@ static int _row_of_line(int type, int line)
  * row's index goes into the high byte of the descriptor's secam_fid. */
 static int _build_linebase(hvk_tables_t *t)
 {
-	const int W = t->k.width, n = 2 * t->conf.lines;
+	const int W = t->k.width, L = t->conf.lines, n = 2 * L;
 	const int stride = ((W + 7) & ~7) + 8;
-	int key[64][3], nbase = 0, i, b, p, j;
+	int key[126][5], nbase = 0, i, b, p, j, pass;
 
+	/* a line's base: its own left and mid pulse, the part of the next line's left pulse in front of that line's sample 0,
+	 * and what the pulses of the line BEFORE leave behind their line's end (key[3], key[4]; -1: nothing) */
+	for(pass = 0; pass < 2; pass++)
 	for(i = 0; i < n; i++)
 	{
 		hvk_linedesc_t *d = &t->desc[i];
-		for(b = 0; b < nbase; b++) if(key[b][0] == d->pulse_left && key[b][1] == d->pulse_mid && key[b][2] == d->pulse_next) break;
+		const hvk_linedesc_t *pd = &t->desc[(i / L) * L + (i % L + L - 1) % L];
+		int k5[5] = { d->pulse_left, d->pulse_mid, d->pulse_next, -1, -1 };
+		if(pass == 0)
+		{
+			if(pd->pulse_left >= 0 && t->k.pulse_offset[pd->pulse_left] + t->k.pulse_length[pd->pulse_left] > W) k5[3] = pd->pulse_left;
+			if(pd->pulse_mid >= 0 && t->k.pulse_offset[pd->pulse_mid] + t->k.pulse_length[pd->pulse_mid] > W) k5[4] = pd->pulse_mid;
+			if(k5[3] >= 0 || k5[4] >= 0) t->k.spill_lines = 1;       /* (the count follows below) */
+		}
+		for(b = 0; b < nbase; b++) if(!memcmp(key[b], k5, sizeof(k5))) break;
 		if(b == nbase)
 		{
-			if(nbase == 64) return(HVK_UNSUPPORTED);
-			key[b][0] = d->pulse_left; key[b][1] = d->pulse_mid; key[b][2] = d->pulse_next;
+			if(nbase == 126) return(HVK_UNSUPPORTED);
+			memcpy(key[b], k5, sizeof(k5));
 			nbase++;
 		}
-		d->secam_fid = (int16_t) ((d->secam_fid & 1) | (b << 8));
+		/* pass 0: the row with what the line before left here (bits 8 ..); pass 1: the row without (bits 1 .. 7) */
+		if(pass == 0) d->secam_fid = (int16_t) ((d->secam_fid & 1) | (b << 8));
+		else d->secam_fid = (int16_t) (d->secam_fid | (b << 1));
 	}
 
 	free(t->linebase);
@@ -142,11 +211,11 @@ static int _build_linebase(hvk_tables_t *t)
 	{
 		int16_t *row = t->linebase + (size_t) b * stride;
 		for(j = 0; j < stride; j++) row[j] = (int16_t) t->k.blanking;
-		for(p = 0; p < 3; p++)
+		for(p = 0; p < 5; p++)
 		{
 			const int id = key[b][p];
 			if(id < 0) continue;
-			const int off = t->k.pulse_offset[id] + (p == 2 ? W : 0);
+			const int off = t->k.pulse_offset[id] + (p == 2 ? W : (p >= 3 ? -W : 0));
 			const int16_t *v = t->pulse_values + t->k.pulse_start[id];
 			for(j = 0; j < t->k.pulse_length[id]; j++)
 			{
@@ -160,10 +229,12 @@ static int _build_linebase(hvk_tables_t *t)
 static int _build_linedesc(hvk_tables_t *t)
 {
 	const hvk_config_t *c = &t->conf;
-	const _run_t *runs = c->type == HVK_RASTER_625 ? _runs_625 : _runs_525;
+	int nl;
+	const _run_t *runs = _runs_of(c->type, &nl);
 	int colour = c->colour_mode == HVK_PAL || c->colour_mode == HVK_NTSC;
 	int p, line;
 
+	if(!runs || nl != c->lines) return(HVK_UNSUPPORTED);
 	t->desc = calloc(2 * c->lines, sizeof(hvk_linedesc_t));
 	if(!t->desc) return(HVK_OUT_OF_MEMORY);
 
@@ -187,6 +258,7 @@ static int _build_linedesc(hvk_tables_t *t)
 			d->ar = (r->act & 2) ? t->k.active_left + t->k.active_width : t->k.half_width;
 		}
 		d->src_row = _row_of_line(c->type, line);
+		if(d->src_row < 0) d->src_row = -1;     /* (a line in front of the picture -- 819 lines: 39 .. 47 -- shows black) */
 
 		/* SECAM field identification lines at the top of each field (src/video.c:3101-3103) */
 		d->secam_fid = c->colour_mode == HVK_SECAM && c->secam_field_id && c->lines == 625 &&
@@ -201,7 +273,48 @@ static int _build_linedesc(hvk_tables_t *t)
 		}
 	}
 
-	return(_build_linebase(t));
+	/* the pulses the lines use end inside the line behind their own at the latest */
+	for(p = 0; p < 2 * c->lines; p++)
+	{
+		const int ids[2] = { t->desc[p].pulse_left, t->desc[p].pulse_mid };
+		for(line = 0; line < 2; line++)
+		{
+			if(ids[line] >= 0 && t->k.pulse_offset[ids[line]] + t->k.pulse_length[ids[line]] > 2 * t->k.width) return(HVK_UNSUPPORTED);
+		}
+	}
+	{
+		int r = _build_linebase(t);
+		if(r != HVK_OK) return(r);
+	}
+	if(t->k.spill_lines)
+	{
+		/* How many lines the stream is old before a pulse can run on into the line behind its own: the reference's line
+		 * buffers form a ring of `olines` (src/video.c:3578: every process adds its window, two neighbours share a buffer unless
+		 * one of them runs on a thread of its own), every buffer starts out with width 0, and the renderer stops at such a
+		 * buffer (src/vbidata.c:219-236) -- the buffer behind the line being drawn has been used once the raster has gone
+		 * round the ring: from stream line olines - 1 on. */
+		int olines = c->raw_bb ? 1 : 3, prev_thread = 0;
+#define PROCESS(nl, th) do { olines += (nl) - ((th) || prev_thread ? 0 : 1); prev_thread = (th); } while(0)
+		if(!c->raw_bb && c->colour_mode == HVK_SECAM) PROCESS(1, 1);
+		if(c->vits) PROCESS(1, 0);
+		if(c->wss) PROCESS(1, 0);
+		if(c->acp) PROCESS(1, 0);
+		if(c->vitc) PROCESS(1, 0);
+		if(c->cc608) PROCESS(1, 0);
+		if(c->sis) PROCESS(1, 0);
+		if(c->teletext) PROCESS(1, 0);
+		if(t->pixel_rate != t->sample_rate) PROCESS(2, 1);
+		if(c->vfilter) PROCESS(2, 1);                   /* (1 + the filter's delay of one line) */
+		PROCESS(1, 1);                                  /* audio, always */
+		if(c->modulation == HVK_FM) PROCESS(1, 1);
+		if(c->swap_iq) PROCESS(1, 0);
+		if(c->offset) PROCESS(1, 1);
+		if(c->passthru) PROCESS(1, 0);
+		PROCESS(1, 0);                                  /* output */
+#undef PROCESS
+		t->k.spill_lines = olines;      /* (the pulses of stream lines 0 .. olines - 2 lose what runs over: lines 1 .. olines - 1 receive nothing, nor does line 0) */
+	}
+	return(HVK_OK);
 }
 
 static hvk_c32_t _unit_phasor(double radians);
@@ -1239,9 +1352,11 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	c = &t->conf;
 
 	/* what the engine renders */
-	if(c->type != HVK_RASTER_625 && c->type != HVK_RASTER_525) return(HVK_UNSUPPORTED);
+	{
+		int nl;
+		if(!_runs_of(c->type, &nl) || nl != c->lines) return(HVK_UNSUPPORTED);
+	}
 	if(c->modulation == HVK_FM && (c->fm_level <= 0 || c->fm_deviation <= 0)) return(HVK_ERROR);
-	if((c->type == HVK_RASTER_625 && c->lines != 625) || (c->type == HVK_RASTER_525 && c->lines != 525)) return(HVK_UNSUPPORTED);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
 
 	/* defaults (src/video.c:3832-3836) */
@@ -1308,8 +1423,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			t->k.pulse_start[i] = total;
 			total += t->k.pulse_length[i] + HVK_PULSE_PAD;
 
-			/* a pulse must end inside its own line (true for every standard) */
-			if(first + t->k.pulse_length[i] > t->k.width || first < -t->k.width) return(HVK_UNSUPPORTED);
+			/* (a pulse may run on into the next line -- _build_linebase -- but no further) */
+			if(first < -t->k.width) return(HVK_UNSUPPORTED);
 		}
 
 		t->pulse_total = total;
@@ -1424,6 +1539,31 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		if(t->k.colour && t->k.burst_left + t->k.burst_width > t->k.width) return(HVK_UNSUPPORTED);
 	}
 	else if(t->k.colour) return(HVK_UNSUPPORTED);
+
+	if(c->colour_mode == HVK_APOLLO_FSC || c->colour_mode == HVK_CBS_FSC)
+	{
+		/* The flag pulse that marks one field of the colour sequence (src/video.c:4050-4073): rendered like the sync pulses,
+		 * kept as dense rows the raster kernel adds on the flag lines -- Apollo: one pulse, CBS: one at the line's start and
+		 * one half a line on */
+		const double amp = (c->fsc_flag_level - c->blanking_level) * level * INT16_MAX;
+		const double rise = c->sync_rise * EDGE_0_100 * pixel_rate;
+		const int np = c->colour_mode == HVK_CBS_FSC ? 2 : 1;
+		int16_t tmp[8192 + 64];
+		int p, first, len, j;
+
+		t->k.fsc_mode = c->colour_mode == HVK_APOLLO_FSC ? 1 : 2;
+		t->k.fsc_split = c->colour_mode == HVK_APOLLO_FSC ? 264 : 202;
+		t->fsc_rows = calloc((size_t) 2 * t->k.width + 32, sizeof(int16_t));
+		if(!t->fsc_rows) return(HVK_OUT_OF_MEMORY);
+		for(p = 0; p < np; p++)
+		{
+			const double at = (p ? line_s / 2 : 0) + c->fsc_flag_left;
+			len = _quantise_pulse(NULL, &first, at * pixel_rate, c->fsc_flag_width * pixel_rate, rise, (int) amp);
+			if(len > 8192 || first < 0 || first + len > t->k.width) return(HVK_UNSUPPORTED);   /* (the flag lies inside its line at every rate there is) */
+			_quantise_pulse(tmp, &first, at * pixel_rate, c->fsc_flag_width * pixel_rate, rise, (int) amp);
+			for(j = 0; j < len; j++) t->fsc_rows[(size_t) p * t->k.width + first + j] = tmp[j];
+		}
+	}
 
 	if(c->colour_mode == HVK_SECAM && (r = _build_secam(t, level)) != HVK_OK) return(r);
 
@@ -1676,6 +1816,7 @@ void hvk_tables_free(hvk_tables_t *t)
 	free(t->rs_taps);
 	free(t->vbi_sym);
 	free(t->vbi_val);
+	free(t->fsc_rows);
 	free(t->vits_l);
 	free(t->vits_c);
 	memset(t, 0, sizeof(*t));

@@ -335,9 +335,12 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 {
 	memset(h, 0, sizeof(*h));
 
-	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525) return(_refuse("this raster type"));
+	/* (src/video.h:50-59: the raster types' numbers are the engine's; MAC is a packet multiplex, not a raster) */
+	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525 && c->type != VID_RASTER_405 && c->type != VID_RASTER_819 && c->type != VID_BAIRD_240 &&
+	   c->type != VID_BAIRD_30 && c->type != VID_NBTV_32 && c->type != VID_APOLLO_320 && c->type != VID_CBS_405) return(_refuse("this raster type"));
 	if(c->modulation == VID_FM && c->fm_energy_dispersal) return(_refuse("FM energy dispersal"));
-	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM) return(_refuse("this colour mode"));
+	if(c->colour_mode != VID_NONE && c->colour_mode != VID_PAL && c->colour_mode != VID_NTSC && c->colour_mode != VID_SECAM &&
+	   c->colour_mode != VID_APOLLO_FSC && c->colour_mode != VID_CBS_FSC) return(_refuse("this colour mode"));
 	if(c->teletext && c->lines != 625) return(_refuse("teletext on a raster other than 625 lines"));
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->eurocrypt) return(_refuse("a scrambler"));
@@ -345,7 +348,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->sis && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->raw_bb_file || c->s_video)) return(_refuse("sound-in-syncs with --pixelrate / raw baseband input / S-Video"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file && c->s_video) return(_refuse("raw baseband input with --s-video"));
-	if(c->frame_orientation) return(_refuse("frame orientation"));
 
 	h->output_type = c->output_type;
 	h->modulation = c->modulation;
@@ -357,7 +359,7 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->fm_mono_level = c->fm_mono_level;
 	h->am_audio_level = c->am_audio_level;
 	h->nicam_level = c->nicam_level;
-	h->type = c->type == VID_RASTER_625 ? HVK_RASTER_625 : HVK_RASTER_525;
+	h->type = c->type;
 	h->frame_rate.num = c->frame_rate.num;
 	h->frame_rate.den = c->frame_rate.den;
 	h->lines = c->lines;
@@ -380,7 +382,12 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	h->rw_co = c->rw_co;
 	h->gw_co = c->gw_co;
 	h->bw_co = c->bw_co;
-	h->colour_mode = c->colour_mode == VID_PAL ? HVK_PAL : (c->colour_mode == VID_NTSC ? HVK_NTSC : (c->colour_mode == VID_SECAM ? HVK_SECAM : HVK_MONOCHROME));
+	h->colour_mode = c->colour_mode == VID_PAL ? HVK_PAL : (c->colour_mode == VID_NTSC ? HVK_NTSC : (c->colour_mode == VID_SECAM ? HVK_SECAM :
+	                 (c->colour_mode == VID_APOLLO_FSC ? HVK_APOLLO_FSC : (c->colour_mode == VID_CBS_FSC ? HVK_CBS_FSC : HVK_MONOCHROME))));
+	h->fsc_flag_width = c->fsc_flag_width;
+	h->fsc_flag_left = c->fsc_flag_left;
+	h->fsc_flag_level = c->fsc_flag_level;
+	h->frame_orientation = c->frame_orientation;
 	h->colour_carrier.num = c->colour_carrier.num;
 	h->colour_carrier.den = c->colour_carrier.den;
 	h->colour_bw = c->colour_bw;
@@ -688,6 +695,14 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket, hvk_engine
 		 * its sound shows its last picture once more (the failed read leaves the frame as it was) and
 		 * blank frames from then on (src/av.c:55-59) */
 		av_read_video(&s->av, f);
+		/* src/video.c:4883-4885: the systems that scan vertically turn every picture (pointer and stride arithmetic, src/av.c:242-290;
+		 * the upload gathers along whatever strides it is given) */
+		if(s->conf.frame_orientation)
+		{
+			av_rotate_frame(f, s->conf.frame_orientation & 3);
+			if(s->conf.frame_orientation & VID_HFLIP) av_hflip_frame(f);
+			if(s->conf.frame_orientation & VID_VFLIP) av_vflip_frame(f);
+		}
 
 		if((m->g ? hvk_group_frame_upload(m->g, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced)
 		        : hvk_frame_upload(m->e, slot, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced)) != HVK_OK) return(-1);
@@ -706,6 +721,12 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket, hvk_engine
 		{
 			if(av_eof(&s->av)) { m->ended = 1; break; }
 			av_read_video(&s->av, f);
+			if(s->conf.frame_orientation)
+			{
+				av_rotate_frame(f, s->conf.frame_orientation & 3);
+				if(s->conf.frame_orientation & VID_HFLIP) av_hflip_frame(f);
+				if(s->conf.frame_orientation & VID_VFLIP) av_vflip_frame(f);
+			}
 			if(hvk_frame_upload(m->e, slot + 1, f->framebuffer, f->width, f->height, f->pixel_stride, f->line_stride, f->interlaced) != HVK_OK) return(-1);
 			slots[slot + 1] = slot + 1;
 			if(s->conf.cc608) _cc_push(m, f->cc608);

@@ -79,6 +79,10 @@ class HvkConfig(C.Structure):
         ("swap_iq", C.c_int),
         ("offset", C.c_int64),
         ("passthru", C.c_int),
+        ("fsc_flag_width", C.c_double),
+        ("fsc_flag_left", C.c_double),
+        ("fsc_flag_level", C.c_double),
+        ("frame_orientation", C.c_int),
     ]
 
 

@@ -30,6 +30,22 @@ extern "C" {
 /* Raster type: src/video.h:50-59 */
 #define HVK_RASTER_625 0
 #define HVK_RASTER_525 1
+#define HVK_RASTER_405 2
+#define HVK_RASTER_819 3
+#define HVK_BAIRD_240  4
+#define HVK_BAIRD_30   5
+#define HVK_NBTV_32    6
+#define HVK_APOLLO_320 7
+#define HVK_CBS_405    9
+
+/* How the caller turns a source picture before it hands it over (src/video.h:62-67, src/video.c:4883-4885): the mechanical
+ * systems scan vertically. The engine shows what it is given; the video.h shim applies this to every frame it pulls. */
+#define HVK_ROTATE_0   0
+#define HVK_ROTATE_90  1
+#define HVK_ROTATE_180 2
+#define HVK_ROTATE_270 3
+#define HVK_HFLIP      4
+#define HVK_VFLIP      8
 
 /* Output modulation: src/video.h:70-73 */
 #define HVK_NONE 0
@@ -42,6 +58,8 @@ extern "C" {
 #define HVK_PAL        1
 #define HVK_NTSC       2
 #define HVK_SECAM      3
+#define HVK_APOLLO_FSC 4 /* field-sequential colour: one of the picture's colour channels per field, as luma */
+#define HVK_CBS_FSC    5
 
 /* Audio pre-emphasis: src/video.h:85-87 */
 #define HVK_50US 1
@@ -68,7 +86,7 @@ typedef struct hvk_config_t {
 	double am_audio_level;
 	double nicam_level;
 
-	int type;                   /* HVK_RASTER_625 | HVK_RASTER_525 */
+	int type;                   /* HVK_RASTER_625 | _525 | _405 | _819, HVK_BAIRD_240 | _30, HVK_NBTV_32, HVK_APOLLO_320, HVK_CBS_405 */
 	hvk_rational_t frame_rate;
 	int lines;
 	int hline;                  /* 0 = derive, src/video.c:3832 */
@@ -167,6 +185,17 @@ typedef struct hvk_config_t {
 	int passthru;               /* != 0: an int16 I/Q stream is added to the output; the samples are
 	                             * supplied with hvk_passthru_write() (the reference's conf.passthru
 	                             * names the file, which stays with the caller) */
+
+	/* (members added after the first release stand at the END: an embedder built against an earlier header hands over a
+	 * struct whose members up to here lie where they lay) */
+
+	/* Field-sequential colour (colour_mode HVK_APOLLO_FSC / HVK_CBS_FSC, src/video.c:2919-2930, :3043-3063): the flag
+	 * pulse that marks one of the three fields of the colour sequence, src/video.h:236-238 */
+	double fsc_flag_width;      /* seconds */
+	double fsc_flag_left;
+	double fsc_flag_level;
+
+	int frame_orientation;      /* HVK_ROTATE_* | HVK_HFLIP | HVK_VFLIP, src/video.h:62-67 */
 
 } hvk_config_t;
 

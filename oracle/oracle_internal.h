@@ -80,6 +80,8 @@ struct orc_t {
 
 	/* the five sync pulses: h, v, V, mid-v, mid-V (src/video.c:3885-3891) */
 	orc_pulse_t sync[5];
+	orc_pulse_t fsc[2];         /* field-sequential colour flag pulses (src/video.c:4050-4073) */
+	int olines;                 /* line buffers in the reference's ring (src/video.c:3578): a buffer has width 0 until the raster has used it once */
 	int16_t *sync_packed;       /* the reference's packed vbidata table, for comparison */
 	long sync_packed_len;
 

@@ -73,6 +73,59 @@ static _linecode_t _line_code(int type, int line)
 		else if(line == 263)                              c = (_linecode_t) { 'h', 'v', 1, 1, 0 };
 		else if(line == 283)                              c = (_linecode_t) { 'h', 0, 1, 0, 1 };
 	}
+	else if(type == HVK_RASTER_819)
+	{
+		/* src/video.c:2592-2696: no colour, no equalising pulses, one long pulse per field */
+		c = (_linecode_t) { 'h', 0, 0, 1, 1 };                                       /* "h_aa" */
+		if(line == 1)                                     c = (_linecode_t) { 'V', 0, 0, 0, 0 };
+		else if(line <= 38 || line >= 817 || (line >= 407 && line <= 446 && line != 409)) c = (_linecode_t) { 'h', 0, 0, 0, 0 };
+		else if(line == 406)                              c = (_linecode_t) { 'h', 0, 0, 1, 0 };
+		else if(line == 409)                              c = (_linecode_t) { 'h', 'V', 0, 0, 0 };
+		else if(line == 447)                              c = (_linecode_t) { 'h', 0, 0, 0, 1 };
+	}
+	else if(type == HVK_RASTER_405)
+	{
+		/* src/video.c:2697-2738 */
+		if(line <= 4 || (line >= 204 && line <= 206))     c = (_linecode_t) { 'V', 'V', 0, 0, 0 };
+		else if(line == 207)                              c = (_linecode_t) { 'V', 0, 0, 0, 0 };
+		else if(line <= 15 || (line >= 208 && line <= 217)) c = (_linecode_t) { 'h', 0, 1, 0, 0 };
+		else if(line == 203)                              c = (_linecode_t) { 'h', 'V', 1, 1, 0 };
+		else if(line == 218)                              c = (_linecode_t) { 'h', 0, 1, 0, 1 };
+	}
+	else if(type == HVK_CBS_405)
+	{
+		/* src/video.c:2739-2779 */
+		c = (_linecode_t) { 'h', 0, 0, 1, 1 };
+		if(line <= 3 || (line >= 7 && line <= 9) || line == 204 || line == 205 ||
+		   line == 210 || line == 211)                    c = (_linecode_t) { 'v', 'v', 0, 0, 0 };
+		else if(line <= 6 || line == 207 || line == 208)  c = (_linecode_t) { 'V', 'V', 0, 0, 0 };
+		else if(line == 206)                              c = (_linecode_t) { 'v', 'V', 0, 0, 0 };
+		else if(line == 209)                              c = (_linecode_t) { 'V', 'v', 0, 0, 0 };
+		else if(line == 212)                              c = (_linecode_t) { 'v', 0, 0, 0, 0 };
+		else if(line <= 14 || (line >= 213 && line <= 216)) c = (_linecode_t) { 'h', 0, 0, 0, 0 };
+		else if(line == 203)                              c = (_linecode_t) { 'h', 'v', 0, 1, 0 };
+		else if(line == 217)                              c = (_linecode_t) { 'h', 0, 0, 0, 1 };
+	}
+	else if(type == HVK_APOLLO_320)
+	{
+		/* src/video.c:2780-2784 */
+		c = line <= 8 ? (_linecode_t) { 'V', 'v', 0, 0, 0 } : (_linecode_t) { 'h', 0, 0, 1, 1 };
+	}
+	else if(type == HVK_BAIRD_240)
+	{
+		/* src/video.c:2785-2812 */
+		c = (_linecode_t) { 'h', 0, 0, 1, 1 };
+		if(line <= 12)                                    c = (_linecode_t) { 'V', 'V', 0, 0, 0 };
+		else if(line <= 20)                               c = (_linecode_t) { 'h', 0, 0, 0, 0 };
+	}
+	else if(type == HVK_BAIRD_30)
+	{
+		c = (_linecode_t) { 0, 0, 0, 1, 1 };             /* no sync pulses at all, src/video.c:2813-2817 */
+	}
+	else if(type == HVK_NBTV_32)
+	{
+		c = (_linecode_t) { (char) (line == 1 ? 0 : 'h'), 0, 0, 1, 1 };            /* src/video.c:2818-2825 */
+	}
 
 	return(c);
 }
@@ -82,6 +135,12 @@ static int _source_row(int type, int line)
 {
 	if(type == HVK_RASTER_625) return(line < 313 ? (line - 23) * 2 : (line - 336) * 2 + 1);
 	if(type == HVK_RASTER_525) return(line < 265 ? (line - 23) * 2 : (line - 286) * 2 + 1);
+	if(type == HVK_RASTER_819) return(line < 406 ? (line - 48) * 2 : (line - 457) * 2 + 1);
+	if(type == HVK_RASTER_405) return(line < 210 ? (line - 16) * 2 : (line - 218) * 2 + 1);
+	if(type == HVK_CBS_405)    return(line < 210 ? (line - 16) * 2 : (line - 219) * 2 + 1);
+	if(type == HVK_APOLLO_320) return(line - 9);
+	if(type == HVK_BAIRD_240)  return(line - 20);
+	if(type == HVK_BAIRD_30 || type == HVK_NBTV_32) return(line - 1);
 	return(-1);
 }
 
@@ -98,6 +157,9 @@ static void _add_pulse(orc_t *s, long g, const orc_pulse_t *p)
 	{
 		int16_t *l;
 		if(n < 0) continue;
+		/* running on into the line behind: that line's buffer has width 0 -- a boundary the renderer stops at
+		 * (src/vbidata.c:219-236) -- until the raster has been round the ring once (src/video.c:4665) */
+		if(n / s->width > g && g < s->olines - 1) break;
 		l = orc_line_ptr(s, n / s->width);
 		if(l == NULL) continue;
 		l[n % s->width] += p->value[x];
@@ -136,7 +198,7 @@ void orc_raster_line(orc_t *s, long g)
 	_linecode_t code = _line_code(c->type, line);
 	int16_t *o = orc_line_ptr(s, g);
 	int W = s->width;
-	int vy, pal = 0, x;
+	int vy, pal = 0, x, fsc = 0;
 	const c16_t *lut = NULL;
 	int vframe_x, vframe_y;
 
@@ -195,6 +257,10 @@ void orc_raster_line(orc_t *s, long g)
 		}
 	}
 
+	/* field-sequential colour: which channel this field shows (src/video.c:2919-2930) */
+	if(c->colour_mode == HVK_APOLLO_FSC) fsc = (frame * 2 + (line < 264 ? 0 : 1)) % 3;
+	if(c->colour_mode == HVK_CBS_FSC)    fsc = (frame * 2 + (line < 202 ? 0 : 1)) % 3;
+
 	/* sync pulses, bit order h, v, V, mid-v, mid-V (src/video.c:2944-2958) */
 	if(code.left == 'h') _add_pulse(s, g, &s->sync[0]);
 	if(code.left == 'v') _add_pulse(s, g, &s->sync[1]);
@@ -211,7 +277,9 @@ void orc_raster_line(orc_t *s, long g)
 		const uint32_t *prgb = NULL;
 		int stride = 0;
 
-		for(x = al; x < s->active_left + vframe_x; x++) o[x] = black;
+		/* (NBTV at 800 kHz: active_left + active_width = W + 1 -- the reference writes one sample past its line buffer,
+		 * into its heap; here the stream is contiguous and that sample would be the next line's first: not written) */
+		for(x = al; x < s->active_left + vframe_x; x++) if(x < W) o[x] = black;
 
 		if(s->fb && vy >= 0)
 		{
@@ -223,8 +291,14 @@ void orc_raster_line(orc_t *s, long g)
 		for(; x < s->active_left + vframe_x + s->fb_width && x < ar; x++)
 		{
 			uint32_t rgb = prgb ? (*prgb & 0xFFFFFF) : 0;
-			o[x] = s->yuv[rgb * 3 + 0];
-			if(pal)
+			if(c->colour_mode == HVK_APOLLO_FSC || c->colour_mode == HVK_CBS_FSC)
+			{
+				/* one channel as a grey, src/video.c:2995-3000 */
+				rgb = (rgb >> (8 * fsc)) & 0xFF;
+				rgb |= (rgb << 8) | (rgb << 16);
+			}
+			if(x < W) o[x] = s->yuv[rgb * 3 + 0];
+			if(pal && x < W)
 			{
 				s->chroma[x * 2 + 0] = s->yuv[rgb * 3 + 1];
 				s->chroma[x * 2 + 1] = s->yuv[rgb * 3 + 2];
@@ -232,7 +306,7 @@ void orc_raster_line(orc_t *s, long g)
 			if(prgb) prgb += stride;
 		}
 
-		for(; x < ar; x++) o[x] = black;
+		for(; x < ar; x++) if(x < W) o[x] = black;
 	}
 
 	if(pal)
@@ -260,6 +334,10 @@ void orc_raster_line(orc_t *s, long g)
 			}
 		}
 	}
+
+	/* the field-sequential colour flags (src/video.c:3043-3063) */
+	if(c->colour_mode == HVK_APOLLO_FSC && fsc == 1 && (line == 18 || line == 281)) _add_pulse(s, g, &s->fsc[0]);
+	if(c->colour_mode == HVK_CBS_FSC && fsc == 2 && (line == 1 || line == 203)) _add_pulse(s, g, &s->fsc[line == 1 ? 0 : 1]);
 }
 
 /* What the SECAM process needs to know about a line (src/video.c:3078-3090) */

@@ -330,6 +330,42 @@ int orc_build_tables(orc_t *s)
 		s->sync_packed_len = o;
 	}
 
+	/* The ring of line buffers (src/video.c:3548-3580, :4176-4638): every process adds its window of `nlines`, two
+	 * neighbours share one buffer unless either runs on a thread of its own */
+	{
+		int prev_thread = 0;
+		s->olines = c->raw_bb ? 1 : 3;
+#define PROCESS(nl, th) do { s->olines += (nl) - ((th) || prev_thread ? 0 : 1); prev_thread = (th); } while(0)
+		if(!c->raw_bb && c->colour_mode == HVK_SECAM) PROCESS(1, 1);
+		if(c->vits) PROCESS(1, 0);
+		if(c->wss) PROCESS(1, 0);
+		if(c->acp) PROCESS(1, 0);
+		if(c->vitc) PROCESS(1, 0);
+		if(c->cc608) PROCESS(1, 0);
+		if(c->sis) PROCESS(1, 0);
+		if(c->teletext) PROCESS(1, 0);
+		if(s->pixel_rate != s->sample_rate) PROCESS(2, 1);
+		if(c->vfilter) PROCESS(2, 1);
+		PROCESS(1, 1);
+		if(c->modulation == HVK_FM) PROCESS(1, 1);
+		if(c->swap_iq) PROCESS(1, 0);
+		if(c->offset) PROCESS(1, 1);
+		if(c->passthru) PROCESS(1, 0);
+		PROCESS(1, 0);
+#undef PROCESS
+	}
+
+	/* field-sequential colour: the flag pulse(s), src/video.c:4050-4073 */
+	if(c->colour_mode == HVK_APOLLO_FSC || c->colour_mode == HVK_CBS_FSC)
+	{
+		const double fd = (c->fsc_flag_level - c->blanking_level) * level * INT16_MAX;
+		_pulse(&s->fsc[0], c->fsc_flag_left * s->pixel_rate, c->fsc_flag_width * s->pixel_rate, c->sync_rise * IRT1090 * s->pixel_rate, (int) fd);
+		if(c->colour_mode == HVK_CBS_FSC)
+		{
+			_pulse(&s->fsc[1], (width / 2 + c->fsc_flag_left) * s->pixel_rate, c->fsc_flag_width * s->pixel_rate, c->sync_rise * IRT1090 * s->pixel_rate, (int) fd);
+		}
+	}
+
 	_build_yuv(s, level);
 
 	/* colour subcarrier: src/video.c:3961-3987 */
@@ -515,6 +551,7 @@ void orc_free_tables(orc_t *s)
 {
 	int i;
 	for(i = 0; i < 5; i++) free(s->sync[i].value);
+	for(i = 0; i < 2; i++) free(s->fsc[i].value);
 	free(s->sync_packed);
 	free(s->yuv);
 	free(s->colour_lookup);

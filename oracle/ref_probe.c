@@ -126,6 +126,13 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 		.sample_rate = (r64_t) { HACKTV_AUDIO_SAMPLE_RATE, 1 },
 	};
 
+	/* src/hacktv.c:1520-1526: the dimensions change places where the lines are scanned vertically */
+	if((p->vid.conf.frame_orientation & 3) == VID_ROTATE_90 || (p->vid.conf.frame_orientation & 3) == VID_ROTATE_270)
+	{
+		p->vid.av.width = p->vid.conf.active_lines;
+		p->vid.av.height = p->vid.active_width;
+	}
+
 	if(av_test_open(&p->vid.av) != AV_OK)
 	{
 		vid_free(&p->vid);

@@ -36,10 +36,13 @@ def test_presets_match_the_reference_mode_ids():
     while H.lib().hvk_preset_id(i):
         ids.append(H.lib().hvk_preset_id(i).decode())
         i += 1
-    # every 625 / 525-line mode of the reference's vid_configs[] (src/video.c:1956-2008) but ntsc-bs (DANCE digital audio)
+    # every mode of the reference's vid_configs[] (src/video.c:1956-2008) but ntsc-bs (DANCE digital audio) and the six MAC
+    # modes (a packet multiplex, not a raster): the 625 / 525-line ones, then 819, 405, Baird, NBTV, Apollo, CBS
     assert ids == ["i", "b", "g", "pal", "l", "secam", "m", "ntsc", "pal-fm", "secam-fm", "ntsc-fm",
                    "pal-d", "pal-k", "pal-m", "pal-n", "525pal", "d", "k", "secam-i", "secam-b", "secam-g", "ntsc-i",
-                   "pal60-i", "pal60"]
+                   "pal60-i", "pal60",
+                   "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
+                   "apollo-fsc-fm", "apollo-fsc", "apollo-fm", "apollo", "m-cbs405", "cbs405"]
     assert H.lib().hvk_config_preset(ctypes.byref(H.HvkConfig()), b"nope") == -1
 
 
@@ -60,7 +63,9 @@ def test_unsupported_configurations_are_refused():
     """Configurations outside the engine's scope fail at open with HVK_UNSUPPORTED."""
     bad = []
     c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
-    c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster other than 625 / 525
+    c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster type whose number of lines the configuration does not have
+    c = H.preset("i"); c.type = 8; bad.append((c, 16000000))                  # not a raster (the reference's VID_MAC)
+    bad.append((H.preset("ntsc-a"), 8100000))                                 # colour without a chroma low pass: no kernel for it
     for conf, sr in bad:
         try:
             H.Engine(conf, sr, device=-1)

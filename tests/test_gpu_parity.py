@@ -65,7 +65,10 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
                                   "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
-                                  "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"])
+                                  "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
+                                  # the rasters other than 625 / 525 lines, field-sequential colour (oracle/make_golden_rasters.py)
+                                  "e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
+                                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]
@@ -376,7 +379,8 @@ def test_dropin_binary_equals_reference_cli(golden):
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
                  "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid", "i_rawbb",
                  "i_rawbb_px16", "pal_rawbb_px135", "i_sis_filter", "ntsc_sv_f_px18", "i_pass_px135", "palm_full", "d_full", "ntsci_full", "pal60_bb", "palfm_f14", "palfm_f14_tail",
-                 "m_px135_s16", "ntsc_px16_s135", "m_4fsc", "pal_9m"):
+                 "m_px135_s16", "ntsc_px16_s135", "m_4fsc", "pal_9m",
+                 "e_full", "405_bb", "240_bb", "30_bb", "nbtv_bb", "apollofm", "apollofsc_bb", "mcbs405_full"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4

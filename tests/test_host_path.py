@@ -14,7 +14,8 @@ HOST_TABLES = ["syncs", "colour_lookup", "burst_win", "chroma_taps", "chroma_gho
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "pal_bb_filter", "g_full", "ntsc_bb", "i_20m", "l_full", "l_tt",
                                   "pal_fm", "ntsc_fm", "secam_fm_tail", "i_px135", "i_px2025", "l_px2025", "pal_px16_s14",
-                                  "m_px135_s27", "pal_px135_s136", "m_px135_s16", "ntsc_px16_s135"])
+                                  "m_px135_s27", "pal_px135_s136", "m_px135_s16", "ntsc_px16_s135",
+                                  "e_full", "a_full", "405i_full", "ntsc405_bb", "240_bb", "30_bb", "nbtv_bb", "apollofm", "apollofsc_bb", "mcbs405_full"])
 def test_host_tables_equal_oracle(golden, case):
     conf, sr = golden.conf(case)
     pr = golden.cases[case].get("pixel_rate", 0)
@@ -40,7 +41,7 @@ def test_host_tables_equal_oracle(golden, case):
             assert e.frame_start(1) == int(np.sum(w[:L])) and e.frame_start(0) == 0
 
 
-@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full", "g_a2", "m_a2"])
+@pytest.mark.parametrize("case", ["i_full", "m_full", "i_audio", "l_full", "g_a2", "m_a2", "e_full", "a_full", "apollofm", "mcbs405_full"])
 def test_serial_carrier_stream_equals_oracle(golden, case):
     """The host pre-pass (FM/AM phasor chains, limiter, 32 kHz tick) produces the same
     per-sample contribution as the oracle's per-sample loop, including the

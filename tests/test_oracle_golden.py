@@ -24,15 +24,18 @@ CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "
 CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt"]
 # rates outside the first rounds' 11 .. 28 MHz: chroma filters of 7, 19, 23 taps (oracle/make_golden_rates.py)
 CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"]
+# the rasters other than 625 / 525 lines and field-sequential colour (oracle/make_golden_rasters.py)
+CASES_RASTERS = ["e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
+                 "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass", "palfm_f14_tail"]
 
 
-@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS + CASES_RATES)
+@pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS + CASES_RATES + CASES_RASTERS)
 def test_oracle_stream_matches_reference_cli(golden, case):
     c = golden.cases[case]
     conf, sr = golden.conf(case)
     W, L = c["width"], c["lines"]
-    nframes = c["frames"] if c.get("extra", {}).get("passthru") else min(2, c["frames"])
+    nframes = c["frames"] if (c.get("extra", {}).get("passthru") or case in CASES_RASTERS) else min(2, c["frames"])
     with oracle.Oracle(conf, sr, c.get("pixel_rate", 0)) as o:
         o.set_frame(golden.frame(case))
         o.set_frame_aspect(12, 13)       # the test source: 4:3 on 832 x 576 (src/av_test.c:50)
