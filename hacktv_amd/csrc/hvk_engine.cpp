@@ -476,7 +476,11 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			for(int l = 0; l < k.lines; l++) if(held[l]) { idx[l] = (int16_t) list.size(); list.push_back((int16_t) l); }
 			/* (a frame's first lines and its last one are also what the frames next to it look into -- from THEIR planes, which
 			 * have no such rows: no inserter of the reference writes there, and if one did the kernel pair would render) */
-			if(held[0] || held[1] || held[k.lines - 1]) e->direct = 0;
+			if(held[0] || held[1] || held[k.lines - 1])
+			{
+				e->direct = 0;
+				fprintf(stderr, "libhvk: an optional stage writes to the frame's first lines or its last: the raster + filter kernel pair renders\n");
+			}
 			if(!list.empty() && e->direct)
 			{
 				e->ovr_n = (int) list.size();
@@ -485,6 +489,22 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				OPENCHK(_upload((void **) &e->d_ovr_idx, idx.data(), idx.size() * sizeof(int16_t)));
 			}
 		}
+		if(e->direct)
+		{
+			/* a window position's line by a multiplication instead of a division: exact up to the last position a tile can ask
+			 * for? (the quotient can only go wrong next to a multiple of the width: those and their neighbours are tried) */
+			e->inv_w = (uint32_t) (((1ULL << 32) + k.width - 1) / k.width);
+			const uint32_t qmax = (uint32_t) ((k.frame_samples + 8 * HVK_TILE) / k.width + 1);
+			for(uint32_t q = 0; q <= qmax && e->direct; q++)
+			{
+				const uint32_t n0 = q * (uint32_t) k.width, n1 = n0 + (uint32_t) k.width - 1;
+				if((uint32_t) (((uint64_t) n0 * e->inv_w) >> 32) != q || (uint32_t) (((uint64_t) n1 * e->inv_w) >> 32) != q) e->direct = 0;
+			}
+			if(!e->direct) fprintf(stderr, "libhvk: no exact reciprocal of the line width %d: the raster + filter kernel pair renders\n", k.width);
+		}
+	}
+	if(e->direct)
+	{
 		const size_t pn = ((size_t) e->plane_rows + (size_t) e->ovr_n * max_frames) * k.width + 32;
 		OPENHIP(hipMalloc((void **) &e->d_Lp, pn * 2));
 		OPENHIP(hipMemset(e->d_Lp, 0, pn * 2));
@@ -510,46 +530,37 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			std::vector<uint32_t> lo((size_t) k.lines + 4, 0);
 			for(int j = 0; j < k.lines + 4 && k.colour && !k.secam && k.clw > 0; j++) lo[j] = (uint32_t) ((((int64_t) (j - 1) * k.width) % k.clw + k.clw) % k.clw);
 			OPENCHK(_upload((void **) &e->d_lineoff, lo.data(), lo.size() * 4));
-			e->inv_w = (uint32_t) (((1ULL << 32) + k.width - 1) / k.width);
-			/* (the quotient can only go wrong next to a multiple of the width: those and their neighbours are tried) */
-			const uint32_t qmax = (uint32_t) ((k.frame_samples + 8 * HVK_TILE) / k.width + 1);
-			for(uint32_t q = 0; q <= qmax && e->direct; q++)
+			if(e->direct && !e->ovr_n && !(getenv("HVK_TILEREC") && atoi(getenv("HVK_TILEREC")) == 0))
 			{
-				const uint32_t n0 = q * (uint32_t) k.width, n1 = n0 + (uint32_t) k.width - 1;
-				if((uint32_t) (((uint64_t) n0 * e->inv_w) >> 32) != q || (uint32_t) (((uint64_t) n1 * e->inv_w) >> 32) != q) e->direct = 0;
-			}
-		if(e->direct && !e->ovr_n && !(getenv("HVK_TILEREC") && atoi(getenv("HVK_TILEREC")) == 0))
-		{
-			/* per frame parity and tile of 1024 outputs (the tiles of the last, partial workgroup included): the lines its window
-			 * lies in -- the arithmetic of hvk_direct.hip:direct_line_loads() / direct_line(), done once here */
-			const int DGT = 4, lead = k.vf_type ? 26 : 0, W = k.width, tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
-			e->tiles_pad = (tiles + DGT - 1) / DGT * DGT;
-			std::vector<hvk_tilerec_t> rec((size_t) 2 * e->tiles_pad);
-			memset(rec.data(), 0, rec.size() * sizeof(hvk_tilerec_t));
-			for(int par_own = 0; par_own < 2; par_own++) for(int tl = 0; tl < e->tiles_pad; tl++)
-			{
-				hvk_tilerec_t &R = rec[(size_t) par_own * e->tiles_pad + tl];
-				const int p0 = tl * HVK_TILE - lead;
-				const int lineA = p0 < 0 ? -1 : p0 / W, xA0 = p0 - lineA * W;
-				R.b1 = W - xA0;
-				for(int X = 0; X < 3; X++)
+				/* per frame parity and tile of 1024 outputs (the tiles of the last, partial workgroup included): the lines its window
+				 * lies in -- the arithmetic of hvk_direct.hip:direct_line_loads() / direct_line(), done once here */
+				const int DGT = 4, lead = k.vf_type ? 26 : 0, W = k.width, tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
+				e->tiles_pad = (tiles + DGT - 1) / DGT * DGT;
+				std::vector<hvk_tilerec_t> rec((size_t) 2 * e->tiles_pad);
+				memset(rec.data(), 0, rec.size() * sizeof(hvk_tilerec_t));
+				for(int par_own = 0; par_own < 2; par_own++) for(int tl = 0; tl < e->tiles_pad; tl++)
 				{
-					const int rel = lineA + X, wstart = X == 0 ? -xA0 : (X == 1 ? R.b1 : R.b1 + W);
-					int line0 = rel, par = par_own, prev = 0;
-					const int own = rel >= 0 && rel < k.lines;
-					if(rel < 0) { line0 = k.lines - 1; par ^= 1; prev = 1; }
-					else if(rel >= k.lines) { line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; par ^= 1; }
-					const int pal = (k.colour && !k.secam) ? e->t.desc[(size_t) par * k.lines + line0].pal : 0;
-					R.meta[X] = line0 | (prev << 16) | (own << 17) | ((pal + 1) << 18);
-					R.lw[X] = line0 * W - wstart;
-					R.nws[X] = -wstart;
-					R.off[X] = lo[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+					hvk_tilerec_t &R = rec[(size_t) par_own * e->tiles_pad + tl];
+					const int p0 = tl * HVK_TILE - lead;
+					const int lineA = p0 < 0 ? -1 : p0 / W, xA0 = p0 - lineA * W;
+					R.b1 = W - xA0;
+					for(int X = 0; X < 3; X++)
+					{
+						const int rel = lineA + X, wstart = X == 0 ? -xA0 : (X == 1 ? R.b1 : R.b1 + W);
+						int line0 = rel, par = par_own, prev = 0;
+						const int own = rel >= 0 && rel < k.lines;
+						if(rel < 0) { line0 = k.lines - 1; par ^= 1; prev = 1; }
+						else if(rel >= k.lines) { line0 = rel - k.lines < k.lines ? rel - k.lines : k.lines - 1; par ^= 1; }
+						const int pal = (k.colour && !k.secam) ? e->t.desc[(size_t) par * k.lines + line0].pal : 0;
+						R.meta[X] = line0 | (prev << 16) | (own << 17) | ((pal + 1) << 18);
+						R.lw[X] = line0 * W - wstart;
+						R.nws[X] = -wstart;
+						R.off[X] = lo[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+					}
 				}
+				OPENCHK(_upload(&e->d_tilerec, rec.data(), rec.size() * sizeof(hvk_tilerec_t)));
 			}
-			OPENCHK(_upload(&e->d_tilerec, rec.data(), rec.size() * sizeof(hvk_tilerec_t)));
 		}
-		}
-		if(!e->direct) fprintf(stderr, "libhvk: no exact reciprocal of the line width %d: the raster + filter kernel pair renders\n", k.width);
 		OPENHIP(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
 		OPENHIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 		for(int i = 0; i < HVK_PREP_EVENTS; i++) OPENHIP(hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming));
@@ -1728,6 +1739,8 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
 	}
 	if(e->t.k.rs_irr && stride != 1) return(HVK_UNSUPPORTED);        /* frames of two lengths: a batch is one run of samples */
+	/* (... whose NICAM symbol starts are kept as 29-bit offsets from its first sample: checked here, before any chain has moved) */
+	if(e->t.k.rs_irr && e->audio && (_fstart(e, first_frame + nframes) - _fstart(e, first_frame)) * 8 >= 0x7FFFFFFF) return(HVK_UNSUPPORTED);
 	if(e->secam && (stride != 1 || first_frame != e->secam_next)) return(HVK_UNSUPPORTED);   /* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
 	{
 		/* Where the last line of a frame shows picture (525 lines) it lies within the video filter's reach of the next
@@ -1940,7 +1953,6 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	if(e->audio && k.rs_irr)
 	{
 		const int64_t A0 = _fstart(e, first_frame), T = _fstart(e, first_frame + nframes) - A0;
-		if(T * 8 >= 0x7FFFFFFF) return(HVK_UNSUPPORTED);         /* (symbol starts are kept as 29-bit offsets from the batch's first sample) */
 		int r = stage_audio(A0, T, 0, 0, e->symbol_stride * nframes, (int) ((T + HVK_TILE - 1) / HVK_TILE), first_frame);
 		if(r != HVK_OK) return(r);
 	}
@@ -1994,18 +2006,23 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		e->carry = *last;
 		e->carry_frame = last->frame_index;
 		e->carry_valid = 1;
-		if(d->ar > d->al && last->fb_valid && vy >= 0 && vy < last->fb_height)
+		if(d->ar > d->al)
 		{
 			/* not the row this batch's first frame is about to read */
 			e->carry_row ^= 1;
-			const size_t carry_off = frame_px * e->frame_slots + (size_t) e->carry_row * k.active_width;
-			HIPCHK(hipMemcpyAsync(e->d_pool + carry_off, e->d_pool + last->fb_offset + (int64_t) vy * last->line_stride,
-			                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
-			e->carry.fb_offset = (int64_t) carry_off;
-			e->carry.line_stride = 0;       /* every row of the kept frame is that one row */
+			if(last->fb_valid && vy >= 0 && vy < last->fb_height)
+			{
+				const size_t carry_off = frame_px * e->frame_slots + (size_t) e->carry_row * k.active_width;
+				HIPCHK(hipMemcpyAsync(e->d_pool + carry_off, e->d_pool + last->fb_offset + (int64_t) vy * last->line_stride,
+				                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
+				e->carry.fb_offset = (int64_t) carry_off;
+				e->carry.line_stride = 0;       /* every row of the kept frame is that one row */
+			}
+			else e->carry.fb_valid = 0;         /* (no picture on that line: black -- the raster kernel's reading) */
 			if(e->direct)
 			{
-				/* ... and its planes' last row: the slot may hold another picture by then */
+				/* ... and its planes' last row, picture on it or not (hvk_k_direct reads the row whatever the frame showed): the
+				 * slot may hold another picture by the time the next batch looks */
 				const size_t W = k.width;
 				e->carry_from = ((size_t) last->plane_row0 + k.lines - 1) * W + 16;
 				e->carry_to = ((size_t) e->plane_carry_row + e->carry_row) * W + 16;

@@ -216,13 +216,22 @@ int hvk_tail_passthru_stream(hvk_tail_t *s, int64_t first, int64_t count, int16_
 		const int64_t FS = s->t->k.frame_samples;
 		const int lines = s->t->k.lines;
 		int32_t *w;
-		if(first % FS || count % FS) return(HVK_ERROR);
+		/* which frame begins at `first`: frame_samples apart -- or, where a raster frame does not resample to a whole number
+		 * of samples (frames of two lengths, FS the longer), where hvk_tables_frame_start() says */
+		int64_t f = first / FS;
+		while(hvk_tables_frame_start(s->t, f) < first) f++;
+		if(hvk_tables_frame_start(s->t, f) != first) return(HVK_ERROR);
+		{
+			int64_t f2 = f;
+			while(hvk_tables_frame_start(s->t, f2) < first + count) f2++;
+			if(hvk_tables_frame_start(s->t, f2) != first + count) return(HVK_ERROR);
+		}
 		w = malloc(sizeof(int32_t) * lines);
 		if(!w) return(HVK_OUT_OF_MEMORY);
-		for(p = first; p < first + count && !s->ended; p += FS)
+		for(; hvk_tables_frame_start(s->t, f) < first + count && !s->ended; f++)
 		{
-			int64_t at = p;
-			hvk_tables_line_widths(s->t, (p / FS) * lines, lines, w);
+			int64_t at = hvk_tables_frame_start(s->t, f);
+			hvk_tables_line_widths(s->t, f * lines, lines, w);
 			for(int l = 0; l < lines && !s->ended; l++)
 			{
 				if((r = _passthru_line(s, at, w[l], out + (at - first) * 2)) != HVK_OK) { free(w); return(r); }

@@ -891,6 +891,8 @@ def test_odd_line_widths(golden, mode, sr):
     ("m", 16000000, 13500000, {"vits": 1, "vitc": 1, "acp": 1, "cc608": 1, "a2stereo": 1}),
     ("pal60", 13500000, 16000000, {"offset": 300000, "swap_iq": 1}),
     ("pal-m", 16000000, 13500000, {"interlace": 1}),
+    ("m", 16000000, 13500000, {"passthru": 1, "offset": 100000}),                     # frames of two lengths: the passthru process finds frame 1 at 533 867, not at 533 867.4
+    ("ntsc", 13500000, 16000000, {"passthru": 1}),
 ])
 def test_options_at_other_rates(golden, mode, sr, pr, members):
     """The optional stages away from 16 MHz (their tables scale with the pixel rate: symbol widths,
@@ -909,6 +911,8 @@ def test_options_at_other_rates(golden, mode, sr, pr, members):
         packets = rng.integers(0, 256, (n, 32, 45), dtype=np.int64).astype(np.uint8)
         masks = [0x00FF00FF, 0xFFFFFFFF]
         o.set_audio(golden.audio, True)
+        if members.get("passthru"):
+            o.set_passthru(util.passthru_signal())
         want = []
         for f in range(n):
             o.set_frame(frames[2 * f])
@@ -926,6 +930,8 @@ def test_options_at_other_rates(golden, mode, sr, pr, members):
             e.frame_aspect(s_, 16, 11)
         while e.audio_needed(n) > 0:
             e.audio_write(golden.audio)
+        if members.get("passthru"):
+            e.passthru_write(util.passthru_signal())
         for f in range(n):
             if members.get("teletext"):
                 e.teletext_packets(f, packets[f], masks[f])
@@ -1125,6 +1131,41 @@ def test_picture_carried_across_batches_on_525_lines(golden, batch):
     got = np.concatenate(got)
     bad = np.nonzero((got != want).any(axis=1))[0]
     fs = len(want) // n
+    assert bad.size == 0, "frame %d sample %d" % (bad[0] // fs, bad[0] % fs)
+
+
+@pytest.mark.parametrize("env", [{}, {"HVK_DIRECT": "0"}])
+def test_last_line_of_a_frame_without_a_picture_on_525_lines(golden, env, monkeypatch):
+    """... and when the frame before shows NO picture on its last line -- an empty frame, a picture too low to reach it --
+    the halo line in front of the next batch's first frame is black, not whatever picture has meanwhile been uploaded into
+    the frame's slot: one slot, batches of one frame, pictures of changing height, an empty frame in between. The picture
+    planes' kept row and the raster kernel's kept source row against the oracle."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    conf = H.preset("m", H.FLAG_FILTER)
+    sr = 13500000
+    rng = np.random.default_rng(21)
+    with oracle.Oracle(conf, sr) as o:
+        aw, ah, L = o.info["active_width"], o.info["active_lines"], o.info["lines"]
+        frames = [rng.integers(0, 1 << 24, (ah, aw), dtype=np.uint32), None, rng.integers(0, 1 << 24, (300, aw), dtype=np.uint32),
+                  rng.integers(0, 1 << 24, (ah, aw), dtype=np.uint32), rng.integers(0, 1 << 24, (200, 400), dtype=np.uint32), rng.integers(0, 1 << 24, (ah, aw), dtype=np.uint32)]
+        o.set_audio(golden.audio, True)
+        want = []
+        for f in frames:
+            o.set_frame(f, interlaced=1)
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    got = []
+    with H.Engine(conf, sr, device=0, max_frames=1) as e:
+        for f in frames:
+            e.frame_upload(0, f, interlaced=1)
+            while e.audio_needed(1) > 0:
+                e.audio_write(golden.audio)
+            e.render(1, slots=[0])
+            got.append(e.fetch(0, e.info["frame_samples"]))
+    got = np.concatenate(got)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    fs = len(want) // len(frames)
     assert bad.size == 0, "frame %d sample %d" % (bad[0] // fs, bad[0] % fs)
 
 
