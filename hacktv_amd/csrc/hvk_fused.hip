@@ -44,12 +44,11 @@ typedef struct {
 	int yp[SPL / 2];            /* luma pairs */
 	int4v mkp, mka;             /* run masks: samples that show a pixel, samples that are assigned luma */
 	hvk_side_t sd;
-	int4u k0, k1;               /* the lane's 8 phasors */
 	bool lane_ok;               /* the lane's samples lie on the line */
 } fline_t;
 
 template<int NT, int LV>
-__device__ __forceinline__ void fused_part1(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const bool pal, const int *__restrict__ clut3, const int cb,
+__device__ __forceinline__ void fused_part1(const hvk_kconst_t &k, const hvk_rptrs_t &P, const hvk_line_t &L, const bool pal,
                                             const int t, const int x0, const int xbase, int16_t *U, int16_t *V, fline_t &F)
 {
 	constexpr int H = NT / 2;
@@ -68,9 +67,6 @@ __device__ __forceinline__ void fused_part1(const hvk_kconst_t &k, const hvk_rpt
 	/* (the over-read samples by the lane's number in its wave pair: the halo wave's lanes stand at the line's end) */
 	F.sd.ghost_u = P.ghost[2 * (t < H ? t : H - 1) + 0];
 	F.sd.ghost_v = P.ghost[2 * (t < H ? t : H - 1) + 1];
-	/* the sub-carrier's phasors of the lane's samples (a line without chroma: the table's copy of zeros) */
-	F.k0 = ((const int4u *) (clut3 + cb + x0))[0];
-	F.k1 = ((const int4u *) (clut3 + cb + x0))[1];
 
 	int up[SPL / 2], vp[SPL / 2];
 	if(L.has_pix)
@@ -112,8 +108,12 @@ __device__ __forceinline__ void fused_part1(const hvk_kconst_t &k, const hvk_rpt
 
 template<int NT>
 __device__ __forceinline__ int4u fused_part2(const hvk_kconst_t &k, const hvk_line_t &L, const bool pal, const hvk_packed_taps_t &ctaps,
+                                             const int *__restrict__ clut3, const int cb,
                                              const int x0, const int xbase, const int16_t *U, const int16_t *V, const fline_t &F)
 {
+	/* the sub-carrier's phasors of the lane's samples (a line without chroma: the table's copy of zeros): asked for here, behind
+	 * the barrier -- they come from L2 while the low pass runs, and eight registers fewer live across the wait */
+	const int4u k0 = ((const int4u *) (clut3 + cb + x0))[0], k1 = ((const int4u *) (clut3 + cb + x0))[1];
 	constexpr int H = NT / 2;
 	constexpr int LEAD = HVK_CHROMA_LEAD;
 	constexpr int BACK = H <= 8 ? 8 : 16;
@@ -175,7 +175,7 @@ __device__ __forceinline__ int4u fused_part2(const hvk_kconst_t &k, const hvk_li
 	}
 
 	/* onto the sub-carrier (src/video.c:3032-3040): L + ((i V pal + q U) >> 15) modulo 2^16 -- hvk_k_direct's direct_eval() */
-	const int K[SPL] = { F.k0.x, F.k0.y, F.k0.z, F.k0.w, F.k1.x, F.k1.y, F.k1.z, F.k1.w };
+	const int K[SPL] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
 	int pr[SPL / 2];
 #pragma unroll
 	for(int m = 0; m < SPL / 2; m++)
@@ -213,8 +213,11 @@ __device__ __forceinline__ fsel_t fused_select(const hvk_kconst_t &k, const hvk_
 	return(q);
 }
 
+#ifndef FUSED_WAVES
+#define FUSED_WAVES 7                /* waves per SIMD the table-levels kernel is compiled for: three workgroups of nine waves per compute unit */
+#endif
 template<int NT, int LV>
-__global__ __launch_bounds__(FTL * FG + 64, 4)
+__global__ __launch_bounds__(FTL * FG + 64, LV ? 4 : FUSED_WAVES)
 void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
                  const int *__restrict__ d_clut3, const int d_creg,
                  const hvk_framedesc_t *__restrict__ d_fdesc, const uint32_t *__restrict__ d_lineoff,
@@ -262,7 +265,6 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	const bool tap_mine = k.has_nicam && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
 	int4v tap_stage = { 0, 0, 0, 0 };
 	if(k.has_nicam) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
-	const int4v a_hh = mfma_a[t & 63], a_hl = mfma_a[64 + (t & 63)];
 	int symv = 0, cc_tile = 0;
 	if(k.has_nicam && !halo)
 	{
@@ -271,6 +273,18 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		symv = row[t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1];
 	}
 	const int n = n0 + x0;
+
+	/* ---- the line: part 1 ---- */
+	fline_t F;
+	F.lane_ok = halo ? t < (FW - FHALO0) / SPL : true;
+	fused_part1<NT, LV>(k, P, q.L, q.pal, t, F.lane_ok ? x0 : FHALO0, xbase, U, V, F);
+	if(tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
+	if(k.has_nicam && !halo && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st_g[sub], sym_ent_g[sub], t);
+	__syncthreads();
+
+	/* (asked for behind the first barrier: the line's own reads are through, these have all of part 2 and the filter to arrive in,
+	 * and sixteen registers fewer are live while the levels are made) */
+	const int4v a_hh = mfma_a[t & 63], a_hl = mfma_a[64 + (t & 63)];
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
 	if(k.has_carriers && tile_valid)
 	{
@@ -279,17 +293,9 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		car1 = __builtin_nontemporal_load(&c[1]);
 	}
 
-	/* ---- the line: part 1 ---- */
-	fline_t F;
-	F.lane_ok = halo ? t < (FW - FHALO0) / SPL : true;
-	fused_part1<NT, LV>(k, P, q.L, q.pal, d_clut3, q.cb, t, F.lane_ok ? x0 : FHALO0, xbase, U, V, F);
-	if(tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
-	if(k.has_nicam && !halo && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st_g[sub], sym_ent_g[sub], t);
-	__syncthreads();
-
 	/* ---- part 2, and into the byte planes: window position of sample x of the group's line j is j * 1024 + x + FLEAD ---- */
 	{
-		int4u g0 = fused_part2<NT>(k, q.L, q.pal, ctaps, F.lane_ok ? x0 : FHALO0, xbase, U, V, F);
+		int4u g0 = fused_part2<NT>(k, q.L, q.pal, ctaps, d_clut3, q.cb, F.lane_ok ? x0 : FHALO0, xbase, U, V, F);
 		if(q.zero) g0 = (int4u) { 0, 0, 0, 0 };
 		int2v ph, pl;
 		split_planes(g0, ph, pl);

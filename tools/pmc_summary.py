@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.c
     acc = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0]
-        if not name.replace("void ", "").startswith(("hvk_k_raster", "hvk_k_filter", "hvk_k_direct", "hvk_k_prep", "hvk_k_secam")):
+        if not name.replace("void ", "").startswith(("hvk_k_raster", "hvk_k_filter", "hvk_k_direct", "hvk_k_prep", "hvk_k_secam", "hvk_k_fused")):
             continue
         name = name.replace("void ", "")
         acc.setdefault((name, row["Counter_Name"]), []).append(float(row["Counter_Value"]))

@@ -24,7 +24,7 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
 	i=$((i + 1))
-	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --no-cpu-baseline --no-moving --no-configs > "$OUT/pmc$i.log" 2>&1
+	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --settle 0 --no-cpu-baseline --no-moving --no-configs > "$OUT/pmc$i.log" 2>&1
 	echo "pmc pass $i ($set): exit $?"
 done
 # 5. the SECAM colour chain (hvk_secam.hip): blocks of 512 frames of the test card, and of noisy pictures with the cells made per frame
@@ -34,5 +34,10 @@ for kind in card noisy; do
 	f=$(find "$OUT/secam_$kind" -name '*kernel_stats.csv' | head -1)
 	[ -n "$f" ] && cp "$f" "$OUT/${TAG}_secam_${kind}_kernel_stats.csv"
 done
+# 6. pictures that change on every frame: the one kernel from the pixels (table levels) and the planes' two (computed levels)
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/moving" -o p -- env HVK_PATHS=0 HVK_CHUNKS=0 python $OLDPWD/tools/prep_speed.py 64 > "$OUT/moving.log" 2>&1
+grep " i " "$OUT/moving.log" | cut -c1-220
+f=$(find "$OUT/moving" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$OUT/${TAG}_moving_kernel_stats.csv"
 cd "$OLDPWD"
 python tools/pmc_summary.py "$OUT" "$TAG"
