@@ -105,7 +105,25 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_p
 		raster_clear(L, t, nth, U, CL);
 		__syncthreads();
 	}
-	raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, sd.ghost_u, sd.ghost_v, Yb, U, V);
+	if(SECAM)
+	{
+		/* SECAM: the pixels' colour-difference levels go to the C plane as they are -- what the colour chain's cells are
+		 * made of (hvk_k_secam_cells), so that a pixel's levels are worked out once */
+		short4v cl[HVK_PIX_PASSES];
+		raster_gather<LV>(k, P, L, rgb, cl);
+		raster_stage<NT, WC, HVK_PIX_PASSES, 0>(k, L, t, nth, cl, sd.ghost_u, sd.ghost_v, Yb, U, V);
+		if(Cp && L.has_pix)
+		{
+			int *row = Cp + ((size_t) f.plane_row0 + rel) * W;
+#pragma unroll
+			for(int i = 0; i < HVK_PIX_PASSES; i++)
+			{
+				const int x = L.ax0 + t + i * nth;
+				if(x < L.ax1) row[x] = ((int) cl[i].y & 0xFFFF) | ((int) cl[i].z << 16);
+			}
+		}
+	}
+	else raster_pixels<NT, WC, LV>(k, P, L, t, nth, rgb, sd.ghost_u, sd.ghost_v, Yb, U, V);
 	if(L.pal || L.has_pix) __syncthreads();
 
 	int s[SPL], cq[SPL];
@@ -147,9 +165,11 @@ void hvk_k_prep(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_p
  * it). One barrier per line. What it computes is raster_compute<..., PREP = 1>'s, stage by stage (hvk_device.h); the parity
  * tests run every plain configuration through it and through the raster + filter kernel pair.
  * src/video.c:2961-3029 (luma, chroma, low pass, burst). */
-template<int NT, int WC, int LV>
+/* SC: SECAM -- no chroma channels (NT = 1); the picture lines' luma through the 51-tap notch (src/video.c:3206), and the
+ * pixels' colour-difference levels as they are into the C plane, for the colour chain's cells (hvk_k_secam_cells) */
+template<int NT, int WC, int LV, int SC = 0>
 __global__ __launch_bounds__(1024)
-void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
+void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_packed_taps_t notch, const hvk_rptrs_t P,
                  int16_t *__restrict__ Lp, int *__restrict__ Cp, const hvk_prepgeo_t geo)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];
@@ -206,7 +226,7 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<0>(px[i] & 0xFFFFFFu, *P.yuvp));
+			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<SC ? 1 : 0>(px[i] & 0xFFFFFFu, *P.yuvp));
 			else lv[i] = ((const int2v *) P.yuv)[px[i] & 0xFFFFFFu];
 		}
 #pragma unroll
@@ -322,6 +342,65 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	}
 
 	const size_t at = ((size_t) f.plane_row0 + rel) * W + x0;
+
+	if(SC && L.active)
+	{
+		/* the luma notch over the active picture (raster_compute()'s stage: a zero-history FIR whose input starts at
+		 * active_left and which looks 25 samples past the picture's right edge) */
+		constexpr int NH = 25, NLEAD = 26;
+		int16_t *Z = lds;                       /* index j <-> sample x = j - NLEAD */
+		if(t < 4) *(int4v *) (Z + t * 8) = (int4v) { 0, 0, 0, 0 };
+		{
+			int w[SPL / 2];
+#pragma unroll
+			for(int m = 0; m < SPL / 2; m++)
+			{
+				const int xa = x0 + 2 * m;
+				w[m] = (xa >= k.active_left ? (sp[m] & 0xFFFF) : 0) | (xa + 1 >= k.active_left ? (sp[m] & (int) 0xFFFF0000u) : 0);
+			}
+			*(int4u *) (Z + NLEAD + x0) = (int4u) { w[0], w[1], w[2], w[3] };
+		}
+		__syncthreads();
+		if(x0 + SPL > k.active_left && x0 < k.active_left + k.active_width)
+		{
+			constexpr int ND = SPL / 2 + (51 + 1) / 2 + 1;
+			int dn[ND], a[SPL];
+			const int4v *pz = (const int4v *) (Z + x0);
+#pragma unroll
+			for(int m = 0; m < (ND + 3) / 4; m++)
+			{
+				const int4v v = pz[m];
+				if(m * 4 + 0 < ND) dn[m * 4 + 0] = v.x;
+				if(m * 4 + 1 < ND) dn[m * 4 + 1] = v.y;
+				if(m * 4 + 2 < ND) dn[m * 4 + 2] = v.z;
+				if(m * 4 + 3 < ND) dn[m * 4 + 3] = v.w;
+			}
+			fir8<51, NLEAD - NH>(dn, notch.p, a);
+#pragma unroll
+			for(int i = 0; i < SPL; i++)
+			{
+				const int x = x0 + i;
+				if(x >= k.active_left && x < k.active_left + k.active_width)
+				{
+					const int q = clamp16(a[i] >> 15);
+					sp[i / 2] = (i & 1) ? ((sp[i / 2] & 0xFFFF) | (q << 16)) : ((sp[i / 2] & (int) 0xFFFF0000u) | (q & 0xFFFF));
+				}
+			}
+		}
+	}
+	if(SC && Cp && L.has_pix && x0 + SPL <= W)
+	{
+		int q[SPL];
+#pragma unroll
+		for(int m = 0; m < SPL / 2; m++)
+		{
+			q[2 * m] = (up[m] & 0xFFFF) | (vp[m] << 16);
+			q[2 * m + 1] = ((up[m] >> 16) & 0xFFFF) | (vp[m] & (int) 0xFFFF0000u);
+		}
+		((int4u *) (Cp + at))[0] = (int4u) { q[0], q[1], q[2], q[3] };
+		((int4u *) (Cp + at))[1] = (int4u) { q[4], q[5], q[6], q[7] };
+	}
+
 	if(x0 + SPL <= W)
 	{
 		*(int4a2 *) (Lp + at) = (int4a2) { sp[0], sp[1], sp[2], sp[3] };
@@ -788,10 +867,12 @@ static int _launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int 
 	hvk_raster_ptrs(a, &P);
 	const dim3 grid((a->k.lines + 7) & ~7, npics), block(threads);
 #define PREP(WCV, LVV, SC) hipLaunchKernelGGL((hvk_k_prep<NT, WCV, LVV, SC>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp, *g)
-#define PREP8(WCV, LVV) hipLaunchKernelGGL((hvk_k_prep8<NT, WCV, LVV>), grid, block, lds, stream, a->k, a->ctaps, P, Lp, Cp, *g)
+#define PREP8(WCV, LVV) hipLaunchKernelGGL((hvk_k_prep8<NT, WCV, LVV>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp, *g)
+#define PREP8S(LVV) hipLaunchKernelGGL((hvk_k_prep8<NT, 0, LVV, (NT == 1 ? 1 : 0)>), grid, block, lds, stream, a->k, a->ctaps, a->notch, P, Lp, Cp, *g)
 	/* (HVK_PREP=1: the one-pixel-per-lane-and-pass kernel built from the raster's stages, kept as the second opinion) */
 	static const int old_prep = getenv("HVK_PREP") ? atoi(getenv("HVK_PREP")) : 0;
-	if(NT == 1 && a->k.secam) { if(a->levels_computed) PREP(0, 1, (NT == 1 ? 1 : 0)); else PREP(0, 0, (NT == 1 ? 1 : 0)); }
+	if(NT == 1 && a->k.secam && (old_prep == 1 || a->k.width % SPL != 0)) { if(a->levels_computed) PREP(0, 1, (NT == 1 ? 1 : 0)); else PREP(0, 0, (NT == 1 ? 1 : 0)); }
+	else if(NT == 1 && a->k.secam) { if(a->levels_computed) PREP8S(1); else PREP8S(0); }
 	else if(old_prep == 1)
 	{
 		if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1, 0); else PREP((NT == 13 ? 1024 : 0), 0, 0); }
@@ -799,6 +880,7 @@ static int _launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int 
 	}
 	else if(NT == 13 && W == 1024) { if(a->levels_computed) PREP8((NT == 13 ? 1024 : 0), 1); else PREP8((NT == 13 ? 1024 : 0), 0); }
 	else { if(a->levels_computed) PREP8(0, 1); else PREP8(0, 0); }
+#undef PREP8S
 #undef PREP8
 #undef PREP
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);

@@ -66,7 +66,9 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[12];          /* what sa points into (freed at close) */
+	void *d_secam[15];          /* what sa points into (freed at close) */
+	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
+	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
 	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
 	int secam_seeds;            /* warm-ups start from the states the picture's lines had the last time (kept per row) */
 	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
@@ -150,6 +152,7 @@ struct hvk_engine {
 	int last_direct;            /* the last launch did: the raster slab in HBM was not written */
 	/* picture planes: [plane_rows][width] each, 16 entries of slack in front; rows: lines per frame slot, two kept
 	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
+	int *d_UVp;                 /* SECAM: the pictures' colour-difference levels, laid out like d_Cp (hvk_k_prep writes them, hvk_k_secam_cells reads them) */
 	int16_t *d_Lp; int *d_Cp; int *d_clut3; uint32_t *d_lineoff; uint32_t inv_w;
 	void *d_tilerec; int tiles_pad;     /* hvk_tilerec_t [2][tiles_pad] */
 	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
@@ -508,7 +511,23 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		const size_t pn = ((size_t) e->plane_rows + (size_t) e->ovr_n * max_frames) * k.width + 32;
 		OPENHIP(hipMalloc((void **) &e->d_Lp, pn * 2));
 		OPENHIP(hipMemset(e->d_Lp, 0, pn * 2));
-		if(k.colour && !k.secam)        /* (SECAM: no (V, U) plane and no phasors -- the sub-carrier is the colour chain's) */
+		if(k.secam && !getenv("HVK_SECAM_NO_UV_PLANE"))
+		{
+			/* (SECAM: no (V, U) plane for the render and no phasors -- the sub-carrier is the colour chain's -- but the pixels'
+			 * colour-difference levels for the chain's cells, if both parities' lines show the same rows) */
+			int same = 1;
+			for(int l = 0; l < k.lines && same; l++)
+			{
+				const hvk_linedesc_t *d0 = &e->t.desc[l], *d1 = &e->t.desc[k.lines + l];
+				same = d0->src_row == d1->src_row && d0->al == d1->al && d0->ar == d1->ar;
+			}
+			if(same)
+			{
+				OPENHIP(hipMalloc((void **) &e->d_UVp, pn * 4));
+				OPENHIP(hipMemset(e->d_UVp, 0, pn * 4));
+			}
+		}
+		if(k.colour && !k.secam)
 		{
 			OPENHIP(hipMalloc((void **) &e->d_Cp, pn * 4));
 			OPENHIP(hipMemset(e->d_Cp, 0, pn * 4));
@@ -756,6 +775,18 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			OPENCHK(_upload(&e->d_secam[1], fid.data(), fid.size() * 2));
 			OPENCHK(_upload(&e->d_secam[2], e->t.secam_lut, 65536 * sizeof(hvk_c32_t)));
 			OPENCHK(_upload(&e->d_secam[3], e->t.secam_bell, 65536 * sizeof(hvk_c16_t)));
+			{
+				std::vector<int32_t> lb((size_t) 65536 * 4);
+				for(int u = 0; u < 65536; u++)
+				{
+					const hvk_c16_t gq = e->t.secam_bell[(u - 32768) & 0xFFFF];
+					lb[(size_t) u * 4 + 0] = e->t.secam_lut[u].i;
+					lb[(size_t) u * 4 + 1] = e->t.secam_lut[u].q;
+					lb[(size_t) u * 4 + 2] = (int32_t) ((uint32_t) (uint16_t) gq.i | ((uint32_t) (uint16_t) gq.q << 16));
+					lb[(size_t) u * 4 + 3] = 0;
+				}
+				OPENCHK(_upload(&e->d_secam[14], lb.data(), lb.size() * 4));
+			}
 			OPENHIP(hipMalloc(&e->d_secam[4], (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMalloc(&e->d_secam[5], (size_t) a.cpad * 32));
 			OPENHIP(hipMalloc(&e->d_secam[6], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
@@ -769,6 +800,26 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				OPENHIP(hipMalloc(&e->d_secam[11], (size_t) 3 * a.cpad * sizeof(hvk_secam_state_t)));
 				OPENHIP(hipMemset(e->d_secam[11], 0, (size_t) 3 * a.cpad * sizeof(hvk_secam_state_t)));    /* (a state of nothing: what every warm-up started from before) */
 			}
+			/* entry states of new pictures' lines by estimate instead of warm-up walks (hvk_k_secam_est); a pinned warm-up
+			 * length (HVK_SECAM_WARMUP) keeps the walks */
+			a.x1 = (k.burst_left + 78 + 7) & ~7;
+			e->secam_est = e->secam_adapt && a.x1 + 16 <= k.width && k.width >= 512 && !(getenv("HVK_SECAM_EST") && atoi(getenv("HVK_SECAM_EST")) == 0);
+			if(e->secam_est)
+			{
+				OPENHIP(hipMalloc(&e->d_secam[12], (size_t) a.cpad * sizeof(double)));
+				OPENHIP(hipMemset(e->d_secam[12], 0, (size_t) a.cpad * sizeof(double)));
+				OPENHIP(hipMalloc(&e->d_secam[13], (size_t) a.tpad * 32));
+				OPENHIP(hipMemset(e->d_secam[13], 0, (size_t) a.tpad * 32));
+				a.iya = (double *) e->d_secam[12];
+				a.est = (int16_t *) e->d_secam[13];
+				a.ES = getenv("HVK_SECAM_EST_RUN") ? atoi(getenv("HVK_SECAM_EST_RUN")) : 4;
+				a.EK = getenv("HVK_SECAM_EST_LINES") ? atoi(getenv("HVK_SECAM_EST_LINES")) : 16;
+				if(a.ES < 1) a.ES = 1;
+				if(a.EK < 1) a.EK = 1;
+				/* a step's angle, src/video.c:2236 with :4080 */
+				a.kap0 = 2.0 * M_PI / (double) e->t.pixel_rate * 4328125.0;
+				a.kap1 = 2.0 * M_PI / (double) e->t.pixel_rate * 1000e3 / (double) INT16_MAX;
+			}
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 4 * sizeof(int), hipHostMallocDefault));
@@ -780,6 +831,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.fid_rows = (const int16_t *) e->d_secam[1];
 			a.lut = (const hvk_secam_c32_t *) e->d_secam[2];
 			a.bell = (const hvk_secam_c16_t *) e->d_secam[3];
+			a.lutb = e->d_secam[14];
 			a.F = (int16_t *) e->d_secam[4];
 			a.acc = (int32_t *) e->d_secam[5];
 			a.entry = (hvk_secam_state_t *) e->d_secam[6];
@@ -839,7 +891,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		(void) hipSetDevice(e->device);
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
-		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_clut3, e->d_lineoff,
+		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_UVp, e->d_clut3, e->d_lineoff,
 		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
@@ -1240,6 +1292,11 @@ extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
 	return(HVK_OK);
 }
 
+extern "C" int64_t hvk_secam_estimated_stages(const hvk_engine_t *e)
+{
+	return(e && e->secam_dev ? e->secam_est_stages : 0);
+}
+
 extern "C" int64_t hvk_frame_start(const hvk_engine_t *e, int64_t frame)
 {
 	if(!e || frame < 0) return(HVK_ERROR);
@@ -1483,6 +1540,8 @@ extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int6
 /* SECAM: the sub-carrier of the staged frames on the device (hvk_secam.hip) -- every line at once from derived entry
  * states, then check / redo rounds until every line started from the state the line before it left. The frame
  * descriptors and pictures are on their way to the device (same stream). */
+static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t stream);
+
 static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 {
 	const hvk_kconst_t &k = e->t.k;
@@ -1495,6 +1554,13 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	a.fdesc = e->d_fdesc;
 	a.levels_computed = e->levels_computed;
 	a.yuvp = e->d_yuvparams;
+	a.uvp = NULL;
+	if(e->direct && e->d_UVp)
+	{
+		/* the staged pictures' planes now, not at the launch: the cells are made of them */
+		if((r = _prep_dirty(e, e->staged_slots, nframes, e->stream)) < 0) return(r);
+		a.uvp = e->d_UVp + 16;
+	}
 	/* A lane's walk is a chain of dependent operations: a SIMD interleaves a few waves of it for free (measured: 1156
 	 * waves on 1024 SIMDs take as long as 578). Longer runs per lane only when the batch has more lines than four
 	 * waves per SIMD hold. */
@@ -1514,7 +1580,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		a.ncells = 0;
 		for(int i = 0; i < nframes; i++)
 		{
-			kf[i] = HVK_SECAM_WARMUP;
+			kf[i] = e->secam_est ? -1 : HVK_SECAM_WARMUP;
 			srows[i] = 0;
 			if(!e->secam_cell_cache)
 			{
@@ -1559,7 +1625,12 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		for(int q = i; q < j; q++) e->chroma_par[q] = (signed char) ((first_frame + q + 1) & 1);
 		i = j + 1;
 	}
-	if((r = hvk_launch_secam_cells_chain(&a, e->stream)) != HVK_OK) return(r);
+	{
+		int want = a.kf == NULL;
+		for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
+		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, e->stream)) != HVK_OK) return(r);
+		if(e->secam_est && want) e->secam_est_stages++;
+	}
 	e->secam_counts[0] += a.total;
 
 	for(;;)
@@ -1668,7 +1739,7 @@ static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t s
 		g.slot0 = todo[i];
 		g.frame_px = (int64_t) k.active_width * k.active_lines;
 		ra.levels_computed = lv;
-		const int r = hvk_launch_prep(&ra, &g, (int) (j - i), e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : NULL, stream);
+		const int r = hvk_launch_prep(&ra, &g, (int) (j - i), e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : (e->d_UVp ? e->d_UVp + 16 : NULL), stream);
 		if(r != HVK_OK) return(r);
 		e->prep_count += (int64_t) (j - i);
 		i = j;

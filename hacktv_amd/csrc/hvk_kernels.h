@@ -140,10 +140,12 @@ typedef struct {
 	const hvk_linedesc_t *desc;
 	const hvk_framedesc_t *fdesc;
 	const uint32_t *pool;
+	const int *uvp;             /* the pictures' (U, V) plane (hvk_k_prep, SECAM): a line's pixels' levels at plane_row0 + line - 1; NULL: none */
 	const void *yuv;
 	const int16_t *fid_rows;    /* [2][W] */
 	const hvk_secam_c32_t *lut;
 	const hvk_secam_c16_t *bell;
+	const void *lutb;           /* [65536] {lut[u].i, lut[u].q, bell[(u - 32768) & 0xFFFF] as one dword, 0} */
 	const int16_t *burst_win;
 	int16_t *F;                 /* [W / 8][cpad][8] */
 	int32_t *acc;               /* [cpad][8] */
@@ -159,7 +161,21 @@ typedef struct {
 	hvk_secam_state_t *seed;    /* [3 cpad], NULL: warm-ups start from a state of nothing */
 	const int *sbase;           /* [nframes] the frame's first row in it: per picture slot and frame number modulo 6 (the parity, and the
 	                             * line's sub-carrier start phase, (frame * lines + line) mod 3) */
-	const int *kf;              /* [nframes] warm-up lines of the tasks of a frame (new pictures: the full number), NULL: K */
+	const int *kf;              /* [nframes] warm-up lines of the tasks of a frame (new pictures: the full number; < 0: entry states from
+	                             * the estimate kernel instead), NULL: K, or the estimates where there are any */
+	/* New pictures: a line's entry state without walking the lines before it (hvk_k_secam_est). What a line hands on is
+	 * the IIR's two doubles -- which forget their start within 450 samples -- and the values behind the line, which the
+	 * FM loop's last steps replace: those need the phasor at the line's end, and the phasor's ANGLE is the sum of the
+	 * steps' angles, each linear in the step's table index (src/video.c:2236). hvk_k_secam_cells leaves the sum of a
+	 * line's indices from x1 on (acc[7]) and the IIR's output at W - 8 from a start of nothing (iya); the estimate kernel
+	 * adds the line's head and its last seven samples under the entry state at hand, turns the angle into the values the
+	 * loop leaves behind the line, and goes on to the next line -- a few hundred additions per line instead of a walk.
+	 * An estimate, right in all but a few cases per ten thousand (tools/secam_est_probe.c): the check decides. */
+	double *iya;                /* [cpad] */
+	int16_t *est;               /* [tpad][16]: the values behind the line at a task's entry; those the valid task before it used */
+	int x1;                     /* where a line's head ends: a multiple of 8, the entry state's influence on the indices is gone by then */
+	int ES, EK;                 /* tasks per lane of the estimate kernel; lines it walks before them */
+	double kap0, kap1;          /* a step's angle: kap0 + kap1 * index */
 	hvk_secam_state_t *entry, *exit;    /* [tpad] */
 	hvk_secam_state_t *carry;   /* the state the batch starts from; after hvk_launch_secam_carry(): the next batch's */
 	int *flags;                 /* [tpad] */
@@ -171,7 +187,7 @@ typedef struct {
 extern "C" {
 #endif
 
-int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream_t stream);
+int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, hipStream_t stream);
 int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);

@@ -95,6 +95,15 @@ __device__ __forceinline__ task_view task_of(const hvk_secam_args_t &a, const in
 	return(v);
 }
 
+/* hvk_secam_round_away() without its branches (a lane test per sample would cost an exec-mask round trip each):
+ * truncate, then look at the exactly representable rest; halves go away from zero */
+__device__ __forceinline__ int32_t round_away_nb(const double x)
+{
+	const int32_t i = (int32_t) x;
+	const double f = x - (double) i;
+	return(i + (int32_t) (f >= 0.5) - (int32_t) (f <= -0.5));
+}
+
 /* ------------------------------------------------------------------ */
 
 template<int LV>
@@ -103,7 +112,12 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 24 zeros */
 	const int W = a.C.W;
-	const int slot = blockIdx.x, i = a.clist[blockIdx.y];
+	/* (workgroups go to the 8 XCDs in turn; the 8 tasks whose outputs share 128 bytes of the transposed store go to ONE,
+	 * so that its L2 sees whole lines: workgroup b of XCD b % 8 is the (b / 8)-th there) */
+	const int bj = (int) blockIdx.x >> 3;
+	const int slot = (((bj >> 3) * 8 + ((int) blockIdx.x & 7)) << 3) + (bj & 7);
+	if(slot >= a.ntasks) return;
+	const int i = a.clist[blockIdx.y];
 	const int t = i * a.ntasks + slot;
 	const int cm = a.cbase[i] + slot;           /* the task's row in the cell stores */
 	const task_view v = task_of(a, t);
@@ -128,6 +142,9 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		int fbw = prime ? a.active_width : (f.fb_valid ? f.fb_width : 0);
 		int p0 = a.active_left + (prime ? 0 : (a.active_width - fbw) / 2);
 		int64_t row = -1, prow = -1;
+		/* the rows of the (U, V) plane that hold this line's and the line above's levels whole (a half line's has only
+		 * the half that is seen) */
+		const int *uvr = NULL, *puvr = NULL;
 
 		if(prime)
 		{
@@ -143,6 +160,11 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 			if(vy >= 0 && a.interlaced != 0 && f.fb_interlaced != a.interlaced) vy += 1;
 			vy -= vframe_y;
 			if(f.fb_valid && vy >= 0 && vy < fbh) row = f.fb_offset + (int64_t) vy * f.line_stride;
+			if(a.uvp && row >= 0)
+			{
+				const hvk_linedesc_t dl = a.desc[parity * a.lines + v.line - 1];
+				if(dl.al <= p0 && dl.ar >= p0 + fbw) uvr = a.uvp + ((size_t) f.plane_row0 + v.line - 1) * W;
+			}
 			have_prev = v.prev_line != 0;
 			{
 				const int pn = (int) v.fnum * a.lines + v.prev_line;
@@ -154,6 +176,11 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 				if(py >= 0 && a.interlaced != 0 && f.fb_interlaced != a.interlaced) py += 1;
 				py -= vframe_y;
 				if(f.fb_valid && py >= 0 && py < fbh) prow = f.fb_offset + (int64_t) py * f.line_stride;
+				if(a.uvp && prow >= 0)
+				{
+					const hvk_linedesc_t dp = a.desc[parity * a.lines + v.prev_line - 1];
+					if(dp.al <= p0 && dp.ar >= p0 + fbw) puvr = a.uvp + ((size_t) f.plane_row0 + v.prev_line - 1) * W;
+				}
 			}
 		}
 
@@ -161,21 +188,48 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		const int16_t rest = comp ? black.z : black.y;
 		/* all of the lane's pixels first (at clamped positions: no load under a lane test, which would be waited for
 		 * on the spot), then all of their level look-ups, then the cells */
-		uint32_t rgb[SPL], prgb[SPL];
 		lvl_t m[SPL], pm[SPL];
-#pragma unroll
-		for(int j = 0; j < SPL; j++)
+		const bool inw = x0 < W;
+		if(uvr)
 		{
-			int xi = x0 + j - p0;
-			xi = xi < 0 ? 0 : (xi < fbw ? xi : (fbw > 0 ? fbw - 1 : 0));
-			rgb[j] = (row >= 0 && fbw > 0) ? (a.pool[row + xi] & 0xFFFFFF) : 0;
-			prgb[j] = (have_prev && prow >= 0 && fbw > 0) ? (a.pool[prow + xi] & 0xFFFFFF) : 0;
+			/* (the plane's rows hold what lvl_of() gives for the pixels under [p0, p0 + fbw); the rest of a row is not looked at) */
+			const int4 q0 = inw ? ((const int4 *) (uvr + x0))[0] : make_int4(0, 0, 0, 0), q1 = inw ? ((const int4 *) (uvr + x0))[1] : make_int4(0, 0, 0, 0);
+			const int qq[SPL] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+			for(int j = 0; j < SPL; j++) { m[j].x = 0; m[j].y = (int16_t) qq[j]; m[j].z = (int16_t) (qq[j] >> 16); m[j].w = 0; }
 		}
-#pragma unroll
-		for(int j = 0; j < SPL; j++)
+		else
 		{
-			m[j] = lvl_of<LV>(a, rgb[j]);
-			pm[j] = lvl_of<LV>(a, prgb[j]);
+			uint32_t rgb[SPL];
+#pragma unroll
+			for(int j = 0; j < SPL; j++)
+			{
+				int xi = x0 + j - p0;
+				xi = xi < 0 ? 0 : (xi < fbw ? xi : (fbw > 0 ? fbw - 1 : 0));
+				rgb[j] = (row >= 0 && fbw > 0) ? (a.pool[row + xi] & 0xFFFFFF) : 0;
+			}
+#pragma unroll
+			for(int j = 0; j < SPL; j++) m[j] = lvl_of<LV>(a, rgb[j]);
+		}
+		if(puvr)
+		{
+			const int4 q0 = inw ? ((const int4 *) (puvr + x0))[0] : make_int4(0, 0, 0, 0), q1 = inw ? ((const int4 *) (puvr + x0))[1] : make_int4(0, 0, 0, 0);
+			const int qq[SPL] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+			for(int j = 0; j < SPL; j++) { pm[j].x = 0; pm[j].y = (int16_t) qq[j]; pm[j].z = (int16_t) (qq[j] >> 16); pm[j].w = 0; }
+		}
+		else
+		{
+			uint32_t prgb[SPL];
+#pragma unroll
+			for(int j = 0; j < SPL; j++)
+			{
+				int xi = x0 + j - p0;
+				xi = xi < 0 ? 0 : (xi < fbw ? xi : (fbw > 0 ? fbw - 1 : 0));
+				prgb[j] = (have_prev && prow >= 0 && fbw > 0) ? (a.pool[prow + xi] & 0xFFFFFF) : 0;
+			}
+#pragma unroll
+			for(int j = 0; j < SPL; j++) pm[j] = lvl_of<LV>(a, prgb[j]);
 		}
 #pragma unroll
 		for(int j = 0; j < SPL; j++)
@@ -209,11 +263,13 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 	else for(int j = 0; j < SPL; j++) if(x0 + j < W) lds[8 + x0 + j] = c[j];
 	__syncthreads();
 
-	if(x0 >= W) return;
+	const bool act = x0 < W;
 
 	/* 15-tap low pass, zero history (src/video.c:3207): output x reads cells x - 7 .. x + 7 = elements x + 1 .. x + 15 --
 	 * the lane's window starts one element behind its 16-byte aligned slice; packed pairs and v_dot2c_i32_i16 */
 	int32_t acc[SPL];
+	int16_t o[SPL];
+	if(act)
 	{
 		constexpr int ND = SPL / 2 + (15 + 1) / 2 + 1;
 		int d[ND], tp[8];
@@ -231,10 +287,10 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		for(int q = 0; q < 8; q++) tp[q] = ((int) a.C.fir[2 * q] & 0xFFFF) | ((q < 7 ? (int) a.C.fir[2 * q + 1] : 0) << 16);
 		fir8<15, 1>(d, tp, acc);
 	}
+	else for(int j = 0; j < SPL; j++) acc[j] = 0;
 
 	/* 8 outputs of one task in 16 bytes, tasks side by side */
 	{
-		int16_t o[SPL];
 		for(int j = 0; j < SPL; j++)
 		{
 			int32_t s = acc[j] >> 15;
@@ -245,16 +301,90 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		pk.y = (uint16_t) o[2] | ((uint32_t) (uint16_t) o[3] << 16);
 		pk.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
 		pk.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
-		((int4 *) a.F)[(size_t) lane * a.cpad + cm] = pk;
+		if(act) ((int4 *) a.F)[(size_t) lane * a.cpad + cm] = pk;
 	}
 	/* the last 7 outputs also as they are before the shift: the share of what lies behind the line comes later */
-	if(x0 + SPL >= W)
+	if(act && x0 + SPL >= W)
 	{
 		for(int j = 0; j < SPL; j++)
 		{
 			const int x = x0 + j;
 			if(x >= W - HVK_SECAM_TAIL && x < W) a.acc[(size_t) cm * 8 + (x - (W - HVK_SECAM_TAIL))] = acc[j];
 		}
+	}
+
+	/* For hvk_k_secam_est: the pre-emphasis IIR over the line from a start of nothing, all lanes at once -- every lane
+	 * its eight samples with nothing carried in, the carries by a scan over the lanes (what a lane hands on reaches the
+	 * next one times 0.90456054^8), then the samples again with the carry: the outputs to within rounding, which is all
+	 * the table indices need. Left behind: the sum of the indices from x1 to the FM window's end short of the line's
+	 * last seven samples, and the IIR's output at W - 8. */
+	if(a.iya)
+	{
+		__shared__ double s_y[4];
+		__shared__ int s_f[4];
+		__shared__ int s_sum;
+		const double CA = 2.90456054, CB = -2.80912108, CC = 0.90456054;
+		const int wl = lane & 63, wv = lane >> 6;
+		if(lane == 0) s_sum = 0;
+		if(wl == 63) s_f[wv] = act ? (int) o[SPL - 1] : 0;
+		__syncthreads();
+		double yl[SPL];
+		{
+			int fp = __shfl_up(act ? (int) o[SPL - 1] : 0, 1);
+			if(wl == 0) fp = wv ? s_f[wv - 1] : 0;
+			double y = 0, xp = (double) fp;
+#pragma unroll
+			for(int j = 0; j < SPL; j++)
+			{
+				const double in = act ? (double) o[j] : 0.0;
+				y = (in * CA + xp * CB) + y * CC;
+				xp = in;
+				yl[j] = y;
+			}
+		}
+		/* (the scan inside a wave by shuffles; from the wave before only its last lane's value matters: what lies further
+		 * back has shrunk by 0.448^64) */
+		double sv = yl[SPL - 1], mul = CC * CC;
+		mul *= mul; mul *= mul;         /* CC^8 */
+		double pw = 1.0;                /* CC^(8 (wl + 1)) */
+		{
+			double sq = mul;
+			for(int b = 0; b < 7; b++) { if((wl + 1) >> b & 1) pw *= sq; sq *= sq; }
+		}
+		for(int d = 1; d < 64; d <<= 1)
+		{
+			const double t = __shfl_up(sv, d);
+			if(wl >= d) sv += mul * t;
+			mul *= mul;
+		}
+		if(wl == 63) s_y[wv] = sv;
+		__syncthreads();
+		const double before = wv ? s_y[wv - 1] : 0.0;
+		sv += pw * before;
+		double cin = __shfl_up(sv, 1);
+		if(wl == 0) cin = before;
+		const int fm_end = v.sr < W ? v.sr : W;
+		const int hi = fm_end < W - HVK_SECAM_TAIL ? fm_end : W - HVK_SECAM_TAIL;
+		const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
+		int sum = 0;
+		double p = CC;
+#pragma unroll
+		for(int j = 0; j < SPL; j++)
+		{
+			const double yj = yl[j] + p * cin;
+			const int x = x0 + j;
+			p *= CC;
+			if(x >= a.x1 && x < hi)
+			{
+				const int32_t r = round_away_nb(yj);
+				sum += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+			}
+			if(x == W - 8) a.iya[cm] = yj;
+		}
+		for(int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+		if(wl == 0 && sum) atomicAdd(&s_sum, sum);
+		__syncthreads();
+		if(lane == 0) a.acc[(size_t) cm * 8 + 7] = s_sum;
 	}
 }
 
@@ -282,15 +412,6 @@ __device__ __forceinline__ int4 pack8(const int16_t *o)
 	po.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
 	po.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
 	return(po);
-}
-
-/* hvk_secam_round_away() without its branches (a lane test per sample would cost an exec-mask round trip each):
- * truncate, then look at the exactly representable rest; halves go away from zero */
-__device__ __forceinline__ int32_t round_away_nb(const double x)
-{
-	const int32_t i = (int32_t) x;
-	const double f = x - (double) i;
-	return(i + (int32_t) (f >= 0.5) - (int32_t) (f <= -0.5));
 }
 
 /* EMIT = false: a warm-up line -- only the state it leaves matters, so the output half of an FM step (level, bell-filter
@@ -364,12 +485,21 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 			 * ends, and half lines): the same steps without a test per sample */
 			hvk_secam_c16_t g[CH];
 			hvk_secam_c32_t st[CH];
-#pragma unroll
-			for(int j = 0; j < CH; j++)
+			if(EMIT)
 			{
-				/* (unsigned indices: the loads take the tables' addresses from scalar registers) */
-				if(EMIT) g[j] = a.bell[(u[j] - 32768u) & 0xFFFFu];
-				st[j] = a.lut[u[j]];
+				/* (step and bell-filter gain of an index side by side: one 16-byte read, one cache line per sample) */
+#pragma unroll
+				for(int j = 0; j < CH; j++)
+				{
+					const int4 q = ((const int4 *) a.lutb)[u[j]];
+					st[j].i = q.x; st[j].q = q.y;
+					g[j].i = (int16_t) q.z; g[j].q = (int16_t) (q.z >> 16);
+				}
+			}
+			else
+			{
+#pragma unroll
+				for(int j = 0; j < CH; j++) st[j] = a.lut[u[j]];     /* (unsigned indices: the loads take the table's address from scalar registers) */
 			}
 #pragma unroll
 			for(int j = 0; j < CH; j++)
@@ -391,12 +521,21 @@ __device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m
 		{
 			hvk_secam_c16_t g[CH];
 			hvk_secam_c32_t st[CH];
-#pragma unroll
-			for(int j = 0; j < CH; j++)
+			if(EMIT)
 			{
-				/* (unsigned indices: the loads take the tables' addresses from scalar registers) */
-				if(EMIT) g[j] = a.bell[(u[j] - 32768u) & 0xFFFFu];
-				st[j] = a.lut[u[j]];
+				/* (step and bell-filter gain of an index side by side: one 16-byte read, one cache line per sample) */
+#pragma unroll
+				for(int j = 0; j < CH; j++)
+				{
+					const int4 q = ((const int4 *) a.lutb)[u[j]];
+					st[j].i = q.x; st[j].q = q.y;
+					g[j].i = (int16_t) q.z; g[j].q = (int16_t) (q.z >> 16);
+				}
+			}
+			else
+			{
+#pragma unroll
+				for(int j = 0; j < CH; j++) st[j] = a.lut[u[j]];     /* (unsigned indices: the loads take the table's address from scalar registers) */
 			}
 #pragma unroll
 			for(int j = 0; j < CH; j++)
@@ -461,6 +600,210 @@ __device__ __forceinline__ int seed_row(const hvk_secam_args_t &a, const int m)
 	return(a.sbase[i] + (m - i * a.ntasks));
 }
 
+/* ------------------------------------------------------------------ */
+
+#define IIR_STEP(in_) do { const double in__ = (in_); const double t0__ = in__ * 2.90456054, t1__ = ix * -2.80912108, t2__ = iy * -0.90456054; \
+                           iy = (t0__ + t1__) - t2__; ix = in__; } while(0)
+
+/* a line's low-pass output x >= W - 7 given the values behind the line (hvk_secam_chain_line) */
+__device__ __forceinline__ int32_t tail_output(const hvk_secam_args_t &a, const int cm, const int x, const int16_t *tail)
+{
+	const int W = a.C.W;
+	int32_t s = a.acc[(size_t) cm * 8 + (x - (W - HVK_SECAM_TAIL))];
+	for(int i = 0; i < HVK_SECAM_TAIL; i++)
+	{
+		const int k = W + 7 + i - x;
+		if(k <= 14) s += (int32_t) tail[i] * a.C.fir[k];
+	}
+	s >>= 15;
+	return(s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+}
+
+/* One line of the estimate: E on entry (the IIR's state to within rounding, the values behind the line), on exit.
+ * The line's head exactly as the walk has it; the middle from hvk_k_secam_cells; the last seven samples with the values
+ * behind the line at hand; then the FM loop's steps past the line's end with the phasor the summed angle gives --
+ * cos and sin of it at the amplitude the floor-after-every-step recurrence has lost one unit per step of -- through
+ * the same integer arithmetic as hvk_secam_fm_step(). */
+__device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m, const task_view &v, hvk_secam_state_t &E)
+{
+	const int W = a.C.W, sl = a.C.sl;
+	const int fm_end = v.sr < W ? v.sr : W;
+	const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
+	const int cm = a.cbase[v.frame] + (m - v.frame * a.ntasks);
+	const int4 *F = (const int4 *) a.F + cm;
+	double ix = E.ix, iy = E.iy;
+	int64_t S = 0;
+
+	/* (four chunks in flight: the loads are a lane's own, 16 bytes each, and nothing else hides their latency) */
+	const int nq = a.x1 / 8;
+	int4 ring[4];
+#pragma unroll
+	for(int q = 0; q < 4; q++) ring[q] = F[(size_t) (q < nq ? q : 0) * a.cpad];
+	const int4 last = F[(size_t) ((W - 8) / 8) * a.cpad];
+	const double iya = a.iya[cm];
+	int32_t tacc[8];
+	{
+		const int4 *pa = (const int4 *) (a.acc + (size_t) cm * 8);
+		const int4 a0 = pa[0], a1 = pa[1];
+		tacc[0] = a0.x; tacc[1] = a0.y; tacc[2] = a0.z; tacc[3] = a0.w;
+		tacc[4] = a1.x; tacc[5] = a1.y; tacc[6] = a1.z; tacc[7] = a1.w;
+	}
+	/* (up to the FM window the IIR alone) */
+	const int q0 = sl / 8 < nq ? sl / 8 : nq;
+	int q = 0;
+	for(; q < q0; q++)
+	{
+		int16_t f[8];
+		unpack8(ring[0], f);
+		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
+		if(q + 4 < nq) ring[3] = F[(size_t) (q + 4) * a.cpad];
+#pragma unroll
+		for(int j = 0; j < 8; j++) IIR_STEP((double) f[j]);
+	}
+	for(; q < nq; q++)
+	{
+		int16_t f[8];
+		unpack8(ring[0], f);
+		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
+		if(q + 4 < nq) ring[3] = F[(size_t) (q + 4) * a.cpad];
+#pragma unroll
+		for(int j = 0; j < 8; j++)
+		{
+			const int x = q * 8 + j;
+			IIR_STEP((double) f[j]);
+			if(x >= sl && x < fm_end)
+			{
+				const int32_t r = round_away_nb(iy);
+				S += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+			}
+		}
+	}
+	S += tacc[7];
+
+	ix = (double) (int16_t) last.x;
+	iy = iya;
+#pragma unroll
+	for(int j = 0; j < HVK_SECAM_TAIL; j++)
+	{
+		const int x = W - HVK_SECAM_TAIL + j;
+		int32_t s = tacc[j];
+#pragma unroll
+		for(int i = 0; i <= j; i++) s += (int32_t) E.tail[i] * a.C.fir[14 + i - j];     /* (tap W + 7 + i - x) */
+		s >>= 15;
+		IIR_STEP((double) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s)));
+		if(x >= sl && x < fm_end)
+		{
+			const int32_t r = round_away_nb(iy);
+			S += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+		}
+	}
+	E.ix = ix;
+	E.iy = iy;
+
+	if(v.sr > W)
+	{
+		const int n = fm_end > sl ? fm_end - sl : 0;
+		double th = (v.phase_pos ? 0.0 : 3.14159265358979323846) + a.kap0 * (double) n + a.kap1 * (double) S;
+		double amp = 2147483647.0 - (double) n;
+		for(int x = W; x < v.sr; x++)
+		{
+			int16_t c = E.tail[x - W];
+			c = c < (int16_t) dmin32 ? (int16_t) dmin32 : (c > (int16_t) dmax32 ? (int16_t) dmax32 : c);
+			th += a.kap0 + a.kap1 * (double) c;
+			amp -= 1.0;
+			double sn, cs;
+			sincos(th, &sn, &cs);
+			const int32_t pi = (int32_t) floor(amp * cs), pq = (int32_t) floor(amp * sn);
+			const hvk_secam_c16_t g = a.bell[(uint16_t) c];
+			const int32_t vi = ((pi >> 16) * a.C.level) >> 15;
+			const int32_t vq = ((pq >> 16) * a.C.level) >> 15;
+			E.tail[x - W] = (int16_t) (((vi * g.i) >> 15) - ((vq * g.q) >> 15));
+		}
+	}
+}
+
+/* One lane per a.ES consecutive tasks: the values behind the line at each of their entries, from a.EK lines further up
+ * walked this way from a state of nothing (the estimate's own errors fade like the walk's: by a factor of about 3 per
+ * line). est[m]: [0..7] at task m's entry (before a field's first line clears them), [8..15] what the valid task
+ * before it worked with. */
+__global__ __launch_bounds__(64)
+void hvk_k_secam_est(const hvk_secam_args_t a)
+{
+	const int g = blockIdx.x * 64 + threadIdx.x;
+	const int t0 = g * a.ES;
+	if(t0 >= a.total) return;
+	const int t1 = t0 + a.ES < a.total ? t0 + a.ES : a.total;
+	if(a.kf)
+	{
+		/* only where a frame asks for it (a run's start looks at most at the task before the segment's first) */
+		const int tn = t1 < a.total ? t1 : a.total - 1;
+		if(a.kf[t0 / a.ntasks] >= 0 && a.kf[(t1 - 1) / a.ntasks] >= 0 && a.kf[tn / a.ntasks] >= 0) return;
+	}
+
+	hvk_secam_state_t E;
+	int16_t used[8];
+	int m = t0 - a.EK;
+	if(m <= 0) { m = 0; E = *a.carry; }
+	else { E.ix = 0; E.iy = 0; for(int i = 0; i < 8; i++) E.tail[i] = 0; }
+	for(int i = 0; i < 8; i++) used[i] = E.tail[i];
+
+	for(; m < t1; m++)
+	{
+		if(m >= t0)
+		{
+			int4 *o = (int4 *) (a.est + (size_t) m * 16);
+			o[0] = pack8(E.tail);
+			o[1] = pack8(used);
+		}
+		if(m == t1 - 1) break;
+		const task_view v = task_of(a, m);
+		if(!v.valid) continue;
+		if(v.clear) for(int i = 0; i < 8; i++) E.tail[i] = 0;
+		for(int i = 0; i < 8; i++) used[i] = E.tail[i];
+		est_line(a, m, v, E);
+	}
+}
+
+/* A run's entry state from the estimate: the values behind the line as hvk_k_secam_est left them; the IIR's two doubles
+ * exactly, by walking the IIR alone over the last 448 samples of the valid task before -- from whatever state, it has
+ * arrived bit for bit at the state of the full walk by then (its pole is 0.90456: 2^-53 after 360 samples, and equal
+ * doubles stay equal) -- with that task's last seven outputs made with the values IT had behind its line. */
+#define PREWALK 448
+__device__ __forceinline__ void est_entry(const hvk_secam_args_t &a, const int t0, hvk_secam_state_t &S)
+{
+	int mp = t0 - 1;
+	while(mp >= 0 && !task_of(a, mp).valid) mp--;
+	if(mp < 0) { S = *a.carry; return; }
+
+	const int W = a.C.W;
+	const task_view v = task_of(a, mp);
+	const int cm = a.cbase[v.frame] + (mp - v.frame * a.ntasks);
+	const int4 *F = (const int4 *) a.F + cm;
+	const int4 *e = (const int4 *) (a.est + (size_t) t0 * 16);
+	int16_t used[8];
+	double ix = 0, iy = 0;
+	const int q1 = W / 8 - 1;
+	int q = q1 - PREWALK / 8 + 1;
+	if(q < 0) q = 0;
+
+	unpack8(e[1], used);
+	int4 nx = F[(size_t) q * a.cpad];
+	for(; q < q1; q++)
+	{
+		int16_t f[8];
+		unpack8(nx, f);
+		nx = F[(size_t) (q + 1) * a.cpad];
+#pragma unroll
+		for(int j = 0; j < 8; j++) IIR_STEP((double) f[j]);
+	}
+	IIR_STEP((double) (int16_t) nx.x);
+	for(int x = W - HVK_SECAM_TAIL; x < W; x++) IIR_STEP((double) tail_output(a, cm, x, used));
+
+	S.ix = ix;
+	S.iy = iy;
+	unpack8(e[0], S.tail);
+}
+
 /* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than four waves per SIMD hold:
  * then the warm-up is shared by the run's lines) */
 __global__ __launch_bounds__(64)
@@ -471,10 +814,16 @@ void hvk_k_secam_chain(const hvk_secam_args_t a)
 	const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
 
 	hvk_secam_state_t S;
-	int m = t0 - (a.kf ? a.kf[t0 / a.ntasks] : a.K);
-	if(m <= 0) { m = 0; S = *a.carry; }
-	else if(a.seed) S = a.seed[seed_row(a, m)];
-	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
+	const int kk = a.kf ? a.kf[t0 / a.ntasks] : (a.est ? -1 : a.K);
+	int m = t0;
+	if(kk < 0) est_entry(a, t0, S);
+	else
+	{
+		m = t0 - kk;
+		if(m <= 0) { m = 0; S = *a.carry; }
+		else if(a.seed) S = a.seed[seed_row(a, m)];
+		else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
+	}
 
 	for(; m < t0; m++) run_task(a, m, S, false);
 	a.entry[r] = S;
@@ -541,15 +890,22 @@ __global__ void hvk_k_secam_carry(const hvk_secam_args_t a)
 	if(threadIdx.x == 0 && blockIdx.x == 0) *a.carry = a.exit[a.nruns - 1];
 }
 
-extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, hipStream_t stream)
+extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, hipStream_t stream)
 {
 	const int lanes = (a->C.W + SPL - 1) / SPL;
 	const int threads = (lanes + 63) & ~63;
 	if(threads > 256 || (a->C.W % 16) != 0) return(HVK_UNSUPPORTED);
 	if(a->ncells > 0)
 	{
-		if(a->levels_computed) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(a->ntasks, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
-		else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(a->ntasks, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+		const int gx = (a->ntasks + 63) & ~63;
+		/* (with the pictures' (U, V) plane the levels are there; the few rows it does not hold whole -- half lines -- go through the table) */
+		if(a->levels_computed && !a->uvp) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(gx, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+		else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(gx, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+	}
+	if(estimate && a->est)
+	{
+		const int lanes_e = (a->total + a->ES - 1) / a->ES;
+		hipLaunchKernelGGL(hvk_k_secam_est, dim3((lanes_e + 63) / 64), dim3(64), 0, stream, *a);
 	}
 	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
-    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches",
+    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages",
 ]
 
 _lib = None
@@ -85,6 +85,8 @@ def lib():
         L.hvk_host_side_streams.argtypes = [vp, i64, i64, vp, vp, i32, vp]
         L.hvk_host_secam_stream.argtypes = [vp, vp, i32, i32, i32, vp]
         L.hvk_secam_stats.argtypes = [vp, vp]
+        L.hvk_secam_estimated_stages.argtypes = [vp]
+        L.hvk_secam_estimated_stages.restype = C.c_int64
         L.hvk_frame_start.argtypes = [vp, C.c_int64]
         L.hvk_frame_start.restype = C.c_int64
         L.hvk_secam_warmup_lines.argtypes = [vp]
@@ -295,6 +297,10 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
         return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
+
+    def secam_estimated_stages(self):
+        """Stages whose new pictures' lines started from estimated states (hvk_k_secam_est) instead of warm-up walks."""
+        return int(lib().hvk_secam_estimated_stages(self.h))
 
     def frame_start(self, frame):
         """First output sample of a stream frame (frame * frame_samples but for rate pairs with frames of two lengths)."""

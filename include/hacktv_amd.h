@@ -309,6 +309,11 @@ int hvk_host_secam_stream(hvk_engine_t *e, const uint32_t *fb, int width, int he
  * counts[0] lines worked on speculatively, [1] lines whose derived entry state was wrong, [2] lines redone in order
  * because of them, [3] frames that went through the host's serial chain instead. */
 int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4]);
+/* ... and how many stages took the entry states of NEW pictures' lines from the estimate kernel (the values behind a line
+ * from the summed angle of the FM loop's steps, the IIR's state from a short walk of the IIR alone) instead of from
+ * warm-up walks over the twelve lines before; HVK_SECAM_EST=0 or a pinned HVK_SECAM_WARMUP keep the walks. The check
+ * is the same either way. */
+int64_t hvk_secam_estimated_stages(const hvk_engine_t *e);
 
 /* SECAM: the number of lines a lane walks in front of a line to derive its entry state, as it stands. It follows the
  * pictures (one less after a block without a wrong start, two more after one with; HVK_SECAM_WARMUP=n in the

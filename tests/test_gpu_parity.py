@@ -475,12 +475,14 @@ def _secam_noisy(n, seed=11):
     return out
 
 
-@pytest.mark.parametrize("env,expect", [({}, "device"), ({"HVK_SECAM_RUN": "3"}, "device"), ({"HVK_SECAM_WARMUP": "5"}, "redo"),
-                                        ({"HVK_LEVELS": "compute"}, "device"),
+@pytest.mark.parametrize("env,expect", [({}, "estimate"), ({"HVK_SECAM_RUN": "3"}, "estimate"), ({"HVK_SECAM_WARMUP": "5"}, "redo"),
+                                        ({"HVK_LEVELS": "compute"}, "estimate"), ({"HVK_SECAM_EST": "0"}, "device"),
+                                        ({"HVK_SECAM_NO_UV_PLANE": "1"}, "estimate"), ({"HVK_DIRECT": "0"}, "estimate"),
+                                        ({"HVK_SECAM_EST_LINES": "3", "HVK_SECAM_EST_RUN": "7"}, "redo"),
                                         ({"HVK_SECAM_WARMUP": "1", "HVK_SECAM_FORCE_FALLBACK": "1"}, "fallback")])
 def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypatch, env, expect):
-    """The SECAM colour sub-carrier computed line-parallel on the device (hvk_secam.hip: derived entry states,
-    check, redo rounds) against the host's serial chain (HVK_SECAM_HOST=1, itself pinned against the reference on
+    """The SECAM colour sub-carrier computed line-parallel on the device (hvk_secam.hip: entry states estimated or
+    derived by warm-up walks, check, redo rounds; cells from the pictures' (U, V) plane or from the pixels) against the host's serial chain (HVK_SECAM_HOST=1, itself pinned against the reference on
     the CPU), over 3 batches of 3 moving noisy pictures + field identification lines: every sample equal; with the
     default warm-up next to nothing needs redoing, with a short one the redo rounds do the work, and a forced
     fall-back hands the batch to the host's chain and takes the chain back afterwards."""
@@ -495,7 +497,9 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
                     e.frame_upload(s_, pics[b * 3 + s_])
                 e.render(3, slots=[0, 1, 2])
                 out.append(e.fetch(0, 3 * 640000))
-            return np.concatenate(out), e.secam_stats()
+            st_ = e.secam_stats()
+            st_["estimated"] = e.secam_estimated_stages()
+            return np.concatenate(out), st_
     monkeypatch.setenv("HVK_SECAM_HOST", "1")
     want, st_host = run()
     monkeypatch.delenv("HVK_SECAM_HOST")
@@ -504,7 +508,9 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
     got, st = run()
     assert np.array_equal(got, want)
     assert st["tasks"] >= 9 * 570
-    if expect == "device":
+    # new pictures' lines start from estimated states (hvk_k_secam_est) unless that is switched off or the warm-up pinned
+    assert (st["estimated"] > 0) == (expect == "estimate" or "HVK_SECAM_EST_LINES" in env), st
+    if expect in ("device", "estimate"):
         # (the number of warm-up lines follows the pictures: a wrong start is found by the check and redone, not a failure)
         assert st["host_frames"] == 0 and st["mismatches"] <= st["tasks"] // 50, st
     elif expect == "redo":
@@ -576,9 +582,14 @@ def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch)
     assert st["host_frames"] == 0
     assert min(ks[:16]) <= 2, ks          # the card: fewer and fewer lines, in the end none
     monkeypatch.setenv("HVK_SECAM_NO_SEEDS", "1")
+    monkeypatch.setenv("HVK_SECAM_EST", "0")
     got2, ks2, _ = run()
     assert np.array_equal(got2, want)
-    assert min(ks2) >= 9, ks2             # without the kept states the card needs its 11 lines
+    assert min(ks2) >= 9, ks2             # without the kept states (and without the estimate kernel) the card needs its 11 lines
+    monkeypatch.delenv("HVK_SECAM_EST")
+    got3, _, st3 = run()                  # without the kept states every line's entry state is an estimate
+    assert np.array_equal(got3, want)
+    assert st3["host_frames"] == 0 and st3["mismatches"] <= st3["tasks"] // 100, st3
 
 
 @pytest.mark.parametrize("case,batches", [("m_px135_s16", (1, 3, 1)), ("m_px135_s16", (5,)), ("ntsc_px16_s135", (2, 1, 1)), ("ntsc_px16_s135", (3, 1))])
