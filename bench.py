@@ -912,7 +912,7 @@ def main():
     # chain on one short block ----
     secam = None
     if N == 1 and not args.no_moving:
-        def secam_run(Fs, ksteps, wsteps=16, pics=None):
+        def secam_run(Fs, ksteps, wsteps=16, pics=None, refresh=False):
             # (the warm-up steps also let the number of warm-up LINES per start state settle: it follows the pictures, one
             # line down per clean block, two up per block with a wrong start -- hvk_engine.cpp)
             es = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=Fs)
@@ -924,12 +924,17 @@ def main():
                     es.frame_upload(i_, p_)
                 slots = [i_ % len(pics) for i_ in range(Fs)]
             for k in range(wsteps):
+                if refresh:
+                    es.planes_refresh(slots)
                 es.stage(k * Fs, 1, Fs, slots=slots)
                 es.launch()
             es.sync()
             st0 = es.secam_stats()
+            est0 = es.secam_estimated_stages()
             t0 = time.perf_counter()
             for k in range(ksteps):
+                if refresh:
+                    es.planes_refresh(slots)        # (every picture's luma and (U, V) planes made again: hvk_k_prep8)
                 es.stage((wsteps + k) * Fs, 1, Fs, slots=slots)
                 es.launch()
             es.sync()
@@ -937,6 +942,7 @@ def main():
             st = es.secam_stats()
             st = {kk: st[kk] - st0[kk] for kk in st}        # the timed steps' lines
             st["warmup_lines_per_start_state"] = es.secam_warmup_lines()
+            st["stages_with_estimated_entry_states"] = es.secam_estimated_stages() - est0
             names_s = es.kernel_names()
             es.close()
             return t_dev, st, names_s
@@ -953,6 +959,9 @@ def main():
             noisy.append(np.where(rngs.random(p_.shape) < 0.2, rngs.integers(0, 1 << 24, p_.shape, dtype=np.uint32), p_).astype(np.uint32))
         os.environ["HVK_SECAM_NO_CELL_CACHE"] = "1"
         t_mov, st_mov, _ = secam_run(4 * F, 3, wsteps=4, pics=noisy)
+        # ... and with a picture slot per frame whose planes (luma through the notch, the pixels' colour-difference levels)
+        # are made again in every step as well: everything a new picture on every frame costs on the device
+        t_new, st_new, names_new = secam_run(4 * F, 3, wsteps=3, pics=[noisy[i_ % 4] for i_ in range(4 * F)], refresh=True)
         del os.environ["HVK_SECAM_NO_CELL_CACHE"]
         os.environ["HVK_SECAM_HOST"] = "1"
         eh = H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), SAMPLE_RATE, device=local_rank, max_frames=8)
@@ -978,9 +987,18 @@ def main():
                                                  "of its dependent steps -- takes nearly as long: about one wave per SIMD instead of four"},
             "pictures_change_every_frame": {"Msamples_per_s": round(4 * F * FS / t_mov / 1e6, 1), "ms_per_step": round(t_mov * 1e3, 3), "lines": st_mov,
                                             "note": "noisy pictures (gradients, a fifth of the pixels random colours), resident in HBM, the cells made for EVERY frame "
-                                                    "(HVK_SECAM_NO_CELL_CACHE=1): what a moving source costs on the device. With the test card a picture's cells are "
+                                                    "(HVK_SECAM_NO_CELL_CACHE=1) and every line's entry state new (no state kept from a last showing): the colour chain's "
+                                                    "share of a moving source -- the measure of rounds 2 and 3. With the test card a picture's cells are "
                                                     "made once per frame parity and kept (per-picture work, like the picture planes of the PAL-I headline); the walk "
-                                                    "from line to line, the check and the render are every frame's in both"},
+                                                    "from line to line, the check and the render are every frame's in both. Since round 4 the entry states of new "
+                                                    "pictures' lines are estimated (hvk_k_secam_est: the values behind a line from the summed angle of the FM steps, "
+                                                    "the IIR's state from a walk of the IIR alone) instead of derived by walking the twelve lines before, and the cells "
+                                                    "are made from the pictures' (U, V) plane"},
+            "new_picture_every_frame": {"Msamples_per_s": round(4 * F * FS / t_new / 1e6, 1), "ms_per_step": round(t_new * 1e3, 3), "lines": st_new,
+                                        "kernels": names_new,
+                                        "note": "%d picture slots, one per frame of the block, and in every step every slot's planes are made again too "
+                                                "(hvk_planes_refresh -> hvk_k_prep8<1, 0, LV, 1>: levels computed per pixel, luma through the 51-tap notch, (U, V) plane) before "
+                                                "cells, estimate, walk, check and render: the whole device-side cost of a new picture on every frame, uploads apart" % (4 * F)},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
             "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
             "note": "lines (of the timed steps): worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; "
@@ -1081,6 +1099,7 @@ def main():
             "new_pictures_every_frame_computed_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "computed_levels_Msamples_per_s"),
             "secam_l_test_card_Msamples_per_s": _g(secam, "Msamples_per_s"),
             "secam_l_pictures_change_every_frame_Msamples_per_s": _g(secam, "pictures_change_every_frame", "Msamples_per_s"),
+            "secam_l_new_picture_every_frame_planes_too_Msamples_per_s": _g(secam, "new_picture_every_frame", "Msamples_per_s"),
             "config1_path_frac": _g(configs, "1_pal_baseband", "path_frac"), "config3_path_frac": _g(configs, "3_ntsc_m", "path_frac"),
             "config4_noaudio_device_path_frac": _g(configs, "4_secam_l_teletext_noaudio_device", "path_frac"),
             "config2_noaudio_path_frac": _g(configs, "2_noaudio", "path_frac"),

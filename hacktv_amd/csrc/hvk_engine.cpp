@@ -31,7 +31,7 @@
 
 #define HVK_VERSION "hacktv-amd 0.1 (gfx950)"
 #define HVK_MIN_FRAME_SLOTS 4
-#define HVK_MAX_FRAME_SLOTS 256
+#define HVK_MAX_FRAME_SLOTS 1024
 #define HVK_TIMING_SLOTS 512
 #define HVK_UPLOAD_RING 8
 #define HVK_FETCH_TICKETS 4
@@ -74,7 +74,7 @@ struct hvk_engine {
 	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
 	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */
 	int *h_secam_count;         /* pinned: failures of the last check */
-	int secam_lanes;            /* lanes of four waves per SIMD */
+	int secam_lanes;            /* lanes of eight waves per SIMD */
 	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
 	int secam_clean, secam_patience;    /* batches without a wrong start in a row; how many of them before a line less is tried */
 	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
@@ -851,8 +851,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.chroma = e->d_chroma;
 			{
 				hipDeviceProp_t prop;
-				e->secam_lanes = 1024 * 64 * 4;
-				if(hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->secam_lanes = prop.multiProcessorCount * 4 * 64 * 4;
+				e->secam_lanes = 1024 * 64 * 8;
+				if(hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->secam_lanes = prop.multiProcessorCount * 4 * 64 * 8;
 			}
 			e->secam_dev = 1;
 		}
@@ -1562,7 +1562,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		a.uvp = e->d_UVp + 16;
 	}
 	/* A lane's walk is a chain of dependent operations: a SIMD interleaves a few waves of it for free (measured: 1156
-	 * waves on 1024 SIMDs take as long as 578). Longer runs per lane only when the batch has more lines than four
+	 * waves on 1024 SIMDs take as long as 578). Longer runs per lane only when the batch has more lines than eight
 	 * waves per SIMD hold. */
 	a.R = (a.total + e->secam_lanes - 1) / e->secam_lanes;
 	if(a.R < 1) a.R = 1;

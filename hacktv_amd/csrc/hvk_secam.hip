@@ -804,7 +804,7 @@ __device__ __forceinline__ void est_entry(const hvk_secam_args_t &a, const int t
 	unpack8(e[0], S.tail);
 }
 
-/* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than four waves per SIMD hold:
+/* One lane per RUN of a.R consecutive tasks (a.R = 1 unless the batch has more tasks than eight waves per SIMD hold:
  * then the warm-up is shared by the run's lines) */
 __global__ __launch_bounds__(64)
 void hvk_k_secam_chain(const hvk_secam_args_t a)
