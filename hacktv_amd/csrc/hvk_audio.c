@@ -408,6 +408,7 @@ struct hvk_audio {
 	int kept_w[KEPT_LINES];
 	int kept_at;
 	int ahead;              /* lines */
+	int ahead_w;            /*   ... of this many samples each (behind the resampler the lines' widths vary: the widest) */
 
 	_sis_t sis;
 };
@@ -421,6 +422,7 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 
 	a->t = t;
 	a->width = t->k.width;
+	a->ahead_w = t->k.rs_L ? t->max_width : t->k.width;
 	a->sample_rate = t->sample_rate;
 
 	if(t->fm_lut)
@@ -546,7 +548,7 @@ int hvk_audio_push(hvk_audio_t *a, const int16_t *stereo, size_t nsamples)
  * position upto_pos: ticks fire when the accumulator crosses sample_rate */
 size_t hvk_audio_source_needed(const hvk_audio_t *a, int64_t upto_pos)
 {
-	int64_t n = upto_pos + (int64_t) a->ahead * a->width - a->pos;
+	int64_t n = upto_pos + (int64_t) a->ahead * a->ahead_w - a->pos;
 	int64_t ticks, have;
 	if(n <= 0) return(0);
 	ticks = ((int64_t) a->interp + n * AUDIO_RATE) / a->sample_rate;
@@ -1283,7 +1285,7 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 	}
 
 	/* ... and new lines up to its end (and `ahead` lines past it) */
-	while(a->pos < end + (int64_t) a->ahead * a->width)
+	while(a->pos < end + (int64_t) a->ahead * a->ahead_w)
 	{
 		const int i = a->kept_at = (a->kept_at + 1) % KEPT_LINES;
 		a->kept_pos[i] = a->pos;
@@ -1330,7 +1332,7 @@ int hvk_audio_generate(hvk_audio_t *a, int64_t first, int64_t count,
 /* Run the chains on to stream position `end` (and the lines they keep ahead of it) without handing anything out */
 int hvk_audio_advance(hvk_audio_t *a, int64_t end)
 {
-	while(a->pos < end + (int64_t) a->ahead * a->width)
+	while(a->pos < end + (int64_t) a->ahead * a->ahead_w)
 	{
 		const int i = a->kept_at = (a->kept_at + 1) % KEPT_LINES;
 		a->kept_pos[i] = a->pos;

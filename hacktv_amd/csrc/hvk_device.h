@@ -79,6 +79,18 @@ __device__ __forceinline__ int pk_mad16(int a, int b, int c)
 template<int NT, int START>
 __device__ __forceinline__ void fir8(const int *d, const int *tp, int (&acc)[SPL])
 {
+	if(NT == 3)
+	{
+		/* "three taps" stands for NO filter (a colour mode without a chroma low pass: `ntsc-a`, src/video.c:3016 with
+		 * :3998): the window's middle element, scaled so that the callers' >> 15 hands it back as it is */
+#pragma unroll
+		for(int i = 0; i < SPL; i++)
+		{
+			const int e = START + i + 1;
+			acc[i] = (int) (((e & 1) ? (d[e / 2] >> 16) : (int) (short) (d[e / 2] & 0xFFFF)) * 32768);
+		}
+		return;
+	}
 	constexpr int NP = (NT + 1) / 2;
 	constexpr int NS = SPL / 2 + NP;   /* shifted pairs needed */
 	int sh[NS];

@@ -892,6 +892,7 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *
 	switch(a->k.colour && !a->k.secam ? a->k.chroma_ntaps : 1)
 	{
 	case 1:  return(_launch_prep<1>(a, g, npics, Lp, Cp, stream));
+	case 3:  return(_launch_prep<3>(a, g, npics, Lp, Cp, stream));    /* (no chroma low pass: fir8<3>) */
 	case 5:  return(_launch_prep<5>(a, g, npics, Lp, Cp, stream));
 	case 7:  return(_launch_prep<7>(a, g, npics, Lp, Cp, stream));
 	case 9:  return(_launch_prep<9>(a, g, npics, Lp, Cp, stream));

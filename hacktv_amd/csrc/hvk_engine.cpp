@@ -26,6 +26,10 @@
 #include <stdio.h>
 #include <vector>
 #include <algorithm>
+#include <deque>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "hvk_internal.h"
 #include "hvk_kernels.h"
 
@@ -101,7 +105,17 @@ struct hvk_engine {
 	int16_t *h_fm;              /* FM video: the batch's modulated samples (host) */
 	int64_t fm_batch_pos;       /* output position of the staged batch's first sample */
 	size_t fm_done;             /* samples of the batch modulated so far */
+	size_t fm_async_upto;       /*   ... of which these went through the FM thread into a caller's buffer (not into h_fm) */
 	int fm_launched;            /* the staged batch has been rendered and is not fully modulated yet */
+	/* FM video behind hvk_fetch_async(): the read-back goes straight into the caller's buffer and a thread of the engine's
+	 * runs the phasor over it there, job after job in stream order; hvk_fetch_wait() waits for the job */
+	struct fm_job_t { int ticket; int64_t pos, count; int16_t *iq; hipEvent_t ev; };
+	std::thread *fm_thread;
+	std::mutex *fm_mu;
+	std::condition_variable *fm_cv;
+	std::deque<fm_job_t> *fm_q;
+	int fm_quit;
+	int fm_status[4];           /* [HVK_FETCH_TICKETS] */
 	int fm_prime_pending;       /* FM video with the video filter: the phasor has yet to run over the pipeline's start-up samples */
 	int16_t *fm_prime_car;      /*   their sound carrier samples (out_prime int16 pairs) */
 	int device;             /* -1: host tables only */
@@ -204,6 +218,9 @@ struct hvk_engine {
 	double t_sum[2];
 	int64_t t_n[2];
 };
+
+static void _fm_worker(hvk_engine *e);
+
 
 /* ... after the serial chains have moved on for a batch: the failure leaves the stream out of step for good */
 #define HIPCHK_P(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
@@ -323,7 +340,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(e->t.k.colour)
 	{
 		const int nt = e->t.k.chroma_ntaps;
-		if(nt < 5 || nt > 25 || !(nt & 1))
+		if((nt < 5 || nt > 25 || !(nt & 1)) && !(nt == 3 && e->t.chroma_unfiltered))
 		{
 			fprintf(stderr, "libhvk: no raster kernel for a %d-tap chroma filter (pixel rate %d Hz)\n", nt, e->t.pixel_rate);
 			hvk_close(e);
@@ -861,6 +878,15 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(e->t.k.fm_video)
 	{
 		OPENHIP(hipHostMalloc((void **) &e->h_fm, (size_t) max_frames * FS * 4, hipHostMallocDefault));
+		/* (--passthru: the caller's thread fills the queue the phasor's pass reads -- no thread beside it then. HVK_FM_SYNC=1:
+		 * the pass in the caller's thread, as before) */
+		if(!e->t.k.has_passthru && !getenv("HVK_FM_SYNC"))
+		{
+			e->fm_mu = new std::mutex;
+			e->fm_cv = new std::condition_variable;
+			e->fm_q = new std::deque<hvk_engine::fm_job_t>;
+			e->fm_thread = new std::thread(_fm_worker, e);
+		}
 	}
 	else
 	{
@@ -885,6 +911,15 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 extern "C" void hvk_close(hvk_engine_t *e)
 {
 	if(!e) return;
+
+	if(e->fm_thread)
+	{
+		{ std::lock_guard<std::mutex> lk(*e->fm_mu); e->fm_quit = 1; }
+		e->fm_cv->notify_all();
+		e->fm_thread->join();
+		delete e->fm_thread; delete e->fm_q; delete e->fm_cv; delete e->fm_mu;
+		e->fm_thread = NULL;
+	}
 
 	if(e->device >= 0)
 	{
@@ -1253,7 +1288,15 @@ extern "C" int hvk_host_sis_bursts(hvk_engine_t *e, int64_t first_line, int nlin
 {
 	if(!e || !out || first_line < 0 || nlines < 0) return(HVK_ERROR);
 	if(!e->t.k.sis || !e->audio) return(HVK_UNSUPPORTED);
-	int r = hvk_audio_advance(e->audio, (first_line + nlines) * (int64_t) e->t.k.width);
+	/* (where line first_line + nlines begins in the stream: behind the resampler emitted line j is chunk j + s, hvk_tables_frame_start()) */
+	int64_t upto = (first_line + nlines) * (int64_t) e->t.k.width;
+	if(e->t.k.rs_L)
+	{
+		const hvk_kconst_t &k = e->t.k;
+		const int64_t s = 1 + (k.vf_type ? k.delay_lines : 0), g = first_line + nlines + s;
+		upto = (g * k.width * k.rs_L + k.rs_D - 1) / k.rs_D - (s * k.width * k.rs_L + k.rs_D - 1) / k.rs_D;
+	}
+	int r = hvk_audio_advance(e->audio, upto);
 	if(r != HVK_OK) return(r);
 	return(hvk_audio_sis_fetch(e->audio, first_line, nlines, out));
 }
@@ -1474,8 +1517,36 @@ extern "C" int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlin
 
 /* FM video: bring the host copy of the current batch up to `upto` samples -- fetch the
  * modulator's input from the device and run the serial tail over it (hvk_tail.c) */
+static void _fm_worker(hvk_engine *e)
+{
+	std::unique_lock<std::mutex> lk(*e->fm_mu);
+	(void) hipSetDevice(e->device);
+	for(;;)
+	{
+		e->fm_cv->wait(lk, [e] { return(e->fm_quit || !e->fm_q->empty()); });
+		if(e->fm_q->empty()) break;
+		const hvk_engine::fm_job_t j = e->fm_q->front();
+		lk.unlock();
+		int r = hipEventSynchronize(j.ev) == hipSuccess ? HVK_OK : HVK_ERROR;
+		if(r == HVK_OK) r = hvk_tail_fm_apply(e->tail, j.pos, j.count, j.iq);
+		lk.lock();
+		e->fm_status[j.ticket] = r;
+		e->fm_q->pop_front();           /* (behind the work: an empty queue means nothing is being worked on) */
+		e->fm_cv->notify_all();
+	}
+}
+
+/* every queued job through (what comes next works on the phasor itself) */
+static void _fm_wait_all(hvk_engine *e)
+{
+	if(!e->fm_thread) return;
+	std::unique_lock<std::mutex> lk(*e->fm_mu);
+	e->fm_cv->wait(lk, [e] { return(e->fm_q->empty()); });
+}
+
 static int _fm_upto(hvk_engine *e, size_t upto)
 {
+	_fm_wait_all(e);
 	if(upto <= e->fm_done) return(HVK_OK);
 	if(upto > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
 	const size_t n = upto - e->fm_done;
@@ -1850,11 +1921,14 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	{
 		/* the FM phasor is one serial chain over the stream (hvk_tail.c): finish the
 		 * previous batch, then take frames in order, no gaps */
+		/* (a batch whose samples have all been handed to the FM thread needs no finishing, and nothing here waits for the
+		 * thread: the next batch's host pre-passes run beside it) */
 		int r = _fm_finish(e);
 		if(r != HVK_OK) return(r);
-		if(stride != 1 || first_frame * FS != hvk_tail_fm_position(e->tail)) return(HVK_UNSUPPORTED);
+		if(stride != 1 || first_frame * FS != e->fm_batch_pos + (int64_t) e->fm_done) return(HVK_UNSUPPORTED);
 		e->fm_batch_pos = first_frame * FS;
 		e->fm_done = 0;
+		e->fm_async_upto = 0;
 	}
 
 	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
@@ -2465,6 +2539,8 @@ extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t coun
 	HIPCHK(hipSetDevice(e->device));
 	if(e->t.k.fm_video)
 	{
+		/* (what went out through hvk_fetch_async() was modulated in the caller's buffer: it is not here) */
+		if(first < e->fm_async_upto) return(HVK_ERROR);
 		int r = _fm_upto(e, first + count);
 		if(r != HVK_OK) return(r);
 		memcpy(iq, e->h_fm + first * 2, count * 4);
@@ -2486,9 +2562,28 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 	 * copies in flight would otherwise wait on the wrong one */
 	if(e->fetch_busy[t]) return(HVK_ERROR);
 	e->fetch_next = (e->fetch_next + 1) % HVK_FETCH_TICKETS;
+	if(e->t.k.fm_video && e->fm_thread && first == e->fm_done && e->fm_launched && count > 0)
+	{
+		/* the FM phasor runs on the host (see hvk_fetch()): the modulator's input goes into the caller's buffer, the
+		 * engine's FM thread turns it into the output there once the copy is through -- in stream order, behind the
+		 * jobs queued before. The caller's thread goes on */
+		HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
+		{
+			std::lock_guard<std::mutex> lk(*e->fm_mu);
+			e->fm_status[t] = HVK_OK;
+			e->fm_q->push_back({ t, e->fm_batch_pos + (int64_t) first, (int64_t) count, iq, e->fetch_ev[t] });
+		}
+		e->fm_cv->notify_all();
+		e->fm_done = first + count;
+		e->fm_async_upto = e->fm_done;
+		if(e->fm_done == (size_t) e->last_frames * e->t.k.frame_samples) e->fm_launched = 0;
+		e->fetch_busy[t] = 2;
+		return(t);
+	}
 	if(e->t.k.fm_video)
 	{
-		/* the FM phasor runs on the host, in this call (see hvk_fetch()) */
+		/* (out of order, or with --passthru, whose queue the caller's thread fills: in this call) */
 		int r = hvk_fetch(e, iq, first, count);
 		if(r != HVK_OK) return(r);
 	}
@@ -2503,6 +2598,14 @@ extern "C" int hvk_fetch_wait(hvk_engine_t *e, int ticket)
 	if(!e || ticket < 0 || ticket >= HVK_FETCH_TICKETS) return(HVK_ERROR);
 	if(e->device < 0) return(HVK_NO_DEVICE);
 	if(!e->fetch_busy[ticket]) return(HVK_ERROR);
+	if(e->fetch_busy[ticket] == 2)
+	{
+		/* a job of the FM thread's */
+		std::unique_lock<std::mutex> lk(*e->fm_mu);
+		e->fm_cv->wait(lk, [e, ticket] { for(const auto &j : *e->fm_q) if(j.ticket == ticket) return(false); return(true); });
+		e->fetch_busy[ticket] = 0;
+		return(e->fm_status[ticket]);
+	}
 	HIPCHK(hipEventSynchronize(e->fetch_ev[ticket]));
 	e->fetch_busy[ticket] = 0;
 	return(HVK_OK);

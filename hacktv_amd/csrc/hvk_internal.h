@@ -152,6 +152,7 @@ typedef struct {
 	hvk_c16_t *colour_lookup; int64_t colour_lookup_len;
 	int16_t *burst_win;
 	int16_t *chroma_taps;
+	int chroma_unfiltered;      /* a colour mode without a chroma low pass: chroma_ntaps = 3 stands for "no filter" (fir8<3>) */
 	int16_t ghost[HVK_GHOST_LEN];
 	int16_t *vf_itaps, *vf_qtaps;
 	/* audio */

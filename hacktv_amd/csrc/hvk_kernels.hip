@@ -812,6 +812,7 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 		if(a->k.secam) return(_launch_raster<1, 1, 1>(a, stream));
 		switch(a->k.colour ? a->k.chroma_ntaps : 1)
 		{
+		case 3:  return(_launch_raster<3, 0, 1>(a, stream));
 		case 5:  return(_launch_raster<5, 0, 1>(a, stream));
 		case 7:  return(_launch_raster<7, 0, 1>(a, stream));
 		case 9:  return(_launch_raster<9, 0, 1>(a, stream));
@@ -830,6 +831,7 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	switch(a->k.colour ? a->k.chroma_ntaps : 1)
 	{
 	case 1:  return(_launch_raster<1, 0, 0>(a, stream));   /* monochrome */
+	case 3:  return(_launch_raster<3, 0, 0>(a, stream));   /* (no chroma low pass: fir8<3>) */
 	case 5:  return(_launch_raster<5, 0, 0>(a, stream));
 	case 7:  return(_launch_raster<7, 0, 0>(a, stream));
 	case 9:  return(_launch_raster<9, 0, 0>(a, stream));

@@ -442,7 +442,7 @@ void hvk_tables_default_ghost(hvk_tables_t *t)
 	int i, o;
 
 	memset(t->ghost, 0, sizeof(t->ghost));
-	if(t->k.chroma_ntaps == 0 || t->burst_win == NULL) return;
+	if(t->k.chroma_ntaps == 0 || t->chroma_unfiltered || t->burst_win == NULL) return;
 
 	o = slack;
 	if(o + 4 > HVK_GHOST_LEN) return;
@@ -1301,6 +1301,10 @@ static int _build_sis(hvk_tables_t *t)
 	 * word, zeros before it). Line 1's own invocation blanks most of it away; the stream's first samples keep it.
 	 * The burst of those invocations is known: the frame store is still all zeros. */
 	t->k.sis_dummies = t->conf.colour_mode == HVK_SECAM ? 3 : 1;
+	/* (--raw-bb-file: the process that reads the lines in works on ONE line, not on the raster's three, and this one
+	 * shares its slot: src/video.c:4190 with :4676-4688 -- no slot in front of line 1, nothing left on it) */
+	if(t->conf.raw_bb) t->k.sis_dummies = 0;
+	if(t->k.sis_dummies > 0)
 	{
 		static const uint8_t gc[2][4] = { { 3, 0, 2, 1 }, { 0, 3, 1, 2 } };
 		int re = 0, nb = 50, call;
@@ -1504,6 +1508,16 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			free(taps);
 			if(!t->chroma_taps) return(HVK_OUT_OF_MEMORY);
 			if(t->k.chroma_ntaps / 2 * 2 > HVK_GHOST_LEN) return(HVK_UNSUPPORTED);
+		}
+		else
+		{
+			/* no chroma low pass (`ntsc-a`): the kernels' filter stage with "three taps", which stands for handing the
+			 * window's middle element on as it is (fir8<3>, hvk_device.h); nothing is read past the line's end */
+			t->k.chroma_ntaps = 3;
+			t->chroma_taps = calloc(4, sizeof(int16_t));
+			if(!t->chroma_taps) return(HVK_OUT_OF_MEMORY);
+			t->chroma_taps[1] = INT16_MAX;
+			t->chroma_unfiltered = 1;
 		}
 	}
 
@@ -1779,9 +1793,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->k.vbi = t->vbi_nsym > 0 || c->acp;
 	if(c->sis)
 	{
-		/* (the burst is laid out in pixels of the raster; behind the resampler the audio process's lines vary in width,
-		 * which the block hand-over's timing goes by: not combined. Nor with a raster that is not built from pictures) */
-		if(c->sis != 1 || t->k.rs_L || c->raw_bb || c->s_video) return(HVK_UNSUPPORTED);
+		/* (the burst is laid out in pixels of the raster and drawn there -- in front of the resampler, beside --s-video's second
+		 * channel, over a line that came from --raw-bb-file all the same; the hand-over of the sound blocks goes by the
+		 * pipeline's steps, whatever the width of the audio process's lines) */
+		if(c->sis != 1) return(HVK_UNSUPPORTED);
 		if((r = _build_sis(t)) != HVK_OK) return(r);
 	}
 

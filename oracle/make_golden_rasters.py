@@ -35,6 +35,7 @@ CASES = [
     ("405i_full",    "405-i",         16200000, ["--filter"], F, False, 2),
     ("405_bb",       "405",            8100000, [],           0, True,  2),
     ("ntsc405_bb",   "ntsc-405",       8100000, [],           0, True,  2),   # NTSC colour on 405 lines
+    ("ntsca_full",   "ntsc-a",         8100000, ["--filter"], F, False, 3),   # ... with VSB and sound, and NO chroma low pass (the preset sets none)
     ("240am",        "240-am",         4800000, [],           0, False, 2),   # Baird 240: the broad pulse at mid-line runs on into the next line
     ("240_bb",       "240",            4800000, [],           0, True,  3),
     ("30_bb",        "30",              750000, [],           0, True,  3),   # Baird 30 lines: no sync, scanned vertically

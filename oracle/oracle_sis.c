@@ -141,7 +141,9 @@ void orc_sis_free(orc_t *s)
 static int _block_seen(orc_t *s, long call, int16_t out[64])
 {
 	const int visible = s->sis_visible;
-	const long long reach = (long long) (call - 1) * s->width + visible;   /* samples [0, reach) are behind the audio thread */
+	/* samples [0, reach) are behind the audio thread: call - 1 of its lines -- behind the resampler those are the resampler's
+	 * chunks, chunk g beginning at ceil(g width L / D) (src/video.c:3627-3651) */
+	const long long reach = (s->rs_taps ? ((long long) (call - 1) * s->width * s->rs_L + s->rs_D - 1) / s->rs_D : (long long) (call - 1) * s->width) + visible;
 	long long j, n;
 	int i;
 

@@ -334,7 +334,13 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 
 		/* sound-in-syncs: behind CC608, in front of teletext (src/video.c:4330-4338); its first invocation works on the
 		 * never-emitted slot in front of line 1 */
-		if(s->conf.sis)
+		if(s->conf.sis && s->conf.raw_bb)
+		{
+			/* the process that reads the lines in works on one line and this one shares its slot (src/video.c:4190 with
+			 * :4676-4688): the line just read, no slot in front of line 1 */
+			orc_sis_line(s, s->rastered - 1, 0);
+		}
+		else if(s->conf.sis)
 		{
 			if(s->rastered == 1)
 			{

@@ -65,7 +65,6 @@ def test_unsupported_configurations_are_refused():
     c = H.preset("i"); c.fm_mono_preemph = 3; bad.append((c, 16000000))       # J.17 FM pre-emphasis
     c = H.preset("i"); c.type = 2; bad.append((c, 16000000))                  # a raster type whose number of lines the configuration does not have
     c = H.preset("i"); c.type = 8; bad.append((c, 16000000))                  # not a raster (the reference's VID_MAC)
-    bad.append((H.preset("ntsc-a"), 8100000))                                 # colour without a chroma low pass: no kernel for it
     for conf, sr in bad:
         try:
             H.Engine(conf, sr, device=-1)

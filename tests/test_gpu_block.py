@@ -186,6 +186,53 @@ def test_queued_read_back_into_page_locked_memory(golden):
     assert e.h is None
 
 
+@pytest.mark.parametrize("case,sync", [("pal_fm", False), ("palfm_f14", False), ("pal_fm", True)])
+def test_fm_video_read_back_through_the_engines_fm_thread(golden, monkeypatch, case, sync):
+    """FM video: the phasor is a host pass over every sample (hvk_tail.c). Behind hvk_fetch_async() the engine's own
+    thread runs it in the caller's buffer, job after job, while the caller stages the next batch (HVK_FM_SYNC=1: in the
+    call, as before): batches of three and two frames, whole and in two pieces, against the reference CLI's digests
+    and hvk_fetch()."""
+    if sync:
+        monkeypatch.setenv("HVK_FM_SYNC", "1")
+    c = golden.cases[case]
+    conf, sr = golden.conf(case)
+    FS = c["width"] * c["lines"]
+    nframes = 8                                  # (the digests hold the first two or three; hvk_fetch() all of them)
+    with H.Engine(conf, sr, max_frames=3) as e, H.Engine(conf, sr, max_frames=3) as plain:
+        bufs = [e.host_buffer(3 * FS), e.host_buffer(3 * FS)]
+        for eng in (e, plain):
+            eng.frame_upload(0, golden.frame(case))
+        got, want, pending, done = [], [], [], 0
+        b = 0
+        while done < nframes:
+            n = min(3 if b % 2 == 0 else 2, nframes - done)
+            for eng in (e, plain):
+                while eng.audio_needed(n) > 0:
+                    eng.audio_write(golden.audio)
+            e.stage(done, 1, n)                  # (nothing here waits for the FM thread's work on the batch before)
+            for t_, buf_, cnt_ in pending:
+                e.fetch_wait(t_)
+            got += [buf_[:cnt_].copy() for _, buf_, cnt_ in pending]
+            e.launch()
+            buf = bufs[b & 1]
+            if b % 2 == 0:
+                pending = [(e.fetch_async(buf, 0, n * FS), buf, n * FS)]
+            else:
+                half = (n * FS) // 2 + 7
+                pending = [(e.fetch_async(buf, 0, half), buf, half), (e.fetch_async(buf[half:], half, n * FS - half), buf[half:], n * FS - half)]
+            plain.render(n)
+            want.append(plain.fetch(0, n * FS))
+            done += n
+            b += 1
+        for t_, buf_, cnt_ in pending:
+            e.fetch_wait(t_)
+        got += [buf_[:cnt_].copy() for _, buf_, cnt_ in pending]
+        got, want = np.concatenate(got), np.concatenate(want)
+        assert np.array_equal(got, want)
+        for n in range(c["frames"]):
+            assert util.sha256(util.stream_bytes(got[: (n + 1) * FS], c["real"])) == c["sha256_cumulative"][n], "frame %d" % (n + 1)
+
+
 @pytest.mark.parametrize("flags", [["-m", "i", "-s", "16000000", "--filter"],
                                    ["-m", "l", "-s", "16000000", "--filter", "--vits", "--vitc"]])
 def test_dropin_resident_set_does_not_grow_with_the_run(flags):

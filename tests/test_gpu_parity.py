@@ -64,10 +64,11 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
+                                  "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025",
                                   "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
                                   "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
                                   # the rasters other than 625 / 525 lines, field-sequential colour (oracle/make_golden_rasters.py)
-                                  "e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
+                                  "e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
                                   "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
@@ -113,7 +114,8 @@ def test_filter_without_the_matrix_unit(golden, case, monkeypatch):
 @pytest.mark.parametrize("case", ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_full", "i_mono", "g_full", "m_full", "ntsc_bb",
                                   "pal_bb_filter", "i_20m", "i_offset", "m_offset_pass", "g_a2", "m_a2", "i_27m", "d_full", "palm_full",
                                   "pal60_bb", "l_full", "secam_bb", "secami_full", "l_raster", "pal_9m", "i_24m", "m_4fsc",
-                                  "i_tt", "l_tt", "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "i_acp_cc", "m_acp_cc", "i_wss_auto", "l_fid", "secam_fid4"])
+                                  "i_tt", "l_tt", "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "i_acp_cc", "m_acp_cc", "i_wss_auto", "l_fid", "secam_fid4",
+                                  "ntsca_full", "ntsc405_bb"])
 def test_kernel_pair_equals_reference_digests(golden, case, monkeypatch):
     """The plain configurations render in one kernel from picture planes (hvk_direct.hip) by default -- that is what
     the digest tests above run. HVK_DIRECT=0 keeps the raster + filter kernel pair for them: same digests."""

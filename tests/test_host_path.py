@@ -298,7 +298,7 @@ def test_passthru_needs_whole_lines_and_stays_ended(golden):
     assert np.array_equal(a[:W], ref[:W] + 1) and np.array_equal(a[W:], ref[W:3 * W]) and np.array_equal(b, ref[3 * W:])
 
 
-@pytest.mark.parametrize("case", ["i_sis", "i_sis_filter", "l_sis_tt"])
+@pytest.mark.parametrize("case", ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025"])
 @pytest.mark.parametrize("loud", [False, True])
 def test_sound_in_syncs_bursts_equal_the_oracles(golden, case, loud):
     """--sis: the bits of every line's burst (hvk_host_sis_bursts(): the host half, framing in step with the sound chains)
@@ -306,21 +306,26 @@ def test_sound_in_syncs_bursts_equal_the_oracles(golden, case, loud):
     (test_oracle_golden.py) -- on the test tone, and on full-scale noise, whose 32-sample blocks all differ: which block
     a NICAM frame carries then shows in every frame (the oracle's and the engine's reading of the reference's unlocked
     hand-over: the newest block of an earlier pipeline step). PAL-I: one never-emitted invocation in front of line 1;
-    SECAM-L: three, and the chains run two lines ahead of the requests."""
+    SECAM-L: three, and the chains run two lines ahead of the requests; --raw-bb-file: none (the process that reads the
+    lines in has one line, not the raster's three); behind the resampler the audio process's lines are the resampler's
+    chunks, of two widths."""
     conf, sr = golden.conf(case)
     audio = golden.audio
     if loud:
         audio = np.random.default_rng(5).integers(-32768, 32768, (len(golden.audio), 2)).astype(np.int16)
     n = 625 * 2 + 100
-    with oracle.Oracle(conf, sr) as o:
+    pr = golden.cases[case].get("pixel_rate", 0)
+    with oracle.Oracle(conf, sr, pr) as o:
         o.set_frame(golden.frame(case))
         o.set_audio(audio, True)
+        if conf.raw_bb:
+            o.set_rawbb(util.rawbb_signal())
         if golden.cases[case].get("teletext"):
             for f in range(4):
                 o.teletext_packets(f, *golden.teletext_rows(f))
         o.render_lines(n)
         want = o.sis_bursts(0, n)
-    with H.Engine(conf, sr, device=-1) as e:
+    with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e:
         for _ in range(3):
             e.audio_write(audio)
         got = np.concatenate([e.host_sis_bursts(0, 700), e.host_sis_bursts(700, 1), e.host_sis_bursts(701, n - 701)])
