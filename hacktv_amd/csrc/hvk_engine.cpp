@@ -1679,7 +1679,9 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			srows[i] = (slot * 6 + ph6) * a.ntasks;
 			if(!e->slots[slot].seeds_valid[ph6]) fresh = 1;
 			e->slots[slot].seeds_valid[ph6] = 1;
-			if(!fresh && !e->secam_last_new) kf[i] = a.K;
+			/* (while that number is still three or more the estimate is the cheaper start: a fifth of a walk instead of
+			 * three and more; the kept states take over below that) */
+			if(!fresh && !e->secam_last_new) kf[i] = (e->secam_est && a.K >= 3) ? -1 : a.K;
 			e->secam_last_new = fresh;
 		}
 		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));

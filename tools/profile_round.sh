@@ -27,8 +27,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
 	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --settle 0 --no-cpu-baseline --no-moving --no-configs > "$OUT/pmc$i.log" 2>&1
 	echo "pmc pass $i ($set): exit $?"
 done
-# 5. the SECAM colour chain (hvk_secam.hip): blocks of 512 frames of the test card, and of noisy pictures with the cells made per frame
-for kind in card noisy; do
+# 5. the SECAM colour chain (hvk_secam.hip): blocks of 512 frames of the test card, of noisy pictures with the cells made per frame, and of
+#    as many new pictures (planes made per frame as well)
+for kind in card noisy new; do
 	timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/secam_$kind" -o p -- python $OLDPWD/tools/secam_blocks.py 512 $kind 8 > "$OUT/secam_$kind.log" 2>&1
 	tail -1 "$OUT/secam_$kind.log"
 	f=$(find "$OUT/secam_$kind" -name '*kernel_stats.csv' | head -1)
@@ -41,3 +42,5 @@ f=$(find "$OUT/moving" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/${TAG}_moving_kernel_stats.csv"
 cd "$OLDPWD"
 python tools/pmc_summary.py "$OUT" "$TAG"
+# 7. FM video through the drop-in binary: the phasor pass in the caller's thread (HVK_FM_SYNC=1) and on the engine's
+bash tools/fm_dropin_speed.sh > "$OUT/${TAG}_fm_dropin.txt" 2>&1; cat "$OUT/${TAG}_fm_dropin.txt" | grep -v worker
