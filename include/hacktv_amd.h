@@ -352,7 +352,11 @@ int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
  * turn; negative: an HVK_* code); iq may be read once hvk_fetch_wait() has returned for that ticket. With iq in page-locked
  * memory (hvk_host_alloc()) the copy runs at PCIe speed beside the host pre-passes of the next hvk_stage() -- how the
  * shim keeps the reference's serial sound chain (src/video.c:2249-2289, the slowest stage of the drop-in) busy all the
- * time. hvk_fetch_wait() may be called from another thread than the one that renders. */
+ * time. hvk_fetch_wait() may be called from another thread than the one that renders.
+ * FM video: the ticket stands for a job of the engine's own FM thread -- the modulator's input is copied into iq and the
+ * serial phasor pass runs over it there, job after job in stream order, beside the caller's next hvk_stage(); a request
+ * that does not continue where the last one ended, a configuration with --passthru (whose queue the caller's thread
+ * fills) and HVK_FM_SYNC=1 keep the pass inside this call. What went out this way is not handed out again by hvk_fetch(). */
 int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_t count);
 int hvk_fetch_wait(hvk_engine_t *e, int ticket);
 
