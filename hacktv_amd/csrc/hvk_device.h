@@ -118,13 +118,41 @@ __device__ __forceinline__ void fir8(const int *d, const int *tp, int (&acc)[SPL
  * contraction. Used to expand the 2^24-entry table once per engine and, when the pictures have too
  * many colours for the table's cache lines to be found again (moving video), per pixel. */
 /* SEC: -1 the mode's kind (SECAM or not) is read from the parameters, 0 / 1: known when the kernel is compiled */
-template<int SEC = -1>
-__device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p)
+/* FAST: 0 the reference's sequence of operations; 2 the short form (hvk_yuvparams_t.fast); 1 the short form for the two
+ * colour-difference levels only, the luma the reference's way (modes whose luma constants make exact ties of many colours:
+ * SECAM-L) -- which of them a mode may use is found by trying all 2^24 colours (hvk_engine.cpp) */
+/* level_from(): from the three gamma values (a caller that keeps the 256 of them in LDS reads them there itself) */
+template<int SEC = -1, int FAST = 0>
+__device__ __forceinline__ short4v level_from(const double r, const double g, const double b, const hvk_yuvparams_t &p)
 {
-	double r = p.glut[(c & 0xFF0000) >> 16];
-	double g = p.glut[(c & 0x00FF00) >> 8];
-	double b = p.glut[(c & 0x0000FF) >> 0];
 	double y, u, v;
+
+	if(FAST)
+	{
+		const double M = 6755399441055744.0;       /* 1.5 * 2^52: the sum's low dword is the addend rounded to nearest */
+		int iy;
+		if(FAST == 2)
+		{
+			y = __builtin_fma(b, p.bw, __builtin_fma(g, p.gw, r * p.rw));
+			iy = __double2loint(__builtin_fma(y, p.f_y1, p.f_y0) + M);
+			iy = iy < -32767 ? -32767 : (iy > 32767 ? 32767 : iy);
+		}
+		else
+		{
+			y = r * p.rw + g * p.gw + b * p.bw;
+			double yl = (p.black + (y * p.range)) * p.level;
+			yl = fmin(fmax(yl, -1.0), 1.0);
+			iy = (int) (short) round(yl * 32767);
+		}
+		const int iu = __double2loint(__builtin_fma(b - y, p.f_u1, p.f_u0) + M);
+		const int iv = __double2loint(__builtin_fma(r - y, p.f_v1, p.f_v0) + M);
+		short4v o;
+		o.x = (short) iy;
+		o.y = (short) (iu < -32767 ? -32767 : (iu > 32767 ? 32767 : iu));
+		o.z = (short) (iv < -32767 ? -32767 : (iv > 32767 ? 32767 : iv));
+		o.w = 0;
+		return(o);
+	}
 
 	y = r * p.rw + g * p.gw + b * p.bw;
 	u = (b - y) * p.eu;
@@ -155,6 +183,12 @@ __device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p
 	o.z = (short) round(v * 32767);
 	o.w = 0;
 	return(o);
+}
+
+template<int SEC = -1, int FAST = 0>
+__device__ __forceinline__ short4v level_of(unsigned c, const hvk_yuvparams_t &p)
+{
+	return(level_from<SEC, FAST>(p.glut[(c & 0xFF0000) >> 16], p.glut[(c & 0x00FF00) >> 8], p.glut[(c & 0x0000FF) >> 0], p));
 }
 
 /* ------------------------------------------------------------------ */

@@ -186,6 +186,13 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	const int rel = (int) blockIdx.x;
 	const int pic = (int) blockIdx.y;
 
+	/* computed levels: the 256 gamma values into LDS (a pixel reads three of them, every lane another) */
+	__shared__ double s_glut[LV ? 256 : 1];
+	if(LV)
+	{
+		for(int i = t; i < 256; i += (int) blockDim.x) s_glut[i] = P.yuvp->glut[i];
+	}
+
 	const hvk_framedesc_t f = prep_fdesc(k, geo, pic);
 	hvk_linedesc_t d = P.desc[__builtin_amdgcn_readfirstlane(rel)];
 	{
@@ -195,6 +202,7 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	}
 	const hvk_line_t L = raster_setup_core<0, 0>(k, P, f, d, pic, rel, rel, true, false);
 	const bool pal = NT > 1 && L.pal != 0;
+	if(LV) __syncthreads();
 
 	const int CL = raster_CL(W);
 	int16_t *U = lds, *V = lds + CL;
@@ -226,8 +234,10 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<SC ? 1 : 0>(px[i] & 0xFFFFFFu, *P.yuvp));
+			if(LV) lv[i] = __builtin_bit_cast(int2v, level_from<SC ? 1 : 0, LV ? LV - 1 : 0>(s_glut[(px[i] >> 16) & 0xFF], s_glut[(px[i] >> 8) & 0xFF], s_glut[px[i] & 0xFF], *P.yuvp));
 			else lv[i] = ((const int2v *) P.yuv)[px[i] & 0xFFFFFFu];
+			/* (computed levels four pixels at a time: twelve doubles in flight instead of twenty-four, a wave more per SIMD) */
+			if(LV && i == SPL / 2 - 1) __builtin_amdgcn_sched_barrier(0);
 		}
 #pragma unroll
 		for(int m = 0; m < SPL / 2; m++)
@@ -872,14 +882,17 @@ static int _launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int 
 	/* (HVK_PREP=1: the one-pixel-per-lane-and-pass kernel built from the raster's stages, kept as the second opinion) */
 	static const int old_prep = getenv("HVK_PREP") ? atoi(getenv("HVK_PREP")) : 0;
 	if(NT == 1 && a->k.secam && (old_prep == 1 || a->k.width % SPL != 0)) { if(a->levels_computed) PREP(0, 1, (NT == 1 ? 1 : 0)); else PREP(0, 0, (NT == 1 ? 1 : 0)); }
-	else if(NT == 1 && a->k.secam) { if(a->levels_computed) PREP8S(1); else PREP8S(0); }
+	else if(NT == 1 && a->k.secam) { switch(a->levels_computed) { case 0: PREP8S(0); break; case 2: PREP8S(2); break; case 3: PREP8S(3); break; default: PREP8S(1); } }
 	else if(old_prep == 1)
 	{
 		if(NT == 13 && W == 1024) { if(a->levels_computed) PREP((NT == 13 ? 1024 : 0), 1, 0); else PREP((NT == 13 ? 1024 : 0), 0, 0); }
 		else { if(a->levels_computed) PREP(0, 1, 0); else PREP(0, 0, 0); }
 	}
-	else if(NT == 13 && W == 1024) { if(a->levels_computed) PREP8((NT == 13 ? 1024 : 0), 1); else PREP8((NT == 13 ? 1024 : 0), 0); }
-	else { if(a->levels_computed) PREP8(0, 1); else PREP8(0, 0); }
+	else if(NT == 13 && W == 1024)
+	{
+		switch(a->levels_computed) { case 0: PREP8((NT == 13 ? 1024 : 0), 0); break; case 2: PREP8((NT == 13 ? 1024 : 0), 2); break; case 3: PREP8((NT == 13 ? 1024 : 0), 3); break; default: PREP8((NT == 13 ? 1024 : 0), 1); }
+	}
+	else { switch(a->levels_computed) { case 0: PREP8(0, 0); break; case 2: PREP8(0, 2); break; case 3: PREP8(0, 3); break; default: PREP8(0, 1); } }
 #undef PREP8S
 #undef PREP8
 #undef PREP

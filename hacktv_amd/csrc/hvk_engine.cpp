@@ -437,6 +437,25 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	OPENHIP(hipMalloc(&e->d_yuv, 0x1000000UL * 8));
 	OPENCHK(hvk_launch_expand_yuv(e->d_yuv, e->d_yuvparams, e->stream));
+	if(!getenv("HVK_EXACT_LEVELS"))
+	{
+		/* Levels computed per pixel (pictures with many colours): the short form of the arithmetic, IF it gives the table's
+		 * levels for every one of the 2^24 colours of this mode -- tried here, once; otherwise the reference's sequence of
+		 * operations stays (hvk_yuvparams_t.fast) */
+		void *d_n = NULL;
+		OPENHIP(hipMalloc(&d_n, sizeof(int)));
+		for(int fast = 2; fast >= 1 && !e->t.yuv.fast; fast--)
+		{
+			int differ = -1;
+			OPENHIP(hipMemsetAsync(d_n, 0, sizeof(int), e->stream));
+			OPENCHK(hvk_launch_check_levels(e->d_yuv, e->d_yuvparams, fast, (int *) d_n, e->stream));
+			OPENHIP(hipMemcpyAsync(&differ, d_n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+			OPENHIP(hipStreamSynchronize(e->stream));
+			if(differ == 0) e->t.yuv.fast = fast;
+			else if(getenv("HVK_SHIM_STATS")) fprintf(stderr, "libhvk: level arithmetic, short form %d, differs on %d colours of this mode\n", fast, differ);
+		}
+		(void) hipFree(d_n);
+	}
 
 	/* One kernel from picture planes (hvk_direct.hip) for the plain configurations; HVK_DIRECT=0 keeps the raster +
 	 * filter kernel pair (the parity tests run both). The planes do not depend on a frame's parity: the two
@@ -1335,6 +1354,11 @@ extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
 	return(HVK_OK);
 }
 
+extern "C" int hvk_levels_short_form(const hvk_engine_t *e)
+{
+	return(e && e->device >= 0 ? e->t.yuv.fast : 0);
+}
+
 extern "C" int64_t hvk_secam_estimated_stages(const hvk_engine_t *e)
 {
 	return(e && e->secam_dev ? e->secam_est_stages : 0);
@@ -1811,7 +1835,7 @@ static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t s
 		}
 		g.slot0 = todo[i];
 		g.frame_px = (int64_t) k.active_width * k.active_lines;
-		ra.levels_computed = lv;
+		ra.levels_computed = lv ? 1 + e->t.yuv.fast : 0;      /* (the plane kernels know the short forms) */
 		const int r = hvk_launch_prep(&ra, &g, (int) (j - i), e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : (e->d_UVp ? e->d_UVp + 16 : NULL), stream);
 		if(r != HVK_OK) return(r);
 		e->prep_count += (int64_t) (j - i);
@@ -2392,8 +2416,10 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		}
 		/* (levels by arithmetic -- pictures of many colours -- cost the one kernel more waves per SIMD than they are worth: 128 registers
 		 * a lane against 76; such blocks go through the planes, whose hvk_k_prep8 holds the arithmetic alone: measured, profiles/README.md) */
-		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || (2 * ndirty >= e->staged && !e->levels_computed)))
+		const bool fused_lv = e->levels_computed && e->t.yuv.fast == 2 && getenv("HVK_FUSED_LV") != NULL;
+		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || (2 * ndirty >= e->staged && (!e->levels_computed || fused_lv))))
 		{
+			ra.levels_computed = e->levels_computed ? (e->t.yuv.fast == 2 ? 3 : 1) : 0;
 			/* most of the block's pictures are new: from the pixels in one kernel (hvk_fused.hip), their planes are not made
 			 * (and stay marked: a later block that shows one of them again makes them then) */
 			da.D.fdesc = e->d_fdesc;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void fused_part1(const hvk_kconst_t &k, const hvk_rpt
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<0>(px[i] & 0xFFFFFFu, *P.yuvp));
+			if(LV) lv[i] = __builtin_bit_cast(int2v, level_of<0, LV == 3 ? 2 : 0>(px[i] & 0xFFFFFFu, *P.yuvp));
 			else lv[i] = ((const int2v *) P.yuv)[px[i] & 0xFFFFFFu];
 		}
 #pragma unroll
@@ -213,11 +213,14 @@ __device__ __forceinline__ fsel_t fused_select(const hvk_kconst_t &k, const hvk_
 	return(q);
 }
 
+#ifndef FUSED_WAVES_LV3
+#define FUSED_WAVES_LV3 5            /* ... the kernel with the short form of the level arithmetic (LV = 3) */
+#endif
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 7                /* waves per SIMD the table-levels kernel is compiled for: three workgroups of nine waves per compute unit */
 #endif
 template<int NT, int LV>
-__global__ __launch_bounds__(FTL * FG + 64, LV ? 4 : FUSED_WAVES)
+__global__ __launch_bounds__(FTL * FG + 64, LV == 1 ? 4 : (LV == 3 ? FUSED_WAVES_LV3 : FUSED_WAVES))
 void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_rptrs_t P,
                  const int *__restrict__ d_clut3, const int d_creg,
                  const hvk_framedesc_t *__restrict__ d_fdesc, const uint32_t *__restrict__ d_lineoff,
@@ -387,7 +390,7 @@ extern "C" int hvk_launch_fused(const hvk_raster_args_t *ra, const hvk_direct_ar
 	hvk_raster_ptrs(ra, &P);
 #define FUSED(LVV) hipLaunchKernelGGL((hvk_k_fused<13, LVV>), grid, block, 0, stream, a->k, ra->ctaps, P, a->D.clut3, a->D.creg, a->D.fdesc, a->D.lineoff, \
 	(const int *) a->carriers, a->tilesyms, a->nicam_tapd, a->nicam_cca, (const int4v *) mfma_a28, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
-	if(ra->levels_computed) FUSED(1); else FUSED(0);
+	if(ra->levels_computed >= 3) FUSED(3); else if(ra->levels_computed) FUSED(1); else FUSED(0);
 #undef FUSED
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }

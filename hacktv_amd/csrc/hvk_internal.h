@@ -53,7 +53,13 @@ typedef struct {
 	double level;
 	double chroma_scale;    /* (white - black) * level */
 	int32_t secam;
-	int32_t pad;
+	/* fast != 0: the short form of the arithmetic below -- Y = f_y0 + y f_y1, U = f_u0 + (b - y) f_u1, V = f_v0 + (r - y) f_v1,
+	 * fused multiply-adds, the scale by 32767 folded in, rounding by the add of 1.5 * 2^52, limits applied to the integers --
+	 * which differs from the reference's sequence of operations only in the last bits of the doubles. Whether that ever
+	 * moves a LEVEL is not argued but tried: the engine sets the flag only after a kernel has computed all 2^24 colours this
+	 * way and found every one equal to the table made the reference's way (hvk_k_check_levels, hvk_engine.cpp) */
+	int32_t fast;
+	double f_y0, f_y1, f_u0, f_u1, f_v0, f_v1;
 } hvk_yuvparams_t;
 
 /* Kernel-visible engine constants */

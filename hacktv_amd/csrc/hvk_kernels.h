@@ -37,7 +37,8 @@ typedef struct {
 	const int16_t *linebase;    /* [nbase][k.base_stride] */
 	const void *yuv;            /* 2^24 x int16x4 */
 	const void *yuvparams;      /* hvk_yuvparams_t on the device */
-	int levels_computed;        /* this block's pictures have many colours: compute the levels, do not look them up */
+	int levels_computed;        /* this block's pictures have many colours: compute the levels, do not look them up (the plane kernels: 1 the
+	                             * reference's sequence of operations, 2 / 3 the forms hvk_yuvparams_t.fast = 1 / 2 name) */
 	const hvk_c16_t *clut;
 	const int16_t *burst_win;
 	const int16_t *ghost;
@@ -192,6 +193,7 @@ int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
+int hvk_launch_check_levels(const void *lut, const void *params, int fast, int *differ, hipStream_t stream);
 int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream);
 int hvk_launch_filter(const hvk_filter_args_t *a, hipStream_t stream);
 /* picture planes of the pictures in slots slot0 .. slot0 + npics - 1, all of one geometry: a kernel argument, nothing is

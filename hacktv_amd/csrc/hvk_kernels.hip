@@ -66,6 +66,16 @@ __global__ void hvk_k_expand_yuv(short4v *lut, const hvk_yuvparams_t *pp)
 	lut[c] = level_of(c, *pp);
 }
 
+/* every colour's levels by the arithmetic `pp` says (the short form) against the table: how many differ */
+template<int FAST>
+__global__ void hvk_k_check_levels(const short4v *lut, const hvk_yuvparams_t *pp, int *differ)
+{
+	unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+	if(c > 0xFFFFFFu) return;
+	const short4v a = level_of<-1, FAST>(c, *pp), b = lut[c];
+	if(a.x != b.x || a.y != b.y || a.z != b.z) atomicAdd(differ, 1);
+}
+
 /* ------------------------------------------------------------------ */
 
 /* One workgroup per scanline of the slab (hvk_device.h has the steps): the samples go to the raster
@@ -734,6 +744,13 @@ extern "C" int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t 
 {
 	hipLaunchKernelGGL(hvk_k_expand_yuv, dim3(0x1000000 / 256), dim3(256), 0, stream,
 	                   (short4v *) lut, (const hvk_yuvparams_t *) params);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_check_levels(const void *lut, const void *params, int fast, int *differ, hipStream_t stream)
+{
+	if(fast == 2) hipLaunchKernelGGL(hvk_k_check_levels<2>, dim3(0x1000000 / 256), dim3(256), 0, stream, (const short4v *) lut, (const hvk_yuvparams_t *) params, differ);
+	else hipLaunchKernelGGL(hvk_k_check_levels<1>, dim3(0x1000000 / 256), dim3(256), 0, stream, (const short4v *) lut, (const hvk_yuvparams_t *) params, differ);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

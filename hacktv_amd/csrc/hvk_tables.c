@@ -1463,6 +1463,19 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->yuv.level = level;
 	t->yuv.chroma_scale = (c->white_level - c->black_level) * level;
 	t->yuv.secam = c->colour_mode == HVK_SECAM;
+	t->yuv.fast = 0;        /* (the engine's to set, once it has checked every colour: hvk_yuvparams_t) */
+	t->yuv.f_y0 = c->black_level * level * 32767.0;
+	t->yuv.f_y1 = (c->white_level - c->black_level) * level * 32767.0;
+	if(t->yuv.secam)
+	{
+		t->yuv.f_u0 = (4250000.0 - 4328125.0) / 1000000.0 * 32767.0; t->yuv.f_u1 = c->eu_co / 1000000.0 * 32767.0;
+		t->yuv.f_v0 = (4406250.0 - 4328125.0) / 1000000.0 * 32767.0; t->yuv.f_v1 = c->ev_co / 1000000.0 * 32767.0;
+	}
+	else
+	{
+		t->yuv.f_u0 = 0; t->yuv.f_u1 = c->eu_co * t->yuv.chroma_scale * 32767.0;
+		t->yuv.f_v0 = 0; t->yuv.f_v1 = c->ev_co * t->yuv.chroma_scale * 32767.0;
+	}
 	{
 		/* luma of black, used wherever the picture does not cover the active area */
 		double y = (c->black_level + (0.0 * (c->white_level - c->black_level))) * level;

@@ -26,7 +26,7 @@ SYMBOLS = [
     "hvk_timing_enable", "hvk_timing_read", "hvk_kernel_names", "hvk_table", "hvk_fetch_raster", "hvk_version",
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
-    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages",
+    "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages", "hvk_levels_short_form",
 ]
 
 _lib = None
@@ -297,6 +297,10 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
         return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
+
+    def levels_short_form(self):
+        """1: computed levels use the short arithmetic, checked at open on all 2^24 colours (hvk_levels_short_form)."""
+        return int(lib().hvk_levels_short_form(self.h))
 
     def secam_estimated_stages(self):
         """Stages whose new pictures' lines started from estimated states (hvk_k_secam_est) instead of warm-up walks."""

@@ -315,6 +315,12 @@ int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4]);
  * is the same either way. */
 int64_t hvk_secam_estimated_stages(const hvk_engine_t *e);
 
+/* Levels computed per pixel (hvk_set_levels(): pictures with many colours) take the short form of the arithmetic -- fused
+ * multiply-adds, the scale folded into the constants, rounding by a magic addend -- where hvk_open() has TRIED it on every one
+ * of the 2^24 colours of the mode and found the table's levels (src/video.c:3912-3958) each time: 1. Otherwise, and with
+ * HVK_EXACT_LEVELS=1, the reference's sequence of operations: 0. */
+int hvk_levels_short_form(const hvk_engine_t *e);
+
 /* SECAM: the number of lines a lane walks in front of a line to derive its entry state, as it stands. It follows the
  * pictures (one less after a block without a wrong start, two more after one with; HVK_SECAM_WARMUP=n in the
  * environment pins it) and decides only how much is redone, never what comes out. < 0: an HVK_* code. */

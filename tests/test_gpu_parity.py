@@ -775,11 +775,15 @@ def test_random_pictures_and_loud_audio(golden, case, members):
 
 
 @pytest.mark.parametrize("case", ["i_full", "m_full", "l_full", "pal_sv"])
-@pytest.mark.parametrize("mode", [1, 2])
-def test_levels_looked_up_or_computed(golden, case, mode):
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_levels_looked_up_or_computed(golden, monkeypatch, case, mode):
     """hvk_set_levels(): the RGB -> level conversion by the 2^24-entry table (1) or by the arithmetic
     that fills it, per pixel (2). AUTO picks by the number of colours, so the other tests see the table
-    with the test card and the arithmetic with random pictures; here each is forced on both."""
+    with the test card and the arithmetic with random pictures; here each is forced on both. The arithmetic is the
+    short form where hvk_open() found it equal to the table on all 2^24 colours (hvk_levels_short_form(): it does for
+    these modes), the reference's sequence of operations with HVK_EXACT_LEVELS=1 (3)."""
+    if mode == 3:
+        monkeypatch.setenv("HVK_EXACT_LEVELS", "1")
     conf, sr = golden.conf(case)
     c = golden.cases[case]
     L = c["lines"]
@@ -793,7 +797,8 @@ def test_levels_looked_up_or_computed(golden, case, mode):
             want.append(o.render_lines(L))
         want = np.concatenate(want)
     with H.Engine(conf, sr, device=0, max_frames=2) as e:
-        e.set_levels(mode)
+        assert e.levels_short_form() == (0 if mode == 3 else (1 if case == "l_full" else 2))   # (SECAM-L's luma constants make exact ties of 149 colours: its luma the reference's way)
+        e.set_levels(2 if mode == 3 else mode)
         for i, fb in enumerate(frames):
             e.frame_upload(i, fb)
         while e.audio_needed(2) > 0:
