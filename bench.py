@@ -894,6 +894,10 @@ def main():
                         "by itself for a block whose pictures are mostly new (HVK_FUSED unset); the first figure of each pair is the faster of the two ways" % Fm,
             },
             "workload": "-m i -s 16000000 --filter --noaudio, a different 832 x 576 picture on every frame (smooth gradients + noise), %d frames per step" % Fm,
+            "computed_levels_arithmetic": {"short_form": em.levels_short_form(),
+                                           "note": "hvk_levels_short_form(): 2 = levels computed per pixel take the short form of the FP64 arithmetic (11 operations "
+                                                   "a pixel instead of 38), which hvk_open() TRIED on all 2^24 colours of the mode against the table made with the "
+                                                   "reference's sequence of operations; 1 = for the colour-difference levels only; 0 = the reference's sequence"},
             "with_uploads_Msamples_per_s": round(Fm * FS * ksteps / t_up / 1e6, 1),
             "with_uploads_from_pinned_memory_Msamples_per_s": round(Fm * FS * ksteps / t_pin / 1e6, 1),
             "pictures_resident_Msamples_per_s": round(Fm * FS * ksteps / t_res / 1e6, 1),
