@@ -807,6 +807,19 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				hvk_secam_fid_row(&e->t, 0, q[1], fid.data());
 				hvk_secam_fid_row(&e->t, 1, q[2], fid.data() + k.width);
 			}
+			/* where a frame's second field begins in the task list of either parity: the second task that clears what lies
+			 * behind the line (HVK_SECAM_REDO_FIELDS=0: the stretch-by-stretch redo rounds of before) */
+			for(int p = 0; p < 2; p++)
+			{
+				int seen = 0;
+				a.half_slot[p] = 0;
+				for(int s_ = 2; s_ < a.ntasks; s_++)
+				{
+					const hvk_secam_task_t &q = tasks[(size_t) p * a.ntasks + s_];
+					if((q.flags & HVK_SECAM_TASK_VALID) && (q.flags & HVK_SECAM_TASK_CLEAR) && ++seen == 2) { a.half_slot[p] = s_; break; }
+				}
+				if(getenv("HVK_SECAM_REDO_FIELDS") && atoi(getenv("HVK_SECAM_REDO_FIELDS")) == 0) a.half_slot[p] = 0;
+			}
 			OPENCHK(_upload(&e->d_secam[0], tasks.data(), tasks.size() * sizeof(hvk_secam_task_t)));
 			OPENCHK(_upload(&e->d_secam[1], fid.data(), fid.size() * 2));
 			OPENCHK(_upload(&e->d_secam[2], e->t.secam_lut, 65536 * sizeof(hvk_c32_t)));
@@ -1780,7 +1793,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			return(HVK_OK);
 		}
 		e->secam_counts[2] += (int64_t) bad * a.R;
-		if((r = hvk_launch_secam_redo(&a, e->stream)) != HVK_OK) return(r);
+		if((r = hvk_launch_secam_redo(&a, rounds, e->stream)) != HVK_OK) return(r);
 	}
 
 	if((r = hvk_launch_secam_carry(&a, e->stream)) != HVK_OK) return(r);

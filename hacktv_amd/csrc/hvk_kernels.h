@@ -174,6 +174,7 @@ typedef struct {
 	 * An estimate, right in all but a few cases per ten thousand (tools/secam_est_probe.c): the check decides. */
 	double *iya;                /* [cpad] */
 	int16_t *est;               /* [tpad][16]: the values behind the line at a task's entry; those the valid task before it used */
+	int half_slot[2];           /* per frame parity: the task slot at which the frame's second field begins (hvk_k_secam_redo_fields) */
 	int x1;                     /* where a line's head ends: a multiple of 8, the entry state's influence on the indices is gone by then */
 	int ES, EK;                 /* tasks per lane of the estimate kernel; lines it walks before them */
 	double kap0, kap1;          /* a step's angle: kap0 + kap1 * index */
@@ -190,7 +191,7 @@ extern "C" {
 
 int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, hipStream_t stream);
 int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream);
-int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream);
+int hvk_launch_secam_redo(const hvk_secam_args_t *a, int round, hipStream_t stream);
 int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_expand_yuv(void *lut, const void *params, hipStream_t stream);
 int hvk_launch_check_levels(const void *lut, const void *params, int fast, int *differ, hipStream_t stream);

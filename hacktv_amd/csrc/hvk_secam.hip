@@ -884,6 +884,40 @@ void hvk_k_secam_redo(const hvk_secam_args_t a)
 	}
 }
 
+/* The same for one line per lane (a.R = 1), one lane per FIELD of the batch: the field's failed runs in order, each walked
+ * on from the exit state of the run before for as long as the state left is not the one the next run had started from --
+ * a stretch of any length in ONE launch (where a picture's colours make the values behind the lines carry a difference on
+ * from line to line instead of forgetting it, a wrong start is wrong to the field's end: the stretch-by-stretch rounds
+ * above would hand such a batch to the host's chain). A run that is consistent with the run before it again ends a stretch;
+ * the flags behind it still hold (their runs' predecessors were not touched). What a field's first run takes from the
+ * field before may be on its way to change in this very launch: the next check finds that. */
+__global__ __launch_bounds__(64)
+void hvk_k_secam_redo_fields(const hvk_secam_args_t a)
+{
+	const int lane = blockIdx.x * 64 + threadIdx.x;
+	const int i = lane >> 1, h = lane & 1;
+	if(i >= a.nframes) return;
+	const int sc = a.half_slot[(int) ((a.first_frame + i + 1) & 1)];
+	const int r_lo = i * a.ntasks + (h ? sc : 0), r_hi = i * a.ntasks + (h ? a.ntasks : sc);
+
+	int r = r_lo;
+	while(r < r_hi)
+	{
+		if(!a.flags[r]) { r++; continue; }
+		hvk_secam_state_t S = r ? a.exit[r - 1] : *a.carry;
+		do
+		{
+			a.entry[r] = S;
+			if(a.seed) a.seed[seed_row(a, r)] = S;
+			run_task(a, r, S, true);
+			a.exit[r] = S;
+			r++;
+		}
+		while(r < r_hi && !same_state(S, a.entry[r]));
+		r++;        /* (that run stands as it is, and so do the flags behind it) */
+	}
+}
+
 /* the batch is through: its last exit state is the next batch's start */
 __global__ void hvk_k_secam_carry(const hvk_secam_args_t a)
 {
@@ -918,9 +952,12 @@ extern "C" int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t str
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
-extern "C" int hvk_launch_secam_redo(const hvk_secam_args_t *a, hipStream_t stream)
+/* round: 1 for the first redo of a stage -- a lane per stretch of failed runs: the few lines an estimate got wrong, side by
+ * side --, more for the ones after it: what is still wrong then is a stretch that runs on, a lane per field */
+extern "C" int hvk_launch_secam_redo(const hvk_secam_args_t *a, int round, hipStream_t stream)
 {
-	hipLaunchKernelGGL(hvk_k_secam_redo, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
+	if(round > 1 && a->R == 1 && a->half_slot[0] > 0 && a->half_slot[1] > 0) hipLaunchKernelGGL(hvk_k_secam_redo_fields, dim3((2 * a->nframes + 63) / 64), dim3(64), 0, stream, *a);
+	else hipLaunchKernelGGL(hvk_k_secam_redo, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

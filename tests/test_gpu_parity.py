@@ -521,6 +521,42 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
         assert st["host_frames"] > 0, st
 
 
+@pytest.mark.parametrize("mode,kind", [("secam", "bars"), ("l", "flat"), ("secam-fm", "bars")])
+def test_secam_pictures_whose_lines_do_not_forget(golden, monkeypatch, mode, kind):
+    """SECAM, new pictures of flat colours: the values behind the lines carry a difference on from line to line instead of
+    forgetting it within a dozen lines, and every sample of a flat stretch takes the same table entry, whose rounding the
+    estimate's summed angle does not know -- more wrong starts than noise has, and a wrong start that stays wrong to the
+    field's end. The first redo round takes the isolated ones side by side, the rounds after it a field per lane
+    (hvk_k_secam_redo_fields): the host's chain is never asked (it used to be, for every block of the colour bars in the
+    baseband modes), and every sample is the host chain's."""
+    conf = H.preset(mode, H.FLAG_NOAUDIO)
+    conf.secam_field_id = 1
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:576, 0:832]
+    pics = []
+    for i in range(21):
+        if kind == "bars":
+            b = (xx * 8 // 832 + i) % 8
+            pics.append((np.where(b & 4, 0xFF0000, 0) | np.where(b & 2, 0xFF00, 0) | np.where(b & 1, 0xFF, 0)).astype(np.uint32))
+        else:
+            pics.append(np.full((576, 832), int(rng.integers(0, 1 << 24)), np.uint32))
+    def run():
+        out = []
+        with H.Engine(conf, 16000000, device=0, max_frames=7) as e:
+            for b in range(3):
+                for s_ in range(7):
+                    e.frame_upload(s_, pics[b * 7 + s_])
+                e.render(7, slots=list(range(7)))
+                out.append(e.fetch(0, 7 * 640000))
+            return np.concatenate(out), e.secam_stats()
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, _ = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    got, st = run()
+    assert np.array_equal(got, want)
+    assert st["host_frames"] == 0 and st["mismatches"] > 0, st
+
+
 def test_secam_cells_of_a_picture_are_kept_and_made_again_when_it_changes(golden, monkeypatch):
     """SECAM: the low-passed colour cells are kept per picture slot and frame parity (hvk_secam.hip). Pictures that
     stay over batches of odd length (the parity a slot is shown with changes), slots shown twice in a batch, a slot that
