@@ -1973,7 +1973,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
 	int many = 0;
 
-	if(k.fm_video && k.vf_type && first_frame == 0 && k.out_prime > 0)
+	if(k.fm_video && (k.vf_type || k.rs_L) && first_frame == 0 && k.out_prime > 0)
 	{
 		/* The line pipeline's never-emitted start-up samples pass through the FM modulator as well
 		 * (src/video.c:4936-4952 drops them only at the output): what the sound carriers add to them is
@@ -2523,8 +2523,57 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		 * zero -- nothing but its last ntaps / 2 outputs, whose windows reach the stream's first samples -- plus the
 		 * sound carriers. The stream's first raster samples come from the slab just rendered. */
 		const hvk_kconst_t &k = e->t.k;
-		const int nt = k.vf_ntaps, H = nt / 2, P = k.out_prime;
+		const int nt = k.vf_type ? k.vf_ntaps : 0, H = nt / 2, P = k.out_prime;
 		std::vector<int16_t> x(H), in((size_t) P);
+		if(k.rs_L)
+		{
+			/* Behind the resampler the start-up samples are not nothing: the resampler's output for raster line N lands in
+			 * the slot of line N - 1, so the resampled raster line 1 (and, with the filter on, the filter's output over it
+			 * and the line after) passes the modulator before the first emitted sample does (hvk_tables.c: out_prime,
+			 * rs_shift). Resampled sample r is made of raster sample floor(r D / L) and the ataps - 1 before it with the
+			 * taps of phase (r D) mod L, nothing in front of the stream's first raster sample (hvk_k_resample says the same
+			 * of the samples it makes); the stream's sample 0 is the filter's output centred on resampled sample rs_shift. */
+			const int64_t L = k.rs_L, D = k.rs_D;
+			const int A = k.rs_ataps;
+			const int Rn = k.rs_shift + H + 1;
+			const int nr = (int) (((int64_t) (Rn - 1) * D) / L) + 1;
+			if(nr > k.raster_samples) { e->poisoned = 1; return(HVK_ERROR); }
+			std::vector<int16_t> xr((size_t) nr), xs((size_t) Rn);
+			HIPCHK(hipMemcpyAsync(xr.data(), e->d_S + (size_t) k.width, (size_t) nr * 2, hipMemcpyDeviceToHost, e->stream));
+			HIPCHK(hipStreamSynchronize(e->stream));
+			for(int rr = 0; rr < Rn; rr++)
+			{
+				const int64_t n = ((int64_t) rr * D) / L, ph = ((int64_t) rr * D) % L;
+				int32_t acc = 0;
+				for(int y = 0; y < A; y++)
+				{
+					const int64_t xi = n - A + 1 + y;
+					if(xi >= 0) acc += (int32_t) xr[(size_t) xi] * e->t.rs_taps[(size_t) ph * A + y];
+				}
+				acc >>= 15;
+				xs[(size_t) rr] = (int16_t) (acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc));
+			}
+			for(int n = 0; n < P; n++)
+			{
+				const int c = n - P + k.rs_shift;       /* the resampled sample this output is centred on */
+				int32_t acc;
+				if(nt)
+				{
+					acc = 0;
+					for(int kk = 0; kk < nt; kk++)
+					{
+						const int xi = c - H + kk;
+						if(xi >= 0 && xi < Rn) acc += (int32_t) e->t.vf_itaps[kk] * xs[(size_t) xi];
+					}
+					acc >>= 15;
+					acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+				}
+				else acc = c >= 0 && c < Rn ? xs[(size_t) c] : 0;
+				in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);
+			}
+		}
+		else
+		{
 		HIPCHK(hipMemcpyAsync(x.data(), e->d_S + (size_t) k.width, (size_t) H * 2, hipMemcpyDeviceToHost, e->stream));
 		HIPCHK(hipStreamSynchronize(e->stream));
 		for(int n = 0; n < P; n++)
@@ -2539,6 +2588,7 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 			acc >>= 15;
 			acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
 			in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);     /* int16 wrap-around add, src/video.c:3431 */
+		}
 		}
 		r = hvk_tail_fm_prime(e->tail, in.data(), P);
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }      /* the sound chain is past these samples: the stream cannot go on */

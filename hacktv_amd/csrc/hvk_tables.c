@@ -1755,10 +1755,9 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			t->fmv_lut[i - INT16_MIN] = _unit_phasor(2.0 * M_PI / t->sample_rate * (0 + (double) i / INT16_MAX * c->fm_deviation));
 		}
 		t->k.fm_video = 1;
-		/* With the resampler the modulator's start-up samples come from the RESAMPLED stream (the pipeline's chunks
-		 * before the first emitted line, src/video.c:4936-4952 with :3627-3651): the engine primes its phasor from
-		 * the raster (hvk_engine.cpp), which is only right without it. Refused, not approximated. */
-		if(t->k.rs_L) return(HVK_UNSUPPORTED);
+		/* (with the resampler the modulator's start-up samples come from the RESAMPLED stream -- the pipeline's chunks
+		 * before the first emitted line, src/video.c:4936-4952 with :3627-3651 --: hvk_engine.cpp primes the phasor with
+		 * them) */
 	}
 
 	/* raw baseband input (src/video.c:2406-2446, :4180-4191): no raster, no colour process, no

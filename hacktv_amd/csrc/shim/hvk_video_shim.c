@@ -345,7 +345,6 @@ static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sampl
 	if(c->videocrypt || c->videocrypt2 || c->videocrypts || c->syster || c->d11 ||
 	   c->systercnr || c->eurocrypt) return(_refuse("a scrambler"));
 	if(c->sis && strcmp(c->sis, "dcsis") != 0) return(_refuse("this sound-in-syncs mode"));      /* (so does the reference, src/sis.c:95-103) */
-	if(c->sis && ((pixel_rate != 0 && pixel_rate != sample_rate) || c->raw_bb_file || c->s_video)) return(_refuse("sound-in-syncs with --pixelrate / raw baseband input / S-Video"));
 	if(c->fm_left_level > 0 || c->fm_right_level > 0 || c->dance_level > 0) return(_refuse("this audio mode"));
 	if(c->raw_bb_file && c->s_video) return(_refuse("raw baseband input with --s-video"));
 
@@ -762,7 +761,7 @@ static int _next_batch(vid_t *s, shim_t *m, int16_t *iq, int *ticket, hvk_engine
 		/* 32 kHz audio for this frame (src/video.c:3278-3286), pulled frame by frame so that the end
 		 * of the sound is seen by the same av_eof() as in the reference; a source that runs dry
 		 * leaves silence (src/video.c:3299-3304) */
-		if(m->info.has_carriers || m->info.has_nicam)
+		if(m->info.has_carriers || m->info.has_nicam || s->conf.sis)      /* (sound-in-syncs takes the sound of a mode without a sound carrier too) */
 		{
 			while((m->g ? hvk_group_audio_needed(m->g, n) : hvk_audio_needed(m->e, n)) > 0)
 			{

@@ -34,6 +34,13 @@ CASES = [
      {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000, "sis": 1}),
     ("i_sis_px135", "i_px135", "i", 16000000, 13500000, ["--filter", "--sis", "dcsis", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 6, {"sis": 1}),
     ("i_sis_px2025", "i_px2025", "i", 16000000, 20250000, ["--sis", "dcsis", "--pixelrate", "20250000"], 0, False, 6, {"sis": 1}),
+    # FM video behind the resampler: the never-emitted start-up samples the modulator runs over are the resampled first raster line
+    # (and the filter's output over it) -- up and down, with and without the pre-emphasis filter
+    ("palfm_px135", "pal_fm", "pal-fm", 16000000, 13500000, ["--pixelrate", "13500000"], 0, False, 3, {}),
+    ("palfm_f14_px135", "palfm_f14", "pal-fm", 14000000, 13500000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 3, {}),
+    ("secamfm_px18", "secam_fm_tail", "secam-fm", 16000000, 18000000, ["--pixelrate", "18000000"], 0, False, 3, {}),
+    ("ntscfm_f18_px135", "ntscfm_f18", "ntsc-fm", 18000000, 13500000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 3, {}),
+    ("palfm_s14_px16", "pal_fm", "pal-fm", 14000000, 16000000, ["--pixelrate", "16000000"], 0, False, 3, {}),
 ]
 # mode, sample rate, flags: what differs from run to run
 UNDEFINED = [
@@ -50,22 +57,30 @@ def runs_of(mode, sr, flags, nbytes, n):
     return [hashlib.sha256(ref_cli(mode, sr, flags, nbytes)).hexdigest() for _ in range(n)]
 
 
+ONLY = sys.argv[1:]
+
+
 def main():
     util.rawbb_signal().tofile("/tmp/hvk_rawbb.bin")
     for cid, base, mode, sr, pr, flags, pflags, real, nframes, extra in CASES:
         cli = [f.replace("@RAWBB@", "/tmp/hvk_rawbb.bin") for f in flags]
+        if ONLY and cid not in ONLY:
+            continue
         d = runs_of(mode, sr, cli, 640000 * 4 * 3, RUNS)
         assert len(set(d)) == 1, (cid, d)
         print(cid, "%d identical runs" % RUNS, flush=True)
     r03.CASES = CASES
-    sys.argv = sys.argv[:1]
+    sys.argv = sys.argv[:1] + ONLY
     r03.main()
     dfile = os.path.join(GOLD, "ref_digests.json")
     digests = json.load(open(dfile))
     for c in CASES:
-        digests[c[0]]["reference_runs"] = "%d runs of the reference CLI, one output" % RUNS
+        if c[0] in digests:
+            digests[c[0]]["reference_runs"] = "%d runs of the reference CLI, one output" % RUNS
     json.dump(digests, open(dfile, "w"), indent=1, sort_keys=True)
 
+    if ONLY:
+        return
     und = {"note": "sha256 of the first 5 frames' worth of samples of RUNS runs of oracle/_ref/hacktv_ref (the unmodified reference), test source; "
                    "`undefined`: the runs differ from each other -- nothing to be equal to; `defined_beside_them`: neighbours whose runs agree",
            "runs": RUNS, "undefined": [], "defined_beside_them": []}
