@@ -115,6 +115,7 @@ typedef struct {
 	int64_t aud_base;
 	int volume;
 	int64_t out_pos;
+	int64_t ticks, tick_rem;    /* out_pos * 32000 = ticks * sample_rate + tick_rem */
 	int64_t aud_blocks_read;
 	int16_t aud_out[SHIM_AUDIO_BLOCK * 2];
 	vid_line_t out;
@@ -501,6 +502,8 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 		return(VID_ERROR);
 	}
 	m->out_pos = m->info.startup_samples;
+	m->ticks = m->out_pos / m->info.sample_rate * SHIM_AUDIO_RATE + m->out_pos % m->info.sample_rate * SHIM_AUDIO_RATE / m->info.sample_rate;
+	m->tick_rem = m->out_pos % m->info.sample_rate * SHIM_AUDIO_RATE % m->info.sample_rate;
 	m->volume = conf->volume;
 
 	/* the read-back buffers: page-locked, so that the copy runs at PCIe speed and beside the next batch's host work
@@ -986,8 +989,11 @@ vid_line_t *vid_next_line(vid_t *s)
 		 * output samples, src/video.c:3272-3274; it is startup_samples ahead of the output); a block goes out on the
 		 * first line that finds it complete, one block per line at most */
 		int64_t ticks, avail;
+		/* (floor(out_pos * 32000 / sample_rate), carried along from line to line: no division on the way) */
 		m->out_pos += l->width;
-		ticks = m->out_pos / m->info.sample_rate * SHIM_AUDIO_RATE + m->out_pos % m->info.sample_rate * SHIM_AUDIO_RATE / m->info.sample_rate;
+		m->tick_rem += (int64_t) l->width * SHIM_AUDIO_RATE;
+		while(m->tick_rem >= m->info.sample_rate) { m->tick_rem -= m->info.sample_rate; m->ticks++; }
+		ticks = m->ticks;
 		avail = ticks >= 1 ? (ticks - 1) / SHIM_AUDIO_BLOCK : 0;
 		if(m->aud_blocks_read < avail)
 		{
