@@ -608,6 +608,11 @@ __device__ __forceinline__ int seed_row(const hvk_secam_args_t &a, const int m)
 #define IIR_STEP(in_) do { const double in__ = (in_); const double t0__ = in__ * 2.90456054, t1__ = ix * -2.80912108, t2__ = iy * -0.90456054; \
                            iy = (t0__ + t1__) - t2__; ix = in__; } while(0)
 
+/* ... and for the estimate, which needs the outputs to within rounding only: the products fused (the chain from sample to
+ * sample is one fused multiply-add long), the index by the add of 1.5 * 2^52 */
+#define EST_STEP(in_) do { const double in__ = (in_); iy = __builtin_fma(iy, 0.90456054, __builtin_fma(in__, 2.90456054, ix * -2.80912108)); ix = in__; } while(0)
+#define EST_INDEX(iy_) med3i(__double2loint((iy_) + 6755399441055744.0), dmin32, dmax32)
+
 /* a line's low-pass output x >= W - 7 given the values behind the line (hvk_secam_chain_line) */
 __device__ __forceinline__ int32_t tail_output(const hvk_secam_args_t &a, const int cm, const int x, const int16_t *tail)
 {
@@ -623,7 +628,7 @@ __device__ __forceinline__ int32_t tail_output(const hvk_secam_args_t &a, const 
 }
 
 /* One line of the estimate: E on entry (the IIR's state to within rounding, the values behind the line), on exit.
- * The line's head exactly as the walk has it; the middle from hvk_k_secam_cells; the last seven samples with the values
+ * The line's head under the entry state at hand; the middle from hvk_k_secam_cells; the last seven samples with the values
  * behind the line at hand; then the FM loop's steps past the line's end with the phasor the summed angle gives --
  * cos and sin of it at the amplitude the floor-after-every-step recurrence has lost one unit per step of -- through
  * the same integer arithmetic as hvk_secam_fm_step(). */
@@ -635,7 +640,7 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 	const int cm = a.cbase[v.frame] + (m - v.frame * a.ntasks);
 	const int4 *F = (const int4 *) a.F + cm;
 	double ix = E.ix, iy = E.iy;
-	int64_t S = 0;
+	int32_t S = 0;              /* (a line's indices: 942 of at most 14 028) */
 
 	/* (four chunks in flight: the loads are a lane's own, 16 bytes each, and nothing else hides their latency) */
 	const int nq = a.x1 / 8;
@@ -661,7 +666,7 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
 		if(q + 4 < nq) ring[3] = F[(size_t) (q + 4) * a.cpad];
 #pragma unroll
-		for(int j = 0; j < 8; j++) IIR_STEP((double) f[j]);
+		for(int j = 0; j < 8; j++) EST_STEP((double) f[j]);
 	}
 	for(; q < nq; q++)
 	{
@@ -673,11 +678,10 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 		for(int j = 0; j < 8; j++)
 		{
 			const int x = q * 8 + j;
-			IIR_STEP((double) f[j]);
+			EST_STEP((double) f[j]);
 			if(x >= sl && x < fm_end)
 			{
-				const int32_t r = round_away_nb(iy);
-				S += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+				S += EST_INDEX(iy);
 			}
 		}
 	}
@@ -693,11 +697,10 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 #pragma unroll
 		for(int i = 0; i <= j; i++) s += (int32_t) E.tail[i] * a.C.fir[14 + i - j];     /* (tap W + 7 + i - x) */
 		s >>= 15;
-		IIR_STEP((double) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s)));
+		EST_STEP((double) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s)));
 		if(x >= sl && x < fm_end)
 		{
-			const int32_t r = round_away_nb(iy);
-			S += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+			S += EST_INDEX(iy);
 		}
 	}
 	E.ix = ix;
