@@ -106,28 +106,37 @@ __device__ __forceinline__ int32_t round_away_nb(const double x)
 
 /* ------------------------------------------------------------------ */
 
+#define CELLS_TASKS 1           /* tasks a workgroup works on side by side (whole waves each). Two were measured: 0.86 against 0.73 ms per 512 frames -- more small workgroups overlap better than fewer larger ones */
 template<int LV>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256 * CELLS_TASKS)
 void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
-	extern __shared__ __attribute__((aligned(16))) int16_t lds[];      /* 8 zeros, W cells, 24 zeros */
+	extern __shared__ __attribute__((aligned(16))) int16_t lds_all[];  /* per task: 8 zeros, W cells, 24 zeros */
 	const int W = a.C.W;
+	const int TH = (int) blockDim.x / CELLS_TASKS;      /* lanes of a task: a multiple of 64 */
+	const int sub = (int) threadIdx.x / TH;
+	int16_t *lds = lds_all + sub * ((W + 32 + 7) & ~7);
 	/* (workgroups go to the 8 XCDs in turn; the 8 tasks whose outputs share 128 bytes of the transposed store go to ONE,
-	 * so that its L2 sees whole lines: workgroup b of XCD b % 8 is the (b / 8)-th there) */
+	 * so that its L2 sees whole lines: workgroup b of XCD b % 8 is the (b / 8)-th there, and 8 / CELLS_TASKS of them make a group) */
 	const int bj = (int) blockIdx.x >> 3;
-	const int slot = (((bj >> 3) * 8 + ((int) blockIdx.x & 7)) << 3) + (bj & 7);
-	if(slot >= a.ntasks) return;
+	constexpr int WPG = 8 / CELLS_TASKS;
+	const int slot_ = (((bj / WPG) * 8 + ((int) blockIdx.x & 7)) << 3) + (bj % WPG) * CELLS_TASKS + sub;
+	const bool in_list = slot_ < a.ntasks;
+	const int slot = in_list ? slot_ : a.ntasks - 1;
 	const int i = a.clist[blockIdx.y];
 	const int t = i * a.ntasks + slot;
 	const int cm = a.cbase[i] + slot;           /* the task's row in the cell stores */
 	const task_view v = task_of(a, t);
-	const int lane = threadIdx.x, x0 = lane * SPL;
-
-	if(!v.valid) return;
+	const int lane = (int) threadIdx.x - sub * TH, x0 = lane * SPL;
+	const bool live = in_list && v.valid;       /* (a task that is none takes part in the barriers and writes nothing) */
 
 	int16_t c[SPL];
 
-	if(v.fid)
+	if(!live)
+	{
+		for(int j = 0; j < SPL; j++) c[j] = 0;
+	}
+	else if(v.fid)
 	{
 		for(int j = 0; j < SPL; j++) c[j] = x0 + j < W ? a.fid_rows[v.dr * W + x0 + j] : 0;
 	}
@@ -263,7 +272,7 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 	else for(int j = 0; j < SPL; j++) if(x0 + j < W) lds[8 + x0 + j] = c[j];
 	__syncthreads();
 
-	const bool act = x0 < W;
+	const bool act = live && x0 < W;
 
 	/* 15-tap low pass, zero history (src/video.c:3207): output x reads cells x - 7 .. x + 7 = elements x + 1 .. x + 15 --
 	 * the lane's window starts one element behind its 16-byte aligned slice; packed pairs and v_dot2c_i32_i16 */
@@ -320,9 +329,12 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 	 * last seven samples, and the IIR's output at W - 8. */
 	if(a.iya)
 	{
-		__shared__ double s_y[4];
-		__shared__ int s_f[4];
-		__shared__ int s_sum;
+		__shared__ double s_y_all[CELLS_TASKS][4];
+		__shared__ int s_f_all[CELLS_TASKS][4];
+		__shared__ int s_sum_all[CELLS_TASKS];
+		double *s_y = s_y_all[sub];
+		int *s_f = s_f_all[sub];
+		int &s_sum = s_sum_all[sub];
 		const double CA = 2.90456054, CB = -2.80912108, CC = 0.90456054;
 		const int wl = lane & 63, wv = lane >> 6;
 		if(lane == 0) s_sum = 0;
@@ -379,12 +391,12 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 				const int32_t r = round_away_nb(yj);
 				sum += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
 			}
-			if(x == W - 8) a.iya[cm] = yj;
+			if(act && x == W - 8) a.iya[cm] = yj;
 		}
 		for(int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
 		if(wl == 0 && sum) atomicAdd(&s_sum, sum);
 		__syncthreads();
-		if(lane == 0) a.acc[(size_t) cm * 8 + 7] = s_sum;
+		if(live && lane == 0) a.acc[(size_t) cm * 8 + 7] = s_sum;
 	}
 }
 
@@ -937,10 +949,11 @@ extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estim
 	if(threads > 256 || (a->C.W % 16) != 0) return(HVK_UNSUPPORTED);
 	if(a->ncells > 0)
 	{
-		const int gx = (a->ntasks + 63) & ~63;
+		const int gx = ((a->ntasks + 63) & ~63) / CELLS_TASKS;
+		const size_t lds_b = (size_t) ((a->C.W + 32 + 7) & ~7) * 2 * CELLS_TASKS;
 		/* (with the pictures' (U, V) plane the levels are there; the few rows it does not hold whole -- half lines -- go through the table) */
-		if(a->levels_computed && !a->uvp) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(gx, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
-		else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(gx, a->ncells), dim3(threads), (size_t) (a->C.W + 32) * 2, stream, *a);
+		if(a->levels_computed && !a->uvp) hipLaunchKernelGGL(hvk_k_secam_cells<1>, dim3(gx, a->ncells), dim3(threads * CELLS_TASKS), lds_b, stream, *a);
+		else hipLaunchKernelGGL(hvk_k_secam_cells<0>, dim3(gx, a->ncells), dim3(threads * CELLS_TASKS), lds_b, stream, *a);
 	}
 	if(estimate && a->est)
 	{
