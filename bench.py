@@ -169,6 +169,19 @@ def ref_stream_sha(mode, sr, cli_flags, first, count, frame_bytes, env_extra=Non
     return h.hexdigest() if left == 0 else None
 
 
+def time_steps(step, sync, warmup, steps):
+    """`warmup` untimed calls of step(), then `steps` timed ones between two sync()s: seconds per step. The sections' clock
+    (the headline has its own: settle phase, barriers, maximum over ranks -- main())."""
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
 def raw_teletext_rows(g, slot_counter):
     """The packets the reference's `raw:` source hands to the 32 teletext lines of the next frame (tests/golden/ttraw.bin,
     256 records): it reads on from where it stood, and the read that hits the end of the file yields NO packet before the
@@ -261,14 +274,7 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
             stage_block()
         e.launch(ctypes.c_void_p(out.data_ptr()))
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = time_steps(step, torch.cuda.synchronize, warmup, steps)
     res = {
         "workload": " ".join(["-m", c["mode"], "-s", str(sr)] + [f if not f.startswith("raw:") else "raw:tests/golden/ttraw.bin" for f in flags] + ["test"]),
         "frames_per_step": F,
@@ -523,26 +529,8 @@ def main():
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
 
     def ref_sha(first, count):
-        """sha256 of frames [first, first + count) of the unmodified reference CLI's output, run now (None: no binary)."""
-        if not os.path.exists(ref_bin):
-            return None
-        # a clean environment: under rocprofv3 the child would inherit the profiler's LD_PRELOAD and tool settings
-        env = {k: v for k, v in os.environ.items()
-               if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS", "ROCPROFILER"))}
-        p = subprocess.Popen([ref_bin, "-m", MODE, "-s", str(SAMPLE_RATE), "--filter", "-o", "-", "test"],
-                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
-        skip, left, h = first * FS * 4, count * FS * 4, hashlib.sha256()
-        while skip > 0:
-            skip -= len(p.stdout.read(min(skip, 1 << 22)))
-        while left > 0:
-            chunk = p.stdout.read(min(left, 1 << 22))
-            if not chunk:
-                break
-            h.update(chunk)
-            left -= len(chunk)
-        p.kill()
-        p.wait()
-        return h.hexdigest()
+        """sha256 of frames [first, first + count) of the unmodified reference CLI's output for the metric configuration, run now (None: no binary)."""
+        return ref_stream_sha(MODE, SAMPLE_RATE, ["--filter"] + (["--noaudio"] if args.noaudio else []), first, count, FS * 4)
 
     def feed_audio(upto_frame, source_pos=None):
         """32 kHz source samples up to frame `upto_frame`; source_pos: the engine has just taken over another rank's sound
@@ -868,14 +856,12 @@ def main():
             ex.set_levels(levels)
             for i in range(Fm):
                 ex.frame_upload(i, np.roll(g.frame("i_full"), 13 * i, axis=1) if card else pics[i % len(pics)])
-            for k in range(2):
-                ex.planes_refresh(slots); ex.stage(k * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm.data_ptr()))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(ksteps * 2):
-                ex.planes_refresh(slots); ex.stage((2 + k) * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm.data_ptr()))
-            torch.cuda.synchronize()
-            dt_ = (time.perf_counter() - t0) / (ksteps * 2)
+            nxt = [0]
+
+            def one():
+                ex.planes_refresh(slots); ex.stage(nxt[0] * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm.data_ptr()))
+                nxt[0] += 1
+            dt_ = time_steps(one, torch.cuda.synchronize, 2, ksteps * 2)
             nf = ex.fused_launches()
             ex.close()
             return round(Fm * FS / dt_ / 1e6, 1), nf
@@ -927,22 +913,18 @@ def main():
                 for i_, p_ in enumerate(pics):
                     es.frame_upload(i_, p_)
                 slots = [i_ % len(pics) for i_ in range(Fs)]
-            for k in range(wsteps):
-                if refresh:
-                    es.planes_refresh(slots)
-                es.stage(k * Fs, 1, Fs, slots=slots)
-                es.launch()
-            es.sync()
-            st0 = es.secam_stats()
-            est0 = es.secam_estimated_stages()
-            t0 = time.perf_counter()
-            for k in range(ksteps):
+            nxt = [0]
+
+            def one():
                 if refresh:
                     es.planes_refresh(slots)        # (every picture's luma and (U, V) planes made again: hvk_k_prep8)
-                es.stage((wsteps + k) * Fs, 1, Fs, slots=slots)
+                es.stage(nxt[0] * Fs, 1, Fs, slots=slots)
                 es.launch()
-            es.sync()
-            t_dev = (time.perf_counter() - t0) / ksteps
+                nxt[0] += 1
+            time_steps(one, es.sync, 0, wsteps)     # (untimed: lets the number of warm-up lines settle)
+            st0 = es.secam_stats()
+            est0 = es.secam_estimated_stages()
+            t_dev = time_steps(one, es.sync, 0, ksteps)
             st = es.secam_stats()
             st = {kk: st[kk] - st0[kk] for kk in st}        # the timed steps' lines
             st["warmup_lines_per_start_state"] = es.secam_warmup_lines()
