@@ -70,7 +70,7 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[15];          /* what sa points into (freed at close) */
+	void *d_secam[17];          /* what sa points into (freed at close) */
 	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
 	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
 	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
@@ -868,6 +868,26 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				/* a step's angle, src/video.c:2236 with :4080 */
 				a.kap0 = 2.0 * M_PI / (double) e->t.pixel_rate * 4328125.0;
 				a.kap1 = 2.0 * M_PI / (double) e->t.pixel_rate * 1000e3 / (double) INT16_MAX;
+				if(!getenv("HVK_SECAM_NO_RES"))
+				{
+					/* the table entries' rounding (hvk_secam_args_t.res): angle and relative length against the nominal ones */
+					std::vector<int16_t> res((size_t) 65536 * 2);
+					for(int u = 0; u < 65536; u++)
+					{
+						const double i_ = e->t.secam_lut[u].i, q_ = e->t.secam_lut[u].q;
+						double dphi = atan2(q_, i_) - (a.kap0 + a.kap1 * (double) (u - 32768));
+						dphi -= 2.0 * M_PI * floor(dphi / (2.0 * M_PI) + 0.5);
+						const double dlen = sqrt(i_ * i_ + q_ * q_) / 2147483647.0 - 1.0;
+						const double p_ = round(dphi * 0x1p46), l_ = round(dlen * 0x1p46);
+						res[(size_t) u * 2 + 0] = (int16_t) (p_ < -32767 ? -32767 : (p_ > 32767 ? 32767 : p_));
+						res[(size_t) u * 2 + 1] = (int16_t) (l_ < -32767 ? -32767 : (l_ > 32767 ? 32767 : l_));
+					}
+					OPENCHK(_upload(&e->d_secam[15], res.data(), res.size() * 2));
+					OPENHIP(hipMalloc(&e->d_secam[16], (size_t) a.cpad * 2 * sizeof(int32_t)));
+					OPENHIP(hipMemset(e->d_secam[16], 0, (size_t) a.cpad * 2 * sizeof(int32_t)));
+					a.res = (const int16_t *) e->d_secam[15];
+					a.corr = (int32_t *) e->d_secam[16];
+				}
 			}
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));

@@ -173,6 +173,12 @@ typedef struct {
 	 * loop leaves behind the line, and goes on to the next line -- a few hundred additions per line instead of a walk.
 	 * An estimate, right in all but a few cases per ten thousand (tools/secam_est_probe.c): the check decides. */
 	double *iya;                /* [cpad] */
+	/* The table's entries are cos / sin rounded to integers: an entry's angle and length differ from the nominal ones by up to
+	 * 0.7 / 2^31 -- noise over a line of many different indices, but a stretch of ONE colour takes one entry hundreds of
+	 * times and the differences add up to several hundred units of the phasor. res[u] holds them (units of 2^-46: angle,
+	 * relative length); hvk_k_secam_cells sums them where a lane's eight samples take the same entry (corr, per line) */
+	const int16_t *res;         /* [65536][2] */
+	int32_t *corr;              /* [cpad][2] */
 	int16_t *est;               /* [tpad][16]: the values behind the line at a task's entry; those the valid task before it used */
 	int half_slot[2];           /* per frame parity: the task slot at which the frame's second field begins (hvk_k_secam_redo_fields) */
 	int x1;                     /* where a line's head ends: a multiple of 8, the entry state's influence on the indices is gone by then */

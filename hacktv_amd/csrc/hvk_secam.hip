@@ -335,9 +335,11 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		double *s_y = s_y_all[sub];
 		int *s_f = s_f_all[sub];
 		int &s_sum = s_sum_all[sub];
+		__shared__ int s_cph_all[CELLS_TASKS], s_cam_all[CELLS_TASKS];
+		int &s_cph = s_cph_all[sub], &s_cam = s_cam_all[sub];
 		const double CA = 2.90456054, CB = -2.80912108, CC = 0.90456054;
 		const int wl = lane & 63, wv = lane >> 6;
-		if(lane == 0) s_sum = 0;
+		if(lane == 0) { s_sum = 0; s_cph = 0; s_cam = 0; }
 		if(wl == 63) s_f[wv] = act ? (int) o[SPL - 1] : 0;
 		__syncthreads();
 		double yl[SPL];
@@ -380,23 +382,42 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
 		int sum = 0;
 		double p = CC;
+		int uu[SPL];
 #pragma unroll
 		for(int j = 0; j < SPL; j++)
 		{
 			const double yj = yl[j] + p * cin;
 			const int x = x0 + j;
 			p *= CC;
-			if(x >= a.x1 && x < hi)
-			{
-				const int32_t r = round_away_nb(yj);
-				sum += r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
-			}
+			const int32_t r = round_away_nb(yj);
+			uu[j] = r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
+			if(x >= a.x1 && x < hi) sum += uu[j];
 			if(act && x == W - 8) a.iya[cm] = yj;
 		}
-		for(int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+		/* (a lane whose eight samples, all of them FM steps, take ONE table entry: that entry's rounding, eight times) */
+		int cph = 0, cam = 0;
+		if(a.res && act && x0 >= a.C.sl && x0 + SPL <= hi)
+		{
+			bool same = true;
+#pragma unroll
+			for(int j = 1; j < SPL; j++) same = same && uu[j] == uu[0];
+			if(same)
+			{
+				const int rr = ((const int *) a.res)[uu[0] + 32768];
+				cph = SPL * (int) (int16_t) rr;
+				cam = SPL * (rr >> 16);
+			}
+		}
+		for(int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d); cph += __shfl_down(cph, d); cam += __shfl_down(cam, d); }
 		if(wl == 0 && sum) atomicAdd(&s_sum, sum);
+		if(wl == 0 && cph) atomicAdd(&s_cph, cph);
+		if(wl == 0 && cam) atomicAdd(&s_cam, cam);
 		__syncthreads();
-		if(live && lane == 0) a.acc[(size_t) cm * 8 + 7] = s_sum;
+		if(live && lane == 0)
+		{
+			a.acc[(size_t) cm * 8 + 7] = s_sum;
+			if(a.corr) { a.corr[(size_t) cm * 2 + 0] = s_cph; a.corr[(size_t) cm * 2 + 1] = s_cam; }
+		}
 	}
 }
 
@@ -723,6 +744,12 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 		const int n = fm_end > sl ? fm_end - sl : 0;
 		double th = (v.phase_pos ? 0.0 : 3.14159265358979323846) + a.kap0 * (double) n + a.kap1 * (double) S;
 		double amp = 2147483647.0 - (double) n;
+		if(a.corr)
+		{
+			/* (what the entries' rounding adds up to over the line's stretches of one colour: hvk_secam_args_t.res) */
+			th += (double) a.corr[(size_t) cm * 2 + 0] * 0x1p-46;
+			amp *= 1.0 + (double) a.corr[(size_t) cm * 2 + 1] * 0x1p-46;
+		}
 		for(int x = W; x < v.sr; x++)
 		{
 			int16_t c = E.tail[x - W];
@@ -783,10 +810,15 @@ void hvk_k_secam_est(const hvk_secam_args_t a)
 }
 
 /* A run's entry state from the estimate: the values behind the line as hvk_k_secam_est left them; the IIR's two doubles
- * exactly, by walking the IIR alone over the last 448 samples of the valid task before -- from whatever state, it has
- * arrived bit for bit at the state of the full walk by then (its pole is 0.90456: 2^-53 after 360 samples, and equal
- * doubles stay equal) -- with that task's last seven outputs made with the values IT had behind its line. */
-#define PREWALK 448
+ * exactly, by walking the IIR alone over the valid task before, from nothing -- with that task's last seven outputs made
+ * with the values IT had behind its line. Over changing input it has arrived bit for bit at the state of the full walk
+ * after 450 samples (its pole is 0.90456: 2^-53 after 360 samples, and equal doubles stay equal); over CONSTANT input --
+ * a picture of one colour -- it has not: the recurrence then has several stationary values a few units of the last place
+ * apart, and which of them a walk settles on depends on the side it comes from. Hence the whole line: the walk from
+ * nothing passes the line's blanking level and the picture's left edge like the true one and comes to the picture's
+ * level from the same side (tools/secam_est_probe.c, tools/secam_flat_probe.py: pictures of one colour had every line of
+ * one kind start wrong with 448 samples, none with the line). */
+#define PREWALK 4096
 __device__ __forceinline__ void est_entry(const hvk_secam_args_t &a, const int t0, hvk_secam_state_t &S)
 {
 	int mp = t0 - 1;
