@@ -71,6 +71,7 @@ struct hvk_engine {
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
 	void *d_secam[17];          /* what sa points into (freed at close) */
+	int secam_est_ran, secam_ek_adapt, secam_ek_base, secam_ek_clean;      /* this stage ran the estimate; its reach (a.EK) follows the blocks */
 	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
 	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
 	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
@@ -863,6 +864,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				a.est = (int16_t *) e->d_secam[13];
 				a.ES = getenv("HVK_SECAM_EST_RUN") ? atoi(getenv("HVK_SECAM_EST_RUN")) : 4;
 				a.EK = getenv("HVK_SECAM_EST_LINES") ? atoi(getenv("HVK_SECAM_EST_LINES")) : 16;
+				e->secam_ek_adapt = getenv("HVK_SECAM_EST_LINES") == NULL;
+				e->secam_ek_base = a.EK;
 				if(a.ES < 1) a.ES = 1;
 				if(a.EK < 1) a.EK = 1;
 				/* a step's angle, src/video.c:2236 with :4080 */
@@ -1760,6 +1763,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
 		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, e->stream)) != HVK_OK) return(r);
 		if(e->secam_est && want) e->secam_est_stages++;
+		e->secam_est_ran = e->secam_est && want;
 	}
 	e->secam_counts[0] += a.total;
 
@@ -1789,6 +1793,15 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 				e->secam_patience = e->secam_patience * 2 < 64 ? e->secam_patience * 2 : 64;
 				e->secam_clean = 0;
 			}
+		}
+		if(rounds == 0 && e->secam_est_ran && e->secam_ek_adapt)
+		{
+			/* How far up an estimate has to start depends on the pictures too: where the values behind the lines forget
+			 * slowly (flat colours in the baseband modes) sixteen lines leave one start in a hundred wrong, twenty-four
+			 * one in a thousand. More than one in two hundred wrong: eight lines more (up to 48); sixteen clean blocks: eight
+			 * fewer again. */
+			if((int64_t) bad * a.R * 200 > a.total) { a.EK = a.EK + 8 < 48 ? a.EK + 8 : 48; e->secam_ek_clean = 0; }
+			else if(++e->secam_ek_clean >= 16 && a.EK > e->secam_ek_base) { a.EK -= 8; e->secam_ek_clean = 0; }
 		}
 		if(bad == 0) break;
 		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;
