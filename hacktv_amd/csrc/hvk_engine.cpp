@@ -1773,7 +1773,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
 		HIPCHK(hipStreamSynchronize(e->stream));
 		const int bad = *e->h_secam_count;
-		if(rounds == 0 && e->secam_adapt)
+		if(rounds == 0 && e->secam_adapt && !(e->secam_est && a.kf == NULL))     /* (no kept states and the estimate for every line: no warm-up length to follow) */
 		{
 			/* How many warm-up lines a start state needs depends on the pictures and costs a walk each. Exactness never
 			 * rests on it -- the check does -- so the number follows what the batches show, carefully: a wrong start costs

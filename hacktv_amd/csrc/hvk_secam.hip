@@ -113,8 +113,8 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 {
 	extern __shared__ __attribute__((aligned(16))) int16_t lds_all[];  /* per task: 8 zeros, W cells, 24 zeros */
 	const int W = a.C.W;
-	const int TH = (int) blockDim.x / CELLS_TASKS;      /* lanes of a task: a multiple of 64 */
-	const int sub = (int) threadIdx.x / TH;
+	const int TH = CELLS_TASKS == 1 ? (int) blockDim.x : (int) blockDim.x / CELLS_TASKS;      /* lanes of a task: a multiple of 64 */
+	const int sub = CELLS_TASKS == 1 ? 0 : (int) threadIdx.x / TH;
 	int16_t *lds = lds_all + sub * ((W + 32 + 7) & ~7);
 	/* (workgroups go to the 8 XCDs in turn; the 8 tasks whose outputs share 128 bytes of the transposed store go to ONE,
 	 * so that its L2 sees whole lines: workgroup b of XCD b % 8 is the (b / 8)-th there, and 8 / CELLS_TASKS of them make a group) */
@@ -122,12 +122,14 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 	constexpr int WPG = 8 / CELLS_TASKS;
 	const int slot_ = (((bj / WPG) * 8 + ((int) blockIdx.x & 7)) << 3) + (bj % WPG) * CELLS_TASKS + sub;
 	const bool in_list = slot_ < a.ntasks;
+	if(CELLS_TASKS == 1 && !in_list) return;
 	const int slot = in_list ? slot_ : a.ntasks - 1;
 	const int i = a.clist[blockIdx.y];
 	const int t = i * a.ntasks + slot;
 	const int cm = a.cbase[i] + slot;           /* the task's row in the cell stores */
 	const task_view v = task_of(a, t);
 	const int lane = (int) threadIdx.x - sub * TH, x0 = lane * SPL;
+	if(CELLS_TASKS == 1 && !v.valid) return;
 	const bool live = in_list && v.valid;       /* (a task that is none takes part in the barriers and writes nothing) */
 
 	int16_t c[SPL];
@@ -408,10 +410,11 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 				cam = SPL * (rr >> 16);
 			}
 		}
-		for(int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d); cph += __shfl_down(cph, d); cam += __shfl_down(cam, d); }
+		for(int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
 		if(wl == 0 && sum) atomicAdd(&s_sum, sum);
-		if(wl == 0 && cph) atomicAdd(&s_cph, cph);
-		if(wl == 0 && cam) atomicAdd(&s_cam, cam);
+		/* (the lanes that have something: in a picture that is not flat that is the blanking's few) */
+		if(cph) atomicAdd(&s_cph, cph);
+		if(cam) atomicAdd(&s_cam, cam);
 		__syncthreads();
 		if(live && lane == 0)
 		{
