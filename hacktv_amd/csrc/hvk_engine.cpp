@@ -1608,7 +1608,7 @@ static int _fm_upto(hvk_engine *e, size_t upto)
 {
 	_fm_wait_all(e);
 	if(upto <= e->fm_done) return(HVK_OK);
-	if(upto > (size_t) e->last_frames * e->t.k.frame_samples) return(HVK_ERROR);
+	if(upto > (size_t) e->last_samples) return(HVK_ERROR);      /* (frames of two lengths: what the batch's frames add up to, not frames x the longer one) */
 	const size_t n = upto - e->fm_done;
 	HIPCHK(hipMemcpyAsync(e->h_fm + e->fm_done * 2, e->d_out + e->fm_done * 2, n * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipStreamSynchronize(e->stream));
@@ -1622,7 +1622,7 @@ static int _fm_upto(hvk_engine *e, size_t upto)
 static int _fm_finish(hvk_engine *e)
 {
 	if(!e->fm_launched) return(HVK_OK);
-	int r = _fm_upto(e, (size_t) e->last_frames * e->t.k.frame_samples);
+	int r = _fm_upto(e, (size_t) e->last_samples);
 	if(r == HVK_OK) e->fm_launched = 0;
 	return(r);
 }
@@ -1997,8 +1997,8 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		 * thread: the next batch's host pre-passes run beside it) */
 		int r = _fm_finish(e);
 		if(r != HVK_OK) return(r);
-		if(stride != 1 || first_frame * FS != e->fm_batch_pos + (int64_t) e->fm_done) return(HVK_UNSUPPORTED);
-		e->fm_batch_pos = first_frame * FS;
+		if(stride != 1 || _fstart(e, first_frame) != e->fm_batch_pos + (int64_t) e->fm_done) return(HVK_UNSUPPORTED);
+		e->fm_batch_pos = _fstart(e, first_frame);
 		e->fm_done = 0;
 		e->fm_async_upto = 0;
 	}
@@ -2701,7 +2701,7 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 		e->fm_cv->notify_all();
 		e->fm_done = first + count;
 		e->fm_async_upto = e->fm_done;
-		if(e->fm_done == (size_t) e->last_frames * e->t.k.frame_samples) e->fm_launched = 0;
+		if(e->fm_done == (size_t) e->last_samples) e->fm_launched = 0;
 		e->fetch_busy[t] = 2;
 		return(t);
 	}

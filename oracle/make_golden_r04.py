@@ -41,6 +41,8 @@ CASES = [
     ("secamfm_px18", "secam_fm_tail", "secam-fm", 16000000, 18000000, ["--pixelrate", "18000000"], 0, False, 3, {}),
     ("ntscfm_f18_px135", "ntscfm_f18", "ntsc-fm", 18000000, 13500000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 3, {}),
     ("palfm_s14_px16", "pal_fm", "pal-fm", 14000000, 16000000, ["--pixelrate", "16000000"], 0, False, 3, {}),
+    # ... and at a rate pair with frames of two lengths (1017 x 525 x 9 / 8): the modulator's place in the stream is what the frames add up to
+    ("ntscfm_s18_px16", "ntsc_fm", "ntsc-fm", 18000000, 16000000, ["--pixelrate", "16000000"], 0, False, 5, {}),
 ]
 # mode, sample rate, flags: what differs from run to run
 UNDEFINED = [

@@ -47,6 +47,15 @@ SETUPS = {
     "l_level":     ("l", 16000000, R.FLAG_FILTER, H.FLAG_FILTER, {"level": 0.5, "gamma": 0.45}, 2, 0, {"level": 0.5, "gamma": 0.45}),
     # 44 frames: the anti-copy AGC level starts to move at frame 39; time code minutes stay 0 but seconds tick
     "i_acp_long":  ("i", 16000000, R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_VITC, H.FLAG_NOAUDIO, {"acp": 1, "vitc": 1}, 44),
+    # the other rasters with pictures that change: which picture a frame's first and last lines show (the mechanical ones
+    # scan vertically: the source's dimensions change places and the reference turns every picture, src/video.c:4883-4885)
+    "30_moving":   ("30", 750000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
+    "nbtv_moving": ("nbtv", 800000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
+    "240_moving":  ("240", 4800000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 3),
+    "405_moving":  ("405", 8100000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 3),
+    "819_moving":  ("819", 16380000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 3),
+    "apollo_mov":  ("apollo-fsc", 13500000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
+    "cbs_moving":  ("cbs405", 17496000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
 }
 
 
@@ -65,6 +74,9 @@ def main():
         w, h, L = info["active_width"], info["active_lines"], info["lines"]
         fields = 2 if members.get("interlace") else 1
         nsrc = min(nframes * fields + 2, 5)                  # shown in turn, over and over
+        turned = (int(conf.frame_orientation) & 3) in (1, 3)
+        if turned:
+            w, h = h, w                                      # (the source's dimensions: src/hacktv.c:1520-1526)
         frames = rng.integers(0, 1 << 24, (nsrc, h, w), dtype=np.uint32)
         frames[1, : h // 2] = 0xFFFFFF                       # white / saturated primaries: the level clamps
         frames[1, h // 2:, : w // 3] = 0xFF0000
@@ -82,10 +94,21 @@ def main():
         ref = r.render_lines(nframes * L)
         ghost_after = r.table("chroma_ghost", np.int16)
 
+    if int(conf.frame_orientation):
+        # the oracle (like the engine) is given the picture as the raster shows it
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from make_golden_rasters import oriented
+        frames = np.stack([oriented(f_, int(conf.frame_orientation)) for f_ in frames])
+
     with oracle.Oracle(conf, sr, pixel_rate) as o:
         o.set_ghost(ghost)
         o.set_audio(audio, True)
         out = []
+        # The oracle rasters ONE line ahead of what it hands out (a line's left sync pulse can begin in the line before it),
+        # with the picture set at that moment. Where a frame's first line shows picture (the 30- and 32-line rasters: every
+        # line does) the next frame's picture therefore has to be set before the frame's LAST line is asked for -- the
+        # reference reads it when it starts the frame's first line (src/video.c:4873-4881), which is the same moment.
+        early = mode in ("30", "30-am", "nbtv", "nbtv-am")
         for f in range(nframes):
             o.set_frame(frames[(f * fields) % nsrc])
             if fields == 2:
@@ -94,7 +117,9 @@ def main():
             c = cc[(f * fields) % nsrc]
             if (int(c[0]) | int(c[1])) & 0x7F:
                 o.set_cc608(f, int(c[0]), int(c[1]))
-            out.append(o.render_lines(L))
+            out.append(o.render_lines((L - 1 if f == 0 else L) if early else L))
+        if early:
+            out.append(o.render_lines(1))
         mine = np.concatenate(out)
 
     W = len(ref) // (nframes * L)          # the output line (differs from info["width"] with the resampler)

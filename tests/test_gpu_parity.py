@@ -633,7 +633,9 @@ def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch)
     assert st3["host_frames"] == 0 and st3["mismatches"] <= st3["tasks"] // 100, st3
 
 
-@pytest.mark.parametrize("case,batches", [("m_px135_s16", (1, 3, 1)), ("m_px135_s16", (5,)), ("ntsc_px16_s135", (2, 1, 1)), ("ntsc_px16_s135", (3, 1))])
+@pytest.mark.parametrize("case,batches", [("m_px135_s16", (1, 3, 1)), ("m_px135_s16", (5,)), ("ntsc_px16_s135", (2, 1, 1)), ("ntsc_px16_s135", (3, 1)),
+                                          # FM video: the modulator's place in the stream is what the frames add up to (found by tools/fuzz_parity.py)
+                                          ("ntscfm_s18_px16", (2, 2, 1)), ("ntscfm_s18_px16", (1, 3, 1)), ("ntscfm_s18_px16", (5,))])
 def test_frames_of_two_lengths(golden, case, batches):
     """--pixelrate pairs at which a raster frame is not a whole number of samples (858 x 525 x 32 / 27 up, 1017 x 525 x
     27 / 32 down): frames of two lengths one sample apart, a batch one run of samples (hvk_frame_start()). Batches of

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""tools/fuzz_parity.py [cases] [seed] [seconds] -- random configurations (any of the 44 mode ids, a rate the mode takes, a random
+set of the options that need no side input: --filter, --noaudio, --nonicam, A2 stereo, --pixelrate, S-Video, sound-in-syncs,
+VITS / VITC / WSS / ACP, field identification, --interlace, --offset, --swap-iq, levels computed or looked up), random pictures
+that change every frame, loud sound: the engine on the GPU against the oracle (which tests/ pin to the reference), three frames
+in batches of two and one, every sample. Configurations the engine refuses are counted, not failed. Run on the GPU box."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import hacktv_amd as H
+import oracle
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 240
+rng = np.random.default_rng(SEED)
+MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
+         "secam-g", "secam-fm", "secam", "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
+         "apollo-fsc-fm", "apollo-fsc", "apollo-fm", "apollo", "m-cbs405", "cbs405"]
+RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000000], 525: [13500000, 16000000, 14318181, 18000000, 27000000], 819: [24570000, 16380000],
+         405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
+done = refused = bad = 0
+t_start = time.time()
+case = 0
+while done < N and time.time() - t_start < LIMIT:
+    case += 1
+    mode = MODES[int(rng.integers(len(MODES)))]
+    try:
+        base = H.preset(mode, 0)
+    except H.HvkError:
+        continue
+    lines = int(base.lines)
+    if mode in ("m-cbs405", "cbs405"):
+        rates = [17496000]
+    else:
+        rates = RATES.get(lines, [16000000])
+    sr = int(rates[int(rng.integers(len(rates)))])
+    flags = 0
+    for f, p in ((H.FLAG_FILTER, 0.5), (H.FLAG_NOAUDIO, 0.35), (H.FLAG_NONICAM, 0.2)):
+        if rng.random() < p:
+            flags |= f
+    conf = H.preset(mode, flags)
+    opts = []
+    def maybe(name, value, p):
+        if rng.random() < p:
+            setattr(conf, name, value); opts.append("%s=%s" % (name, value)); return True
+        return False
+    if lines in (625, 525):
+        maybe("vits", 1, 0.2); maybe("vitc", 1, 0.2); maybe("acp", 1, 0.15)
+        if lines == 625:
+            maybe("wss", int(rng.integers(1, 9)), 0.2); maybe("sis", 1, 0.2)
+        maybe("interlace", 1, 0.12)
+        if mode in ("g", "b", "m") and not (flags & H.FLAG_NOAUDIO):
+            maybe("a2stereo", 1, 0.3)
+    if mode in ("l", "d", "k", "secam", "secam-fm", "secam-i", "secam-b", "secam-g"):
+        maybe("secam_field_id", 1, 0.5)
+    if mode in ("pal", "ntsc", "secam", "pal60", "525pal"):
+        maybe("s_video", 1, 0.3)
+    if base.output_type != 0 if hasattr(base, "output_type") else False:
+        pass
+    if rng.random() < 0.15: conf.swap_iq = 1; opts.append("swap_iq")
+    if rng.random() < 0.15: conf.offset = int(rng.integers(-8, 9)) * 50000 or 250000; opts.append("offset=%d" % conf.offset)
+    pr = 0
+    if lines in (625, 525) and rng.random() < 0.3:
+        cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
+        pr = int(cand[int(rng.integers(len(cand)))])
+    levels = int(rng.integers(1, 3))
+    desc = "%-13s %9d px %9d flags %d %s levels %d" % (mode, sr, pr, flags, " ".join(opts), levels)
+    try:
+        e = H.Engine(conf, sr, device=0, max_frames=2, pixel_rate=pr)
+    except H.HvkError as err:
+        refused += 1
+        print("refused  ", desc, flush=True)
+        continue
+    try:
+        with e:
+            w, h = e.info["active_width"], e.info["active_lines"]
+            fs = e.info["frame_samples"]
+            L = e.info["lines"]
+            nfr = 3
+            npic = nfr * (2 if conf.interlace else 1)
+            pics = []
+            for i in range(npic):
+                kind = int(rng.integers(4))
+                if kind == 0: p = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+                elif kind == 1: p = np.full((h, w), int(rng.integers(0, 1 << 24)), np.uint32)
+                elif kind == 2:
+                    yy, xx = np.mgrid[0:h, 0:w]
+                    p = ((((xx * 255 // max(w - 1, 1) + i * 9) % 256).astype(np.uint32) << 16) | (((yy * 255 // max(h - 1, 1)) % 256).astype(np.uint32) << 8) | ((xx + yy) % 256).astype(np.uint32))
+                else: p = None
+                pics.append(None if p is None else np.ascontiguousarray(p))
+            audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
+            with oracle.Oracle(conf, sr, pr) as o:
+                o.set_audio(audio, True)
+                o.set_frame_aspect(12, 13)
+                want = []
+                # (the oracle rasters one line ahead with the picture set at that moment: where a frame's first line shows
+                # picture the next picture is set before the frame's last line is asked for -- tests/ref_random_check.py)
+                early = mode in ("30", "30-am", "nbtv", "nbtv-am")
+                for f in range(nfr):
+                    if conf.interlace:
+                        o.set_frame(pics[2 * f] if pics[2 * f] is not None else np.zeros((0, 0), np.uint32)); o.set_frame2(pics[2 * f + 1] if pics[2 * f + 1] is not None else np.zeros((0, 0), np.uint32))
+                    else:
+                        o.set_frame(pics[f] if pics[f] is not None else np.zeros((0, 0), np.uint32))
+                    want.append(o.render_lines((L - 1 if f == 0 else L) if early else L))
+                if early:
+                    want.append(o.render_lines(1))
+                want = np.concatenate(want)
+            e.set_levels(levels)
+            got, fdone = [], 0
+            for n in (2, 1):
+                per = 2 if conf.interlace else 1
+                for i in range(n * per):
+                    e.frame_upload(i, pics[fdone * per + i])
+                    e.frame_aspect(i, 12, 13)
+                while e.audio_needed(n) > 0:
+                    e.audio_write(audio)
+                e.render(n, slots=list(range(n * per)))
+                cnt = e.frame_start(fdone + n) - e.frame_start(fdone)
+                got.append(e.fetch(0, cnt))
+                fdone += n
+            got = np.concatenate(got)
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad += 1
+            if got.shape == want.shape:
+                d = np.nonzero((got != want).any(axis=1))[0]
+                print("DIFFERENT", desc, "first at sample %d (line %d), %d samples" % (d[0], d[0] // max(e.info["width"], 1), d.size), flush=True)
+            else:
+                print("DIFFERENT", desc, "shapes", got.shape, want.shape, flush=True)
+        else:
+            print("equal    ", desc, flush=True)
+        done += 1
+    except Exception as ex:
+        bad += 1
+        print("ERROR    ", desc, repr(ex)[:200], flush=True)
+        done += 1
+print("%d compared, %d refused, %d bad, %.0f s" % (done, refused, bad, time.time() - t_start))
+sys.exit(1 if bad else 0)
