@@ -491,8 +491,9 @@ hvk_audio_t *hvk_audio_new(const hvk_tables_t *t)
 		a->sis.enc.reserve = 0;
 		/* invocation t needs the audio lines before t - 1 complete, line g is invocation g + 1 + dummies: its burst is known
 		 * once audio line g + dummies - 1 is through. A frame's render also wants the burst of the line BEHIND it (the video
-		 * filter looks into that line's first samples): the chains stay `dummies` lines ahead of the requests */
-		a->ahead = a->sis.dummies;
+		 * filter looks into that line's first samples): the chains stay `dummies` lines ahead of the requests -- one more
+		 * behind the resampler, whose output stands a raster line back: there the filter looks into the line after that */
+		a->ahead = a->sis.dummies + (t->k.rs_L ? 1 : 0);
 		_sis_invocation(a);                 /* the first one runs before any audio line has */
 	}
 

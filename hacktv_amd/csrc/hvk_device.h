@@ -208,7 +208,7 @@ typedef struct {
 	const int16_t *sis_dense;     /* sound-in-syncs: [50][HVK_SIS_SPAN] the half symbols as dense rows */
 	const int16_t *sis_win;       /*   the blanking window, k.sis_width values from sample k.sis_left */
 	const int16_t *sis_first;     /*   [HVK_SIS_SPAN] what the last never-emitted invocation leaves on the stream's first line */
-	const unsigned *sis_bits;     /*   [frames][lines + 1][2]: a line's burst (the last: the line behind the frame) -- 7 bytes of bits (MSB first), their number in the eighth */
+	const unsigned *sis_bits;     /*   [frames][lines + 1 (+ 2 with the resampler)][2]: a line's burst (the last: the line(s) behind the frame) -- 7 bytes of bits (MSB first), their number in the eighth */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const int16_t *linebase;      /* [rows][k.base_stride]: blanking + sync pulses of every kind of line */
@@ -899,10 +899,11 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 	 * sync area blanked to the sync level through a window, then the burst's half symbols added -- 46 or 50 bits, most
 	 * significant first, bit b shaped by entry 50 - nb + b (vbidata_render() passes over the first 50 - nb). All of it
 	 * lies in the line's first HVK_SIS_SPAN samples: the first wave's business. */
-	if(EXTRAS && k.sis && (own || rel == k.lines) && wx0 < HVK_SIS_SPAN)
+	if(EXTRAS && k.sis && (own || rel == k.lines || (k.rs_L && rel == k.lines + 1)) && wx0 < HVK_SIS_SPAN)
 	{
-		/* (also on the line behind the frame: the video filter of the frame's last samples looks into its first ones) */
-		const unsigned *rec = P.sis_bits + ((size_t) y * (k.lines + 1) + rel) * 2;
+		/* (also on the line behind the frame: the video filter of the frame's last samples looks into its first ones -- and
+		 * behind the resampler, whose output stands a line back (k.rs_shift), into the first ones of the line after that) */
+		const unsigned *rec = P.sis_bits + ((size_t) y * (k.lines + (k.rs_L ? 2 : 1)) + rel) * 2;
 		const unsigned w0 = __builtin_amdgcn_readfirstlane(rec[0]), w1 = __builtin_amdgcn_readfirstlane(rec[1]);
 		const int nb = (int) (w1 >> 24);
 		if(x0 < HVK_SIS_SPAN)

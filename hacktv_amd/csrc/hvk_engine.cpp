@@ -743,8 +743,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		OPENCHK(_upload(&e->d_sis_dense, e->t.sis_dense, sizeof(int16_t) * 50 * HVK_SIS_SPAN));
 		OPENCHK(_upload(&e->d_sis_win, e->t.sis_win, sizeof(int16_t) * k.sis_width));
 		OPENCHK(_upload(&e->d_sis_first, e->t.sis_first, sizeof(int16_t) * HVK_SIS_SPAN));
-		OPENHIP(hipMalloc((void **) &e->d_sis_bits, (size_t) max_frames * (k.lines + 1) * 8));
-		OPENHIP(hipHostMalloc((void **) &e->h_sis_bits, (size_t) max_frames * (k.lines + 1) * 8, hipHostMallocDefault));
+		OPENHIP(hipMalloc((void **) &e->d_sis_bits, (size_t) max_frames * (k.lines + 2) * 8));
+		OPENHIP(hipHostMalloc((void **) &e->h_sis_bits, (size_t) max_frames * (k.lines + 2) * 8, hipHostMallocDefault));
 	}
 
 	if(k.rawbb)
@@ -2039,7 +2039,9 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		{
 			/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
 			/* (and the first line's of the frame behind it: the filter of this frame's last samples looks into it) */
-			int r = hvk_audio_sis_fetch(e->audio, a_frame * k.lines, k.lines + 1, (uint8_t *) (e->h_sis_bits + (size_t) a_row * (k.lines + 1) * 2));
+			/* (behind the resampler the output stands a raster line back, k.rs_shift: the line after that one as well) */
+			const int rows = k.lines + (k.rs_L ? 2 : 1);
+			int r = hvk_audio_sis_fetch(e->audio, a_frame * k.lines, rows, (uint8_t *) (e->h_sis_bits + (size_t) a_row * rows * 2));
 			if(r != HVK_OK) { e->poisoned = 1; return(r); }
 		}
 
@@ -2278,7 +2280,7 @@ static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nfra
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
-	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + 1) * 8, hipMemcpyHostToDevice, e->stream));
+	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + (k.rs_L ? 2 : 1)) * 8, hipMemcpyHostToDevice, e->stream));
 	e->staged_samples = _fstart(e, first_frame + nframes) - _fstart(e, first_frame);     /* (nframes * FS but for frames of two lengths) */
 	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));

@@ -31,7 +31,7 @@ typedef struct {
 	const int16_t *vits_l, *vits_c;
 	const int16_t *fsc_rows;    /* field-sequential colour flag pulses */
 	const int16_t *sis_dense, *sis_win, *sis_first;     /* sound-in-syncs tables */
-	const unsigned *sis_bits;   /* [nframes][lines + 1][2] */
+	const unsigned *sis_bits;   /* [nframes][lines + 1 (+ 2 with the resampler)][2] */
 	const hvk_linedesc_t *desc;
 	const int16_t *pulses;
 	const int16_t *linebase;    /* [nbase][k.base_stride] */

@@ -294,7 +294,9 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 			 * with :4665-4667). Both are D'r or D'b alike: the second finds the OTHER component
 			 * of the first kept */
 			const int dr = (frame * s->lines) & 1;
-			_cells_fir(s, NULL, dr ? 1 : 0, i == 1, dr ? 0 : 1, NULL, NULL, k->active_width, 0, s->F + (size_t) i * W, s->acc + (size_t) i * 8);
+			/* (with the place and width of the picture in force, the stream's first, and no row of it: none for an empty frame) */
+			const int fw = fb1 ? fb1_width : 0;
+			_cells_fir(s, NULL, dr ? 1 : 0, i == 1, dr ? 0 : 1, NULL, NULL, fw, (k->active_width - fw) / 2, s->F + (size_t) i * W, s->acc + (size_t) i * 8);
 			continue;
 		}
 		{

@@ -6,6 +6,7 @@ Round 4: the combinations the engine used to refuse. Adds to tests/golden/ref_di
   pal_sv_sis     hacktv_ref -m pal -s 16000000 --s-video --sis dcsis            (sound-in-syncs beside the sub-carrier's own channel)
   i_rawbb_sis    hacktv_ref -m i -s 16000000 --filter --raw-bb-file ... --sis dcsis   (the burst on a line that was not drawn from a picture)
   i_sis_px135    hacktv_ref -m i -s 16000000 --filter --sis dcsis --pixelrate 13500000   (the burst drawn at the pixel rate, resampled)
+  l_sis_px16_s14 hacktv_ref -m l -s 14000000 --filter --sis dcsis --pixelrate 16000000   (downwards: the filter reaches the next frame's second line)
 
 and writes tests/golden/ref_undefined.json: configurations whose output the reference does not define -- the runs'
 digests differ from one run of the same binary to the next (uninitialised memory the FM modulator then carries along
@@ -34,6 +35,9 @@ CASES = [
      {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000, "sis": 1}),
     ("i_sis_px135", "i_px135", "i", 16000000, 13500000, ["--filter", "--sis", "dcsis", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 6, {"sis": 1}),
     ("i_sis_px2025", "i_px2025", "i", 16000000, 20250000, ["--sis", "dcsis", "--pixelrate", "20250000"], 0, False, 6, {"sis": 1}),
+    # ... downwards with the filter on: the filter of a frame's last samples looks past the resampler's one-line lag into the burst of the
+    # SECOND line of the next frame
+    ("l_sis_px16_s14", "l_full", "l", 14000000, 16000000, ["--filter", "--sis", "dcsis", "--pixelrate", "16000000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
     # FM video behind the resampler: the never-emitted start-up samples the modulator runs over are the resampled first raster line
     # (and the filter's output over it) -- up and down, with and without the pre-emphasis filter
     ("palfm_px135", "pal_fm", "pal-fm", 16000000, 13500000, ["--pixelrate", "13500000"], 0, False, 3, {}),

@@ -33,6 +33,9 @@
 #define REF_FLAG_ACP      (1 << 8)
 #define REF_FLAG_VITS     (1 << 9)
 #define REF_FLAG_VITC     (1 << 10)
+#define REF_FLAG_SVIDEO   (1 << 11)
+#define REF_FLAG_SECAM_FID (1 << 12)
+#define REF_FLAG_SIS      (1 << 13)
 
 typedef struct {
 	vid_t vid;
@@ -96,6 +99,10 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 	if(flags & REF_FLAG_ACP) conf.acp = 1;
 	if(flags & REF_FLAG_VITS) conf.vits = 1;
 	if(flags & REF_FLAG_VITC) conf.vitc = 1;
+	/* src/hacktv.c:1136-1147, :1417-1425, :1436 */
+	if(flags & REF_FLAG_SVIDEO) conf.s_video = 1;
+	if(flags & REF_FLAG_SECAM_FID) conf.secam_field_id = 1;
+	if(flags & REF_FLAG_SIS) conf.sis = "dcsis";
 	if(teletext && teletext[0]) conf.teletext = (char *) teletext;
 	conf.volume = 1.0 * 256 + 0.5;
 	if(_override.gamma > 0) conf.gamma = _override.gamma;
@@ -157,11 +164,22 @@ typedef struct {
 } _src_t;
 
 static _src_t _src;
+static unsigned _blank_mask;
+
+/* frames (by their place in the stream, the first 32) the source has no picture for; applies to the next ref_set_source() */
+void ref_blank_frames(unsigned mask) { _blank_mask = mask; }
 
 static int _src_read_video(void *ctx, av_frame_t *frame)
 {
 	_src_t *c = ctx;
 	const int i = c->pos % c->nframes;
+	if(c->pos < 32 && ((_blank_mask >> c->pos) & 1))
+	{
+		/* no picture for this frame: what av_read_video() hands out without a source (src/av.c:50-53) */
+		av_frame_init(frame, 0, 0, NULL, 0, 0);
+		c->pos++;
+		return(AV_OK);
+	}
 	av_frame_init(frame, c->width, c->height, (uint32_t *) c->frames + (size_t) i * c->width * c->height, 1, c->width);
 	frame->interlaced = c->interlaced;
 	frame->pixel_aspect_ratio = (r64_t) { c->par_num, c->par_den };

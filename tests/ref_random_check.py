@@ -56,6 +56,16 @@ SETUPS = {
     "819_moving":  ("819", 16380000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 3),
     "apollo_mov":  ("apollo-fsc", 13500000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
     "cbs_moving":  ("cbs405", 17496000, R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, {}, 4),
+    # frames the source has no picture for (src/av.c:50-53), S-Video's second channel, SECAM's field identification lines
+    "secam_sv_blank": ("secam", 14000000, R.FLAG_NONICAM | R.FLAG_SVIDEO | R.FLAG_SECAM_FID, H.FLAG_NONICAM, {"s_video": 1, "secam_field_id": 1}, 3, 0, {"blank": 0b101}),
+    "secam_sv_16":    ("secam", 16000000, R.FLAG_NONICAM | R.FLAG_SVIDEO | R.FLAG_SECAM_FID, H.FLAG_NONICAM, {"s_video": 1, "secam_field_id": 1}, 3, 0, {"blank": 0b101}),
+    # NOT in the test list: sound-in-syncs with sound that differs from block to block. The reference hands 32-sample blocks from
+    # its audio thread to the burst encoder on the main thread without a lock (src/sis.c:217-221, src/video.c:3370-3373); which
+    # block a frame encode sees depends on which thread is further into the step. The oracle's reading (hand-overs of earlier
+    # steps only) is the reference's through the first seven encodes here (lines 1-124, three runs alike) and differs in about a
+    # third of the lines after that; with the test tone, whose blocks are alike, both are the same for good (tests/golden).
+    "l_sis_px16_14":  ("l", 14000000, R.FLAG_FILTER | R.FLAG_SIS, H.FLAG_FILTER, {"sis": 1}, 3, 16000000),
+    "i_sis_loud":     ("i", 16000000, R.FLAG_FILTER | R.FLAG_SIS, H.FLAG_FILTER, {"sis": 1}, 3),
 }
 
 
@@ -63,7 +73,8 @@ def main():
     name = sys.argv[1]
     mode, sr, pflags, hflags, members, nframes = SETUPS[name][:6]
     pixel_rate = SETUPS[name][6] if len(SETUPS[name]) > 6 else 0
-    override = SETUPS[name][7] if len(SETUPS[name]) > 7 else {}
+    override = dict(SETUPS[name][7]) if len(SETUPS[name]) > 7 else {}
+    blank = override.pop("blank", 0)
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
     conf = H.preset(mode, hflags)
     for k, v in members.items():
@@ -89,7 +100,7 @@ def main():
         cc = rng.integers(0, 256, (nsrc, 2), dtype=np.int64).astype(np.uint8)
         cc[1] = 0
         par = (16, 11) if name == "i_wss_auto" else (1, 1)
-        r.set_source(frames, audio, par=par, cc=cc)
+        r.set_source(frames, audio, par=par, cc=cc, blank=blank)
         ghost = r.table("chroma_ghost", np.int16)
         ref = r.render_lines(nframes * L)
         ghost_after = r.table("chroma_ghost", np.int16)
@@ -103,6 +114,8 @@ def main():
     with oracle.Oracle(conf, sr, pixel_rate) as o:
         o.set_ghost(ghost)
         o.set_audio(audio, True)
+        if os.environ.get("REF_CHECK_VISIBLE"):
+            o.set_sis_visible(int(os.environ["REF_CHECK_VISIBLE"]))
         out = []
         # The oracle rasters ONE line ahead of what it hands out (a line's left sync pulse can begin in the line before it),
         # with the picture set at that moment. Where a frame's first line shows picture (the 30- and 32-line rasters: every
@@ -110,7 +123,7 @@ def main():
         # reference reads it when it starts the frame's first line (src/video.c:4873-4881), which is the same moment.
         early = mode in ("30", "30-am", "nbtv", "nbtv-am")
         for f in range(nframes):
-            o.set_frame(frames[(f * fields) % nsrc])
+            o.set_frame(frames[(f * fields) % nsrc] if not (blank >> f) & 1 else np.zeros((0, 0), np.uint32))
             if fields == 2:
                 o.set_frame2(frames[(f * fields + 1) % nsrc])
             o.set_frame_aspect(*par)
@@ -149,6 +162,9 @@ def main():
             print("EQUAL-EXCEPT-LINE-ENDS (%d of %d samples compared; the over-read bytes were not stable)" % (keep.sum(), len(ref)))
             return
     d = np.nonzero((ref != mine).any(axis=1))[0]
+    if os.environ.get("REF_CHECK_VERBOSE"):
+        x = d % W
+        print("x range of the differences %d..%d; lines %d; largest difference %d" % (x.min(), x.max(), len(np.unique(d // W)), np.abs(ref[d].astype(int) - mine[d].astype(int)).max()))
     print("DIFFERENT %d samples, first at line %d x %d: ref %s oracle %s" % (len(d), d[0] // W, d[0] % W, ref[d[0]].tolist(), mine[d[0]].tolist()))
 
 

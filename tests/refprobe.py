@@ -14,6 +14,7 @@ BIN_PATH = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
 
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
 FLAG_INTERLACE, FLAG_A2STEREO, FLAG_CC608, FLAG_WSS_AUTO, FLAG_ACP, FLAG_VITS, FLAG_VITC = 16, 32, 64, 128, 256, 512, 1024
+FLAG_SVIDEO, FLAG_SECAM_FID, FLAG_SIS = 2048, 4096, 8192
 
 INFO_NAMES = [
     "width", "half_width", "active_width", "active_left", "lines", "active_lines",
@@ -71,8 +72,9 @@ class RefProbe:
         n = lib().ref_info(self.p, v.ctypes.data, 64)
         self.info = dict(zip(INFO_NAMES, v[:n].tolist()))
 
-    def set_source(self, frames, audio, interlaced=0, par=(1, 1), cc=None):
-        """Replace the test source: frames [n][h][w] RGBx shown in turn, audio [m][2] looped."""
+    def set_source(self, frames, audio, interlaced=0, par=(1, 1), cc=None, blank=0):
+        """Replace the test source: frames [n][h][w] RGBx shown in turn, audio [m][2] looped; `blank`: bit f set = the stream's frame f has no picture."""
+        lib().ref_blank_frames(blank)
         f = np.ascontiguousarray(frames, np.uint32)
         a = np.ascontiguousarray(audio, np.int16)
         c = np.ascontiguousarray(cc, np.uint8) if cc is not None else None

@@ -64,7 +64,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
-                                  "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025",
+                                  "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14",
                                   "palfm_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16",
                                   "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
                                   "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
@@ -385,7 +385,7 @@ def test_dropin_binary_equals_reference_cli(golden):
                  "m_px135_s16", "ntsc_px16_s135", "m_4fsc", "pal_9m",
                  "e_full", "405_bb", "240_bb", "30_bb", "nbtv_bb", "apollofm", "apollofsc_bb", "mcbs405_full",
                  # round 4: the combinations that used to be refused, and ntsc-a
-                 "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "palfm_px135", "palfm_f14_px135", "secamfm_px18", "palfm_s14_px16", "ntsca_full"):
+                 "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "palfm_px135", "palfm_f14_px135", "secamfm_px18", "palfm_s14_px16", "ntsca_full"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4
@@ -558,6 +558,49 @@ def test_secam_pictures_whose_lines_do_not_forget(golden, monkeypatch, mode, kin
     got, st = run()
     assert np.array_equal(got, want)
     assert st["host_frames"] == 0, st
+
+
+@pytest.mark.parametrize("mode,sr,sv", [("secam", 14000000, 1), ("secam", 13500000, 1), ("l", 16000000, 0), ("secam-fm", 16000000, 0)])
+@pytest.mark.parametrize("first", ["none", "narrow"])
+def test_secam_stream_that_starts_without_a_full_picture(first, mode, sr, sv):
+    """SECAM: the two never-emitted slots the line pipeline hands the colour process before the stream's first line are
+    picture lines with the place and width of the picture in force then -- the stream's first -- and no row of it
+    (src/video.c:3135-3197 with vy = -1; tests/ref_random_check.py secam_sv_blank has the reference on it). A stream that
+    starts with no picture at all or with a narrow one: the values the two slots leave are not those of a full-width
+    picture, and the first lines with sub-carrier (the field identification's) show it. Every sample is the oracle's, by
+    the device's chain and by the host's."""
+    import os
+    conf = H.preset(mode, H.FLAG_NOAUDIO | H.FLAG_NONICAM)
+    conf.secam_field_id = 1
+    conf.s_video = sv
+    out = {}
+    for host in (0, 1):
+        rng = np.random.default_rng(3)
+        if host: os.environ["HVK_SECAM_HOST"] = "1"
+        try:
+            with H.Engine(conf, sr, device=0, max_frames=2) as e:
+                w, h, L = e.info["active_width"], e.info["active_lines"], e.info["lines"]
+                full = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+                narrow = np.ascontiguousarray(full[:, : (w // 3) & ~1])
+                pics = [None if first == "none" else narrow, full, narrow if first == "none" else None]
+                got, f = [], 0
+                for n in (2, 1):
+                    for i in range(n):
+                        e.frame_upload(i, pics[f + i])
+                    e.render(n, slots=list(range(n)))
+                    got.append(e.fetch(0, e.frame_start(f + n) - e.frame_start(f)))
+                    f += n
+                out[host] = np.concatenate(got)
+        finally:
+            os.environ.pop("HVK_SECAM_HOST", None)
+    with oracle.Oracle(conf, sr) as o:
+        want = []
+        for p in pics:
+            o.set_frame(p if p is not None else np.zeros((0, 0), np.uint32))
+            want.append(o.render_lines(L))
+        want = np.concatenate(want)
+    assert np.array_equal(out[1], want)
+    assert np.array_equal(out[0], want)
 
 
 def test_secam_cells_of_a_picture_are_kept_and_made_again_when_it_changes(golden, monkeypatch):

@@ -298,7 +298,7 @@ def test_passthru_needs_whole_lines_and_stays_ended(golden):
     assert np.array_equal(a[:W], ref[:W] + 1) and np.array_equal(a[W:], ref[W:3 * W]) and np.array_equal(b, ref[3 * W:])
 
 
-@pytest.mark.parametrize("case", ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025"])
+@pytest.mark.parametrize("case", ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14"])
 @pytest.mark.parametrize("loud", [False, True])
 def test_sound_in_syncs_bursts_equal_the_oracles(golden, case, loud):
     """--sis: the bits of every line's burst (hvk_host_sis_bursts(): the host half, framing in step with the sound chains)

@@ -21,7 +21,7 @@ CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_f
 CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster", "ntsci_full",
                  "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m"]
 # sound-in-syncs: a NICAM stream of its own inside every sync pulse (oracle/make_golden_sis.py: ten runs of the reference, one output)
-CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025"]
+CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14"]
 # rates outside the first rounds' 11 .. 28 MHz: chroma filters of 7, 19, 23 taps (oracle/make_golden_rates.py)
 CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"]
 # the rasters other than 625 / 525 lines and field-sequential colour (oracle/make_golden_rasters.py)

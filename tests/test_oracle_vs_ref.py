@@ -101,7 +101,8 @@ def test_oracle_long_run_equals_cli(golden, mode, sr, flags, pflags):
                                    "i_px_moving", "palfm_loud", "secamfm_mov",
                                    "i_vbi_135", "m_16m", "l_2025", "g_a2_2025",
                                    "i_gamma_lvl", "m_invert", "l_level",
-                                   "30_moving", "nbtv_moving", "240_moving", "405_moving", "819_moving", "apollo_mov", "cbs_moving"])
+                                   "30_moving", "nbtv_moving", "240_moving", "405_moving", "819_moving", "apollo_mov", "cbs_moving",
+                                   "secam_sv_blank", "secam_sv_16"])
 def test_random_source_through_the_real_reference(setup):
     """The unmodified reference, in-process, on a source of our own (tests/ref_random_check.py): random
     pictures that change every frame or field, saturated colours, full-scale noise and clipped bursts as

@@ -14,6 +14,7 @@ import oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 240
+ONLY = os.environ.get("FUZZ_ONLY", "")      # compare only the cases whose description holds this
 rng = np.random.default_rng(SEED)
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
          "secam-g", "secam-fm", "secam", "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
@@ -91,6 +92,9 @@ while done < N and time.time() - t_start < LIMIT:
                 else: p = None
                 pics.append(None if p is None else np.ascontiguousarray(p))
             audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
+            if ONLY and ONLY not in desc:       # (the random draws made: the cases behind it are the same ones)
+                done += 1
+                continue
             with oracle.Oracle(conf, sr, pr) as o:
                 o.set_audio(audio, True)
                 o.set_frame_aspect(12, 13)
@@ -125,7 +129,8 @@ while done < N and time.time() - t_start < LIMIT:
             bad += 1
             if got.shape == want.shape:
                 d = np.nonzero((got != want).any(axis=1))[0]
-                print("DIFFERENT", desc, "first at sample %d (line %d), %d samples" % (d[0], d[0] // max(e.info["width"], 1), d.size), flush=True)
+                print("DIFFERENT", desc, "first at sample %d (line %d), last %d, %d samples; got %s want %s; pictures %s" % (d[0], d[0] // max(e.info["width"], 1), d[-1], d.size, got[d[0]].tolist(), want[d[0]].tolist(),
+                      ["none" if p is None else ("flat" if (p == p.flat[0]).all() else "varied") for p in pics]), flush=True)
             else:
                 print("DIFFERENT", desc, "shapes", got.shape, want.shape, flush=True)
         else:
