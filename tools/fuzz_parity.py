@@ -14,6 +14,7 @@ import oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 240
+EXTRA = os.environ.get("FUZZ_PLAIN", "") == ""     # pictures' interlace flags, caption bytes, other batch splits (draws more random numbers)
 ONLY = os.environ.get("FUZZ_ONLY", "")      # compare only the cases whose description holds this
 rng = np.random.default_rng(SEED)
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
@@ -49,6 +50,7 @@ while done < N and time.time() - t_start < LIMIT:
         return False
     if lines in (625, 525):
         maybe("vits", 1, 0.2); maybe("vitc", 1, 0.2); maybe("acp", 1, 0.15)
+        if lines == 525 and EXTRA: maybe("cc608", 1, 0.25)
         if lines == 625:
             maybe("wss", int(rng.integers(1, 9)), 0.2); maybe("sis", 1, 0.2)
         maybe("interlace", 1, 0.12)
@@ -69,7 +71,7 @@ while done < N and time.time() - t_start < LIMIT:
     levels = int(rng.integers(1, 3))
     desc = "%-13s %9d px %9d flags %d %s levels %d" % (mode, sr, pr, flags, " ".join(opts), levels)
     try:
-        e = H.Engine(conf, sr, device=0, max_frames=2, pixel_rate=pr)
+        e = H.Engine(conf, sr, device=0, max_frames=3, pixel_rate=pr)
     except H.HvkError as err:
         refused += 1
         print("refused  ", desc, flush=True)
@@ -83,14 +85,22 @@ while done < N and time.time() - t_start < LIMIT:
             npic = nfr * (2 if conf.interlace else 1)
             pics = []
             for i in range(npic):
-                kind = int(rng.integers(4))
+                kind = int(rng.integers(5))
                 if kind == 0: p = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
                 elif kind == 1: p = np.full((h, w), int(rng.integers(0, 1 << 24)), np.uint32)
                 elif kind == 2:
                     yy, xx = np.mgrid[0:h, 0:w]
                     p = ((((xx * 255 // max(w - 1, 1) + i * 9) % 256).astype(np.uint32) << 16) | (((yy * 255 // max(h - 1, 1)) % 256).astype(np.uint32) << 8) | ((xx + yy) % 256).astype(np.uint32))
-                else: p = None
+                elif kind == 3: p = None
+                else:
+                    # a picture of another size: narrower, shorter (centred, src/video.c:4896-4897)
+                    ww, hh = int(rng.integers(2, w + 1)), int(rng.integers(1, h + 1))
+                    p = rng.integers(0, 1 << 24, (hh, ww), dtype=np.uint32)
                 pics.append(None if p is None else np.ascontiguousarray(p))
+            # (the pictures' interlace flag: which field the source says comes first, src/video.c:3081-3084)
+            ilace = [int(rng.integers(3)) if EXTRA else 0 for _ in range(npic)]
+            cc = rng.integers(0, 256, (nfr, 2)) if (EXTRA and conf.cc608) else None
+            split = [(2, 1), (1, 2), (3,), (1, 1, 1)][int(rng.integers(4))] if EXTRA else (2, 1)
             audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
             if ONLY and ONLY not in desc:       # (the random draws made: the cases behind it are the same ones)
                 done += 1
@@ -104,20 +114,25 @@ while done < N and time.time() - t_start < LIMIT:
                 early = mode in ("30", "30-am", "nbtv", "nbtv-am")
                 for f in range(nfr):
                     if conf.interlace:
-                        o.set_frame(pics[2 * f] if pics[2 * f] is not None else np.zeros((0, 0), np.uint32)); o.set_frame2(pics[2 * f + 1] if pics[2 * f + 1] is not None else np.zeros((0, 0), np.uint32))
+                        o.set_frame(pics[2 * f] if pics[2 * f] is not None else np.zeros((0, 0), np.uint32), ilace[2 * f]); o.set_frame2(pics[2 * f + 1] if pics[2 * f + 1] is not None else np.zeros((0, 0), np.uint32), ilace[2 * f + 1])
                     else:
-                        o.set_frame(pics[f] if pics[f] is not None else np.zeros((0, 0), np.uint32))
+                        o.set_frame(pics[f] if pics[f] is not None else np.zeros((0, 0), np.uint32), ilace[f])
+                    if cc is not None and (int(cc[f][0]) | int(cc[f][1])) & 0x7F:
+                        o.set_cc608(f, int(cc[f][0]), int(cc[f][1]))
                     want.append(o.render_lines((L - 1 if f == 0 else L) if early else L))
                 if early:
                     want.append(o.render_lines(1))
                 want = np.concatenate(want)
             e.set_levels(levels)
             got, fdone = [], 0
-            for n in (2, 1):
+            for n in split:
                 per = 2 if conf.interlace else 1
                 for i in range(n * per):
-                    e.frame_upload(i, pics[fdone * per + i])
+                    e.frame_upload(i, pics[fdone * per + i], ilace[fdone * per + i])
                     e.frame_aspect(i, 12, 13)
+                if cc is not None:
+                    for i in range(n):
+                        e.cc608_write(i, int(cc[fdone + i][0]), int(cc[fdone + i][1]))
                 while e.audio_needed(n) > 0:
                     e.audio_write(audio)
                 e.render(n, slots=list(range(n * per)))
@@ -130,7 +145,7 @@ while done < N and time.time() - t_start < LIMIT:
             if got.shape == want.shape:
                 d = np.nonzero((got != want).any(axis=1))[0]
                 print("DIFFERENT", desc, "first at sample %d (line %d), last %d, %d samples; got %s want %s; pictures %s" % (d[0], d[0] // max(e.info["width"], 1), d[-1], d.size, got[d[0]].tolist(), want[d[0]].tolist(),
-                      ["none" if p is None else ("flat" if (p == p.flat[0]).all() else "varied") for p in pics]), flush=True)
+                      ["none" if p is None else ("flat" if (p == p.flat[0]).all() else "varied") + " %dx%d" % (p.shape[1], p.shape[0]) for p in pics]), "interlace flags", ilace, "batches", split, flush=True)
             else:
                 print("DIFFERENT", desc, "shapes", got.shape, want.shape, flush=True)
         else:
