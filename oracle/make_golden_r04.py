@@ -38,6 +38,9 @@ CASES = [
     # ... downwards with the filter on: the filter of a frame's last samples looks past the resampler's one-line lag into the burst of the
     # SECOND line of the next frame
     ("l_sis_px16_s14", "l_full", "l", 14000000, 16000000, ["--filter", "--sis", "dcsis", "--pixelrate", "16000000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
+    # --raw-bb-file in a SECAM mode: the reference adds no colour process at all beside the line reader (src/video.c:4190 against :4206-4212)
+    ("l_rawbb", "l_full", "l", 16000000, 16000000, ["--filter"] + RAWBB + ["--secam-field-id"], refprobe.FLAG_FILTER, False, 3,
+     {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000, "secam_field_id": 1}),
     # FM video behind the resampler: the never-emitted start-up samples the modulator runs over are the resampled first raster line
     # (and the filter's output over it) -- up and down, with and without the pre-emphasis filter
     ("palfm_px135", "pal_fm", "pal-fm", 16000000, 13500000, ["--pixelrate", "13500000"], 0, False, 3, {}),

@@ -293,7 +293,8 @@ static void _raster_until(orc_t *s, long last, long keep_from)
 		 * the first real line the process is handed two never-emitted slots
 		 * with frame 1, line 0, which it treats as picture lines without a
 		 * picture; they advance its IIR state. */
-		if(s->conf.colour_mode == HVK_SECAM)
+		/* (not with --raw-bb-file: the line reader stands where the raster AND the colour process would, src/video.c:4190) */
+		if(s->conf.colour_mode == HVK_SECAM && !s->conf.raw_bb)
 		{
 			int frame, line, la, ra, vy;
 

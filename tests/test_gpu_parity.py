@@ -60,7 +60,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
                                   "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv",
-                                  "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb",
+                                  "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb",
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
@@ -380,7 +380,7 @@ def test_dropin_binary_equals_reference_cli(golden):
     util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
     util.rawbb_signal().tofile("/tmp/hvk_rawbb.bin")
     for case in ("i_full", "pal_bb", "m_full", "l_full", "l_tt", "i_swap_pass", "pal_fm_pass", "secam_fm_tail",
-                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid", "i_rawbb",
+                 "i_px135", "pal_px135_s136", "i_vbi_tt", "m_vbi", "i_acp_cc", "ntsc_sv_f", "l_fid", "i_rawbb", "l_rawbb",
                  "i_rawbb_px16", "pal_rawbb_px135", "i_sis_filter", "ntsc_sv_f_px18", "i_pass_px135", "palm_full", "d_full", "ntsci_full", "pal60_bb", "palfm_f14", "palfm_f14_tail",
                  "m_px135_s16", "ntsc_px16_s135", "m_4fsc", "pal_9m",
                  "e_full", "405_bb", "240_bb", "30_bb", "nbtv_bb", "apollofm", "apollofsc_bb", "mcbs405_full",

@@ -16,7 +16,7 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_rawbb_px135", "i_rawbb_px16", "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136", "m_px135_s16", "ntsc_px16_s135"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
 CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
-CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb"]
+CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb"]
 # the other 625 / 525-line presets; FM video with its pre-emphasis filter
 CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster", "ntsci_full",
                  "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m"]

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """tools/fuzz_parity.py [cases] [seed] [seconds] -- random configurations (any of the 44 mode ids, a rate the mode takes, a random
 set of the options that need no side input: --filter, --noaudio, --nonicam, A2 stereo, --pixelrate, S-Video, sound-in-syncs,
-VITS / VITC / WSS / ACP, field identification, --interlace, --offset, --swap-iq, levels computed or looked up), random pictures
-that change every frame, loud sound: the engine on the GPU against the oracle (which tests/ pin to the reference), three frames
-in batches of two and one, every sample. Configurations the engine refuses are counted, not failed. Run on the GPU box."""
+VITS / VITC / WSS / ACP / CC608, field identification, --interlace, --offset, --swap-iq, --gamma / --level / --invert-video /
+--volume, teletext packets, --passthru, --raw-bb-file, levels computed or looked up), random pictures that change every frame
+(noise, flat, gradients, none, other sizes, either field-order flag), loud sound: the engine on the GPU against the oracle (which tests/ pin to the reference), three frames
+in a random batch split, every sample. FUZZ_ONLY=text compares only the cases whose description holds the text. Configurations the engine refuses are counted, not failed. Run on the GPU box."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +16,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 240
 EXTRA = os.environ.get("FUZZ_PLAIN", "") == ""     # pictures' interlace flags, caption bytes, other batch splits (draws more random numbers)
+SIDE = os.environ.get("FUZZ_NO_SIDE", "") == ""    # --gamma / --level / --invert-video / --volume, teletext packets, --passthru, --raw-bb-file
 ONLY = os.environ.get("FUZZ_ONLY", "")      # compare only the cases whose description holds this
 rng = np.random.default_rng(SEED)
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
@@ -62,6 +64,16 @@ while done < N and time.time() - t_start < LIMIT:
         maybe("s_video", 1, 0.3)
     if base.output_type != 0 if hasattr(base, "output_type") else False:
         pass
+    tt = pt = rb = False
+    if SIDE:
+        if rng.random() < 0.15: conf.gamma = float(rng.uniform(0.4, 2.6)); opts.append("gamma=%.3f" % conf.gamma)
+        if rng.random() < 0.15: conf.level = float(conf.level * rng.uniform(0.3, 1.0)); opts.append("level=%.3f" % conf.level)
+        maybe("invert_video", 1, 0.1)
+        maybe("volume", int(rng.integers(64, 700)), 0.15)
+        if lines == 625: tt = maybe("teletext", 1, 0.15)
+        pt = maybe("passthru", 1, 0.1)
+        if lines in (625, 525) and not tt and rng.random() < 0.08:
+            conf.raw_bb = 1; conf.raw_bb_blanking_level = 2000; conf.raw_bb_white_level = 21000; rb = True; opts.append("raw_bb")
     if rng.random() < 0.15: conf.swap_iq = 1; opts.append("swap_iq")
     if rng.random() < 0.15: conf.offset = int(rng.integers(-8, 9)) * 50000 or 250000; opts.append("offset=%d" % conf.offset)
     pr = 0
@@ -102,12 +114,20 @@ while done < N and time.time() - t_start < LIMIT:
             cc = rng.integers(0, 256, (nfr, 2)) if (EXTRA and conf.cc608) else None
             split = [(2, 1), (1, 2), (3,), (1, 1, 1)][int(rng.integers(4))] if EXTRA else (2, 1)
             audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
+            ttp = [(rng.integers(0, 256, (32, 45), dtype=np.uint8), int(rng.integers(0, 1 << 32))) for _ in range(nfr)] if tt else None
+            pti = rng.integers(-3000, 3000, (int(fs * 2.4) + 17, 2)).astype(np.int16) if pt else None
+            rbs = None
+            if rb:
+                rbs = rng.integers(300, 24000, (e.info["width"] * L + 311,)).astype(np.int16)
+                rbs = np.tile(rbs, (nfr + 2))
             if ONLY and ONLY not in desc:       # (the random draws made: the cases behind it are the same ones)
                 done += 1
                 continue
             with oracle.Oracle(conf, sr, pr) as o:
                 o.set_audio(audio, True)
                 o.set_frame_aspect(12, 13)
+                if pti is not None: o.set_passthru(pti)
+                if rbs is not None: o.set_rawbb(rbs)
                 want = []
                 # (the oracle rasters one line ahead with the picture set at that moment: where a frame's first line shows
                 # picture the next picture is set before the frame's last line is asked for -- tests/ref_random_check.py)
@@ -117,6 +137,7 @@ while done < N and time.time() - t_start < LIMIT:
                         o.set_frame(pics[2 * f] if pics[2 * f] is not None else np.zeros((0, 0), np.uint32), ilace[2 * f]); o.set_frame2(pics[2 * f + 1] if pics[2 * f + 1] is not None else np.zeros((0, 0), np.uint32), ilace[2 * f + 1])
                     else:
                         o.set_frame(pics[f] if pics[f] is not None else np.zeros((0, 0), np.uint32), ilace[f])
+                    if ttp is not None: o.teletext_packets(f, ttp[f][0], ttp[f][1])
                     if cc is not None and (int(cc[f][0]) | int(cc[f][1])) & 0x7F:
                         o.set_cc608(f, int(cc[f][0]), int(cc[f][1]))
                     want.append(o.render_lines((L - 1 if f == 0 else L) if early else L))
@@ -124,6 +145,8 @@ while done < N and time.time() - t_start < LIMIT:
                     want.append(o.render_lines(1))
                 want = np.concatenate(want)
             e.set_levels(levels)
+            if pti is not None: e.passthru_write(pti)
+            if rbs is not None: e.rawbb_write(rbs)
             got, fdone = [], 0
             for n in split:
                 per = 2 if conf.interlace else 1
@@ -133,6 +156,9 @@ while done < N and time.time() - t_start < LIMIT:
                 if cc is not None:
                     for i in range(n):
                         e.cc608_write(i, int(cc[fdone + i][0]), int(cc[fdone + i][1]))
+                if ttp is not None:
+                    for i in range(n):
+                        e.teletext_packets(i, ttp[fdone + i][0], ttp[fdone + i][1])
                 while e.audio_needed(n) > 0:
                     e.audio_write(audio)
                 e.render(n, slots=list(range(n * per)))
