@@ -290,9 +290,19 @@ int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)
 	int64_t n;
 
 	if(!lut || first != s->fm_pos || count < 0) return(HVK_ERROR);
-	if(pass && (first % s->W || count % s->W)) return(HVK_ERROR);
+	/* --passthru is added line by line as the lines end; behind the resampler, where the lines' widths vary, frame by
+	 * frame behind the loop (hvk_tail_passthru_stream() walks whole frames there; the sum does not feed the modulator) */
+	const int pass_frames = pass && t->k.rs_L;
+	if(pass && !pass_frames && (first % s->W || count % s->W)) return(HVK_ERROR);
+	if(pass_frames)
+	{
+		int64_t f = first / t->k.frame_samples, f2;
+		while(hvk_tables_frame_start(t, f) < first) f++;
+		for(f2 = f; hvk_tables_frame_start(t, f2) < first + count; f2++);
+		if(hvk_tables_frame_start(t, f) != first || hvk_tables_frame_start(t, f2) != first + count) return(HVK_ERROR);
+	}
 
-	if(pass)
+	if(pass && !pass_frames)
 	{
 		line = malloc((size_t) s->W * 2 * sizeof(int16_t));
 		if(!line) return(HVK_OUT_OF_MEMORY);
@@ -336,7 +346,7 @@ int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)
 		iq[n * 2 + 0] = i;
 		iq[n * 2 + 1] = q;
 
-		if(pass && (n + 1) % s->W == 0)
+		if(pass && !pass_frames && (n + 1) % s->W == 0)
 		{
 			/* the line that just ended */
 			const int64_t p = first + n + 1 - s->W;
@@ -348,6 +358,16 @@ int hvk_tail_fm_apply(hvk_tail_t *s, int64_t first, int64_t count, int16_t *iq)
 	}
 
 	free(line);
+	if(pass_frames && count > 0)
+	{
+		int16_t *add = malloc((size_t) count * 2 * sizeof(int16_t));
+		int r;
+		if(!add) return(HVK_OUT_OF_MEMORY);
+		r = hvk_tail_passthru_stream(s, first, count, add);
+		if(r != HVK_OK) { free(add); return(r); }
+		for(n = 0; n < count * 2; n++) iq[n] = (int16_t) (iq[n] + add[n]);
+		free(add);
+	}
 	s->fm_pos += count;
 	return(HVK_OK);
 }

@@ -48,6 +48,8 @@ CASES = [
     ("secamfm_px18", "secam_fm_tail", "secam-fm", 16000000, 18000000, ["--pixelrate", "18000000"], 0, False, 3, {}),
     ("ntscfm_f18_px135", "ntscfm_f18", "ntsc-fm", 18000000, 13500000, ["--filter", "--pixelrate", "13500000"], refprobe.FLAG_FILTER, False, 3, {}),
     ("palfm_s14_px16", "pal_fm", "pal-fm", 14000000, 16000000, ["--pixelrate", "16000000"], 0, False, 3, {}),
+    # ... with --passthru (lines of varying width behind the resampler: the sum is made frame by frame, behind the modulator)
+    ("palfm_pass_px135", "pal_fm", "pal-fm", 16000000, 13500000, ["--passthru", "@PASS@", "--pixelrate", "13500000"], 0, False, 4, {"passthru": 1}),
     # ... and at a rate pair with frames of two lengths (1017 x 525 x 9 / 8): the modulator's place in the stream is what the frames add up to
     ("ntscfm_s18_px16", "ntsc_fm", "ntsc-fm", 18000000, 16000000, ["--pixelrate", "16000000"], 0, False, 5, {}),
 ]
@@ -71,8 +73,9 @@ ONLY = sys.argv[1:]
 
 def main():
     util.rawbb_signal().tofile("/tmp/hvk_rawbb.bin")
+    util.passthru_signal().tofile("/tmp/hvk_passthru.bin")
     for cid, base, mode, sr, pr, flags, pflags, real, nframes, extra in CASES:
-        cli = [f.replace("@RAWBB@", "/tmp/hvk_rawbb.bin") for f in flags]
+        cli = [f.replace("@RAWBB@", "/tmp/hvk_rawbb.bin").replace("@PASS@", "/tmp/hvk_passthru.bin") for f in flags]
         if ONLY and cid not in ONLY:
             continue
         d = runs_of(mode, sr, cli, 640000 * 4 * 3, RUNS)

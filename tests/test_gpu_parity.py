@@ -65,7 +65,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
                                   "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14",
-                                  "palfm_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16",
+                                  "palfm_px135", "palfm_pass_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16",
                                   "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
                                   "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
                                   # the rasters other than 625 / 525 lines, field-sequential colour (oracle/make_golden_rasters.py)
@@ -385,7 +385,7 @@ def test_dropin_binary_equals_reference_cli(golden):
                  "m_px135_s16", "ntsc_px16_s135", "m_4fsc", "pal_9m",
                  "e_full", "405_bb", "240_bb", "30_bb", "nbtv_bb", "apollofm", "apollofsc_bb", "mcbs405_full",
                  # round 4: the combinations that used to be refused, and ntsc-a
-                 "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "palfm_px135", "palfm_f14_px135", "secamfm_px18", "palfm_s14_px16", "ntsca_full"):
+                 "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "palfm_px135", "palfm_pass_px135", "palfm_f14_px135", "secamfm_px18", "palfm_s14_px16", "ntsca_full"):
         c = golden.cases[case]
         fs = c.get("frame_samples", c["width"] * c["lines"])
         bps = 2 if c["real"] else 4

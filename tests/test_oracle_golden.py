@@ -28,7 +28,7 @@ CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"]
 CASES_RASTERS = ["e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass", "palfm_f14_tail",
-              "palfm_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16", "ntscfm_s18_px16"]
+              "palfm_px135", "palfm_pass_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16", "ntscfm_s18_px16"]
 
 
 @pytest.mark.parametrize("case", CASES_FAST + CASES_TAIL + CASES_PIXELRATE + CASES_VBI + CASES_A2 + CASES_PRESETS + CASES_SIS + CASES_RATES + CASES_RASTERS)
