@@ -1479,8 +1479,9 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 
 		if(t.conf.acp)
 		{
-			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where
-			 * VITS holds the line (src/acp.c:93-108); the AGC level moves with the frame number */
+			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where the line
+			 * is held already (src/acp.c:93-108): by VITS, or by SECAM's colour process, which marks its field
+			 * identification lines (src/video.c:3101-3103, :3135); the AGC level moves with the frame number */
 			const int frame = (int) (e->h_fdesc[(size_t) i * (t.k.fields + 1) + 1].frame_index + 1);
 			const int agc = hvk_acp_agc_level(&t, frame);
 			const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
@@ -1491,7 +1492,7 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 				{
 					bool vits = false;
 					for(int q = 0; q < t.k.vits; q++) if(t.k.vits_line[q] == l - 1) vits = true;
-					if(vits || n >= HVK_VBI_OPS) continue;
+					if(vits || (!t.conf.raw_bb && (t.desc[l - 1].secam_fid & 1)) || n >= HVK_VBI_OPS) continue;
 					uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
 					op[0] = 0;
 					op[1] = 1u << 16;       /* mode 1: assign list */
@@ -1570,8 +1571,9 @@ extern "C" int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlin
 		hold(t.vitc_lines[1]); hold(t.vitc_lines[1] + 2);
 	}
 	if(t.conf.cc608) hold(t.cc608_line);
-	/* SECAM field identification lines carry the sub-carrier ramp (src/video.c:3101-3103, :4132-4137) */
-	for(int l = 1; l <= lines; l++) if(t.desc[l - 1].secam_fid & 1) hold(l);
+	/* SECAM field identification lines carry the sub-carrier ramp (src/video.c:3101-3103, :4132-4137); raw baseband has
+	 * no colour process to mark them (src/video.c:4180-4190) */
+	if(!t.conf.raw_bb) for(int l = 1; l <= lines; l++) if(t.desc[l - 1].secam_fid & 1) hold(l);
 	return(HVK_OK);
 }
 

@@ -1778,6 +1778,13 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->s_video)
 	{
 		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME) return(HVK_UNSUPPORTED);
+		/* With the video filter behind a resampler whose lines are not all of one width (525 lines at 16 MHz: 1017, 1017,
+		 * ..., 1016) the reference pairs a line's luma -- as many samples as the chunk the filter was last fed, dst->width =
+		 * fir_int16_process(), src/video.c:3243 -- with the sub-carrier its line buffer holds, which is a chunk of another
+		 * width: a sample short (the line then ends on what the buffer held before) or a sample long, and one sample
+		 * earlier or later in the stream from line to line. The filter kernel reads the sub-carrier at the luma's own
+		 * stream position; the oracle models the buffers (oracle_video.c). Refused rather than rendered a sample off. */
+		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0) return(HVK_UNSUPPORTED);
 		t->k.s_video = 1;
 	}
 

@@ -243,6 +243,7 @@ void orc_vbi_free(orc_t *s);
 void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut);
 int orc_vbi_allocated(orc_t *s, int line);
 int orc_vbi_allocated_by_vits(orc_t *s, int line);
+int orc_vbi_allocated_by_secam(orc_t *s, int line);
 
 /* oracle_tail.c */
 int orc_tail_init(orc_t *s);

@@ -399,8 +399,9 @@ void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut)
 		if(c->lines == 625) on = (line >= 9 && line <= 18) || (line >= 321 && line <= 330);
 		else on = (line >= 12 && line <= 19) || (line >= 275 && line <= 282);
 
-		/* lines another inserter holds are left alone: only VITS comes earlier */
-		if(on && !(c->vits && orc_vbi_allocated_by_vits(s, line)))
+		/* lines already held are left alone (src/acp.c:108): of the inserters only VITS comes earlier, and SECAM's
+		 * field identification lines are marked by the colour process before any of them (src/video.c:3135) */
+		if(on && !(c->vits && orc_vbi_allocated_by_vits(s, line)) && !orc_vbi_allocated_by_secam(s, line))
 		{
 			for(i = 0; i < 6; i++)
 			{
@@ -475,6 +476,15 @@ void orc_vbi_line(orc_t *s, long g, int frame, int line, const c16_t *lut)
 	}
 }
 
+/* SECAM's colour process marks its field identification lines as held (src/video.c:3101-3103, :3135); it runs where the
+ * mode's colour is SECAM and the video is not raw baseband (src/video.c:4200-4215) */
+int orc_vbi_allocated_by_secam(orc_t *s, int line)
+{
+	const hvk_config_t *c = &s->conf;
+	if(c->colour_mode != HVK_SECAM || c->raw_bb || !c->secam_field_id) return(0);
+	return((line >= 7 && line < 7 + s->sc_fid_lines) || (line >= 320 && line < 320 + s->sc_fid_lines));
+}
+
 int orc_vbi_allocated_by_vits(orc_t *s, int line)
 {
 	if(s->conf.lines == 625) return(line == 17 || line == 18 || line == 330 || line == 331);
@@ -486,6 +496,7 @@ int orc_vbi_allocated_by_vits(orc_t *s, int line)
 int orc_vbi_allocated(orc_t *s, int line)
 {
 	const hvk_config_t *c = &s->conf;
+	if(orc_vbi_allocated_by_secam(s, line)) return(1);
 	if(c->vits)
 	{
 		if(c->lines == 625 && (line == 17 || line == 18 || line == 330 || line == 331)) return(1);

@@ -520,22 +520,33 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 		if(s->conf.s_video && s->rs_taps)
 		{
 			/* ... behind the resampler, which has a second channel for it (src/video.c:4361-4367: an instance of the same
-			 * filter, fed the Q channel of the same slots): the sub-carrier of chunk c - delay_lines, resampled */
+			 * filter, fed the Q channel of the same slots): the sub-carrier of chunk c - delay_lines, resampled.
+			 * The reference keeps it in the Q channel of the lines' own buffers, a ring of `olines` of them (src/video.c:3578):
+			 * the raster writes line c's sub-carrier into buffer c at the raster's width, the resampler reads it there and
+			 * writes chunk c over the front of buffer c - 1 (its two line pointers: dst = lines[0], src = lines[1]), and the
+			 * filter process then gives the line it finishes the width of the chunk it has just been fed (dst->width =
+			 * fir_int16_process(), src/video.c:3243). Where the widths differ from line to line (525 lines at 16 MHz:
+			 * 1017, 1017, ..., 1016) a line one sample shorter than its new width ends on what its buffer held before:
+			 * the raster's sub-carrier of the line before it at that place when resampling downwards, the end of an
+			 * earlier chunk when upwards. Hence the same ring of buffers here, written in the same order, never cleared. */
+			const int ring = s->olines > s->delay_lines + 2 ? s->olines : s->delay_lines + 2;
+			const size_t qw = (size_t) (s->max_width > W ? s->max_width : W);
 			const int16_t *cl = orc_cline_ptr(s, c);
-			int16_t *zero = NULL;
+			int16_t *own;
 			int wq, back;
 			if(!s->prev_q)
 			{
-				s->prev_q = calloc((size_t) (s->delay_lines + 1) * s->max_width, sizeof(int16_t));
+				s->prev_q = calloc((size_t) ring * qw, sizeof(int16_t));
 				s->rs_win2 = calloc(s->rs_ataps, sizeof(int16_t));
 				s->rs_d2 = s->rs_L;
 			}
-			if(!cl) cl = zero = calloc(W, sizeof(int16_t));
-			wq = _resample_ch(s, &s->rs_d2, s->rs_win2, cl, W, s->prev_q + (size_t) slot * s->max_width);
-			free(zero);
+			own = s->prev_q + (size_t) (c % ring) * qw;
+			if(cl) memcpy(own, cl, W * sizeof(int16_t));
+			else memset(own, 0, W * sizeof(int16_t));
+			wq = _resample_ch(s, &s->rs_d2, s->rs_win2, own, W, s->prev_q + (size_t) ((c - 1 + ring) % ring) * qw);
 			(void) wq;      /* == w: both channels consume the same inputs from the same phase */
-			back = (int) ((c - s->delay_lines + (s->delay_lines + 1)) % (s->delay_lines + 1));
-			for(x = 0; x < w; x++) s->ciq[x * 2 + 1] = c >= s->delay_lines ? s->prev_q[(size_t) back * s->max_width + x] : 0;
+			back = (int) ((c - s->delay_lines - 1 + 2 * ring) % ring);
+			for(x = 0; x < w; x++) s->ciq[x * 2 + 1] = c >= s->delay_lines ? s->prev_q[(size_t) back * qw + x] : 0;
 		}
 		else if(s->conf.s_video)
 		{

@@ -66,15 +66,34 @@ SETUPS = {
     # third of the lines after that; with the test tone, whose blocks are alike, both are the same for good (tests/golden).
     "l_sis_px16_14":  ("l", 14000000, R.FLAG_FILTER | R.FLAG_SIS, H.FLAG_FILTER, {"sis": 1}, 3, 16000000),
     "i_sis_loud":     ("i", 16000000, R.FLAG_FILTER | R.FLAG_SIS, H.FLAG_FILTER, {"sis": 1}, 3),
+    # found by tools/fuzz_oracle_ref.py (random configurations, reference against oracle):
+    # anti-copy pulses leave SECAM's field identification lines alone -- the colour process marks them first (src/video.c:3135, src/acp.c:108)
+    "l_acp_fid":      ("l", 16000000, R.FLAG_FILTER | R.FLAG_NONICAM | R.FLAG_ACP | R.FLAG_SECAM_FID, H.FLAG_FILTER | H.FLAG_NONICAM, {"acp": 1, "secam_field_id": 1}, 2),
+    "secamfm_acp_fid_px": ("secam-fm", 14000000, R.FLAG_FILTER | R.FLAG_NOAUDIO | R.FLAG_ACP | R.FLAG_SECAM_FID, H.FLAG_FILTER | H.FLAG_NOAUDIO, {"acp": 1, "secam_field_id": 1}, 2, 16000000),
+    # S-Video behind the resampler AND the video filter where the lines are not all of one width: a line ends on what its buffer
+    # held before (oracle_video.c; the engine refuses these, hvk_tables.c)
+    "ntsc_sv_f_down": ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 2, 27000000),
+    "ntsc_sv_f_up":   ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 13500000),
+    "pal60_sv_f_18":  ("pal60", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 18000000),
+    # caption pairs queue as the pictures are read -- two a frame with --interlace, none for a frame without a picture -- and leave one a frame
+    "m_cc_ilace":     ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_INTERLACE, H.FLAG_NOAUDIO, {"cc608": 1, "interlace": 1}, 4, 0, {"blank": 0b100010}),
+    "secami_ilace_blank": ("secam-i", 27000000, R.FLAG_INTERLACE | R.FLAG_SECAM_FID, 0, {"interlace": 1, "secam_field_id": 1}, 2, 20250000, {"blank": 0b0101}),
 }
 
 
 def main():
     name = sys.argv[1]
+    if name.startswith("@"):
+        # a setup of the caller's own (tools/fuzz_oracle_ref.py): @{"name": .., "setup": [mode, rate, probe flags, hvk flags, members, frames, pixel rate, overrides]}
+        import json
+        spec = json.loads(name[1:])
+        name = spec["name"]
+        SETUPS[name] = tuple(spec["setup"])
     mode, sr, pflags, hflags, members, nframes = SETUPS[name][:6]
     pixel_rate = SETUPS[name][6] if len(SETUPS[name]) > 6 else 0
     override = dict(SETUPS[name][7]) if len(SETUPS[name]) > 7 else {}
     blank = override.pop("blank", 0)
+    flat_audio = override.pop("flat_audio", None)        # every sample alike: what sound-in-syncs reads does not depend on the threads' race then
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
     conf = H.preset(mode, hflags)
     for k, v in members.items():
@@ -97,6 +116,8 @@ def main():
         audio = rng.integers(-32768, 32768, (4096 + 37, 2), dtype=np.int64).astype(np.int16)
         audio[1000:1400] = 32767                              # a clipped burst into the limiter
         audio[2000:2300, 0] = -32768
+        if flat_audio is not None:
+            audio[:] = flat_audio
         cc = rng.integers(0, 256, (nsrc, 2), dtype=np.int64).astype(np.uint8)
         cc[1] = 0
         par = (16, 11) if name == "i_wss_auto" else (1, 1)
@@ -122,14 +143,26 @@ def main():
         # line does) the next frame's picture therefore has to be set before the frame's LAST line is asked for -- the
         # reference reads it when it starts the frame's first line (src/video.c:4873-4881), which is the same moment.
         early = mode in ("30", "30-am", "nbtv", "nbtv-am")
+        fifo, late = [], []
         for f in range(nframes):
-            o.set_frame(frames[(f * fields) % nsrc] if not (blank >> f) & 1 else np.zeros((0, 0), np.uint32))
+            # (`blank` counts the source's reads: one per frame, one per field with --interlace)
+            none = np.zeros((0, 0), np.uint32)
+            o.set_frame(frames[(f * fields) % nsrc] if not (blank >> (f * fields)) & 1 else none)
             if fields == 2:
-                o.set_frame2(frames[(f * fields + 1) % nsrc])
+                o.set_frame2(frames[(f * fields + 1) % nsrc] if not (blank >> (f * fields + 1)) & 1 else none)
             o.set_frame_aspect(*par)
-            c = cc[(f * fields) % nsrc]
-            if (int(c[0]) | int(c[1])) & 0x7F:
+            # caption pairs queue up as the pictures are read (empty pairs and frames without a picture add none,
+            # src/cc608.c:47-75, src/video.c:4900-4903) and leave one per frame on the caption line; a field's second
+            # picture is read behind that line
+            for k in range(fields):
+                c = cc[(f * fields + k) % nsrc]
+                if not (blank >> (f * fields + k)) & 1 and (int(c[0]) | int(c[1])) & 0x7F:
+                    (fifo if k == 0 else late).append(c)
+            if fifo:
+                c = fifo.pop(0)
                 o.set_cc608(f, int(c[0]), int(c[1]))
+            fifo += late
+            del late[:]
             out.append(o.render_lines((L - 1 if f == 0 else L) if early else L))
         if early:
             out.append(o.render_lines(1))

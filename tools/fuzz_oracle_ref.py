@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""tools/fuzz_oracle_ref.py [cases] [seed] [seconds] [jobs] -- TEST INFRASTRUCTURE, runs without a GPU.
+
+Random configurations -- any of the 43 mode ids, a rate the mode takes, a random set of --filter / --noaudio / --nonicam /
+A2 stereo / --pixelrate / S-Video / VITS / VITC / WSS auto / ACP / CC608 / SECAM field identification / --interlace / --gamma /
+--level / --invert-video / --volume / sound-in-syncs (with sound whose blocks are alike: tests/ref_random_check.py says why) /
+frames the source has no picture for -- each given to the UNMODIFIED reference in-process (oracle/_ref/libhacktv_ref.so) and to
+the oracle on the same random pictures and loud sound, every sample compared (tests/ref_random_check.py, one process per case:
+the reference's heap over-read is read out of that process's heap). The third side of the triangle tools/fuzz_parity.py draws
+on the GPU (engine against oracle over the same family of configurations)."""
+import json
+import os
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hacktv_amd as H  # noqa: E402
+import oracle  # noqa: E402
+import refprobe as R  # noqa: E402
+import util  # noqa: E402
+from test_host_path import HOST_TABLES  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 600
+JOBS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+
+MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
+         "secam-g", "secam-fm", "secam", "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
+         "apollo-fsc-fm", "apollo-fsc", "apollo-fm", "apollo", "m-cbs405", "cbs405"]
+RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000000], 525: [13500000, 16000000, 14318181, 18000000, 27000000], 819: [24570000, 16380000],
+         405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
+
+
+def draw(rng, case):
+    mode = MODES[int(rng.integers(len(MODES)))]
+    base = H.preset(mode, 0)
+    lines = int(base.lines)
+    rates = [17496000] if mode in ("m-cbs405", "cbs405") else RATES.get(lines, [16000000])
+    sr = int(rates[int(rng.integers(len(rates)))])
+    pf = hf = 0
+    members, over = {}, {}
+    for p_, h_, prob in ((R.FLAG_FILTER, H.FLAG_FILTER, 0.5), (R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, 0.35), (R.FLAG_NONICAM, H.FLAG_NONICAM, 0.2)):
+        if rng.random() < prob:
+            pf |= p_
+            hf |= h_
+
+    def maybe(flag, name, value, prob):
+        nonlocal pf
+        if rng.random() < prob:
+            pf |= flag
+            members[name] = value
+            return True
+        return False
+    if lines in (625, 525):
+        maybe(R.FLAG_VITS, "vits", 1, 0.2)
+        maybe(R.FLAG_VITC, "vitc", 1, 0.2)
+        maybe(R.FLAG_ACP, "acp", 1, 0.15)
+        if lines == 525:
+            maybe(R.FLAG_CC608, "cc608", 1, 0.25)
+        if lines == 625:
+            maybe(R.FLAG_WSS_AUTO, "wss", 0xFF, 0.2)
+            if maybe(R.FLAG_SIS, "sis", 1, 0.15):
+                # (FM video carries what the never-emitted start-up lines held along as a phase for ever: whether their bursts saw
+                # the first block of sound or the silence before it is the reference's threads' race -- silence, then)
+                over["flat_audio"] = 0 if mode.endswith("-fm") else int(rng.integers(-20000, 20000))
+        maybe(R.FLAG_INTERLACE, "interlace", 1, 0.12)
+        if mode in ("g", "b", "m") and not (hf & H.FLAG_NOAUDIO):
+            maybe(R.FLAG_A2STEREO, "a2stereo", 1, 0.3)
+    if mode in ("l", "d", "k", "secam", "secam-fm", "secam-i", "secam-b", "secam-g"):
+        maybe(R.FLAG_SECAM_FID, "secam_field_id", 1, 0.5)
+    if mode in ("pal", "ntsc", "secam", "pal60", "525pal"):
+        maybe(R.FLAG_SVIDEO, "s_video", 1, 0.3)
+    if rng.random() < 0.15:
+        over["gamma"] = members["gamma"] = round(float(rng.uniform(0.4, 2.6)), 3)
+    if rng.random() < 0.15:
+        over["level"] = round(float(rng.uniform(0.3, 1.0)), 3)
+        members["level"] = float(base.level) * over["level"]
+    if rng.random() < 0.1:
+        over["invert"] = members["invert_video"] = 1
+    if rng.random() < 0.15:
+        over["volume"] = members["volume"] = int(rng.integers(64, 700))
+    if rng.random() < 0.15:
+        over["blank"] = int(rng.integers(1, 8))
+    pr = 0
+    if lines in (625, 525) and rng.random() < 0.3:
+        cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
+        pr = int(cand[int(rng.integers(len(cand)))])
+    nfr = 2 if lines >= 405 else 4
+    name = "fz%d_%d" % (SEED, case)
+    desc = "%-13s %9d px %9d %s %s" % (mode, sr, pr, " ".join(n for n, b in (("filter", H.FLAG_FILTER), ("noaudio", H.FLAG_NOAUDIO), ("nonicam", H.FLAG_NONICAM)) if hf & b),
+                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio")]))
+    return name, desc, [mode, sr, pf, hf, members, nfr, pr, over]
+
+
+def run(item):
+    name, desc, setup = item
+    # the engine's host half (tables only, device -1): refused configurations are counted, not compared; the tables it
+    # builds for the others against the oracle's (what tests/test_host_path.py does for the golden cases)
+    try:
+        conf = H.preset(setup[0], setup[3])
+        for k, v in setup[4].items():
+            setattr(conf, k, v)
+        with H.Engine(conf, setup[1], device=-1, pixel_rate=setup[6]) as e, oracle.Oracle(conf, setup[1], setup[6]) as o:
+            for t in HOST_TABLES:
+                if t == "chroma_taps" and setup[0] == "ntsc-a":
+                    continue        # (colour without a chroma low pass: the engine's table holds the three taps that stand for "none")
+                if not np.array_equal(e.table(t, util.TABLE_DTYPES[t]), o.table(t, util.TABLE_DTYPES[t])):
+                    return "TABLES", desc, t
+    except H.HvkError as err:
+        return "refused", desc, str(err)[:80]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_random_check.py"), "@" + json.dumps({"name": name, "setup": setup})],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    out = r.stdout.strip().splitlines()
+    last = out[-1] if out else ""
+    if last.startswith("EQUAL"):
+        return "equal", desc, last if last != "EQUAL" else ""
+    if r.returncode != 0:
+        err = (r.stderr.strip().splitlines() or ["?"])[-1]
+        return ("refused" if "HvkError" in err or "ref_open failed" in err else "ERROR"), desc, err[:200]
+    return "DIFFERENT", desc, last + "\n          rerun: python tests/ref_random_check.py '@%s'" % json.dumps({"name": name, "setup": setup})
+
+
+def main():
+    if not R.available():
+        sys.exit("oracle/_ref/libhacktv_ref.so has not been built (make -C oracle ref)")
+    rng = np.random.default_rng(SEED)
+    items = [draw(rng, c) for c in range(N)]
+    t0 = time.time()
+    counts = {}
+    with ThreadPoolExecutor(JOBS) as ex:
+        for verdict, desc, note in ex.map(run, items):
+            counts[verdict] = counts.get(verdict, 0) + 1
+            print("%-9s %s %s" % (verdict, desc, note), flush=True)
+            if time.time() - t0 > LIMIT:
+                break
+    print(" ".join("%d %s" % (v, k) for k, v in sorted(counts.items())), "%.0f s" % (time.time() - t0))
+    sys.exit(1 if counts.get("DIFFERENT") or counts.get("ERROR") or counts.get("TABLES") else 0)
+
+
+if __name__ == "__main__":
+    main()
