@@ -11,11 +11,16 @@
  * array with an index, the per-line code strings become a [2][lines] array of
  * descriptors, filter taps are stored in the order they meet the samples.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include "hvk_internal.h"
 #include "hvk_fm_taps.h"
+
+/* a configuration the engine does not render says why on stderr, as hvk_open()'s own checks do (the reference prints its
+ * refusals the same way, src/video.c, src/hacktv.c), and hvk_open() returns HVK_UNSUPPORTED */
+#define REFUSE(...) do { fprintf(stderr, "libhvk: refused: "); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); return(HVK_UNSUPPORTED); } while(0)
 
 #define EDGE_0_100 2.0738786   /* 10-90 % rise time -> full width of an integrated raised-cosine edge (src/common.h:28) */
 
@@ -192,7 +197,7 @@ static int _build_linebase(hvk_tables_t *t)
 		for(b = 0; b < nbase; b++) if(!memcmp(key[b], k5, sizeof(k5))) break;
 		if(b == nbase)
 		{
-			if(nbase == 126) return(HVK_UNSUPPORTED);
+			if(nbase == 126) REFUSE("more than 126 kinds of line start in this raster");
 			memcpy(key[b], k5, sizeof(k5));
 			nbase++;
 		}
@@ -234,7 +239,7 @@ static int _build_linedesc(hvk_tables_t *t)
 	int colour = c->colour_mode == HVK_PAL || c->colour_mode == HVK_NTSC;
 	int p, line;
 
-	if(!runs || nl != c->lines) return(HVK_UNSUPPORTED);
+	if(!runs || nl != c->lines) REFUSE("no line sequence for a raster of %d lines of this type", c->lines);
 	t->desc = calloc(2 * c->lines, sizeof(hvk_linedesc_t));
 	if(!t->desc) return(HVK_OUT_OF_MEMORY);
 
@@ -279,7 +284,7 @@ static int _build_linedesc(hvk_tables_t *t)
 		const int ids[2] = { t->desc[p].pulse_left, t->desc[p].pulse_mid };
 		for(line = 0; line < 2; line++)
 		{
-			if(ids[line] >= 0 && t->k.pulse_offset[ids[line]] + t->k.pulse_length[ids[line]] > 2 * t->k.width) return(HVK_UNSUPPORTED);
+			if(ids[line] >= 0 && t->k.pulse_offset[ids[line]] + t->k.pulse_length[ids[line]] > 2 * t->k.width) REFUSE("a sync pulse of this raster runs on past the line after its own at %u Hz", t->pixel_rate);
 		}
 	}
 	{
@@ -548,7 +553,7 @@ static int _build_audio(hvk_tables_t *t, double slevel)
 			}
 			t->has_limiter = 1;
 		}
-		else if(c->fm_mono_preemph != 0) return(HVK_UNSUPPORTED);
+		else if(c->fm_mono_preemph != 0) REFUSE("FM sound pre-emphasis %d (the reference has 50 us, 75 us and J.17)", c->fm_mono_preemph);
 
 		t->k.has_carriers = 1;
 	}
@@ -893,8 +898,8 @@ static int _build_wss(hvk_tables_t *t)
 	int level = round((t->white_level - t->black_level) * (5.0 / 7.0));
 	int o = 29 + 24, r;
 
-	if(c->lines != 625) return(HVK_UNSUPPORTED);            /* src/hacktv.c: 625-line modes only */
-	if(c->wss != 0xFF && (c->wss < 0 || c->wss > 0x0F)) return(HVK_UNSUPPORTED);
+	if(c->lines != 625) REFUSE("widescreen signalling needs a 625-line mode (src/hacktv.c:1350-1356)");            /* src/hacktv.c: 625-line modes only */
+	if(c->wss != 0xFF && (c->wss < 0 || c->wss > 0x0F)) REFUSE("WSS mode byte 0x%X (src/wss.c:33-44 has 0x01 .. 0x0E and auto)", c->wss);
 
 	r = _append_step_lut(t, 1, 137, level, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 200e-9, (double) t->pixel_rate * 11e-6);
 	if(r != HVK_OK) return(r);
@@ -939,7 +944,7 @@ static int _build_vitc(hvk_tables_t *t)
 
 	if(c->frame_rate.num <= 30 && c->frame_rate.den == 1) { t->vitc_fps = c->frame_rate.num; t->vitc_drop = 0; }
 	else if(c->frame_rate.num == 30000 && c->frame_rate.den == 1001) { t->vitc_fps = 30; t->vitc_drop = 1; }
-	else return(HVK_UNSUPPORTED);
+	else REFUSE("VITC time code at a frame rate of %d/%d (src/vitc.c:135-152: whole rates up to 30, and 30000/1001)", (int) c->frame_rate.num, (int) c->frame_rate.den);
 
 	return(_append_step_lut(t, 2, hr, level, (double) t->k.width / hr, t->pixel_rate * 200e-9, 0));
 }
@@ -1270,7 +1275,7 @@ static int _build_sis(hvk_tables_t *t)
 			if(len[b] == 0) off[b] = x;
 			while(len[b] < x - off[b]) packed[pos[b] + len[b]++] = 0;
 			packed[pos[b] + len[b]++] = (int16_t) v;
-			if(x >= HVK_SIS_SPAN) { free(packed); return(HVK_UNSUPPORTED); }       /* (a burst longer than the kernel looks at: not at any rate hvk_open takes) */
+			if(x >= HVK_SIS_SPAN) { free(packed); REFUSE("the sound-in-syncs burst at %u Hz is longer than the %d samples the kernel looks at", t->pixel_rate, HVK_SIS_SPAN); }       /* (a burst longer than the kernel looks at: not at any rate hvk_open takes) */
 			t->sis_dense[(size_t) b * HVK_SIS_SPAN + x] = (int16_t) v;
 		}
 		packed[n] = (int16_t) len[b];
@@ -1282,7 +1287,7 @@ static int _build_sis(hvk_tables_t *t)
 	/* the blanking window */
 	t->k.sis_left = (int) floor(t->pixel_rate * (left - rise / 2));
 	t->k.sis_width = (int) ceil(t->pixel_rate * (width + rise));
-	if(t->k.sis_left < 0 || t->k.sis_left + t->k.sis_width > HVK_SIS_SPAN) { free(packed); return(HVK_UNSUPPORTED); }
+	if(t->k.sis_left < 0 || t->k.sis_left + t->k.sis_width > HVK_SIS_SPAN) { free(packed); REFUSE("the sound-in-syncs blanking window at %u Hz does not fit the %d samples the kernel looks at", t->pixel_rate, HVK_SIS_SPAN); }
 	t->sis_win = calloc(t->k.sis_width, sizeof(int16_t));
 	t->sis_first = calloc(HVK_SIS_SPAN, sizeof(int16_t));
 	if(!t->sis_win || !t->sis_first) { free(packed); return(HVK_OUT_OF_MEMORY); }
@@ -1358,7 +1363,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	/* what the engine renders */
 	{
 		int nl;
-		if(!_runs_of(c->type, &nl) || nl != c->lines) return(HVK_UNSUPPORTED);
+		if(!_runs_of(c->type, &nl) || nl != c->lines) REFUSE("video type %d with %d lines: not one of the rasters of src/video.c:2447-2862 (D/D2-MAC has a line process of its own)", c->type, c->lines);
 	}
 	if(c->modulation == HVK_FM && (c->fm_level <= 0 || c->fm_deviation <= 0)) return(HVK_ERROR);
 	if(c->frame_rate.num <= 0 || c->frame_rate.den <= 0) return(HVK_ERROR);
@@ -1387,7 +1392,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	t->k.slab_lines = t->k.lines + 2;
 	t->max_width = t->k.width;
 
-	if(t->k.width < 64 || t->k.width > 8192) return(HVK_UNSUPPORTED);
+	if(t->k.width < 64 || t->k.width > 8192) REFUSE("lines of %d samples (%u Hz): the kernels take 64 .. 8192", t->k.width, t->pixel_rate);
 
 	/* levels (src/video.c:3858-3881) */
 	/* sub-carriers ride on the FM baseband at unit level; the overall level then scales the FM phasor */
@@ -1428,7 +1433,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			total += t->k.pulse_length[i] + HVK_PULSE_PAD;
 
 			/* (a pulse may run on into the next line -- _build_linebase -- but no further) */
-			if(first < -t->k.width) return(HVK_UNSUPPORTED);
+			if(first < -t->k.width) REFUSE("a sync pulse of this raster begins more than a line before its own line at %u Hz", t->pixel_rate);
 		}
 
 		t->pulse_total = total;
@@ -1498,7 +1503,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		while((e = a % b)) { a = b; b = e; }
 		num /= b;
 		den /= b;
-		if(num > 0x7FFFFFFF) return(HVK_UNSUPPORTED);
+		if(num > 0x7FFFFFFF) REFUSE("the colour sub-carrier's table at %u Hz would hold more than 2^31 entries", t->pixel_rate);
 
 		t->k.clw = num;
 		step = 2.0 * M_PI * ((double) den / num);
@@ -1520,7 +1525,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			t->chroma_taps = _q15_applied(taps, t->k.chroma_ntaps, 1);
 			free(taps);
 			if(!t->chroma_taps) return(HVK_OUT_OF_MEMORY);
-			if(t->k.chroma_ntaps / 2 * 2 > HVK_GHOST_LEN) return(HVK_UNSUPPORTED);
+			if(t->k.chroma_ntaps / 2 * 2 > HVK_GHOST_LEN) REFUSE("a chroma filter of %d taps (pixel rate %u Hz) reads further past the line than the %d samples modelled", t->k.chroma_ntaps, t->pixel_rate, HVK_GHOST_LEN);
 		}
 		else
 		{
@@ -1563,9 +1568,9 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			t->k.burst_q = 0;
 		}
 
-		if(t->k.colour && t->k.burst_left + t->k.burst_width > t->k.width) return(HVK_UNSUPPORTED);
+		if(t->k.colour && t->k.burst_left + t->k.burst_width > t->k.width) REFUSE("the colour burst ends behind the line at %u Hz", t->pixel_rate);
 	}
-	else if(t->k.colour) return(HVK_UNSUPPORTED);
+	else if(t->k.colour) REFUSE("colour without a sub-carrier frequency");
 
 	if(c->colour_mode == HVK_APOLLO_FSC || c->colour_mode == HVK_CBS_FSC)
 	{
@@ -1586,7 +1591,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		{
 			const double at = (p ? line_s / 2 : 0) + c->fsc_flag_left;
 			len = _quantise_pulse(NULL, &first, at * pixel_rate, c->fsc_flag_width * pixel_rate, rise, (int) amp);
-			if(len > 8192 || first < 0 || first + len > t->k.width) return(HVK_UNSUPPORTED);   /* (the flag lies inside its line at every rate there is) */
+			if(len > 8192 || first < 0 || first + len > t->k.width) REFUSE("the field-sequential colour flag does not lie inside its line at %u Hz", t->pixel_rate);   /* (the flag lies inside its line at every rate there is) */
 			_quantise_pulse(tmp, &first, at * pixel_rate, c->fsc_flag_width * pixel_rate, rise, (int) amp);
 			for(j = 0; j < len; j++) t->fsc_rows[(size_t) p * t->k.width + first + j] = tmp[j];
 		}
@@ -1599,7 +1604,8 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	 * (13.5 MHz: 140 + 702 + 25 > 864) the reference reads behind its line buffer -- whatever the
 	 * heap holds there. There is nothing to be exact to: refused. (S-Video has no notch.) */
 	if(c->colour_mode == HVK_SECAM && !c->s_video && !c->raw_bb &&
-	   t->k.active_left + t->k.active_width + 25 > t->k.width) return(HVK_UNSUPPORTED);
+	   t->k.active_left + t->k.active_width + 25 > t->k.width)
+		REFUSE("SECAM at %u Hz: the reference's luma notch reads %d samples past its line buffer there (src/video.c:3206) -- its output depends on its heap", t->pixel_rate, t->k.active_left + t->k.active_width + 25 - t->k.width);
 
 	hvk_tables_default_ghost(t);
 
@@ -1618,7 +1624,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			const hvk_fm_taps_t *f = hvk_fm_taps;
 			int k;
 			while(f->lines && !(f->lines == c->lines && (f->sample_rate == (int) sample_rate || f->sample_rate == 0))) f++;
-			if(!f->lines || f->ntaps > HVK_MAX_VF_TAPS) return(HVK_UNSUPPORTED);
+			if(!f->lines || f->ntaps > HVK_MAX_VF_TAPS) REFUSE("no FM video pre-emphasis taps for %d lines at %u Hz (src/video.c:3452-3564)", c->lines, sample_rate);
 			ntaps = f->ntaps;
 			t->k.vf_type = 1;
 			t->k.vf_ntaps = ntaps;
@@ -1679,7 +1685,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		D = pixel_rate / a;
 
 		/* what the device kernel is sized for */
-		if(L > 256 || D > 4 * L) return(HVK_UNSUPPORTED);
+		if(L > 256 || D > 4 * L) REFUSE("resampling %u -> %u Hz is %d : %d in lowest terms: the kernel takes up to 256 phases and a decimation of up to four times that", pixel_rate, sample_rate, L, D);
 		/* frames of constant length, or (525 lines at 13.5 -> 16 MHz: 450450 * 32 / 27) of two lengths one sample apart */
 		t->k.rs_irr = ((int64_t) t->k.raster_samples * L) % D != 0;
 
@@ -1694,7 +1700,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		t->k.rs_D = D;
 		t->k.rs_ataps = (ntaps + L - 1) / L;
 		total = t->k.rs_ataps * L;
-		if(total > 8192) { free(taps); return(HVK_UNSUPPORTED); }
+		if(total > 8192) { free(taps); REFUSE("the resampler %u -> %u Hz has %d taps: the kernel's table holds 8192", pixel_rate, sample_rate, total); }
 		t->rs_taps = calloc(total, sizeof(int16_t));
 		if(!t->rs_taps) { free(taps); return(HVK_OUT_OF_MEMORY); }
 
@@ -1709,7 +1715,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		free(taps);
 
 		/* the kernel's position arithmetic is 32-bit: (frame-local resampled index) * D */
-		if(((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; return(HVK_UNSUPPORTED); }
+		if(((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; REFUSE("resampling %u -> %u Hz: a frame's positions times %d leave the kernel's 32-bit arithmetic", pixel_rate, sample_rate, D); }
 		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D) + (t->k.rs_irr ? 1 : 0);
 		t->k.slab_lines = t->k.lines + 3;
 		t->max_width = (int32_t) (((int64_t) t->k.width * L + D - 1) / D);   /* fir_int16_output_size, src/fir.c:376-381 */
@@ -1722,7 +1728,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		w1 = ((int64_t) 2 * t->k.width * L + D - 1) / D - w0;
 		t->k.rs_shift = (int32_t) (w0 + (t->k.vf_type ? w1 - round((double) sample_rate * line_s) : 0));
 		t->k.out_prime = (int32_t) (w0 + (t->k.vf_type ? w1 : 0));
-		if(t->k.rs_shift < 64 + (t->k.rs_irr ? 2 : 0)) return(HVK_UNSUPPORTED);
+		if(t->k.rs_shift < 64 + (t->k.rs_irr ? 2 : 0)) REFUSE("resampling %u -> %u Hz: lines of %d samples are shorter than the kernel's lead", pixel_rate, sample_rate, (int) w0);
 	}
 	else
 	{
@@ -1765,7 +1771,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->raw_bb)
 	{
 		if(c->raw_bb_white_level == c->raw_bb_blanking_level) return(HVK_ERROR);
-		if(c->s_video) return(HVK_UNSUPPORTED);
+		if(c->s_video) REFUSE("--s-video beside --raw-bb-file: raw baseband has no sub-carrier to put on a second channel");
 		t->k.rawbb = 1;
 		t->k.rawbb_blank = c->raw_bb_blanking_level;
 		t->k.rawbb_range = c->raw_bb_white_level - c->raw_bb_blanking_level;
@@ -1777,14 +1783,15 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	/* S-Video: baseband colour modes only (src/hacktv.c:1136-1148); behind the resampler the sub-carrier has a channel of its own (src/video.c:4361-4367) */
 	if(c->s_video)
 	{
-		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME) return(HVK_UNSUPPORTED);
+		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME) REFUSE("--s-video needs a baseband colour mode (src/hacktv.c:1136-1148)");
 		/* With the video filter behind a resampler whose lines are not all of one width (525 lines at 16 MHz: 1017, 1017,
 		 * ..., 1016) the reference pairs a line's luma -- as many samples as the chunk the filter was last fed, dst->width =
 		 * fir_int16_process(), src/video.c:3243 -- with the sub-carrier its line buffer holds, which is a chunk of another
 		 * width: a sample short (the line then ends on what the buffer held before) or a sample long, and one sample
 		 * earlier or later in the stream from line to line. The filter kernel reads the sub-carrier at the luma's own
 		 * stream position; the oracle models the buffers (oracle_video.c). Refused rather than rendered a sample off. */
-		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0) return(HVK_UNSUPPORTED);
+		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0)
+			REFUSE("--s-video with --filter and --pixelrate %u -> %u Hz: the lines are not all of one width there, and the reference pairs luma and sub-carrier of different lines' widths", pixel_rate, sample_rate);
 		t->k.s_video = 1;
 	}
 
@@ -1799,7 +1806,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 	if(c->teletext)
 	{
 		/* 625-line systems only (src/hacktv.c:1182-1186) */
-		if(c->lines != 625) return(HVK_UNSUPPORTED);
+		if(c->lines != 625) REFUSE("teletext needs a 625-line mode (src/hacktv.c:1182-1186)");
 		if((r = _build_teletext(t)) != HVK_OK) return(r);
 		if((r = _append_teletext_lut(t)) != HVK_OK) return(r);
 	}
@@ -1815,7 +1822,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		/* (the burst is laid out in pixels of the raster and drawn there -- in front of the resampler, beside --s-video's second
 		 * channel, over a line that came from --raw-bb-file all the same; the hand-over of the sound blocks goes by the
 		 * pipeline's steps, whatever the width of the audio process's lines) */
-		if(c->sis != 1) return(HVK_UNSUPPORTED);
+		if(c->sis != 1) REFUSE("sound-in-syncs mode %d (the reference has dcsis)", c->sis);
 		if((r = _build_sis(t)) != HVK_OK) return(r);
 	}
 

@@ -93,6 +93,9 @@ def main():
     pixel_rate = SETUPS[name][6] if len(SETUPS[name]) > 6 else 0
     override = dict(SETUPS[name][7]) if len(SETUPS[name]) > 7 else {}
     blank = override.pop("blank", 0)
+    pic = override.pop("pic", None)                      # pictures narrower / shorter than the raster's (centred, src/video.c:4888-4897)
+    src_ilace = override.pop("src_ilace", 0)             # the pictures' field-order flag (src/video.c:3081-3084)
+    par_o = override.pop("par", None)                    # their pixel aspect (WSS auto, src/wss.c)
     flat_audio = override.pop("flat_audio", None)        # every sample alike: what sound-in-syncs reads does not depend on the threads' race then
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
     conf = H.preset(mode, hflags)
@@ -107,6 +110,8 @@ def main():
         turned = (int(conf.frame_orientation) & 3) in (1, 3)
         if turned:
             w, h = h, w                                      # (the source's dimensions: src/hacktv.c:1520-1526)
+        if pic:
+            w, h = min(w, int(pic[0])), min(h, int(pic[1]))
         frames = rng.integers(0, 1 << 24, (nsrc, h, w), dtype=np.uint32)
         frames[1, : h // 2] = 0xFFFFFF                       # white / saturated primaries: the level clamps
         frames[1, h // 2:, : w // 3] = 0xFF0000
@@ -120,11 +125,14 @@ def main():
             audio[:] = flat_audio
         cc = rng.integers(0, 256, (nsrc, 2), dtype=np.int64).astype(np.uint8)
         cc[1] = 0
-        par = (16, 11) if name == "i_wss_auto" else (1, 1)
-        r.set_source(frames, audio, par=par, cc=cc, blank=blank)
+        par = (16, 11) if name == "i_wss_auto" else (tuple(par_o) if par_o else (1, 1))
+        r.set_source(frames, audio, interlaced=src_ilace, par=par, cc=cc, blank=blank)
         ghost = r.table("chroma_ghost", np.int16)
         ref = r.render_lines(nframes * L)
         ghost_after = r.table("chroma_ghost", np.int16)
+    if os.environ.get("REF_CHECK_SHA"):
+        import hashlib
+        print("REFSHA", hashlib.sha256(ref.tobytes()).hexdigest())       # (tools/fuzz_oracle_ref.py: do two runs of the reference agree?)
 
     if int(conf.frame_orientation):
         # the oracle (like the engine) is given the picture as the raster shows it
@@ -147,9 +155,9 @@ def main():
         for f in range(nframes):
             # (`blank` counts the source's reads: one per frame, one per field with --interlace)
             none = np.zeros((0, 0), np.uint32)
-            o.set_frame(frames[(f * fields) % nsrc] if not (blank >> (f * fields)) & 1 else none)
+            o.set_frame(frames[(f * fields) % nsrc] if not (blank >> (f * fields)) & 1 else none, src_ilace)
             if fields == 2:
-                o.set_frame2(frames[(f * fields + 1) % nsrc] if not (blank >> (f * fields + 1)) & 1 else none)
+                o.set_frame2(frames[(f * fields + 1) % nsrc] if not (blank >> (f * fields + 1)) & 1 else none, src_ilace)
             o.set_frame_aspect(*par)
             # caption pairs queue up as the pictures are read (empty pairs and frames without a picture add none,
             # src/cc608.c:47-75, src/video.c:4900-4903) and leave one per frame on the caption line; a field's second

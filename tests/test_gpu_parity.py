@@ -977,6 +977,7 @@ def test_odd_line_widths(golden, mode, sr):
     # a second round of combinations nothing else covers
     ("l", 20250000, 16000000, {"interlace": 1}),
     ("secam", 16000000, 0, {"s_video": 1, "secam_field_id": 1}),
+    ("l", 16000000, 0, {"acp": 1, "secam_field_id": 1, "vits": 1}),     # anti-copy pulses leave the field identification lines alone (src/video.c:3135, src/acp.c:108; the reference: tests/ref_random_check.py l_acp_fid)
     ("b", 16000000, 0, {"a2stereo": 1, "vitc": 1}),
     ("d", 16000000, 0, {"teletext": 1, "wss": 0x0D, "vits": 1, "vitc": 1, "secam_field_id": 1}),
     ("pal-d", 13500000, 16000000, {"vits": 1}),

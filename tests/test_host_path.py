@@ -332,3 +332,38 @@ def test_sound_in_syncs_bursts_equal_the_oracles(golden, case, loud):
     assert set(want[:, 7]) == {46, 50}
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, "line %d: %s != %s" % (bad[0], got[bad[0]], want[bad[0]])
+
+
+@pytest.mark.parametrize("mode,sr,pr,flags,members,words", [
+    ("d", 14000000, 0, H.FLAG_FILTER, {}, "luma notch"),                                  # the reference reads past its line buffer there
+    ("ntsc", 16000000, 27000000, H.FLAG_FILTER, {"s_video": 1}, "not all of one width"),  # tests/ref_random_check.py ntsc_sv_f_down has the reference on it
+    ("ntsc", 16000000, 13500000, H.FLAG_FILTER, {"s_video": 1}, "not all of one width"),
+    ("pal-k", 17734475, 27000000, 0, {}, "lowest terms"),
+    ("pal-d", 27000000, 0, 0, {"sis": 1}, "sound-in-syncs burst"),
+    ("m", 13500000, 0, 0, {"wss": 8}, "625-line"),
+    ("apollo-fm", 8000000, 0, H.FLAG_FILTER, {}, "pre-emphasis taps"),
+])
+def test_refusals_say_why(capfd, mode, sr, pr, flags, members, words):
+    """A configuration the engine does not render is refused at open with HVK_UNSUPPORTED and one line on stderr that says
+    why (the reference prints its own refusals the same way); nothing is rendered approximately."""
+    conf = H.preset(mode, flags)
+    for k, v in members.items():
+        setattr(conf, k, v)
+    with pytest.raises(H.HvkError) as err:
+        H.Engine(conf, sr, device=-1, pixel_rate=pr)
+    assert err.value.code == H.HVK_UNSUPPORTED
+    said = capfd.readouterr().err
+    assert "libhvk: refused: " in said and words in said, said
+
+
+@pytest.mark.parametrize("mode,sr,pr,flags,members", [
+    ("ntsc", 16000000, 27000000, 0, {"s_video": 1}),                   # lines of two widths, but no filter to give a line another line's width
+    ("ntsc", 13500000, 18000000, H.FLAG_FILTER, {"s_video": 1}),       # the filter, but every line 858 samples
+    ("pal", 16000000, 13500000, H.FLAG_FILTER, {"s_video": 1}),
+])
+def test_s_video_behind_the_resampler_where_it_is_defined(mode, sr, pr, flags, members):
+    conf = H.preset(mode, flags)
+    for k, v in members.items():
+        setattr(conf, k, v)
+    with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e:
+        assert e.info["width"] > 0
