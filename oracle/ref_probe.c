@@ -55,6 +55,18 @@ void ref_override(double gamma, double level, int invert, int volume)
 	_override.volume = volume;
 }
 
+/* --offset, --swap-iq, --wss <mode>, --secam-field-id-lines (src/hacktv.c:1428-1437, :1341-1356), applied by the NEXT ref_open() */
+static struct { long long offset; int swap_iq, fid_lines; char wss[32]; } _override2;
+
+void ref_override2(long long offset, int swap_iq, const char *wss, int fid_lines)
+{
+	_override2.offset = offset;
+	_override2.swap_iq = swap_iq;
+	_override2.fid_lines = fid_lines;
+	_override2.wss[0] = 0;
+	if(wss) strncpy(_override2.wss, wss, sizeof(_override2.wss) - 1);
+}
+
 ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int pixel_rate, int flags, const char *teletext)
 {
 	const vid_configs_t *vc;
@@ -110,6 +122,10 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 	if(_override.invert) conf.invert_video = 1;
 	if(_override.volume > 0) conf.volume = _override.volume;
 	memset(&_override, 0, sizeof(_override));
+	if(_override2.offset) conf.offset = _override2.offset;
+	if(_override2.swap_iq) conf.swap_iq = 1;
+	if(_override2.fid_lines) conf.secam_field_id_lines = _override2.fid_lines;
+	if(_override2.wss[0]) conf.wss = strdup(_override2.wss);     /* (the reference keeps the pointer; a few bytes per open, never freed) */
 
 	p = calloc(1, sizeof(ref_probe_t));
 	if(!p) return(NULL);
@@ -148,6 +164,7 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 	}
 
 	p->open = 1;
+	memset(&_override2, 0, sizeof(_override2));
 	return(p);
 }
 

@@ -43,6 +43,8 @@ def lib():
         L.ref_close.argtypes = [ctypes.c_void_p]
         L.ref_override.restype = None
         L.ref_override.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.ref_override2.restype = None
+        L.ref_override2.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.ref_set_source.restype = None
         L.ref_set_source.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
@@ -61,9 +63,12 @@ def lib():
 
 
 class RefProbe:
-    def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None, gamma=0.0, level=0.0, invert=0, volume=0):
+    def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None, gamma=0.0, level=0.0, invert=0, volume=0,
+                 offset=0, swap_iq=0, wss=None, fid_lines=0):
         if gamma or level or invert or volume:
             lib().ref_override(gamma, level, invert, volume)
+        if offset or swap_iq or wss or fid_lines:
+            lib().ref_override2(offset, swap_iq, wss.encode() if wss else None, fid_lines)
         self.p = lib().ref_open(mode.encode(), sample_rate, pixel_rate, flags,
                                 teletext.encode() if teletext else None)
         if not self.p:

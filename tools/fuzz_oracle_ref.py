@@ -39,6 +39,9 @@ RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000
          405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
 
 
+WSS_MODES = [("4:3", 0x08), ("14:9-letterbox", 0x01), ("14:9-top", 0x02), ("16:9-letterbox", 0x0B), ("16:9-top", 0x04), ("16:9+-letterbox", 0x0D), ("14:9-window", 0x0E), ("16:9", 0x07)]
+
+
 def draw(rng, case):
     mode = MODES[int(rng.integers(len(MODES)))]
     base = H.preset(mode, 0)
@@ -90,6 +93,21 @@ def draw(rng, case):
     if rng.random() < 0.15:
         over["blank"] = int(rng.integers(1, 8))
     if WIDE:
+        # --offset / --swap-iq (the complex tail, src/video.c:4587-4645), an explicit --wss mode, --secam-field-id-lines, --nocolour
+        if int(base.output_type) == 0:       # HVK_INT16_COMPLEX
+            if rng.random() < 0.2:
+                over["offset"] = members["offset"] = (int(rng.integers(-8, 9)) * 50000) or 250000
+            if rng.random() < 0.15:
+                over["swap_iq"] = members["swap_iq"] = 1
+        if lines == 625 and "wss" not in members and rng.random() < 0.15:
+            name_, code = WSS_MODES[int(rng.integers(len(WSS_MODES)))]
+            over["wss"] = name_
+            members["wss"] = code
+        if members.get("secam_field_id") and rng.random() < 0.4:
+            over["fid_lines"] = members["secam_field_id_lines"] = int(rng.integers(1, 10))
+        if rng.random() < 0.08:
+            pf |= R.FLAG_NOCOLOUR
+            hf |= H.FLAG_NOCOLOUR
         if rng.random() < 0.2:
             over["pic"] = [int(rng.integers(2, 1200)), int(rng.integers(1, 600))]
         if rng.random() < 0.2:
@@ -100,10 +118,10 @@ def draw(rng, case):
     if lines in (625, 525) and rng.random() < 0.3:
         cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
         pr = int(cand[int(rng.integers(len(cand)))])
-    nfr = 2 if lines >= 405 else 4
+    nfr = (2 if lines >= 405 else 4) + (int(rng.integers(0, 4)) if WIDE and rng.random() < 0.25 else 0)     # (PAL's sub-carrier sequence is four frames long)
     name = "fz%d_%d" % (SEED, case)
     desc = "%-13s %9d px %9d %s %s" % (mode, sr, pr, " ".join(n for n, b in (("filter", H.FLAG_FILTER), ("noaudio", H.FLAG_NOAUDIO), ("nonicam", H.FLAG_NONICAM)) if hf & b),
-                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par")]))
+                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par")] + ([("nocolour", 1)] if hf & H.FLAG_NOCOLOUR else [])))
     return name, desc, [mode, sr, pf, hf, members, nfr, pr, over]
 
 
