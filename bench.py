@@ -680,7 +680,18 @@ def main():
     if not args.walk_rounds:
         torch.cuda.synchronize()
         t_set = time.perf_counter()
-        while time.perf_counter() - t_set < args.settle:
+
+        def settle_on():
+            """Another group of settling steps? Rank 0's clock decides for everybody: every step is a send / receive pair
+            between the ranks, and two ranks that looked at their own clocks a millisecond apart would leave the loop a
+            group apart -- one of them waiting for a block nobody sends."""
+            more = time.perf_counter() - t_set < args.settle
+            if N > 1:
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32)
+                dist.broadcast(flag, 0, group=hostg)
+                more = bool(flag.item())
+            return more
+        while settle_on():
             for i in range(20):
                 step(settle_steps + i)
             drain()
