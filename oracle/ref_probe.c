@@ -41,6 +41,7 @@ typedef struct {
 	vid_t vid;
 	int open;
 	long rendered;
+	int16_t *own_cb, *pinned_cb;    /* ref_pin_ghost() */
 } ref_probe_t;
 
 /* Settings main() takes from --gamma / --level / --invert-video / --volume (src/hacktv.c:1179-1184,
@@ -65,6 +66,19 @@ void ref_override2(long long offset, int swap_iq, const char *wss, int fid_lines
 	_override2.fid_lines = fid_lines;
 	_override2.wss[0] = 0;
 	if(wss) strncpy(_override2.wss, wss, sizeof(_override2.wss) - 1);
+}
+
+/* --raw-bb-file <path> --raw-bb-blanking <n> --raw-bb-white <n>, --passthru <path> (src/hacktv.c:1158-1171, :1428-1430),
+ * applied by the NEXT ref_open(); the paths are kept by the reference */
+static struct { char raw_bb[256], passthru[256]; int blanking, white; } _override3;
+
+void ref_override_files(const char *raw_bb, int blanking, int white, const char *passthru)
+{
+	memset(&_override3, 0, sizeof(_override3));
+	if(raw_bb) strncpy(_override3.raw_bb, raw_bb, sizeof(_override3.raw_bb) - 1);
+	if(passthru) strncpy(_override3.passthru, passthru, sizeof(_override3.passthru) - 1);
+	_override3.blanking = blanking;
+	_override3.white = white;
 }
 
 ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int pixel_rate, int flags, const char *teletext)
@@ -125,6 +139,14 @@ ref_probe_t *ref_open(const char *mode, unsigned int sample_rate, unsigned int p
 	if(_override2.offset) conf.offset = _override2.offset;
 	if(_override2.swap_iq) conf.swap_iq = 1;
 	if(_override2.fid_lines) conf.secam_field_id_lines = _override2.fid_lines;
+	if(_override3.raw_bb[0])
+	{
+		conf.raw_bb_file = strdup(_override3.raw_bb);
+		conf.raw_bb_blanking_level = _override3.blanking;
+		conf.raw_bb_white_level = _override3.white;
+	}
+	if(_override3.passthru[0]) conf.passthru = strdup(_override3.passthru);
+	memset(&_override3, 0, sizeof(_override3));
 	if(_override2.wss[0]) conf.wss = strdup(_override2.wss);     /* (the reference keeps the pointer; a few bytes per open, never freed) */
 
 	p = calloc(1, sizeof(ref_probe_t));
@@ -231,8 +253,34 @@ void ref_set_source(ref_probe_t *p, const uint32_t *frames, int nframes, int wid
 	p->vid.av.close = _src_close;
 }
 
+/* The chroma filter reads up to ataps / 2 samples per channel past the 2 * width chrominance buffer: bytes
+ * that belong to whatever the allocator put behind it -- in some heap layouts an object of the reference's own that
+ * changes while it runs, and then no read-out before or after the run describes what the filter saw. For comparisons
+ * that are not about the heap: move the buffer into one of the probe's with `n` (<= 64) samples of the caller's choosing
+ * behind it -- normally the ones just read out with ref_table("chroma_ghost") -- so that they stay what they were. Only
+ * the pointer changes hands (every use goes through s->chrominance_buffer); ref_close() gives the reference its own back. */
+void ref_pin_ghost(ref_probe_t *p, const int16_t *ghost, int n)
+{
+	vid_t *s = &p->vid;
+	int16_t *nb;
+	if(!s->chrominance_buffer || p->pinned_cb || n < 0 || n > 64) return;
+	nb = calloc((size_t) 2 * s->width + 64, sizeof(int16_t));
+	if(!nb) return;
+	memcpy(nb, s->chrominance_buffer, sizeof(int16_t) * 2 * s->width);
+	memcpy(nb + 2 * s->width, ghost, sizeof(int16_t) * n);
+	p->own_cb = s->chrominance_buffer;
+	p->pinned_cb = nb;
+	s->chrominance_buffer = nb;
+}
+
 void ref_close(ref_probe_t *p)
 {
+	if(p && p->pinned_cb)
+	{
+		p->vid.chrominance_buffer = p->own_cb;
+		free(p->pinned_cb);
+		p->pinned_cb = NULL;
+	}
 	if(!p) return;
 	/* vid_free() is not usable from a long-lived test process: its worker
 	 * shutdown (src/video.c:4714-4721 against :3590-3613) races twice -- the

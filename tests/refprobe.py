@@ -45,6 +45,10 @@ def lib():
         L.ref_override.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
         L.ref_override2.restype = None
         L.ref_override2.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.ref_override_files.restype = None
+        L.ref_override_files.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        L.ref_pin_ghost.restype = None
+        L.ref_pin_ghost.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.ref_set_source.restype = None
         L.ref_set_source.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
@@ -64,11 +68,13 @@ def lib():
 
 class RefProbe:
     def __init__(self, mode, sample_rate, flags=0, pixel_rate=0, teletext=None, gamma=0.0, level=0.0, invert=0, volume=0,
-                 offset=0, swap_iq=0, wss=None, fid_lines=0):
+                 offset=0, swap_iq=0, wss=None, fid_lines=0, raw_bb=None, raw_bb_levels=(0, 32767), passthru=None):
         if gamma or level or invert or volume:
             lib().ref_override(gamma, level, invert, volume)
         if offset or swap_iq or wss or fid_lines:
             lib().ref_override2(offset, swap_iq, wss.encode() if wss else None, fid_lines)
+        if raw_bb or passthru:
+            lib().ref_override_files(raw_bb.encode() if raw_bb else None, int(raw_bb_levels[0]), int(raw_bb_levels[1]), passthru.encode() if passthru else None)
         self.p = lib().ref_open(mode.encode(), sample_rate, pixel_rate, flags,
                                 teletext.encode() if teletext else None)
         if not self.p:
@@ -86,6 +92,11 @@ class RefProbe:
         self._keep = (f, a, c)
         lib().ref_set_source(self.p, f.ctypes.data, f.shape[0], f.shape[2], f.shape[1], interlaced, par[0], par[1],
                              c.ctypes.data if c is not None else None, a.ctypes.data, a.shape[0])
+
+    def pin_ghost(self, ghost):
+        """Keep the samples the chroma filter reads past its buffer what `ghost` says (oracle/ref_probe.c:ref_pin_ghost)."""
+        g = np.ascontiguousarray(ghost, np.int16)
+        lib().ref_pin_ghost(self.p, g.ctypes.data, min(len(g), 64))
 
     def pipeline_depths(self):
         """(reference, shim): lines held back by the reference's line pipeline, and the shim's count of them."""

@@ -70,10 +70,11 @@ def draw(rng, case):
             maybe(R.FLAG_CC608, "cc608", 1, 0.25)
         if lines == 625:
             maybe(R.FLAG_WSS_AUTO, "wss", 0xFF, 0.2)
-            if maybe(R.FLAG_SIS, "sis", 1, 0.15):
-                # (FM video carries what the never-emitted start-up lines held along as a phase for ever: whether their bursts saw
-                # the first block of sound or the silence before it is the reference's threads' race -- silence, then)
-                over["flat_audio"] = 0 if mode.endswith("-fm") else int(rng.integers(-20000, 20000))
+            # (not with FM video: the modulator carries what the never-emitted start-up lines held along as a phase for ever, and
+            # what their bursts hold is the reference's threads' race even with silence as sound -- its runs differ from each
+            # other there, two to three digests in five runs at most rates: DESIGN.md section 3)
+            if not mode.endswith("-fm") and maybe(R.FLAG_SIS, "sis", 1, 0.15):
+                over["flat_audio"] = int(rng.integers(-20000, 20000))
         maybe(R.FLAG_INTERLACE, "interlace", 1, 0.12)
         if mode in ("g", "b", "m") and not (hf & H.FLAG_NOAUDIO):
             maybe(R.FLAG_A2STEREO, "a2stereo", 1, 0.3)
@@ -108,6 +109,13 @@ def draw(rng, case):
         if rng.random() < 0.08:
             pf |= R.FLAG_NOCOLOUR
             hf |= H.FLAG_NOCOLOUR
+        # --raw-bb-file (a little more than a frame of samples, not a whole number of lines) and --passthru (2.4 frames: it ends inside the run)
+        if lines in (625, 525) and rng.random() < 0.08:
+            members.update({"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000})
+            over["rawbb"] = int(sr if False else 0) or None
+        if rng.random() < 0.1:
+            members["passthru"] = 1
+            over["passthru"] = -1
         if rng.random() < 0.2:
             over["pic"] = [int(rng.integers(2, 1200)), int(rng.integers(1, 600))]
         if rng.random() < 0.2:
@@ -119,9 +127,15 @@ def draw(rng, case):
         cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
         pr = int(cand[int(rng.integers(len(cand)))])
     nfr = (2 if lines >= 405 else 4) + (int(rng.integers(0, 4)) if WIDE and rng.random() < 0.25 else 0)     # (PAL's sub-carrier sequence is four frames long)
+    fs_raster = int(round((pr or sr) * float(base.frame_rate.den) / float(base.frame_rate.num)))     # samples per frame at the raster's rate
+    fs_out = int(round(sr * float(base.frame_rate.den) / float(base.frame_rate.num)))
+    if "rawbb" in over:
+        over["rawbb"] = fs_raster + 311
+    if "passthru" in over:
+        over["passthru"] = int(fs_out * 2.4) + 17
     name = "fz%d_%d" % (SEED, case)
     desc = "%-13s %9d px %9d %s %s" % (mode, sr, pr, " ".join(n for n, b in (("filter", H.FLAG_FILTER), ("noaudio", H.FLAG_NOAUDIO), ("nonicam", H.FLAG_NONICAM)) if hf & b),
-                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par")] + ([("nocolour", 1)] if hf & H.FLAG_NOCOLOUR else [])))
+                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par", "rawbb", "passthru")] + ([("nocolour", 1)] if hf & H.FLAG_NOCOLOUR else [])))
     return name, desc, [mode, sr, pf, hf, members, nfr, pr, over]
 
 
