@@ -160,7 +160,9 @@ int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, int width, i
 int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t *fb, int width, int height, int interlaced);
 
 /* The pixel aspect ratio of the frame in `slot` (av_frame_t.pixel_aspect_ratio, src/av.h:43):
- * only `--wss auto` (conf.wss == 0xFF) looks at it (src/wss.c:166-179). 1:1 unless set. */
+ * only `--wss auto` (conf.wss == 0xFF) looks at it (src/wss.c:166-179). 1:1 unless set, and it stays with the slot: a
+ * caller that mirrors a source says it again with every upload -- the reference's frames without a picture have square
+ * pixels (av_frame_init(), src/av.c:21-33; the shim passes what the source's frame says). */
 int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den);
 
 /* Teletext (conf.teletext != 0): the packets for the VBI lines of frame

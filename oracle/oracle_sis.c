@@ -120,6 +120,10 @@ long orc_sis_bursts(orc_t *s, long first_line, long nlines, uint8_t *out)
 
 void orc_set_sis_visible(orc_t *s, int samples) { s->sis_visible = samples < 0 ? 0 : samples; }
 
+/* the 8 samples in front of the reference's symbol table as THIS process's heap has them (oracle/ref_probe.c, table
+ * "sis_heap"): the default above is what the reference CLI's heap holds there */
+void orc_set_sis_heap(orc_t *s, const int16_t *h8) { memcpy(s->sis_heap, h8, sizeof(s->sis_heap)); }
+
 void orc_sis_free(orc_t *s)
 {
 	int b;

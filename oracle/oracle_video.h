@@ -57,6 +57,7 @@ void orc_set_cc608(orc_t *s, long frame_index, uint8_t c1, uint8_t c2);
 /* --sis: how many samples of a step's audio line the reference's audio thread is taken to have behind it when its SiS
  * process looks for the newest audio block (oracle_sis.c; 0: none -- the default) */
 void orc_set_sis_visible(orc_t *s, int samples);
+void orc_set_sis_heap(orc_t *s, const int16_t *h8);
 /* ... the bursts of the lines rendered so far (8 bytes a line: 7 bytes of bits, MSB first, and their number); -1: not made yet */
 long orc_sis_bursts(orc_t *s, long first_line, long nlines, uint8_t *out);
 

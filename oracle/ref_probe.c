@@ -413,6 +413,12 @@ long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
 		return(_copy(dst, max_bytes, s->burst_win, s->burst_win ? (long) s->burst_width * sizeof(int16_t) : 0));
 	if(strcmp(name, "chroma_taps") == 0)
 		return(_copy(dst, max_bytes, s->chrominance_fir.itaps, s->chrominance_fir.itaps ? (long) s->chrominance_fir.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "sis_heap") == 0)
+	{
+		/* The 8 int16s in front of the sound-in-syncs symbol table on the heap: the burst encoder's first invocation
+		 * reads them (src/vbidata.c:211-217 with a slot of no width, oracle_sis.c) */
+		return(_copy(dst, max_bytes, s->conf.sis && s->sis.lut ? (const int16_t *) s->sis.lut - 8 : NULL, 8 * sizeof(int16_t)));
+	}
 	if(strcmp(name, "chroma_ghost") == 0)
 	{
 		/* The int16s that follow the 2*width chrominance buffer on the heap:

@@ -36,6 +36,8 @@ def lib():
         L.orc_set_rawbb.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.orc_set_cc608.restype = None
         L.orc_set_cc608.argtypes = [C.c_void_p, C.c_long, C.c_uint8, C.c_uint8]
+        L.orc_set_sis_heap.restype = None
+        L.orc_set_sis_heap.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_sis_visible.restype = None
         L.orc_set_sis_visible.argtypes = [C.c_void_p, C.c_int]
         L.orc_sis_bursts.restype = C.c_long
@@ -134,6 +136,13 @@ class Oracle:
 
     def set_cc608(self, frame_index, c1, c2):
         lib().orc_set_cc608(self.p, frame_index, c1, c2)
+
+    def set_sis_heap(self, h8):
+        """What lies in front of the reference's sound-in-syncs symbol table on ITS heap (8 samples; the stream's first
+        samples show it, oracle_sis.c)."""
+        a = np.ascontiguousarray(h8, np.int16)
+        assert a.shape == (8,)
+        lib().orc_set_sis_heap(self.p, a.ctypes.data)
 
     def set_sis_visible(self, samples):
         """--sis: samples of a step's audio line the reference's audio thread is taken to have behind it when the SiS

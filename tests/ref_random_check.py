@@ -104,8 +104,15 @@ def main():
     for k, v in members.items():
         setattr(conf, k, v)
 
-    rawbb = passiq = None
+    rawbb = passiq = ttrec = None
     tmp = []
+    if override.pop("teletext", 0):
+        # --teletext raw:<file> (src/teletext.c:1082, :1188-1201): 42-byte records, one per teletext line that no other inserter
+        # holds, enough of them that the file does not wrap
+        ttrec = rng.integers(0, 256, (nframes * 32, 42), dtype=np.int64).astype(np.uint8)
+        tmp.append("/tmp/hvk_fuzz_tt_%d.bin" % os.getpid())
+        ttrec.tofile(tmp[-1])
+        override["teletext"] = "raw:" + tmp[-1]
     if rawbb_n:
         rawbb = rng.integers(300, 24000, (rawbb_n,)).astype(np.int16)
         tmp.append("/tmp/hvk_fuzz_rawbb_%d.bin" % os.getpid())
@@ -149,6 +156,10 @@ def main():
         # ... and kept what they are: in some heap layouts an object of the reference's own lies there and changes while it
         # runs (found by tools/fuzz_oracle_ref.py: the same case equal in one build of the probe, different in the next)
         r.pin_ghost(ghost)
+        # (the same kind of thing at the stream's first samples with sound-in-syncs: the burst encoder's first invocation reads
+        # what the heap holds in front of its symbol table -- the allocation's own chunk header, constant, and the last 8 bytes
+        # of the chunk before it, which are this process's and not the CLI's)
+        sis_heap = r.table("sis_heap", np.int16) if members.get("sis") else None
         ref = r.render_lines(nframes * L)
         ghost_after = r.table("chroma_ghost", np.int16)
     if os.environ.get("REF_CHECK_SHA"):
@@ -163,6 +174,8 @@ def main():
 
     with oracle.Oracle(conf, sr, pixel_rate) as o:
         o.set_ghost(ghost)
+        if sis_heap is not None and len(sis_heap) == 8:
+            o.set_sis_heap(sis_heap)
         o.set_audio(audio, True)
         if rawbb is not None:
             o.set_rawbb(rawbb)
@@ -177,7 +190,26 @@ def main():
         # reference reads it when it starts the frame's first line (src/video.c:4873-4881), which is the same moment.
         early = mode in ("30", "30-am", "nbtv", "nbtv-am")
         fifo, late = [], []
+        tt_used = 0
+        if ttrec is not None:
+            # the lines the other inserters (and SECAM's field identification) hold: teletext leaves them alone and keeps the
+            # record for the next free line (src/teletext.c:1219) -- from the engine's own list, which the shim schedules by
+            with H.Engine(conf, sr, device=-1, pixel_rate=pixel_rate) as eh:
+                held = set(eh.vbi_lines_held())       # (1-based line numbers)
         for f in range(nframes):
+            if ttrec is not None:
+                rows = np.zeros((32, 45), np.uint8)
+                rows[:, 0:2] = 0x55
+                rows[:, 2] = 0x27
+                mask = 0
+                for row in range(32):
+                    line1 = 7 + row if row < 16 else 320 + row - 16
+                    if line1 in held:
+                        continue
+                    rows[row, 3:] = ttrec[tt_used]
+                    tt_used += 1
+                    mask |= 1 << row
+                o.teletext_packets(f, rows, mask)
             # (`blank` counts the source's reads: one per frame, one per field with --interlace)
             none = np.zeros((0, 0), np.uint32)
             o.set_frame(frames[(f * fields) % nsrc] if not (blank >> (f * fields)) & 1 else none, src_ilace)

@@ -176,3 +176,20 @@ def test_sound_in_syncs_block_hand_over_as_the_reference_does_it(golden):
             got[visible] = hashlib.sha256(o.render_lines(625 * nfr).tobytes()).hexdigest()
     assert got[0] == got[300] == got[639] == ref
     assert got[640] == got[1024] != ref
+
+
+def test_random_configurations_against_the_real_reference():
+    """tools/fuzz_oracle_ref.py on a small fixed draw: random mode / rate / option sets, random pictures and loud sound, the
+    unmodified reference in-process against the oracle, every sample (the long runs are the tool's: DESIGN.md section 3).
+    Cases where the reference's own runs differ from each other are counted as undefined, not as failures."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(refprobe.LIB_PATH):
+        pytest.skip("oracle/_ref/libhacktv_ref.so not built")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_ref.py"), "32", "1234", "300", "4"],
+                         capture_output=True, text=True, timeout=900)
+    tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
+    assert out.returncode == 0 and " equal" in tail, out.stdout[-3000:] + out.stderr[-1000:]
+    assert int(tail.split(" equal")[0].split()[-1]) >= 20, tail

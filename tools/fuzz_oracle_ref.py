@@ -116,6 +116,9 @@ def draw(rng, case):
         if rng.random() < 0.1:
             members["passthru"] = 1
             over["passthru"] = -1
+        if lines == 625 and "raw_bb" not in members and rng.random() < 0.12:
+            members["teletext"] = 1
+            over["teletext"] = 1
         if rng.random() < 0.2:
             over["pic"] = [int(rng.integers(2, 1200)), int(rng.integers(1, 600))]
         if rng.random() < 0.2:
@@ -135,7 +138,7 @@ def draw(rng, case):
         over["passthru"] = int(fs_out * 2.4) + 17
     name = "fz%d_%d" % (SEED, case)
     desc = "%-13s %9d px %9d %s %s" % (mode, sr, pr, " ".join(n for n, b in (("filter", H.FLAG_FILTER), ("noaudio", H.FLAG_NOAUDIO), ("nonicam", H.FLAG_NONICAM)) if hf & b),
-                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par", "rawbb", "passthru")] + ([("nocolour", 1)] if hf & H.FLAG_NOCOLOUR else [])))
+                                       " ".join("%s=%s" % kv for kv in list(members.items()) + [(k, v) for k, v in over.items() if k in ("blank", "flat_audio", "pic", "src_ilace", "par", "rawbb", "passthru", "teletext")] + ([("nocolour", 1)] if hf & H.FLAG_NOCOLOUR else [])))
     return name, desc, [mode, sr, pf, hf, members, nfr, pr, over]
 
 
