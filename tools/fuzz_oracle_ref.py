@@ -39,6 +39,8 @@ RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000
          405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
 
 
+ODD_RATES = {625: [10000000, 12000000, 15000000, 17000000, 21000000, 22500000, 24000000, 25000000, 30000000, 16384000], 525: [10000000, 12272727, 15000000, 20250000, 21000000, 24545454, 12000000],
+             819: [20475000, 27300000, 18000000], 405: [10125000, 6075000, 9000000], 240: [3000000, 6000000], 320: [5000000, 6400000]}
 WSS_MODES = [("4:3", 0x08), ("14:9-letterbox", 0x01), ("14:9-top", 0x02), ("16:9-letterbox", 0x0B), ("16:9-top", 0x04), ("16:9+-letterbox", 0x0D), ("14:9-window", 0x0E), ("16:9", 0x07)]
 
 
@@ -48,6 +50,8 @@ def draw(rng, case):
     lines = int(base.lines)
     rates = [17496000] if mode in ("m-cbs405", "cbs405") else RATES.get(lines, [16000000])
     sr = int(rates[int(rng.integers(len(rates)))])
+    if WIDE and mode not in ("m-cbs405", "cbs405") and lines in ODD_RATES and rng.random() < 0.2:
+        sr = int(ODD_RATES[lines][int(rng.integers(len(ODD_RATES[lines])))])     # lines that are not a whole number of samples, rates nothing was tuned for
     pf = hf = 0
     members, over = {}, {}
     for p_, h_, prob in ((R.FLAG_FILTER, H.FLAG_FILTER, 0.5), (R.FLAG_NOAUDIO, H.FLAG_NOAUDIO, 0.35), (R.FLAG_NONICAM, H.FLAG_NONICAM, 0.2)):
@@ -151,6 +155,8 @@ def run(item):
         for k, v in setup[4].items():
             setattr(conf, k, v)
         with H.Engine(conf, setup[1], device=-1, pixel_rate=setup[6]) as e, oracle.Oracle(conf, setup[1], setup[6]) as o:
+            if setup[4].get("teletext"):
+                o.teletext_packets(0, np.zeros((32, 45), np.uint8), 0)      # (the oracle builds its teletext symbols when first asked for a row)
             for t in HOST_TABLES:
                 if t == "chroma_taps" and setup[0] == "ntsc-a":
                     continue        # (colour without a chroma low pass: the engine's table holds the three taps that stand for "none")
