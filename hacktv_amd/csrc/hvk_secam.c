@@ -294,8 +294,12 @@ int hvk_secam_frame(hvk_secam_t *s, int64_t frame_index, const uint32_t *fb1, in
 			 * with :4665-4667). Both are D'r or D'b alike: the second finds the OTHER component
 			 * of the first kept */
 			const int dr = (frame * s->lines) & 1;
-			/* (with the place and width of the picture in force, the stream's first, and no row of it: none for an empty frame) */
-			const int fw = fb1 ? fb1_width : 0;
+			/* (the second with the place and width of the picture in force, the stream's first, and no row of it: none for
+			 * an empty frame; the FIRST is taken by the colour process's thread before the source has been read at all,
+			 * while vid_init()'s frame is in force -- the full active width, no pixels, src/video.c:4169-4177: with a first
+			 * picture narrower than the raster the filter state behind the two slots differs, and at 13.5 / 14 MHz the first
+			 * field identification line shows it; the reference on it: tests/ref_random_check.py secam_sv_narrow) */
+			const int fw = i == 0 ? k->active_width : (fb1 ? fb1_width : 0);
 			_cells_fir(s, NULL, dr ? 1 : 0, i == 1, dr ? 0 : 1, NULL, NULL, fw, (k->active_width - fw) / 2, s->F + (size_t) i * W, s->acc + (size_t) i * 8);
 			continue;
 		}

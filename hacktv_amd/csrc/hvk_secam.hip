@@ -152,7 +152,8 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 		const hvk_framedesc_t f = a.fdesc[i * (a.fields + 1) + 1 + (second ? 1 : 0)];
 		/* (the fill slots as well: they pass while the stream's first picture is the one in force, with its place and width
 		 * and no row of it -- src/video.c:3135-3197 with vy = -1) */
-		int fbw = f.fb_valid ? f.fb_width : 0;
+		/* (... the second one; the FIRST is processed before the source has been read: the full active width, hvk_secam.c) */
+		int fbw = (prime && slot == 0) ? a.active_width : (f.fb_valid ? f.fb_width : 0);
 		int p0 = a.active_left + (a.active_width - fbw) / 2;
 		int64_t row = -1, prow = -1;
 		/* the rows of the (U, V) plane that hold this line's and the line above's levels whole (a half line's has only

@@ -187,6 +187,7 @@ struct orc_t {
 	long sc_done;               /* lines the process has been applied to */
 	int16_t sc_fsync_level;
 	int sc_fid_lines;
+	int sc_fill_slots;          /* fill slots (line 0) the colour process has seen */
 
 	/* teletext render (oracle_teletext.c): symbol table and the packets queued per frame */
 	orc_pulse_t *tt_sym;

@@ -192,12 +192,20 @@ void orc_secam_line(orc_t *s, int16_t *o, int16_t *oq, int frame, int line, int 
 	int16_t *cb = s->chroma;
 	int sl = 0, sr = 0;
 	int dr = ((frame * c->lines) + line) & 1;
-	int vframe_x;
+	int vframe_x, fbw;
 
 	/* (the reference's process looks at the frame the RASTER is on, two lines ahead; the lines
 	 * around a field change show no picture, so the line's own field is the same thing) */
 	if(line >= 1) orc_select_frame(s, line);
-	vframe_x = (s->active_width - s->fb_width) / 2;
+	fbw = s->fb_width;
+	/* The FIRST of the two fill slots (line 0) is processed before the source has been read at all -- the colour process's
+	 * thread takes it while vid_init()'s frame is still in force: the full active width at offset 0, no pixels
+	 * (src/video.c:4169-4177); the second one finds the stream's first picture, its place and width. Found with a first
+	 * picture narrower than the raster at 13.5 and 14 MHz, where the sub-carrier's last two samples run past the line into
+	 * the buffer's upper half and the next line's low pass reads them (tools/fuzz_oracle_ref.py, FUZZ_LONG; the filter state
+	 * behind the two slots now equals the reference's to the last bit: ref_table("secam_iir")). */
+	if(line == 0 && s->sc_fill_slots++ == 0) fbw = s->active_width;
+	vframe_x = (s->active_width - fbw) / 2;
 
 	if(line == 1 || line == c->hline) memset(cb, 0, sizeof(int16_t) * 2 * W);
 
@@ -236,7 +244,7 @@ void orc_secam_line(orc_t *s, int16_t *o, int16_t *oq, int frame, int line, int 
 
 		for(x = 0; x < s->active_left + vframe_x; x++) cb[x] = base;
 
-		for(; x < s->active_left + vframe_x + s->fb_width; x++)
+		for(; x < s->active_left + vframe_x + fbw; x++)
 		{
 			uint32_t rgb = prgb ? (*prgb & 0xFFFFFF) : 0;
 			cb[x] = (s->yuv[rgb * 3 + comp] + cb[W + x]) / 2;

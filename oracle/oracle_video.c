@@ -119,6 +119,16 @@ static long _copy(void *dst, long max_bytes, const void *src, long bytes)
 
 long orc_table(orc_t *s, const char *name, void *dst, long max_bytes)
 {
+	if(strcmp(name, "secam_iir") == 0)
+	{
+		/* as oracle/ref_probe.c's: the pre-emphasis filter's state and the chrominance buffer */
+		static unsigned char tmp[16 + 2 * 8192 * 2];
+		if(s->conf.colour_mode != HVK_SECAM || !s->chroma || s->width > 8192) return(0);
+		memcpy(tmp, &s->sc_ix, 8);
+		memcpy(tmp + 8, &s->sc_iy, 8);
+		memcpy(tmp + 16, s->chroma, (size_t) 2 * s->width * 2);
+		return(_copy(dst, max_bytes, tmp, 16 + (long) 2 * s->width * 2));
+	}
 	if(strcmp(name, "syncs") == 0) return(_copy(dst, max_bytes, s->sync_packed, s->sync_packed_len * sizeof(int16_t)));
 	if(strcmp(name, "yuv") == 0) return(_copy(dst, max_bytes, s->yuv, 0x1000000L * 3 * sizeof(int16_t)));
 	if(strcmp(name, "colour_lookup") == 0) return(_copy(dst, max_bytes, s->colour_lookup, s->colour_lookup ? (long) (s->colour_lookup_width + s->width) * sizeof(c16_t) : 0));

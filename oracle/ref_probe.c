@@ -413,6 +413,16 @@ long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
 		return(_copy(dst, max_bytes, s->burst_win, s->burst_win ? (long) s->burst_width * sizeof(int16_t) : 0));
 	if(strcmp(name, "chroma_taps") == 0)
 		return(_copy(dst, max_bytes, s->chrominance_fir.itaps, s->chrominance_fir.itaps ? (long) s->chrominance_fir.ntaps * sizeof(int16_t) : 0));
+	if(strcmp(name, "secam_iir") == 0)
+	{
+		/* the pre-emphasis filter's state (ix, iy) as two doubles, and behind them the chrominance buffer (2 * width int16) */
+		static unsigned char tmp[16 + 2 * 8192 * 2];
+		if(s->conf.colour_mode != VID_SECAM || !s->chrominance_buffer || s->width > 8192) return(0);
+		memcpy(tmp, &s->fm_secam_iir.ix, 8);
+		memcpy(tmp + 8, &s->fm_secam_iir.iy, 8);
+		memcpy(tmp + 16, s->chrominance_buffer, (size_t) 2 * s->width * 2);
+		return(_copy(dst, max_bytes, tmp, 16 + (long) 2 * s->width * 2));
+	}
 	if(strcmp(name, "sis_heap") == 0)
 	{
 		/* The 8 int16s in front of the sound-in-syncs symbol table on the heap: the burst encoder's first invocation

@@ -77,6 +77,11 @@ SETUPS = {
     "pal60_sv_f_18":  ("pal60", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 18000000),
     # caption pairs queue as the pictures are read -- two a frame with --interlace, none for a frame without a picture -- and leave one a frame
     "m_cc_ilace":     ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_INTERLACE, H.FLAG_NOAUDIO, {"cc608": 1, "interlace": 1}, 4, 0, {"blank": 0b100010}),
+    # SECAM's first fill slot is processed before the source is read (the full active width), the second with the stream's first
+    # picture: a narrow or missing first picture at 13.5 / 14 MHz, where the next line's low pass reads the sub-carrier's overrun
+    "secam_sv_narrow":   ("secam", 13500000, R.FLAG_NONICAM | R.FLAG_SVIDEO | R.FLAG_SECAM_FID, H.FLAG_NONICAM, {"s_video": 1, "secam_field_id": 1}, 3, 0, {"pic": [301, 100]}),
+    "secam_sv_narrow14": ("secam", 14000000, R.FLAG_NONICAM | R.FLAG_SVIDEO, H.FLAG_NONICAM, {"s_video": 1}, 2, 0, {"pic": [175, 246]}),
+    "secam_sv_blank135": ("secam", 13500000, R.FLAG_NONICAM | R.FLAG_SVIDEO | R.FLAG_SECAM_FID, H.FLAG_NONICAM, {"s_video": 1, "secam_field_id": 1}, 3, 0, {"blank": 0b001}),
     "secami_ilace_blank": ("secam-i", 27000000, R.FLAG_INTERLACE | R.FLAG_SECAM_FID, 0, {"interlace": 1, "secam_field_id": 1}, 2, 20250000, {"blank": 0b0101}),
 }
 

@@ -367,3 +367,32 @@ def test_s_video_behind_the_resampler_where_it_is_defined(mode, sr, pr, flags, m
         setattr(conf, k, v)
     with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e:
         assert e.info["width"] > 0
+
+
+@pytest.mark.parametrize("sr", [13500000, 14000000, 16000000])
+@pytest.mark.parametrize("first", ["narrow", "none", "full"])
+def test_secam_fill_slots_see_the_init_frame_then_the_first_picture(sr, first):
+    """The colour process's two never-emitted fill slots: the first is taken before the source has been read -- the full
+    active width of vid_init()'s frame, no pixels (src/video.c:4169-4177) --, the second with the place and width of the
+    stream's first picture. With a first picture narrower than the raster the filter state they leave differs from a
+    full-width one's, and at 13.5 / 14 MHz -- where the sub-carrier's last samples run past the line into what the next
+    line's low pass reads -- the first field identification line shows it (tests/ref_random_check.py secam_sv_narrow has
+    the unmodified reference on it). S-Video: the Q channel IS the sub-carrier, so the host's chain (hvk_secam.c, the
+    arithmetic the device kernels share) is compared with the oracle sample for sample."""
+    conf = H.preset("secam", H.FLAG_NOAUDIO)
+    conf.s_video = 1
+    conf.secam_field_id = 1
+    rng = np.random.default_rng(11)
+    with oracle.Oracle(conf, sr) as o:
+        w, h, L, W = o.info["active_width"], o.info["active_lines"], o.info["lines"], o.info["width"]
+        full = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+        pics = [{"narrow": np.ascontiguousarray(full[:100, :301]), "none": None, "full": full}[first], full]
+        want = []
+        for p in pics:
+            o.set_frame(p if p is not None else np.zeros((0, 0), np.uint32))
+            want.append(o.render_lines(L)[:, 1].reshape(L, W))
+    with H.Engine(conf, sr, device=-1) as e:
+        got = [e.host_secam_stream(p).reshape(L, W) for p in pics]
+    for f in range(2):
+        bad = np.nonzero((got[f] != want[f]).any(axis=1))[0]
+        assert bad.size == 0, "frame %d: %d lines differ, first line %d" % (f, bad.size, bad[0] + 1)

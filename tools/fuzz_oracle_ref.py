@@ -30,6 +30,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 600
 JOBS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+LONG = os.environ.get("FUZZ_LONG", "") != ""      # a few dozen frames per case instead of two to seven
 WIDE = os.environ.get("FUZZ_PLAIN", "") == ""    # pictures of other sizes, their field-order flag and pixel aspect (draws more random numbers)
 
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
@@ -134,6 +135,8 @@ def draw(rng, case):
         cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
         pr = int(cand[int(rng.integers(len(cand)))])
     nfr = (2 if lines >= 405 else 4) + (int(rng.integers(0, 4)) if WIDE and rng.random() < 0.25 else 0)     # (PAL's sub-carrier sequence is four frames long)
+    if LONG:
+        nfr = int(rng.integers(20, 56)) if lines >= 405 else int(rng.integers(100, 400))      # slow counters: time code seconds, the anti-copy level, NICAM's frame count, sub-carrier sequences
     fs_raster = int(round((pr or sr) * float(base.frame_rate.den) / float(base.frame_rate.num)))     # samples per frame at the raster's rate
     fs_out = int(round(sr * float(base.frame_rate.den) / float(base.frame_rate.num)))
     if "rawbb" in over:
@@ -166,7 +169,7 @@ def run(item):
         return "refused", desc, str(err)[:80]
     def once():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_random_check.py"), "@" + json.dumps({"name": name, "setup": setup})],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, REF_CHECK_SHA="1"))
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000, env=dict(os.environ, REF_CHECK_SHA="1"))
         out = r.stdout.strip().splitlines()
         sha = [l for l in out if l.startswith("REFSHA")]
         return r, (out[-1] if out else ""), (sha[-1] if sha else "")
