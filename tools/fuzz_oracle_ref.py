@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """tools/fuzz_oracle_ref.py [cases] [seed] [seconds] [jobs] -- TEST INFRASTRUCTURE, runs without a GPU.
 
-Random configurations -- any of the 43 mode ids, a rate the mode takes, a random set of --filter / --noaudio / --nonicam /
-A2 stereo / --pixelrate / S-Video / VITS / VITC / WSS auto / ACP / CC608 / SECAM field identification / --interlace / --gamma /
---level / --invert-video / --volume / sound-in-syncs (with sound whose blocks are alike: tests/ref_random_check.py says why) /
-frames the source has no picture for -- each given to the UNMODIFIED reference in-process (oracle/_ref/libhacktv_ref.so) and to
-the oracle on the same random pictures and loud sound, every sample compared (tests/ref_random_check.py, one process per case:
-the reference's heap over-read is read out of that process's heap). The third side of the triangle tools/fuzz_parity.py draws
-on the GPU (engine against oracle over the same family of configurations)."""
+Random configurations -- any of the 43 mode ids; a rate the mode takes or one nothing was tuned for; a random set of --filter /
+--noaudio / --nonicam / --nocolour / A2 stereo / --pixelrate / S-Video / VITS / VITC / ACP / CC608 / WSS auto or one of its eight
+modes / SECAM field identification with 1 .. 9 lines / --interlace / --gamma / --level / --invert-video / --volume / --offset /
+--swap-iq / --raw-bb-file / --passthru / --teletext raw: (random files) / sound-in-syncs (not with FM video, and with sound whose
+blocks are alike: tests/ref_random_check.py says why); frames the source has no picture for, pictures narrower and shorter
+than the raster, either field-order flag, six pixel aspects; two to seven frames (FUZZ_LONG=1: 20 .. 55, hundreds on the
+30-line rasters) -- each given to the UNMODIFIED reference in-process (oracle/_ref/libhacktv_ref.so) and to the oracle on the
+same random pictures and loud sound, every sample compared (tests/ref_random_check.py '@{json}', one process per case). Before
+that the engine's host half is opened on the configuration (device -1): what it refuses is counted; what it takes has its
+host tables and -- with sound -- its serial sound pre-pass compared with the oracle's. A case that differs is run four more
+times: where the reference's own runs differ from each other it is "undefined", not a failure. The third side of the triangle
+tools/fuzz_parity.py draws on the GPU (engine against oracle over the same family of configurations)."""
 import json
 import os
 import subprocess
@@ -165,6 +170,23 @@ def run(item):
                     continue        # (colour without a chroma low pass: the engine's table holds the three taps that stand for "none")
                 if not np.array_equal(e.table(t, util.TABLE_DTYPES[t]), o.table(t, util.TABLE_DTYPES[t])):
                     return "TABLES", desc, t
+            # ... and the host's serial sound pre-pass (FM / AM phasor chains, limiter, A2's pilot, the 32 kHz tick; hvk_audio.c)
+            # on loud random sound against the oracle's per-sample loop, a few hundred lines (tests/test_host_path.py does it
+            # for ten golden cases) -- where the audio process sees the raster's own lines
+            if not (setup[3] & H.FLAG_NOAUDIO) and not setup[6] and e.info.get("has_carriers", 1):
+                arng = np.random.default_rng(len(desc))
+                audio = arng.integers(-32768, 32768, (4096 + 37, 2), dtype=np.int64).astype(np.int16)
+                audio[1000:1400] = 32767
+                W, nl = o.info["width"], 260
+                o.set_audio(audio, True)
+                o.set_frame(np.zeros((0, 0), np.uint32))
+                o.render_lines(nl)
+                want = o.last_carrier()
+                for _ in range(3):
+                    e.audio_write(audio)
+                got, _, _ = e.host_side_streams(e.info["delay_lines"] * W, nl * W)
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    return "CARRIERS", desc, "the host's sound pre-pass differs from the oracle's carriers"
     except H.HvkError as err:
         return "refused", desc, str(err)[:80]
     def once():
@@ -204,7 +226,7 @@ def main():
             if time.time() - t0 > LIMIT:
                 break
     print(" ".join("%d %s" % (v, k) for k, v in sorted(counts.items())), "%.0f s" % (time.time() - t0))
-    sys.exit(1 if counts.get("DIFFERENT") or counts.get("ERROR") or counts.get("TABLES") else 0)
+    sys.exit(1 if counts.get("DIFFERENT") or counts.get("ERROR") or counts.get("TABLES") or counts.get("CARRIERS") else 0)
 
 
 if __name__ == "__main__":
