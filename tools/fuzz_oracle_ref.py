@@ -187,6 +187,23 @@ def run(item):
                 got, _, _ = e.host_side_streams(e.info["delay_lines"] * W, nl * W)
                 if got.shape != want.shape or not np.array_equal(got, want):
                     return "CARRIERS", desc, "the host's sound pre-pass differs from the oracle's carriers"
+        # ... and the sound-in-syncs burst records (which symbols every line's burst carries: the NICAM framer fed through the
+        # hand-over of 32-sample blocks, hvk_audio.c) on LOUD random sound -- the oracle's reading of the hand-over is the
+        # engine's, whatever the reference's threads do (tests/test_host_path.py has eight golden cases)
+        if setup[4].get("sis") and not setup[4].get("raw_bb") and not setup[4].get("teletext"):
+            with H.Engine(conf, setup[1], device=-1, pixel_rate=setup[6]) as e, oracle.Oracle(conf, setup[1], setup[6]) as o:
+                arng = np.random.default_rng(len(desc) + 1)
+                audio = arng.integers(-32768, 32768, (4096 + 37, 2), dtype=np.int64).astype(np.int16)
+                n = 1400
+                o.set_audio(audio, True)
+                o.set_frame(np.zeros((0, 0), np.uint32))
+                o.render_lines(n)
+                want = o.sis_bursts(0, n)
+                for _ in range(4):
+                    e.audio_write(audio)
+                got = np.concatenate([e.host_sis_bursts(0, 700), e.host_sis_bursts(700, 1), e.host_sis_bursts(701, n - 701)])
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    return "SIS", desc, "the host's sound-in-syncs burst records differ from the oracle's"
     except H.HvkError as err:
         return "refused", desc, str(err)[:80]
     def once():
@@ -226,7 +243,7 @@ def main():
             if time.time() - t0 > LIMIT:
                 break
     print(" ".join("%d %s" % (v, k) for k, v in sorted(counts.items())), "%.0f s" % (time.time() - t0))
-    sys.exit(1 if counts.get("DIFFERENT") or counts.get("ERROR") or counts.get("TABLES") or counts.get("CARRIERS") else 0)
+    sys.exit(1 if counts.get("DIFFERENT") or counts.get("ERROR") or counts.get("TABLES") or counts.get("CARRIERS") or counts.get("SIS") else 0)
 
 
 if __name__ == "__main__":
