@@ -1392,6 +1392,9 @@ size_t hvk_audio_state_bytes(void) { return(sizeof(_audio_state_t)); }
 
 int64_t hvk_audio_generated(const hvk_audio_t *a) { return(a ? a->generated : 0); }
 
+/* the position in the 32 kHz source behind the last pair the queue holds: the next hvk_audio_push() continues there */
+int64_t hvk_audio_source_end(const hvk_audio_t *a) { return(a ? a->src_base + (int64_t) a->src_len : 0); }
+
 int hvk_audio_state_export(hvk_audio_t *a, void *buf, size_t bytes)
 {
 	_audio_state_t *st = buf;

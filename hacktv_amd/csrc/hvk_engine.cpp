@@ -308,6 +308,12 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	if(!pe || !conf) return(HVK_ERROR);
 	*pe = NULL;
+	if(conf->struct_size != sizeof(hvk_config_t))
+	{
+		fprintf(stderr, "libhvk: hvk_config_t.struct_size is %u, this library's is %zu: the caller was built against another include/hvk_config.h "
+		                "(or did not set it: hvk_config_preset() and HVK_CONFIG_INIT do)\n", conf->struct_size, sizeof(hvk_config_t));
+		return(HVK_ERROR);
+	}
 	if(max_frames < 1) max_frames = 1;
 
 	e = (hvk_engine *) calloc(1, sizeof(hvk_engine));
@@ -1018,6 +1024,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 extern "C" int hvk_get_info(const hvk_engine_t *e, hvk_info_t *info)
 {
 	if(!e || !info) return(HVK_ERROR);
+	if(info->struct_size != sizeof(hvk_info_t)) return(HVK_ERROR);     /* (the caller's layout is not this library's: nothing is written) */
 	const hvk_kconst_t &k = e->t.k;
 	info->sample_rate = e->t.sample_rate;
 	info->width = k.width;
@@ -1227,6 +1234,46 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	return(HVK_OK);
 }
 
+/* The picture of another engine's slot (same configuration; any device) into a slot of this one, device to device:
+ * what a group does on 525 lines with the picture a block's last frame shows, which the next block's engine needs in
+ * front of its first frame. Ordered behind everything queued on the source engine's stream so far; the source engine's
+ * next work waits for the copy. */
+extern "C" int hvk_frame_copy(hvk_engine_t *e, int slot, hvk_engine_t *from, int from_slot)
+{
+	if(!e || !from || slot < 0 || slot >= e->frame_slots || from_slot < 0 || from_slot >= from->frame_slots) return(HVK_ERROR);
+	if(e->device < 0 || from->device < 0) return(HVK_NO_DEVICE);
+	const hvk_kconst_t &k = e->t.k;
+	if(k.active_width != from->t.k.active_width || k.active_lines != from->t.k.active_lines || e->secam || from->secam) return(HVK_UNSUPPORTED);
+	if(e == from && slot == from_slot) return(HVK_OK);
+
+	hvk_slot_t *s = &e->slots[slot];
+	const hvk_slot_t *f = &from->slots[from_slot];
+	s->valid = f->valid; s->width = f->width; s->height = f->height; s->interlaced = f->interlaced;
+	s->par_num = f->par_num; s->par_den = f->par_den; s->many_colours = f->many_colours;
+	s->plane_dirty = 1;
+	s->shown = 0;
+	s->cells_valid[0] = s->cells_valid[1] = 0;
+	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
+	if(!f->valid) return(HVK_OK);
+
+	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	hipEvent_t a = NULL, b = NULL;
+	HIPCHK(hipSetDevice(from->device));
+	HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(a, from->stream));
+	HIPCHK(hipSetDevice(e->device));
+	HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+	HIPCHK(hipStreamWaitEvent(e->stream, a, 0));
+	HIPCHK(hipMemcpyPeerAsync(e->d_pool + slot * frame_px, e->device, from->d_pool + from_slot * frame_px, from->device,
+	                          (size_t) f->width * f->height * 4, e->stream));
+	HIPCHK(hipEventRecord(b, e->stream));
+	HIPCHK(hipSetDevice(from->device));
+	HIPCHK(hipStreamWaitEvent(from->stream, b, 0));
+	(void) hipEventDestroy(a);      /* (released once the work queued on them is through) */
+	(void) hipEventDestroy(b);
+	return(HVK_OK);
+}
+
 extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
 {
 	if(!e || mode < HVK_LEVELS_AUTO || mode > HVK_LEVELS_COMPUTE) return(HVK_ERROR);
@@ -1320,6 +1367,11 @@ extern "C" int hvk_sound_state_import(hvk_engine_t *e, const void *buf, size_t b
 extern "C" int64_t hvk_sound_samples_generated(const hvk_engine_t *e)
 {
 	return((e && e->audio) ? hvk_audio_generated(e->audio) : 0);
+}
+
+extern "C" int64_t hvk_sound_source_end(const hvk_engine_t *e)
+{
+	return((e && e->audio) ? hvk_audio_source_end(e->audio) : 0);
 }
 
 extern "C" size_t hvk_audio_needed(const hvk_engine_t *e, int nframes)
@@ -1593,6 +1645,7 @@ static void _fm_worker(hvk_engine *e)
 		if(r == HVK_OK) r = hvk_tail_fm_apply(e->tail, j.pos, j.count, j.iq);
 		lk.lock();
 		e->fm_status[j.ticket] = r;
+		if(r != HVK_OK) e->poisoned = 1;        /* the phasor did not run over these samples: every later job would be out of step */
 		e->fm_q->pop_front();           /* (behind the work: an empty queue means nothing is being worked on) */
 		e->fm_cv->notify_all();
 	}
@@ -2829,7 +2882,9 @@ extern "C" int hvk_stream_is_one_chain(const hvk_engine_t *e)
 {
 	if(!e) return(0);
 	const hvk_kconst_t &k = e->t.k;
-	return(k.secam || k.fm_video || k.rs_irr || k.has_passthru || k.rawbb);
+	/* (sound-in-syncs: its burst encoder keeps the sound chains a line or more ahead of the requests, and a state that
+	 * stands past the last request is not one hvk_sound_state_export() hands on) */
+	return(k.secam || k.fm_video || k.rs_irr || k.has_passthru || k.rawbb || k.sis);
 }
 
 /* hvk_k_sums: a grid-stride pass over the words, a lane's two partial sums folded through the wave and one pair of

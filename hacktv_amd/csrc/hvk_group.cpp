@@ -48,8 +48,14 @@ typedef struct {
 	int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t);
 	int (*GroupStart)(void);
 	int (*GroupEnd)(void);
+	int (*GetVersion)(int *);   /* (not needed by the gather: hvk_rccl_probe() reports it) */
 } rccl_t;
 #define NCCL_INT32 2
+
+/* how the blocks of a round reach the root device */
+enum { GATHER_LOCAL = 0,        /* every engine on the root's device: device-to-device copies on the root's stream */
+       GATHER_RCCL = 1,         /* distinct devices: grouped ncclSend / ncclRecv, one communicator per device */
+       GATHER_PEER = 2 };       /* hipMemcpyPeerAsync, every sender pushing its block over its own link on its own stream */
 
 struct hvk_group {
 	int n, block;
@@ -68,21 +74,20 @@ struct hvk_group {
 	int chains_taken;           /* the block being prepared has taken the chains over already */
 	std::vector<uint8_t> state; /* the chains as exported after the last block staged */
 	int have_state;
-	/* the last picture uploaded (dense copy): the next block's engine needs it too on 525 lines */
-	std::vector<uint32_t> lastpic;
-	int last_w, last_h, last_il, last_valid;
 	/* gather */
 	rccl_t rccl;
 	std::vector<ncclComm_t> comms;
 	int distinct;               /* every engine on a device of its own */
+	int mode;                   /* GATHER_* */
+	int peer_ready;             /* peer access between the devices asked for (once) */
 	std::vector<hipStream_t> gstream;
 	std::vector<hipEvent_t> gev;
 	char backend[96];
 };
 
-static int _rccl_load(hvk_group *g)
+static int _rccl_load(rccl_t *out)
 {
-	if(g->rccl.lib) return(HVK_OK);
+	if(out->lib) return(HVK_OK);
 	void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 	if(!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 	if(!lib) { fprintf(stderr, "libhvk: librccl.so.1 not found (%s)\n", dlerror()); return(HVK_UNSUPPORTED); }
@@ -96,14 +101,37 @@ static int _rccl_load(hvk_group *g)
 	*(void **) &r.Recv = dlsym(lib, "ncclRecv");
 	*(void **) &r.GroupStart = dlsym(lib, "ncclGroupStart");
 	*(void **) &r.GroupEnd = dlsym(lib, "ncclGroupEnd");
+	*(void **) &r.GetVersion = dlsym(lib, "ncclGetVersion");
 	if(!r.CommInitAll || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
 	{
 		fprintf(stderr, "libhvk: librccl.so.1 lacks a symbol the gather needs\n");
 		dlclose(lib);
 		return(HVK_UNSUPPORTED);
 	}
-	g->rccl = r;
+	*out = r;
 	return(HVK_OK);
+}
+
+/* Can the RCCL reassembly be used at all on this machine? Loads librccl.so.1 the way the gather does, binds the seven
+ * entry points it calls and writes "rccl <version code>" into msg. Needs no device (a CPU-only test calls it). */
+extern "C" int hvk_rccl_probe(char *msg, size_t len)
+{
+	rccl_t r;
+	memset(&r, 0, sizeof(r));
+	int rc = _rccl_load(&r);
+	if(rc != HVK_OK) { if(msg && len) snprintf(msg, len, "librccl.so.1 could not be loaded or lacks a symbol"); return(rc); }
+	int v = 0;
+	if(r.GetVersion) (void) r.GetVersion(&v);
+	if(msg && len) snprintf(msg, len, "rccl %d: ncclCommInitAll ncclCommDestroy ncclGetErrorString ncclSend ncclRecv ncclGroupStart ncclGroupEnd bound", v);
+	dlclose(r.lib);
+	return(HVK_OK);
+}
+
+static void _name_backend(hvk_group *g)
+{
+	snprintf(g->backend, sizeof(g->backend), "%s", g->n == 1 ? "none (one engine)" :
+		g->mode == GATHER_RCCL ? "rccl (grouped ncclSend / ncclRecv, one communicator per device)" :
+		g->mode == GATHER_PEER ? "peer (hipMemcpyPeerAsync, every sender on its own stream)" : "hipMemcpyAsync (engines share a device)");
 }
 
 extern "C" int hvk_group_open(hvk_group_t **pg, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
@@ -111,12 +139,20 @@ extern "C" int hvk_group_open(hvk_group_t **pg, const hvk_config_t *conf, unsign
 {
 	if(!pg || !conf || !devices || ndevices < 1 || ndevices > 64 || block_frames < 1) return(HVK_ERROR);
 	*pg = NULL;
+	if(conf->struct_size != sizeof(hvk_config_t)) return(hvk_open_rates((hvk_engine_t **) pg, conf, sample_rate, pixel_rate, -1, 1));   /* (says why, returns HVK_ERROR) */
 	hvk_group *g = new hvk_group();
 	g->n = ndevices;
 	g->block = block_frames;
 	g->prev_slot = block_frames;
 	g->distinct = 1;
 	for(int i = 0; i < ndevices; i++) for(int j = 0; j < i; j++) if(devices[i] == devices[j]) g->distinct = 0;
+	if(conf->interlace)
+	{
+		/* (two pictures per frame: the block's slot list, the upload call and the carried picture here all count frames) */
+		fprintf(stderr, "libhvk: refused: a group renders one picture per frame; --interlace (a picture per field, src/video.c:4873) goes through one engine's own calls\n");
+		delete g;
+		return(HVK_UNSUPPORTED);
+	}
 	for(int i = 0; i < ndevices; i++)
 	{
 		hvk_engine_t *e = NULL;
@@ -126,18 +162,24 @@ extern "C" int hvk_group_open(hvk_group_t **pg, const hvk_config_t *conf, unsign
 		g->eng.push_back(e);
 		g->dev.push_back(devices[i]);
 	}
+	g->info.struct_size = (uint32_t) sizeof(g->info);
 	hvk_get_info(g->eng[0], &g->info);
 	g->has_sound = g->info.has_carriers || g->info.has_nicam || hvk_sound_state_size(g->eng[0]) > 0;
 	g->needs_prev = hvk_last_line_shows_picture(g->eng[0]);
 	if(ndevices > 1 && hvk_stream_is_one_chain(g->eng[0]))
 	{
-		fprintf(stderr, "libhvk: this configuration is one serial chain over the stream (SECAM colour, FM video, frames of two lengths, or a sound-in-syncs "
-		                "process behind a threaded colour process): one engine renders it, a group of %d does not\n", ndevices);
+		fprintf(stderr, "libhvk: refused: this configuration is one serial chain over the stream (SECAM colour, FM video, frames of two lengths, passthru, raw "
+		                "baseband, or sound-in-syncs, whose burst encoder runs ahead of the sound chains): one engine renders it, a group of %d does not\n", ndevices);
 		hvk_group_close(g);
 		return(HVK_UNSUPPORTED);
 	}
 	g->state.resize(hvk_sound_state_size(g->eng[0]));
-	snprintf(g->backend, sizeof(g->backend), "%s", ndevices == 1 ? "none (one engine)" : (g->distinct ? "rccl (grouped ncclSend / ncclRecv, one communicator per device)" : "hipMemcpyAsync (engines share a device)"));
+	/* HVK_GATHER=peer: hipMemcpyPeerAsync instead of RCCL (also between engines that share a device: the one-GPU test of
+	 * that branch); HVK_GATHER=rccl (the default between distinct devices) falls back to peer copies when librccl cannot
+	 * be loaded or its communicators cannot be made */
+	const char *want = getenv("HVK_GATHER");
+	g->mode = ndevices == 1 ? GATHER_LOCAL : (want && !strcmp(want, "peer")) ? GATHER_PEER : g->distinct ? GATHER_RCCL : GATHER_LOCAL;
+	_name_backend(g);
 	*pg = g;
 	return(HVK_OK);
 }
@@ -184,7 +226,9 @@ static int _take_chains(hvk_group *g)
 			g->src_base += drop;
 		}
 		if(pos < g->src_base) return(HVK_ERROR);     /* (cannot happen: nothing behind the chains' position is dropped) */
-		g->fed_to = pos;
+		/* an engine whose queue still holds `pos` keeps what it was dealt behind it the last time round (hvk_audio.c:
+		 * hvk_audio_state_import): it goes on from the END of what it holds, not from pos -- or it would get those pairs twice */
+		g->fed_to = std::max<int64_t>(pos, hvk_sound_source_end(e));
 	}
 	g->chains_taken = 1;
 	return(HVK_OK);
@@ -226,26 +270,7 @@ extern "C" int hvk_group_frame_upload(hvk_group_t *g, int frame_in_block, const 
                                       int pixel_stride, int line_stride, int interlaced)
 {
 	if(!g || frame_in_block < 0 || frame_in_block >= g->block) return(HVK_ERROR);
-	int r = hvk_frame_upload(hvk_group_block_engine(g), frame_in_block, fb, width, height, pixel_stride, line_stride, interlaced);
-	if(r != HVK_OK) return(r);
-	if(g->needs_prev && g->n > 1)
-	{
-		/* kept dense: the engine of the next block wants the stream's last picture so far in a slot of its own */
-		g->last_valid = fb != NULL && width > 0 && height > 0;
-		g->last_w = width; g->last_h = height; g->last_il = interlaced;
-		if(g->last_valid)
-		{
-			g->lastpic.resize((size_t) width * height);
-			for(int y = 0; y < height; y++)
-			{
-				const uint32_t *p = fb + (int64_t) y * line_stride;
-				uint32_t *o = g->lastpic.data() + (size_t) y * width;
-				if(pixel_stride == 1) memcpy(o, p, (size_t) width * 4);
-				else for(int x = 0; x < width; x++) o[x] = p[(int64_t) x * pixel_stride];
-			}
-		}
-	}
-	return(HVK_OK);
+	return(hvk_frame_upload(hvk_group_block_engine(g), frame_in_block, fb, width, height, pixel_stride, line_stride, interlaced));
 }
 
 /* Stage the next block: nframes <= block_frames frames from the stream's next frame on, on engine (block mod N); `slots`
@@ -282,9 +307,10 @@ extern "C" int hvk_group_stage(hvk_group_t *g, int nframes, const int32_t *slots
 	}
 	if(g->needs_prev)
 	{
-		/* the stream's last picture so far, for the engine of the block behind this one */
+		/* the picture this block's LAST frame shows -- the slot named for it, whenever and in whatever order it was
+		 * uploaded -- for the engine of the block behind this one: device to device, into the slot kept for it */
 		hvk_engine_t *nx = g->eng[(size_t) ((g->next_block + 1) % g->n)];
-		r = hvk_frame_upload(nx, g->prev_slot, g->last_valid ? g->lastpic.data() : NULL, g->last_w, g->last_h, 1, g->last_w, g->last_il);
+		r = hvk_frame_copy(nx, g->prev_slot, e, slots ? slots[nframes - 1] : nframes - 1);
 		if(r != HVK_OK) return(r);
 	}
 	g->staged = nframes;
@@ -323,13 +349,35 @@ extern "C" int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t s
 			HIPCHK(hipEventCreateWithFlags(&g->gev[i], hipEventDisableTiming));
 		}
 	}
-	if(g->distinct && g->n > 1 && g->comms.empty())
+	if(g->mode == GATHER_RCCL && g->comms.empty())
 	{
-		int r = _rccl_load(g);
-		if(r != HVK_OK) return(r);
-		g->comms.resize(g->n, NULL);
-		int e = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data());
-		if(e != 0) { fprintf(stderr, "libhvk: ncclCommInitAll: %s\n", g->rccl.GetErrorString(e)); g->comms.clear(); return(HVK_ERROR); }
+		int r = _rccl_load(&g->rccl);
+		if(r == HVK_OK)
+		{
+			g->comms.resize(g->n, NULL);
+			int e = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data());
+			if(e != 0)
+			{
+				fprintf(stderr, "libhvk: ncclCommInitAll: %s -- the gather goes by hipMemcpyPeerAsync instead\n", g->rccl.GetErrorString(e));
+				g->comms.clear();
+				r = HVK_ERROR;
+			}
+		}
+		if(r != HVK_OK) { g->mode = GATHER_PEER; _name_backend(g); }
+	}
+	if(g->mode == GATHER_PEER && !g->peer_ready)
+	{
+		/* direct access both ways where the devices allow it (a copy between devices without it is staged by the runtime) */
+		for(int i = 0; i < g->n; i++) for(int j = 0; j < g->n; j++)
+		{
+			int can = 0;
+			if(g->dev[i] == g->dev[j] || hipDeviceCanAccessPeer(&can, g->dev[i], g->dev[j]) != hipSuccess || !can) continue;
+			HIPCHK(hipSetDevice(g->dev[i]));
+			hipError_t pe = hipDeviceEnablePeerAccess(g->dev[j], 0);
+			if(pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); }
+		}
+		(void) hipGetLastError();
+		g->peer_ready = 1;
 	}
 
 	/* the transfers run on streams of their own, behind each engine's render (an event on the engine's stream) */
@@ -343,7 +391,7 @@ extern "C" int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t s
 	}
 	char *dst = (char *) d_root;
 	const size_t bytes = samples * 4;
-	if(g->distinct && g->n > 1)
+	if(g->mode == GATHER_RCCL)
 	{
 		int e = g->rccl.GroupStart();
 		for(int i = 0; i < g->n && e == 0; i++)
@@ -355,13 +403,33 @@ extern "C" int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t s
 		const int e2 = g->rccl.GroupEnd();
 		if(e != 0 || e2 != 0) { fprintf(stderr, "libhvk: rccl gather: %s\n", g->rccl.GetErrorString(e ? e : e2)); return(HVK_ERROR); }
 	}
+	else if(g->mode == GATHER_PEER)
+	{
+		/* every sender pushes its block on ITS stream (N - 1 links at once); the root's stream then waits for each of them */
+		for(int i = 0; i < g->n; i++)
+		{
+			if(i == root) continue;
+			HIPCHK(hipSetDevice(g->dev[i]));
+			HIPCHK(hipMemcpyPeerAsync(dst + (size_t) i * bytes, g->dev[root], hvk_output_device_ptr(g->eng[i]), g->dev[i], bytes, g->gstream[i]));
+			HIPCHK(hipEventRecord(g->gev[i], g->gstream[i]));
+			HIPCHK(hipSetDevice(g->dev[root]));
+			HIPCHK(hipStreamWaitEvent(g->gstream[root], g->gev[i], 0));
+		}
+	}
 	else
 	{
 		for(int i = 0; i < g->n; i++)
 		{
 			if(i == root) continue;
 			HIPCHK(hipSetDevice(g->dev[root]));
-			HIPCHK(hipMemcpyAsync(dst + (size_t) i * bytes, hvk_output_device_ptr(g->eng[i]), bytes, hipMemcpyDeviceToDevice, g->gstream[root]));
+			if(g->dev[i] == g->dev[root])
+			{
+				HIPCHK(hipMemcpyAsync(dst + (size_t) i * bytes, hvk_output_device_ptr(g->eng[i]), bytes, hipMemcpyDeviceToDevice, g->gstream[root]));
+			}
+			else
+			{
+				HIPCHK(hipMemcpyPeerAsync(dst + (size_t) i * bytes, g->dev[root], hvk_output_device_ptr(g->eng[i]), g->dev[i], bytes, g->gstream[root]));
+			}
 		}
 	}
 	/* the root's own block, and the root engine's stream behind all of it */
@@ -377,17 +445,10 @@ extern "C" int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t s
 	for(int i = 0; i < g->n; i++)
 	{
 		if(i == root) continue;
-		if(g->distinct)
-		{
-			HIPCHK(hipSetDevice(g->dev[i]));
-			HIPCHK(hipEventRecord(g->gev[i], g->gstream[i]));
-			HIPCHK(hipStreamWaitEvent((hipStream_t) hvk_engine_stream(g->eng[i]), g->gev[i], 0));
-		}
-		else
-		{
-			HIPCHK(hipSetDevice(g->dev[i]));
-			HIPCHK(hipStreamWaitEvent((hipStream_t) hvk_engine_stream(g->eng[i]), g->gev[root], 0));
-		}
+		HIPCHK(hipSetDevice(g->dev[i]));
+		if(g->mode == GATHER_RCCL) HIPCHK(hipEventRecord(g->gev[i], g->gstream[i]));
+		/* (peer: gev[i] was recorded behind the sender's copy; local: the root's stream did the copying) */
+		HIPCHK(hipStreamWaitEvent((hipStream_t) hvk_engine_stream(g->eng[i]), g->gev[g->mode == GATHER_LOCAL ? root : i], 0));
 	}
 	return(HVK_OK);
 }

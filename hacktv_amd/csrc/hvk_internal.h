@@ -279,6 +279,7 @@ size_t hvk_audio_state_bytes(void);
 int hvk_audio_state_export(hvk_audio_t *a, void *buf, size_t bytes);
 int hvk_audio_state_import(hvk_audio_t *a, const void *buf, size_t bytes, int64_t *source_pos);
 int64_t hvk_audio_generated(const hvk_audio_t *a);
+int64_t hvk_audio_source_end(const hvk_audio_t *a);
 /* sound-in-syncs: the bursts of stream lines [g_first, g_first + count), 8 bytes a line (7 bytes of bits MSB first, their number) */
 int hvk_audio_sis_fetch(hvk_audio_t *a, int64_t g_first, int count, uint8_t *out);
 int hvk_audio_advance(hvk_audio_t *a, int64_t end);

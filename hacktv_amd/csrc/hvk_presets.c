@@ -282,6 +282,7 @@ int hvk_config_preset(hvk_config_t *c, const char *id)
 	if(c == NULL || id == NULL) return(HVK_ERROR);
 
 	memset(c, 0, sizeof(*c));
+	c->struct_size = (uint32_t) sizeof(*c);
 	c->volume = 256; /* src/hacktv.c:1431 with the default --volume 1.0 */
 
 	if(strcmp(id, "i") == 0)

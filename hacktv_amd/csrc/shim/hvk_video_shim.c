@@ -334,7 +334,7 @@ static int _refuse(const char *what)
 
 static int _translate(hvk_config_t *h, const vid_config_t *c, unsigned int sample_rate, unsigned int pixel_rate)
 {
-	memset(h, 0, sizeof(*h));
+	HVK_CONFIG_INIT(h);
 
 	/* (src/video.h:50-59: the raster types' numbers are the engine's; MAC is a packet multiplex, not a raster) */
 	if(c->type != VID_RASTER_625 && c->type != VID_RASTER_525 && c->type != VID_RASTER_405 && c->type != VID_RASTER_819 && c->type != VID_BAIRD_240 &&
@@ -494,6 +494,7 @@ int vid_init(vid_t *s, unsigned int sample_rate, unsigned int pixel_rate, const 
 		return(r == HVK_OUT_OF_MEMORY ? VID_OUT_OF_MEMORY : VID_ERROR);
 	}
 
+	m->info.struct_size = (uint32_t) sizeof(m->info);
 	hvk_get_info(m->e, &m->info);
 	if(m->info.lines > (int) sizeof(m->held) || hvk_vbi_lines_held(m->e, m->held, (int) sizeof(m->held)) != HVK_OK)
 	{

@@ -11,6 +11,7 @@ class HvkRational(C.Structure):
 class HvkConfig(C.Structure):
     # field order == include/hvk_config.h
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("output_type", C.c_int),
         ("modulation", C.c_int),
         ("video_bw", C.c_double),
@@ -85,9 +86,13 @@ class HvkConfig(C.Structure):
         ("frame_orientation", C.c_int),
     ]
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)      # (HVK_CONFIG_INIT)
+
 
 class HvkInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in (
         "sample_rate", "width", "half_width", "active_width", "active_left",
         "lines", "active_lines",
         "white_level", "black_level", "blanking_level", "sync_level",
@@ -95,8 +100,12 @@ class HvkInfo(C.Structure):
         "colour_lookup_width", "burst_left", "burst_width",
         "has_carriers", "has_nicam", "pixel_rate", "max_width", "startup_samples")]
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
+
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "struct_size"}
 
 
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8

@@ -27,6 +27,7 @@ SYMBOLS = [
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
     "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages", "hvk_levels_short_form",
+    "hvk_sound_source_end", "hvk_frame_copy", "hvk_rccl_probe",
 ]
 
 _lib = None
@@ -147,6 +148,10 @@ def lib():
         L.hvk_block_sums.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
         L.hvk_fused_launches.argtypes = [vp]
         L.hvk_fused_launches.restype = i64
+        L.hvk_sound_source_end.argtypes = [vp]
+        L.hvk_sound_source_end.restype = i64
+        L.hvk_frame_copy.argtypes = [vp, i32, vp, i32]
+        L.hvk_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -159,6 +164,13 @@ def preset(mode, flags=0):
         raise HvkError("hvk_config_preset(%r)" % mode, r)
     lib().hvk_config_apply_flags(C.byref(c), flags)
     return c
+
+
+def rccl_probe():
+    """(code, message): does librccl.so.1 load and hold the seven entry points hvk_group_gather() calls? No device needed."""
+    buf = C.create_string_buffer(256)
+    r = lib().hvk_rccl_probe(buf, len(buf))
+    return r, buf.value.decode()
 
 
 class Engine:

@@ -81,6 +81,8 @@ typedef struct hvk_engine hvk_engine_t;
  * members hacktv.c reads from vid_t after vid_init() (src/hacktv.c:1503-1518)
  * are all here. */
 typedef struct hvk_info_t {
+	uint32_t struct_size;       /* set by the CALLER to sizeof(hvk_info_t) before hvk_get_info(): any other value is
+	                             * HVK_ERROR and nothing is written (a caller built against another release's layout) */
 	int32_t sample_rate;
 	int32_t width;              /* samples per line */
 	int32_t half_width;
@@ -213,11 +215,14 @@ size_t hvk_audio_needed(const hvk_engine_t *e, int nframes);
  * (may be NULL) receives the position in the 32 kHz source stream the chains go on from: an engine whose audio queue
  * does not hold it drops what it holds and takes the next hvk_audio_write() to start there. With it a rank of a
  * sharded render runs the chains over its own frames only (hvk_sound_samples_generated() says over how many samples
- * it did) instead of over the whole stream up to them. */
+ * it did) instead of over the whole stream up to them. An engine whose queue DOES hold the position keeps the pairs
+ * behind it: hvk_sound_source_end() is the source position the next hvk_audio_write() continues at (the caller must not
+ * write pairs in front of it a second time). */
 size_t hvk_sound_state_size(const hvk_engine_t *e);
 int hvk_sound_state_export(hvk_engine_t *e, void *buf, size_t bytes);
 int hvk_sound_state_import(hvk_engine_t *e, const void *buf, size_t bytes, int64_t *source_position);
 int64_t hvk_sound_samples_generated(const hvk_engine_t *e);
+int64_t hvk_sound_source_end(const hvk_engine_t *e);
 
 /* --passthru (conf.passthru != 0): the next nsamples int16 I/Q pairs of the
  * external signal that is added to the output (src/video.c:3517-3541), in
@@ -412,9 +417,9 @@ int hvk_set_levels(hvk_engine_t *e, int mode);
  * from PICTURE PLANES: what src/video.c:2864-3030 computes of a scanline before the sub-carrier is modulated -- sync
  * pulses, the levels of the pixels, the low-passed chroma, the burst -- depends on the picture alone and is made once
  * per uploaded picture, by the first hvk_stage_strided() / hvk_render() that shows it (a picture that stays is not
- * worked on again) -- when that block is LAUNCHED, a chunk of frames at a time on a second stream,
- * each chunk's render behind its planes, so that the planes of one chunk are made beside the render of the chunk
- * before. hvk_planes_refresh() has the planes of the named slots made again by the next launch that shows them: for a
+ * worked on again) -- when that block is LAUNCHED, on the engine's stream in front of the render
+ * (HVK_PREP_CHUNK / HVK_PREP_STREAMS=2 keep the measured-and-lost experiment of making them a chunk of frames at a time
+ * on a second stream beside the render of the chunk before). hvk_planes_refresh() has the planes of the named slots made again by the next launch that shows them: for a
  * caller that wants that work inside a clock of its own. SECAM has a
  * per-picture share of the same kind: the low-passed colour-difference cells of a picture, kept per slot and frame
  * parity (hvk_secam.hip); for the named slots they are dropped and made again by the next stage that shows them.
@@ -454,7 +459,7 @@ const char *hvk_version(void);
  * serial sound chains are handed from engine to engine in process, the 32 kHz source is kept by the group and dealt to
  * the engine whose block draws it, and on 525 lines the picture of the frame before a block reaches the block's engine
  * too (hvk_group.cpp). Configurations that are one chain over every sample of the stream (SECAM colour, FM video,
- * --pixelrate pairs with frames of two lengths) are refused for N > 1.
+ * --pixelrate pairs with frames of two lengths, passthru, raw baseband, sound-in-syncs) are refused for N > 1.
  *
  * A block: hvk_group_frame_upload() for its pictures (frame i of the block -> slot i of the block's engine),
  * hvk_group_audio_write() while hvk_group_audio_needed() > 0, anything per frame (teletext packets, caption pairs)
@@ -463,7 +468,11 @@ const char *hvk_version(void);
  *        page-locked stream buffer -- N devices, N PCIe links, the shape a host rf_* sink wants; or
  *   (ii) gathered on one device: hvk_group_gather() after a round of N blocks -- grouped ncclSend / ncclRecv from C
  *        (librccl is loaded on first use) between distinct devices, device-to-device copies between engines that share
- *        one (hvk_group_gather_backend() says which). */
+ *        one; HVK_GATHER=peer takes hipMemcpyPeerAsync instead (every sender pushing its block on a stream of its own),
+ *        which is also what a machine without a usable librccl falls back to (hvk_group_gather_backend() says which was
+ *        taken; hvk_rccl_probe() whether librccl.so.1 loads and has the seven entry points -- no device needed).
+ * Refused: --interlace (a picture per field: one engine's own calls), and for N > 1 the configurations above and
+ * sound-in-syncs. */
 typedef struct hvk_group hvk_group_t;
 int hvk_group_open(hvk_group_t **g, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
                    const int *devices, int ndevices, int block_frames);
@@ -476,12 +485,17 @@ int hvk_group_block_index(const hvk_group_t *g);           /* ... and its index 
 int64_t hvk_group_next_frame(const hvk_group_t *g);        /* the stream's next frame (frames launched so far) */
 int hvk_group_frame_upload(hvk_group_t *g, int frame_in_block, const uint32_t *fb, int width, int height,
                            int pixel_stride, int line_stride, int interlaced);
+/* The picture of slot from_slot of engine `from` into slot `slot` of engine e, device to device (any two devices;
+ * engines of one configuration). hvk_group_stage() uses it on 525 lines: the picture the block's last frame shows
+ * goes to the next block's engine, which needs it within its first samples' filter reach. */
+int hvk_frame_copy(hvk_engine_t *e, int slot, hvk_engine_t *from, int from_slot);
 int hvk_group_audio_write(hvk_group_t *g, const int16_t *stereo, size_t nsamples);
 size_t hvk_group_audio_needed(hvk_group_t *g, int nframes);
 int hvk_group_stage(hvk_group_t *g, int nframes, const int32_t *slots);
 int hvk_group_launch(hvk_group_t *g, void *d_iq);          /* returns the index of the engine that renders the block */
 int hvk_group_gather(hvk_group_t *g, int root, void *d_root, size_t samples);
 const char *hvk_group_gather_backend(const hvk_group_t *g);
+int hvk_rccl_probe(char *msg, size_t len);
 
 /* What a group asks of an engine: the HIP stream it launches on; whether the last line of a frame shows picture (525
  * lines: a block's first frame needs the picture of the frame before); whether the stream is one serial chain that

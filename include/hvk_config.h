@@ -16,6 +16,7 @@
 #define HVK_CONFIG_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -72,6 +73,11 @@ typedef struct {
 } hvk_rational_t; /* r64_t, src/common.h:31-34 */
 
 typedef struct hvk_config_t {
+
+	uint32_t struct_size;       /* sizeof(hvk_config_t) of the header the CALLER was built with: hvk_config_preset() fills it
+	                             * in, a caller that fills the struct member by member sets it itself (HVK_CONFIG_INIT).
+	                             * hvk_open() / hvk_open_rates() / hvk_group_open() return HVK_ERROR on any other value -- an
+	                             * embedder built against another release's layout is told so instead of being misread */
 
 	int output_type;            /* HVK_INT16_COMPLEX | HVK_INT16_REAL */
 
@@ -198,6 +204,9 @@ typedef struct hvk_config_t {
 	int frame_orientation;      /* HVK_ROTATE_* | HVK_HFLIP | HVK_VFLIP, src/video.h:62-67 */
 
 } hvk_config_t;
+
+/* all members zero, struct_size set: the starting point of a configuration filled member by member */
+#define HVK_CONFIG_INIT(c) do { memset((c), 0, sizeof(hvk_config_t)); (c)->struct_size = (uint32_t) sizeof(hvk_config_t); } while(0)
 
 #ifdef __cplusplus
 }

@@ -160,3 +160,65 @@ def test_lines_held_by_the_other_inserters():
     c.secam_field_id, c.secam_field_id_lines = 1, 5
     with H.Engine(c, 16000000, device=-1) as e:
         assert e.vbi_lines_held() == list(range(7, 12)) + list(range(320, 325))
+
+
+def test_a_caller_built_against_another_layout_is_told_so():
+    """hvk_config_t.struct_size / hvk_info_t.struct_size: an embedder whose structs are not this library's (a shorter,
+    older hvk_config_t; an info struct of another size) gets HVK_ERROR from hvk_open() / hvk_get_info() -- it is not
+    misread, and nothing is written into a struct of the wrong size."""
+    L = H.lib()
+    c = H.preset("i", H.FLAG_FILTER)
+    assert c.struct_size == ctypes.sizeof(H.HvkConfig)
+    h = ctypes.c_void_p()
+    for bad in (0, ctypes.sizeof(H.HvkConfig) - 32, ctypes.sizeof(H.HvkConfig) + 8):
+        c.struct_size = bad
+        assert L.hvk_open(ctypes.byref(h), ctypes.byref(c), 16000000, -1, 1) == H.HVK_ERROR and not h.value
+        assert L.hvk_open_rates(ctypes.byref(h), ctypes.byref(c), 16000000, 0, -1, 1) == H.HVK_ERROR and not h.value
+        devs = (ctypes.c_int * 1)(-1)
+        assert L.hvk_group_open(ctypes.byref(h), ctypes.byref(c), 16000000, 0, devs, 1, 1) == H.HVK_ERROR and not h.value
+    c.struct_size = ctypes.sizeof(H.HvkConfig)
+    with H.Engine(c, 16000000, device=-1) as e:
+        info = H.HvkInfo()
+        info.struct_size = ctypes.sizeof(info) - 4
+        info.width = -7
+        assert L.hvk_get_info(e.h, ctypes.byref(info)) == H.HVK_ERROR and info.width == -7
+        info.struct_size = ctypes.sizeof(info)
+        assert L.hvk_get_info(e.h, ctypes.byref(info)) == H.HVK_OK and info.width == 1024
+
+
+def test_rccl_loads_and_has_the_gathers_entry_points():
+    """hvk_rccl_probe(): librccl.so.1 is found the way hvk_group_gather() finds it and all seven entry points the grouped
+    ncclSend / ncclRecv reassembly calls are bound (the container and the GPU box carry /opt/rocm/lib/librccl.so.1). No
+    device needed: communicators are made at the first gather between distinct devices."""
+    from hacktv_amd.engine import rccl_probe
+    code, msg = rccl_probe()
+    assert code == H.HVK_OK, msg
+    assert msg.startswith("rccl ") and int(msg.split()[1].rstrip(":")) >= 20000
+    for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGetErrorString", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
+        assert name in msg
+
+
+def test_groups_refuse_what_they_cannot_cut_into_blocks(capfd):
+    """--interlace (a picture per field: every N) and, for N > 1, the streams that are one serial chain -- SECAM colour,
+    FM video, sound-in-syncs (its burst encoder keeps the sound chains ahead of the requests: the state cannot be handed
+    on) -- are refused when the group is opened, with a line that says why; host tables only, no device."""
+    def try_open(conf, sr, devices):
+        h = ctypes.c_void_p()
+        devs = (ctypes.c_int * len(devices))(*devices)
+        r = H.lib().hvk_group_open(ctypes.byref(h), ctypes.byref(conf), sr, 0, devs, len(devices), 2)
+        if r == H.HVK_OK:
+            H.lib().hvk_group_close(h)
+        return r
+
+    c = H.preset("i", H.FLAG_FILTER)
+    assert try_open(c, 16000000, [-1, -1]) == H.HVK_OK
+    c.interlace = 1
+    assert try_open(c, 16000000, [-1]) == H.HVK_UNSUPPORTED and try_open(c, 16000000, [-1, -1]) == H.HVK_UNSUPPORTED
+    assert "--interlace" in capfd.readouterr().err
+    c = H.preset("i", H.FLAG_FILTER)
+    c.sis = 1
+    assert try_open(c, 16000000, [-1]) == H.HVK_OK
+    assert try_open(c, 16000000, [-1, -1]) == H.HVK_UNSUPPORTED
+    assert "sound-in-syncs" in capfd.readouterr().err
+    for mode in ("l", "pal-fm"):
+        assert try_open(H.preset(mode, 0), 16000000 if mode == "l" else 14000000, [-1, -1]) == H.HVK_UNSUPPORTED

@@ -56,6 +56,101 @@ def test_three_engines_with_sound_host_direct(golden):
         assert sum(gen) <= 129 * fs and max(gen) < 60 * fs, gen
 
 
+def test_sound_written_far_ahead_of_the_blocks(golden):
+    """The caller writes the 32 kHz source a long way ahead (one 204 800-pair chunk = 160 frames at a time) and the
+    stream runs PAST it: 165 frames in blocks of 5 over three engines. An engine that comes round again still holds what
+    it was dealt behind its last block (hvk_sound_state_import keeps a queue that holds the position) -- the group must go
+    on from the END of what the engine holds, not deal those pairs a second time (they would be played, time-shifted,
+    once the first chunk is used up: frames 160 on). Cumulative digests at 37, 128 and 165 frames; and no engine's
+    queue grows beyond what the stream has written."""
+    conf, sr = golden.conf("i_full")
+    want = LONG["i_full"]["sha256_at_frames"]
+    h = hashlib.sha256()
+    done = 0
+    written = 0
+    with H.Group(conf, sr, [0, 0, 0], 5) as g:
+        fs = g.info["frame_samples"]
+        blocks = [5] * 7 + [2] + [5] * 18 + [1] + [5] * 7 + [2]
+        assert sum(blocks) == 165
+        for b in blocks:
+            e = g.block_engine()
+            for i in range(b):
+                g.frame_upload(i, golden.frame("i_full"))
+            while g.audio_needed(b) > 0:
+                g.audio_write(golden.audio)
+                written += len(golden.audio)
+            g.stage(b)
+            g.launch()
+            h.update(e.fetch(0, b * fs).tobytes())
+            done += b
+            assert H.lib().hvk_sound_source_end(e.h) <= written, "an engine holds source pairs the caller never wrote: dealt twice"
+            if str(done) in want:
+                assert h.copy().hexdigest() == want[str(done)], "first %d frames differ from the reference" % done
+        assert done == 165 and written >= 2 * len(golden.audio)
+
+
+def _gather_rounds(golden, case, devices, expect, monkeypatch=None):
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipSetDevice.argtypes = [ctypes.c_int]
+    conf, sr = golden.conf(case)
+    want = golden.cases[case]["sha256_cumulative"]
+    n = len(devices)
+    with H.Group(conf, sr, devices, 1) as g:
+        fs = g.info["frame_samples"]
+        root = ctypes.c_void_p()
+        hip.hipSetDevice(devices[0])
+        assert hip.hipMalloc(ctypes.byref(root), n * fs * 4) == 0
+        host = np.zeros((n * fs, 2), np.int16)
+        h = hashlib.sha256()
+        for rnd in range(len(want) // n):           # (the committed cumulative digests hold four frames)
+            for k in range(n):
+                g.frame_upload(0, golden.frame(case))
+                _feed(g, golden, 1)
+                g.stage(1)
+                g.launch()
+            g.gather(0, root, fs)
+            assert expect in g.gather_backend(), g.gather_backend()
+            g.engines[0].sync()
+            hip.hipSetDevice(devices[0])
+            assert hip.hipMemcpy(host.ctypes.data, root, n * fs * 4, 2) == 0
+            h.update(host.tobytes())
+            assert h.copy().hexdigest() == want[n * (rnd + 1) - 1], (case, rnd, g.gather_backend())
+        hip.hipFree(root)
+
+
+def test_gather_by_peer_copies(golden, monkeypatch):
+    """HVK_GATHER=peer: hipMemcpyPeerAsync, every sender pushing its block on a stream of its own and the root's stream
+    waiting for each -- the reassembly for a machine without a usable librccl, here between engines on one device."""
+    monkeypatch.setenv("HVK_GATHER", "peer")
+    for case in ("i_vsb", "i_full"):
+        _gather_rounds(golden, case, [0, 0], "peer")
+
+
+def _device_count():
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0)
+    return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+
+
+def test_gather_between_distinct_devices(golden, monkeypatch):
+    """More than one HIP device (an 8-GPU node; one MI355X in CPX / DPX partition mode): the RCCL branch -- one
+    communicator per device, grouped ncclSend / ncclRecv -- and the peer-copy branch, each against the reference's
+    digests, with sound (the chains handed on between engines on different devices) and without."""
+    nd = _device_count()
+    if nd < 2:
+        pytest.skip("one HIP device: hvk_group_gather's RCCL branch needs two (tools/probe_partitions.sh says whether this box can be partitioned)")
+    for devs in ([0, 1], list(range(min(nd, 4)))):
+        monkeypatch.delenv("HVK_GATHER", raising=False)
+        for case in ("i_vsb", "i_full"):
+            _gather_rounds(golden, case, devs, "rccl")
+        monkeypatch.setenv("HVK_GATHER", "peer")
+        for case in ("i_vsb", "i_full"):
+            _gather_rounds(golden, case, devs, "peer")
+
+
 def test_two_engines_gathered_on_one_device(golden):
     """--noaudio and with sound: rounds of two 1-frame blocks, gathered into the root engine's device memory
     (hvk_group_gather: engines that share a device -> device-to-device copies; distinct devices -> RCCL), read back from
