@@ -455,6 +455,108 @@ def c_group_section(H, g, devices, Fb, rounds, log):
     return res
 
 
+def c_group_timed(H, g, dist, torch, rank, devices, F, steps, warmup, noaudio, log):
+    """N > 1, the path of record: ONE process (rank 0) drives one engine per device through hvk_group_* -- host code in C,
+    as north_star asks -- and a step is a round: every engine renders its block of F frames, the blocks are reassembled on
+    the root device (hvk_group_gather: RCCL between distinct devices, peer copies where RCCL is not to be had). K steps
+    between barriers over ALL ranks (the others hold their devices idle), the maximum over ranks taken by the caller's
+    all_reduce. Round 0 goes through the group's own stage / launch calls with the sound chains handed from engine to
+    engine, and is hashed against the reference before anything is timed; the timed steps launch the staged blocks again
+    (inputs resident in HBM, like the headline at N = 1)."""
+    import ctypes as C_
+    import hashlib
+    N = len(devices)
+    res = None
+    t_steps = t_render = t_host = 0.0
+    if rank == 0:
+        conf = H.preset(MODE, H.FLAG_FILTER | (H.FLAG_NOAUDIO if noaudio else 0))
+        grp = H.Group(conf, SAMPLE_RATE, devices, F)
+        fs = grp.info["frame_samples"]
+        hip = C_.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C_.POINTER(C_.c_void_p), C_.c_size_t]
+        hip.hipMemcpy.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_size_t, C_.c_int]
+        hip.hipFree.argtypes = [C_.c_void_p]
+        hip.hipSetDevice.argtypes = [C_.c_int]
+        hip.hipSetDevice(devices[0])
+        root = C_.c_void_p()
+        if hip.hipMalloc(C_.byref(root), N * F * fs * 4) != 0:
+            raise SystemExit("c_group: no room for the gathered round on the root device")
+        for e in grp.engines:
+            e.frame_upload(0, g.frame("i_full"))
+        for b in range(N):
+            if not noaudio:
+                while grp.audio_needed(F) > 0:
+                    grp.audio_write(g.audio)
+            grp.stage(F, slots=[0] * F)
+            grp.launch()
+        grp.gather(0, root, F * fs)
+        grp.engines[0].sync()
+        gate = "skipped (--noaudio is not the metric configuration)"
+        if not noaudio:
+            host = np.zeros((N * F * fs, 2), np.int16)
+            hip.hipSetDevice(devices[0])
+            assert hip.hipMemcpy(host.ctypes.data, root, N * F * fs * 4, 2) == 0
+            got = hashlib.sha256(host.tobytes()).hexdigest()
+            del host
+            want = ref_stream_sha(MODE, SAMPLE_RATE, ["--filter"], 0, N * F, fs * 4)
+            if want is None:
+                raise SystemExit("c_group gate: oracle/_ref/hacktv_ref is missing -- refusing to report a number")
+            if got != want:
+                raise SystemExit("c_group gate failed: %d engines x %d frames gathered on the root device differ from the reference CLI's output" % (N, F))
+            gate = "round 0: %d frames over %d engines, sound chains handed on in process, gathered on device %d (%s): sha256 == hacktv_ref run in this job" % (N * F, N, devices[0], grp.gather_backend())
+            log("c_group gate ok: " + gate)
+
+        def one(gather=True):
+            for e in grp.engines:
+                e.launch()
+            if gather:
+                grp.gather(0, root, F * fs)
+
+        def sync_all():
+            for e in grp.engines:
+                e.sync()
+        for _ in range(warmup):
+            one()
+        sync_all()
+    dist.barrier()
+    if rank == 0:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        sync_all()
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        t_steps = time.perf_counter() - t0
+        # beside it: the same launches without the reassembly, and with the host-direct reassembly (every engine's block
+        # read back into its place in one page-locked stream buffer: N PCIe links, what a host rf_* sink wants)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one(False)
+        sync_all()
+        t_render = time.perf_counter() - t0
+        hb = grp.engines[0].host_buffer(N * F * fs)
+        k_hd = max(2, min(steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(k_hd):
+            one(False)
+            tk = [(e, e.fetch_async(hb[i * F * fs:(i + 1) * F * fs], 0, F * fs)) for i, e in enumerate(grp.engines)]
+            for e, t in tk:
+                e.fetch_wait(t)
+        t_host = (time.perf_counter() - t0) / k_hd
+        res = {"devices": list(devices), "engines": N, "block_frames": F, "gather_backend": grp.gather_backend(), "parity_gate": gate,
+               "gathered_on_root_device_Msamples_per_s": round(N * F * fs * steps / t_steps / 1e6, 1),
+               "render_only_Msamples_per_s": round(N * F * fs * steps / t_render / 1e6, 1),
+               "host_direct_Msamples_per_s": round(N * F * fs / t_host / 1e6, 1),
+               "note": "one process, N devices, host code in C (hvk_group_*): `value` is the gathered figure -- bound by the root's ingest, about 38 Gsamples/s per "
+                       "xGMI link, not by the kernels; render_only is the same launches without the reassembly; host_direct reads every engine's block back into "
+                       "its place in one page-locked stream buffer (N PCIe links)"}
+        hip.hipSetDevice(devices[0])
+        hip.hipFree(root)
+        grp.close()
+    return t_steps, res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -768,6 +870,21 @@ def main():
     if gather and not args.walk_rounds:
         dt2 = timed(lambda i: e.launch(ctypes.c_void_p(mines[i % nbuf].data_ptr())), lambda: None)
         render_only = samples_per_step * args.steps / dt2 / 1e6
+
+    # ---- N > 1: the path of record is the C group (one process, N devices); what the ranks measured above through
+    # torch.distributed stays beside it as the cross-check ----
+    cg_timed = None
+    harness = None
+    if N > 1 and not args.walk_rounds:
+        harness = {"gathered_Msamples_per_s": round(value, 1) if gather else None, "ms_per_step": round(ms_per_step, 4),
+                   "render_only_Msamples_per_s": None if render_only is None else round(render_only, 1)}
+        dt_c, cg_timed = c_group_timed(H, g, dist, torch, rank, [0] * N if dry else list(range(N)), F, args.steps, args.warmup, args.noaudio, log)
+        tt = torch.tensor([dt_c], dtype=torch.float64, device="cpu" if dry else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        value = samples_per_step * args.steps / dt / 1e6
+        ms_per_step = dt / args.steps * 1e3
+        sub_ms = []
 
     # ---- one FRESH block end to end: host pre-pass + H2D of the side inputs, render, D2H of the samples ----
     e2e = None
@@ -1129,23 +1246,29 @@ def main():
                 "frames_per_gpu_per_step": F,
                 "samples_per_step": samples_per_step,
                 "also_measured": also,
-                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, ", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else ""),
+                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, (", one process driving an engine per device (hvk_group_*), blocks gathered on the root device in the step: " + cg_timed["gather_backend"]) if cg_timed else
+                                                                         (", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else "")),
             },
             "parity_gate": gate,
             "multi_gpu": {"ranks": 1, "backend": "none (one process, one device)", "c_group": cgroup,
                           "reassembly": "host-direct (every engine's block straight into the host stream buffer) and gathered on a root device (hvk_group_gather): both in c_group",
                           "sound_chains": "one recurrence over every sample of the stream: with sound the scaling curve is flat by construction (about 0.5 Gsamples/s, one host core), only --noaudio scales"} if N == 1 else {
                 "c_group": cgroup,
+                "c_group_timed": cg_timed,
+                "value_from": "walk over rounds through the torch.distributed harness (--walk-rounds)" if args.walk_rounds else
+                              "c_group_timed: rank 0 drives one engine per device through hvk_group_* (C inside libhvk), K rounds of N blocks + hvk_group_gather between barriers over all ranks",
+                "torch_harness": harness,
                 "ranks": N, "world_size": dist.get_world_size(),
                 "backend": (args.dry_run_backend + " (dry run: every rank on GPU 0, transport through host memory)") if dry else "nccl (RCCL); the sound chains' state between hosts: gloo",
                 "walk_rounds": bool(args.walk_rounds), "walk_gate": walk_gate,
-                "gathered_Msamples_per_s": round(value, 1) if gather else None,
+                "gathered_Msamples_per_s": round(value, 1) if (gather or cg_timed) else None,
                 "sound_chains": "handed from rank to rank (hvk_sound_state_export / _import): every rank runs them over its own frames only",
                 "gather_in_step": bool(gather), "gather_overlaps_render": bool(gather and not dry),
                 "seam_gate": seam_gate,
                 "render_only_Msamples_per_s": None if render_only is None else round(render_only, 1),
-                "note": "value includes the reassembly of the contiguous stream on rank 0 (grouped send/recv, one xGMI link per peer): it is bound by "
-                        "the root's ingest (about 38 Gsamples/s per link), not by the kernels; render_only is the same steps without it. With sound on, a run "
+                "note": "value includes the reassembly of the contiguous stream on the root device (hvk_group_gather: one xGMI link per peer): it is bound by "
+                        "the root's ingest (about 38 Gsamples/s per link), not by the kernels; render_only is the same steps without it. torch_harness: the same "
+                        "sharding with one process per GPU over torch.distributed (the earlier rounds' path of record), kept as the cross-check. With sound on, a run "
                         "that also stages every round is bound by the serial host pre-pass (host_prepass), whatever the number of GPUs",
             },
             "roofline": roof,

@@ -148,6 +148,13 @@ def test_two_ranks_on_one_gpu_reassemble_the_reference_stream(walk):
     assert d["multi_gpu"]["seam_gate"] and "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
     assert "sha256 ==" in d["parity_gate"]
     assert d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["walk_rounds"] == walk
+    if not walk:
+        # the path of record at N > 1: one process, one engine per device, hvk_group_* in C; the harness beside it
+        cg = d["multi_gpu"]["c_group_timed"]
+        assert d["multi_gpu"]["value_from"].startswith("c_group_timed")
+        assert cg["engines"] == 2 and "sha256 == hacktv_ref" in cg["parity_gate"]
+        assert abs(d["value"] - cg["gathered_on_root_device_Msamples_per_s"]) < 0.2 and cg["host_direct_Msamples_per_s"] > 0
+        assert d["multi_gpu"]["torch_harness"]["gathered_Msamples_per_s"] > 0
     if walk:
         # every step staged and rendered the next round, the sound chains went from rank to rank, and the last round
         # walked (round 3: frames 18 .. 20 on rank 0) still is the reference's
