@@ -70,7 +70,10 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[17];          /* what sa points into (freed at close) */
+	void *d_secam[19];          /* what sa points into (freed at close) */
+	int secam_walk_ok;          /* 1: hvk_k_secam_walk<0> may be taken; 2: its computed FM steps and decoded gains equal the tables' on every index (tried at open) */
+	int secam_walk_mode;        /* HVK_SECAM_WALK: -1 the engine's choice per stage, 0 the chain kernel, 1 / 2 hvk_k_secam_walk<0 / 1> */
+	int64_t secam_walk_stages[3];   /* stages that went through the chain kernel / hvk_k_secam_walk<0> / <1> */
 	int secam_est_ran, secam_ek_adapt, secam_ek_base, secam_ek_clean;      /* this stage ran the estimate; its reach (a.EK) follows the blocks */
 	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
 	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
@@ -898,6 +901,61 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 					a.corr = (int32_t *) e->d_secam[16];
 				}
 			}
+			{
+				/* hvk_k_secam_walk<1> (hvk_secam_args_t.phc): the coarse phasors, the bell filter's gains in 32-index blocks --
+				 * and every index of the deviation range tried on the device against the tables before the kernel may be taken */
+				const double rate = (double) e->t.pixel_rate, fm_dev = 1000e3, fm_freq = 4328125;       /* src/video.c:45-46 */
+				std::vector<double> phc((size_t) 513 * 2);
+				for(int i = 0; i < 513; i++)
+				{
+					const double d = 2.0 * M_PI / rate * (fm_freq + (double) (i * 128 - 32768) / INT16_MAX * fm_dev);
+					phc[(size_t) i * 2 + 0] = cos(d) * INT32_MAX;
+					phc[(size_t) i * 2 + 1] = sin(d) * INT32_MAX;
+				}
+				a.ph_k1 = 2.0 * M_PI / rate * (fm_dev / INT16_MAX);
+				const int lo = a.C.dmin[0] < a.C.dmin[1] ? a.C.dmin[0] : a.C.dmin[1], hi = a.C.dmax[0] > a.C.dmax[1] ? a.C.dmax[0] : a.C.dmax[1];
+				a.bell_c0 = lo & ~31;
+				a.bell_blocks = (hi - a.bell_c0) / 32 + 1;
+				std::vector<uint32_t> bz((size_t) a.bell_blocks * 4, 0);
+				bool ok = lo > INT16_MIN + 64 && hi < INT16_MAX - 64 && a.bell_blocks <= 4096;
+				for(int b = 0; b < a.bell_blocks && ok; b++)
+				{
+					const int first = a.bell_c0 + 32 * b;
+					hvk_c16_t g0 = e->t.secam_bell[(uint16_t) (int16_t) first];
+					bz[(size_t) b * 4] = (uint32_t) (uint16_t) g0.i | ((uint32_t) (uint16_t) g0.q << 16);
+					for(int t = 0; t < 31 && first + t + 1 <= hi; t++)
+					{
+						const hvk_c16_t g1 = e->t.secam_bell[(uint16_t) (int16_t) (first + t + 1)];
+						const int di = g1.i - g0.i, dq = g1.q - g0.q;
+						if(dq < 0 || dq > 1 || di < -1 || di > 1) { ok = false; break; }
+						if(dq) bz[(size_t) b * 4 + 1] |= 1u << t;
+						if(di > 0) bz[(size_t) b * 4 + 2] |= 1u << t;
+						if(di < 0) bz[(size_t) b * 4 + 3] |= 1u << t;
+						g0 = g1;
+					}
+				}
+				e->secam_walk_ok = 1;
+				if(ok)
+				{
+					OPENCHK(_upload(&e->d_secam[17], phc.data(), phc.size() * sizeof(double)));
+					OPENCHK(_upload(&e->d_secam[18], bz.data(), bz.size() * 4));
+					a.phc = (const double *) e->d_secam[17];
+					a.bellz = (const uint32_t *) e->d_secam[18];
+					a.lut = (const hvk_secam_c32_t *) e->d_secam[2];
+					a.bell = (const hvk_secam_c16_t *) e->d_secam[3];
+					void *d_n = NULL;
+					int differ = -1;
+					OPENHIP(hipMalloc(&d_n, sizeof(int)));
+					OPENCHK(hvk_launch_secam_check_walk(&a, (int *) d_n, e->stream));
+					OPENHIP(hipMemcpyAsync(&differ, d_n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+					OPENHIP(hipStreamSynchronize(e->stream));
+					(void) hipFree(d_n);
+					if(differ == 0) e->secam_walk_ok = 2;
+					else { a.phc = NULL; a.bellz = NULL; }
+					if(getenv("HVK_SHIM_STATS")) fprintf(stderr, "libhvk: SECAM FM steps computed / gains from blocks: %d of %d indices differ from the tables\n", differ, hi - lo + 1);
+				}
+				e->secam_walk_mode = getenv("HVK_SECAM_WALK") ? atoi(getenv("HVK_SECAM_WALK")) : -1;
+			}
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 4 * sizeof(int), hipHostMallocDefault));
@@ -1452,6 +1510,13 @@ extern "C" int64_t hvk_secam_estimated_stages(const hvk_engine_t *e)
 	return(e && e->secam_dev ? e->secam_est_stages : 0);
 }
 
+extern "C" int hvk_secam_walk_stages(const hvk_engine_t *e, int64_t counts[3])
+{
+	if(!e || !counts) return(HVK_ERROR);
+	for(int i = 0; i < 3; i++) counts[i] = e->secam_dev ? e->secam_walk_stages[i] : 0;
+	return(e->secam_dev ? e->secam_walk_ok : 0);
+}
+
 extern "C" int64_t hvk_frame_start(const hvk_engine_t *e, int64_t frame)
 {
 	if(!e || frame < 0) return(HVK_ERROR);
@@ -1816,7 +1881,22 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	{
 		int want = a.kf == NULL;
 		for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
-		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, e->stream)) != HVK_OK) return(r);
+		/* One line per lane and no warm-up line anywhere in the block (entry states estimated, or kept from the picture's
+		 * last showing): hvk_k_secam_walk. Its FM steps computed and its gains from LDS where the block shows pictures of many
+		 * colours -- their table reads would scatter over a cache line per sample --, both from the table otherwise (the
+		 * lines of a wave then read neighbouring entries) */
+		int walk = e->secam_walk_ok && a.R == 1;
+		if(a.kf == NULL) walk = walk && (a.est != NULL || a.K == 0);
+		else for(int i = 0; i < nframes && walk; i++) walk = e->h_secam_rows[2 * e->max_frames + i] <= 0;
+		if(walk)
+		{
+			int many = 0;
+			for(int i = 0; i < nframes && !many; i++) many = e->slots[e->staged_slots[i]].many_colours;
+			walk = (many && e->secam_walk_ok == 2) ? 2 : 1;
+			if(e->secam_walk_mode >= 0) walk = e->secam_walk_mode > e->secam_walk_ok ? e->secam_walk_ok : e->secam_walk_mode;
+		}
+		e->secam_walk_stages[walk]++;
+		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, walk, e->stream)) != HVK_OK) return(r);
 		if(e->secam_est && want) e->secam_est_stages++;
 		e->secam_est_ran = e->secam_est && want;
 	}

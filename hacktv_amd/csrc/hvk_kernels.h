@@ -189,13 +189,28 @@ typedef struct {
 	int *flags;                 /* [tpad] */
 	int *count;
 	int16_t *chroma;            /* [nframes][raster_samples] */
+	/* hvk_k_secam_walk<1>: a line's walk without a table read from HBM per sample. The FM step of index c is
+	 * lround(INT32_MAX cos / sin(kap0 + kap1 c)) (src/video.c:2236): c = 128 kh + kl, the coarse phasors (already times
+	 * INT32_MAX) from a 513-entry table that lives in LDS, the fine one by a polynomial in kap1 kl (|kl| <= 64: 7.7e-4 rad at
+	 * most), the product rounded -- equal to the table's entry for every index of the deviation range: hvk_k_secam_check_walk
+	 * tries them all when the engine is opened, and an engine for which one differs keeps the table. The bell filter's gain
+	 * (two int16) moves by at most one unit from index to index: 32 indices a 16-byte block -- the values at the block's
+	 * first index, then a bit per step up (q; i) and per step down (i) -- decoded by population counts, 14 KB in LDS
+	 * instead of a 256 KB table in HBM. */
+	const double *phc;          /* [513][2]: INT32_MAX * (cos, sin) of the angle of index 128 k - 32768 */
+	const uint32_t *bellz;      /* [bell_blocks][4]: {gain i | gain q << 16, q steps up, i steps up, i steps down} */
+	int bell_c0, bell_blocks;   /* the first index the blocks cover (a multiple of 32 below the deviation limits) */
+	double ph_k1;               /* the angle of one index step */
 } hvk_secam_args_t;
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, hipStream_t stream);
+/* walk: 0 the general chain kernel (warm-up lines, runs of several tasks); 1 hvk_k_secam_walk<0> -- one line per lane from
+ * an estimated or kept entry state, FM steps and gains from the table; 2 hvk_k_secam_walk<1> -- steps computed, gains from LDS */
+int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, int walk, hipStream_t stream);
+int hvk_launch_secam_check_walk(const hvk_secam_args_t *a, int *differ, hipStream_t stream);
 int hvk_launch_secam_check(const hvk_secam_args_t *a, hipStream_t stream);
 int hvk_launch_secam_redo(const hvk_secam_args_t *a, int round, hipStream_t stream);
 int hvk_launch_secam_carry(const hvk_secam_args_t *a, hipStream_t stream);

@@ -95,13 +95,14 @@ __device__ __forceinline__ task_view task_of(const hvk_secam_args_t &a, const in
 	return(v);
 }
 
-/* hvk_secam_round_away() without its branches (a lane test per sample would cost an exec-mask round trip each):
- * truncate, then look at the exactly representable rest; halves go away from zero */
+/* hvk_secam_round_away() -- to the nearest whole number, halves away from zero -- without branches, comparisons or the
+ * condition register: 2 x is exact, k = trunc(2 x) keeps every half, and round(x) = (k + 1) >> 1 for k >= 0, k >> 1 for k < 0
+ * (floor(k / 2) = -ceil(|k| / 2)). Needs |2 x| < 2^31: the IIR's output stays below 2^21 (its gain is at most 3 and its
+ * impulse response sums to less than 60, over int16 input). */
 __device__ __forceinline__ int32_t round_away_nb(const double x)
 {
-	const int32_t i = (int32_t) x;
-	const double f = x - (double) i;
-	return(i + (int32_t) (f >= 0.5) - (int32_t) (f <= -0.5));
+	const int32_t k = (int32_t) (x + x);
+	return((k + 1 + (k >> 31)) >> 1);
 }
 
 /* ------------------------------------------------------------------ */
@@ -429,15 +430,12 @@ void hvk_k_secam_cells(const hvk_secam_args_t a)
 
 /* ------------------------------------------------------------------ */
 
-/* One line's walk by one lane: hvk_secam_chain_line() in chunks of CH samples -- the low pass read 8 at a time from
- * the transposed store (the next chunk's loads go out before this chunk's arithmetic), the IIR over the whole
- * chunk first, then all of the chunk's table reads at once (the bell-filter gain and the FM step of every sample:
- * 2 x CH loads in flight instead of one round trip per sample), then the FM recurrence, then the output 8 at a
- * time. Same arithmetic, same order per sample. */
-#define CH 16
-/* (the walk's table reads as plain loads: marked non-temporal they take twice as long, 2.69 against 1.43 ms per 512 noisy frames --
- * what reuse there is happens in L1) */
-#define LUTB_LOAD(p) (*(p))
+/* One line's walk by one lane (walk_fast, below): hvk_secam_chain_line() in chunks of 8 samples -- the low pass read 8 at a
+ * time from the transposed store (the next chunk's load goes out before this chunk's arithmetic), the IIR over the whole
+ * chunk first, then all of the chunk's table reads at once (plain loads: marked non-temporal they take twice as long --
+ * what reuse there is happens in L1), then the FM recurrence, then the output 8 at a time. Same arithmetic, same order
+ * per sample. (Chunks of 16 with 2 x 16 table reads in flight were the form of rounds 3 and 4: 134 registers a lane and
+ * 155 spilled scalar registers; at 8 the kernels hold five to six waves per SIMD, which hides the reads as well.) */
 __device__ __forceinline__ void unpack8(const int4 pk, int16_t *f)
 {
 	f[0] = (int16_t) pk.x; f[1] = (int16_t) (pk.x >> 16);
@@ -456,183 +454,23 @@ __device__ __forceinline__ int4 pack8(const int16_t *o)
 	return(po);
 }
 
-/* EMIT = false: a warm-up line -- only the state it leaves matters, so the output half of an FM step (level, bell-filter
- * gain and its table read, burst window) is left out */
-template<bool EMIT>
-__device__ __forceinline__ void walk_line(const hvk_secam_args_t &a, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
-{
-	const int W = a.C.W, sl = a.C.sl;
-	const int16_t dmin = a.C.dmin[v.dr], dmax = a.C.dmax[v.dr];
-	const int32_t dmin32 = dmin, dmax32 = dmax;
-	const int32_t level = a.C.level;
-	const int fm_end = v.sr < W ? v.sr : W;
-	double ix = S.ix, iy = S.iy;
-	int32_t pi = v.phase_pos ? INT32_MAX : -INT32_MAX, pq = 0;
-	const int cm = a.cbase[v.frame] + (m - v.frame * a.ntasks);     /* the task's row in the cell stores */
-	const int4 *F = (const int4 *) a.F + cm;
-	const int chunks = W / CH;          /* W is a multiple of 16 (checked by the launcher) */
-
-	int4 nx0 = F[0], nx1 = F[(size_t) a.cpad];
-	for(int ch = 0; ch < chunks; ch++)
-	{
-		int16_t f[CH], o[CH];
-		unpack8(nx0, f);
-		unpack8(nx1, f + 8);
-		if(ch + 1 < chunks)
-		{
-			nx0 = F[(size_t) (2 * ch + 2) * a.cpad];
-			nx1 = F[(size_t) (2 * ch + 3) * a.cpad];
-		}
-
-		if(ch == chunks - 1)
-		{
-			/* the last 7: add what lies behind the line (output x reads tail[i] through tap W + 7 + i - x) */
-			for(int j = CH - HVK_SECAM_TAIL; j < CH; j++)
-			{
-				const int x = ch * CH + j;
-				int32_t s = a.acc[(size_t) cm * 8 + (j - (CH - HVK_SECAM_TAIL))];
-				for(int i = 0; i < HVK_SECAM_TAIL; i++)
-				{
-					const int k = W + 7 + i - x;
-					if(k <= 14) s += (int32_t) S.tail[i] * a.C.fir[k];
-				}
-				s >>= 15;
-				f[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
-			}
-		}
-
-		/* (u[j]: the table index of sample j -- the IIR's output rounded, limited to int16 (src/fir.c:729-733:
-		 * clamp-then-round == round-then-clamp, the bounds are whole numbers and rounding is monotone; |iy| stays far
-		 * below 2^31) and then to the line's deviation range (src/video.c:3215-3216), which lies inside int16: ONE
-		 * v_med3_i32 does both) */
-		unsigned u[CH];
-#pragma unroll
-		for(int j = 0; j < CH; j++)
-		{
-			const double in = (double) f[j];
-			const double t0 = in * 2.90456054;
-			const double t1 = ix * -2.80912108;
-			const double t2 = iy * -0.90456054;
-			iy = (t0 + t1) - t2;
-			ix = in;
-			const int32_t r = round_away_nb(iy);
-			const int32_t c = r < dmin32 ? dmin32 : (r > dmax32 ? dmax32 : r);
-			u[j] = (unsigned) (c + 32768);
-		}
-
-		const int x0 = ch * CH;
-		if(__all(x0 >= sl && x0 + CH <= fm_end))
-		{
-			/* the chunk lies inside the sub-carrier window of every line of the wave (all but the chunks at the window's
-			 * ends, and half lines): the same steps without a test per sample */
-			hvk_secam_c16_t g[CH];
-			hvk_secam_c32_t st[CH];
-			if(EMIT)
-			{
-				/* (step and bell-filter gain of an index side by side: one 16-byte read, one cache line per sample) */
-#pragma unroll
-				for(int j = 0; j < CH; j++)
-				{
-					const int4 q = LUTB_LOAD(((const int4 *) a.lutb) + u[j]);
-					st[j].i = q.x; st[j].q = q.y;
-					g[j].i = (int16_t) q.z; g[j].q = (int16_t) (q.z >> 16);
-				}
-			}
-			else
-			{
-#pragma unroll
-				for(int j = 0; j < CH; j++) st[j] = a.lut[u[j]];     /* (unsigned indices: the loads take the table's address from scalar registers) */
-			}
-#pragma unroll
-			for(int j = 0; j < CH; j++)
-			{
-				const int64_t ni = (int64_t) pi * st[j].i - (int64_t) pq * st[j].q;
-				const int64_t nq = (int64_t) pi * st[j].q + (int64_t) pq * st[j].i;
-				pi = (int32_t) (ni >> 31);
-				pq = (int32_t) (nq >> 31);
-				if(EMIT)
-				{
-					const int32_t vi = ((pi >> 16) * level) >> 15;
-					const int32_t vq = ((pq >> 16) * level) >> 15;
-					const int16_t vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
-					o[j] = (int16_t) ((vv * a.burst_win[x0 + j - sl]) >> 15);
-				}
-			}
-		}
-		else if(x0 + CH > sl && x0 < fm_end)
-		{
-			hvk_secam_c16_t g[CH];
-			hvk_secam_c32_t st[CH];
-			if(EMIT)
-			{
-				/* (step and bell-filter gain of an index side by side: one 16-byte read, one cache line per sample) */
-#pragma unroll
-				for(int j = 0; j < CH; j++)
-				{
-					const int4 q = LUTB_LOAD(((const int4 *) a.lutb) + u[j]);
-					st[j].i = q.x; st[j].q = q.y;
-					g[j].i = (int16_t) q.z; g[j].q = (int16_t) (q.z >> 16);
-				}
-			}
-			else
-			{
-#pragma unroll
-				for(int j = 0; j < CH; j++) st[j] = a.lut[u[j]];     /* (unsigned indices: the loads take the table's address from scalar registers) */
-			}
-#pragma unroll
-			for(int j = 0; j < CH; j++)
-			{
-				const int x = x0 + j;
-				int16_t vv = 0;
-				if(x >= sl && x < fm_end)
-				{
-					/* hvk_secam_fm_step() with the table entries already here */
-					const int64_t ni = (int64_t) pi * st[j].i - (int64_t) pq * st[j].q;
-					const int64_t nq = (int64_t) pi * st[j].q + (int64_t) pq * st[j].i;
-					pi = (int32_t) (ni >> 31);
-					pq = (int32_t) (nq >> 31);
-					if(EMIT)
-					{
-						const int32_t vi = ((pi >> 16) * level) >> 15;
-						const int32_t vq = ((pq >> 16) * level) >> 15;
-						vv = (int16_t) (((vi * g[j].i) >> 15) - ((vq * g[j].q) >> 15));
-						vv = (int16_t) ((vv * a.burst_win[x - sl]) >> 15);
-					}
-				}
-				o[j] = vv;
-			}
-		}
-		else
-		{
-#pragma unroll
-			for(int j = 0; j < CH; j++) o[j] = 0;
-		}
-
-		if(EMIT && out)
-		{
-			*(int4 *) (out + x0) = pack8(o);
-			*(int4 *) (out + x0 + 8) = pack8(o + 8);
-		}
-	}
-
-	S.ix = ix;
-	S.iy = iy;
-	for(int x = W; x < v.sr; x++) S.tail[x - W] = hvk_secam_fm_step(a.lut, a.bell, S.tail[x - W], dmin, dmax, level, &pi, &pq);
-}
-
 __device__ __forceinline__ int16_t *out_of(const hvk_secam_args_t &a, const task_view &v)
 {
 	if(v.line < 1) return(NULL);        /* the fill slots are never seen */
 	return(a.chroma + (size_t) v.frame * a.raster_samples + (size_t) (v.line - 1) * a.C.W);
 }
 
+typedef struct { double x, y; } dbl2_t;
+template<int PH, bool EMIT = true>
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out);
+
 __device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit)
 {
 	const task_view v = task_of(a, m);
 	if(!v.valid) return;
 	if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
-	if(emit) walk_line<true>(a, m, v, S, out_of(a, v));
-	else walk_line<false>(a, m, v, S, NULL);
+	if(emit) walk_fast<0, true>(a, NULL, NULL, m, v, S, out_of(a, v));
+	else walk_fast<0, false>(a, NULL, NULL, m, v, S, NULL);
 }
 
 /* the row of task m in the store of kept states */
@@ -891,6 +729,207 @@ void hvk_k_secam_chain(const hvk_secam_args_t a)
 	a.exit[r] = S;
 }
 
+/* ---- hvk_k_secam_walk: the walk of ONE line per lane from an estimated or kept entry state (no warm-up lines, no runs
+ * of several tasks: what a settled stream and a stream of new pictures both end at). The chain kernel above keeps every
+ * other case; this one is what the time goes to, so it carries nothing it does not use. PH = 1: no table read from HBM
+ * per sample (hvk_secam_args_t.phc). ---- */
+/* the FM step of index c, computed: lround(INT32_MAX (cos, sin)(kap0 + kap1 c)) as the product of the coarse phasor of
+ * c's 128-index cell and the fine one of its place in the cell (hvk_secam_args_t.phc; tried on every index at open) */
+__device__ __forceinline__ void ph_step(const dbl2_t *phc, const double k1, const int c, int32_t &si, int32_t &sq)
+{
+	const int t = c + (32768 + 64);
+	const dbl2_t C = phc[t >> 7];
+	const double x = (double) ((t & 127) - 64) * k1, x2 = x * x;
+	const double sf = x * __builtin_fma(x2, -1.0 / 6.0, 1.0);
+	const double cf = __builtin_fma(x2, __builtin_fma(x2, 1.0 / 24.0, -0.5), 1.0);
+	si = __double2int_rn(__builtin_fma(-C.y, sf, C.x * cf));
+	sq = __double2int_rn(__builtin_fma(C.x, sf, C.y * cf));
+}
+
+/* the bell filter's gain at index c from its 32-index block: the values at the block's first index and a bit per step */
+__device__ __forceinline__ void bell_gain(const uint4 *bz, const int c0, const int c, int32_t &gi, int32_t &gq)
+{
+	const unsigned t = (unsigned) (c - c0);
+	const uint4 b = bz[t >> 5];
+	const unsigned m = (1u << (t & 31)) - 1u;
+	gq = (int32_t) (int16_t) (b.x >> 16) + __popc(b.y & m);
+	gi = (int32_t) (int16_t) b.x + __popc(b.z & m) - __popc(b.w & m);
+}
+
+/* One FM step with the table's entries at hand (hvk_secam_fm_step's arithmetic) and the sample it leaves. EMIT = false: a
+ * warm-up line -- only the state it leaves matters, so the output half of a step (level, bell-filter gain and its table
+ * read, burst window) is left out */
+#define WALK_FM(si_, sq_, gi_, gq_, bw_) do { \
+		const int64_t ni__ = (int64_t) pi * (si_) - (int64_t) pq * (sq_); \
+		const int64_t nq__ = (int64_t) pi * (sq_) + (int64_t) pq * (si_); \
+		pi = (int32_t) (ni__ >> 31); \
+		pq = (int32_t) (nq__ >> 31); \
+		if(EMIT) { \
+		const int32_t vi__ = ((pi >> 16) * level) >> 15; \
+		const int32_t vq__ = ((pq >> 16) * level) >> 15; \
+		vv = (int16_t) (((vi__ * (gi_)) >> 15) - ((vq__ * (gq_)) >> 15)); \
+		vv = (int16_t) ((vv * (bw_)) >> 15); } } while(0)
+
+template<int PH, bool EMIT>
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
+{
+	const int W = a.C.W, sl = a.C.sl;
+	const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
+	const int32_t level = a.C.level;
+	const int fm_end = v.sr < W ? v.sr : W;
+	const double k1 = a.ph_k1;
+	const int c0 = a.bell_c0;
+	double ix = S.ix, iy = S.iy;
+	int32_t pi = v.phase_pos ? INT32_MAX : -INT32_MAX, pq = 0;
+	const int cm = a.cbase[v.frame] + (m - v.frame * a.ntasks);     /* the task's row in the cell stores */
+	const int4 *F = (const int4 *) a.F + cm;
+	const int chunks = W / 8;
+
+	int4 nx = F[0];
+	for(int q = 0; q < chunks; q++)
+	{
+		int16_t f[8], o[8];
+		int32_t c[8];
+		unpack8(nx, f);
+		if(q + 1 < chunks) nx = F[(size_t) (q + 1) * a.cpad];
+		if(q == chunks - 1)
+		{
+			/* the last 7: with what lies behind the line (hvk_secam_chain_line) */
+#pragma unroll
+			for(int j = 1; j < 8; j++)
+			{
+				int32_t s = a.acc[(size_t) cm * 8 + (j - 1)];
+#pragma unroll
+				for(int i = 0; i < j; i++) s += (int32_t) S.tail[i] * a.C.fir[15 + i - j];      /* (tap W + 7 + i - x, x = W - 8 + j) */
+				s >>= 15;
+				f[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+			}
+		}
+#pragma unroll
+		for(int j = 0; j < 8; j++)
+		{
+			const double in = (double) f[j];
+			const double t0 = in * 2.90456054;
+			const double t1 = ix * -2.80912108;
+			const double t2 = iy * -0.90456054;
+			iy = (t0 + t1) - t2;
+			ix = in;
+			c[j] = med3i(round_away_nb(iy), dmin32, dmax32);     /* (src/fir.c:729-733 and src/video.c:3215-3216 in one: walk_line) */
+		}
+
+		const int x0 = q * 8;
+		if(x0 + 8 > sl && x0 < fm_end)
+		{
+			int4 tq[8];
+			if(!PH && EMIT)
+			{
+				/* (step and bell-filter gain of an index side by side: one 16-byte read, one cache line per sample) */
+#pragma unroll
+				for(int j = 0; j < 8; j++) tq[j] = ((const int4 *) a.lutb)[(unsigned) (c[j] + 32768)];
+			}
+			if(!PH && !EMIT)
+			{
+#pragma unroll
+				for(int j = 0; j < 8; j++) { const hvk_secam_c32_t st = a.lut[(unsigned) (c[j] + 32768)]; tq[j].x = st.i; tq[j].y = st.q; tq[j].z = 0; }
+			}
+			const int16_t *bw = a.burst_win + (x0 - sl);
+			if(__all(x0 >= sl && x0 + 8 <= fm_end))
+			{
+				/* the chunk lies inside the sub-carrier window of every line of the wave: no test per sample */
+#pragma unroll
+				for(int j = 0; j < 8; j++)
+				{
+					int32_t si, sq, gi, gq;
+					int16_t vv = 0;
+					if(PH) { ph_step(phc, k1, c[j], si, sq); bell_gain(bz, c0, c[j], gi, gq); }
+					else { si = tq[j].x; sq = tq[j].y; gi = (int16_t) tq[j].z; gq = (int16_t) (tq[j].z >> 16); }
+					WALK_FM(si, sq, gi, gq, bw[j]);
+					o[j] = vv;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for(int j = 0; j < 8; j++)
+				{
+					const int x = x0 + j;
+					int16_t vv = 0;
+					if(x >= sl && x < fm_end)
+					{
+						int32_t si, sq, gi, gq;
+						if(PH) { ph_step(phc, k1, c[j], si, sq); bell_gain(bz, c0, c[j], gi, gq); }
+						else { si = tq[j].x; sq = tq[j].y; gi = (int16_t) tq[j].z; gq = (int16_t) (tq[j].z >> 16); }
+						WALK_FM(si, sq, gi, gq, bw[j]);
+					}
+					o[j] = vv;
+				}
+			}
+		}
+		else
+		{
+#pragma unroll
+			for(int j = 0; j < 8; j++) o[j] = 0;
+		}
+		if(EMIT && out) *(int4 *) (out + x0) = pack8(o);
+	}
+
+	S.ix = ix;
+	S.iy = iy;
+	/* (past the line the loop works on what lies behind it: two steps at 16 MHz, through the table like hvk_secam_chain_line) */
+	const int16_t dmin = (int16_t) dmin32, dmax = (int16_t) dmax32;
+#pragma unroll
+	for(int i = 0; i < HVK_SECAM_TAIL; i++)
+	{
+		if(W + i < v.sr) S.tail[i] = hvk_secam_fm_step(a.lut, a.bell, S.tail[i], dmin, dmax, level, &pi, &pq);
+	}
+}
+
+#define WALK_THREADS 256
+#define WALK_PHC 520            /* 16-byte entries of LDS kept for the coarse phasors (513 used) */
+template<int PH>
+__global__ __launch_bounds__(WALK_THREADS)
+void hvk_k_secam_walk(const hvk_secam_args_t a)
+{
+	extern __shared__ uint4 walk_lds[];
+	if(PH)
+	{
+		for(int i = threadIdx.x; i < 513; i += WALK_THREADS) walk_lds[i] = ((const uint4 *) a.phc)[i];
+		for(int i = threadIdx.x; i < a.bell_blocks; i += WALK_THREADS) walk_lds[WALK_PHC + i] = ((const uint4 *) a.bellz)[i];
+		__syncthreads();
+	}
+	const int r = blockIdx.x * WALK_THREADS + threadIdx.x;
+	if(r >= a.total) return;
+
+	hvk_secam_state_t S;
+	const int kk = a.kf ? a.kf[r / a.ntasks] : (a.est ? -1 : 0);
+	if(kk < 0) est_entry(a, r, S);
+	else if(r == 0) S = *a.carry;
+	else if(a.seed) S = a.seed[seed_row(a, r)];
+	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
+	a.entry[r] = S;
+	if(a.seed) a.seed[seed_row(a, r)] = S;
+	const task_view v = task_of(a, r);
+	if(v.valid)
+	{
+		if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
+		walk_fast<PH>(a, (const dbl2_t *) walk_lds, walk_lds + WALK_PHC, r, v, S, out_of(a, v));
+	}
+	a.exit[r] = S;
+}
+
+/* every index of the deviation range: the computed FM step and the decoded gain against the tables' entries */
+__global__ void hvk_k_secam_check_walk(const hvk_secam_args_t a, const int c_lo, const int c_hi, int *differ)
+{
+	const int c = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+	if(c > c_hi) return;
+	int32_t si, sq, gi, gq;
+	ph_step((const dbl2_t *) a.phc, a.ph_k1, c, si, sq);
+	bell_gain((const uint4 *) a.bellz, a.bell_c0, c, gi, gq);
+	const hvk_secam_c32_t st = a.lut[c + 32768];
+	const hvk_secam_c16_t g = a.bell[(uint16_t) (int16_t) c];
+	if(si != st.i || sq != st.q || gi != g.i || gq != g.q) atomicAdd(differ, 1);
+}
+
 __device__ __forceinline__ bool same_state(const hvk_secam_state_t &p, const hvk_secam_state_t &q)
 {
 	bool same = __double_as_longlong(p.ix) == __double_as_longlong(q.ix) && __double_as_longlong(p.iy) == __double_as_longlong(q.iy);
@@ -980,7 +1019,17 @@ __global__ void hvk_k_secam_carry(const hvk_secam_args_t a)
 	if(threadIdx.x == 0 && blockIdx.x == 0) *a.carry = a.exit[a.nruns - 1];
 }
 
-extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, hipStream_t stream)
+extern "C" int hvk_launch_secam_check_walk(const hvk_secam_args_t *a, int *differ, hipStream_t stream)
+{
+	int lo = a->C.dmin[0] < a->C.dmin[1] ? a->C.dmin[0] : a->C.dmin[1];
+	int hi = a->C.dmax[0] > a->C.dmax[1] ? a->C.dmax[0] : a->C.dmax[1];
+	if(!a->phc || !a->bellz || lo < a->bell_c0 || hi >= a->bell_c0 + 32 * a->bell_blocks) return(HVK_ERROR);
+	if(hipMemsetAsync(differ, 0, sizeof(int), stream) != hipSuccess) return(HVK_ERROR);
+	hipLaunchKernelGGL(hvk_k_secam_check_walk, dim3((hi - lo + 256) / 256), dim3(256), 0, stream, *a, lo, hi, differ);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
+}
+
+extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estimate, int walk, hipStream_t stream)
 {
 	const int lanes = (a->C.W + SPL - 1) / SPL;
 	const int threads = (lanes + 63) & ~63;
@@ -998,7 +1047,13 @@ extern "C" int hvk_launch_secam_cells_chain(const hvk_secam_args_t *a, int estim
 		const int lanes_e = (a->total + a->ES - 1) / a->ES;
 		hipLaunchKernelGGL(hvk_k_secam_est, dim3((lanes_e + 63) / 64), dim3(64), 0, stream, *a);
 	}
-	hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
+	if(walk && a->R == 1 && (a->C.W % 8) == 0)
+	{
+		const int gx = (a->total + WALK_THREADS - 1) / WALK_THREADS;
+		if(walk == 2 && a->phc && a->bellz) hipLaunchKernelGGL(hvk_k_secam_walk<1>, dim3(gx), dim3(WALK_THREADS), (size_t) (WALK_PHC + a->bell_blocks) * 16, stream, *a);
+		else hipLaunchKernelGGL(hvk_k_secam_walk<0>, dim3(gx), dim3(WALK_THREADS), 0, stream, *a);
+	}
+	else hipLaunchKernelGGL(hvk_k_secam_chain, dim3((a->nruns + 63) / 64), dim3(64), 0, stream, *a);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

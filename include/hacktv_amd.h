@@ -321,6 +321,14 @@ int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4]);
  * warm-up walks over the twelve lines before; HVK_SECAM_EST=0 or a pinned HVK_SECAM_WARMUP keep the walks. The check
  * is the same either way. */
 int64_t hvk_secam_estimated_stages(const hvk_engine_t *e);
+/* Which kernel walked the stages' lines: counts[0] hvk_k_secam_chain (warm-up lines, runs of several lines per lane),
+ * [1] hvk_k_secam_walk<0> (one line per lane from an estimated or kept entry state; FM step and bell-filter gain of a
+ * sample from the 16-byte table entry), [2] hvk_k_secam_walk<1> (the step COMPUTED -- coarse phasor from LDS times a
+ * polynomial fine one, rounded -- and the gain decoded from 32-index blocks in LDS: no table read from HBM per sample;
+ * taken for blocks that show pictures of many colours). Returns 2 where hvk_open() tried the computed steps and decoded
+ * gains on every index of the deviation range and found them equal to the tables' (src/video.c:2218-2243, :2172-2185),
+ * 1 where only the table form may be taken, 0 without the device's chain. HVK_SECAM_WALK=0 / 1 / 2 forces a kernel. */
+int hvk_secam_walk_stages(const hvk_engine_t *e, int64_t counts[3]);
 
 /* Levels computed per pixel (hvk_set_levels(): pictures with many colours) take the short form of the arithmetic -- fused
  * multiply-adds, the scale folded into the constants, rounding by a magic addend -- where hvk_open() has TRIED it on every one

@@ -484,6 +484,8 @@ def _secam_noisy(n, seed=11):
                                         ({"HVK_LEVELS": "compute"}, "estimate"), ({"HVK_SECAM_EST": "0"}, "device"),
                                         ({"HVK_SECAM_NO_UV_PLANE": "1"}, "estimate"), ({"HVK_DIRECT": "0"}, "estimate"),
                                         ({"HVK_SECAM_EST_LINES": "3", "HVK_SECAM_EST_RUN": "7"}, "redo"),
+                                        ({"HVK_SECAM_WALK": "0"}, "estimate"), ({"HVK_SECAM_WALK": "1"}, "estimate"), ({"HVK_SECAM_WALK": "2"}, "estimate"),
+                                        ({"HVK_SECAM_WALK": "2", "HVK_SECAM_NO_SEEDS": "1"}, "estimate"),
                                         ({"HVK_SECAM_WARMUP": "1", "HVK_SECAM_FORCE_FALLBACK": "1"}, "fallback")])
 def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypatch, env, expect):
     """The SECAM colour sub-carrier computed line-parallel on the device (hvk_secam.hip: entry states estimated or
@@ -504,6 +506,7 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
                 out.append(e.fetch(0, 3 * 640000))
             st_ = e.secam_stats()
             st_["estimated"] = e.secam_estimated_stages()
+            st_["walk_ok"], st_["walk"] = e.secam_walk_stages()
             return np.concatenate(out), st_
     monkeypatch.setenv("HVK_SECAM_HOST", "1")
     want, st_host = run()
@@ -513,6 +516,16 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
     got, st = run()
     assert np.array_equal(got, want)
     assert st["tasks"] >= 9 * 570
+    # which kernel walked the lines: one line per lane from estimated entry states -> hvk_k_secam_walk, and for these
+    # pictures of many colours the form that computes the FM steps (tried on every index when the engine was opened);
+    # warm-up lines, runs of several lines per lane and HVK_SECAM_WALK=0 keep hvk_k_secam_chain
+    assert st["walk_ok"] == 2, st
+    if "HVK_SECAM_WALK" in env:
+        assert st["walk"][int(env["HVK_SECAM_WALK"])] == 3 and sum(st["walk"]) == 3, st
+    elif env in ({}, {"HVK_LEVELS": "compute"}, {"HVK_SECAM_NO_UV_PLANE": "1"}, {"HVK_DIRECT": "0"}):
+        assert st["walk"] == [0, 0, 3], st
+    elif "HVK_SECAM_RUN" in env or "HVK_SECAM_WARMUP" in env or env == {"HVK_SECAM_EST": "0"}:
+        assert st["walk"][0] == 3, st
     # new pictures' lines start from estimated states (hvk_k_secam_est) unless that is switched off or the warm-up pinned
     assert (st["estimated"] > 0) == (expect == "estimate" or "HVK_SECAM_EST_LINES" in env), st
     if expect in ("device", "estimate"):

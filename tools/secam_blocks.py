@@ -48,5 +48,5 @@ with H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), 16000000, device=0,
     e.sync()
     t = (time.perf_counter() - t0) / steps
     st = e.secam_stats()
-    print("%s, %d frames per block: %.3f ms per block = %.1f Gsamples/s; warm-up lines %d; lines of the timed blocks %s"
-          % (kind, F, t * 1e3, F * FS / t * 1e-9, e.secam_warmup_lines(), {k: st[k] - st0[k] for k in st}))
+    print("%s, %d frames per block: %.3f ms per block = %.1f Gsamples/s; warm-up lines %d; lines of the timed blocks %s; walk kernels (ok, [chain, walk<0>, walk<1>]) %s"
+          % (kind, F, t * 1e3, F * FS / t * 1e-9, e.secam_warmup_lines(), {k: st[k] - st0[k] for k in st}, e.secam_walk_stages()))
