@@ -227,14 +227,16 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
     tt_slots = [0]
     state = {"next": 0}
 
-    tt_rows = []        # (the packets of every block to come, made before any clock starts: building them is this script's work, not the engine's)
+    tt_blocks = []      # (the packets of every block to come, made before any clock starts: building them is this script's work, not the engine's)
 
     def stage_block():
         first = state["next"]
         if teletext:
-            for i in range(F):
-                rows, mask = tt_rows[first + i] if first + i < len(tt_rows) else raw_teletext_rows(g, tt_slots)
-                e.teletext_packets(i, rows, mask)
+            blk = first // F
+            if blk >= len(tt_blocks):
+                rm = [raw_teletext_rows(g, tt_slots) for _ in range(F)]
+                tt_blocks.append((np.stack([r for r, _ in rm]), np.array([m for _, m in rm], np.uint32)))
+            e.teletext_packets_block(0, *tt_blocks[blk])        # (one call per block: hvk_teletext_packets_block)
         e.stage(first, 1, F)
         state["next"] = first + F
 
@@ -247,7 +249,9 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
 
     nblocks = 1 + ((warmup + steps + 1) if stage_every_step else 0) + (1 if fresh_e2e else 0)
     if teletext:
-        tt_rows = [raw_teletext_rows(g, tt_slots) for _ in range(nblocks * F)]
+        for _ in range(nblocks):
+            rm = [raw_teletext_rows(g, tt_slots) for _ in range(F)]
+            tt_blocks.append((np.stack([r for r, _ in rm]), np.array([m for _, m in rm], np.uint32)))
     feed(nblocks)
     t0 = time.perf_counter()
     stage_block()
@@ -291,13 +295,12 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
     except Exception:
         pass
     if fresh_e2e:
-        host_out = torch.empty((F * fs * 2,), dtype=torch.int16).pin_memory()
+        host_out = e.host_buffer(F * fs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         stage_block()
-        e.launch(ctypes.c_void_p(out.data_ptr()))
-        host_out.copy_(out, non_blocking=True)
-        torch.cuda.synchronize()
+        e.launch()
+        e.fetch_wait(e.fetch_async(host_out, 0, F * fs))
         t1 = time.perf_counter() - t0
         res["fresh_block_end_to_end_Msamples_per_s"] = round(F * fs / t1 / 1e6, 1)
         res["fresh_block_note"] = "one fresh block, nothing overlapped: stage (host pre-passes + H2D) + render + D2H of the int16 IQ into pinned host memory"
@@ -570,7 +573,8 @@ def main():
     ap.add_argument("--noaudio", action="store_true", help="render the --noaudio variant instead")
     ap.add_argument("--no-moving", action="store_true", help="skip the moving-picture section")
     ap.add_argument("--no-configs", action="store_true", help="skip the sections for BASELINE configs 1, 3, 4 and --noaudio")
-    ap.add_argument("--hour-sound", action="store_true", help="5_one_hour: also the whole hour WITH sound (two minutes: the host's serial FM chain)")
+    ap.add_argument("--hour-sound", action="store_true", help="(the default since round 5) 5_one_hour: the whole hour WITH sound as well (two minutes: the host's serial FM chain)")
+    ap.add_argument("--no-hour-sound", action="store_true", help="5_one_hour: leave the run with sound out (it takes two minutes)")
     ap.add_argument("--no-hour", action="store_true", help="skip the one-hour section")
     ap.add_argument("--settle", type=float, default=0.6, help="seconds of untimed launches before the clock starts (sustained clocks)")
     ap.add_argument("--dry-run-backend", default=None, help="gloo: dry-run the N > 1 path with every rank on GPU 0 (no RCCL peers needed)")
@@ -889,16 +893,15 @@ def main():
     # ---- one FRESH block end to end: host pre-pass + H2D of the side inputs, render, D2H of the samples ----
     e2e = None
     if N == 1 and not args.walk_rounds:
-        host_out = torch.empty((F * FS * 2,), dtype=torch.int16).pin_memory()
+        host_out = e.host_buffer(F * FS)
         nxt = first_frame + F
         t0 = time.perf_counter()
         while e.audio_needed(nxt + F) > 0:
             e.audio_write(g.audio)
         e.stage(nxt, 1, F)
         t1 = time.perf_counter()
-        e.launch(ctypes.c_void_p(mine.data_ptr()))
-        host_out.copy_(mine, non_blocking=True)
-        torch.cuda.synchronize()
+        e.launch()
+        e.fetch_wait(e.fetch_async(host_out, 0, F * FS))     # (hvk_fetch_async: a large read-back goes out in two halves on two streams)
         t2 = time.perf_counter()
         e2e = {"stage_s": round(t1 - t0, 4), "render_and_d2h_s": round(t2 - t1, 4),
                "Msamples_per_s": round(F * FS / (t2 - t0) / 1e6, 1),
@@ -1156,11 +1159,12 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import hour as hour_mod
         hour = {"noaudio": hour_mod.run(H, g.frame("i_full"), g.audio, device=local_rank, sound=False, log=log)}
-        if args.hour_sound:
+        if not args.no_hour_sound:
+            # the metric configuration HAS sound (src/video.c:2259-2276): the hour as written, every block's sums and the
+            # cumulative sha256 at 9 000 / 45 000 / 90 000 frames against the reference's -- two minutes, the host's serial FM chain
             hour["with_sound"] = hour_mod.run(H, g.frame("i_full"), g.audio, device=local_rank, sound=True, log=log)
         else:
-            hour["with_sound"] = {"not_run": "two minutes (the host's serial FM chain over 57.6 G samples): python bench.py --hour-sound; the run of record, every block's "
-                                             "sums and the cumulative sha256 at 9 000 / 45 000 / 90 000 frames against the reference: profiles/r04_hour_sound_full.json"}
+            hour["with_sound"] = {"not_run": "--no-hour-sound (two minutes: the host's serial FM chain over 57.6 G samples)"}
 
     if rank == 0:
         names = e.kernel_names()
@@ -1201,6 +1205,7 @@ def main():
         roof["path_frac"] = round(path_ach / HBM_PEAK_GBS, 4)
         roof["path_achieved"] = round(path_ach, 1)
         roof["path_note"] = "4 B x samples of a step / ms_per_step / n_gpus against the same 8 TB/s: the fraction the whole path achieves per GPU"
+        roof_also = True
         # the handful of numbers a reader of the headline wants beside it (their sections below have the detail)
         def _g(d, *keys):
             for k_ in keys:
@@ -1220,7 +1225,13 @@ def main():
             "end_to_end_Msamples_per_s": _g(e2e, "Msamples_per_s"),
             "dropin_config2_Msamples_per_s": _g(configs, "2_dropin", "Msamples_per_s"), "dropin_config2_noaudio_Msamples_per_s": _g(configs, "2_noaudio_dropin", "Msamples_per_s"),
             "one_hour_noaudio_wall_s": _g(hour, "noaudio", "wall_s"),
+            "one_hour_with_sound_wall_s": _g(hour, "with_sound", "wall_s"),
+            "one_hour_with_sound_gate": _g(hour, "with_sound", "gate"),
             "c_group_noaudio_host_direct_Msamples_per_s": _g(cgroup, "noaudio", "host_direct_Msamples_per_s"),
+            "c_group_noaudio_gathered_Msamples_per_s": _g(cgroup, "noaudio", "gathered_on_root_device_Msamples_per_s"),
+            "c_group_with_sound_host_direct_Msamples_per_s": _g(cgroup, "with_sound", "host_direct_Msamples_per_s"),
+            "c_group_gather_backend": _g(cgroup, "gather_backend"),
+            "render_and_d2h_Msamples_per_s": _g(e2e, "render_and_d2h_Msamples_per_s"),
         }
         res = {
             "metric": "IQ Msamples/s (PAL-I AM-VSB, 16 MHz SR)",
@@ -1246,6 +1257,7 @@ def main():
                 "frames_per_gpu_per_step": F,
                 "samples_per_step": samples_per_step,
                 "also_measured": also,
+                **{("also_" + k_): v_ for k_, v_ in also.items()},       # (the same scalars as keys of `config` itself: a record that keeps only flat keys keeps them)
                 "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, (", one process driving an engine per device (hvk_group_*), blocks gathered on the root device in the step: " + cg_timed["gather_backend"]) if cg_timed else
                                                                          (", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else "")),
             },
@@ -1280,6 +1292,12 @@ def main():
                 "a2_stereo": a2_prepass(H, g.audio) if N == 1 and not args.no_moving else None,
             },
         }
+        if roof_also:
+            for k_ in ("secam_l_pictures_change_every_frame_Msamples_per_s", "secam_l_new_picture_every_frame_planes_too_Msamples_per_s",
+                       "new_pictures_every_frame_table_levels_Msamples_per_s", "new_pictures_every_frame_computed_levels_Msamples_per_s",
+                       "config3_path_frac", "config4_noaudio_device_path_frac", "config2_noaudio_path_frac", "one_hour_with_sound_wall_s",
+                       "c_group_noaudio_host_direct_Msamples_per_s", "c_group_noaudio_gathered_Msamples_per_s"):
+                res["roofline"]["also_" + k_] = also.get(k_)
         if other:
             res["roofline_other_kernel"] = other
         if e2e:

@@ -52,6 +52,19 @@ __device__ __forceinline__ int wrap16(int v) { return((int) (short) v); }
 /* the middle one of three (v_med3_i32): a clamp when lo <= hi */
 __device__ __forceinline__ int med3i(int v, int lo, int hi) { return(v < lo ? lo : (v > hi ? hi : v)); }
 __device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+/* a.lo * b.lo + a.hi * b.hi with nothing to add to: the three-operand form with the constant 0 (from the builtin the
+ * compiler makes the two-operand v_dot2c, which accumulates into its destination -- and a v_mov of 0 in front of every one) */
+__device__ __forceinline__ int dot2z(int a, int b)
+{
+#ifdef HVK_V_NO_DOT2Z
+	return(__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), 0, false));
+#else
+	int d;
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+	return(d);
+#endif
+}
+
 __device__ __forceinline__ int dot2(int a, int b, int c)
 {
 	return(__builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false));
@@ -707,12 +720,12 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		{
 			/* S-Video: onto the (empty) Q channel instead of the luma (src/video.c:3032) */
 #pragma unroll
-			for(int i = 0; i < SPL; i++) cq[i] = wrap16(dot2(c[i], vu[i], 0) >> 15);
+			for(int i = 0; i < SPL; i++) cq[i] = wrap16(dot2z(c[i], vu[i]) >> 15);
 		}
 		else
 		{
 #pragma unroll
-			for(int i = 0; i < SPL; i++) s[i] = s[i] + (dot2(c[i], vu[i], 0) >> 15);   /* modulo 2^16 at the store (no SECAM here: pal is 0 there) */
+			for(int i = 0; i < SPL; i++) s[i] = s[i] + (dot2z(c[i], vu[i]) >> 15);   /* modulo 2^16 at the store (no SECAM here: pal is 0 there) */
 		}
 	}
 
@@ -950,7 +963,7 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 /* One NICAM symbol slot of a tile's table (src/nicam728.c:33, :386-407): `v` is the host's word for
  * the slot (start << 3 | valid << 2 | value), n0 the tile's first sample. sym_st gets the start
  * relative to the tile, sym_ent { LEAD - start, offset of the shifted pulse copy, sign pair I, sign pair Q }. */
-__device__ __forceinline__ void nicam_symbol_slot(const int v, const int n0, int *sym_st, int4v *sym_ent, const int slot)
+__device__ __forceinline__ void nicam_symbol_slot(const int v, const int n0, int *sym_st, int4v *sym_ent, const int slot, const int16_t *tapd)
 {
 	const int st = (v >> 3) - n0;
 	const bool valid = (v & 4) && st < HVK_TILE;
@@ -958,15 +971,23 @@ __device__ __forceinline__ void nicam_symbol_slot(const int v, const int n0, int
 	 * (src/nicam728.c:33, :386-396) */
 	const int cs = (0x2310 >> ((v & 3) * 4)) & 3;
 	sym_st[slot] = valid ? st : 0x3FFFFFFF;
-	/* x0 is a multiple of 8, so which of the four shifted copies of the pulse
-	 * table a lane needs depends on the symbol only. A slot without a symbol
-	 * gets an offset that clamps into the table's zero tail. */
+	/* x0 is a multiple of 8, so which of the shifted copies of the pulse table a lane needs depends on the symbol only
+	 * (CM = copies - 1), and so does everything else of the address but x0 itself: the lane reads its 8 taps at BYTE
+	 * offset min(2 x0 + e.x, e.y) of the table -- e.x = 2 (copy + (rel & ~CM)), rel = LEAD - start (x0 + (rel & ~CM) =
+	 * (x0 + rel) & ~CM for a multiple of 8), e.y = 2 (copy + TAPD - 8): a pulse that is over clamps into its copy's zero
+	 * tail. A slot without a symbol gets offsets that do so at once. Two vector instructions per symbol and lane instead
+	 * of seven. */
+	static_assert((HVK_NICAM_COPIES == 8 || HVK_NICAM_COPIES == 4) && HVK_NICAM_LEAD >= HVK_NICAM_COPIES - 1 && SPL == 8, "pulse table copies");
+	constexpr int CM = HVK_NICAM_COPIES - 1;
 	const int rel = HVK_NICAM_LEAD - st;
+	/* (where the table lies in LDS goes into the offsets too: the low half of its flat address) */
+	const int copy = (rel & CM) * HVK_NICAM_TAPD + (int) ((unsigned) (size_t) tapd >> 1);
 	/* +1 or -1 in both halves: the pulse shapes two samples of a channel per packed multiply-add */
 	const int sgi = (cs & 1) ? 0x00010001 : (int) 0xFFFFFFFFu;
 	const int sgq = (cs & 2) ? 0x00010001 : (int) 0xFFFFFFFFu;
-	sym_ent[slot] = valid ? (int4v) { rel, (rel & 3) * HVK_NICAM_TAPD, sgi, sgq }
-	                      : (int4v) { 0x10000000, 0, 0, 0 };
+	const int none = (int) (unsigned) (size_t) tapd + 2 * (HVK_NICAM_TAPD - SPL);
+	sym_ent[slot] = valid ? (int4v) { 2 * (copy + (rel & ~CM)), 2 * (copy + HVK_NICAM_TAPD - SPL), sgi, sgq }
+	                      : (int4v) { none, none, 0, 0 };
 }
 
 /* NICAM onto a lane's 8 packed (I, Q) outputs: sum the pulses of the symbols in flight (int16
@@ -993,6 +1014,7 @@ __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, c
 	}
 
 	/* I and Q apart while the pulses are summed: (I[2m], I[2m + 1]) and (Q[2m], Q[2m + 1]) */
+	const int xb = 2 * x0;
 	int bi[SPL / 2], bq[SPL / 2];
 #pragma unroll
 	for(int i = 0; i < SPL / 2; i++) bi[i] = bq[i] = 0;
@@ -1000,18 +1022,36 @@ __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, c
 	/* the newest symbol and the six before it: everything older is over. A pulse
 	 * that is over (or a slot without a symbol) reads the zero tail of the table:
 	 * no branch. idx >= HVK_NICAM_BACK - 1 by construction. */
+	/* (the next symbol's entry is asked for before this one's taps are: one LDS round trip per symbol in the chain of
+	 * dependent reads, not two) */
+#if HVK_NICAM_COPIES == 8
+	typedef __attribute__((address_space(3))) const int4v *lds_taps_t;
+#else
+	typedef __attribute__((address_space(3))) const int2v *lds_taps_t;
+#endif
+	const int4v *ep = sym_ent + idx;
+	int4v en = ep[0];
 #pragma unroll 1
 	for(int b = 0; b < (ABLATE(32) ? 0 : HVK_NICAM_BACK); b++)
 	{
-		const int4v en = sym_ent[idx - b];
-		int base = x0 + en.x;                                   /* >= 1 */
-		base = base < HVK_NICAM_TAPD - SPL ? base : HVK_NICAM_TAPD - SPL;
-		const int2v *tp = (const int2v *) (tapd + en.y + (base & ~3));
-		const int2v ta = tp[0], tb = tp[1];
+		/* (the entry in front of the oldest symbol -- one in front of the table where idx = HVK_NICAM_BACK - 1: the callers'
+		 * tables have an entry of slack there -- is read and not used) */
+		ep--;
+		const int4v nx = ep[0];
+		int at = xb + en.x;                                     /* (an LDS byte address; the symbol has started by the lane's last sample) */
+		at = at < en.y ? at : en.y;
+		const lds_taps_t tp = (lds_taps_t) (size_t) (unsigned) at;
+#if HVK_NICAM_COPIES == 8
+		const int4v ta = tp[0];
+#else
+		const int2v ta0 = tp[0], ta1 = tp[1];
+		const int4v ta = { ta0.x, ta0.y, ta1.x, ta1.y };
+#endif
 		bi[0] = pk_mad16(ta.x, en.z, bi[0]); bi[1] = pk_mad16(ta.y, en.z, bi[1]);
-		bi[2] = pk_mad16(tb.x, en.z, bi[2]); bi[3] = pk_mad16(tb.y, en.z, bi[3]);
+		bi[2] = pk_mad16(ta.z, en.z, bi[2]); bi[3] = pk_mad16(ta.w, en.z, bi[3]);
 		bq[0] = pk_mad16(ta.x, en.w, bq[0]); bq[1] = pk_mad16(ta.y, en.w, bq[1]);
-		bq[2] = pk_mad16(tb.x, en.w, bq[2]); bq[3] = pk_mad16(tb.y, en.w, bq[3]);
+		bq[2] = pk_mad16(ta.z, en.w, bq[2]); bq[3] = pk_mad16(ta.w, en.w, bq[3]);
+		en = nx;
 	}
 
 	int bb[SPL];                            /* (I, Q) of each sample */
@@ -1029,8 +1069,8 @@ __device__ __forceinline__ void nicam_add(const hvk_kconst_t &k, const int x0, c
 #pragma unroll
 		for(int i = 0; i < SPL; i++)
 		{
-			const int mi = dot2(bb[i], ca[i], 0);           /* bb.i * cc.i - bb.q * cc.q */
-			const int mq = dot2(bb[i], cq[i], 0);           /* bb.i * cc.q + bb.q * cc.i */
+			const int mi = dot2z(bb[i], ca[i]);           /* bb.i * cc.i - bb.q * cc.q */
+			const int mq = dot2z(bb[i], cq[i]);           /* bb.i * cc.q + bb.q * cc.i */
 			/* ((mi >> 15) & 0xFFFF) | ((mq >> 15) << 16) */
 			const int pk = (int) ((((unsigned) mq << 1) & 0xFFFF0000u) | (((unsigned) mi >> 15) & 0xFFFFu));
 			o[i] = pk_add16(o[i], pk);
@@ -1083,7 +1123,15 @@ __device__ __forceinline__ void mfma_filter(const unsigned char *xh, const unsig
 		p_ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hl, bl, p_ll, 0, 0, 0);
 		int y[4];
 #pragma unroll
-		for(int i = 0; i < 4; i++) y[i] = (int) ((((unsigned) p_hh[i] << 8) + (unsigned) p_m[i]) << 8) + p_ll[i];
+		for(int i = 0; i < 4; i++)
+		{
+			/* Horner: two v_lshl_add_u32 (left alone the compiler makes it two shifts and a three-operand add) */
+			unsigned hm = ((unsigned) p_hh[i] << 8) + (unsigned) p_m[i];
+#ifndef HVK_V_NO_HORNER
+			asm("" : "+v"(hm));
+#endif
+			y[i] = (int) ((hm << 8) + (unsigned) p_ll[i]);
+		}
 		int2v pk;
 		pk.x = sat_pack16(y[0] >> 15, y[1] >> 15);
 		pk.y = sat_pack16(y[2] >> 15, y[3] >> 15);

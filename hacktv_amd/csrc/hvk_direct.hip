@@ -39,7 +39,9 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#ifndef DG
 #define DG    4                     /* tiles per workgroup (2 and 8 measured: 3 % and 6 % slower) */
+#endif
 #define DLEAD 26                    /* window position 0 is this many samples before the tile's first output (_mfma_taps) */
 
 /* ------------------------------------------------------------------ */
@@ -541,7 +543,7 @@ __device__ __forceinline__ int4u direct_make(const dload_t &q)
 		for(int m = 0; m < SPL / 2; m++)
 		{
 			/* (i * V * pal + q * U) >> 15 as one dot2 of the packed table entry with (V, U); modulo 2^16 at the add */
-			const int t0 = dot2(K[2 * m], C[2 * m], 0) >> 15, t1 = dot2(K[2 * m + 1], C[2 * m + 1], 0) >> 15;
+			const int t0 = dot2z(K[2 * m], C[2 * m]) >> 15, t1 = dot2z(K[2 * m + 1], C[2 * m + 1]) >> 15;
 			pr[m] = (int) __builtin_amdgcn_perm((unsigned) t1, (unsigned) t0, 0x05040100u);
 		}
 		s.x = pk_add16(s.x, pr[0]); s.y = pk_add16(s.y, pr[1]); s.z = pk_add16(s.z, pr[2]); s.w = pk_add16(s.w, pr[3]);
@@ -626,6 +628,36 @@ __device__ __forceinline__ int4u direct_group(const hvk_dptrs_t &D, const dline_
 	return(direct_group_make<COLOUR>(D, G, w));
 }
 
+/* make PHASES=1 (-DHVK_PHASE_TIMES): where a workgroup's time goes. Its first lane reads the shader clock at the marks below and
+ * leaves it in a slot of the workgroup's own (tools/phase_times.py prints the averages per workgroup). Results are unchanged,
+ * the kernel a little slower: a measuring build, never the product's. */
+#ifdef HVK_PHASE_TIMES
+#define HVK_PHASE_WGS 32768
+__device__ unsigned long long hvk_phase_buf[HVK_PHASE_WGS * 10];     /* per workgroup: the clock at its start and at the eight marks, a count */
+#define PT_START() const unsigned pt_wg = (blockIdx.y * gridDim.x + blockIdx.x) % HVK_PHASE_WGS; if(threadIdx.x == 0) hvk_phase_buf[pt_wg * 10 + 8] = clock64()
+#define PT(i) do { __builtin_amdgcn_sched_barrier(0); if(threadIdx.x == 0) hvk_phase_buf[pt_wg * 10 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while(0)
+extern "C" int hvk_phase_times(unsigned long long *out, int reset)
+{
+	/* out[0..7]: cycles between the marks, summed over the workgroups of the LAST launch that wrote; out[15]: how many */
+	static unsigned long long host[HVK_PHASE_WGS * 10];
+	if(hipMemcpyFromSymbol(host, HIP_SYMBOL(hvk_phase_buf), sizeof(host)) != hipSuccess) return(HVK_ERROR);
+	for(int i = 0; i < 16; i++) out[i] = 0;
+	for(int w = 0; w < HVK_PHASE_WGS; w++)
+	{
+		const unsigned long long *q = host + (size_t) w * 10;
+		if(!q[8] || !q[7]) continue;
+		unsigned long long last = q[8];
+		for(int i = 0; i < 8; i++) { out[i] += q[i] - last; last = q[i]; }
+		out[15]++;
+	}
+	if(reset) { static unsigned long long z[HVK_PHASE_WGS * 10]; if(hipMemcpyToSymbol(HIP_SYMBOL(hvk_phase_buf), z, sizeof(z)) != hipSuccess) return(HVK_ERROR); }
+	return(HVK_OK);
+}
+#else
+#define PT_START() do { } while(0)
+#define PT(i) do { } while(0)
+#endif
+
 /* SND = 1: the configuration has FM / AM carriers AND NICAM (the metric's), known when the kernel is compiled: no read hangs
  * under a test at whose merge point it would be waited for */
 template<int VF, int COLOUR, int EXACT, int OVR, int SND, int TR>
@@ -657,44 +689,55 @@ void hvk_k_direct(const hvk_kconst_t k,
 	constexpr int TL = HVK_TILE / HVK_SPL;      /* lanes of a tile */
 	__shared__ __attribute__((aligned(16))) unsigned char xh[VF ? NP : 16], xl[VF ? NP : 16];
 	__shared__ __attribute__((aligned(16))) int outl_g[DG][VF ? HVK_TILE : 4];
-	__shared__ __attribute__((aligned(16))) int16_t tapd[4 * HVK_NICAM_TAPD];
+	__shared__ __attribute__((aligned(16))) int16_t tapd[HVK_NICAM_COPIES * HVK_NICAM_TAPD];
 	__shared__ int sym_st_g[DG][HVK_NICAM_SYMS];
-	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[DG][HVK_NICAM_SYMS];
+	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[1 + DG * HVK_NICAM_SYMS];     /* (an entry of slack in front: nicam_add()) */
 
 	/* the grid's x extent is padded to a multiple of 8: with workgroups dealt round-robin to the 8 XCDs, the same
 	 * lines of EVERY frame then run on the same XCD, whose L2 keeps their plane rows (a picture that stays) and
 	 * their slices of the colour table (the same again every few frames) */
 	const int bx = (int) blockIdx.x;
 	const int y = (int) blockIdx.y;
-	if(bx * DG >= tiles) return;
+	/* (the workgroups the grid's padding adds leave further down, behind the tile's set-up: an early return here would put
+	 * a round trip of its own -- the tile count, a kernel argument -- in front of every other scalar load) */
+	PT_START();
+	/* The kernel arguments the set-up reads, wanted HERE, in the entry block -- one round of scalar loads. Left alone the
+	 * compiler loads an argument in the block that first uses it: four dependent round trips before the tile's first vector
+	 * load could go out, an eighth of a workgroup's life (tools/phase_times.py). (Pass-through statements without side
+	 * effects: a volatile one would count as a write to memory and turn every scalar table read behind it into a vector read.) */
+	unsigned k_clw = k.clw;
+	int k_w = k.width, k_fs = k.frame_samples, a_tiles = tiles, a_tiles_pad = tiles_pad, a_creg = d_creg, a_zero = d_zero_row;
+	int64_t a_ff = first_frame, a_fst = frame_stride;
+	/* (numbers only: a pointer that has been through such a statement is one the compiler knows nothing about any more) */
+	asm("" : "+s"(k_clw), "+s"(k_w), "+s"(k_fs), "+s"(a_tiles), "+s"(a_tiles_pad), "+s"(a_creg), "+s"(a_zero), "+s"(a_ff), "+s"(a_fst));
 
 	hvk_dptrs_t D;
-	D.Lp = d_Lp; D.Cp = d_Cp; D.clut3 = d_clut3; D.creg = d_creg; D.zero_row = d_zero_row;
+	D.Lp = d_Lp; D.Cp = d_Cp; D.clut3 = d_clut3; D.creg = a_creg; D.zero_row = a_zero;
 	D.desc = d_desc; D.fdesc = d_fdesc; D.lineoff = d_lineoff; D.inv_w = d_inv_w;
 	D.chroma = d_chroma; D.chroma_zero = d_chroma_zero;
 	D.ovr_idx = d_ovr_idx; D.ovr_row0 = d_ovr_row0; D.ovr_n = d_ovr_n;
 
-	const int FS = k.frame_samples, W = k.width;
+	const int FS = k_fs, W = k_w;
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
 	const int t = threadIdx.x % TL;
 	const int x0 = t * SPL;
 	/* a workgroup that reaches past the frame's last tile still fills its planes (the last tile's filter looks into
 	 * them); nothing of such a tile is stored */
 	const int tile_raw = bx * DG + sub;
-	const bool tile_valid = tile_raw < tiles;
-	const int tile = tile_valid ? tile_raw : tiles - 1;
+	const bool tile_valid = tile_raw < a_tiles;
+	const int tile = tile_valid ? tile_raw : a_tiles - 1;
 	const int n0 = tile_raw * HVK_TILE;         /* first output sample of the tile, frame local */
 	int *const outl = outl_g[sub];
 	int *const sym_st = sym_st_g[sub];
-	int4v *const sym_ent = sym_ent_g[sub];
+	int4v *const sym_ent = sym_ent_g + 1 + sub * HVK_NICAM_SYMS;
 	(void) outl;
 
 	/* the NICAM pulse table, staged once per workgroup (hvk_k_filter has the layout) */
-	static_assert(TL * DG >= HVK_NICAM_TAPD / 2, "one pulse-table vector per thread");
+	static_assert(TL * DG >= HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8, "one pulse-table vector per thread");
 	const bool has_car = SND ? true : k.has_carriers != 0, has_nic = SND ? true : k.has_nicam != 0;
-	const bool tap_mine = has_nic && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	const bool tap_mine = has_nic && (int) threadIdx.x < HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8;
 	int4v tap_stage = { 0, 0, 0, 0 };
-	if(has_nic) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
+	if(has_nic) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8 - 1)];
 
 	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
 	if(VF)
@@ -704,7 +747,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	}
 
 	/* ---- the lines this tile's window lies in (all scalar) ---- */
-	const int64_t frame_index = first_frame + (int64_t) y * frame_stride;
+	const int64_t frame_index = a_ff + (int64_t) y * a_fst;
 	const int par_own = (int) ((frame_index + 1) & 1);
 	const bool first = frame_index == 0;
 	/* (the frame before: the row its LAST line's planes start at less lines - 1; the frame: the row of its line 0) */
@@ -732,7 +775,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 		 * position depend on the tile and the frame's parity only: tabulated by the host (hvk_engine.cpp:_tile_records, the
 		 * arithmetic of direct_line_loads() / direct_line()), ONE 64-byte scalar load instead of a dozen dependent ones. What
 		 * is the frame's own -- where its picture's planes lie, its colour table position -- comes from its descriptor. */
-		const hvk_tilerec_t R = d_tilerec[__builtin_amdgcn_readfirstlane(par_own * tiles_pad + tile_raw)];
+		const hvk_tilerec_t R = d_tilerec[__builtin_amdgcn_readfirstlane(par_own * a_tiles_pad + (tile_raw < a_tiles_pad ? tile_raw : a_tiles_pad - 1))];
 		b1 = R.b1; b2 = b1 + W;
 		dline_t l3[3];
 #pragma unroll
@@ -747,18 +790,20 @@ void hvk_k_direct(const hvk_kconst_t k,
 			if(COLOUR == 1 && !zero && pal != 0)
 			{
 				unsigned coff = clut_off0 + R.off[X];
-				if(coff >= k.clw) coff -= k.clw;
+				if(coff >= k_clw) coff -= k_clw;
 				l3[X].cb = (pal < 0 ? D.creg : 0) + (int) coff + R.nws[X];
 			}
 		}
 		lA = l3[0]; lB = l3[1]; lC = l3[2];
 	}
 
+	if(bx * DG >= a_tiles) return;
+	PT(0);      /* the tile's lines: scalar loads and arithmetic */
 	/* ---- loads ---- */
 	int symv = 0, cc_tile = 0;
 	if(has_nic)
 	{
-		const int *row = tilesyms + ((size_t) y * tiles + tile) * HVK_NICAM_ROW;
+		const int *row = tilesyms + ((size_t) y * a_tiles + tile) * HVK_NICAM_ROW;
 		cc_tile = row[HVK_NICAM_SYMS];
 		symv = row[t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1];
 	}
@@ -767,7 +812,26 @@ void hvk_k_direct(const hvk_kconst_t k,
 	/* the lane's 8 outputs are inside the frame (EXACT: the frame is a whole number of tiles) */
 	const bool whole = tile_valid && (EXACT || n + SPL <= FS);
 
-	const int4u g0 = direct_group<COLOUR>(D, lA, lB, lC, b1, b2, x0);
+	dgroup_t G0;
+	direct_group_load<COLOUR>(D, lA, lB, lC, b1, b2, x0, G0);
+	/* The 64 window positions behind the workgroup's last tile (its filter's reach into the next group's first line): ONE
+	 * position per lane of that tile's first wave, read in the SAME round trip as the lane's own eight -- three registers a lane,
+	 * each lane with the parameters of the line its position lies in (no boundary inside a lane: nothing to merge). As eight
+	 * positions for each of eight lanes they cost that wave a second round trip of its own (twenty registers could not be
+	 * held beside the first), and the other seven waves of the workgroup waited at the barrier for it: a quarter of a
+	 * workgroup's life (tools/phase_times.py). */
+	const bool trail = VF && sub == DG - 1 && t < 64;
+	int tr_l = 0, tr_c = 0, tr_k = 0;
+	if(trail)
+	{
+		const int w1 = HVK_TILE + t;
+		const bool inB = w1 >= b1, inC = w1 >= b2;
+		const int lb = inC ? lC.lb : (inB ? lB.lb : lA.lb), cb = inC ? lC.cb : (inB ? lB.cb : lA.cb);
+		tr_l = D.Lp[lb + w1];
+		if(COLOUR == 1) { tr_c = D.Cp[lb + w1]; tr_k = D.clut3[cb + w1]; }
+		if(COLOUR == 2) tr_c = D.chroma[cb + w1];
+	}
+	const int4u g0 = direct_group_make<COLOUR>(D, G0, x0);
 
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
 	if(has_car && (SND || whole))
@@ -790,13 +854,14 @@ void hvk_k_direct(const hvk_kconst_t k,
 		split_planes(g0, ph, pl);
 		((int2v *) (xh + sub * HVK_TILE))[t] = ph;
 		((int2v *) (xl + sub * HVK_TILE))[t] = pl;
-		if(sub == DG - 1 && t < 8)
+		if(trail)
 		{
-			/* the 64 positions behind the workgroup's last tile */
-			const int4u g1 = direct_group<COLOUR>(D, lA, lB, lC, b1, b2, HVK_TILE + x0);
-			split_planes(g1, ph, pl);
-			((int2v *) (xh + DG * HVK_TILE))[t] = ph;
-			((int2v *) (xl + DG * HVK_TILE))[t] = pl;
+			/* the 64 positions behind the workgroup's last tile: direct_make()'s arithmetic on one sample, its two bytes */
+			int s1 = tr_l;
+			if(COLOUR == 1) s1 += dot2z(tr_k, tr_c) >> 15;
+			if(COLOUR == 2) s1 += tr_c;
+			xh[DG * HVK_TILE + t] = (unsigned char) ((s1 >> 8) & 0xFF);
+			xl[DG * HVK_TILE + t] = (unsigned char) ((s1 & 0xFF) ^ 0x80);
 		}
 	}
 	else
@@ -806,8 +871,10 @@ void hvk_k_direct(const hvk_kconst_t k,
 		o[4] = g0.z & 0xFFFF; o[5] = (int) ((unsigned) g0.z >> 16); o[6] = g0.w & 0xFFFF; o[7] = (int) ((unsigned) g0.w >> 16);
 	}
 
-	if(has_nic && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
+	if(has_nic && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t, tapd);
+	PT(1);      /* the reads' round trip, the modulator, the byte planes into LDS */
 	__syncthreads();
+	PT(2);      /* the first barrier */
 
 	/* the mixer row (i, -q) of this lane's samples: on its way while the filter and the pulse sums run */
 	int4u mix[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
@@ -822,7 +889,9 @@ void hvk_k_direct(const hvk_kconst_t k,
 	if(VF)
 	{
 		mfma_filter(xh + sub * HVK_TILE, xl + sub * HVK_TILE, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
+		PT(3);  /* the filter on the matrix unit */
 		__syncthreads();
+		PT(4);  /* the second barrier */
 		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
 		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
 		o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
@@ -845,7 +914,9 @@ void hvk_k_direct(const hvk_kconst_t k,
 		}
 	}
 
+	PT(5);      /* the filter's outputs back from LDS, the carriers added */
 	if(has_nic) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
+	PT(6);      /* NICAM */
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + (size_t) y * out_stride * FS + n;
@@ -859,6 +930,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 #pragma unroll
 		for(int i = 0; i < SPL; i++) if(n + i < FS) dst[i] = o[i];
 	}
+	PT(7);      /* the stores issued */
 }
 
 /* ------------------------------------------------------------------ */

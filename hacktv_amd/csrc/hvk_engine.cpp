@@ -151,6 +151,13 @@ struct hvk_engine {
 	int16_t *d_S;
 	int16_t *d_C;           /* --s-video: the sub-carrier slab */
 	int16_t *d_C2;          /* --s-video with --pixelrate: the resampled sub-carrier (the resampler's second channel) */
+	/* ... where the lines have two widths and the video filter is on (hvk_kconst_t.sv_ring): the Q channel made line by line
+	 * the way the reference's ring of line buffers pairs it (hvk_k_svq) */
+	int16_t *d_C2_alloc;    /* d_C2 lies sv_hist samples inside it: the end of the batch before's stream, kept in front of this batch's */
+	int16_t *d_Cq;          /* what the filter kernel reads as Q */
+	int *h_svrec, *d_svrec; /* [max_frames * lines][4] per emitted line: first sample in the batch, width | delta << 16 | kind << 20, source of the last sample */
+	int sv_hist;
+	int64_t sv_tail_first, sv_tail_total;   /* the batch whose sub-carrier stream lies in d_C2 (first frame; -1: none), its samples */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
 	int16_t *d_car;
 	int32_t *d_sym;
@@ -199,6 +206,9 @@ struct hvk_engine {
 	hipEvent_t ev_staged;       /* after the last host-to-device copy of a stage: the pinned side buffers are free again */
 	int staged_busy;
 	hipEvent_t fetch_ev[HVK_FETCH_TICKETS];   /* hvk_fetch_async() */
+	hipStream_t copy_stream;                  /* a large read-back goes out in two halves, this stream's beside the engine's own: two DMA engines, one PCIe link */
+	hipEvent_t copy_fork, copy_join;
+	size_t copy_split;                        /* bytes from which on a read-back is split (HVK_FETCH_SPLIT_MB, 0: never) */
 	int fetch_busy[HVK_FETCH_TICKETS];        /* handed out and not waited for yet */
 	int fetch_next;
 
@@ -640,18 +650,18 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(k.has_nicam)
 	{
 		/* device forms of the NICAM tables: the pulse as int16 behind HVK_NICAM_LEAD
-		 * zeros and zero padded (no bounds test is needed), in four copies of which
+		 * zeros and zero padded (no bounds test is needed), in HVK_NICAM_COPIES copies of which
 		 * copy s starts s entries later, so that any eight consecutive entries start
-		 * 8-byte aligned in one of them; the mixer as the first row of the rotation
+		 * 8-byte aligned in one of them (hvk_kernels.h has why four and not eight); the mixer as the first row of the rotation
 		 * matrix, (i, -q), extended by 8 entries past the wrap, and its second row, (q, i), likewise */
-		std::vector<int16_t> tapd(4 * HVK_NICAM_TAPD, 0);
+		std::vector<int16_t> tapd(HVK_NICAM_COPIES * HVK_NICAM_TAPD, 0);
 		std::vector<int> cca(2 * (size_t) (k.nicam_cc_len + 8));
 		if(HVK_NICAM_LEAD + k.nicam_ntaps + HVK_SPL > HVK_NICAM_TAPD) { *pe = NULL; hvk_close(e); return(HVK_UNSUPPORTED); }
 		for(int i = 0; i < k.nicam_ntaps; i++)
 		{
 			const int v = e->t.nicam_taps[i];
 			/* copy s holds entry j + s at position j */
-			for(int sft = 0; sft < 4; sft++) tapd[sft * HVK_NICAM_TAPD + HVK_NICAM_LEAD + i - sft] = (int16_t) v;
+			for(int sft = 0; sft < HVK_NICAM_COPIES; sft++) tapd[sft * HVK_NICAM_TAPD + HVK_NICAM_LEAD + i - sft] = (int16_t) v;
 		}
 		for(int i = 0; i < k.nicam_cc_len + 8; i++)
 		{
@@ -678,7 +688,22 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(k.rs_L)
 	{
 		OPENHIP(hipMalloc((void **) &e->d_S2, (size_t) max_frames * k.s_stride * 2 + 256));
-		if(k.s_video) OPENHIP(hipMalloc((void **) &e->d_C2, (size_t) max_frames * k.s_stride * 2 + 256));
+		if(k.s_video && !k.sv_ring) OPENHIP(hipMalloc((void **) &e->d_C2, (size_t) max_frames * k.s_stride * 2 + 256));
+		if(k.s_video && k.sv_ring)
+		{
+			/* (a line's old content can be the last sample of a chunk several turns of the ring back: that much of the stream
+			 * stays in front of the batch) */
+			e->sv_hist = ((8 * k.sv_ring + 4) * e->t.max_width + 7) & ~7;
+			const size_t n = (size_t) e->sv_hist + (size_t) max_frames * k.s_stride + 128;
+			OPENHIP(hipMalloc((void **) &e->d_C2_alloc, n * 2));
+			OPENHIP(hipMemset(e->d_C2_alloc, 0, n * 2));
+			e->d_C2 = e->d_C2_alloc + e->sv_hist;
+			OPENHIP(hipMalloc((void **) &e->d_Cq, ((size_t) max_frames * k.s_stride + 128) * 2));
+			OPENHIP(hipMemset(e->d_Cq, 0, ((size_t) max_frames * k.s_stride + 128) * 2));
+			OPENHIP(hipHostMalloc((void **) &e->h_svrec, (size_t) max_frames * k.lines * 16, hipHostMallocDefault));
+			OPENHIP(hipMalloc((void **) &e->d_svrec, (size_t) max_frames * k.lines * 16));
+			e->sv_tail_first = -1;
+		}
 		/* one 16-byte aligned row of 12 packed dwords per phase: pairs (t[0], t[1]) ... oldest sample
 		 * first; a 21-tap phase gets a zero 22nd (hvk_k_resample stages the rows as they are) */
 		std::vector<int> rows((size_t) k.rs_L * 12, 0);
@@ -702,6 +727,10 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	OPENHIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
 	for(int i = 0; i < HVK_FETCH_TICKETS; i++) OPENHIP(hipEventCreateWithFlags(&e->fetch_ev[i], hipEventDisableTiming));
+	OPENHIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+	OPENHIP(hipEventCreateWithFlags(&e->copy_fork, hipEventDisableTiming));
+	OPENHIP(hipEventCreateWithFlags(&e->copy_join, hipEventDisableTiming));
+	e->copy_split = (size_t) (getenv("HVK_FETCH_SPLIT_MB") ? atoi(getenv("HVK_FETCH_SPLIT_MB")) : 16) << 20;
 
 	if(e->t.k.has_carriers)
 	{
@@ -1046,7 +1075,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_UVp, e->d_clut3, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
+		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2_alloc ? (void *) e->d_C2_alloc : (void *) e->d_C2, e->d_Cq, e->d_svrec, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
@@ -1057,6 +1086,10 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		for(int i = 0; i < HVK_PREP_EVENTS; i++) if(e->ev_prep[i]) (void) hipEventDestroy(e->ev_prep[i]);
 		if(e->prep_stream) { (void) hipStreamSynchronize(e->prep_stream); (void) hipStreamDestroy(e->prep_stream); }
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
+		if(e->h_svrec) (void) hipHostFree(e->h_svrec);
+		if(e->copy_stream) { (void) hipStreamSynchronize(e->copy_stream); (void) hipStreamDestroy(e->copy_stream); }
+		if(e->copy_fork) (void) hipEventDestroy(e->copy_fork);
+		if(e->copy_join) (void) hipEventDestroy(e->copy_join);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_sis_bits, e->h_secam_rows, e->h_frec };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
@@ -1369,6 +1402,18 @@ extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const u
 		memcpy(dst + r * 12, row, 48);     /* little endian: bit b of the packet is bit b & 31 of word b >> 5 */
 	}
 	e->h_tt_mask[frame_in_batch] = mask;
+	return(HVK_OK);
+}
+
+/* ... for a run of frames in one call: packets [nframes][32][45], masks [nframes] */
+extern "C" int hvk_teletext_packets_block(hvk_engine_t *e, int first_frame_in_batch, int nframes, const uint8_t *packets, const uint32_t *masks)
+{
+	if(!e || !packets || !masks || nframes < 0 || first_frame_in_batch < 0 || first_frame_in_batch + nframes > e->max_frames) return(HVK_ERROR);
+	for(int i = 0; i < nframes; i++)
+	{
+		const int r = hvk_teletext_packets(e, first_frame_in_batch + i, packets + (size_t) i * 32 * 45, masks[i]);
+		if(r != HVK_OK) return(r);
+	}
 	return(HVK_OK);
 }
 
@@ -2447,6 +2492,84 @@ extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
 }
 
 /* the kernels' arguments for the staged batch */
+/* S-Video behind resampler + video filter, lines of two widths (hvk_kconst_t.sv_ring): the staged batch's Q channel, line by
+ * line, as the reference's ring of line buffers pairs it (hvk_k_svq has the rule). Emitted line j of the stream begins at
+ * S(j) = ceil((j + s) W L / D) - ceil(s W L / D), s the chunks dropped at start-up (hvk_tables_frame_start()); its content
+ * is a chunk of the width of line j - 1. */
+static int _sv_ring_q(hvk_engine *e)
+{
+	const hvk_kconst_t &k = e->t.k;
+	const int64_t s = 1 + (k.vf_type ? k.delay_lines : 0), WL = (int64_t) k.width * k.rs_L, D = k.rs_D;
+	auto S = [&](int64_t j) { return(((j + s) * WL + D - 1) / D - (s * WL + D - 1) / D); };
+	auto width = [&](int64_t j) { return((int) (S(j + 1) - S(j))); };
+	const int wmax = e->t.max_width, ring = k.sv_ring;
+	const int64_t f0 = e->staged_first, j0 = f0 * k.lines, base = S(j0);
+	const long slab_in = (long) k.slab_lines * k.width;
+	const int nlines = e->staged * k.lines;
+	if(e->staged_stride != 1) return(HVK_UNSUPPORTED);
+
+	for(int i = 0; i < nlines; i++)
+	{
+		const int64_t j = j0 + i;
+		const int w = width(j), wp = j + s - 1 >= 0 ? width(j - 1) : wmax, delta = wmax - wp;
+		int kind = 0, src = 0;
+		if(w > wp)
+		{
+			if(k.rs_L < k.rs_D)
+			{
+				/* downwards: the raster's sub-carrier of the line before the content's, at the place the content ends */
+				const int y = i / k.lines;
+				const int64_t pl = S(j) - S((f0 + y) * k.lines);                    /* the line's first sample in its frame */
+				const int64_t rr = pl + delta + k.rs_shift;
+				const int64_t n0 = (rr * D + e->h_frec[2 * y]) / k.rs_L;
+				const int64_t rho = n0 / k.width;
+				kind = 1;
+				src = (int) ((int64_t) y * slab_in + rho * k.width + wp);
+			}
+			else
+			{
+				/* upwards: the last sample of the newest chunk of the longer width that lay in this buffer: k turns of the ring back */
+				kind = 3;       /* (none: the buffer is as it was allocated) */
+				for(int t = 1; t <= 8; t++)
+				{
+					const int64_t m = j - (int64_t) t * ring;
+					if(m + s - 1 < 0) break;
+					if(width(m - 1) == wmax)
+					{
+						const int64_t at = S(m) + (wmax - 1) - base;        /* (its delta is 0) */
+						if(at >= -(int64_t) e->sv_hist) { kind = 2; src = (int) at; }
+						break;
+					}
+				}
+			}
+		}
+		e->h_svrec[4 * i + 0] = (int) (S(j) - base);
+		e->h_svrec[4 * i + 1] = w | (delta << 16) | (kind << 20);
+		e->h_svrec[4 * i + 2] = src;
+		e->h_svrec[4 * i + 3] = 0;
+	}
+	HIPCHK(hipMemcpyAsync(e->d_svrec, e->h_svrec, (size_t) nlines * 16, hipMemcpyHostToDevice, e->stream));
+	int r = hvk_launch_svq(e->d_svrec, nlines, e->d_C2, e->d_C, e->d_Cq, k.s_lead, e->stream);
+	if(r != HVK_OK) return(r);
+	e->sv_tail_first = f0;
+	e->sv_tail_total = e->staged_samples;
+	return(HVK_OK);
+}
+
+/* ... before a NEW batch's sub-carrier stream is made: the end of the stream that lies there (the batch before's) goes in front
+ * of it (a batch launched again finds what it found the first time) */
+static int _sv_ring_keep(hvk_engine *e)
+{
+	const hvk_kconst_t &k = e->t.k;
+	if(e->sv_tail_first < 0 || e->sv_tail_first == e->staged_first) return(HVK_OK);
+	if(e->sv_tail_total >= e->sv_hist)
+	{
+		HIPCHK(hipMemcpyAsync(e->d_C2 + k.s_lead - e->sv_hist, e->d_C2 + k.s_lead + e->sv_tail_total - e->sv_hist, (size_t) e->sv_hist * 2, hipMemcpyDeviceToDevice, e->stream));
+	}
+	else HIPCHK(hipMemsetAsync(e->d_C2 + k.s_lead - e->sv_hist, 0, (size_t) e->sv_hist * 2, e->stream));
+	return(HVK_OK);
+}
+
 static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride)
 {
 	hvk_raster_args_t &ra = *pra;
@@ -2491,7 +2614,7 @@ static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_
 	fa.qtaps = e->qtaps;
 	fa.fdesc = e->d_fdesc;
 	fa.S = e->t.k.rs_L ? e->d_S2 : e->d_S;
-	fa.C = e->t.k.rs_L ? e->d_C2 : e->d_C;
+	fa.C = e->t.k.rs_L ? (e->t.k.sv_ring ? e->d_Cq : e->d_C2) : e->d_C;
 	fa.carriers = (const hvk_c16_t *) e->d_car;
 	fa.tilesyms = e->d_tile;
 	fa.nicam_tapd = (const int *) e->d_tapd;
@@ -2661,7 +2784,9 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
 		if(e->t.k.rs_irr && out_stride != 1) return(HVK_UNSUPPORTED);
 		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.sv_ring && (r = _sv_ring_keep(e)) != HVK_OK) return(r);
 		if(e->t.k.rs_L && e->t.k.s_video && (r = hvk_launch_resample(&e->t.k, e->d_C, e->d_rs_taps, e->d_C2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
+		if(e->t.k.sv_ring && (r = _sv_ring_q(e)) != HVK_OK) return(r);
 		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
 		if(e->t.k.rs_irr)
 		{
@@ -2847,6 +2972,18 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 		/* (out of order, or with --passthru, whose queue the caller's thread fills: in this call) */
 		int r = hvk_fetch(e, iq, first, count);
 		if(r != HVK_OK) return(r);
+	}
+	else if(e->copy_split && count * 4 >= e->copy_split)
+	{
+		/* One copy engine moves about 27 GB/s of a read-back, the link twice that: the second half goes out on a stream of
+		 * its own, behind everything queued so far, and the engine's stream goes on when both are through */
+		const size_t h = (count / 2) & ~(size_t) 1023;
+		HIPCHK(hipEventRecord(e->copy_fork, e->stream));
+		HIPCHK(hipStreamWaitEvent(e->copy_stream, e->copy_fork, 0));
+		HIPCHK(hipMemcpyAsync(iq + h * 2, e->d_out + (first + h) * 2, (count - h) * 4, hipMemcpyDeviceToHost, e->copy_stream));
+		HIPCHK(hipEventRecord(e->copy_join, e->copy_stream));
+		HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, h * 4, hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipStreamWaitEvent(e->stream, e->copy_join, 0));
 	}
 	else HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));

@@ -180,7 +180,7 @@ __device__ __forceinline__ int4u fused_part2(const hvk_kconst_t &k, const hvk_li
 #pragma unroll
 	for(int m = 0; m < SPL / 2; m++)
 	{
-		const int t0 = dot2(K[2 * m], vu[2 * m], 0) >> 15, t1 = dot2(K[2 * m + 1], vu[2 * m + 1], 0) >> 15;
+		const int t0 = dot2z(K[2 * m], vu[2 * m]) >> 15, t1 = dot2z(K[2 * m + 1], vu[2 * m + 1]) >> 15;
 		pr[m] = (int) __builtin_amdgcn_perm((unsigned) t1, (unsigned) t0, 0x05040100u);
 	}
 	s.x = pk_add16(s.x, pr[0]); s.y = pk_add16(s.y, pr[1]); s.z = pk_add16(s.z, pr[2]); s.w = pk_add16(s.w, pr[3]);
@@ -236,9 +236,9 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	/* the chroma channels of the four lines while they are low-passed; the filter's outputs afterwards (never both) */
 	__shared__ __attribute__((aligned(16))) int stage_g[FG][FW + 2 * HVK_CHROMA_LEAD];
 	__shared__ __attribute__((aligned(16))) int16_t halo_uv[2][128];
-	__shared__ __attribute__((aligned(16))) int16_t tapd[4 * HVK_NICAM_TAPD];
+	__shared__ __attribute__((aligned(16))) int16_t tapd[HVK_NICAM_COPIES * HVK_NICAM_TAPD];
 	__shared__ int sym_st_g[FG][HVK_NICAM_SYMS];
-	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[FG][HVK_NICAM_SYMS];
+	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[1 + FG * HVK_NICAM_SYMS];      /* (an entry of slack in front: nicam_add()) */
 	static_assert(sizeof(int) * (FW + 2 * HVK_CHROMA_LEAD) >= 2 * sizeof(int16_t) * CL, "U and V of a line fit its filter-output row");
 
 	const int bx = (int) blockIdx.x;
@@ -265,9 +265,9 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	const fsel_t q = fused_select(k, P, d_fdesc, d_lineoff, d_creg, y, rel, frame_index);
 
 	/* ---- the second half's loads (hvk_k_direct): NICAM pulse table and symbols, the filter's A operand, carriers ---- */
-	const bool tap_mine = k.has_nicam && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	const bool tap_mine = k.has_nicam && (int) threadIdx.x < HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8;
 	int4v tap_stage = { 0, 0, 0, 0 };
-	if(k.has_nicam) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
+	if(k.has_nicam) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8 - 1)];
 	int symv = 0, cc_tile = 0;
 	if(k.has_nicam && !halo)
 	{
@@ -282,7 +282,7 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	F.lane_ok = halo ? t < (FW - FHALO0) / SPL : true;
 	fused_part1<NT, LV>(k, P, q.L, q.pal, t, F.lane_ok ? x0 : FHALO0, xbase, U, V, F);
 	if(tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
-	if(k.has_nicam && !halo && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st_g[sub], sym_ent_g[sub], t);
+	if(k.has_nicam && !halo && t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st_g[sub], sym_ent_g + 1 + sub * HVK_NICAM_SYMS, t, tapd);
 	__syncthreads();
 
 	/* (asked for behind the first barrier: the line's own reads are through, these have all of part 2 and the filter to arrive in,
@@ -358,7 +358,7 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		o[0] = pk_add16(o[0], car0.x); o[1] = pk_add16(o[1], car0.y); o[2] = pk_add16(o[2], car0.z); o[3] = pk_add16(o[3], car0.w);
 		o[4] = pk_add16(o[4], car1.x); o[5] = pk_add16(o[5], car1.y); o[6] = pk_add16(o[6], car1.z); o[7] = pk_add16(o[7], car1.w);
 	}
-	if(k.has_nicam) nicam_add(k, x0, sym_st_g[sub], sym_ent_g[sub], tapd, mix, o);
+	if(k.has_nicam) nicam_add(k, x0, sym_st_g[sub], sym_ent_g + 1 + sub * HVK_NICAM_SYMS, tapd, mix, o);
 
 	int *dst = iq + (size_t) y * out_stride * FS + n;
 	__builtin_nontemporal_store(((int4u) { o[0], o[1], o[2], o[3] }), &((int4u *) dst)[0]);

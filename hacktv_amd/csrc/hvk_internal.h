@@ -124,6 +124,9 @@ typedef struct {
 	int32_t fsc_mode;       /* field-sequential colour: 0 none, 1 Apollo (525 lines), 2 CBS (405 lines): a line shows ONE colour channel of the
 	                         * picture as grey -- channel (frame * 2 + field) mod 3, frames counted from 1 (src/video.c:2919-2930, :2995-3000) */
 	int32_t fsc_split;      /* first line (1-based) of the second field for that count: 264, 202 */
+	int32_t sv_ring;        /* S-Video behind resampler + video filter where the lines have two widths: the reference pairs a line's luma
+	                         * with what ITS RING of line buffers holds in the Q channel (src/video.c:3243, :3578; hvk_k_svq, hvk_engine.cpp).
+	                         * The ring's length in lines; 0: every line has one width (or no such combination) */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;
 

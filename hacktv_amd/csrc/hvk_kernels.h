@@ -12,6 +12,12 @@
 #define HVK_NICAM_ROW   64   /* ints per tile row: the slots, then the mixer position */
 #define HVK_MFMA_A_BYTES (2 * 64 * 16)
 #define HVK_NICAM_TAPD  512  /* entries of one copy of the zero padded NICAM pulse table */
+#ifndef HVK_NICAM_COPIES
+/* copies of it, copy s shifted left by s entries: any run of 8 entries starts 8-byte aligned in one of four (two 8-byte reads
+ * a lane), 16-byte aligned in one of eight (one 16-byte read, no bank conflict between the lanes of a wave -- and 4 KB more
+ * LDS a workgroup: measured 1 % SLOWER on the metric configuration, profiles/r05_direct_variants.txt; kept as a build variant) */
+#define HVK_NICAM_COPIES 4
+#endif
 
 /* FIR taps packed two int16 per dword, zero padded: passed by value so they
  * live in SGPRs (wave-uniform operands of v_dot2c_i32_i16) */
@@ -63,7 +69,7 @@ typedef struct {
 	const int16_t *C;           /* --s-video: the Q channel, laid out like S */
 	const hvk_c16_t *carriers;
 	const int *tilesyms;        /* [nframes][tiles][HVK_NICAM_ROW] */
-	const int *nicam_tapd;      /* 4 x HVK_NICAM_TAPD int16: the pulse, four shifted copies, zero padded */
+	const int *nicam_tapd;      /* HVK_NICAM_COPIES x HVK_NICAM_TAPD int16: the pulse, shifted copies, zero padded */
 	const int *nicam_cca;       /* 2 x (nicam_cc_len + 8) dwords: the mixer's rows (cc.i, -cc.q), then (cc.q, cc.i) */
 	const void *mfma_a;         /* HVK_MFMA_A_BYTES: the taps as MFMA A operand (hvk_engine.cpp:_mfma_taps), NULL: use the VALU filter */
 	int mfma_ci, mfma_cq;       /* 128 * sum of the taps, per channel */
@@ -232,6 +238,7 @@ int hvk_launch_direct(const hvk_direct_args_t *a, hipStream_t stream);
 int hvk_fused_supported(const hvk_kconst_t *k, const hvk_linedesc_t *desc);
 int hvk_launch_fused(const hvk_raster_args_t *ra, const hvk_direct_args_t *a, const void *mfma_a28, hipStream_t stream);
 int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream);
+int hvk_launch_svq(const void *rec, int nlines, const void *C2, const void *Craster, void *Q, int s_lead, hipStream_t stream);
 int hvk_launch_tail(void *iq, const void *off, const void *pass, int swap, long frame_samples, long out_stride,
                     int nframes, hipStream_t stream);
 int hvk_launch_convert(const void *iq, size_t count, int type, int cplx, void *dst, hipStream_t stream);

@@ -172,7 +172,7 @@ void hvk_k_filter(const hvk_kconst_t k,
                   const int16_t *__restrict__ S,
                   const int *__restrict__ carriers,      /* [frames][frame_samples] int16 pairs */
                   const int *__restrict__ tilesyms,      /* [frames][tiles][HVK_NICAM_ROW]: symbols (start << 3 | valid << 2 | dsym), mixer position */
-                  const int *__restrict__ nicam_tapd,    /* pulse taps: four shifted int16 copies, zero padded (hvk_engine.cpp) */
+                  const int *__restrict__ nicam_tapd,    /* pulse taps: HVK_NICAM_COPIES shifted int16 copies, zero padded (hvk_engine.cpp) */
                   const int *__restrict__ nicam_cca,     /* mixer (i, -q), 8 entries past the wrap */
                   const int16_t *__restrict__ Cq,        /* --s-video: the Q channel, laid out like S */
                   const int4v *__restrict__ mfma_a,      /* MF: the taps as A operand, [hh, hl][lane] (hvk_engine.cpp:_mfma_taps) */
@@ -190,9 +190,9 @@ void hvk_k_filter(const hvk_kconst_t k,
 	__shared__ __attribute__((aligned(16))) int16_t win_g[G][MF ? 8 : NWIN];
 	__shared__ __attribute__((aligned(16))) unsigned char xh_g[G][MF ? NPL : 16], xl_g[G][MF ? NPL : 16];
 	__shared__ __attribute__((aligned(16))) int outl_g[G][MF ? HVK_TILE : 4];
-	__shared__ __attribute__((aligned(16))) int16_t tapd[4 * HVK_NICAM_TAPD];   /* four copies of the pulse, copy s one entry further left */
+	__shared__ __attribute__((aligned(16))) int16_t tapd[HVK_NICAM_COPIES * HVK_NICAM_TAPD];   /* HVK_NICAM_COPIES copies of the pulse, copy s one entry further left */
 	__shared__ int sym_st_g[G][HVK_NICAM_SYMS];                               /* start, relative to the tile's first sample */
-	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[G][HVK_NICAM_SYMS];   /* { LEAD - start, copy offset, sign pair, 0 } */
+	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[1 + G * HVK_NICAM_SYMS];   /* nicam_symbol_slot(); an entry of slack in front: nicam_add() */
 
 	const int FS = k.frame_samples;
 	const int sub = threadIdx.x / (HVK_TILE / HVK_SPL);        /* which of the workgroup's tiles */
@@ -203,17 +203,17 @@ void hvk_k_filter(const hvk_kconst_t k,
 	unsigned char *const xh = xh_g[sub], *const xl = xl_g[sub];
 	int *const outl = outl_g[sub];
 	int *const sym_st = sym_st_g[sub];
-	int4v *const sym_ent = sym_ent_g[sub];
+	int4v *const sym_ent = sym_ent_g + 1 + sub * HVK_NICAM_SYMS;
 	(void) win; (void) xh; (void) xl; (void) outl;
 
-	/* four copies of the NICAM pulse table (int16), copy s shifted left by s entries, so that
-	 * any run of 8 entries starts 8-byte aligned in one of them: one ds_read2_b64, lanes side by
+	/* HVK_NICAM_COPIES copies of the NICAM pulse table (int16), copy s shifted left by s entries, so that
+	 * any run of 8 entries starts aligned in one of them: one ds_read2_b64 (four copies), lanes side by
 	 * side; staged once per workgroup. The load goes out here, the LDS write waits until the first
 	 * tile's own loads are on their way. */
-	static_assert(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP >= HVK_NICAM_TAPD / 2, "one pulse-table vector per thread");
-	const bool tap_mine = k.has_nicam && !ABLATE(16) && (int) threadIdx.x < HVK_NICAM_TAPD / 2;
+	static_assert(HVK_TILE / HVK_SPL * HVK_FILTER_GROUP >= HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8, "one pulse-table vector per thread");
+	const bool tap_mine = k.has_nicam && !ABLATE(16) && (int) threadIdx.x < HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8;
 	int4v tap_stage = { 0, 0, 0, 0 };
-	if(k.has_nicam && !ABLATE(16)) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_TAPD / 2 - 1)];
+	if(k.has_nicam && !ABLATE(16)) tap_stage = ((const int4v *) nicam_tapd)[min((int) threadIdx.x, HVK_NICAM_COPIES * HVK_NICAM_TAPD / 8 - 1)];
 
 	/* MF: this lane's share of the tap matrix, 16 rows (8 outputs x I, Q) by 64 window positions */
 	int4v a_hh = { 0, 0, 0, 0 }, a_hl = { 0, 0, 0, 0 };
@@ -329,7 +329,7 @@ void hvk_k_filter(const hvk_kconst_t k,
 		/* the symbols whose pulses can touch this tile, oldest first: start
 		 * (relative to the tile's first sample) and sign pair. The schedule
 		 * (src/nicam728.c:398-407) is tabulated per frame by the host. */
-		if(t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t);
+		if(t < HVK_NICAM_SYMS) nicam_symbol_slot(symv, n0, sym_st, sym_ent, t, tapd);
 	}
 	__syncthreads();
 
@@ -653,6 +653,32 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	{
 		for(int i = 0; i < 4; i++) if(q + i < k.s_stride) out[q + i] = v[i];
 	}
+}
+
+/* S-Video behind the resampler and the video filter where the lines have two widths (hvk_kconst_t.sv_ring; src/video.c:3243,
+ * :3578): the Q channel of an emitted line is what its buffer of the reference's ring holds -- the resampled sub-carrier of
+ * the line's own content, which has the width of the line BEFORE it: a sample further on in the sub-carrier stream where
+ * that was the shorter one (delta), and a line a sample longer than that ends on the buffer's old content (src: where that
+ * is found -- the raster's sub-carrier of the line before at that place, or the last sample of an earlier chunk a turn of
+ * the ring back; < 0 with kind 0: nothing, zero). One workgroup per emitted line; rec[line] = { first output sample of the
+ * line in the batch, width | delta << 16 | kind << 20, src, 0 }. C2 and Q in the batch's run of samples, s_lead in front. */
+__global__ __launch_bounds__(256) void hvk_k_svq(const int4v *__restrict__ rec, const int16_t *__restrict__ C2, const int16_t *__restrict__ Craster,
+                                                 int16_t *__restrict__ Q, const int s_lead)
+{
+	const int4v r = rec[blockIdx.x];
+	const int w = r.y & 0xFFFF, delta = (r.y >> 16) & 15, kind = (r.y >> 20) & 15;
+	const int16_t *src = C2 + s_lead + r.x + delta;
+	int16_t *dst = Q + s_lead + r.x;
+	const int valid = kind ? w - 1 : w;         /* (kind != 0: the line's last sample is the buffer's old content) */
+	for(int x = threadIdx.x; x < valid; x += 256) dst[x] = src[x];
+	if(kind && threadIdx.x == 0) dst[w - 1] = kind == 1 ? Craster[r.z] : (kind == 2 ? C2[s_lead + r.z] : (int16_t) 0);
+}
+
+extern "C" int hvk_launch_svq(const void *rec, int nlines, const void *C2, const void *Craster, void *Q, int s_lead, hipStream_t stream)
+{
+	if(nlines < 1) return(HVK_OK);
+	hipLaunchKernelGGL(hvk_k_svq, dim3(nlines), dim3(256), 0, stream, (const int4v *) rec, (const int16_t *) C2, (const int16_t *) Craster, (int16_t *) Q, s_lead);
+	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 
 extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream)

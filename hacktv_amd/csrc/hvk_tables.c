@@ -231,6 +231,33 @@ static int _build_linebase(hvk_tables_t *t)
 	return(HVK_OK);
 }
 
+/* The reference's line buffers form a ring of `olines` (src/video.c:3578: every process adds its window, two neighbours
+ * share a buffer unless one of them runs on a thread of its own): its length for this configuration */
+static int _ring_lines(const hvk_tables_t *t)
+{
+	const hvk_config_t *c = &t->conf;
+	int olines = c->raw_bb ? 1 : 3, prev_thread = 0;
+#define PROCESS(nl, th) do { olines += (nl) - ((th) || prev_thread ? 0 : 1); prev_thread = (th); } while(0)
+	if(!c->raw_bb && c->colour_mode == HVK_SECAM) PROCESS(1, 1);
+	if(c->vits) PROCESS(1, 0);
+	if(c->wss) PROCESS(1, 0);
+	if(c->acp) PROCESS(1, 0);
+	if(c->vitc) PROCESS(1, 0);
+	if(c->cc608) PROCESS(1, 0);
+	if(c->sis) PROCESS(1, 0);
+	if(c->teletext) PROCESS(1, 0);
+	if(t->pixel_rate != t->sample_rate) PROCESS(2, 1);
+	if(c->vfilter) PROCESS(2, 1);                   /* (1 + the filter's delay of one line) */
+	PROCESS(1, 1);                                  /* audio, always */
+	if(c->modulation == HVK_FM) PROCESS(1, 1);
+	if(c->swap_iq) PROCESS(1, 0);
+	if(c->offset) PROCESS(1, 1);
+	if(c->passthru) PROCESS(1, 0);
+	PROCESS(1, 0);                                  /* output */
+#undef PROCESS
+	return(olines);
+}
+
 static int _build_linedesc(hvk_tables_t *t)
 {
 	const hvk_config_t *c = &t->conf;
@@ -293,31 +320,12 @@ static int _build_linedesc(hvk_tables_t *t)
 	}
 	if(t->k.spill_lines)
 	{
-		/* How many lines the stream is old before a pulse can run on into the line behind its own: the reference's line
-		 * buffers form a ring of `olines` (src/video.c:3578: every process adds its window, two neighbours share a buffer unless
-		 * one of them runs on a thread of its own), every buffer starts out with width 0, and the renderer stops at such a
-		 * buffer (src/vbidata.c:219-236) -- the buffer behind the line being drawn has been used once the raster has gone
-		 * round the ring: from stream line olines - 1 on. */
-		int olines = c->raw_bb ? 1 : 3, prev_thread = 0;
-#define PROCESS(nl, th) do { olines += (nl) - ((th) || prev_thread ? 0 : 1); prev_thread = (th); } while(0)
-		if(!c->raw_bb && c->colour_mode == HVK_SECAM) PROCESS(1, 1);
-		if(c->vits) PROCESS(1, 0);
-		if(c->wss) PROCESS(1, 0);
-		if(c->acp) PROCESS(1, 0);
-		if(c->vitc) PROCESS(1, 0);
-		if(c->cc608) PROCESS(1, 0);
-		if(c->sis) PROCESS(1, 0);
-		if(c->teletext) PROCESS(1, 0);
-		if(t->pixel_rate != t->sample_rate) PROCESS(2, 1);
-		if(c->vfilter) PROCESS(2, 1);                   /* (1 + the filter's delay of one line) */
-		PROCESS(1, 1);                                  /* audio, always */
-		if(c->modulation == HVK_FM) PROCESS(1, 1);
-		if(c->swap_iq) PROCESS(1, 0);
-		if(c->offset) PROCESS(1, 1);
-		if(c->passthru) PROCESS(1, 0);
-		PROCESS(1, 0);                                  /* output */
-#undef PROCESS
-		t->k.spill_lines = olines;      /* (the pulses of stream lines 0 .. olines - 2 lose what runs over: lines 1 .. olines - 1 receive nothing, nor does line 0) */
+		/* How many lines the stream is old before a pulse can run on into the line behind its own: every buffer of the ring
+		 * (_ring_lines()) starts out with width 0, and the renderer stops at such a buffer (src/vbidata.c:219-236) -- the
+		 * buffer behind the line being drawn has been used once the raster has gone round the ring: from stream line
+		 * olines - 1 on. (The pulses of stream lines 0 .. olines - 2 lose what runs over: lines 1 .. olines - 1 receive
+		 * nothing, nor does line 0.) */
+		t->k.spill_lines = _ring_lines(t);
 	}
 	return(HVK_OK);
 }
@@ -1786,12 +1794,18 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		if(c->output_type != HVK_INT16_REAL || c->colour_mode == HVK_MONOCHROME) REFUSE("--s-video needs a baseband colour mode (src/hacktv.c:1136-1148)");
 		/* With the video filter behind a resampler whose lines are not all of one width (525 lines at 16 MHz: 1017, 1017,
 		 * ..., 1016) the reference pairs a line's luma -- as many samples as the chunk the filter was last fed, dst->width =
-		 * fir_int16_process(), src/video.c:3243 -- with the sub-carrier its line buffer holds, which is a chunk of another
-		 * width: a sample short (the line then ends on what the buffer held before) or a sample long, and one sample
-		 * earlier or later in the stream from line to line. The filter kernel reads the sub-carrier at the luma's own
-		 * stream position; the oracle models the buffers (oracle_video.c). Refused rather than rendered a sample off. */
+		 * fir_int16_process(), src/video.c:3243 -- with the sub-carrier its line buffer holds, which is the chunk of the line
+		 * before's width: where that is the shorter one the sub-carrier stands a sample earlier in the line, and a line a
+		 * sample longer than it ends on what the buffer held before -- the raster's sub-carrier of the line before it at that
+		 * place when resampling downwards, the end of an earlier chunk (a whole turn of the ring of line buffers back,
+		 * src/video.c:3578) when upwards. hvk_k_svq makes the Q channel line by line that way (hvk_engine.cpp has the
+		 * per-line records); the oracle keeps the ring itself (oracle_video.c). */
 		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0)
-			REFUSE("--s-video with --filter and --pixelrate %u -> %u Hz: the lines are not all of one width there, and the reference pairs luma and sub-carrier of different lines' widths", pixel_rate, sample_rate);
+		{
+			const int olines = _ring_lines(t);
+			t->k.sv_ring = olines > t->k.delay_lines + 2 ? olines : t->k.delay_lines + 2;
+			if(getenv("HVK_SV_EXPERIMENT")) t->k.sv_ring = 0;       /* (tools/sv_probe.py: the sub-carrier at the luma's own position, as before) */
+		}
 		t->k.s_video = 1;
 	}
 

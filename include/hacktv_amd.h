@@ -178,6 +178,9 @@ int hvk_frame_aspect(hvk_engine_t *e, int slot, int64_t par_num, int64_t par_den
  * and adds them to the line (vbidata_render, src/vbidata.c:186-239). Frames
  * without a call carry no teletext. */
 int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const uint8_t *packets, uint32_t mask);
+/* The same for frames [first_frame_in_batch, first_frame_in_batch + nframes) of the next batch in one call: packets
+ * [nframes][32][45], masks [nframes] (a caller in an interpreted language pays its call overhead once per batch). */
+int hvk_teletext_packets_block(hvk_engine_t *e, int first_frame_in_batch, int nframes, const uint8_t *packets, const uint32_t *masks);
 
 /* Which lines (held[line - 1] != 0) the configuration's other inserters -- VITS, WSS, ACP, VITC, CC608, SECAM field
  * identification -- write to: the lines on which the reference's vid_line_t.vbialloc is already set when its

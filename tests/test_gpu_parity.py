@@ -690,6 +690,10 @@ def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch)
 
 
 @pytest.mark.parametrize("case,batches", [("m_px135_s16", (1, 3, 1)), ("m_px135_s16", (5,)), ("ntsc_px16_s135", (2, 1, 1)), ("ntsc_px16_s135", (3, 1)),
+                                          # S-Video behind resampler + filter where the lines have two widths (hvk_k_svq: the reference's ring of line
+                                          # buffers; a line's old content may lie in the batch before): whole, frame by frame, uneven
+                                          ("ntsc_sv_f_px135_s16", (4,)), ("ntsc_sv_f_px135_s16", (1, 1, 1, 1)), ("ntsc_sv_f_px135_s16", (1, 2, 1)),
+                                          ("ntsc_sv_f_px18_s16", (4,)), ("ntsc_sv_f_px18_s16", (1, 1, 2)), ("pal60_sv_f_px27_s16", (3,)), ("pal60_sv_f_px27_s16", (1, 2)),
                                           # FM video: the modulator's place in the stream is what the frames add up to (found by tools/fuzz_parity.py)
                                           ("ntscfm_s18_px16", (2, 2, 1)), ("ntscfm_s18_px16", (1, 3, 1)), ("ntscfm_s18_px16", (5,))])
 def test_frames_of_two_lengths(golden, case, batches):
