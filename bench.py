@@ -296,6 +296,7 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
         pass
     if fresh_e2e:
         host_out = e.host_buffer(F * fs)
+        e.fetch_wait(e.fetch_async(host_out, 0, F * fs))     # (a buffer that has been written to once: see end_to_end)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         stage_block()
@@ -894,6 +895,7 @@ def main():
     e2e = None
     if N == 1 and not args.walk_rounds:
         host_out = e.host_buffer(F * FS)
+        e.fetch_wait(e.fetch_async(host_out, 0, F * FS))     # (the first copy into a fresh page-locked buffer runs at half the link's rate: not what a sink that keeps its buffers sees)
         nxt = first_frame + F
         t0 = time.perf_counter()
         while e.audio_needed(nxt + F) > 0:
@@ -901,7 +903,7 @@ def main():
         e.stage(nxt, 1, F)
         t1 = time.perf_counter()
         e.launch()
-        e.fetch_wait(e.fetch_async(host_out, 0, F * FS))     # (hvk_fetch_async: a large read-back goes out in two halves on two streams)
+        e.fetch_wait(e.fetch_async(host_out, 0, F * FS))
         t2 = time.perf_counter()
         e2e = {"stage_s": round(t1 - t0, 4), "render_and_d2h_s": round(t2 - t1, 4),
                "Msamples_per_s": round(F * FS / (t2 - t0) / 1e6, 1),
@@ -997,6 +999,33 @@ def main():
             ex.close()
             return round(Fm * FS / dt_ / 1e6, 1), nf
 
+        def new_pictures_m(levels):
+            """The same at BASELINE config 3's geometry (-m m -s 13500000 --filter --noaudio: 858-sample lines, 11-tap chroma): the one kernel
+            from the pixels exists for 1024-sample lines only, so new pictures go through hvk_k_prep8 + hvk_k_direct there."""
+            ex = H.Engine(H.preset("m", H.FLAG_FILTER | H.FLAG_NOAUDIO), 13500000, device=local_rank, max_frames=Fm)
+            ex.set_stream(ctypes.c_void_p(stream.cuda_stream))
+            ex.set_levels(levels)
+            base = g.frame("m_full")
+            rr = np.random.default_rng(2)
+            for i in range(Fm):
+                pic = np.roll(base, 13 * i, axis=1)
+                if levels == 2:
+                    pic = (pic ^ (rr.integers(0, 4, base.shape, dtype=np.uint32) * np.uint32(0x010101))).astype(np.uint32)     # (low-bit noise: many colours)
+                ex.frame_upload(i, pic)
+            fsm = ex.info["frame_samples"]
+            outm_m = torch.empty((Fm * fsm * 2,), dtype=torch.int16, device=dev)
+            nxt = [0]
+
+            def one():
+                ex.planes_refresh(slots); ex.stage(nxt[0] * Fm, 1, Fm, slots=slots); ex.launch(ctypes.c_void_p(outm_m.data_ptr()))
+                nxt[0] += 1
+            dt_ = time_steps(one, torch.cuda.synchronize, 2, ksteps * 2)
+            names_m = ex.kernel_names()
+            ex.close()
+            return round(Fm * fsm / dt_ / 1e6, 1), names_m
+
+        np_m_tab, names_m = new_pictures_m(1)
+        np_m_cmp, _ = new_pictures_m(2)
         np_tab_f, nf1 = new_pictures(1, True, True)
         np_tab_p, _ = new_pictures(1, False, True)
         np_cmp_f, nf2 = new_pictures(2, True, False)
@@ -1006,6 +1035,9 @@ def main():
                 "table_levels_Msamples_per_s": max(np_tab_f, np_tab_p), "computed_levels_Msamples_per_s": max(np_cmp_f, np_cmp_p),
                 "one_kernel_from_the_pixels": {"table_levels": np_tab_f, "computed_levels": np_cmp_f, "kernel": "hvk_k_fused<13, LV>", "launches_that_way": [nf1, nf2]},
                 "through_picture_planes": {"table_levels": np_tab_p, "computed_levels": np_cmp_p, "kernels": "hvk_k_prep8<13, 1024, LV> + hvk_k_direct"},
+                "ntsc_m": {"table_levels_Msamples_per_s": np_m_tab, "computed_levels_Msamples_per_s": np_m_cmp, "kernels": "hvk_k_prep8<11, 0, LV> + " + names_m[-1],
+                           "workload": "-m m -s 13500000 --filter --noaudio (BASELINE config 3's geometry: 858-sample lines), %d new pictures per step; through the picture planes: "
+                                       "the one kernel from the pixels (hvk_k_fused) is 1024 samples a line" % Fm},
                 "note": "%d pictures resident in HBM, every one NEW in every step (hvk_planes_refresh): table levels = shifted test cards (few colours: the 2^24-entry "
                         "level table serves from cache), computed levels = gradients + noise (levels by FP64 arithmetic per pixel). The engine takes the one kernel "
                         "by itself for a block whose pictures are mostly new (HVK_FUSED unset); the first figure of each pair is the faster of the two ways" % Fm,
@@ -1216,6 +1248,7 @@ def main():
         also = {
             "new_pictures_every_frame_table_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "table_levels_Msamples_per_s"),
             "new_pictures_every_frame_computed_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "computed_levels_Msamples_per_s"),
+            "new_pictures_every_frame_ntsc_m_table_levels_Msamples_per_s": _g(moving, "new_pictures_every_frame", "ntsc_m", "table_levels_Msamples_per_s"),
             "secam_l_test_card_Msamples_per_s": _g(secam, "Msamples_per_s"),
             "secam_l_pictures_change_every_frame_Msamples_per_s": _g(secam, "pictures_change_every_frame", "Msamples_per_s"),
             "secam_l_new_picture_every_frame_planes_too_Msamples_per_s": _g(secam, "new_picture_every_frame", "Msamples_per_s"),

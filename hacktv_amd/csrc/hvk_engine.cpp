@@ -206,9 +206,6 @@ struct hvk_engine {
 	hipEvent_t ev_staged;       /* after the last host-to-device copy of a stage: the pinned side buffers are free again */
 	int staged_busy;
 	hipEvent_t fetch_ev[HVK_FETCH_TICKETS];   /* hvk_fetch_async() */
-	hipStream_t copy_stream;                  /* a large read-back goes out in two halves, this stream's beside the engine's own: two DMA engines, one PCIe link */
-	hipEvent_t copy_fork, copy_join;
-	size_t copy_split;                        /* bytes from which on a read-back is split (HVK_FETCH_SPLIT_MB, 0: never) */
 	int fetch_busy[HVK_FETCH_TICKETS];        /* handed out and not waited for yet */
 	int fetch_next;
 
@@ -727,10 +724,6 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	}
 	OPENHIP(hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
 	for(int i = 0; i < HVK_FETCH_TICKETS; i++) OPENHIP(hipEventCreateWithFlags(&e->fetch_ev[i], hipEventDisableTiming));
-	OPENHIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-	OPENHIP(hipEventCreateWithFlags(&e->copy_fork, hipEventDisableTiming));
-	OPENHIP(hipEventCreateWithFlags(&e->copy_join, hipEventDisableTiming));
-	e->copy_split = (size_t) (getenv("HVK_FETCH_SPLIT_MB") ? atoi(getenv("HVK_FETCH_SPLIT_MB")) : 16) << 20;
 
 	if(e->t.k.has_carriers)
 	{
@@ -1087,9 +1080,6 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->prep_stream) { (void) hipStreamSynchronize(e->prep_stream); (void) hipStreamDestroy(e->prep_stream); }
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
 		if(e->h_svrec) (void) hipHostFree(e->h_svrec);
-		if(e->copy_stream) { (void) hipStreamSynchronize(e->copy_stream); (void) hipStreamDestroy(e->copy_stream); }
-		if(e->copy_fork) (void) hipEventDestroy(e->copy_fork);
-		if(e->copy_join) (void) hipEventDestroy(e->copy_join);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_sis_bits, e->h_secam_rows, e->h_frec };
 		for(void *p : host) if(p) (void) hipHostFree(p);
 		if(e->own_stream) (void) hipStreamDestroy(e->own_stream);
@@ -2973,18 +2963,8 @@ extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_
 		int r = hvk_fetch(e, iq, first, count);
 		if(r != HVK_OK) return(r);
 	}
-	else if(e->copy_split && count * 4 >= e->copy_split)
-	{
-		/* One copy engine moves about 27 GB/s of a read-back, the link twice that: the second half goes out on a stream of
-		 * its own, behind everything queued so far, and the engine's stream goes on when both are through */
-		const size_t h = (count / 2) & ~(size_t) 1023;
-		HIPCHK(hipEventRecord(e->copy_fork, e->stream));
-		HIPCHK(hipStreamWaitEvent(e->copy_stream, e->copy_fork, 0));
-		HIPCHK(hipMemcpyAsync(iq + h * 2, e->d_out + (first + h) * 2, (count - h) * 4, hipMemcpyDeviceToHost, e->copy_stream));
-		HIPCHK(hipEventRecord(e->copy_join, e->copy_stream));
-		HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, h * 4, hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipStreamWaitEvent(e->stream, e->copy_join, 0));
-	}
+	/* (one copy moves a block at the link's rate -- 56 GB/s, profiles/r05_d2h_speed.txt; in two halves on two streams it is no
+	 * faster. What halves the rate is the FIRST copy into a fresh page-locked buffer: a caller keeps its buffers) */
 	else HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
 	HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
 	e->fetch_busy[t] = 1;
@@ -3149,6 +3129,35 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	const int mf = (vnt == 51 && e->d_mfma_a) ? 1 : 0;
 	snprintf(buf, n, "hvk_k_raster<%d, %d, %d, %d, %d, %d>;%shvk_k_filter<%d, %d, %d, %d, %d>", nt, k.secam ? 1 : 0, sv, extras, wc, lv,
 	         k.rs_L ? "hvk_k_resample;" : "", vnt, k.vf_type, sv, exact, mf);
+	return(HVK_OK);
+}
+
+/* The same with everything beside the per-launch kernels: what runs once per uploaded picture, once per staged block, per
+ * launch, behind it -- one line per stage, "when: kernels [(condition)]" (tools/kernel_table.py makes DESIGN.md's table of it) */
+extern "C" int hvk_kernel_plan(const hvk_engine_t *e, char *buf, int n)
+{
+	if(!e || !buf || n < 1) return(HVK_ERROR);
+	const hvk_kconst_t &k = e->t.k;
+	char launch[512];
+	int r = hvk_kernel_names(e, launch, (int) sizeof(launch));
+	if(r != HVK_OK) return(r);
+	for(char *p = launch; *p; p++) if(*p == ';') *p = '+';
+	const int nt = k.secam ? 1 : (k.colour ? k.chroma_ntaps : 1);
+	int o = 0;
+	buf[0] = 0;
+#define PLAN(...) do { if(o < n) o += snprintf(buf + o, (size_t) (n - o), __VA_ARGS__); } while(0)
+	if(e->direct) PLAN("per uploaded picture: hvk_k_prep8<%d, %d, LV%s> (picture planes; LV 0 table levels, 1-3 computed)\n", nt, (nt == 13 && k.width == 1024) ? 1024 : 0, k.secam ? ", 1" : "");
+	if(k.secam && e->secam_dev)
+		PLAN("per staged block: hvk_k_secam_cells (a picture's cells once per slot and parity) + hvk_k_secam_est (new pictures' entry states) + hvk_k_secam_walk<%s> (one line per lane; hvk_k_secam_chain where warm-up lines are walked) + hvk_k_secam_check [+ hvk_k_secam_redo / _redo_fields] + hvk_k_secam_carry\n",
+		     e->secam_walk_ok == 2 ? "0 | 1" : "0");
+	else if(k.secam) PLAN("per staged block: the host's serial colour chain (hvk_secam.c)\n");
+	PLAN("per launch: %s\n", launch);
+	if(e->fused_ok) PLAN("per launch of a block of mostly NEW pictures: hvk_k_fused<%d, LV> instead (from the pixels, no planes)\n", nt);
+	if(k.sv_ring) PLAN("per launch, between resampler and filter: hvk_k_svq (the Q channel line by line: the reference's ring of line buffers)\n");
+	if(!k.fm_video && (k.swap_iq || k.has_offset || k.has_passthru)) PLAN("behind it: hvk_k_tail<%d, %d, %d>\n", k.swap_iq ? 1 : 0, k.has_offset ? 1 : 0, k.has_passthru ? 1 : 0);
+	if(k.fm_video) PLAN("behind it: the FM video phasor on the host (hvk_tail.c; behind hvk_fetch_async() on the engine's thread)\n");
+	if(k.has_carriers || k.has_nicam) PLAN("side inputs per staged block: the sound carriers' serial chain and the NICAM framing on the host (hvk_audio.c)\n");
+#undef PLAN
 	return(HVK_OK);
 }
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
     "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages", "hvk_levels_short_form",
-    "hvk_sound_source_end", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block",
+    "hvk_sound_source_end", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block", "hvk_kernel_plan",
 ]
 
 _lib = None
@@ -154,6 +154,7 @@ def lib():
         L.hvk_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
         L.hvk_secam_walk_stages.argtypes = [vp, vp]
         L.hvk_teletext_packets_block.argtypes = [vp, i32, i32, vp, vp]
+        L.hvk_kernel_plan.argtypes = [vp, C.c_char_p, i32]
         _lib = L
     return _lib
 
@@ -245,7 +246,7 @@ class Engine:
         p = np.ascontiguousarray(packets, np.uint8)
         m = np.ascontiguousarray(masks, np.uint32)
         assert p.ndim == 3 and p.shape[1:] == (32, 45) and m.shape == (p.shape[0],)
-        return self._chk("hvk_teletext_packets_block", lib().hvk_teletext_packets_block(self.h, first_frame_in_batch, p.shape[0], p.ctypes.data, m.ctypes.data))
+        return self._chk("hvk_teletext_packets_block", "hvk_kernel_plan", lib().hvk_teletext_packets_block(self.h, first_frame_in_batch, p.shape[0], p.ctypes.data, m.ctypes.data))
 
     def line_widths(self, first_line, nlines):
         w = np.zeros(nlines, np.int32)
@@ -318,6 +319,11 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._chk("hvk_secam_stats", lib().hvk_secam_stats(self.h, c))
         return dict(zip(("tasks", "mismatches", "redone", "host_frames"), list(c)))
+
+    def kernel_plan(self):
+        buf = C.create_string_buffer(4096)
+        self._chk("hvk_kernel_plan", lib().hvk_kernel_plan(self.h, buf, len(buf)))
+        return buf.value.decode()
 
     def secam_walk_stages(self):
         """(what hvk_open() allows: 0 / 1 / 2, [stages through hvk_k_secam_chain, hvk_k_secam_walk<0>, hvk_k_secam_walk<1>])"""

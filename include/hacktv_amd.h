@@ -451,6 +451,8 @@ int hvk_timing_enable(hvk_engine_t *e, int on);
  * [; resampler] ; filter. With one kernel hvk_timing_read() reports its time as kernel 1 and nothing
  * for kernel 0. */
 int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n);
+/* ... and the whole plan: what runs per uploaded picture, per staged block, per launch and behind it, one line each. */
+int hvk_kernel_plan(const hvk_engine_t *e, char *buf, int n);
 int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64_t *launches);
 
 /* ---- host tables (for parity tests): same names as the oracle's ---- */
