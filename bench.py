@@ -901,6 +901,7 @@ def main():
         while e.audio_needed(nxt + F) > 0:
             e.audio_write(g.audio)
         e.stage(nxt, 1, F)
+        e.sync()                    # (the side inputs' copies to the device are part of the stage, not of the render: 328 MB of carriers over the same link)
         t1 = time.perf_counter()
         e.launch()
         e.fetch_wait(e.fetch_async(host_out, 0, F * FS))
@@ -909,7 +910,8 @@ def main():
                "Msamples_per_s": round(F * FS / (t2 - t0) / 1e6, 1),
                "render_and_d2h_Msamples_per_s": round(F * FS / (t2 - t1) / 1e6, 1),
                "note": "one fresh block, nothing overlapped: host audio control path (the serial FM phasor chain, one core) + H2D of the "
-                       "side inputs, then render + D2H of the int16 IQ into pinned host memory; the PCIe-inclusive rate, never `value`"}
+                       "side inputs (waited for: stage_s), then render + D2H of the int16 IQ into page-locked host memory that has been written to before "
+                       "(render_and_d2h_s: the link's 56 GB/s; rounds 3-4 counted the tail of the side inputs' H2D in it); the PCIe-inclusive rate, never `value`"}
 
     # ---- pictures that change every frame (the 7 B/sample regime): F new pictures per step, uploaded
     # inside the timed loop (pinned ring, asynchronous copies), --noaudio so that the serial sound pre-pass does not

@@ -20,226 +20,7 @@
  * off / pass (offset phasor, passthru samples), chroma (SECAM), vbi_sym / vbi_val / ops / map
  * (VBI data lines), vits tables. DESIGN.md section 2 has the sizes.
  */
-#include <hip/hip_runtime.h>
-#include <stdlib.h>
-#include <string.h>
-#include <stdio.h>
-#include <vector>
-#include <algorithm>
-#include <deque>
-#include <thread>
-#include <mutex>
-#include <condition_variable>
-#include "hvk_internal.h"
-#include "hvk_kernels.h"
-
-#define HVK_VERSION "hacktv-amd 0.1 (gfx950)"
-#define HVK_MIN_FRAME_SLOTS 4
-#define HVK_MAX_FRAME_SLOTS 1024
-#define HVK_TIMING_SLOTS 512
-#define HVK_UPLOAD_RING 8
-#define HVK_FETCH_TICKETS 4
-#define HVK_POOL_PAD 4096
-#define HVK_PREP_EVENTS 8
-
-extern "C" {
-int hvk_audio_symbol_info(const hvk_audio_t *a, int64_t m, int64_t *k, int64_t *start);
-}
-
-struct hvk_slot_t {
-	int valid;
-	int width, height;      /* after the centre crop */
-	int interlaced;
-	int64_t par_num, par_den;   /* pixel aspect of the source frame (hvk_frame_aspect), 1:1 unless told */
-	int many_colours;           /* a sample of its pixels shows more colours than the level table serves from cache */
-	int plane_dirty;            /* the picture planes (hvk_direct.hip) have not been made from this picture yet */
-	int shown;                  /* ... although a block has shown it already (from the pixels, hvk_fused.hip): it stays, so its planes are worth making now */
-	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
-	int seeds_valid[6];         /* SECAM: the picture has been shown with this frame number modulo 6: its lines' entry states are kept */
-};
-
-struct hvk_engine {
-	hvk_tables_t t;
-	hvk_audio_t *audio;
-	hvk_secam_t *secam;
-	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
-	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
-	int16_t *d_chroma, *h_chroma;
-	signed char *chroma_par;    /* [max_frames] the frame parity the slab's rows were last written with by the device's chain (-1: clear before use) */
-	int16_t *d_chroma_alloc;    /* (d_chroma lies 64 entries inside it: a lane of hvk_k_direct whose 8 samples straddle the start of a frame's first line reads up to 7 entries in front) */
-	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
-	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
-	hvk_secam_args_t sa;
-	void *d_secam[19];          /* what sa points into (freed at close) */
-	int secam_walk_ok;          /* 1: hvk_k_secam_walk<0> may be taken; 2: its computed FM steps and decoded gains equal the tables' on every index (tried at open) */
-	int secam_walk_mode;        /* HVK_SECAM_WALK: -1 the engine's choice per stage, 0 the chain kernel, 1 / 2 hvk_k_secam_walk<0 / 1> */
-	int64_t secam_walk_stages[3];   /* stages that went through the chain kernel / hvk_k_secam_walk<0> / <1> */
-	int secam_est_ran, secam_ek_adapt, secam_ek_base, secam_ek_clean;      /* this stage ran the estimate; its reach (a.EK) follows the blocks */
-	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
-	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
-	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
-	int secam_seeds;            /* warm-ups start from the states the picture's lines had the last time (kept per row) */
-	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
-	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */
-	int *h_secam_count;         /* pinned: failures of the last check */
-	int secam_lanes;            /* lanes of eight waves per SIMD */
-	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
-	int secam_clean, secam_patience;    /* batches without a wrong start in a row; how many of them before a line less is tried */
-	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
-	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
-	int64_t secam_counts[4];
-	int32_t *staged_slots2;     /* [max_frames] the slot of the second field's picture */
-	uint32_t *h_tt_pk;          /* teletext packets queued for the next batch: [max_frames][32][12] */
-	uint32_t *h_tt_mask;        /* [max_frames] rows present */
-	/* VBI data lines (teletext, WSS, VITC): symbol store, per-frame op list and line map */
-	void *d_vbi_sym, *d_vbi_val;
-	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
-	int8_t *d_map, *h_map;      /* [max_frames][lines] */
-	void *d_vits_l, *d_vits_c, *d_fsc_rows;
-	void *d_sis_dense, *d_sis_win, *d_sis_first;    /* sound-in-syncs tables */
-	uint32_t *d_sis_bits, *h_sis_bits;              /* [max_frames][lines][2]: the lines' bursts */
-	/* --raw-bb-file: queued stream (raw_q[0] is sample raw_base) and its per-batch slab */
-	std::vector<int16_t> *raw_q; int64_t raw_base;
-	int16_t *d_raw, *h_raw;
-	uint8_t *cc_pairs;          /* CC608: [max_frames][3] { present, c1, c2 } queued for the next batch */
-	hvk_packed_taps_t notch;
-	hvk_tail_t *tail;           /* FM video / offset / passthru serial state (hvk_tail.c) */
-	int16_t *d_off, *h_off;     /* offset phasor side stream, int16 pairs */
-	int16_t *d_pass, *h_pass;   /* passthru samples, int16 pairs */
-	int16_t *h_fm;              /* FM video: the batch's modulated samples (host) */
-	int64_t fm_batch_pos;       /* output position of the staged batch's first sample */
-	size_t fm_done;             /* samples of the batch modulated so far */
-	size_t fm_async_upto;       /*   ... of which these went through the FM thread into a caller's buffer (not into h_fm) */
-	int fm_launched;            /* the staged batch has been rendered and is not fully modulated yet */
-	/* FM video behind hvk_fetch_async(): the read-back goes straight into the caller's buffer and a thread of the engine's
-	 * runs the phasor over it there, job after job in stream order; hvk_fetch_wait() waits for the job */
-	struct fm_job_t { int ticket; int64_t pos, count; int16_t *iq; hipEvent_t ev; };
-	std::thread *fm_thread;
-	std::mutex *fm_mu;
-	std::condition_variable *fm_cv;
-	std::deque<fm_job_t> *fm_q;
-	int fm_quit;
-	int fm_status[4];           /* [HVK_FETCH_TICKETS] */
-	int fm_prime_pending;       /* FM video with the video filter: the phasor has yet to run over the pipeline's start-up samples */
-	int16_t *fm_prime_car;      /*   their sound carrier samples (out_prime int16 pairs) */
-	int device;             /* -1: host tables only */
-	int max_frames;
-	int frame_slots;
-	int symbol_stride;
-	hipStream_t stream;         /* stream in use */
-	hipStream_t own_stream;
-
-	/* constant tables */
-	void *d_yuv, *d_yuvparams, *d_desc, *d_pulses, *d_linebase, *d_clut, *d_burst, *d_ghost, *d_tapd, *d_cca;
-	int levels_mode;            /* HVK_LEVELS_AUTO / _TABLE / _COMPUTE (hvk_set_levels) */
-	int levels_computed;        /* what the staged block uses */
-	void *d_mfma_a;             /* video filter taps as the A operand of v_mfma_i32_16x16x64_i8 (NULL: taps out of its range) */
-	void *d_mfma_a28;           /* ... for hvk_k_fused's window (28 samples of lead) */
-	int fused_ok;               /* this configuration can render from the pixels in one kernel (hvk_fused.hip) */
-	int fused_mode;             /* HVK_FUSED: 0 never, 1 always, unset (-1): when at least half of a block's pictures are new */
-	int64_t fused_count;        /* launches that went that way */
-	int mfma_ci, mfma_cq;
-	/* per batch */
-	uint32_t *d_pool;
-	uint32_t *d_pool_alloc;     /* (d_pool lies HVK_POOL_PAD pixels inside it and as many lie behind the slots: hvk_k_prep's lanes read the 8 pixels
-	                             * under their 8 samples wherever the line's picture begins and ends, and keep what is picture) */
-	hvk_framedesc_t *d_fdesc;   /* [max_frames][1 + fields]: the frame before (only its last line is looked at:
-	                             * the halo line in front), then one descriptor per field */
-	/* the last line's source row of the last frame staged, kept behind the slots: the next batch's first halo */
-	hvk_framedesc_t carry; int carry_valid; int64_t carry_frame;
-	int carry_row;              /* which of the two kept rows `carry` points at: the batch being staged reads one while the other is written */
-	int16_t *d_S;
-	int16_t *d_C;           /* --s-video: the sub-carrier slab */
-	int16_t *d_C2;          /* --s-video with --pixelrate: the resampled sub-carrier (the resampler's second channel) */
-	/* ... where the lines have two widths and the video filter is on (hvk_kconst_t.sv_ring): the Q channel made line by line
-	 * the way the reference's ring of line buffers pairs it (hvk_k_svq) */
-	int16_t *d_C2_alloc;    /* d_C2 lies sv_hist samples inside it: the end of the batch before's stream, kept in front of this batch's */
-	int16_t *d_Cq;          /* what the filter kernel reads as Q */
-	int *h_svrec, *d_svrec; /* [max_frames * lines][4] per emitted line: first sample in the batch, width | delta << 16 | kind << 20, source of the last sample */
-	int sv_hist;
-	int64_t sv_tail_first, sv_tail_total;   /* the batch whose sub-carrier stream lies in d_C2 (first frame; -1: none), its samples */
-	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
-	int16_t *d_car;
-	int32_t *d_sym;
-	int32_t *d_tile;
-	int16_t *d_out;
-	void *d_conv; size_t conv_bytes;   /* hvk_fetch_as scratch */
-	void *d_sums;               /* hvk_block_sums(): two 64-bit sums */
-
-	/* pinned staging */
-	hvk_framedesc_t *h_fdesc;
-	int16_t *h_car;
-	int32_t *h_sym;
-	int32_t *h_tile;
-	uint8_t *sym_tmp;
-	int tiles;                  /* NICAM symbol rows per frame: one per filter tile */
-	int direct;                 /* this configuration renders in one kernel from picture planes (hvk_direct.hip) */
-	int last_direct;            /* the last launch did: the raster slab in HBM was not written */
-	/* picture planes: [plane_rows][width] each, 16 entries of slack in front; rows: lines per frame slot, two kept
-	 * last lines (the halo of the next batch's first frame, 525-line modes), a row of zeros */
-	int *d_UVp;                 /* SECAM: the pictures' colour-difference levels, laid out like d_Cp (hvk_k_prep writes them, hvk_k_secam_cells reads them) */
-	int16_t *d_Lp; int *d_Cp; int *d_clut3; uint32_t *d_lineoff; uint32_t inv_w;
-	void *d_tilerec; int tiles_pad;     /* hvk_tilerec_t [2][tiles_pad] */
-	int plane_rows, plane_carry_row, plane_zero_row, clut_reg;
-	/* ... and behind them, per frame of a batch, a row for every line the optional stages (VBI data, test signals) can
-	 * write to: rendered whole by the raster kernel per frame, taken by hvk_k_direct instead of the planes' rows */
-	int ovr_n, ovr_row0;
-	int16_t *d_ovr_list, *d_ovr_idx;
-	/* The planes of the pictures a staged block shows for the first time are made when the block is LAUNCHED, a chunk of
-	 * frames at a time on a stream of their own, each chunk's render behind its planes: hvk_k_prep of chunk c + 1 runs
-	 * beside hvk_k_direct of chunk c (one is bound by memory latency, the other by vector issue), and a chunk's planes
-	 * are read back while they still lie in the 256 MiB Infinity Cache */
-	hipStream_t prep_stream;
-	hipEvent_t ev_fork, ev_prep[HVK_PREP_EVENTS];
-	int prep_chunk;             /* frames per chunk (HVK_PREP_CHUNK) */
-	int prep_streams;           /* 2: the planes on a stream of their own (HVK_PREP_STREAMS) */
-	int prep_pending;           /* the staged block's planes have not been made yet */
-	int32_t *staged_prev;       /* [max_frames] the slot the caller named for the frame before (hvk_stage_strided_prev), -1: none */
-	int carry_copy_pending; size_t carry_from, carry_to;    /* the staged block's last plane row has yet to be kept (525 lines) */
-	int64_t prep_count;         /* pictures the planes were made from so far */
-	/* pinned staging for source frames: a small ring, each buffer guarded by an event recorded behind its copy, so that
-	 * hvk_frame_upload() waits for the copy that last used THAT buffer only -- never for the stream */
-	uint32_t *h_frame[HVK_UPLOAD_RING];
-	hipEvent_t up_ev[HVK_UPLOAD_RING];
-	int up_busy[HVK_UPLOAD_RING];
-	int up_next;
-	hipEvent_t ev_staged;       /* after the last host-to-device copy of a stage: the pinned side buffers are free again */
-	int staged_busy;
-	hipEvent_t fetch_ev[HVK_FETCH_TICKETS];   /* hvk_fetch_async() */
-	int fetch_busy[HVK_FETCH_TICKETS];        /* handed out and not waited for yet */
-	int fetch_next;
-
-	hvk_slot_t *slots;          /* [frame_slots] */
-	hvk_packed_taps_t ctaps, itaps, qtaps;
-
-	int64_t next_frame;
-	int staged;             /* frames staged for the next launch */
-	int64_t staged_samples, last_samples;   /* output samples of the staged / the last launched batch (frames x frame_samples; frames of two lengths: what they add up to) */
-	int *h_frec, *d_frec;   /* [max_frames][2] --pixelrate with frames of two lengths: hvk_k_resample's per-frame record */
-	int32_t *staged_slots;  /* [max_frames] the slot each of them shows */
-	int64_t staged_first, staged_stride;
-	int last_frames;        /* frames of the last launch (for fetch) */
-	int ghost_dirty;
-	int poisoned;           /* a stage failed after the serial chains had moved on: the stream is out of step, nothing more is rendered */
-
-	/* kernel timing with HIP events on the engine's stream */
-	int timing;
-	hipEvent_t ev[HVK_TIMING_SLOTS][3];
-	int ev_used;
-	double t_sum[2];
-	int64_t t_n[2];
-};
-
-static void _fm_worker(hvk_engine *e);
-
-
-/* ... after the serial chains have moved on for a batch: the failure leaves the stream out of step for good */
-#define HIPCHK_P(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
-	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-	e->poisoned = 1; return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
-#define HIPCHK(call) do { hipError_t _e = (call); if(_e != hipSuccess) { \
-	fprintf(stderr, "libhvk: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-	return(_e == hipErrorOutOfMemory ? HVK_OUT_OF_MEMORY : HVK_ERROR); } } while(0)
+#include "hvk_engine_priv.h"
 
 /* The video filter as a matrix product (hvk_k_filter, MF = 1). Eight consecutive outputs of a
  * segment and both channels make the 16 rows of A, 64 window positions its columns:
@@ -290,9 +71,6 @@ static void _pack_taps(hvk_packed_taps_t *p, const int16_t *taps, int ntaps)
 		p->p[k / 2] |= (k & 1) ? ((int) taps[k] << 16) : ((int) taps[k] & 0xFFFF);
 	}
 }
-
-/* first output sample of stream frame f (frames of two lengths with some --pixelrate pairs: hvk_tables.c) */
-static inline int64_t _fstart(const hvk_engine *e, int64_t f) { return(hvk_tables_frame_start(&e->t, f)); }
 
 static int _upload(void **dst, const void *src, size_t bytes)
 {
@@ -1026,7 +804,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			e->fm_mu = new std::mutex;
 			e->fm_cv = new std::condition_variable;
 			e->fm_q = new std::deque<hvk_engine::fm_job_t>;
-			e->fm_thread = new std::thread(_fm_worker, e);
+			e->fm_thread = new std::thread(hvk_e_fm_worker, e);
 		}
 	}
 	else
@@ -1564,224 +1342,6 @@ extern "C" int hvk_secam_warmup_lines(hvk_engine_t *e)
 	if(!e->secam || !e->secam_dev) return(HVK_UNSUPPORTED);
 	return(e->sa.K);
 }
-
-/* ---- render ---- */
-
-/* The VBI data lines of the staged frames (h_fdesc holds their stream frame numbers): per
- * frame a list of ops -- which symbol table, how many bits, the bits -- and a line -> op map.
- * Ops of one line are chained in the reference's process order WSS, ACP, VITC, CC608, teletext
- * (src/video.c:4234-4358). Of the inserters only ACP and teletext yield to a line that is
- * already held (vbialloc, src/acp.c:108, src/teletext.c:1219): ACP's test is done here,
- * teletext's is the caller's business -- it decides which rows carry packets. */
-static void _build_vbi_ops(hvk_engine *e, int nframes)
-{
-	const hvk_tables_t &t = e->t;
-	const int lines = t.k.lines;
-
-	memset(e->h_map, 0xFF, (size_t) nframes * lines);
-	memset(e->h_ops, 0, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4);
-
-	for(int i = 0; i < nframes; i++)
-	{
-		uint32_t *ops = e->h_ops + (size_t) i * HVK_VBI_OPS * HVK_VBI_OPWORDS;
-		int8_t *map = e->h_map + (size_t) i * lines;
-		int n = 0;
-
-		/* hang op n on its line: the first op goes into the map, later ones behind the line's last op
-		 * (op word 0: symbol base | (next op + 1) << 16) */
-		auto link = [&](int line0)
-		{
-			if(map[line0] < 0) { map[line0] = (int8_t) n; return; }
-			uint32_t *last = ops + (size_t) map[line0] * HVK_VBI_OPWORDS;
-			while(last[0] >> 16) last = ops + (size_t) ((last[0] >> 16) - 1) * HVK_VBI_OPWORDS;
-			last[0] |= (uint32_t) (n + 1) << 16;
-		};
-
-		auto add = [&](int line0, int lut, int first_symbol, int nbits, const uint8_t *lsb_first_bits, int blank_lo, int blank_hi)
-		{
-			if(n >= HVK_VBI_OPS || line0 < 0 || line0 >= lines) return;
-			if(nbits > t.lut_nsym[lut] - first_symbol) nbits = t.lut_nsym[lut] - first_symbol;   /* the table's end stops the render */
-			if(nbits > 384) nbits = 384;
-			uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
-			uint8_t bytes[48] = { 0 };
-			if(nbits < 0) nbits = 0;
-			memcpy(bytes, lsb_first_bits, (nbits + 7) / 8);
-			op[0] = (uint32_t) (t.lut_base[lut] + first_symbol);
-			op[1] = (uint32_t) nbits;
-			op[2] = (uint32_t) blank_lo | ((uint32_t) blank_hi << 16);
-			memcpy(op + 4, bytes, 48);
-			link(line0);
-			n++;
-		};
-
-		if(t.conf.wss)
-		{
-			/* line 23; the table's bits are MSB first (src/wss.c:184) */
-			uint8_t rev[18], bits[18];
-			const hvk_slot_t &sl = e->slots[e->staged_slots[i]];
-			hvk_wss_bits(&t, sl.par_den ? sl.par_num : 1, sl.par_den ? sl.par_den : 1, bits);
-			for(int b = 0; b < 18; b++)
-			{
-				uint8_t v = bits[b], r = 0;
-				for(int q = 0; q < 8; q++) if(v & (1 << q)) r |= 0x80 >> q;
-				rev[b] = r;
-			}
-			add(22, 1, 0, 137, rev, t.wss_blank_lo, t.wss_blank_hi > t.wss_blank_lo ? t.wss_blank_hi : t.wss_blank_lo);
-		}
-
-		if(t.conf.acp)
-		{
-			/* six P-sync / AGC pulse pairs on ten lines per field (eight on 525 lines), except where the line
-			 * is held already (src/acp.c:93-108): by VITS, or by SECAM's colour process, which marks its field
-			 * identification lines (src/video.c:3101-3103, :3135); the AGC level moves with the frame number */
-			const int frame = (int) (e->h_fdesc[(size_t) i * (t.k.fields + 1) + 1].frame_index + 1);
-			const int agc = hvk_acp_agc_level(&t, frame);
-			const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
-			const int count = lines == 625 ? 10 : 8;
-			for(int fld = 0; fld < 2; fld++)
-			{
-				for(int l = first[fld]; l < first[fld] + count; l++)
-				{
-					bool vits = false;
-					for(int q = 0; q < t.k.vits; q++) if(t.k.vits_line[q] == l - 1) vits = true;
-					if(vits || (!t.conf.raw_bb && (t.desc[l - 1].secam_fid & 1)) || n >= HVK_VBI_OPS) continue;
-					uint32_t *op = ops + (size_t) n * HVK_VBI_OPWORDS;
-					op[0] = 0;
-					op[1] = 1u << 16;       /* mode 1: assign list */
-					op[2] = 0;
-					op[3] = ((uint32_t) t.acp_psync_level & 0xFFFF) | ((uint32_t) agc << 16);
-					for(int q = 0; q < 6; q++)
-					{
-						const uint32_t a = t.acp_left[q], b = a + t.acp_psync_width, c = b + t.acp_pagc_width;
-						op[4 + q * 2 + 0] = a | (b << 16);
-						op[4 + q * 2 + 1] = b | (c << 16);
-					}
-					link(l - 1);
-					n++;
-				}
-			}
-		}
-
-		if(t.conf.vitc)
-		{
-			const int frame = (int) (e->h_fdesc[(size_t) i * (t.k.fields + 1) + 1].frame_index + 1);
-			const int vl[4] = { t.vitc_lines[0], t.vitc_lines[0] + 2, t.vitc_lines[1], t.vitc_lines[1] + 2 };
-			for(int q = 0; q < 4; q++)
-			{
-				uint8_t data[12];
-				const int nb = hvk_vitc_bits(&t, frame, vl[q], data);
-				add(vl[q] - 1, 2, 21, nb, data, 0, 0);      /* src/vitc.c:193: the first 21 symbols stay empty */
-			}
-		}
-
-		if(t.conf.cc608)
-		{
-			/* the frame's byte pair (zeros without one), 17 bits, and the clock run-in: symbol 32 of
-			 * the table, whose bit is always set (src/cc608.c:188-221) */
-			uint8_t bits[8] = { 0 };
-			const uint8_t *pr = e->cc_pairs + (size_t) i * 3;
-			hvk_cc608_bits(pr[0] ? pr[1] : 0, pr[0] ? pr[2] : 0, bits);
-			bits[2] &= 1;
-			bits[4] |= 1;           /* bit 32 */
-			add(t.cc608_line - 1, 3, 0, 33, bits, 0, 0);
-		}
-
-		if(t.k.teletext && e->h_tt_mask[i])
-		{
-			for(int r = 0; r < 32; r++)
-			{
-				if(!((e->h_tt_mask[i] >> r) & 1)) continue;
-				add(r < 16 ? 6 + r : 319 + r - 16, 0, 0, 360, (const uint8_t *) (e->h_tt_pk + ((size_t) i * 32 + r) * 12), 0, 0);
-			}
-		}
-	}
-}
-
-/* Which lines of a frame the inserters other than teletext write to -- the lines on which the reference's
- * vid_line_t.vbialloc is set by the time the teletext process sees them (src/teletext.c:1219; the processes run in the
- * order VITS, WSS, ACP, VITC, CC608, ..., teletext, src/video.c:4234-4358). From the same tables the op list above is
- * built from, so that a caller who schedules teletext packets (the shim) does not keep a list of its own. */
-extern "C" int hvk_vbi_lines_held(const hvk_engine_t *e, uint8_t *held, int nlines)
-{
-	if(!e || !held || nlines < e->t.k.lines) return(HVK_ERROR);
-	const hvk_tables_t &t = e->t;
-	const int lines = t.k.lines;
-	memset(held, 0, (size_t) nlines);
-	auto hold = [&](int line1) { if(line1 >= 1 && line1 <= lines) held[line1 - 1] = 1; };
-
-	for(int q = 0; q < t.k.vits; q++) hold(t.k.vits_line[q] + 1);
-	if(t.conf.wss) hold(23);
-	if(t.conf.acp)
-	{
-		const int first[2] = { lines == 625 ? 9 : 12, lines == 625 ? 321 : 275 };
-		const int count = lines == 625 ? 10 : 8;
-		for(int fld = 0; fld < 2; fld++) for(int l = first[fld]; l < first[fld] + count; l++) hold(l);
-	}
-	if(t.conf.vitc)
-	{
-		hold(t.vitc_lines[0]); hold(t.vitc_lines[0] + 2);
-		hold(t.vitc_lines[1]); hold(t.vitc_lines[1] + 2);
-	}
-	if(t.conf.cc608) hold(t.cc608_line);
-	/* SECAM field identification lines carry the sub-carrier ramp (src/video.c:3101-3103, :4132-4137); raw baseband has
-	 * no colour process to mark them (src/video.c:4180-4190) */
-	if(!t.conf.raw_bb) for(int l = 1; l <= lines; l++) if(t.desc[l - 1].secam_fid & 1) hold(l);
-	return(HVK_OK);
-}
-
-/* FM video: bring the host copy of the current batch up to `upto` samples -- fetch the
- * modulator's input from the device and run the serial tail over it (hvk_tail.c) */
-static void _fm_worker(hvk_engine *e)
-{
-	std::unique_lock<std::mutex> lk(*e->fm_mu);
-	(void) hipSetDevice(e->device);
-	for(;;)
-	{
-		e->fm_cv->wait(lk, [e] { return(e->fm_quit || !e->fm_q->empty()); });
-		if(e->fm_q->empty()) break;
-		const hvk_engine::fm_job_t j = e->fm_q->front();
-		lk.unlock();
-		int r = hipEventSynchronize(j.ev) == hipSuccess ? HVK_OK : HVK_ERROR;
-		if(r == HVK_OK) r = hvk_tail_fm_apply(e->tail, j.pos, j.count, j.iq);
-		lk.lock();
-		e->fm_status[j.ticket] = r;
-		if(r != HVK_OK) e->poisoned = 1;        /* the phasor did not run over these samples: every later job would be out of step */
-		e->fm_q->pop_front();           /* (behind the work: an empty queue means nothing is being worked on) */
-		e->fm_cv->notify_all();
-	}
-}
-
-/* every queued job through (what comes next works on the phasor itself) */
-static void _fm_wait_all(hvk_engine *e)
-{
-	if(!e->fm_thread) return;
-	std::unique_lock<std::mutex> lk(*e->fm_mu);
-	e->fm_cv->wait(lk, [e] { return(e->fm_q->empty()); });
-}
-
-static int _fm_upto(hvk_engine *e, size_t upto)
-{
-	_fm_wait_all(e);
-	if(upto <= e->fm_done) return(HVK_OK);
-	if(upto > (size_t) e->last_samples) return(HVK_ERROR);      /* (frames of two lengths: what the batch's frames add up to, not frames x the longer one) */
-	const size_t n = upto - e->fm_done;
-	HIPCHK(hipMemcpyAsync(e->h_fm + e->fm_done * 2, e->d_out + e->fm_done * 2, n * 4, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	int r = hvk_tail_fm_apply(e->tail, e->fm_batch_pos + (int64_t) e->fm_done, (int64_t) n, e->h_fm + e->fm_done * 2);
-	if(r != HVK_OK) return(r);
-	e->fm_done = upto;
-	return(HVK_OK);
-}
-
-/* ... and to its end, so that the phasor stands at the next batch's first sample */
-static int _fm_finish(hvk_engine *e)
-{
-	if(!e->fm_launched) return(HVK_OK);
-	int r = _fm_upto(e, (size_t) e->last_samples);
-	if(r == HVK_OK) e->fm_launched = 0;
-	return(r);
-}
-
 extern "C" int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsamples)
 {
 	if(!e) return(HVK_ERROR);
@@ -1810,1260 +1370,6 @@ extern "C" int hvk_host_fm_video(hvk_engine_t *e, int16_t *iq, int64_t count)
 	return(hvk_tail_fm_apply(e->tail, hvk_tail_fm_position(e->tail), count, iq));
 }
 
-static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots);
-static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride);
-
-extern "C" int hvk_stage_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots)
-{
-	return(_stage(e, first_frame, stride, nframes, slots, NULL));
-}
-
-extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
-{
-	return(_stage(e, first_frame, stride, nframes, slots, prev_slots));
-}
-
-/* SECAM: the sub-carrier of the staged frames on the device (hvk_secam.hip) -- every line at once from derived entry
- * states, then check / redo rounds until every line started from the state the line before it left. The frame
- * descriptors and pictures are on their way to the device (same stream). */
-static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t stream);
-
-static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
-{
-	const hvk_kconst_t &k = e->t.k;
-	hvk_secam_args_t &a = e->sa;
-	int r, rounds = 0;
-
-	a.nframes = nframes;
-	a.total = nframes * a.ntasks;
-	a.first_frame = first_frame;
-	a.fdesc = e->d_fdesc;
-	a.levels_computed = e->levels_computed;
-	a.yuvp = e->d_yuvparams;
-	a.uvp = NULL;
-	if(e->direct && e->d_UVp)
-	{
-		/* the staged pictures' planes now, not at the launch: the cells are made of them */
-		if((r = _prep_dirty(e, e->staged_slots, nframes, e->stream)) < 0) return(r);
-		a.uvp = e->d_UVp + 16;
-	}
-	/* A lane's walk is a chain of dependent operations: a SIMD interleaves a few waves of it for free (measured: 1156
-	 * waves on 1024 SIMDs take as long as 578). Longer runs per lane only when the batch has more lines than eight
-	 * waves per SIMD hold. */
-	a.R = (a.total + e->secam_lanes - 1) / e->secam_lanes;
-	if(a.R < 1) a.R = 1;
-	if(getenv("HVK_SECAM_RUN")) a.R = atoi(getenv("HVK_SECAM_RUN")) > 0 ? atoi(getenv("HVK_SECAM_RUN")) : 1;
-	a.nruns = (a.total + a.R - 1) / a.R;
-	e->secam_start = *e->h_secam_carry;
-
-	/* Which rows of the cell stores the frames read, and which of them are made now: a picture's cells depend on the
-	 * picture and on the parity of the frame's number only (which of the two colour-difference signals a line carries,
-	 * which picture rows a field shows), so a picture that stays has them made once per parity -- the per-picture
-	 * share of SECAM's work, as the picture planes are PAL's and NTSC's. (The list's last copy is through: every stage
-	 * ends with the check's count read back.) */
-	{
-		int *rows = e->h_secam_rows, *list = rows + e->max_frames, *kf = rows + 2 * e->max_frames, *srows = rows + 3 * e->max_frames;
-		a.ncells = 0;
-		for(int i = 0; i < nframes; i++)
-		{
-			kf[i] = e->secam_est ? -1 : HVK_SECAM_WARMUP;
-			srows[i] = 0;
-			if(!e->secam_cell_cache)
-			{
-				rows[i] = i * a.ntasks;
-				list[a.ncells++] = i;
-				continue;
-			}
-			const int slot = e->staged_slots[i];
-			const int parity = (int) ((first_frame + i + 1) & 1);
-			int fresh = 0;
-			rows[i] = (slot * 2 + parity) * a.ntasks;
-			if(!e->slots[slot].cells_valid[parity] || first_frame + i == 0)      /* (the stream's first frame has the two fill slots) */
-			{
-				list[a.ncells++] = i;
-				e->slots[slot].cells_valid[parity] = 1;
-				fresh = 1;
-			}
-			/* The states kept per row are those the picture's lines had the last time it was shown: good for a picture that
-			 * was here before, behind a frame that was here before. A new picture, and the frame behind one (its first
-			 * lines' warm-ups start in it), take the full number of warm-up lines; the others the number that follows how
-			 * the batches have gone (a.K) */
-			/* (what a line starts from also follows its sub-carrier's start phase, (frame * lines + line) mod 3: with the
-			 * parity, the frame's number modulo 6) */
-			const int ph6 = (int) ((first_frame + i + 1) % 6);
-			srows[i] = (slot * 6 + ph6) * a.ntasks;
-			if(!e->slots[slot].seeds_valid[ph6]) fresh = 1;
-			e->slots[slot].seeds_valid[ph6] = 1;
-			/* (while that number is still three or more the estimate is the cheaper start: a fifth of a walk instead of
-			 * three and more; the kept states take over below that) */
-			if(!fresh && !e->secam_last_new) kf[i] = (e->secam_est && a.K >= 3) ? -1 : a.K;
-			e->secam_last_new = fresh;
-		}
-		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
-	}
-
-	/* The chain writes every line on its task list whole and never another; the list follows the frame's parity. A slab
-	 * row that was last written with the same parity has nothing to clear (blocks of even length, one after the other:
-	 * none of them), the others are cleared in runs. */
-	for(int i = 0; i < nframes; )
-	{
-		int j = i;
-		while(j < nframes && e->chroma_par[j] != (signed char) ((first_frame + j + 1) & 1)) j++;
-		if(j > i) HIPCHK(hipMemsetAsync(e->d_chroma + (size_t) i * k.raster_samples, 0, (size_t) (j - i) * k.raster_samples * 2, e->stream));
-		for(int q = i; q < j; q++) e->chroma_par[q] = (signed char) ((first_frame + q + 1) & 1);
-		i = j + 1;
-	}
-	{
-		int want = a.kf == NULL;
-		for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
-		/* One line per lane and no warm-up line anywhere in the block (entry states estimated, or kept from the picture's
-		 * last showing): hvk_k_secam_walk. Its FM steps computed and its gains from LDS where the block shows pictures of many
-		 * colours -- their table reads would scatter over a cache line per sample --, both from the table otherwise (the
-		 * lines of a wave then read neighbouring entries) */
-		int walk = e->secam_walk_ok && a.R == 1;
-		if(a.kf == NULL) walk = walk && (a.est != NULL || a.K == 0);
-		else for(int i = 0; i < nframes && walk; i++) walk = e->h_secam_rows[2 * e->max_frames + i] <= 0;
-		if(walk)
-		{
-			int many = 0;
-			for(int i = 0; i < nframes && !many; i++) many = e->slots[e->staged_slots[i]].many_colours;
-			walk = (many && e->secam_walk_ok == 2) ? 2 : 1;
-			if(e->secam_walk_mode >= 0) walk = e->secam_walk_mode > e->secam_walk_ok ? e->secam_walk_ok : e->secam_walk_mode;
-		}
-		e->secam_walk_stages[walk]++;
-		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, walk, e->stream)) != HVK_OK) return(r);
-		if(e->secam_est && want) e->secam_est_stages++;
-		e->secam_est_ran = e->secam_est && want;
-	}
-	e->secam_counts[0] += a.total;
-
-	for(;;)
-	{
-		if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
-		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipStreamSynchronize(e->stream));
-		const int bad = *e->h_secam_count;
-		if(rounds == 0 && e->secam_adapt && !(e->secam_est && a.kf == NULL))     /* (no kept states and the estimate for every line: no warm-up length to follow) */
-		{
-			/* How many warm-up lines a start state needs depends on the pictures and costs a walk each. Exactness never
-			 * rests on it -- the check does -- so the number follows what the batches show, carefully: a wrong start costs
-			 * a redo round, which is dearer than the walk it saved. One line fewer after a run of clean batches (a run
-			 * twice as long after every attempt that failed), two more as soon as anything fails. With the lines' states
-			 * kept from the picture's last showing (a.seed) a picture that stays ends at NO warm-up line: its lines start
-			 * from what they started from six frames ago, which is what they start from now. */
-			if(bad == 0)
-			{
-				if(++e->secam_clean >= e->secam_patience && a.K > (e->secam_seeds ? 0 : 2)) { a.K--; e->secam_clean = 0; }
-			}
-			else
-			{
-				/* a few wrong starts: two lines more; many (a batch at K = 8 can have a quarter of its lines wrong, and the
-				 * redo rounds then cost a hundred times what the warm-up saved): back to the full number at once */
-				a.K = (int64_t) bad * a.R * 500 > a.total ? HVK_SECAM_WARMUP : (a.K + 2 < HVK_SECAM_WARMUP ? a.K + 2 : HVK_SECAM_WARMUP);
-				e->secam_patience = e->secam_patience * 2 < 64 ? e->secam_patience * 2 : 64;
-				e->secam_clean = 0;
-			}
-		}
-		if(rounds == 0 && e->secam_est_ran && e->secam_ek_adapt)
-		{
-			/* How far up an estimate has to start depends on the pictures too: where the values behind the lines forget
-			 * slowly (flat colours in the baseband modes) sixteen lines leave one start in a hundred wrong, twenty-four
-			 * one in a thousand. More than one in two hundred wrong: eight lines more (up to 48); sixteen clean blocks: eight
-			 * fewer again. */
-			if((int64_t) bad * a.R * 200 > a.total) { a.EK = a.EK + 8 < 48 ? a.EK + 8 : 48; e->secam_ek_clean = 0; }
-			else if(++e->secam_ek_clean >= 16 && a.EK > e->secam_ek_base) { a.EK -= 8; e->secam_ek_clean = 0; }
-		}
-		if(bad == 0) break;
-		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;
-		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
-		{
-			/* the host's chain takes the batch over from the state it began with */
-			hvk_secam_set_state(e->secam, &e->secam_start, first_frame);
-			for(int i = 0; i < nframes; i++)
-			{
-				const int slot = e->staged_slots[i], slot2 = e->staged_slots2[i];
-				const hvk_slot_t *s = &e->slots[slot], *s2 = &e->slots[slot2];
-				r = hvk_secam_frame(e->secam, first_frame + i, s->valid ? e->host_frames[slot] : NULL, s->valid ? s->width : 0, s->valid ? s->height : 0, s->interlaced,
-				                    s2->valid ? e->host_frames[slot2] : NULL, s2->valid ? s2->width : 0, s2->valid ? s2->height : 0, s2->interlaced,
-				                    e->h_chroma + (size_t) i * k.raster_samples);
-				if(r != HVK_OK) return(r);
-			}
-			hvk_secam_get_state(e->secam, e->h_secam_carry, NULL);
-			HIPCHK_P(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
-			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
-			e->secam_counts[3] += nframes;
-			memset(e->chroma_par, -1, (size_t) e->max_frames);      /* (the host's chain wrote the rows) */
-			return(HVK_OK);
-		}
-		e->secam_counts[2] += (int64_t) bad * a.R;
-		if((r = hvk_launch_secam_redo(&a, rounds, e->stream)) != HVK_OK) return(r);
-	}
-
-	if((r = hvk_launch_secam_carry(&a, e->stream)) != HVK_OK) return(r);
-	HIPCHK(hipMemcpyAsync(e->h_secam_carry, a.carry, sizeof(hvk_secam_state_t), hipMemcpyDeviceToHost, e->stream));
-	return(HVK_OK);
-}
-
-/* The picture planes (hvk_direct.hip) of those of the named slots whose picture is new since its planes were made: one
- * prep launch for the pictures whose levels are looked up, one for those whose levels are computed. On the engine's
- * stream: behind the pictures' uploads, in front of every later render. */
-/* The planes of those of the named slots whose picture is new since its planes were made, on `stream`: runs of
- * neighbouring slots with pictures of one geometry go into one launch, which gets the run as an argument -- nothing is
- * copied to the device and nothing waited for. Returns the number of pictures worked on (< 0: failure). */
-static int _prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t stream)
-{
-	const hvk_kconst_t &k = e->t.k;
-	std::vector<int> todo;
-
-	for(int i = 0; i < n; i++)
-	{
-		const int sl = slots[i];
-		if(sl < 0 || sl >= e->frame_slots || !e->slots[sl].plane_dirty) continue;
-		e->slots[sl].plane_dirty = 0;
-		todo.push_back(sl);
-	}
-	if(todo.empty()) return(0);
-	std::sort(todo.begin(), todo.end());
-
-	auto kind = [&](int sl, hvk_prepgeo_t *g) -> int
-	{
-		const hvk_slot_t *ss = &e->slots[sl];
-		g->fb_width = ss->valid ? ss->width : 0;
-		g->fb_height = ss->valid ? ss->height : 0;
-		g->fb_interlaced = ss->interlaced;
-		g->fb_valid = ss->valid;
-		return(e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && ss->valid && ss->many_colours));
-	};
-
-	hvk_raster_args_t ra;
-	hvk_filter_args_t fa;
-	_kernel_args(e, &ra, &fa, NULL, 1);
-	for(size_t i = 0; i < todo.size();)
-	{
-		hvk_prepgeo_t g, g2;
-		memset(&g, 0, sizeof(g));
-		const int lv = kind(todo[i], &g);
-		size_t j = i + 1;
-		for(; j < todo.size() && todo[j] == todo[j - 1] + 1; j++)
-		{
-			memset(&g2, 0, sizeof(g2));
-			if(kind(todo[j], &g2) != lv || g2.fb_width != g.fb_width || g2.fb_height != g.fb_height || g2.fb_interlaced != g.fb_interlaced || g2.fb_valid != g.fb_valid) break;
-		}
-		g.slot0 = todo[i];
-		g.frame_px = (int64_t) k.active_width * k.active_lines;
-		ra.levels_computed = lv ? 1 + e->t.yuv.fast : 0;      /* (the plane kernels know the short forms) */
-		const int r = hvk_launch_prep(&ra, &g, (int) (j - i), e->d_Lp + 16, e->d_Cp ? e->d_Cp + 16 : (e->d_UVp ? e->d_UVp + 16 : NULL), stream);
-		if(r != HVK_OK) return(r);
-		e->prep_count += (int64_t) (j - i);
-		i = j;
-	}
-	return((int) todo.size());
-}
-
-/* ... of the staged block's frames [y0, y0 + n) (and of the slots named for the frames before them) */
-static int _prep_staged(hvk_engine *e, int y0, int n, hipStream_t stream)
-{
-	int r = _prep_dirty(e, e->staged_slots + y0, n, stream);
-	if(r < 0) return(r);
-	const int r2 = _prep_dirty(e, e->staged_prev + y0, n, stream);
-	return(r2 < 0 ? r2 : r + r2);
-}
-
-/* the last plane row of the staged block's last frame, kept for the next block's first frame (its slot may hold another
- * picture by then): behind the launch that made the planes */
-static int _carry_copy(hvk_engine *e)
-{
-	if(!e->carry_copy_pending) return(HVK_OK);
-	const size_t W = e->t.k.width;
-	HIPCHK(hipMemcpyAsync(e->d_Lp + e->carry_to, e->d_Lp + e->carry_from, W * 2, hipMemcpyDeviceToDevice, e->stream));
-	if(e->d_Cp) HIPCHK(hipMemcpyAsync(e->d_Cp + e->carry_to, e->d_Cp + e->carry_from, W * 4, hipMemcpyDeviceToDevice, e->stream));
-	e->carry_copy_pending = 0;
-	return(HVK_OK);
-}
-
-/* A block that was staged and never launched: its planes are made all the same (the next block's first frame may look
- * into its last one's) */
-static int _flush_planes(hvk_engine *e)
-{
-	if(!e->direct || !e->prep_pending || !e->carry_copy_pending) return(HVK_OK);
-	const int r = _prep_staged(e, 0, e->staged, e->stream);
-	if(r < 0) return(r);
-	e->prep_pending = 0;
-	return(_carry_copy(e));
-}
-
-/* The planes of the named slots are made again before the next render shows them: what a caller does who wants the
- * per-picture work inside a clock of its own (bench.py). */
-extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
-{
-	if(!e || !slots || n < 0) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	for(int i = 0; i < n; i++) if(slots[i] < 0 || slots[i] >= e->frame_slots) return(HVK_ERROR);
-	if(e->secam_dev) for(int i = 0; i < n; i++)
-	{
-		e->slots[slots[i]].cells_valid[0] = e->slots[slots[i]].cells_valid[1] = 0;
-		memset(e->slots[slots[i]].seeds_valid, 0, sizeof(e->slots[slots[i]].seeds_valid));
-	}
-	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
-	for(int i = 0; i < n; i++) { e->slots[slots[i]].plane_dirty = 1; e->slots[slots[i]].shown = 0; }
-	return(HVK_OK);
-}
-
-static int _stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots)
-{
-	if(!e || nframes < 1 || nframes > e->max_frames || stride < 1 || first_frame < 0) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	/* A stage that fails half way has moved the serial chains (sound carriers, SECAM colour, offset, passthru, FM
-	 * video) forward for the frames before the failure; they cannot be rewound, so the stream would go on out of step
-	 * without anyone noticing. Everything that can be checked is checked before the first of them is touched, and a
-	 * failure after that point poisons the engine: every later call fails too. */
-	if(e->poisoned) return(HVK_ERROR);
-	for(int i = 0; i < nframes * e->t.k.fields; i++)
-	{
-		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
-	}
-	if(e->t.k.rs_irr && stride != 1) return(HVK_UNSUPPORTED);        /* frames of two lengths: a batch is one run of samples */
-	/* (... whose NICAM symbol starts are kept as 29-bit offsets from its first sample: checked here, before any chain has moved) */
-	if(e->t.k.rs_irr && e->audio && (_fstart(e, first_frame + nframes) - _fstart(e, first_frame)) * 8 >= 0x7FFFFFFF) return(HVK_UNSUPPORTED);
-	if(e->secam && (stride != 1 || first_frame != e->secam_next)) return(HVK_UNSUPPORTED);   /* one serial chain over the whole stream (hvk_secam.c): frames in order, no gaps */
-	{
-		/* Where the last line of a frame shows picture (525 lines) it lies within the video filter's reach of the next
-		 * frame's first samples: a frame whose predecessor the engine does not have -- a stride, a jump -- needs the
-		 * caller to name the slot that holds it (hvk_stage_strided_prev(); the frame's own slot where the picture stays).
-		 * Exact or refused: no "nearly". */
-		const hvk_linedesc_t *dl = &e->t.desc[e->t.k.lines - 1];
-		if(dl->ar > dl->al && !e->t.k.rawbb)
-		{
-			for(int i = 0; i < nframes; i++)
-			{
-				if(first_frame + i * stride == 0) continue;
-				if(stride == 1 && i > 0) continue;
-				if(stride == 1 && e->carry_valid && e->carry_frame + 1 == first_frame) continue;
-				if(prev_slots && prev_slots[i] >= 0 && prev_slots[i] < e->frame_slots) continue;
-				return(HVK_UNSUPPORTED);
-			}
-		}
-	}
-
-	const hvk_kconst_t &k = e->t.k;
-	const int64_t FS = k.frame_samples;
-	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-
-	HIPCHK(hipSetDevice(e->device));
-	{
-		int r = _flush_planes(e);           /* (a block staged and not launched) */
-		if(r != HVK_OK) return(r);
-	}
-	/* the pinned side buffers are reused: the copies of the stage before have to be through. (Not the whole stream: a
-	 * read-back queued with hvk_fetch_async() goes on while this stage's host pre-passes run.) */
-	if(k.fm_video) HIPCHK(hipStreamSynchronize(e->stream));
-	else if(e->staged_busy) { HIPCHK(hipEventSynchronize(e->ev_staged)); e->staged_busy = 0; }
-
-	if(k.fm_video)
-	{
-		/* the FM phasor is one serial chain over the stream (hvk_tail.c): finish the
-		 * previous batch, then take frames in order, no gaps */
-		/* (a batch whose samples have all been handed to the FM thread needs no finishing, and nothing here waits for the
-		 * thread: the next batch's host pre-passes run beside it) */
-		int r = _fm_finish(e);
-		if(r != HVK_OK) return(r);
-		if(stride != 1 || _fstart(e, first_frame) != e->fm_batch_pos + (int64_t) e->fm_done) return(HVK_UNSUPPORTED);
-		e->fm_batch_pos = _fstart(e, first_frame);
-		e->fm_done = 0;
-		e->fm_async_upto = 0;
-	}
-
-	const int fields = k.fields;            /* descriptors (and slots named by the caller) per frame */
-	int many = 0;
-
-	if(k.fm_video && (k.vf_type || k.rs_L) && first_frame == 0 && k.out_prime > 0)
-	{
-		/* The line pipeline's never-emitted start-up samples pass through the FM modulator as well
-		 * (src/video.c:4936-4952 drops them only at the output): what the sound carriers add to them is
-		 * wanted now, before the audio chain moves on to the first frame (hvk_launch does the rest) */
-		free(e->fm_prime_car);
-		e->fm_prime_car = (int16_t *) calloc((size_t) k.out_prime * 2, sizeof(int16_t));
-		if(!e->fm_prime_car) return(HVK_OUT_OF_MEMORY);
-		if(e->audio && k.has_carriers)
-		{
-			int64_t k0 = 0;
-			int n = hvk_audio_generate(e->audio, 0, k.out_prime, e->fm_prime_car, e->sym_tmp, e->sym_tmp ? e->symbol_stride : 0, &k0);
-			if(n < 0) { e->poisoned = 1; return(n); }
-		}
-		e->fm_prime_pending = 1;
-	}
-
-	/* The sound chains over a run of samples: the carriers' side stream, and NICAM's symbol schedule as rows per tile.
-	 * Per frame -- or, with frames of two lengths, once for the batch, which the filter kernel then takes as one long
-	 * frame (tiles counted from the batch's first sample). */
-	auto stage_audio = [&](const int64_t a_pos, const int64_t a_len, const size_t a_off, const int a_row, const int a_symcap, const int a_ntiles, const int64_t a_frame) -> int
-	{
-		const int64_t m0 = a_pos + (int64_t) k.out_prime;
-		int64_t k0 = 0;
-		int n = hvk_audio_generate(e->audio, m0, a_len,
-			e->h_car ? e->h_car + a_off * 2 : NULL,
-			e->sym_tmp, a_symcap, &k0);
-		if(n < 0) { e->poisoned = 1; return(n); }
-
-		if(k.sis)
-		{
-			/* the frame's sound-in-syncs bursts: made by the chains' pass just now, line by line (hvk_audio.c) */
-			/* (and the first line's of the frame behind it: the filter of this frame's last samples looks into it) */
-			/* (behind the resampler the output stands a raster line back, k.rs_shift: the line after that one as well) */
-			const int rows = k.lines + (k.rs_L ? 2 : 1);
-			int r = hvk_audio_sis_fetch(e->audio, a_frame * k.lines, rows, (uint8_t *) (e->h_sis_bits + (size_t) a_row * rows * 2));
-			if(r != HVK_OK) { e->poisoned = 1; return(r); }
-		}
-
-		if(k.has_nicam)
-		{
-			/* tabulate the symbol schedule for the frame (src/nicam728.c:398-407):
-			 * symbol k starts at sps * k - floor(k * dsl / decimation); entries are
-			 * (start relative to the frame's first sample) << 3 | valid << 2 | value */
-			int32_t *tab = e->h_sym + (size_t) a_row * e->symbol_stride;
-			int32_t *tile = e->h_tile + (size_t) a_row * e->tiles * HVK_NICAM_ROW;
-			int newest = 0;
-
-			for(int j = 0; j < a_symcap; j++)
-			{
-				const int64_t kk = k0 + j;
-				if(j >= n || kk < 0 || e->sym_tmp[j] == 0xFF) { tab[j] = 0; continue; }
-				const int64_t start = (int64_t) k.nicam_sps * kk - (kk * k.nicam_dsl) / k.nicam_decimation - m0;
-				tab[j] = (int32_t) (start * 8) | 4 | (e->sym_tmp[j] & 3);
-			}
-
-			/* per tile a dense row: the HVK_NICAM_SYMS symbols from 6 before the newest
-			 * one that has started by the tile's first sample, then the mixer table
-			 * position of that sample */
-			while(newest + 1 < n && !(tab[newest] & 4)) newest++;   /* slab entries before the stream's first symbol */
-			for(int b = 0; b < a_ntiles; b++)
-			{
-				const int64_t pos = (int64_t) b * HVK_TILE;
-				int32_t *row = tile + (size_t) b * HVK_NICAM_ROW;
-				while(newest + 1 < n && (tab[newest + 1] & 4) && (tab[newest + 1] >> 3) <= pos) newest++;
-				for(int q = 0; q < HVK_NICAM_SYMS; q++)
-				{
-					const int j = newest - (HVK_NICAM_BACK - 1) + q;
-					row[q] = (j >= 0 && j < a_symcap) ? tab[j] : 0;
-				}
-				row[HVK_NICAM_SYMS] = (int32_t) ((m0 + pos) % k.nicam_cc_len);
-			}
-		}
-		return(HVK_OK);
-	};
-
-	for(int i = 0; i < nframes; i++)
-	{
-		hvk_framedesc_t *f = &e->h_fdesc[(size_t) i * (fields + 1) + 1];
-		const int slot = slots ? slots[(size_t) i * fields] : 0;
-		const int slot2 = (slots && fields == 2) ? slots[(size_t) i * fields + 1] : slot;
-		if(slot < 0 || slot >= e->frame_slots || slot2 < 0 || slot2 >= e->frame_slots) return(HVK_ERROR);
-		const hvk_slot_t *s = &e->slots[slot];
-		e->staged_slots[i] = slot;
-		e->staged_slots2[i] = slot2;
-
-		for(int fld = 0; fld < fields; fld++)
-		{
-			hvk_framedesc_t *d = f + fld;
-			const int sl = fld ? slot2 : slot;
-			const hvk_slot_t *ss = &e->slots[sl];
-
-			memset(d, 0, sizeof(*d));
-			d->frame_index = first_frame + i * stride;
-			d->fb_offset = (int64_t) sl * frame_px;
-			d->fb_width = ss->valid ? ss->width : 0;
-			d->fb_height = ss->valid ? ss->height : 0;
-			d->pixel_stride = 1;
-			d->line_stride = ss->width;
-			d->vframe_x = (k.active_width - d->fb_width) / 2;      /* src/video.c:4896-4897 */
-			d->vframe_y = (k.active_lines - d->fb_height) / 2;
-			d->fb_interlaced = ss->interlaced;
-			d->fb_valid = ss->valid;
-			if(ss->valid && ss->many_colours) many = 1;
-			d->parity = (int32_t) ((d->frame_index + 1) & 1);
-			d->plane_row0 = sl * k.lines;
-			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
-		}
-
-		if(e->secam && e->secam_dev) e->secam_next++;
-		else if(e->secam)
-		{
-			const hvk_slot_t *s2 = &e->slots[slot2];
-			int r = hvk_secam_frame(e->secam, f->frame_index, s->valid ? e->host_frames[slot] : NULL,
-			                        f->fb_width, f->fb_height, s->interlaced,
-			                        s2->valid ? e->host_frames[slot2] : NULL, s2->valid ? s2->width : 0, s2->valid ? s2->height : 0, s2->interlaced,
-			                        e->h_chroma + (size_t) i * k.raster_samples);
-			if(r != HVK_OK) return(r);
-			e->secam_next++;
-		}
-
-		if(e->h_raw)
-		{
-			/* the lines of this frame's slab: the last line of the frame before, the frame, the first
-			 * line of the next (the filter looks 25 samples into it); zeros where nothing is queued */
-			const int W = k.width;
-			int16_t *dst = e->h_raw + (size_t) i * k.slab_lines * W;
-			for(int j = 0; j < k.slab_lines; j++)
-			{
-				const int64_t g = f->frame_index * k.lines + j - 1;
-				const int64_t at = g * W - e->raw_base;
-				if(g >= 0 && at >= 0 && at + W <= (int64_t) e->raw_q->size()) memcpy(dst + (size_t) j * W, e->raw_q->data() + at, (size_t) W * 2);
-				else memset(dst + (size_t) j * W, 0, (size_t) W * 2);
-			}
-		}
-
-		/* where the frame's samples stand in the stream, how many they are, where they go in the batch's side buffers */
-		const int64_t fpos = _fstart(e, f->frame_index), flen = _fstart(e, f->frame_index + 1) - fpos;
-		const size_t foff = k.rs_irr ? (size_t) (fpos - _fstart(e, first_frame)) : (size_t) i * FS;
-		if(k.rs_irr)
-		{
-			/* hvk_k_resample: c = B D - f RS L, and the frame's place in the batch's run */
-			e->h_frec[2 * i + 0] = (int) (fpos * k.rs_D - f->frame_index * (int64_t) k.raster_samples * k.rs_L);
-			e->h_frec[2 * i + 1] = (int) foff;
-		}
-
-		if(e->h_off)
-		{
-			int r = hvk_tail_offset_stream(e->tail, fpos, flen, e->h_off + foff * 2);
-			if(r != HVK_OK) { e->poisoned = 1; return(r); }
-		}
-		if(e->h_pass)
-		{
-			int r = hvk_tail_passthru_stream(e->tail, fpos, flen, e->h_pass + foff * 2);
-			if(r != HVK_OK) { e->poisoned = 1; return(r); }
-		}
-
-		if(e->audio && !k.rs_irr)
-		{
-			int r = stage_audio(fpos, flen, foff, i, e->symbol_stride, e->tiles, f->frame_index);
-			if(r != HVK_OK) return(r);
-		}
-	}
-	if(e->audio && k.rs_irr)
-	{
-		const int64_t A0 = _fstart(e, first_frame), T = _fstart(e, first_frame + nframes) - A0;
-		int r = stage_audio(A0, T, 0, 0, e->symbol_stride * nframes, (int) ((T + HVK_TILE - 1) / HVK_TILE), first_frame);
-		if(r != HVK_OK) return(r);
-	}
-
-	/* The frame before each frame: the one staged just before it, the last frame of the batch before
-	 * (its last line's source row was kept), nothing at the start of the stream. A strided render does
-	 * not have the frames in between: it takes the frame's own picture, which is right for a picture
-	 * that does not change and wrong by up to the filter's reach (25 samples) otherwise. */
-	for(int i = 0; i < nframes; i++)
-	{
-		hvk_framedesc_t *p = &e->h_fdesc[(size_t) i * (fields + 1)];
-		const hvk_framedesc_t *own = &e->h_fdesc[(size_t) i * (fields + 1) + fields];
-		const int ps = prev_slots ? prev_slots[i] : -1;
-		if(first_frame + i * stride == 0) { memset(p, 0, sizeof(*p)); }     /* nothing before the stream */
-		else if(stride == 1 && i > 0) *p = e->h_fdesc[(size_t) (i - 1) * (fields + 1) + fields];
-		else if(stride == 1 && e->carry_valid && e->carry_frame + 1 == first_frame) *p = e->carry;
-		else if(ps >= 0 && ps < e->frame_slots)
-		{
-			/* the caller has the frame before in a slot (hvk_stage_strided_prev): its picture on the halo line */
-			const hvk_slot_t *ss = &e->slots[ps];
-			*p = *own;
-			p->fb_offset = (int64_t) ps * frame_px;
-			p->fb_width = ss->valid ? ss->width : 0;
-			p->fb_height = ss->valid ? ss->height : 0;
-			p->line_stride = ss->width;
-			p->vframe_x = (k.active_width - p->fb_width) / 2;
-			p->vframe_y = (k.active_lines - p->fb_height) / 2;
-			p->fb_interlaced = ss->interlaced;
-			p->fb_valid = ss->valid;
-			p->plane_row0 = ps * k.lines;
-		}
-		else *p = *own;                                             /* a strided render or a jump without it: the frame's own picture */
-		/* the colour table position the kernel counts lines from is this frame's, also on the halo line */
-		p->clut_off0 = own->clut_off0;
-		p->frame_index = own->frame_index;
-		p->parity = own->parity;
-	}
-	if(e->direct)
-	{
-		/* the picture planes of every picture this batch shows that is new since its planes were made: when it is launched */
-		for(int i = 0; i < nframes; i++) e->staged_prev[i] = (prev_slots && prev_slots[i] >= 0 && prev_slots[i] < e->frame_slots) ? prev_slots[i] : -1;
-		e->prep_pending = 1;
-	}
-	{
-		/* keep what the last frame of this batch shows on its last line */
-		const hvk_framedesc_t *last = &e->h_fdesc[(size_t) (nframes - 1) * (fields + 1) + fields];
-		const hvk_linedesc_t *d = &e->t.desc[(size_t) last->parity * k.lines + k.lines - 1];
-		int vy = d->src_row;
-		if(vy >= 0 && k.interlaced != 0 && last->fb_interlaced != k.interlaced) vy += 1;
-		vy -= last->vframe_y;
-		e->carry = *last;
-		e->carry_frame = last->frame_index;
-		e->carry_valid = 1;
-		if(d->ar > d->al)
-		{
-			/* not the row this batch's first frame is about to read */
-			e->carry_row ^= 1;
-			if(last->fb_valid && vy >= 0 && vy < last->fb_height)
-			{
-				const size_t carry_off = frame_px * e->frame_slots + (size_t) e->carry_row * k.active_width;
-				HIPCHK(hipMemcpyAsync(e->d_pool + carry_off, e->d_pool + last->fb_offset + (int64_t) vy * last->line_stride,
-				                      (size_t) last->fb_width * 4, hipMemcpyDeviceToDevice, e->stream));
-				e->carry.fb_offset = (int64_t) carry_off;
-				e->carry.line_stride = 0;       /* every row of the kept frame is that one row */
-			}
-			else e->carry.fb_valid = 0;         /* (no picture on that line: black -- the raster kernel's reading) */
-			if(e->direct)
-			{
-				/* ... and its planes' last row, picture on it or not (hvk_k_direct reads the row whatever the frame showed): the
-				 * slot may hold another picture by the time the next batch looks */
-				const size_t W = k.width;
-				e->carry_from = ((size_t) last->plane_row0 + k.lines - 1) * W + 16;
-				e->carry_to = ((size_t) e->plane_carry_row + e->carry_row) * W + 16;
-				e->carry_copy_pending = 1;         /* (copied behind the launch that makes the planes) */
-				e->carry.plane_row0 = e->plane_carry_row + e->carry_row - (k.lines - 1);
-			}
-		}
-		else e->carry.fb_valid = 0;
-	}
-	HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
-	if(e->h_ops)
-	{
-		_build_vbi_ops(e, nframes);
-		HIPCHK_P(hipMemcpyAsync(e->d_ops, e->h_ops, (size_t) nframes * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipMemcpyHostToDevice, e->stream));
-		HIPCHK_P(hipMemcpyAsync(e->d_map, e->h_map, (size_t) nframes * k.lines, hipMemcpyHostToDevice, e->stream));
-		/* teletext packets and caption pairs are consumed by the batch they were queued for */
-		if(e->h_tt_mask) memset(e->h_tt_mask, 0, (size_t) e->max_frames * 4);
-		if(e->cc_pairs) memset(e->cc_pairs, 0, (size_t) e->max_frames * 3);
-	}
-	if(e->h_raw)
-	{
-		HIPCHK_P(hipMemcpyAsync(e->d_raw, e->h_raw, (size_t) nframes * k.slab_lines * k.width * 2, hipMemcpyHostToDevice, e->stream));
-		/* what no later frame can need goes: everything before the last line of the last frame staged */
-		const int64_t keep = ((first_frame + (int64_t) (nframes - 1) * stride + 1) * k.lines - 1) * k.width;
-		if(keep > e->raw_base)
-		{
-			const int64_t drop = std::min<int64_t>(keep - e->raw_base, (int64_t) e->raw_q->size());
-			e->raw_q->erase(e->raw_q->begin(), e->raw_q->begin() + drop);
-			e->raw_base += drop;
-		}
-	}
-	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
-	if(e->secam_dev)
-	{
-		int r = _secam_on_device(e, first_frame, nframes);
-		if(r != HVK_OK) { e->poisoned = 1; return(r); }
-	}
-	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
-	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + (k.rs_L ? 2 : 1)) * 8, hipMemcpyHostToDevice, e->stream));
-	e->staged_samples = _fstart(e, first_frame + nframes) - _fstart(e, first_frame);     /* (nframes * FS but for frames of two lengths) */
-	if(e->h_car) HIPCHK_P(hipMemcpyAsync(e->d_car, e->h_car, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
-	if(e->h_frec) HIPCHK_P(hipMemcpyAsync(e->d_frec, e->h_frec, (size_t) nframes * 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
-	if(e->h_sym)
-	{
-		HIPCHK_P(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));
-	}
-
-	HIPCHK_P(hipEventRecord(e->ev_staged, e->stream));
-	e->staged_busy = 1;
-
-	e->levels_computed = e->levels_mode == HVK_LEVELS_COMPUTE || (e->levels_mode == HVK_LEVELS_AUTO && many);
-	e->staged = nframes;
-	e->staged_first = first_frame;
-	e->staged_stride = stride;
-	return(HVK_OK);
-}
-
-extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
-{
-	if(!e) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	e->stream = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
-	return(HVK_OK);
-}
-
-/* the kernels' arguments for the staged batch */
-/* S-Video behind resampler + video filter, lines of two widths (hvk_kconst_t.sv_ring): the staged batch's Q channel, line by
- * line, as the reference's ring of line buffers pairs it (hvk_k_svq has the rule). Emitted line j of the stream begins at
- * S(j) = ceil((j + s) W L / D) - ceil(s W L / D), s the chunks dropped at start-up (hvk_tables_frame_start()); its content
- * is a chunk of the width of line j - 1. */
-static int _sv_ring_q(hvk_engine *e)
-{
-	const hvk_kconst_t &k = e->t.k;
-	const int64_t s = 1 + (k.vf_type ? k.delay_lines : 0), WL = (int64_t) k.width * k.rs_L, D = k.rs_D;
-	auto S = [&](int64_t j) { return(((j + s) * WL + D - 1) / D - (s * WL + D - 1) / D); };
-	auto width = [&](int64_t j) { return((int) (S(j + 1) - S(j))); };
-	const int wmax = e->t.max_width, ring = k.sv_ring;
-	const int64_t f0 = e->staged_first, j0 = f0 * k.lines, base = S(j0);
-	const long slab_in = (long) k.slab_lines * k.width;
-	const int nlines = e->staged * k.lines;
-	if(e->staged_stride != 1) return(HVK_UNSUPPORTED);
-
-	for(int i = 0; i < nlines; i++)
-	{
-		const int64_t j = j0 + i;
-		const int w = width(j), wp = j + s - 1 >= 0 ? width(j - 1) : wmax, delta = wmax - wp;
-		int kind = 0, src = 0;
-		if(w > wp)
-		{
-			if(k.rs_L < k.rs_D)
-			{
-				/* downwards: the raster's sub-carrier of the line before the content's, at the place the content ends */
-				const int y = i / k.lines;
-				const int64_t pl = S(j) - S((f0 + y) * k.lines);                    /* the line's first sample in its frame */
-				const int64_t rr = pl + delta + k.rs_shift;
-				const int64_t n0 = (rr * D + e->h_frec[2 * y]) / k.rs_L;
-				const int64_t rho = n0 / k.width;
-				kind = 1;
-				src = (int) ((int64_t) y * slab_in + rho * k.width + wp);
-			}
-			else
-			{
-				/* upwards: the last sample of the newest chunk of the longer width that lay in this buffer: k turns of the ring back */
-				kind = 3;       /* (none: the buffer is as it was allocated) */
-				for(int t = 1; t <= 8; t++)
-				{
-					const int64_t m = j - (int64_t) t * ring;
-					if(m + s - 1 < 0) break;
-					if(width(m - 1) == wmax)
-					{
-						const int64_t at = S(m) + (wmax - 1) - base;        /* (its delta is 0) */
-						if(at >= -(int64_t) e->sv_hist) { kind = 2; src = (int) at; }
-						break;
-					}
-				}
-			}
-		}
-		e->h_svrec[4 * i + 0] = (int) (S(j) - base);
-		e->h_svrec[4 * i + 1] = w | (delta << 16) | (kind << 20);
-		e->h_svrec[4 * i + 2] = src;
-		e->h_svrec[4 * i + 3] = 0;
-	}
-	HIPCHK(hipMemcpyAsync(e->d_svrec, e->h_svrec, (size_t) nlines * 16, hipMemcpyHostToDevice, e->stream));
-	int r = hvk_launch_svq(e->d_svrec, nlines, e->d_C2, e->d_C, e->d_Cq, k.s_lead, e->stream);
-	if(r != HVK_OK) return(r);
-	e->sv_tail_first = f0;
-	e->sv_tail_total = e->staged_samples;
-	return(HVK_OK);
-}
-
-/* ... before a NEW batch's sub-carrier stream is made: the end of the stream that lies there (the batch before's) goes in front
- * of it (a batch launched again finds what it found the first time) */
-static int _sv_ring_keep(hvk_engine *e)
-{
-	const hvk_kconst_t &k = e->t.k;
-	if(e->sv_tail_first < 0 || e->sv_tail_first == e->staged_first) return(HVK_OK);
-	if(e->sv_tail_total >= e->sv_hist)
-	{
-		HIPCHK(hipMemcpyAsync(e->d_C2 + k.s_lead - e->sv_hist, e->d_C2 + k.s_lead + e->sv_tail_total - e->sv_hist, (size_t) e->sv_hist * 2, hipMemcpyDeviceToDevice, e->stream));
-	}
-	else HIPCHK(hipMemsetAsync(e->d_C2 + k.s_lead - e->sv_hist, 0, (size_t) e->sv_hist * 2, e->stream));
-	return(HVK_OK);
-}
-
-static void _kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride)
-{
-	hvk_raster_args_t &ra = *pra;
-	memset(&ra, 0, sizeof(ra));
-	ra.k = e->t.k;
-	ra.ctaps = e->ctaps;
-	ra.notch = e->notch;
-	ra.chroma = e->t.k.rawbb ? e->d_raw : e->d_chroma;
-	ra.vbi_sym = (const int *) e->d_vbi_sym;
-	ra.vbi_val = (const int16_t *) e->d_vbi_val;
-	ra.vbi_ops = e->d_ops;
-	ra.vbi_map = (const signed char *) e->d_map;
-	ra.fsc_rows = (const int16_t *) e->d_fsc_rows;
-	ra.vits_l = (const int16_t *) e->d_vits_l;
-	ra.vits_c = (const int16_t *) e->d_vits_c;
-	ra.sis_dense = (const int16_t *) e->d_sis_dense;
-	ra.sis_win = (const int16_t *) e->d_sis_win;
-	ra.sis_first = (const int16_t *) e->d_sis_first;
-	ra.sis_bits = e->d_sis_bits;
-	ra.desc = (const hvk_linedesc_t *) e->d_desc;
-	ra.pulses = (const int16_t *) e->d_pulses;
-	ra.linebase = (const int16_t *) e->d_linebase;
-	ra.yuv = e->d_yuv;
-	ra.yuvparams = e->d_yuvparams;
-	ra.levels_computed = e->levels_computed;
-	ra.clut = (const hvk_c16_t *) e->d_clut;
-	ra.burst_win = (const int16_t *) e->d_burst + HVK_PULSE_PAD;
-	ra.ghost = (const int16_t *) e->d_ghost;
-	ra.pool = e->d_pool;
-	ra.fdesc = e->d_fdesc;
-	ra.S = e->d_S;
-	ra.C = e->d_C;
-	ra.nframes = e->staged;
-	ra.secam_fid = e->t.conf.secam_field_id != 0;
-	ra.first_frame = e->staged_first;
-	ra.frame_stride = e->staged_stride;
-
-	hvk_filter_args_t &fa = *pfa;
-	memset(&fa, 0, sizeof(fa));
-	fa.k = e->t.k;
-	fa.itaps = e->itaps;
-	fa.qtaps = e->qtaps;
-	fa.fdesc = e->d_fdesc;
-	fa.S = e->t.k.rs_L ? e->d_S2 : e->d_S;
-	fa.C = e->t.k.rs_L ? (e->t.k.sv_ring ? e->d_Cq : e->d_C2) : e->d_C;
-	fa.carriers = (const hvk_c16_t *) e->d_car;
-	fa.tilesyms = e->d_tile;
-	fa.nicam_tapd = (const int *) e->d_tapd;
-	fa.nicam_cca = (const int *) e->d_cca;
-	fa.mfma_a = e->d_mfma_a;
-	fa.mfma_ci = e->mfma_ci;
-	fa.mfma_cq = e->mfma_cq;
-	fa.iq = d_iq ? (int16_t *) d_iq : e->d_out;
-	fa.nframes = e->staged;
-	fa.out_stride = out_stride;
-
-}
-
-extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
-{
-	return(hvk_launch_strided_out(e, d_iq, 1));
-}
-
-extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride)
-{
-	if(!e || out_stride < 1) return(HVK_ERROR);
-	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(e->staged < 1) return(HVK_ERROR);
-	/* FM video: the device buffer holds the modulator's input; the samples exist on the host only (hvk_fetch) */
-	if(e->t.k.fm_video && d_iq != NULL) return(HVK_UNSUPPORTED);
-
-	HIPCHK(hipSetDevice(e->device));
-
-	hvk_raster_args_t ra;
-	hvk_filter_args_t fa;
-	_kernel_args(e, &ra, &fa, d_iq, out_stride);
-
-	const bool timed = e->timing && e->ev_used < HVK_TIMING_SLOTS;
-	hipEvent_t *ev = timed ? e->ev[e->ev_used] : NULL;
-	int r;
-
-	if(timed) HIPCHK(hipEventRecord(ev[0], e->stream));
-	if(e->direct)
-	{
-		/* one kernel: its time is reported as the second (filter) kernel's; the first one's is nil, or that of the raster
-		 * kernel over the few lines the optional stages write to */
-		if(e->ovr_n)
-		{
-			hvk_raster_args_t rl = ra;
-			rl.linelist = e->d_ovr_list;
-			rl.nlist = e->ovr_n;
-			rl.S = e->d_Lp + 16 + (size_t) e->ovr_row0 * e->t.k.width;
-			if((r = hvk_launch_raster(&rl, e->stream)) != HVK_OK) return(r);
-		}
-		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
-		hvk_direct_args_t da;
-		memset(&da, 0, sizeof(da));
-		da.k = e->t.k;
-		da.D.Lp = e->d_Lp + 16;
-		da.D.Cp = e->d_Cp ? e->d_Cp + 16 : NULL;
-		da.D.clut3 = e->d_clut3 ? e->d_clut3 + 16 : NULL;
-		da.D.creg = e->clut_reg;
-		da.D.zero_row = e->plane_zero_row;
-		da.D.desc = (const hvk_linedesc_t *) e->d_desc;
-		da.D.lineoff = e->d_lineoff;
-		da.D.inv_w = e->inv_w;
-		da.D.ovr_idx = e->d_ovr_idx;
-		da.D.ovr_n = e->ovr_n;
-		da.tilerec = e->d_tilerec;
-		da.tiles_pad = e->tiles_pad;
-		da.nicam_tapd = fa.nicam_tapd;
-		da.nicam_cca = fa.nicam_cca;
-		da.mfma_a = fa.mfma_a;
-		da.mfma_ci = fa.mfma_ci;
-		da.mfma_cq = fa.mfma_cq;
-		da.out_stride = out_stride;
-		da.frame_stride = e->staged_stride;
-		/* frames [y0, y0 + n) of the staged block */
-		auto direct_range = [&](const int y0, const int n) -> int
-		{
-			const size_t FS = (size_t) e->t.k.frame_samples;
-			da.D.fdesc = e->d_fdesc + 2 * (size_t) y0;
-			da.D.chroma = e->d_chroma ? e->d_chroma + (size_t) y0 * e->t.k.raster_samples : NULL;
-			da.D.chroma_zero = (int) ((size_t) (e->max_frames - y0) * e->t.k.raster_samples + 16);
-			da.D.ovr_row0 = e->ovr_row0 + y0 * e->ovr_n;
-			da.carriers = fa.carriers ? fa.carriers + (size_t) y0 * FS : NULL;
-			da.tilesyms = fa.tilesyms ? fa.tilesyms + (size_t) y0 * e->tiles * HVK_NICAM_ROW : NULL;
-			da.iq = fa.iq + (size_t) y0 * (size_t) out_stride * FS * 2;
-			da.nframes = n;
-			da.first_frame = e->staged_first + (int64_t) y0 * e->staged_stride;
-			return(hvk_launch_direct(&da, e->stream));
-		};
-		bool dirty = false, fused_now = false;
-		int ndirty = 0;         /* new pictures among those the block shows (each counted once) */
-		if(e->prep_pending)
-		{
-			std::vector<uint8_t> seen((size_t) e->frame_slots, 0);
-			for(int i = 0; i < e->staged; i++)
-			{
-				const int sl[2] = { e->staged_slots[i], e->staged_prev[i] };
-				for(int j = 0; j < 2; j++)
-				{
-					if(sl[j] < 0 || !e->slots[sl[j]].plane_dirty || seen[sl[j]]) continue;
-					seen[sl[j]] = 1;
-					dirty = true;
-					if(!e->slots[sl[j]].shown) ndirty++;       /* (a picture that was shown before and is still here: its planes are made now) */
-				}
-			}
-		}
-		/* (levels by arithmetic -- pictures of many colours -- cost the one kernel more waves per SIMD than they are worth: 128 registers
-		 * a lane against 76; such blocks go through the planes, whose hvk_k_prep8 holds the arithmetic alone: measured, profiles/README.md) */
-		const bool fused_lv = e->levels_computed && e->t.yuv.fast == 2 && getenv("HVK_FUSED_LV") != NULL;
-		if(dirty && e->fused_ok && e->fused_mode != 0 && (e->fused_mode == 1 || (2 * ndirty >= e->staged && (!e->levels_computed || fused_lv))))
-		{
-			ra.levels_computed = e->levels_computed ? (e->t.yuv.fast == 2 ? 3 : 1) : 0;
-			/* most of the block's pictures are new: from the pixels in one kernel (hvk_fused.hip), their planes are not made
-			 * (and stay marked: a later block that shows one of them again makes them then) */
-			da.D.fdesc = e->d_fdesc;
-			da.carriers = fa.carriers;
-			da.tilesyms = fa.tilesyms;
-			da.iq = fa.iq;
-			da.nframes = e->staged;
-			da.first_frame = e->staged_first;
-			if((r = hvk_launch_fused(&ra, &da, e->d_mfma_a28, e->stream)) != HVK_OK) return(r);
-			e->fused_count++;
-			fused_now = true;
-			for(int i = 0; i < e->staged; i++)
-			{
-				e->slots[e->staged_slots[i]].shown = 1;
-				if(e->staged_prev[i] >= 0) e->slots[e->staged_prev[i]].shown = 1;
-			}
-		}
-		else if(!dirty)
-		{
-			if((r = direct_range(0, e->staged)) != HVK_OK) return(r);
-		}
-		else
-		{
-			/* new pictures: their planes chunk by chunk on the second stream (behind everything queued so far: the pictures'
-			 * uploads, the renders that still read the planes' old contents), each chunk's render behind its planes */
-			const bool two = e->prep_streams == 2;
-			hipStream_t ps = two ? e->prep_stream : e->stream;
-			if(two)
-			{
-				HIPCHK_P(hipEventRecord(e->ev_fork, e->stream));
-				HIPCHK_P(hipStreamWaitEvent(e->prep_stream, e->ev_fork, 0));
-			}
-			int ci = 0;
-			for(int y0 = 0; y0 < e->staged; y0 += e->prep_chunk, ci++)
-			{
-				const int n = std::min(e->prep_chunk, e->staged - y0);
-				const int np = _prep_staged(e, y0, n, ps);
-				if(np < 0) { e->poisoned = 1; return(np); }
-				if(np > 0 && two)
-				{
-					hipEvent_t evp = e->ev_prep[ci % HVK_PREP_EVENTS];
-					HIPCHK_P(hipEventRecord(evp, e->prep_stream));
-					HIPCHK_P(hipStreamWaitEvent(e->stream, evp, 0));
-				}
-				if((r = direct_range(y0, n)) != HVK_OK) { e->poisoned = 1; return(r); }
-			}
-		}
-		if(!fused_now)
-		{
-			e->prep_pending = 0;
-			if((r = _carry_copy(e)) != HVK_OK) return(r);
-		}
-	}
-	else
-	{
-		if((r = hvk_launch_raster(&ra, e->stream)) != HVK_OK) return(r);
-		if(e->t.k.rs_irr && out_stride != 1) return(HVK_UNSUPPORTED);
-		if(e->t.k.rs_L && (r = hvk_launch_resample(&e->t.k, e->d_S, e->d_rs_taps, e->d_S2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
-		if(e->t.k.sv_ring && (r = _sv_ring_keep(e)) != HVK_OK) return(r);
-		if(e->t.k.rs_L && e->t.k.s_video && (r = hvk_launch_resample(&e->t.k, e->d_C, e->d_rs_taps, e->d_C2, e->staged, e->d_frec, e->stream)) != HVK_OK) return(r);
-		if(e->t.k.sv_ring && (r = _sv_ring_q(e)) != HVK_OK) return(r);
-		if(timed) HIPCHK(hipEventRecord(ev[1], e->stream));
-		if(e->t.k.rs_irr)
-		{
-			/* frames of two lengths: the resampled frames lie one behind the other, and everything from here on -- the
-			 * filter never knew about lines, nor does it need to know about frames -- takes the batch as ONE frame of
-			 * staged_samples samples (64 of halo either side, as every frame has them otherwise) */
-			fa.k.frame_samples = (int32_t) e->staged_samples;
-			fa.k.s_stride = (int32_t) ((e->staged_samples + 2 * 64 + 7) & ~7);
-			fa.nframes = 1;
-		}
-		if((r = hvk_launch_filter(&fa, e->stream)) != HVK_OK) return(r);
-	}
-	if(timed) { HIPCHK(hipEventRecord(ev[2], e->stream)); e->ev_used++; }
-	e->last_direct = e->direct;
-	if(!e->t.k.fm_video && (e->t.k.swap_iq || e->d_off || e->d_pass))
-	{
-		if(e->t.k.rs_irr) r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, (int) e->staged_samples, 1, 1, e->stream);
-		else r = hvk_launch_tail(fa.iq, e->d_off, e->d_pass, e->t.k.swap_iq, e->t.k.frame_samples, out_stride, e->staged, e->stream);
-		if(r != HVK_OK) return(r);
-	}
-
-	e->last_frames = e->staged;
-	e->last_samples = e->staged_samples;
-	e->fm_launched = e->t.k.fm_video;
-
-	if(e->fm_prime_pending)
-	{
-		/* The modulator's input over the start-up samples: the video filter's output while its history is still
-		 * zero -- nothing but its last ntaps / 2 outputs, whose windows reach the stream's first samples -- plus the
-		 * sound carriers. The stream's first raster samples come from the slab just rendered. */
-		const hvk_kconst_t &k = e->t.k;
-		const int nt = k.vf_type ? k.vf_ntaps : 0, H = nt / 2, P = k.out_prime;
-		std::vector<int16_t> x(H), in((size_t) P);
-		if(k.rs_L)
-		{
-			/* Behind the resampler the start-up samples are not nothing: the resampler's output for raster line N lands in
-			 * the slot of line N - 1, so the resampled raster line 1 (and, with the filter on, the filter's output over it
-			 * and the line after) passes the modulator before the first emitted sample does (hvk_tables.c: out_prime,
-			 * rs_shift). Resampled sample r is made of raster sample floor(r D / L) and the ataps - 1 before it with the
-			 * taps of phase (r D) mod L, nothing in front of the stream's first raster sample (hvk_k_resample says the same
-			 * of the samples it makes); the stream's sample 0 is the filter's output centred on resampled sample rs_shift. */
-			const int64_t L = k.rs_L, D = k.rs_D;
-			const int A = k.rs_ataps;
-			const int Rn = k.rs_shift + H + 1;
-			const int nr = (int) (((int64_t) (Rn - 1) * D) / L) + 1;
-			if(nr > k.raster_samples) { e->poisoned = 1; return(HVK_ERROR); }
-			std::vector<int16_t> xr((size_t) nr), xs((size_t) Rn);
-			HIPCHK(hipMemcpyAsync(xr.data(), e->d_S + (size_t) k.width, (size_t) nr * 2, hipMemcpyDeviceToHost, e->stream));
-			HIPCHK(hipStreamSynchronize(e->stream));
-			for(int rr = 0; rr < Rn; rr++)
-			{
-				const int64_t n = ((int64_t) rr * D) / L, ph = ((int64_t) rr * D) % L;
-				int32_t acc = 0;
-				for(int y = 0; y < A; y++)
-				{
-					const int64_t xi = n - A + 1 + y;
-					if(xi >= 0) acc += (int32_t) xr[(size_t) xi] * e->t.rs_taps[(size_t) ph * A + y];
-				}
-				acc >>= 15;
-				xs[(size_t) rr] = (int16_t) (acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc));
-			}
-			for(int n = 0; n < P; n++)
-			{
-				const int c = n - P + k.rs_shift;       /* the resampled sample this output is centred on */
-				int32_t acc;
-				if(nt)
-				{
-					acc = 0;
-					for(int kk = 0; kk < nt; kk++)
-					{
-						const int xi = c - H + kk;
-						if(xi >= 0 && xi < Rn) acc += (int32_t) e->t.vf_itaps[kk] * xs[(size_t) xi];
-					}
-					acc >>= 15;
-					acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
-				}
-				else acc = c >= 0 && c < Rn ? xs[(size_t) c] : 0;
-				in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);
-			}
-		}
-		else
-		{
-		HIPCHK(hipMemcpyAsync(x.data(), e->d_S + (size_t) k.width, (size_t) H * 2, hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipStreamSynchronize(e->stream));
-		for(int n = 0; n < P; n++)
-		{
-			int32_t acc = 0;
-			const int m = n - P;                    /* stream position of this output: -P .. -1 */
-			for(int kk = 0; kk < nt; kk++)
-			{
-				const int xi = m - H + kk;
-				if(xi >= 0 && xi < H) acc += (int32_t) e->t.vf_itaps[kk] * x[xi];
-			}
-			acc >>= 15;
-			acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
-			in[n] = (int16_t) (acc + e->fm_prime_car[(size_t) n * 2]);     /* int16 wrap-around add, src/video.c:3431 */
-		}
-		}
-		r = hvk_tail_fm_prime(e->tail, in.data(), P);
-		if(r != HVK_OK) { e->poisoned = 1; return(r); }      /* the sound chain is past these samples: the stream cannot go on */
-		e->fm_prime_pending = 0;
-	}
-	return(HVK_OK);
-}
-
-extern "C" int hvk_render_strided(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes,
-                                  const int32_t *slots, void *d_iq)
-{
-	int r = hvk_stage_strided(e, first_frame, stride, nframes, slots);
-	if(r != HVK_OK) return(r);
-	return(hvk_launch(e, d_iq));
-}
-
-extern "C" int hvk_render(hvk_engine_t *e, int nframes, const int32_t *slots, void *d_iq)
-{
-	if(!e) return(HVK_ERROR);
-	int r = hvk_render_strided(e, e->next_frame, 1, nframes, slots, d_iq);
-	if(r == HVK_OK) e->next_frame += nframes;
-	return(r);
-}
-
-extern "C" int hvk_sync(hvk_engine_t *e)
-{
-	if(!e) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	return(HVK_OK);
-}
-
-extern "C" int hvk_fetch(hvk_engine_t *e, int16_t *iq, size_t first, size_t count)
-{
-	if(!e || !iq) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
-	HIPCHK(hipSetDevice(e->device));
-	if(e->t.k.fm_video)
-	{
-		/* (what went out through hvk_fetch_async() was modulated in the caller's buffer: it is not here) */
-		if(first < e->fm_async_upto) return(HVK_ERROR);
-		int r = _fm_upto(e, first + count);
-		if(r != HVK_OK) return(r);
-		memcpy(iq, e->h_fm + first * 2, count * 4);
-		return(HVK_OK);
-	}
-	HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	return(HVK_OK);
-}
-
-extern "C" int hvk_fetch_async(hvk_engine_t *e, int16_t *iq, size_t first, size_t count)
-{
-	if(!e || !iq) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
-	HIPCHK(hipSetDevice(e->device));
-	const int t = e->fetch_next;
-	/* a ticket goes out again only when its last copy has been waited for: a caller with more than HVK_FETCH_TICKETS
-	 * copies in flight would otherwise wait on the wrong one */
-	if(e->fetch_busy[t]) return(HVK_ERROR);
-	e->fetch_next = (e->fetch_next + 1) % HVK_FETCH_TICKETS;
-	if(e->t.k.fm_video && e->fm_thread && first == e->fm_done && e->fm_launched && count > 0)
-	{
-		/* the FM phasor runs on the host (see hvk_fetch()): the modulator's input goes into the caller's buffer, the
-		 * engine's FM thread turns it into the output there once the copy is through -- in stream order, behind the
-		 * jobs queued before. The caller's thread goes on */
-		HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
-		{
-			std::lock_guard<std::mutex> lk(*e->fm_mu);
-			e->fm_status[t] = HVK_OK;
-			e->fm_q->push_back({ t, e->fm_batch_pos + (int64_t) first, (int64_t) count, iq, e->fetch_ev[t] });
-		}
-		e->fm_cv->notify_all();
-		e->fm_done = first + count;
-		e->fm_async_upto = e->fm_done;
-		if(e->fm_done == (size_t) e->last_samples) e->fm_launched = 0;
-		e->fetch_busy[t] = 2;
-		return(t);
-	}
-	if(e->t.k.fm_video)
-	{
-		/* (out of order, or with --passthru, whose queue the caller's thread fills: in this call) */
-		int r = hvk_fetch(e, iq, first, count);
-		if(r != HVK_OK) return(r);
-	}
-	/* (one copy moves a block at the link's rate -- 56 GB/s, profiles/r05_d2h_speed.txt; in two halves on two streams it is no
-	 * faster. What halves the rate is the FIRST copy into a fresh page-locked buffer: a caller keeps its buffers) */
-	else HIPCHK(hipMemcpyAsync(iq, e->d_out + first * 2, count * 4, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(hipEventRecord(e->fetch_ev[t], e->stream));
-	e->fetch_busy[t] = 1;
-	return(t);
-}
-
-extern "C" int hvk_fetch_wait(hvk_engine_t *e, int ticket)
-{
-	if(!e || ticket < 0 || ticket >= HVK_FETCH_TICKETS) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(!e->fetch_busy[ticket]) return(HVK_ERROR);
-	if(e->fetch_busy[ticket] == 2)
-	{
-		/* a job of the FM thread's */
-		std::unique_lock<std::mutex> lk(*e->fm_mu);
-		e->fm_cv->wait(lk, [e, ticket] { for(const auto &j : *e->fm_q) if(j.ticket == ticket) return(false); return(true); });
-		e->fetch_busy[ticket] = 0;
-		return(e->fm_status[ticket]);
-	}
-	HIPCHK(hipEventSynchronize(e->fetch_ev[ticket]));
-	e->fetch_busy[ticket] = 0;
-	return(HVK_OK);
-}
-
-extern "C" void *hvk_host_alloc(hvk_engine_t *e, size_t bytes)
-{
-	void *p = NULL;
-	if(!e || e->device < 0 || bytes == 0) return(NULL);
-	if(hipSetDevice(e->device) != hipSuccess) return(NULL);
-	if(hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return(NULL);
-	return(p);
-}
-
-extern "C" void hvk_host_free(hvk_engine_t *e, void *p)
-{
-	(void) e;
-	if(p) (void) hipHostFree(p);
-}
-
-extern "C" long hvk_fetch_as(hvk_engine_t *e, void *dst, size_t first, size_t count, int type, int complex_out)
-{
-	if(!e || !dst || type < HVK_UINT8 || type > HVK_FLOAT) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(e->t.k.fm_video) return(HVK_UNSUPPORTED);   /* the final samples are not on the device */
-	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
-
-	const size_t unit = (type <= HVK_INT8 ? 1 : (type <= HVK_INT16 ? 2 : 4)) * (complex_out ? 2 : 1);
-	const size_t bytes = count * unit;
-	HIPCHK(hipSetDevice(e->device));
-
-	/* converted samples go through a scratch buffer sized on first use */
-	if(bytes > e->conv_bytes)
-	{
-		if(e->d_conv) HIPCHK(hipFree(e->d_conv));
-		e->d_conv = NULL;
-		e->conv_bytes = 0;
-		HIPCHK(hipMalloc(&e->d_conv, bytes));
-		e->conv_bytes = bytes;
-	}
-
-	int r = hvk_launch_convert(e->d_out + first * 2, count, type, complex_out != 0, e->d_conv, e->stream);
-	if(r != HVK_OK) return(r);
-	HIPCHK(hipMemcpyAsync(dst, e->d_conv, bytes, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	return((long) bytes);
-}
-
-extern "C" int hvk_fetch_raster(hvk_engine_t *e, int16_t *dst, size_t first, size_t count)
-{
-	/* frame-local raster of the last launch: frame i's samples follow frame
-	 * i - 1's; the slab's halo lines are skipped */
-	if(!e || !dst) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	const hvk_kconst_t &k = e->t.k;
-	const size_t FS = k.raster_samples;
-	if(first + count > (size_t) e->last_frames * FS) return(HVK_ERROR);
-	HIPCHK(hipSetDevice(e->device));
-	if(e->last_direct)
-	{
-		/* the one-kernel render keeps the raster in LDS: run the raster kernel over the staged batch to have
-		 * it in HBM */
-		hvk_raster_args_t ra;
-		hvk_filter_args_t fa;
-		if(e->staged != e->last_frames) return(HVK_ERROR);
-		_kernel_args(e, &ra, &fa, NULL, 1);
-		int r = hvk_launch_raster(&ra, e->stream);
-		if(r != HVK_OK) return(r);
-	}
-	HIPCHK(hipStreamSynchronize(e->stream));
-	while(count > 0)
-	{
-		const size_t fr = first / FS, off = first % FS;
-		const size_t n = count < FS - off ? count : FS - off;
-		HIPCHK(hipMemcpy(dst, e->d_S + fr * (size_t) k.slab_lines * k.width + k.width + off, n * 2, hipMemcpyDeviceToHost));
-		dst += n; first += n; count -= n;
-	}
-	return(HVK_OK);
-}
-
 extern "C" void *hvk_output_device_ptr(hvk_engine_t *e) { return(e ? e->d_out : NULL); }
 extern "C" void *hvk_engine_stream(hvk_engine_t *e) { return(e ? (void *) e->stream : NULL); }
 extern "C" int64_t hvk_fused_launches(const hvk_engine_t *e) { return(e ? e->fused_count : 0); }
@@ -3084,25 +1390,6 @@ extern "C" int hvk_stream_is_one_chain(const hvk_engine_t *e)
 	return(k.secam || k.fm_video || k.rs_irr || k.has_passthru || k.rawbb || k.sis);
 }
 
-/* hvk_k_sums: a grid-stride pass over the words, a lane's two partial sums folded through the wave and one pair of
- * 64-bit atomic adds per wave (the sums are modulo 2^64: any order gives the same) */
-extern "C" int hvk_launch_sums(const void *iq, size_t count, unsigned long long *sums, hipStream_t stream);
-
-extern "C" int hvk_block_sums(hvk_engine_t *e, size_t first, size_t count, uint64_t sums[2])
-{
-	if(!e || !sums) return(HVK_ERROR);
-	if(e->device < 0) return(HVK_NO_DEVICE);
-	if(e->t.k.fm_video) return(HVK_UNSUPPORTED);
-	if(first + count > (size_t) e->last_samples) return(HVK_ERROR);
-	HIPCHK(hipSetDevice(e->device));
-	if(!e->d_sums) HIPCHK(hipMalloc((void **) &e->d_sums, 16));
-	HIPCHK(hipMemsetAsync(e->d_sums, 0, 16, e->stream));
-	int r = hvk_launch_sums(e->d_out + first * 2, count, (unsigned long long *) e->d_sums, e->stream);
-	if(r != HVK_OK) return(r);
-	HIPCHK(hipMemcpyAsync(sums, e->d_sums, 16, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(hipStreamSynchronize(e->stream));
-	return(HVK_OK);
-}
 
 /* The kernels hvk_launch() enqueues for this configuration, as rocprofv3 prints them, ';' between
  * them: the launchers' choice of template arguments restated (hvk_kernels.hip, hvk_direct.hip). */
@@ -3190,3 +1477,4 @@ extern "C" int hvk_timing_read(hvk_engine_t *e, int which, double *avg_ms, int64
 	if(launches) *launches = e->t_n[which];
 	return(HVK_OK);
 }
+

@@ -102,7 +102,7 @@ typedef struct {
 	int32_t rs_shift;       /* resampled-stream index (frame local) of output sample 0's filter centre */
 	int32_t rs_irr;         /* a raster frame does not resample to a whole number of samples (858 x 525 at 13.5 -> 16 MHz): frames
 	                         * of floor / ceil length, frame f's first output sample ceil(f * raster_samples * L / D); frame_samples is the
-	                         * longer of the two lengths. A staged batch is then ONE run of samples (hvk_engine.cpp) */
+	                         * longer of the two lengths. A staged batch is then ONE run of samples (hvk_engine_stage.cpp) */
 	int32_t secam;          /* SECAM: luma notch + the FM sub-carrier stream (hvk_secam.hip; hvk_secam.c where the device does not take it) */
 	int32_t teletext;       /* teletext symbol table present */
 	int32_t vbi;            /* VBI data lines (teletext / WSS / VITC ops) may be present */
@@ -125,7 +125,7 @@ typedef struct {
 	                         * picture as grey -- channel (frame * 2 + field) mod 3, frames counted from 1 (src/video.c:2919-2930, :2995-3000) */
 	int32_t fsc_split;      /* first line (1-based) of the second field for that count: 264, 202 */
 	int32_t sv_ring;        /* S-Video behind resampler + video filter where the lines have two widths: the reference pairs a line's luma
-	                         * with what ITS RING of line buffers holds in the Q channel (src/video.c:3243, :3578; hvk_k_svq, hvk_engine.cpp).
+	                         * with what ITS RING of line buffers holds in the Q channel (src/video.c:3243, :3578; hvk_k_svq, hvk_engine_launch.cpp).
 	                         * The ring's length in lines; 0: every line has one width (or no such combination) */
 	int32_t ablate;         /* profiling only (HVK_ABLATE): bit mask of stages to skip; 0 in production */
 } hvk_kconst_t;

@@ -823,7 +823,7 @@ static int _launch_raster3(const hvk_raster_args_t *a, hipStream_t stream)
 template<int NT, int SECAM, int SV, int EXTRAS, int WC>
 static int _launch_raster2(const hvk_raster_args_t *a, hipStream_t stream)
 {
-	/* levels computed per pixel or looked up: the engine decides per block of frames (hvk_engine.cpp) */
+	/* levels computed per pixel or looked up: the engine decides per block of frames (hvk_engine_stage.cpp) */
 	if(a->levels_computed) return(_launch_raster3<NT, SECAM, SV, EXTRAS, WC, 1>(a, stream));
 	return(_launch_raster3<NT, SECAM, SV, EXTRAS, WC, 0>(a, stream));
 }

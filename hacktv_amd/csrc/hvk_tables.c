@@ -1770,7 +1770,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		}
 		t->k.fm_video = 1;
 		/* (with the resampler the modulator's start-up samples come from the RESAMPLED stream -- the pipeline's chunks
-		 * before the first emitted line, src/video.c:4936-4952 with :3627-3651 --: hvk_engine.cpp primes the phasor with
+		 * before the first emitted line, src/video.c:4936-4952 with :3627-3651 --: hvk_engine_launch.cpp primes the phasor with
 		 * them) */
 	}
 
@@ -1798,7 +1798,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		 * before's width: where that is the shorter one the sub-carrier stands a sample earlier in the line, and a line a
 		 * sample longer than it ends on what the buffer held before -- the raster's sub-carrier of the line before it at that
 		 * place when resampling downwards, the end of an earlier chunk (a whole turn of the ring of line buffers back,
-		 * src/video.c:3578) when upwards. hvk_k_svq makes the Q channel line by line that way (hvk_engine.cpp has the
+		 * src/video.c:3578) when upwards. hvk_k_svq makes the Q channel line by line that way (hvk_engine_launch.cpp has the
 		 * per-line records); the oracle keeps the ring itself (oracle_video.c). */
 		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0)
 		{

@@ -246,7 +246,7 @@ class Engine:
         p = np.ascontiguousarray(packets, np.uint8)
         m = np.ascontiguousarray(masks, np.uint32)
         assert p.ndim == 3 and p.shape[1:] == (32, 45) and m.shape == (p.shape[0],)
-        return self._chk("hvk_teletext_packets_block", "hvk_kernel_plan", lib().hvk_teletext_packets_block(self.h, first_frame_in_batch, p.shape[0], p.ctypes.data, m.ctypes.data))
+        return self._chk("hvk_teletext_packets_block", lib().hvk_teletext_packets_block(self.h, first_frame_in_batch, p.shape[0], p.ctypes.data, m.ctypes.data))
 
     def line_widths(self, first_line, nlines):
         w = np.zeros(nlines, np.int32)
