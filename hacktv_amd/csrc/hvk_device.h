@@ -327,7 +327,9 @@ __device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, c
 	 * one line of one field of the three (:3043-3063) */
 	L.fsc = 0;
 	L.fsc_flag = -1;
-	if(k.fsc_mode)
+	/* (lines read from an external baseband stream are not drawn at all -- _vid_next_line_rawbb, src/video.c:2406-2446 -- and
+	 * carry no flag: tools/fuzz_parity.py 300 9090 found the engine adding one, round 5) */
+	if(k.fsc_mode && !(EXTRAS && k.rawbb))
 	{
 		const int64_t frame_no = f.frame_index + 1 + (rel < 0 ? -1 : (rel >= k.lines ? 1 : 0));
 		const int line = line0 + 1;

@@ -651,6 +651,14 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			OPENHIP(hipMalloc(&e->d_secam[6], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
 			OPENHIP(hipMalloc(&e->d_secam[7], (size_t) a.tpad * sizeof(hvk_secam_state_t)));
 			OPENHIP(hipMalloc(&e->d_secam[8], sizeof(hvk_secam_state_t) + 64));
+			if(!getenv("HVK_SECAM_NO_MID"))
+			{
+				/* what a line's walk had in hand in front of its last eight samples (a start wrong only in the values behind the
+				 * line: hvk_k_secam_redo walks those eight again, not the line) */
+				OPENHIP(hipMalloc(&e->d_secam[19], (size_t) a.tpad * sizeof(hvk_secam_mid_t)));
+				OPENHIP(hipMemset(e->d_secam[19], 0, (size_t) a.tpad * sizeof(hvk_secam_mid_t)));
+				a.mid = (hvk_secam_mid_t *) e->d_secam[19];
+			}
 			OPENHIP(hipMalloc(&e->d_secam[9], (size_t) a.tpad * 4 + 64));
 			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 4 * sizeof(int)));
 			e->secam_seeds = e->secam_cell_cache && !getenv("HVK_SECAM_NO_SEEDS");

@@ -59,7 +59,7 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[19];          /* what sa points into (freed at close) */
+	void *d_secam[20];          /* what sa points into (freed at close) */
 	int secam_walk_ok;          /* 1: hvk_k_secam_walk<0> may be taken; 2: its computed FM steps and decoded gains equal the tables' on every index (tried at open) */
 	int secam_walk_mode;        /* HVK_SECAM_WALK: -1 the engine's choice per stage, 0 the chain kernel, 1 / 2 hvk_k_secam_walk<0 / 1> */
 	int64_t secam_walk_stages[3];   /* stages that went through the chain kernel / hvk_k_secam_walk<0> / <1> */

@@ -328,6 +328,19 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			else if(++e->secam_ek_clean >= 16 && a.EK > e->secam_ek_base) { a.EK -= 8; e->secam_ek_clean = 0; }
 		}
 		if(bad == 0) break;
+		if(rounds == 0 && getenv("HVK_SECAM_DEBUG"))
+		{
+			/* which lines started wrong (a diagnostic: tools/secam_wrong_starts.py) */
+			std::vector<int> fl((size_t) a.nruns);
+			HIPCHK(hipMemcpy(fl.data(), a.flags, (size_t) a.nruns * sizeof(int), hipMemcpyDeviceToHost));
+			int shown = 0;
+			for(int r_ = 0; r_ < a.nruns && shown < 24; r_++) if(fl[(size_t) r_])
+			{
+				const int t_ = r_ * a.R, fr = t_ / a.ntasks, sl = t_ - fr * a.ntasks;
+				fprintf(stderr, "libhvk: SECAM wrong start: frame %lld of the stream, task slot %d (run %d)\n", (long long) (first_frame + fr), sl, r_);
+				shown++;
+			}
+		}
 		if(rounds == 0) e->secam_counts[1] += (int64_t) bad * a.R;
 		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
 		{

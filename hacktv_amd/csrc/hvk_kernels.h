@@ -129,6 +129,8 @@ typedef struct {
 /* SECAM colour sub-carrier on the device (hvk_secam.hip) */
 #define HVK_SECAM_WARMUP 12     /* lines walked before a task's own to find its entry state */
 #define HVK_SECAM_ROUNDS 16     /* check / redo rounds before the batch goes through the host's chain */
+typedef struct { double ix, iy; int32_t pi, pq, pad[2]; } hvk_secam_mid_t;
+
 typedef struct {
 	hvk_secam_consts_t C;
 	int lines, hline, fields, interlaced, active_left, active_width, active_lines, burst_left, burst_width;
@@ -207,6 +209,11 @@ typedef struct {
 	const uint32_t *bellz;      /* [bell_blocks][4]: {gain i | gain q << 16, q steps up, i steps up, i steps down} */
 	int bell_c0, bell_blocks;   /* the first index the blocks cover (a multiple of 32 below the deviation limits) */
 	double ph_k1;               /* the angle of one index step */
+	/* What a walk had in hand in front of its line's last chunk of 8 samples -- the IIR's two doubles and the FM phasor --, per
+	 * task. A line that started from a state whose IIR half was right and whose values behind the line were not (the estimate's
+	 * usual way of being wrong) differs from the true walk in those eight samples and the state it leaves alone: the redo
+	 * goes on from here instead of walking the line again (hvk_k_secam_redo). */
+	hvk_secam_mid_t *mid;       /* [tpad], NULL: none kept */
 } hvk_secam_args_t;
 
 #ifdef __cplusplus

@@ -462,14 +462,15 @@ __device__ __forceinline__ int16_t *out_of(const hvk_secam_args_t &a, const task
 
 typedef struct { double x, y; } dbl2_t;
 template<int PH, bool EMIT = true>
-__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out);
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out,
+                                          const bool resume = false);
 
-__device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit)
+__device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit, const bool resume = false)
 {
 	const task_view v = task_of(a, m);
 	if(!v.valid) return;
 	if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
-	if(emit) walk_fast<0, true>(a, NULL, NULL, m, v, S, out_of(a, v));
+	if(emit) walk_fast<0, true>(a, NULL, NULL, m, v, S, out_of(a, v), resume);
 	else walk_fast<0, false>(a, NULL, NULL, m, v, S, NULL);
 }
 
@@ -770,8 +771,11 @@ __device__ __forceinline__ void bell_gain(const uint4 *bz, const int c0, const i
 		vv = (int16_t) (((vi__ * (gi_)) >> 15) - ((vq__ * (gq_)) >> 15)); \
 		vv = (int16_t) ((vv * (bw_)) >> 15); } } while(0)
 
+/* resume: only the line's last chunk, from what the walk before it had in hand there (hvk_secam_args_t.mid) and the values
+ * behind the line S has now */
 template<int PH, bool EMIT>
-__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out,
+                                          const bool resume)
 {
 	const int W = a.C.W, sl = a.C.sl;
 	const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
@@ -785,8 +789,15 @@ __device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_
 	const int4 *F = (const int4 *) a.F + cm;
 	const int chunks = W / 8;
 
-	int4 nx = F[0];
-	for(int q = 0; q < chunks; q++)
+	int q = 0;
+	if(resume)
+	{
+		const hvk_secam_mid_t md = a.mid[m];
+		ix = md.ix; iy = md.iy; pi = md.pi; pq = md.pq;
+		q = chunks - 1;
+	}
+	int4 nx = F[(size_t) q * a.cpad];
+	for(; q < chunks; q++)
 	{
 		int16_t f[8], o[8];
 		int32_t c[8];
@@ -794,6 +805,12 @@ __device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_
 		if(q + 1 < chunks) nx = F[(size_t) (q + 1) * a.cpad];
 		if(q == chunks - 1)
 		{
+			if(EMIT && a.mid && !resume)
+			{
+				hvk_secam_mid_t md;
+				md.ix = ix; md.iy = iy; md.pi = pi; md.pq = pq; md.pad[0] = md.pad[1] = 0;
+				a.mid[m] = md;
+			}
 			/* the last 7: with what lies behind the line (hvk_secam_chain_line) */
 #pragma unroll
 			for(int j = 1; j < 8; j++)
@@ -969,11 +986,15 @@ void hvk_k_secam_redo(const hvk_secam_args_t a)
 			if(same_state(S, a.entry[r])) break;                                  /* from here on everything stands */
 			if(!a.flags[r] && r + 1 < a.nruns && a.flags[r + 1]) break;           /* its exit state is another lane's start */
 		}
+		/* (a start whose IIR half was right -- only the values behind the line were not: the line's last chunk again, from what
+		 * its walk had in hand there, instead of the whole line) */
+		const hvk_secam_state_t was = a.entry[r];
+		const bool tail_only = a.mid != NULL && a.R == 1 && __double_as_longlong(was.ix) == __double_as_longlong(S.ix) && __double_as_longlong(was.iy) == __double_as_longlong(S.iy);
 		a.entry[r] = S;
 		for(int m = t0; m < t1; m++)
 		{
 			if(a.seed) a.seed[seed_row(a, m)] = S;      /* (the hint the chain kernel left here came from the wrong start) */
-			run_task(a, m, S, true);
+			run_task(a, m, S, true, tail_only);
 		}
 		a.exit[r] = S;
 	}

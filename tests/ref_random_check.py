@@ -75,6 +75,10 @@ SETUPS = {
     "ntsc_sv_f_down": ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 2, 27000000),
     "ntsc_sv_f_up":   ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 13500000),
     "pal60_sv_f_18":  ("pal60", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 18000000),
+    # field-sequential colour on lines that are read from a raw baseband file: no flag pulse -- the line reader takes the raster's
+    # place (src/video.c:2406-2446 against :3043-3063); tools/fuzz_parity.py found the engine drawing one (round 5)
+    "apollofsc_rawbb": ("apollo-fsc", 13500000, 0, 0, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000}, 7, 0, {"rawbb": 500000}),
+    "cbs405_rawbb":    ("cbs405", 17496000, 0, 0, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000}, 7, 0, {"rawbb": 300000}),
     # caption pairs queue as the pictures are read -- two a frame with --interlace, none for a frame without a picture -- and leave one a frame
     "m_cc_ilace":     ("m", 13500000, R.FLAG_NOAUDIO | R.FLAG_CC608 | R.FLAG_INTERLACE, H.FLAG_NOAUDIO, {"cc608": 1, "interlace": 1}, 4, 0, {"blank": 0b100010}),
     # SECAM's first fill slot is processed before the source is read (the full active width), the second with the stream's first

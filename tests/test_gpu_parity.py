@@ -689,6 +689,41 @@ def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch)
     assert st3["host_frames"] == 0 and st3["mismatches"] <= st3["tasks"] // 100, st3
 
 
+@pytest.mark.parametrize("mode,sr,pr", [("apollo-fsc", 13500000, 0), ("apollo-fsc", 27000000, 13500000), ("cbs405", 17496000, 0)])
+def test_raw_baseband_lines_carry_no_field_sequential_flag(mode, sr, pr):
+    """Field-sequential colour with --raw-bb-file: the lines are read, not drawn (src/video.c:2406-2446), and the flag pulse
+    that marks one field in three (:3043-3063, inside the raster function) is not added -- the engine did add it
+    (tools/fuzz_parity.py 300 9090, round 5). Seven frames (every field of the colour sequence) against the oracle, which
+    tests/ref_random_check.py apollofsc_rawbb / cbs405_rawbb hold against the unmodified reference."""
+    conf = H.preset(mode, 0)
+    conf.raw_bb, conf.raw_bb_blanking_level, conf.raw_bb_white_level = 1, 2000, 21000
+    rng = np.random.default_rng(12)
+    nfr = 7
+    with H.Engine(conf, sr, device=0, max_frames=4, pixel_rate=pr) as e:
+        W, L = e.info["width"], e.info["lines"]
+        rbs = np.tile(rng.integers(300, 24000, (W * L + 311,)).astype(np.int16), nfr + 2)
+        audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
+        with oracle.Oracle(conf, sr, pr) as o:
+            o.set_audio(audio, True)
+            o.set_rawbb(rbs)
+            o.set_frame(np.zeros((0, 0), np.uint32))
+            want = o.render_lines(nfr * L)
+        e.rawbb_write(rbs)
+        got, f = [], 0
+        for n in (4, 3):
+            for i in range(n):
+                e.frame_upload(i, None)
+            while e.audio_needed(n) > 0:
+                e.audio_write(audio)
+            e.render(n, slots=list(range(n)))
+            got.append(e.fetch(0, e.frame_start(f + n) - e.frame_start(f)))
+            f += n
+    got = np.concatenate(got)
+    assert got.shape == want.shape
+    d = np.nonzero((got != want).any(axis=1))[0]
+    assert d.size == 0, "%d samples differ, first at %d (line %d)" % (d.size, d[0], d[0] // W)
+
+
 @pytest.mark.parametrize("case,batches", [("m_px135_s16", (1, 3, 1)), ("m_px135_s16", (5,)), ("ntsc_px16_s135", (2, 1, 1)), ("ntsc_px16_s135", (3, 1)),
                                           # S-Video behind resampler + filter where the lines have two widths (hvk_k_svq: the reference's ring of line
                                           # buffers; a line's old content may lie in the batch before): whole, frame by frame, uneven
