@@ -309,7 +309,7 @@ def case_section(H, g, torch, case, F, steps, warmup, device, stream, label, sta
     return res
 
 
-def dropin_section(flags, seconds=4, pin_clock=False):
+def dropin_section(flags, seconds=4, pin_clock=False, devnull_s=0):
     """The drop-in binary (the reference's own main(), av_test.c, rf_file.c, teletext.c + the video.h shim + libhvk) on
     these CLI flags: its first frames against the reference CLI's (both with the wall clock pinned where teletext needs
     it), then its steady-state rate from two run lengths."""
@@ -358,7 +358,24 @@ def dropin_section(flags, seconds=4, pin_clock=False):
         t2, _ = run(hvk, (1 + seconds) * sr * 4)
     r1, _ = run(ref, 1 * sr * 4)
     r2, _ = run(ref, 3 * sr * 4)
+    devnull = None
+    if devnull_s:
+        # the same binary writing to /dev/null for a few seconds, stopped by SIGINT: the shim's own count at exit (no pipe, no reader)
+        import re, signal
+        p = subprocess.Popen([hvk] + flags + ["-o", "/dev/null", "test"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(env, HVK_SHIM_STATS="1"), text=True)
+        time.sleep(devnull_s)
+        p.send_signal(signal.SIGINT)
+        try:
+            err = p.communicate(timeout=30)[1]
+        except subprocess.TimeoutExpired:
+            p.kill()
+            err = p.communicate()[1]
+        m = re.search(r"(\d+) frames in ([0-9.]+) s from the first line on = ([0-9.]+) Msamples/s", err or "")
+        devnull = float(m.group(3)) if m else None
     return {
+        **({"to_dev_null_Msamples_per_s": devnull,
+            "to_dev_null_note": "-o /dev/null for %d s, the shim's count at exit: the unchanged main()'s loop -- one rf_write -> fwrite -> write(2) per line -- is what is left" % devnull_s}
+           if devnull_s else {}),
         "workload": "hacktv_hvk " + " ".join(os.path.basename(f) if f.endswith(".tti") else f for f in flags) + " -o - test" + (" (time() pinned for both binaries: oracle/pin_time.c)" if pin_clock else ""),
         "parity_gate": "first %d frames of the drop-in binary's output sha256 == the reference CLI's, both run in this job" % nfr,
         "Msamples_per_s": round(seconds * sr / (t2 - t1) / 1e6, 1),
@@ -1168,7 +1185,7 @@ def main():
                                                               stage_every_step=True, teletext=True, noaudio=True),
             "4_secam_l_teletext_demo_tti_dropin": dropin_section(["-m", "l", "-s", "16000000", "--filter", "--teletext", "@REF@/demo.tti"], pin_clock=True),
             "2_noaudio": case_section(H, g, torch, "i_vsb", F, ksteps, 3, local_rank, stream, "config 2 --noaudio", fresh_e2e=True),
-            "2_noaudio_dropin": dropin_section(["-m", "i", "-s", "16000000", "--filter", "--noaudio"]),
+            "2_noaudio_dropin": dropin_section(["-m", "i", "-s", "16000000", "--filter", "--noaudio"], devnull_s=5),
             "2_dropin": dropin_section(["-m", "i", "-s", "16000000", "--filter"]),
         }
         for k2, v2 in configs.items():
@@ -1258,7 +1275,7 @@ def main():
             "config4_noaudio_device_path_frac": _g(configs, "4_secam_l_teletext_noaudio_device", "path_frac"),
             "config2_noaudio_path_frac": _g(configs, "2_noaudio", "path_frac"),
             "end_to_end_Msamples_per_s": _g(e2e, "Msamples_per_s"),
-            "dropin_config2_Msamples_per_s": _g(configs, "2_dropin", "Msamples_per_s"), "dropin_config2_noaudio_Msamples_per_s": _g(configs, "2_noaudio_dropin", "Msamples_per_s"),
+            "dropin_config2_Msamples_per_s": _g(configs, "2_dropin", "Msamples_per_s"), "dropin_config2_noaudio_Msamples_per_s": _g(configs, "2_noaudio_dropin", "Msamples_per_s"), "dropin_config2_noaudio_to_dev_null_Msamples_per_s": _g(configs, "2_noaudio_dropin", "to_dev_null_Msamples_per_s"),
             "one_hour_noaudio_wall_s": _g(hour, "noaudio", "wall_s"),
             "one_hour_with_sound_wall_s": _g(hour, "with_sound", "wall_s"),
             "one_hour_with_sound_gate": _g(hour, "with_sound", "gate"),

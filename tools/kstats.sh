@@ -4,7 +4,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 D=$(mktemp -d /tmp/kstats.XXXX)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o p -- "$@" > "$D/log" 2>&1)
-tail -3 "$D/log"
+grep -v "rocprofv3\|simple_timer\|output_stream" "$D/log" | tail -8
 python - "$D" <<'P'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
