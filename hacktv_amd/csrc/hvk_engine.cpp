@@ -466,9 +466,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		if(k.s_video && !k.sv_ring) OPENHIP(hipMalloc((void **) &e->d_C2, (size_t) max_frames * k.s_stride * 2 + 256));
 		if(k.s_video && k.sv_ring)
 		{
-			/* (a line's old content can be the last sample of a chunk several turns of the ring back: that much of the stream
-			 * stays in front of the batch) */
-			e->sv_hist = ((8 * k.sv_ring + 4) * e->t.max_width + 7) & ~7;
+			/* (a line's content can begin a sample in front of the line's own place in the stream -- the batch's first line's in
+			 * front of the batch: the end of the batch before's stream stays in front of this one's) */
+			e->sv_hist = (4 * e->t.max_width + 7) & ~7;
 			const size_t n = (size_t) e->sv_hist + (size_t) max_frames * k.s_stride + 128;
 			OPENHIP(hipMalloc((void **) &e->d_C2_alloc, n * 2));
 			OPENHIP(hipMemset(e->d_C2_alloc, 0, n * 2));

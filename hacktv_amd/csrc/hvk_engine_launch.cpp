@@ -16,14 +16,17 @@ extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
 /* S-Video behind resampler + video filter, lines of two widths (hvk_kconst_t.sv_ring): the staged batch's Q channel, line by
  * line, as the reference's ring of line buffers pairs it (hvk_k_svq has the rule). Emitted line j of the stream begins at
  * S(j) = ceil((j + s) W L / D) - ceil(s W L / D), s the chunks dropped at start-up (hvk_tables_frame_start()); its content
- * is a chunk of the width of line j - 1. */
+ * is a chunk of the width of line j - 1, which began delta = w(-1) - w(j - 1) samples behind S(j) in the sub-carrier stream. */
 static int _sv_ring_q(hvk_engine *e)
 {
 	const hvk_kconst_t &k = e->t.k;
 	const int64_t s = 1 + (k.vf_type ? k.delay_lines : 0), WL = (int64_t) k.width * k.rs_L, D = k.rs_D;
 	auto S = [&](int64_t j) { return(((j + s) * WL + D - 1) / D - (s * WL + D - 1) / D); };
 	auto width = [&](int64_t j) { return((int) (S(j + 1) - S(j))); };
-	const int wmax = e->t.max_width, ring = k.sv_ring;
+	const int wmax = e->t.max_width;
+	/* (the luma stream lags the chunks by the first chunk the filter was fed and gave nothing for -- the last one dropped at
+	 * start-up: ITS width is what a content chunk's width is held against, the longer one or the shorter one as the rates have it) */
+	const int wref = s >= 1 ? width(-1) : wmax;
 	const int64_t f0 = e->staged_first, j0 = f0 * k.lines, base = S(j0);
 	const long slab_in = (long) k.slab_lines * k.width;
 	const int nlines = e->staged * k.lines;
@@ -32,7 +35,7 @@ static int _sv_ring_q(hvk_engine *e)
 	for(int i = 0; i < nlines; i++)
 	{
 		const int64_t j = j0 + i;
-		const int w = width(j), wp = j + s - 1 >= 0 ? width(j - 1) : wmax, delta = wmax - wp;
+		const int w = width(j), wp = j + s - 1 >= 0 ? width(j - 1) : wref, delta = wref - wp;       /* -1, 0 or 1 */
 		int kind = 0, src = 0;
 		if(w > wp)
 		{
@@ -49,23 +52,13 @@ static int _sv_ring_q(hvk_engine *e)
 			}
 			else
 			{
-				/* upwards: the last sample of the newest chunk of the longer width that lay in this buffer: k turns of the ring back */
-				kind = 3;       /* (none: the buffer is as it was allocated) */
-				for(int t = 1; t <= 8; t++)
-				{
-					const int64_t m = j - (int64_t) t * ring;
-					if(m + s - 1 < 0) break;
-					if(width(m - 1) == wmax)
-					{
-						const int64_t at = S(m) + (wmax - 1) - base;        /* (its delta is 0) */
-						if(at >= -(int64_t) e->sv_hist) { kind = 2; src = (int) at; }
-						break;
-					}
-				}
+				/* upwards: the raster's blanking -- it clears the whole buffer, max_width samples, before it writes its (shorter)
+				 * line there (src/video.c:2934-2939 with :3645-3646), and nothing has written that place since */
+				kind = 3;
 			}
 		}
 		e->h_svrec[4 * i + 0] = (int) (S(j) - base);
-		e->h_svrec[4 * i + 1] = w | (delta << 16) | (kind << 20);
+		e->h_svrec[4 * i + 1] = w | ((delta & 15) << 16) | (kind << 20);
 		e->h_svrec[4 * i + 2] = src;
 		e->h_svrec[4 * i + 3] = 0;
 	}
@@ -74,6 +67,7 @@ static int _sv_ring_q(hvk_engine *e)
 	if(r != HVK_OK) return(r);
 	e->sv_tail_first = f0;
 	e->sv_tail_total = e->staged_samples;
+	e->sv_tail_frames = e->staged;
 	return(HVK_OK);
 }
 
@@ -82,12 +76,28 @@ static int _sv_ring_q(hvk_engine *e)
 static int _sv_ring_keep(hvk_engine *e)
 {
 	const hvk_kconst_t &k = e->t.k;
+	int16_t *const at = e->d_C2 + k.s_lead;         /* the batch's first sample; the sv_hist samples in front of it are the stream before */
+	const int64_t H = e->sv_hist, T = e->sv_tail_total;
 	if(e->sv_tail_first < 0 || e->sv_tail_first == e->staged_first) return(HVK_OK);
-	if(e->sv_tail_total >= e->sv_hist)
+	if(e->sv_tail_first + e->sv_tail_frames != e->staged_first)
 	{
-		HIPCHK(hipMemcpyAsync(e->d_C2 + k.s_lead - e->sv_hist, e->d_C2 + k.s_lead + e->sv_tail_total - e->sv_hist, (size_t) e->sv_hist * 2, hipMemcpyDeviceToDevice, e->stream));
+		/* (not the frames behind the batch before: what lay in the line buffers is not known -- nothing, as at the stream's start) */
+		HIPCHK(hipMemsetAsync(at - H, 0, (size_t) H * 2, e->stream));
+		return(HVK_OK);
 	}
-	else HIPCHK(hipMemsetAsync(e->d_C2 + k.s_lead - e->sv_hist, 0, (size_t) e->sv_hist * 2, e->stream));
+	if(T >= H)
+	{
+		HIPCHK(hipMemcpyAsync(at - H, at + T - H, (size_t) H * 2, hipMemcpyDeviceToDevice, e->stream));
+		return(HVK_OK);
+	}
+	/* a batch shorter than what is kept: the older part moves up by the batch's length (in pieces no longer than the move: source
+	 * and destination of a piece do not overlap), the batch goes behind it */
+	for(int64_t off = 0; off < H - T; off += T)
+	{
+		const int64_t n = H - T - off < T ? H - T - off : T;
+		HIPCHK(hipMemcpyAsync(at - H + off, at - H + T + off, (size_t) n * 2, hipMemcpyDeviceToDevice, e->stream));
+	}
+	HIPCHK(hipMemcpyAsync(at - T, at, (size_t) T * 2, hipMemcpyDeviceToDevice, e->stream));
 	return(HVK_OK);
 }
 

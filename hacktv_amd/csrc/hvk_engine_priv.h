@@ -145,8 +145,8 @@ struct hvk_engine {
 	int16_t *d_C2_alloc;    /* d_C2 lies sv_hist samples inside it: the end of the batch before's stream, kept in front of this batch's */
 	int16_t *d_Cq;          /* what the filter kernel reads as Q */
 	int *h_svrec, *d_svrec; /* [max_frames * lines][4] per emitted line: first sample in the batch, width | delta << 16 | kind << 20, source of the last sample */
-	int sv_hist;
-	int64_t sv_tail_first, sv_tail_total;   /* the batch whose sub-carrier stream lies in d_C2 (first frame; -1: none), its samples */
+	int sv_hist;            /* samples of the stream kept in front of a batch */
+	int64_t sv_tail_first, sv_tail_total, sv_tail_frames;   /* the batch whose sub-carrier stream lies in d_C2 (first frame; -1: none), its samples, its frames */
 	int16_t *d_S2; void *d_rs_taps;     /* --pixelrate: the resampled stream the filter kernel reads, the poly-phase taps */
 	int16_t *d_car;
 	int32_t *d_sym;

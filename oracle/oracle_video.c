@@ -537,8 +537,8 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 			 * filter process then gives the line it finishes the width of the chunk it has just been fed (dst->width =
 			 * fir_int16_process(), src/video.c:3243). Where the widths differ from line to line (525 lines at 16 MHz:
 			 * 1017, 1017, ..., 1016) a line one sample shorter than its new width ends on what its buffer held before:
-			 * the raster's sub-carrier of the line before it at that place when resampling downwards, the end of an
-			 * earlier chunk when upwards. Hence the same ring of buffers here, written in the same order, never cleared. */
+			 * the raster's sub-carrier of the line before it at that place when resampling downwards, the raster's blanking
+			 * (zero) when upwards. Hence the same ring of buffers here, written in the same order. */
 			const int ring = s->olines > s->delay_lines + 2 ? s->olines : s->delay_lines + 2;
 			const size_t qw = (size_t) (s->max_width > W ? s->max_width : W);
 			const int16_t *cl = orc_cline_ptr(s, c);
@@ -551,8 +551,10 @@ long orc_render_lines(orc_t *s, int16_t *iq, long nlines)
 				s->rs_d2 = s->rs_L;
 			}
 			own = s->prev_q + (size_t) (c % ring) * qw;
+			/* (the raster blanks the whole buffer -- max_width samples, the resampled chunks' width where that is the larger,
+			 * src/video.c:2934-2939 with :3645-3646 -- two lines before it writes its line there) */
+			memset(own, 0, qw * sizeof(int16_t));
 			if(cl) memcpy(own, cl, W * sizeof(int16_t));
-			else memset(own, 0, W * sizeof(int16_t));
 			wq = _resample_ch(s, &s->rs_d2, s->rs_win2, own, W, s->prev_q + (size_t) ((c - 1 + ring) % ring) * qw);
 			(void) wq;      /* == w: both channels consume the same inputs from the same phase */
 			back = (int) ((c - s->delay_lines - 1 + 2 * ring) % ring);

@@ -75,6 +75,10 @@ SETUPS = {
     "ntsc_sv_f_down": ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 2, 27000000),
     "ntsc_sv_f_up":   ("ntsc", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 13500000),
     "pal60_sv_f_18":  ("pal60", 16000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 18000000),
+    # (the raster's 1017 samples a line resampled UP to rates whose lines are mostly the SHORTER of two widths: 1716 / 1717, 1144 / 1145 --
+    # tools/fuzz_parity.py seed 2718 found the engine's Q channel a sample off there)
+    "ntsc_sv_f_16_27": ("ntsc", 27000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
+    "ntsc_sv_f_16_18": ("ntsc", 18000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
     # field-sequential colour on lines that are read from a raw baseband file: no flag pulse -- the line reader takes the raster's
     # place (src/video.c:2406-2446 against :3043-3063); tools/fuzz_parity.py found the engine drawing one (round 5)
     "apollofsc_rawbb": ("apollo-fsc", 13500000, 0, 0, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000}, 7, 0, {"rawbb": 500000}),

@@ -729,6 +729,8 @@ def test_raw_baseband_lines_carry_no_field_sequential_flag(mode, sr, pr):
                                           # buffers; a line's old content may lie in the batch before): whole, frame by frame, uneven
                                           ("ntsc_sv_f_px135_s16", (4,)), ("ntsc_sv_f_px135_s16", (1, 1, 1, 1)), ("ntsc_sv_f_px135_s16", (1, 2, 1)),
                                           ("ntsc_sv_f_px18_s16", (4,)), ("ntsc_sv_f_px18_s16", (1, 1, 2)), ("pal60_sv_f_px27_s16", (3,)), ("pal60_sv_f_px27_s16", (1, 2)),
+                                          # ... and where most lines are the SHORTER of the two (the raster's 1017 samples up to 27 and 18 MHz: found by tools/fuzz_parity.py)
+                                          ("ntsc_sv_f_px16_s27", (3,)), ("ntsc_sv_f_px16_s27", (1, 1, 1)), ("ntsc_sv_f_px16_s18", (2, 1)),
                                           # FM video: the modulator's place in the stream is what the frames add up to (found by tools/fuzz_parity.py)
                                           ("ntscfm_s18_px16", (2, 2, 1)), ("ntscfm_s18_px16", (1, 3, 1)), ("ntscfm_s18_px16", (5,))])
 def test_frames_of_two_lengths(golden, case, batches):

@@ -15,7 +15,7 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 # --pixelrate: raster at the pixel rate + poly-phase resampler (the last one has lines of 870 / 871 samples)
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_rawbb_px135", "i_rawbb_px16", "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136", "m_px135_s16", "ntsc_px16_s135",
                    # S-Video behind resampler + filter, lines of two widths: the ring of line buffers (oracle/make_golden_r05.py)
-                   "ntsc_sv_f_px135_s16", "ntsc_sv_f_px18_s16", "pal60_sv_f_px27_s16"]
+                   "ntsc_sv_f_px135_s16", "ntsc_sv_f_px18_s16", "pal60_sv_f_px27_s16", "ntsc_sv_f_px16_s27", "ntsc_sv_f_px16_s18"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
 CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
 CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb"]

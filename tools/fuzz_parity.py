@@ -25,6 +25,7 @@ MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "52
 RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000000], 525: [13500000, 16000000, 14318181, 18000000, 27000000], 819: [24570000, 16380000],
          405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
 done = refused = bad = 0
+bad_lines = []
 t_start = time.time()
 case = 0
 while done < N and time.time() - t_start < LIMIT:
@@ -170,16 +171,20 @@ while done < N and time.time() - t_start < LIMIT:
             bad += 1
             if got.shape == want.shape:
                 d = np.nonzero((got != want).any(axis=1))[0]
+                bad_lines.append("(differed) " + desc)
                 print("DIFFERENT", desc, "first at sample %d (line %d), last %d, %d samples; got %s want %s; pictures %s" % (d[0], d[0] // max(e.info["width"], 1), d[-1], d.size, got[d[0]].tolist(), want[d[0]].tolist(),
                       ["none" if p is None else ("flat" if (p == p.flat[0]).all() else "varied") + " %dx%d" % (p.shape[1], p.shape[0]) for p in pics]), "interlace flags", ilace, "batches", split, flush=True)
             else:
+                bad_lines.append("(differed in shape) " + desc)
                 print("DIFFERENT", desc, "shapes", got.shape, want.shape, flush=True)
         else:
             print("equal    ", desc, flush=True)
         done += 1
     except Exception as ex:
         bad += 1
+        bad_lines.append("(error) " + desc + " " + repr(ex)[:120])
         print("ERROR    ", desc, repr(ex)[:200], flush=True)
         done += 1
+for ln in bad_lines: print(ln)
 print("%d compared, %d refused, %d bad, %.0f s" % (done, refused, bad, time.time() - t_start))
 sys.exit(1 if bad else 0)
