@@ -70,7 +70,8 @@ struct hvk_engine {
 	int secam_seeds;            /* warm-ups start from the states the picture's lines had the last time (kept per row) */
 	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
 	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */
-	int *h_secam_count;         /* pinned: failures of the last check */
+	int *h_secam_count;         /* pinned: failures of the last check [0], of the check behind a redo queued with it [1] */
+	int secam_spec_left;        /* blocks to go for which the first check brings its redo round along (a recent block had a wrong start) */
 	int secam_lanes;            /* lanes of eight waves per SIMD */
 	int secam_adapt;            /* the number of warm-up lines follows the pictures (no HVK_SECAM_WARMUP in the environment) */
 	int secam_clean, secam_patience;    /* batches without a wrong start in a row; how many of them before a line less is tried */

@@ -291,12 +291,34 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	}
 	e->secam_counts[0] += a.total;
 
+	/* Where recent blocks had lines that started wrong, the first check is followed at once by the redo round and ITS check (a redo
+	 * without failed runs returns at once): one wait for both counts instead of two -- a wrong start costs one trip to the host
+	 * less (HVK_SECAM_NO_SPEC=1: one check per wait, as before) */
+	int pending = -1;
 	for(;;)
 	{
-		if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
-		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-		HIPCHK(hipStreamSynchronize(e->stream));
-		const int bad = *e->h_secam_count;
+		int bad;
+		if(pending >= 0) { bad = pending; pending = -1; }
+		else
+		{
+			const bool spec = rounds == 0 && e->secam_spec_left > 0 && !getenv("HVK_SECAM_DEBUG");
+			if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
+			HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+			if(spec)
+			{
+				if((r = hvk_launch_secam_redo(&a, 1, e->stream)) != HVK_OK) return(r);
+				if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
+				HIPCHK(hipMemcpyAsync(e->h_secam_count + 1, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+			}
+			HIPCHK(hipStreamSynchronize(e->stream));
+			bad = e->h_secam_count[0];
+			if(spec && bad) pending = e->h_secam_count[1];
+			if(rounds == 0)
+			{
+				if(bad) e->secam_spec_left = getenv("HVK_SECAM_NO_SPEC") ? 0 : 64;
+				else if(e->secam_spec_left > 0) e->secam_spec_left--;
+			}
+		}
 		if(rounds == 0 && e->secam_adapt && !(e->secam_est && a.kf == NULL))     /* (no kept states and the estimate for every line: no warm-up length to follow) */
 		{
 			/* How many warm-up lines a start state needs depends on the pictures and costs a walk each. Exactness never
@@ -363,6 +385,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			return(HVK_OK);
 		}
 		e->secam_counts[2] += (int64_t) bad * a.R;
+		if(pending >= 0) continue;      /* (this round's redo has run, and its check) */
 		if((r = hvk_launch_secam_redo(&a, rounds, e->stream)) != HVK_OK) return(r);
 	}
 

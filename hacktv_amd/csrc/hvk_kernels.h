@@ -129,7 +129,10 @@ typedef struct {
 /* SECAM colour sub-carrier on the device (hvk_secam.hip) */
 #define HVK_SECAM_WARMUP 12     /* lines walked before a task's own to find its entry state */
 #define HVK_SECAM_ROUNDS 16     /* check / redo rounds before the batch goes through the host's chain */
-typedef struct { double ix, iy; int32_t pi, pq, pad[2]; } hvk_secam_mid_t;
+/* What a line's walk had in hand in front of the line's last eight samples: the IIR pair, the FM phasor, those eight low-pass
+ * outputs (packed) and the seven sums that the values behind the line are added to -- all that a walk of those eight samples from
+ * another set of values behind the line needs (hvk_k_secam_redo), in one 80-byte read */
+typedef struct { double ix, iy; int32_t f[4]; int32_t pi, pq, acc[7], pad[3]; } hvk_secam_mid_t;
 
 typedef struct {
 	hvk_secam_consts_t C;

@@ -462,15 +462,14 @@ __device__ __forceinline__ int16_t *out_of(const hvk_secam_args_t &a, const task
 
 typedef struct { double x, y; } dbl2_t;
 template<int PH, bool EMIT = true>
-__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out,
-                                          const bool resume = false);
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out);
 
-__device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit, const bool resume = false)
+__device__ __forceinline__ void run_task(const hvk_secam_args_t &a, const int m, hvk_secam_state_t &S, const bool emit)
 {
 	const task_view v = task_of(a, m);
 	if(!v.valid) return;
 	if(v.clear) for(int i = 0; i < 8; i++) S.tail[i] = 0;
-	if(emit) walk_fast<0, true>(a, NULL, NULL, m, v, S, out_of(a, v), resume);
+	if(emit) walk_fast<0, true>(a, NULL, NULL, m, v, S, out_of(a, v));
 	else walk_fast<0, false>(a, NULL, NULL, m, v, S, NULL);
 }
 
@@ -771,11 +770,8 @@ __device__ __forceinline__ void bell_gain(const uint4 *bz, const int c0, const i
 		vv = (int16_t) (((vi__ * (gi_)) >> 15) - ((vq__ * (gq_)) >> 15)); \
 		vv = (int16_t) ((vv * (bw_)) >> 15); } } while(0)
 
-/* resume: only the line's last chunk, from what the walk before it had in hand there (hvk_secam_args_t.mid) and the values
- * behind the line S has now */
 template<int PH, bool EMIT>
-__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out,
-                                          const bool resume)
+__device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_t *phc, const uint4 *bz, const int m, const task_view &v, hvk_secam_state_t &S, int16_t *out)
 {
 	const int W = a.C.W, sl = a.C.sl;
 	const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
@@ -789,15 +785,8 @@ __device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_
 	const int4 *F = (const int4 *) a.F + cm;
 	const int chunks = W / 8;
 
-	int q = 0;
-	if(resume)
-	{
-		const hvk_secam_mid_t md = a.mid[m];
-		ix = md.ix; iy = md.iy; pi = md.pi; pq = md.pq;
-		q = chunks - 1;
-	}
-	int4 nx = F[(size_t) q * a.cpad];
-	for(; q < chunks; q++)
+	int4 nx = F[0];
+	for(int q = 0; q < chunks; q++)
 	{
 		int16_t f[8], o[8];
 		int32_t c[8];
@@ -805,17 +794,28 @@ __device__ __forceinline__ void walk_fast(const hvk_secam_args_t &a, const dbl2_
 		if(q + 1 < chunks) nx = F[(size_t) (q + 1) * a.cpad];
 		if(q == chunks - 1)
 		{
-			if(EMIT && a.mid && !resume)
+			int32_t ac[7];
 			{
-				hvk_secam_mid_t md;
-				md.ix = ix; md.iy = iy; md.pi = pi; md.pq = pq; md.pad[0] = md.pad[1] = 0;
-				a.mid[m] = md;
+				const int4 *pa = (const int4 *) (a.acc + (size_t) cm * 8);
+				const int4 a0 = pa[0], a1 = pa[1];
+				ac[0] = a0.x; ac[1] = a0.y; ac[2] = a0.z; ac[3] = a0.w; ac[4] = a1.x; ac[5] = a1.y; ac[6] = a1.z;
+			}
+			if(EMIT && a.mid)
+			{
+				/* (five 16-byte stores) */
+				int4 *pm = (int4 *) (a.mid + m);
+				const int2 xi = __builtin_bit_cast(int2, ix), yi = __builtin_bit_cast(int2, iy);
+				pm[0] = make_int4(xi.x, xi.y, yi.x, yi.y);
+				pm[1] = nx;
+				pm[2] = make_int4(pi, pq, ac[0], ac[1]);
+				pm[3] = make_int4(ac[2], ac[3], ac[4], ac[5]);
+				pm[4] = make_int4(ac[6], 0, 0, 0);
 			}
 			/* the last 7: with what lies behind the line (hvk_secam_chain_line) */
 #pragma unroll
 			for(int j = 1; j < 8; j++)
 			{
-				int32_t s = a.acc[(size_t) cm * 8 + (j - 1)];
+				int32_t s = ac[j - 1];
 #pragma unroll
 				for(int i = 0; i < j; i++) s += (int32_t) S.tail[i] * a.C.fir[15 + i - j];      /* (tap W + 7 + i - x, x = W - 8 + j) */
 				s >>= 15;
@@ -971,6 +971,201 @@ __global__ void hvk_k_secam_check(const hvk_secam_args_t a)
  * corrected exit state makes the next run's start wrong too). It stops in front of a run that passed and is followed
  * by a failed one: that run's exit state is what another lane of this launch starts from. Whatever is left
  * inconsistent -- that case, hvk_k_secam_check finds it -- is next round's. */
+/* A line again from a start that differs from the one it had only in the values behind the line (the IIR pair equal to the bit):
+ * those values enter the line's last eight samples and what the line leaves, nothing else. From the record its walk left
+ * (hvk_secam_mid_t) -- read, with the task's record and the start the line had, while the line BEFORE is worked on (redo_pre):
+ * nothing of it depends on the state handed on --, the two table entries of the steps past the line asked for at once (their
+ * indices are the values behind the line), so that a line of a stretch costs one dependent read: the eight samples' entries. */
+struct redo_pre_t {
+	hvk_secam_state_t entry;
+	hvk_secam_task_t q;
+	int4 m0, m1, m2, m3, m4;
+	int flag, flag_next, cbase;
+};
+
+__device__ __forceinline__ redo_pre_t redo_pre(const hvk_secam_args_t &a, const int r)
+{
+	redo_pre_t p;
+	const int i = r / a.ntasks, slot = r - i * a.ntasks;
+	const int parity = (int) ((a.first_frame + i + 1) & 1);
+	p.entry = a.entry[r];
+	p.q = a.tasks[parity * a.ntasks + slot];
+	const int4 *pm = (const int4 *) (a.mid + r);
+	p.m0 = pm[0]; p.m1 = pm[1]; p.m2 = pm[2]; p.m3 = pm[3]; p.m4 = pm[4];
+	p.flag = a.flags[r];
+	p.flag_next = r + 1 < a.nruns ? a.flags[r + 1] : 0;
+	p.cbase = a.cbase[i] + slot;        /* the task's row in the cell stores */
+	return(p);
+}
+
+__device__ __forceinline__ void redo_tail(const hvk_secam_args_t &a, const redo_pre_t &p, const task_view &v, hvk_secam_state_t &S, int16_t *out)
+{
+	const int W = a.C.W, sl = a.C.sl;
+	const int32_t dmin32 = a.C.dmin[v.dr], dmax32 = a.C.dmax[v.dr];
+	const int32_t level = a.C.level;
+	const int fm_end = v.sr < W ? v.sr : W;
+	const int x0 = W - 8;
+
+	/* the steps past the line: their table entries now */
+	hvk_secam_c32_t tst[HVK_SECAM_TAIL];
+	hvk_secam_c16_t tg[HVK_SECAM_TAIL];
+#pragma unroll
+	for(int i = 0; i < HVK_SECAM_TAIL; i++)
+	{
+		if(W + i < v.sr)
+		{
+			const int32_t c = med3i((int32_t) S.tail[i], dmin32, dmax32);
+			tst[i] = a.lut[c + 32768];
+			tg[i] = a.bell[(uint16_t) (int16_t) c];
+		}
+	}
+
+	double ix = __builtin_bit_cast(double, make_int2(p.m0.x, p.m0.y)), iy = __builtin_bit_cast(double, make_int2(p.m0.z, p.m0.w));
+	int32_t pi = p.m2.x, pq = p.m2.y;
+	const int32_t ac[7] = { p.m2.z, p.m2.w, p.m3.x, p.m3.y, p.m3.z, p.m3.w, p.m4.x };
+	int16_t f[8], o[8];
+	int32_t c[8];
+	unpack8(p.m1, f);
+#pragma unroll
+	for(int j = 1; j < 8; j++)
+	{
+		int32_t s = ac[j - 1];
+#pragma unroll
+		for(int i = 0; i < j; i++) s += (int32_t) S.tail[i] * a.C.fir[15 + i - j];
+		s >>= 15;
+		f[j] = (int16_t) (s < INT16_MIN ? INT16_MIN : (s > INT16_MAX ? INT16_MAX : s));
+	}
+#pragma unroll
+	for(int j = 0; j < 8; j++)
+	{
+		const double in = (double) f[j];
+		const double t0 = in * 2.90456054;
+		const double t1 = ix * -2.80912108;
+		const double t2 = iy * -0.90456054;
+		iy = (t0 + t1) - t2;
+		ix = in;
+		c[j] = med3i(round_away_nb(iy), dmin32, dmax32);
+	}
+	if(x0 + 8 > sl && x0 < fm_end)
+	{
+		int4 tq[8];
+#pragma unroll
+		for(int j = 0; j < 8; j++) tq[j] = ((const int4 *) a.lutb)[(unsigned) (c[j] + 32768)];
+		const int16_t *bw = a.burst_win + (x0 - sl);
+		constexpr bool EMIT = true;
+#pragma unroll
+		for(int j = 0; j < 8; j++)
+		{
+			const int x = x0 + j;
+			int16_t vv = 0;
+			if(x >= sl && x < fm_end)
+			{
+				const int32_t si = tq[j].x, sq = tq[j].y, gi = (int16_t) tq[j].z, gq = (int16_t) (tq[j].z >> 16);
+				WALK_FM(si, sq, gi, gq, bw[j]);
+			}
+			o[j] = vv;
+		}
+	}
+	else
+	{
+#pragma unroll
+		for(int j = 0; j < 8; j++) o[j] = 0;
+	}
+	if(out) *(int4 *) (out + x0) = pack8(o);
+
+	S.ix = ix;
+	S.iy = iy;
+#pragma unroll
+	for(int i = 0; i < HVK_SECAM_TAIL; i++)
+	{
+		if(W + i < v.sr)
+		{
+			/* hvk_secam_fm_step() with the entries at hand */
+			const int64_t ni = (int64_t) pi * tst[i].i - (int64_t) pq * tst[i].q;
+			const int64_t nq = (int64_t) pi * tst[i].q + (int64_t) pq * tst[i].i;
+			pi = (int32_t) (ni >> 31);
+			pq = (int32_t) (nq >> 31);
+			const int32_t vi = ((pi >> 16) * level) >> 15, vq = ((pq >> 16) * level) >> 15;
+			S.tail[i] = (int16_t) (((vi * tg[i].i) >> 15) - ((vq * tg[i].q) >> 15));
+		}
+	}
+}
+
+/* A line again from a start whose IIR pair differs from the one it had (by a unit of the last place or two: the seven samples
+ * in front of it changed): the IIR alone from both starts side by side. Its pole is 0.90456 -- over changing input the two
+ * are equal to the bit after a few hundred samples (equal doubles stay equal), and if every table index of the FM window on the
+ * way was the same for both, the line's walk from there on, the FM phasor and every output up to there are what they were: true. A differing
+ * index, or no agreement in front of the line's last eight samples: false (the whole line is walked). */
+__device__ __forceinline__ bool redo_converges(const hvk_secam_args_t &a, const int cm, const int32_t dmin32, const int32_t dmax32, const int fm_end,
+                                               const hvk_secam_state_t &was, const hvk_secam_state_t &S)
+{
+	const int4 *F = (const int4 *) a.F + cm;
+	const int last = a.C.W / 8 - 1;
+	double ax = was.ix, ay = was.iy, bx = S.ix, by = S.iy;
+	int4 ring[4];
+#pragma unroll
+	for(int q = 0; q < 4; q++) ring[q] = F[(size_t) (q < last ? q : 0) * a.cpad];
+	for(int q = 0; q < last; q++)
+	{
+		int16_t f[8];
+		unpack8(ring[0], f);
+		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
+		if(q + 4 < last) ring[3] = F[(size_t) (q + 4) * a.cpad];
+		bool differ = false;
+#pragma unroll
+		for(int j = 0; j < 8; j++)
+		{
+			const double in = (double) f[j];
+			const double t0 = in * 2.90456054;
+			const double u1 = ax * -2.80912108, u2 = ay * -0.90456054;
+			const double w1 = bx * -2.80912108, w2 = by * -0.90456054;
+			ay = (t0 + u1) - u2;
+			by = (t0 + w1) - w2;
+			ax = in;
+			bx = in;
+			/* (an index is looked at inside the FM window only: in front of it -- the sync pulse and the porch, where a changed
+			 * sample behind the line before still shows -- the line's outputs are zero whatever it is) */
+			const int x = q * 8 + j;
+			differ = differ || (x >= a.C.sl && x < fm_end && med3i(round_away_nb(ay), dmin32, dmax32) != med3i(round_away_nb(by), dmin32, dmax32));
+		}
+		if(differ) return(false);
+		if(__double_as_longlong(ay) == __double_as_longlong(by)) return(true);
+	}
+	return(false);
+}
+
+/* (task_of() from a record already read) */
+__device__ __forceinline__ task_view task_from(const hvk_secam_args_t &a, const int t, const hvk_secam_task_t q)
+{
+	task_view v;
+	const int i = t / a.ntasks, slot = t - i * a.ntasks;
+	const int64_t findex = a.first_frame + i;
+	v.frame = i;
+	v.fnum = findex + 1;
+	v.valid = (q.flags & HVK_SECAM_TASK_VALID) != 0;
+	if(slot < 2)
+	{
+		v.valid = findex == 0;
+		v.line = 0;
+		v.prev_line = 0;
+		v.sr = a.burst_left + a.burst_width;
+		v.clear = false;
+		v.fid = false;
+	}
+	else
+	{
+		v.line = q.line;
+		v.prev_line = q.prev_line;
+		v.sr = q.sr;
+		v.clear = (q.flags & HVK_SECAM_TASK_CLEAR) != 0;
+		v.fid = (q.flags & HVK_SECAM_TASK_FID) != 0;
+	}
+	const int n = (int) v.fnum * a.lines + v.line;
+	v.dr = n & 1;
+	v.phase_pos = n % 3 == 0;
+	return(v);
+}
+
 __global__ __launch_bounds__(64)
 void hvk_k_secam_redo(const hvk_secam_args_t a)
 {
@@ -978,6 +1173,52 @@ void hvk_k_secam_redo(const hvk_secam_args_t a)
 	if(r0 >= a.nruns || !a.flags[r0] || (r0 > 0 && a.flags[r0 - 1])) return;
 
 	hvk_secam_state_t S = r0 ? a.exit[r0 - 1] : *a.carry;
+	if(a.mid != NULL && a.R == 1)
+	{
+		/* one line a run: the stretch with the next line's records on their way while a line is worked on */
+		redo_pre_t p = redo_pre(a, r0);
+		for(int r = r0; r < a.nruns; r++)
+		{
+			if(r > r0)
+			{
+				if(same_state(S, p.entry)) break;
+				if(!p.flag && p.flag_next) break;
+			}
+			const bool iir_same = __double_as_longlong(p.entry.ix) == __double_as_longlong(S.ix) && __double_as_longlong(p.entry.iy) == __double_as_longlong(S.iy);
+			const redo_pre_t cur = p;
+#ifdef HVK_REDO_TRACE
+			printf("redo: stretch from run %d, run %d, %s (ix %d iy %d, tail %d %d -> %d %d)\n", r0, r, iir_same ? "IIR pair equal" : "IIR pair differs", (int) (__double_as_longlong(p.entry.ix) == __double_as_longlong(S.ix)), (int) (__double_as_longlong(p.entry.iy) == __double_as_longlong(S.iy)), (int) p.entry.tail[0], (int) p.entry.tail[1], (int) S.tail[0], (int) S.tail[1]);
+#endif
+			if(r + 1 < a.nruns) p = redo_pre(a, r + 1);
+			a.entry[r] = S;
+			if(a.seed) a.seed[seed_row(a, r)] = S;
+			const task_view v = task_from(a, r, cur.q);
+			if(v.valid)
+			{
+				hvk_secam_state_t was = cur.entry;
+				if(v.clear) for(int i = 0; i < 8; i++) { S.tail[i] = 0; was.tail[i] = 0; }
+				if(iir_same || redo_converges(a, cur.cbase, a.C.dmin[v.dr], a.C.dmax[v.dr], v.sr < a.C.W ? v.sr : a.C.W, was, S))
+				{
+					bool tails_same = true;
+					for(int i = 0; i < HVK_SECAM_TAIL; i++) tails_same = tails_same && was.tail[i] == S.tail[i];
+#ifdef HVK_REDO_TRACE
+					printf("redo:    run %d: %s\n", r, tails_same ? "nothing of the line changes" : "last chunk");
+#endif
+					if(tails_same) S = a.exit[r];       /* (the line from where the two agree on is the line as it was walked) */
+					else redo_tail(a, cur, v, S, out_of(a, v));
+				}
+				else
+				{
+#ifdef HVK_REDO_TRACE
+					printf("redo:    run %d: whole line\n", r);
+#endif
+					run_task(a, r, S, true);
+				}
+			}
+			a.exit[r] = S;
+		}
+		return;
+	}
 	for(int r = r0; r < a.nruns; r++)
 	{
 		const int t0 = r * a.R, t1 = t0 + a.R < a.total ? t0 + a.R : a.total;
@@ -986,15 +1227,11 @@ void hvk_k_secam_redo(const hvk_secam_args_t a)
 			if(same_state(S, a.entry[r])) break;                                  /* from here on everything stands */
 			if(!a.flags[r] && r + 1 < a.nruns && a.flags[r + 1]) break;           /* its exit state is another lane's start */
 		}
-		/* (a start whose IIR half was right -- only the values behind the line were not: the line's last chunk again, from what
-		 * its walk had in hand there, instead of the whole line) */
-		const hvk_secam_state_t was = a.entry[r];
-		const bool tail_only = a.mid != NULL && a.R == 1 && __double_as_longlong(was.ix) == __double_as_longlong(S.ix) && __double_as_longlong(was.iy) == __double_as_longlong(S.iy);
 		a.entry[r] = S;
 		for(int m = t0; m < t1; m++)
 		{
 			if(a.seed) a.seed[seed_row(a, m)] = S;      /* (the hint the chain kernel left here came from the wrong start) */
-			run_task(a, m, S, true, tail_only);
+			run_task(a, m, S, true);
 		}
 		a.exit[r] = S;
 	}

@@ -484,6 +484,10 @@ def _secam_noisy(n, seed=11):
                                         ({"HVK_LEVELS": "compute"}, "estimate"), ({"HVK_SECAM_EST": "0"}, "device"),
                                         ({"HVK_SECAM_NO_UV_PLANE": "1"}, "estimate"), ({"HVK_DIRECT": "0"}, "estimate"),
                                         ({"HVK_SECAM_EST_LINES": "3", "HVK_SECAM_EST_RUN": "7"}, "redo"),
+                                        # (a redo round queued with the first check / asked for after it; the line's last chunk again / the whole line)
+                                        ({"HVK_SECAM_EST_LINES": "3", "HVK_SECAM_EST_RUN": "7", "HVK_SECAM_NO_SPEC": "1"}, "redo"),
+                                        ({"HVK_SECAM_EST_LINES": "3", "HVK_SECAM_EST_RUN": "7", "HVK_SECAM_NO_MID": "1"}, "redo"),
+                                        ({"HVK_SECAM_WARMUP": "5", "HVK_SECAM_NO_SPEC": "1"}, "redo"),
                                         ({"HVK_SECAM_WALK": "0"}, "estimate"), ({"HVK_SECAM_WALK": "1"}, "estimate"), ({"HVK_SECAM_WALK": "2"}, "estimate"),
                                         ({"HVK_SECAM_WALK": "2", "HVK_SECAM_NO_SEEDS": "1"}, "estimate"),
                                         ({"HVK_SECAM_WARMUP": "1", "HVK_SECAM_FORCE_FALLBACK": "1"}, "fallback")])
@@ -535,6 +539,42 @@ def test_secam_sub_carrier_on_the_device_equals_the_hosts_chain(golden, monkeypa
         assert st["host_frames"] == 0 and st["redone"] > 0, st
     else:
         assert st["host_frames"] > 0, st
+
+
+def test_secam_wrong_starts_of_the_benchs_pictures_are_redone_from_the_lines_last_samples(golden, monkeypatch):
+    """bench.py's noisy SECAM pictures (its `pictures_change_every_frame` section) have one line in four frames start from an
+    estimate whose values behind the line are a unit off: the redo round walks such a line's last eight samples from what its walk
+    left (hvk_secam_mid_t), follows the difference down the lines behind it for as long as there is one, and where a line's IIR pair
+    changed walks the IIR alone until it agrees with the line's own again (redo_converges) -- against the host's chain, 3 blocks of
+    64 frames, every sample (a digest per block); and the wrong starts are there to be redone."""
+    import hashlib
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:576, 0:832]
+    pics = []
+    for i in range(4):
+        p = (((xx * 255 // 831 + i * 17) % 256).astype(np.uint32) << 16) | (((yy * 255 // 575) % 256).astype(np.uint32) << 8) | (((xx + yy) // 3 % 256).astype(np.uint32))
+        pics.append(np.where(rng.random(p.shape) < 0.2, rng.integers(0, 1 << 24, p.shape, dtype=np.uint32), p).astype(np.uint32))
+    F = 64
+    monkeypatch.setenv("HVK_SECAM_NO_CELL_CACHE", "1")
+    def run():
+        out = []
+        with H.Engine(H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO), 16000000, device=0, max_frames=F) as e:
+            for i, p in enumerate(pics):
+                e.frame_upload(i, p)
+            for b in range(3):
+                e.stage(b * F, 1, F, slots=[i % 4 for i in range(F)])
+                e.launch()
+                out.append(hashlib.sha256(e.fetch(0, F * 640000).tobytes()).hexdigest())
+            return out, e.secam_stats()
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, _ = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    got, st = run()
+    assert got == want
+    assert st["host_frames"] == 0 and st["mismatches"] > 0 and st["redone"] > 0, st
+    monkeypatch.setenv("HVK_SECAM_NO_MID", "1")     # (the whole line again, as before round 5)
+    got, st = run()
+    assert got == want and st["host_frames"] == 0 and st["mismatches"] > 0, st
 
 
 @pytest.mark.parametrize("mode,kind", [("secam", "bars"), ("l", "flat"), ("secam-fm", "bars")])

@@ -10,5 +10,5 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 if not f: sys.exit("no kernel stats")
 for i, r in enumerate(csv.DictReader(open(f[0]))):
-    if i < 12: print("%-72s %6s avg %10.1f us  min %9.1f  max %9.1f  %5s%%" % (r["Name"][:72], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"][:5]))
+    if i < 40: print("%-72s %6s avg %10.1f us  min %9.1f  max %9.1f  %5s%%" % (r["Name"][:72], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"][:5]))
 P
