@@ -1168,7 +1168,7 @@ def main():
                                                 "(hvk_planes_refresh -> hvk_k_prep8<1, 0, LV, 1>: levels computed per pixel, luma through the 51-tap notch, (U, V) plane) before "
                                                 "cells, estimate, walk, check and render: the whole device-side cost of a new picture on every frame, uploads apart" % (4 * F)},
             "host_chain_Msamples_per_s": round(8 * FS / t_host / 1e6, 1),
-            "kernels": ["hvk_k_secam_cells", "hvk_k_secam_chain", "hvk_k_secam_check"] + names_s,
+            "kernels": ["hvk_k_secam_cells", "hvk_k_secam_est (new pictures)", "hvk_k_secam_walk<0 / 1> (hvk_k_secam_chain where warm-up lines are walked)", "hvk_k_secam_check", "hvk_k_secam_redo (lines that started wrong)"] + names_s,
             "note": "lines (of the timed steps): worked on from derived entry states / found to have started wrong / redone / frames sent through the host's chain; "
                     "the number of warm-up lines per start state follows the pictures (exactness rests on the check, not on it) and has settled over the untimed blocks",
         }
