@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/fuzz_parity.py [cases] [seed] [seconds] -- random configurations (any of the 44 mode ids, a rate the mode takes, a random
 set of the options that need no side input: --filter, --noaudio, --nonicam, A2 stereo, --pixelrate, S-Video, sound-in-syncs,
-VITS / VITC / WSS / ACP / CC608, field identification, --interlace, --offset, --swap-iq, --gamma / --level / --invert-video /
+VITS / VITC / WSS (a mode, or auto with one of six pixel aspects) / ACP / CC608, field identification (1 .. 9 lines), --nocolour, --interlace, --offset, --swap-iq, --gamma / --level / --invert-video /
 --volume, teletext packets, --passthru, --raw-bb-file, levels computed or looked up), random pictures that change every frame
 (noise, flat, gradients, none, other sizes, either field-order flag), loud sound: the engine on the GPU against the oracle (which tests/ pin to the reference), three frames
 in a random batch split, every sample. FUZZ_ONLY=text compares only the cases whose description holds the text. Configurations the engine refuses are counted, not failed. Run on the GPU box."""
@@ -18,6 +18,8 @@ LIMIT = float(sys.argv[3]) if len(sys.argv) > 3 else 240
 EXTRA = os.environ.get("FUZZ_PLAIN", "") == ""     # pictures' interlace flags, caption bytes, other batch splits (draws more random numbers)
 SIDE = os.environ.get("FUZZ_NO_SIDE", "") == ""    # --gamma / --level / --invert-video / --volume, teletext packets, --passthru, --raw-bb-file
 ONLY = os.environ.get("FUZZ_ONLY", "")      # compare only the cases whose description holds this
+MORE = os.environ.get("FUZZ_NO_MORE", "") == ""    # --nocolour, --wss auto with one of six pixel aspects, --secam-field-id-lines 1 .. 9 (drawn since the end of round 5: FUZZ_NO_MORE=1 redraws the earlier seeds' cases)
+PARS = [(1, 1), (12, 13), (16, 11), (64, 45), (4, 3), (16, 15)]
 rng = np.random.default_rng(SEED)
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
          "secam-g", "secam-fm", "secam", "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
@@ -45,8 +47,11 @@ while done < N and time.time() - t_start < LIMIT:
     for f, p in ((H.FLAG_FILTER, 0.5), (H.FLAG_NOAUDIO, 0.35), (H.FLAG_NONICAM, 0.2)):
         if rng.random() < p:
             flags |= f
+    if MORE and rng.random() < 0.1:
+        flags |= H.FLAG_NOCOLOUR
     conf = H.preset(mode, flags)
     opts = []
+    par = (12, 13)
     def maybe(name, value, p):
         if rng.random() < p:
             setattr(conf, name, value); opts.append("%s=%s" % (name, value)); return True
@@ -60,7 +65,8 @@ while done < N and time.time() - t_start < LIMIT:
         if mode in ("g", "b", "m") and not (flags & H.FLAG_NOAUDIO):
             maybe("a2stereo", 1, 0.3)
     if mode in ("l", "d", "k", "secam", "secam-fm", "secam-i", "secam-b", "secam-g"):
-        maybe("secam_field_id", 1, 0.5)
+        if maybe("secam_field_id", 1, 0.5) and MORE and rng.random() < 0.5:
+            conf.secam_field_id_lines = int(rng.integers(1, 10)); opts.append("secam_field_id_lines=%d" % conf.secam_field_id_lines)
     if mode in ("pal", "ntsc", "secam", "pal60", "525pal"):
         maybe("s_video", 1, 0.3)
     if base.output_type != 0 if hasattr(base, "output_type") else False:
@@ -75,6 +81,11 @@ while done < N and time.time() - t_start < LIMIT:
         pt = maybe("passthru", 1, 0.1)
         if lines in (625, 525) and not tt and rng.random() < 0.08:
             conf.raw_bb = 1; conf.raw_bb_blanking_level = 2000; conf.raw_bb_white_level = 21000; rb = True; opts.append("raw_bb")
+    if MORE and lines == 625 and not conf.wss and rng.random() < 0.15:
+        conf.wss = 0xFF; opts.append("wss=auto")
+    if MORE:
+        par = PARS[int(rng.integers(len(PARS)))]
+        if conf.wss == 0xFF: opts.append("par=%d:%d" % par)
     if rng.random() < 0.15: conf.swap_iq = 1; opts.append("swap_iq")
     if rng.random() < 0.15: conf.offset = int(rng.integers(-8, 9)) * 50000 or 250000; opts.append("offset=%d" % conf.offset)
     pr = 0
@@ -126,7 +137,7 @@ while done < N and time.time() - t_start < LIMIT:
                 continue
             with oracle.Oracle(conf, sr, pr) as o:
                 o.set_audio(audio, True)
-                o.set_frame_aspect(12, 13)
+                o.set_frame_aspect(*par)
                 if pti is not None: o.set_passthru(pti)
                 if rbs is not None: o.set_rawbb(rbs)
                 want = []
@@ -153,7 +164,7 @@ while done < N and time.time() - t_start < LIMIT:
                 per = 2 if conf.interlace else 1
                 for i in range(n * per):
                     e.frame_upload(i, pics[fdone * per + i], ilace[fdone * per + i])
-                    e.frame_aspect(i, 12, 13)
+                    e.frame_aspect(i, *par)
                 if cc is not None:
                     for i in range(n):
                         e.cc608_write(i, int(cc[fdone + i][0]), int(cc[fdone + i][1]))
