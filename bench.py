@@ -489,7 +489,38 @@ def c_group_timed(H, g, dist, torch, rank, devices, F, steps, warmup, noaudio, l
     N = len(devices)
     res = None
     t_steps = t_render = t_host = 0.0
-    if rank == 0:
+    failed = None
+    grp = fs = hip = root = gate = one = sync_all = t0 = None
+
+    def guarded(fn):
+        # (rank 0's part may fail -- a gate, a device call, a collective this machine has never run -- without leaving the other ranks
+        # at a barrier: the failure is reported in the JSON, `value` then stays what the ranks measured through torch.distributed)
+        nonlocal failed
+        if rank != 0 or failed:
+            return
+        try:
+            fn()
+        except (Exception, SystemExit) as ex:
+            failed = "%s: %s" % (type(ex).__name__, ex)
+            log("c_group FAILED: " + failed)
+
+    def setup():
+        nonlocal grp, fs, hip, root, gate, one, sync_all, t0, t_steps, t_render, t_host, res
+        if os.environ.get("BENCH_FAIL_C_GROUP"):      # (tests/test_gpu_block.py: what a failure of this part leaves of the line)
+            raise RuntimeError("asked to fail (BENCH_FAIL_C_GROUP)")
+        if len(set(devices)) > 1 and os.environ.get("HVK_GATHER") is None:
+            # the collective branch has never met this machine: a small round in a process of its own, with a time limit, first
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gather_probe.py"), ",".join(str(d) for d in devices)],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+                ok = pr.returncode == 0 and "BACKEND" in pr.stdout
+                log("c_group gather probe: " + (pr.stdout.strip().splitlines()[-1] if pr.stdout.strip() else "no output") + ("" if ok else " | " + pr.stderr[-300:]))
+            except subprocess.TimeoutExpired:
+                ok = False
+                log("c_group gather probe: no answer within 180 s")
+            if not ok:
+                os.environ["HVK_GATHER"] = "peer"
+                log("c_group: the gather goes by hipMemcpyPeerAsync (HVK_GATHER=peer)")
         conf = H.preset(MODE, H.FLAG_FILTER | (H.FLAG_NOAUDIO if noaudio else 0))
         grp = H.Group(conf, SAMPLE_RATE, devices, F)
         fs = grp.info["frame_samples"]
@@ -539,15 +570,16 @@ def c_group_timed(H, g, dist, torch, rank, devices, F, steps, warmup, noaudio, l
         for _ in range(warmup):
             one()
         sync_all()
-    dist.barrier()
-    if rank == 0:
+
+    def timed_steps():
+        nonlocal grp, fs, hip, root, gate, one, sync_all, t0, t_steps, t_render, t_host, res
         t0 = time.perf_counter()
         for _ in range(steps):
             one()
         sync_all()
-    torch.cuda.synchronize()
-    dist.barrier()
-    if rank == 0:
+
+    def rest():
+        nonlocal grp, fs, hip, root, gate, one, sync_all, t0, t_steps, t_render, t_host, res
         t_steps = time.perf_counter() - t0
         # beside it: the same launches without the reassembly, and with the host-direct reassembly (every engine's block
         # read back into its place in one page-locked stream buffer: N PCIe links, what a host rf_* sink wants)
@@ -575,8 +607,16 @@ def c_group_timed(H, g, dist, torch, rank, devices, F, steps, warmup, noaudio, l
         hip.hipSetDevice(devices[0])
         hip.hipFree(root)
         grp.close()
-    return t_steps, res
 
+    guarded(setup)
+    dist.barrier()
+    guarded(timed_steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    guarded(rest)
+    if failed:
+        return -1.0, {"failed": failed, "devices": list(devices)}
+    return t_steps, res
 
 def main():
     ap = argparse.ArgumentParser()
@@ -902,11 +942,18 @@ def main():
                    "render_only_Msamples_per_s": None if render_only is None else round(render_only, 1)}
         dt_c, cg_timed = c_group_timed(H, g, dist, torch, rank, [0] * N if dry else list(range(N)), F, args.steps, args.warmup, args.noaudio, log)
         tt = torch.tensor([dt_c], dtype=torch.float64, device="cpu" if dry else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        c_failed = float(tt.item()) < 0
+        tt = torch.tensor([dt_c], dtype=torch.float64, device="cpu" if dry else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        value = samples_per_step * args.steps / dt / 1e6
-        ms_per_step = dt / args.steps * 1e3
-        sub_ms = []
+        if not c_failed:
+            dt = float(tt.item())
+            value = samples_per_step * args.steps / dt / 1e6
+            ms_per_step = dt / args.steps * 1e3
+            sub_ms = []
+        else:
+            # (reported, not hidden: `value` stays the gathered figure of the torch.distributed harness above, which has its own gate)
+            log("c_group failed: `value` is the harness's")
 
     # ---- one FRESH block end to end: host pre-pass + H2D of the side inputs, render, D2H of the samples ----
     e2e = None
@@ -1310,7 +1357,7 @@ def main():
                 "samples_per_step": samples_per_step,
                 "also_measured": also,
                 **{("also_" + k_): v_ for k_, v_ in also.items()},       # (the same scalars as keys of `config` itself: a record that keeps only flat keys keeps them)
-                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, (", one process driving an engine per device (hvk_group_*), blocks gathered on the root device in the step: " + cg_timed["gather_backend"]) if cg_timed else
+                "parallelism": "frames block-cyclic over %d GPU(s)%s" % (N, (", one process driving an engine per device (hvk_group_*), blocks gathered on the root device in the step: " + cg_timed["gather_backend"]) if (cg_timed and "gather_backend" in cg_timed) else
                                                                          (", RCCL gather to rank 0 in the step, overlapped with the next block's render" if gather else "")),
             },
             "parity_gate": gate,
@@ -1320,6 +1367,7 @@ def main():
                 "c_group": cgroup,
                 "c_group_timed": cg_timed,
                 "value_from": "walk over rounds through the torch.distributed harness (--walk-rounds)" if args.walk_rounds else
+                              ("the torch.distributed harness (c_group_timed FAILED: see c_group_timed.failed)" if (cg_timed and "failed" in cg_timed) else "") or
                               "c_group_timed: rank 0 drives one engine per device through hvk_group_* (C inside libhvk), K rounds of N blocks + hvk_group_gather between barriers over all ranks",
                 "torch_harness": harness,
                 "ranks": N, "world_size": dist.get_world_size(),

@@ -123,6 +123,29 @@ def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
             raise AssertionError("%d samples differ, first at %d (line %d)" % (bad.size, bad[0], bad[0] // 1024))
 
 
+def test_a_failure_of_the_c_group_leaves_the_harness_value_and_says_so():
+    """bench.py at N > 1: rank 0's one-process part (hvk_group_*, the gather) made to fail -- the other rank is not left at a
+    barrier, the line is printed with the torch.distributed harness's gathered figure as `value`, and says which."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    require_ref(os.path.join(REF, "hacktv_ref"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+           "--dry-run-backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT, env=dict(os.environ, BENCH_FAIL_C_GROUP="1"))
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert "asked to fail" in d["multi_gpu"]["c_group_timed"]["failed"]
+    assert d["multi_gpu"]["value_from"].startswith("the torch.distributed harness")
+    assert abs(d["value"] - d["multi_gpu"]["torch_harness"]["gathered_Msamples_per_s"]) < 0.2 and d["value"] > 0
+    assert "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
+
+
 @pytest.mark.parametrize("walk", [False, True])
 def test_two_ranks_on_one_gpu_reassemble_the_reference_stream(walk):
     """bench.py's N > 1 path with the engine in it: two ranks (both on GPU 0, gloo through host memory) stage, render and
