@@ -20,6 +20,7 @@ SIDE = os.environ.get("FUZZ_NO_SIDE", "") == ""    # --gamma / --level / --inver
 ONLY = os.environ.get("FUZZ_ONLY", "")      # compare only the cases whose description holds this
 MORE = os.environ.get("FUZZ_NO_MORE", "") == ""    # --nocolour, --wss auto with one of six pixel aspects, --secam-field-id-lines 1 .. 9 (drawn since the end of round 5: FUZZ_NO_MORE=1 redraws the earlier seeds' cases)
 PARS = [(1, 1), (12, 13), (16, 11), (64, 45), (4, 3), (16, 15)]
+FRAMES = int(os.environ.get("FUZZ_FRAMES", "3"))   # frames a case (3: the batch splits of old; more: random batches of 1 .. 6 frames -- the serial chains over a longer run)
 rng = np.random.default_rng(SEED)
 MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "525pal", "m", "ntsc-i", "ntsc-fm", "ntsc", "pal60-i", "pal60", "l", "d", "k", "secam-i", "secam-b",
          "secam-g", "secam-fm", "secam", "e", "819", "a", "ntsc-a", "405-i", "405", "ntsc-405", "240-am", "240", "30-am", "30", "nbtv-am", "nbtv",
@@ -95,7 +96,7 @@ while done < N and time.time() - t_start < LIMIT:
     levels = int(rng.integers(1, 3))
     desc = "%-13s %9d px %9d flags %d %s levels %d" % (mode, sr, pr, flags, " ".join(opts), levels)
     try:
-        e = H.Engine(conf, sr, device=0, max_frames=3, pixel_rate=pr)
+        e = H.Engine(conf, sr, device=0, max_frames=3 if FRAMES == 3 else 6, pixel_rate=pr)
     except H.HvkError as err:
         refused += 1
         print("refused  ", desc, flush=True)
@@ -105,7 +106,7 @@ while done < N and time.time() - t_start < LIMIT:
             w, h = e.info["active_width"], e.info["active_lines"]
             fs = e.info["frame_samples"]
             L = e.info["lines"]
-            nfr = 3
+            nfr = FRAMES
             npic = nfr * (2 if conf.interlace else 1)
             pics = []
             for i in range(npic):
@@ -125,6 +126,12 @@ while done < N and time.time() - t_start < LIMIT:
             ilace = [int(rng.integers(3)) if EXTRA else 0 for _ in range(npic)]
             cc = rng.integers(0, 256, (nfr, 2)) if (EXTRA and conf.cc608) else None
             split = [(2, 1), (1, 2), (3,), (1, 1, 1)][int(rng.integers(4))] if EXTRA else (2, 1)
+            if FRAMES != 3:
+                split, left = [], nfr
+                while left > 0:
+                    split.append(int(min(left, rng.integers(1, 7))))
+                    left -= split[-1]
+                split = tuple(split)
             audio = rng.integers(-32768, 32768, (65536, 2)).astype(np.int16)
             ttp = [(rng.integers(0, 256, (32, 45), dtype=np.uint8), int(rng.integers(0, 1 << 32))) for _ in range(nfr)] if tt else None
             pti = rng.integers(-3000, 3000, (int(fs * 2.4) + 17, 2)).astype(np.int16) if pt else None
