@@ -19,11 +19,19 @@
  *                       line's start state on its end state shrinks by a factor of ~3 per line; K = 12). Tasks
  *                       whose warm-up reaches back to the batch's first task start from the true state carried
  *                       over from the batch before. Every lane records the state it assumed and the state it left
+ *   hvk_k_secam_est     (round 4) entry states of new pictures' lines by estimate instead of warm-up walks: the values behind
+ *                       a line from the summed angle of its FM steps, the IIR pair from a walk of the IIR alone
+ *   hvk_k_secam_walk    (round 5) one line per lane from estimated or kept entry states -- no warm-up line anywhere in the
+ *                       block --, the FM step computed and the bell filter's gain decoded from LDS (<1>) or both read from
+ *                       the table (<0>); hvk_k_secam_chain stays for runs of several lines and for warm-up walks
  *   hvk_k_secam_check   entry state of task t == exit state of task t - 1, bit for bit? By induction from the
  *                       carried state every task that passes is exact
- *   hvk_k_secam_redo    the tasks that failed walk their line again from the exit state of the task before; then
- *                       the check again, until nothing fails (a run of r wrong tasks takes r rounds; the engine gives
- *                       up after HVK_SECAM_ROUNDS and sends the batch through the host's chain)
+ *   hvk_k_secam_redo    the tasks that failed again from the exit state of the task before; then the check again, until
+ *                       nothing fails (the engine gives up after HVK_SECAM_ROUNDS and sends the batch through the host's
+ *                       chain). With one line a task: from the record the line's walk left in front of its last eight
+ *                       samples (hvk_secam_mid_t) where only the values behind the line changed, the IIR alone from both
+ *                       starts until they agree where the IIR pair changed, the whole line otherwise (round 5)
+ *   hvk_k_secam_redo_fields  from the second round on: one lane per field, a stretch of any length in one launch
  *
  * Doubles: the IIR is evaluated term by term with contraction off (this file is compiled with -ffp-contract=off),
  * like the reference's x86-64 build. */
