@@ -495,6 +495,9 @@ __device__ __forceinline__ int seed_row(const hvk_secam_args_t &a, const int m)
 
 /* ... and for the estimate, which needs the outputs to within rounding only: the products fused (the chain from sample to
  * sample is one fused multiply-add long), the index by the add of 1.5 * 2^52 */
+#ifndef EST_RING
+#define EST_RING 4       /* (8 and 12 measured: 3 % and 7 % slower -- the kernel does not wait for these reads) */
+#endif
 #define EST_STEP(in_) do { const double in__ = (in_); iy = __builtin_fma(iy, 0.90456054, __builtin_fma(in__, 2.90456054, ix * -2.80912108)); ix = in__; } while(0)
 #define EST_INDEX(iy_) med3i(__double2loint((iy_) + 6755399441055744.0), dmin32, dmax32)
 
@@ -527,11 +530,12 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 	double ix = E.ix, iy = E.iy;
 	int32_t S = 0;              /* (a line's indices: 942 of at most 14 028) */
 
-	/* (four chunks in flight: the loads are a lane's own, 16 bytes each, and nothing else hides their latency) */
+	/* (EST_RING chunks in flight: the loads are a lane's own, 16 bytes each; the kernel is not bound by them -- 8 or 12 in flight
+	 * change nothing) */
 	const int nq = a.x1 / 8;
-	int4 ring[4];
+	int4 ring[EST_RING];
 #pragma unroll
-	for(int q = 0; q < 4; q++) ring[q] = F[(size_t) (q < nq ? q : 0) * a.cpad];
+	for(int q = 0; q < EST_RING; q++) ring[q] = F[(size_t) (q < nq ? q : 0) * a.cpad];
 	const int4 last = F[(size_t) ((W - 8) / 8) * a.cpad];
 	const double iya = a.iya[cm];
 	int32_t tacc[8];
@@ -548,8 +552,9 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 	{
 		int16_t f[8];
 		unpack8(ring[0], f);
-		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
-		if(q + 4 < nq) ring[3] = F[(size_t) (q + 4) * a.cpad];
+#pragma unroll
+		for(int i = 0; i + 1 < EST_RING; i++) ring[i] = ring[i + 1];
+		if(q + EST_RING < nq) ring[EST_RING - 1] = F[(size_t) (q + EST_RING) * a.cpad];
 #pragma unroll
 		for(int j = 0; j < 8; j++) EST_STEP((double) f[j]);
 	}
@@ -557,8 +562,9 @@ __device__ __forceinline__ void est_line(const hvk_secam_args_t &a, const int m,
 	{
 		int16_t f[8];
 		unpack8(ring[0], f);
-		ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
-		if(q + 4 < nq) ring[3] = F[(size_t) (q + 4) * a.cpad];
+#pragma unroll
+		for(int i = 0; i + 1 < EST_RING; i++) ring[i] = ring[i + 1];
+		if(q + EST_RING < nq) ring[EST_RING - 1] = F[(size_t) (q + EST_RING) * a.cpad];
 #pragma unroll
 		for(int j = 0; j < 8; j++)
 		{
