@@ -79,6 +79,9 @@ SETUPS = {
     # tools/fuzz_parity.py seed 2718 found the engine's Q channel a sample off there)
     "ntsc_sv_f_16_27": ("ntsc", 27000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
     "ntsc_sv_f_16_18": ("ntsc", 18000000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
+    # (... and DOWN from them: 858 / 859, the longer line the rare one)
+    "ntsc_sv_f_16_135": ("ntsc", 13500000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
+    "pal60_sv_f_16_135": ("pal60", 13500000, R.FLAG_FILTER | R.FLAG_SVIDEO, H.FLAG_FILTER, {"s_video": 1}, 3, 16000000),
     # field-sequential colour on lines that are read from a raw baseband file: no flag pulse -- the line reader takes the raster's
     # place (src/video.c:2406-2446 against :3043-3063); tools/fuzz_parity.py found the engine drawing one (round 5)
     "apollofsc_rawbb": ("apollo-fsc", 13500000, 0, 0, {"raw_bb": 1, "raw_bb_blanking_level": 2000, "raw_bb_white_level": 21000}, 7, 0, {"rawbb": 500000}),

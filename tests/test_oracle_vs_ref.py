@@ -103,7 +103,7 @@ def test_oracle_long_run_equals_cli(golden, mode, sr, flags, pflags):
                                    "i_gamma_lvl", "m_invert", "l_level",
                                    "30_moving", "nbtv_moving", "240_moving", "405_moving", "819_moving", "apollo_mov", "cbs_moving",
                                    "secam_sv_blank", "secam_sv_16",
-                                   "l_acp_fid", "secamfm_acp_fid_px", "ntsc_sv_f_down", "ntsc_sv_f_up", "pal60_sv_f_18", "ntsc_sv_f_16_27", "ntsc_sv_f_16_18", "apollofsc_rawbb", "cbs405_rawbb", "m_cc_ilace", "secami_ilace_blank",
+                                   "l_acp_fid", "secamfm_acp_fid_px", "ntsc_sv_f_down", "ntsc_sv_f_up", "pal60_sv_f_18", "ntsc_sv_f_16_27", "ntsc_sv_f_16_18", "ntsc_sv_f_16_135", "pal60_sv_f_16_135", "apollofsc_rawbb", "cbs405_rawbb", "m_cc_ilace", "secami_ilace_blank",
                                    "secam_sv_narrow", "secam_sv_narrow14", "secam_sv_blank135"])
 def test_random_source_through_the_real_reference(setup):
     """The unmodified reference, in-process, on a source of our own (tests/ref_random_check.py): random
