@@ -253,6 +253,18 @@ void ref_set_source(ref_probe_t *p, const uint32_t *frames, int nframes, int wid
 	p->vid.av.close = _src_close;
 }
 
+/* The reference's malloc() in this build (oracle/Makefile: -Dmalloc=ref_zmalloc for its translation units): zeroed memory. The
+ * reference reads some of what it allocates before it has written it -- SECAM's chrominance buffer is malloc'd (src/video.c:4156),
+ * and the colour process's first two invocations, on the never-emitted slots in front of line 1, average their cells with the
+ * buffer's upper half (:3160) before line 1 clears it (:3095): what those two lines leave in the pre-emphasis IIR and behind the
+ * line, and with it the stream's first line with a sub-carrier, is whatever the allocator handed out. In the CLI's fresh heap that
+ * is zeros (what the oracle and the engine assume, SURVEY H2's kind); in a test process that has freed megabytes before it is not
+ * (tools/fuzz_oracle_ref.py seed 60221 found it; clang's MemorySanitizer named the read: tools/ref_msan.sh). */
+void *ref_zmalloc(size_t n)
+{
+	return(calloc(1, n ? n : 1));
+}
+
 /* The chroma filter reads up to ataps / 2 samples per channel past the 2 * width chrominance buffer: bytes
  * that belong to whatever the allocator put behind it -- in some heap layouts an object of the reference's own that
  * changes while it runs, and then no read-out before or after the run describes what the filter saw. For comparisons
@@ -428,6 +440,12 @@ long ref_table(ref_probe_t *p, const char *name, void *dst, long max_bytes)
 		/* The 8 int16s in front of the sound-in-syncs symbol table on the heap: the burst encoder's first invocation
 		 * reads them (src/vbidata.c:211-217 with a slot of no width, oracle_sis.c) */
 		return(_copy(dst, max_bytes, s->conf.sis && s->sis.lut ? (const int16_t *) s->sis.lut - 8 : NULL, 8 * sizeof(int16_t)));
+	}
+	if(strcmp(name, "chroma_buffer") == 0)
+	{
+		/* the 2 * width chrominance buffer as it stands (SECAM: the line's cells in the lower half, the line before's other
+		 * colour difference in the upper) */
+		return(_copy(dst, max_bytes, s->chrominance_buffer, s->chrominance_buffer ? (long) 2 * s->width * sizeof(int16_t) : 0));
 	}
 	if(strcmp(name, "chroma_ghost") == 0)
 	{

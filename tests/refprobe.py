@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "_ref", "libhacktv_ref.so")
+LIB_PATH = os.environ.get("HVK_REF_LIB") or os.path.join(ROOT, "oracle", "_ref", "libhacktv_ref.so")      # (HVK_REF_LIB: another build of it, e.g. one with -fsanitize=address)
 BIN_PATH = os.path.join(ROOT, "oracle", "_ref", "hacktv_ref")
 
 FLAG_FILTER, FLAG_NOAUDIO, FLAG_NONICAM, FLAG_NOCOLOUR = 1, 2, 4, 8
