@@ -658,9 +658,10 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 /* S-Video behind the resampler and the video filter where the lines have two widths (hvk_kconst_t.sv_ring; src/video.c:3243,
  * :3578): the Q channel of an emitted line is what its buffer of the reference's ring holds -- the resampled sub-carrier of
  * the line's own content, which has the width of the line BEFORE it: a sample further on (or back) in the sub-carrier stream
- * where that width is not the one the stream's alignment was set by (delta: -1, 0, 1), and a line a sample longer than that ends on the buffer's old content (src: where that
- * is found -- the raster's sub-carrier of the line before at that place, or the last sample of an earlier chunk a turn of
- * the ring back; < 0 with kind 0: nothing, zero). One workgroup per emitted line; rec[line] = { first output sample of the
+ * where that width is not the one the stream's alignment was set by (delta: -1, 0, 1), and a line a sample longer than that
+ * ends on what the buffer held (kind 1: the raster's sub-carrier of the line before at that place, src -- downwards; kind 3:
+ * the raster's blanking, zero -- upwards; kind 2, an earlier sample of the stream, is no longer made by the host). One
+ * workgroup per emitted line; rec[line] = { first output sample of the
  * line in the batch, width | delta << 16 | kind << 20, src, 0 }. C2 and Q in the batch's run of samples, s_lead in front. */
 __global__ __launch_bounds__(256) void hvk_k_svq(const int4v *__restrict__ rec, const int16_t *__restrict__ C2, const int16_t *__restrict__ Craster,
                                                  int16_t *__restrict__ Q, const int s_lead)

@@ -1795,10 +1795,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		/* With the video filter behind a resampler whose lines are not all of one width (525 lines at 16 MHz: 1017, 1017,
 		 * ..., 1016) the reference pairs a line's luma -- as many samples as the chunk the filter was last fed, dst->width =
 		 * fir_int16_process(), src/video.c:3243 -- with the sub-carrier its line buffer holds, which is the chunk of the line
-		 * before's width: where that is the shorter one the sub-carrier stands a sample earlier in the line, and a line a
-		 * sample longer than it ends on what the buffer held before -- the raster's sub-carrier of the line before it at that
-		 * place when resampling downwards, the end of an earlier chunk (a whole turn of the ring of line buffers back,
-		 * src/video.c:3578) when upwards. hvk_k_svq makes the Q channel line by line that way (hvk_engine_launch.cpp has the
+		 * before's width: where that differs from the width of the last chunk dropped at start-up the sub-carrier stands a
+		 * sample off in the line, and a line a sample longer than it ends on what the buffer held before -- the raster's
+		 * sub-carrier of the line before it at that place when resampling downwards, the raster's blanking (it clears
+		 * max_width samples, src/video.c:2934-2939) when upwards. hvk_k_svq makes the Q channel line by line that way (hvk_engine_launch.cpp has the
 		 * per-line records); the oracle keeps the ring itself (oracle_video.c). */
 		if(t->k.rs_L && t->k.vf_type && ((int64_t) t->k.width * t->k.rs_L) % t->k.rs_D != 0)
 		{
