@@ -17,8 +17,11 @@ extern "C" int hvk_set_stream(hvk_engine_t *e, void *hip_stream)
  * line, as the reference's ring of line buffers pairs it (hvk_k_svq has the rule). Emitted line j of the stream begins at
  * S(j) = ceil((j + s) W L / D) - ceil(s W L / D), s the chunks dropped at start-up (hvk_tables_frame_start()); its content
  * is a chunk of the width of line j - 1, which began delta = w(-1) - w(j - 1) samples behind S(j) in the sub-carrier stream. */
-static int _sv_ring_q(hvk_engine *e)
+int hvk_e_sv_ring_records(hvk_engine *e, int64_t first_frame, int nframes)
 {
+	/* Made when the batch is STAGED (hvk_stage_strided*), with its other side inputs: the one pinned buffer is rewritten only
+	 * after ev_staged of the stage before -- which this copy is in front of -- so a launch never reads another batch's
+	 * records, however far stage / launch / fetch calls are pipelined. */
 	const hvk_kconst_t &k = e->t.k;
 	const int64_t s = 1 + (k.vf_type ? k.delay_lines : 0), WL = (int64_t) k.width * k.rs_L, D = k.rs_D;
 	auto S = [&](int64_t j) { return(((j + s) * WL + D - 1) / D - (s * WL + D - 1) / D); };
@@ -27,10 +30,9 @@ static int _sv_ring_q(hvk_engine *e)
 	/* (the luma stream lags the chunks by the first chunk the filter was fed and gave nothing for -- the last one dropped at
 	 * start-up: ITS width is what a content chunk's width is held against, the longer one or the shorter one as the rates have it) */
 	const int wref = s >= 1 ? width(-1) : wmax;
-	const int64_t f0 = e->staged_first, j0 = f0 * k.lines, base = S(j0);
+	const int64_t f0 = first_frame, j0 = f0 * k.lines, base = S(j0);
 	const long slab_in = (long) k.slab_lines * k.width;
-	const int nlines = e->staged * k.lines;
-	if(e->staged_stride != 1) return(HVK_UNSUPPORTED);
+	const int nlines = nframes * k.lines;
 
 	for(int i = 0; i < nlines; i++)
 	{
@@ -63,9 +65,15 @@ static int _sv_ring_q(hvk_engine *e)
 		e->h_svrec[4 * i + 3] = 0;
 	}
 	HIPCHK(hipMemcpyAsync(e->d_svrec, e->h_svrec, (size_t) nlines * 16, hipMemcpyHostToDevice, e->stream));
-	int r = hvk_launch_svq(e->d_svrec, nlines, e->d_C2, e->d_C, e->d_Cq, k.s_lead, e->stream);
+	return(HVK_OK);
+}
+
+static int _sv_ring_q(hvk_engine *e)
+{
+	const hvk_kconst_t &k = e->t.k;
+	int r = hvk_launch_svq(e->d_svrec, e->staged * k.lines, e->d_C2, e->d_C, e->d_Cq, k.s_lead, e->stream);
 	if(r != HVK_OK) return(r);
-	e->sv_tail_first = f0;
+	e->sv_tail_first = e->staged_first;
 	e->sv_tail_total = e->staged_samples;
 	e->sv_tail_frames = e->staged;
 	return(HVK_OK);
@@ -78,7 +86,7 @@ static int _sv_ring_keep(hvk_engine *e)
 	const hvk_kconst_t &k = e->t.k;
 	int16_t *const at = e->d_C2 + k.s_lead;         /* the batch's first sample; the sv_hist samples in front of it are the stream before */
 	const int64_t H = e->sv_hist, T = e->sv_tail_total;
-	if(e->sv_tail_first < 0 || e->sv_tail_first == e->staged_first) return(HVK_OK);
+	if(e->sv_tail_first < 0 || (e->sv_tail_first == e->staged_first && e->sv_tail_frames == e->staged)) return(HVK_OK);       /* (the same batch launched again) */
 	if(e->sv_tail_first + e->sv_tail_frames != e->staged_first)
 	{
 		/* (not the frames behind the batch before: what lay in the line buffers is not known -- nothing, as at the stream's start) */

@@ -240,6 +240,7 @@ int hvk_e_prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t str
 int hvk_e_prep_staged(hvk_engine *e, int y0, int n, hipStream_t stream);
 int hvk_e_carry_copy(hvk_engine *e);
 int hvk_e_flush_planes(hvk_engine *e);
+int hvk_e_sv_ring_records(hvk_engine *e, int64_t first_frame, int nframes);  /* hvk_k_svq's per-line records of a batch being staged (hvk_engine_launch.cpp) */
 int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots);
 void hvk_e_kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride);
 

@@ -538,6 +538,7 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 	const hvk_kconst_t &k = e->t.k;
 	const int64_t FS = k.frame_samples;
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	if(k.sv_ring && stride != 1) return(HVK_UNSUPPORTED);       /* the ring of line buffers is walked in stream order: refused before anything is queued */
 
 	HIPCHK(hipSetDevice(e->device));
 	{
@@ -846,6 +847,11 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 	if(e->h_off) HIPCHK_P(hipMemcpyAsync(e->d_off, e->h_off, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_pass) HIPCHK_P(hipMemcpyAsync(e->d_pass, e->h_pass, (size_t) e->staged_samples * 4, hipMemcpyHostToDevice, e->stream));
 	if(e->h_frec) HIPCHK_P(hipMemcpyAsync(e->d_frec, e->h_frec, (size_t) nframes * 2 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+	if(k.sv_ring)
+	{
+		int r = hvk_e_sv_ring_records(e, first_frame, nframes);        /* (hvk_k_svq's per-line records: in front of ev_staged like every side input) */
+		if(r != HVK_OK) { e->poisoned = 1; return(r); }
+	}
 	if(e->h_sym)
 	{
 		HIPCHK_P(hipMemcpyAsync(e->d_tile, e->h_tile, (size_t) nframes * e->tiles * HVK_NICAM_ROW * 4, hipMemcpyHostToDevice, e->stream));

@@ -123,61 +123,104 @@ def test_config4_teletext_from_demo_tti_with_the_clock_pinned():
             raise AssertionError("%d samples differ, first at %d (line %d)" % (bad.size, bad[0], bad[0] // 1024))
 
 
-def test_a_failure_of_the_c_group_leaves_the_harness_value_and_says_so():
-    """bench.py at N > 1: rank 0's one-process part (hvk_group_*, the gather) made to fail -- the other rank is not left at a
-    barrier, the line is printed with the torch.distributed harness's gathered figure as `value`, and says which."""
+def _free_port():
     import socket
-    import sys
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def _last_line(stdout):
+    """The driver's view: the LAST line of stdout is the JSON object, and it is short."""
+    lines = stdout.decode().splitlines()
+    assert lines and lines[-1].startswith("{"), lines[-3:]
+    assert len(lines[-1].encode()) <= 4096
+    assert sum(1 for l in lines if l.startswith("{")) == 1
+    return json.loads(lines[-1])
+
+
+def test_bench_gpus_2_as_typed_runs_the_group_in_process():
+    """`python3 bench.py --gpus 2 --devices 0,0 ...` exactly as typed (no torch.distributed.run): one process, two engines on
+    the one GPU through hvk_group_*, round 0 gated against the reference CLI, the compact line printed last."""
+    import sys
+    require_ref(os.path.join(REF, "hacktv_ref"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "2", "--frames", "3", "--detail-out", ""]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    d = _last_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 2
+    assert "sha256 == hacktv_ref" in d["parity_gate"]
+    mg = d["multi_gpu"]
+    assert mg["engines"] == 2 and mg["gather_backend"] and mg["render_only_Msamples_per_s"] > 0
+    assert mg["host_direct_Msamples_per_s"] > 0 and mg["staged_every_round_Msamples_per_s"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["avg_launch_ms"] > 0
+
+
+def test_bench_default_line_parses_and_carries_roofline_and_cpu_baseline():
+    """N = 1 as the driver runs it (short: 3 frames, 5 steps): one compact JSON line, last on stdout, with `roofline` and
+    `cpu_baseline`; the detail in the sidecar."""
+    import sys
+    import tempfile
+    require_ref(os.path.join(REF, "hacktv_ref"))
+    with tempfile.TemporaryDirectory() as td:
+        side = os.path.join(td, "detail.json")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--frames", "3", "--settle", "0", "--detail-out", side]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+        d = _last_line(r.stdout)
+        full = json.load(open(side))
+    assert d["n_gpus"] == 1 and d["metric"].startswith("IQ Msamples/s") and d["unit"] == "Msamples/s"
+    assert "sha256 == hacktv_ref" in d["parity_gate"]
+    assert d["roofline"]["kernel"].startswith("hvk_k_direct") and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0
+    assert d["config"]["frames_per_gpu_per_step"] == 3
+    assert "baseline_configs" in full and full["baseline_configs"]["4_secam_l_teletext_noaudio_device"]["secam_lines"]["host_frames"] == 0
+
+
+def test_a_failure_of_the_c_group_leaves_the_harness_value_and_says_so():
+    """bench.py under torch.distributed.run: the one-process group beside the harness (a child process of rank 0) made to
+    fail -- the other rank is not left at a barrier, the line is printed with the harness's gathered figure, and says so."""
+    import sys
     require_ref(os.path.join(REF, "hacktv_ref"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
-           "--dry-run-backend", "gloo", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT, env=dict(os.environ, BENCH_FAIL_C_GROUP="1"))
-    out = r.stdout.decode()
-    assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
-    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert "asked to fail" in d["multi_gpu"]["c_group_timed"]["failed"]
-    assert d["multi_gpu"]["value_from"].startswith("the torch.distributed harness")
-    assert abs(d["value"] - d["multi_gpu"]["torch_harness"]["gathered_Msamples_per_s"]) < 0.2 and d["value"] > 0
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+           "--dry-run-backend", "gloo", "--no-cpu-baseline", "--detail-out", ""]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=dict(os.environ, BENCH_FAIL_C_GROUP="1"))
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    d = _last_line(r.stdout)
+    assert "asked to fail" in d["multi_gpu"]["c_group_failed"]
+    assert abs(d["value"] - d["multi_gpu"]["gathered_Msamples_per_s"]) < 0.2 and d["value"] > 0
     assert "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
 
 
 @pytest.mark.parametrize("walk", [False, True])
 def test_two_ranks_on_one_gpu_reassemble_the_reference_stream(walk):
-    """bench.py's N > 1 path with the engine in it: two ranks (both on GPU 0, gloo through host memory) stage, render and
-    send block-cyclic blocks -- the serial sound chains handed from rank to rank, each running them over its own frames only; before timing anything rank 0 hashes the stream reassembled from two rounds -- block seams
-    and round seams included -- against the reference CLI run in the same job, every rank hashes its timed block, and
-    rank 0 the gathered round. The JSON line must carry the seam gate's verdict."""
-    import socket
+    """bench.py's torch.distributed path with the engine in it: two ranks (both on GPU 0, gloo through host memory) stage,
+    render and send block-cyclic blocks -- the serial sound chains handed from rank to rank, each running them over its own
+    frames only; before timing anything rank 0 hashes the stream reassembled from two rounds -- block seams and round seams
+    included -- against the reference CLI run in the same job, every rank hashes its timed block, and rank 0 the gathered
+    round. The JSON line must carry the seam gate's verdict."""
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     require_ref(os.path.join(REF, "hacktv_ref"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
-           "--dry-run-backend", "gloo", "--no-cpu-baseline"] + (["--walk-rounds"] if walk else [])
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT)
-    out = r.stdout.decode()
-    assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-3000:]
-    line = [l for l in out.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "3",
+           "--dry-run-backend", "gloo", "--no-cpu-baseline", "--detail-out", ""] + (["--walk-rounds"] if walk else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-3000:]
+    d = _last_line(r.stdout)
     assert d["n_gpus"] == 2
     assert d["multi_gpu"]["seam_gate"] and "sha256 == reference CLI" in d["multi_gpu"]["seam_gate"]
     assert "sha256 ==" in d["parity_gate"]
     assert d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["walk_rounds"] == walk
     if not walk:
-        # the path of record at N > 1: one process, one engine per device, hvk_group_* in C; the harness beside it
-        cg = d["multi_gpu"]["c_group_timed"]
-        assert d["multi_gpu"]["value_from"].startswith("c_group_timed")
-        assert cg["engines"] == 2 and "sha256 == hacktv_ref" in cg["parity_gate"]
-        assert abs(d["value"] - cg["gathered_on_root_device_Msamples_per_s"]) < 0.2 and cg["host_direct_Msamples_per_s"] > 0
-        assert d["multi_gpu"]["torch_harness"]["gathered_Msamples_per_s"] > 0
+        # `value` is the ranks' own (launch + gather between barriers); beside it the one-process group over the same devices
+        assert abs(d["value"] - d["multi_gpu"]["gathered_Msamples_per_s"]) < 0.2
+        assert d["multi_gpu"]["c_group_gathered_Msamples_per_s"] > 0 and d["multi_gpu"]["c_group_host_direct_Msamples_per_s"] > 0
+        assert "sha256 == hacktv_ref" in d["multi_gpu"]["c_group_parity_gate"]
     if walk:
         # every step staged and rendered the next round, the sound chains went from rank to rank, and the last round
         # walked (round 3: frames 18 .. 20 on rank 0) still is the reference's

@@ -15,16 +15,16 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $PWD/bench.py"
 
-timeout 900 $BENCH $BENCH_FLAGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 $BENCH $BENCH_FLAGS --detail-out "$OUT/bench_detail.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
 
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $BENCH --steps 200 --warmup 10 --no-cpu-baseline --no-moving --no-configs > "$OUT/stats.log" 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $BENCH --steps 200 --warmup 10 --no-cpu-baseline --no-configs > "$OUT/stats.log" 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
 	i=$((i + 1))
-	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --settle 0 --no-cpu-baseline --no-moving --no-configs > "$OUT/pmc$i.log" 2>&1
+	timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o p -- $BENCH --steps 20 --warmup 2 --settle 0 --no-cpu-baseline --no-configs > "$OUT/pmc$i.log" 2>&1
 	echo "pmc pass $i ($set): exit $?"
 done
 # 5. the SECAM colour chain (hvk_secam.hip): blocks of 512 frames of the test card, of noisy pictures with the cells made per frame, and of
