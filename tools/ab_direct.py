@@ -11,7 +11,7 @@ for spec in sys.argv[1:] or [""]:
             k, v = kv.split("=", 1)
             env[k] = v
     steps = env.get("AB_STEPS", "200")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-moving", "--no-configs", "--steps", steps] + (["--noaudio"] if env.get("AB_NOAUDIO") else []),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-configs", "--detail-out", "", "--steps", steps] + (["--noaudio"] if env.get("AB_NOAUDIO") else []),
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
