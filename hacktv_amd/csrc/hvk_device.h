@@ -254,6 +254,7 @@ typedef struct {
 	int ax0, ax1, ar_eff;   /* samples [ax0, ax1) show a source pixel; luma is assigned up to ar_eff */
 	bool active, has_pix;
 	bool stream_first;      /* line 1 of the stream's first frame */
+	int chroma_row;         /* SECAM: the row of the sub-carrier store the line's frame has its colour chain's output in */
 } hvk_line_t;
 
 /* which line of which frame, without dividing the global line number: line of the field table, frame parity,
@@ -306,6 +307,7 @@ __device__ __forceinline__ hvk_line_t raster_setup_core(const hvk_kconst_t &k, c
 	L.own = own;
 	L.zero = zero;
 	L.stream_first = own && rel == 0 && f.frame_index == 0;
+	L.chroma_row = f.chroma_row;
 	L.d = d;
 	L.pal = k.colour ? L.d.pal : 0;
 
@@ -783,7 +785,7 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		if(PREP) { }                   /* (the planes hold the line without its sub-carrier: hvk_k_direct adds the frame's) */
 		else if(own && x0 + SPL <= W)
 		{
-			const int4u cv = *(const int4u *) (P.chroma + (size_t) y * k.raster_samples + (size_t) rel * W + x0);
+			const int4u cv = *(const int4u *) (P.chroma + (size_t) L.chroma_row * k.raster_samples + (size_t) rel * W + x0);
 			const int cw[4] = { cv.x, cv.y, cv.z, cv.w };
 #pragma unroll
 			for(int i = 0; i < SPL; i++)
@@ -796,7 +798,7 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 		else if(own && x0 < W)
 		{
 			/* the last, partial group of a line whose width is not a multiple of 8 */
-			const int16_t *cp = P.chroma + (size_t) y * k.raster_samples + (size_t) rel * W + x0;
+			const int16_t *cp = P.chroma + (size_t) L.chroma_row * k.raster_samples + (size_t) rel * W + x0;
 			for(int i = 0; i < SPL; i++)
 			{
 				if(x0 + i >= W) break;

@@ -65,7 +65,7 @@ __device__ __forceinline__ hvk_framedesc_t prep_fdesc(const hvk_kconst_t &k, con
 	f.clut_off0 = 0;
 	f.parity = 0;
 	f.plane_row0 = slot * k.lines;
-	f.pad = 0;
+	f.chroma_row = 0;
 	return(f);
 }
 
@@ -475,7 +475,7 @@ __device__ __forceinline__ dline_in_t direct_line_loads(const hvk_kconst_t &k, c
 
 template<int COLOUR, int OVR>
 __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_dptrs_t &D, const dline_in_t &q, const int row0_prev, const int row0_own,
-                                               const unsigned clut_off0, const int wstart, const int y)
+                                               const unsigned clut_off0, const int wstart, const int y, const int crow = 0)
 {
 	dline_t l;
 	const int row0 = q.prev ? row0_prev : row0_own;
@@ -495,7 +495,7 @@ __device__ __forceinline__ dline_t direct_line(const hvk_kconst_t &k, const hvk_
 	if(COLOUR == 2)
 	{
 		/* SECAM: the sub-carrier is the colour chain's, a slab per frame of the batch; the lines around a frame have none */
-		l.cb = (q.own && !q.zero ? y * (int) k.raster_samples + q.line0 * k.width : D.chroma_zero) - wstart;
+		l.cb = (q.own && !q.zero ? crow * (int) k.raster_samples + q.line0 * k.width : D.chroma_zero) - wstart;
 	}
 	if(COLOUR == 1 && !q.zero)
 	{
@@ -754,6 +754,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int row0_prev = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y].plane_row0);
 	const int row0_own = __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].plane_row0);
 	const unsigned clut_off0 = (unsigned) __builtin_amdgcn_readfirstlane((int) D.fdesc[2 * y + 1].clut_off0);
+	const int crow = COLOUR == 2 ? __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].chroma_row) : 0;     /* SECAM: where the frame's sub-carrier lies */
 	int b1, b2;
 	dline_t lA, lB, lC;
 	if(OVR || !TR)
@@ -765,9 +766,9 @@ void hvk_k_direct(const hvk_kconst_t k,
 		const dline_in_t qA = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA);
 		const dline_in_t qB = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 1);
 		const dline_in_t qC = direct_line_loads<COLOUR, OVR>(k, D, par_own, first, lineA + 2);
-		lA = direct_line<COLOUR, OVR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y);
-		lB = direct_line<COLOUR, OVR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y);
-		lC = direct_line<COLOUR, OVR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y);
+		lA = direct_line<COLOUR, OVR>(k, D, qA, row0_prev, row0_own, clut_off0, -xA0, y, crow);
+		lB = direct_line<COLOUR, OVR>(k, D, qB, row0_prev, row0_own, clut_off0, b1, y, crow);
+		lC = direct_line<COLOUR, OVR>(k, D, qC, row0_prev, row0_own, clut_off0, b2, y, crow);
 	}
 	else
 	{
@@ -786,7 +787,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 			const bool zero = prev && first;        /* before the stream: the filter's history is zero, not blanking */
 			l3[X].lb = zero ? D.zero_row * W + R.nws[X] : (prev ? row0_prev : row0_own) * W + R.lw[X];
 			l3[X].cb = 2 * D.creg + R.nws[X];
-			if(COLOUR == 2) l3[X].cb = (own && !zero ? y * (int) k.raster_samples + line0 * W : D.chroma_zero) + R.nws[X];
+			if(COLOUR == 2) l3[X].cb = (own && !zero ? crow * (int) k.raster_samples + line0 * W : D.chroma_zero) + R.nws[X];
 			if(COLOUR == 1 && !zero && pal != 0)
 			{
 				unsigned coff = clut_off0 + R.off[X];

@@ -566,9 +566,19 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 	if(e->t.k.secam)
 	{
 		const size_t RS = k.raster_samples;   /* the colour side stream is at the pixel rate */
-		/* (a line's worth of zeros behind the frames: what hvk_k_direct adds to the lines around a frame) */
-		OPENHIP(hipMalloc((void **) &e->d_chroma_alloc, ((size_t) max_frames * RS + k.width + 128) * 2));
-		OPENHIP(hipMemset(e->d_chroma_alloc, 0, ((size_t) max_frames * RS + k.width + 128) * 2));
+		/* The kept sub-carrier: six rows per picture slot (one per frame number modulo 6) behind the batch's rows, for as many
+		 * slots as a 32-bit sample index and a budget of 1 GB allow (hvk_engine_stage.cpp) */
+		e->secam_memo_slots = 0;
+		if(k.fields == 1 && !(getenv("HVK_SECAM_KEEP") && atoi(getenv("HVK_SECAM_KEEP")) == 0) && !getenv("HVK_SECAM_NO_CELL_CACHE") && !getenv("HVK_SECAM_NO_SEEDS") && !getenv("HVK_SECAM_HOST"))
+		{
+			int64_t rows = (int64_t) 0x7FFF0000 / (int64_t) RS - max_frames - 2;
+			if(rows > (int64_t) (1e9 / (double) (RS * 2))) rows = (int64_t) (1e9 / (double) (RS * 2));
+			e->secam_memo_slots = (int) (rows / 6 < e->frame_slots ? (rows / 6 > 0 ? rows / 6 : 0) : e->frame_slots);
+		}
+		const size_t crows = (size_t) max_frames + 6 * (size_t) e->secam_memo_slots;
+		/* (a line's worth of zeros behind the rows: what hvk_k_direct adds to the lines around a frame) */
+		OPENHIP(hipMalloc((void **) &e->d_chroma_alloc, (crows * RS + k.width + 128) * 2));
+		OPENHIP(hipMemset(e->d_chroma_alloc, 0, (crows * RS + k.width + 128) * 2));
 		e->d_chroma = e->d_chroma_alloc + 64;
 		e->chroma_par = (signed char *) malloc((size_t) max_frames);
 		if(!e->chroma_par) { hvk_close(e); return(HVK_OUT_OF_MEMORY); }
@@ -660,7 +670,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				a.mid = (hvk_secam_mid_t *) e->d_secam[19];
 			}
 			OPENHIP(hipMalloc(&e->d_secam[9], (size_t) a.tpad * 4 + 64));
-			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 4 * sizeof(int)));
+			OPENHIP(hipMalloc(&e->d_secam[10], (size_t) max_frames * 8 * sizeof(int)));
+			OPENHIP(hipMemset(e->d_secam[10], 0, (size_t) max_frames * 8 * sizeof(int)));
 			e->secam_seeds = e->secam_cell_cache && !getenv("HVK_SECAM_NO_SEEDS");
 			if(e->secam_seeds)
 			{
@@ -766,7 +777,13 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			}
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
-			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 4 * sizeof(int), hipHostMallocDefault));
+			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 8 * sizeof(int), hipHostMallocDefault));
+			memset(e->h_secam_rows, 0, (size_t) max_frames * 8 * sizeof(int));
+			if(e->secam_memo_slots > 0)
+			{
+				OPENHIP(hipMalloc(&e->d_secam[20], (size_t) 6 * e->secam_memo_slots * sizeof(hvk_secam_state_t)));
+				OPENHIP(hipMemset(e->d_secam[20], 0, (size_t) 6 * e->secam_memo_slots * sizeof(hvk_secam_state_t)));
+			}
 			OPENHIP(hipMemset(e->d_secam[8], 0, sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_count, 64, hipHostMallocDefault));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_carry, sizeof(hvk_secam_state_t), hipHostMallocDefault));
@@ -788,6 +805,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			a.seed = (hvk_secam_state_t *) e->d_secam[11];
 			a.kf = e->secam_seeds && e->secam_adapt ? a.cbase + 2 * max_frames : NULL;
 			a.sbase = a.cbase + 3 * max_frames;
+			a.orow = a.cbase + 6 * max_frames;        /* (every frame has a row; which frames take or make a kept set is the stage's to say: mflag, owner) */
+			a.mrow = a.cbase + 7 * max_frames;
+			a.seedx = (hvk_secam_state_t *) e->d_secam[20];
 			a.desc = (const hvk_linedesc_t *) e->d_desc;
 			a.pool = e->d_pool;
 			a.yuv = e->d_yuv;
@@ -1020,6 +1040,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->shown = 0;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
+	memset(s->memo_valid, 0, sizeof(s->memo_valid));
 	if(fb == NULL)
 	{
 		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
@@ -1089,6 +1110,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->shown = 0;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
+	memset(s->memo_valid, 0, sizeof(s->memo_valid));
 	if(!s->valid) return(HVK_OK);
 
 	const uint32_t *src = fb + (size_t) y * width + x;
@@ -1121,6 +1143,7 @@ extern "C" int hvk_frame_copy(hvk_engine_t *e, int slot, hvk_engine_t *from, int
 	s->shown = 0;
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
+	memset(s->memo_valid, 0, sizeof(s->memo_valid));
 	if(!f->valid) return(HVK_OK);
 
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
@@ -1150,6 +1173,7 @@ extern "C" int hvk_set_levels(hvk_engine_t *e, int mode)
 		e->slots[i].plane_dirty = 1;
 		e->slots[i].cells_valid[0] = e->slots[i].cells_valid[1] = 0;
 		memset(e->slots[i].seeds_valid, 0, sizeof(e->slots[i].seeds_valid));
+		memset(e->slots[i].memo_valid, 0, sizeof(e->slots[i].memo_valid));
 	}
 	return(HVK_OK);
 }
@@ -1329,6 +1353,15 @@ extern "C" int hvk_levels_short_form(const hvk_engine_t *e)
 extern "C" int64_t hvk_secam_estimated_stages(const hvk_engine_t *e)
 {
 	return(e && e->secam_dev ? e->secam_est_stages : 0);
+}
+
+extern "C" int hvk_secam_kept(const hvk_engine_t *e, int64_t counts[3])
+{
+	if(!e || !counts) return(HVK_ERROR);
+	counts[0] = e->secam_dev ? e->secam_memo_frames : 0;
+	counts[1] = e->secam_dev ? e->secam_memo_restarts : 0;
+	counts[2] = e->secam_dev ? e->secam_memo_slots : 0;
+	return(HVK_OK);
 }
 
 extern "C" int hvk_secam_walk_stages(const hvk_engine_t *e, int64_t counts[3])

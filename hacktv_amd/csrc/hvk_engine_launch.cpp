@@ -232,8 +232,9 @@ extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_s
 		{
 			const size_t FS = (size_t) e->t.k.frame_samples;
 			da.D.fdesc = e->d_fdesc + 2 * (size_t) y0;
-			da.D.chroma = e->d_chroma ? e->d_chroma + (size_t) y0 * e->t.k.raster_samples : NULL;
-			da.D.chroma_zero = (int) ((size_t) (e->max_frames - y0) * e->t.k.raster_samples + 16);
+			/* (SECAM: a frame's sub-carrier lies in the row its descriptor names -- hvk_framedesc_t.chroma_row, counted from the store's start) */
+			da.D.chroma = e->d_chroma;
+			da.D.chroma_zero = (int) (((size_t) e->max_frames + 6 * (size_t) e->secam_memo_slots) * e->t.k.raster_samples + 16);
 			da.D.ovr_row0 = e->ovr_row0 + y0 * e->ovr_n;
 			da.carriers = fa.carriers ? fa.carriers + (size_t) y0 * FS : NULL;
 			da.tilesyms = fa.tilesyms ? fa.tilesyms + (size_t) y0 * e->tiles * HVK_NICAM_ROW : NULL;

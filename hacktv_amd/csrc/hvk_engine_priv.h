@@ -45,6 +45,7 @@ struct hvk_slot_t {
 	int shown;                  /* ... although a block has shown it already (from the pixels, hvk_fused.hip): it stays, so its planes are worth making now */
 	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
 	int seeds_valid[6];         /* SECAM: the picture has been shown with this frame number modulo 6: its lines' entry states are kept */
+	int memo_valid[6];          /* SECAM: ... and the sub-carrier rows and states that walk left are kept whole (hvk_engine_stage.cpp: kept sub-carrier) */
 };
 
 struct hvk_engine {
@@ -59,14 +60,18 @@ struct hvk_engine {
 	/* SECAM on the device (hvk_secam.hip): tables, the transposed low-pass store, the tasks' states */
 	int secam_dev;              /* the sub-carrier is computed by the device; the host's chain is the fall-back */
 	hvk_secam_args_t sa;
-	void *d_secam[20];          /* what sa points into (freed at close) */
+	void *d_secam[21];          /* what sa points into (freed at close) */
 	int secam_walk_ok;          /* 1: hvk_k_secam_walk<0> may be taken; 2: its computed FM steps and decoded gains equal the tables' on every index (tried at open) */
 	int secam_walk_mode;        /* HVK_SECAM_WALK: -1 the engine's choice per stage, 0 the chain kernel, 1 / 2 hvk_k_secam_walk<0 / 1> */
 	int64_t secam_walk_stages[3];   /* stages that went through the chain kernel / hvk_k_secam_walk<0> / <1> */
 	int secam_est_ran, secam_ek_adapt, secam_ek_base, secam_ek_clean;      /* this stage ran the estimate; its reach (a.EK) follows the blocks */
 	int secam_est;              /* new pictures' lines start from estimated states (hvk_k_secam_est), not from warm-up walks */
 	int64_t secam_est_stages;   /* stages that ran the estimate kernel */
-	int *h_secam_rows;          /* [4][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states */
+	int *h_secam_rows;          /* [8][max_frames] pinned: the frames' rows in the cell stores, the frames whose cells are made, warm-up lines per frame, rows of the kept states;
+	                             * kept sub-carrier: frames that take their set, frames that make it, rows of the sub-carrier store, sets */
+	int secam_memo_slots;       /* picture slots whose sub-carrier is kept per frame number modulo 6 (0: none); their rows follow the batch's in d_chroma */
+	int secam_memo_off;         /* HVK_SECAM_KEEP=0, or a stage is being done again without them */
+	int64_t secam_memo_frames, secam_memo_restarts;   /* frames that took a kept set; stages done again because one did not start where its set had */
 	int secam_seeds;            /* warm-ups start from the states the picture's lines had the last time (kept per row) */
 	int secam_last_new;         /* the last staged frame showed a picture whose cells had to be made */
 	int secam_cell_cache;       /* a picture's cells are kept for the frames that show it again (one picture per frame: no --interlace) */

@@ -182,6 +182,89 @@ extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int6
  * states, then check / redo rounds until every line started from the state the line before it left. The frame
  * descriptors and pictures are on their way to the device (same stream). */
 
+static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes);
+
+/* ---- The kept sub-carrier -------------------------------------------------------------------------------------------
+ * What the colour chain makes of a frame is a function of three things: the picture's cells (kept per slot and parity already),
+ * the frame's number modulo 6 (which colour-difference signal a line carries: modulo 2; the sub-carrier's start phase,
+ * (frame * lines + line) mod 3, src/video.c:3211-3212), and the state the frame's first line starts from. A picture that stays
+ * -- the test card of BASELINE config 4, a paused source -- meets all three again and again, so the rows of a walk whose every
+ * line passed the check are KEPT, six sets per picture slot, with every line's entry state (the seeds, which the walks keep
+ * anyway) and the state behind the frame's last line. A later frame of that picture and number takes the set instead of being
+ * walked -- hvk_k_secam_walk hands the kept states to the check, which compares the frame's start with the exit of the frame
+ * before exactly as it does for every line; the render reads the kept rows (hvk_framedesc_t.chroma_row). The per-picture share
+ * of SECAM's work, as the picture planes are PAL's: by induction from the carried state a frame that passes is the walk's, bit
+ * for bit. A frame that fails sends the whole block through the chain again without kept sets (_secam_on_device).
+ *
+ * A set is made by ONE frame per block -- the last that shows the picture with that number: its `owner`, the only one whose walk
+ * writes the set's rows, seeds and exit state -- and becomes valid when that block's first check finds nothing wrong. It stops
+ * being valid when its slot gets another picture, when a block it took part in had a wrong start, when the seeds are written by
+ * anything but an owner's hvk_k_secam_walk (the chain kernel's warm-up walks, the host's chain). */
+static void _secam_kept_drop(hvk_engine_t *e, int nframes)
+{
+	for(int i = 0; i < nframes; i++) memset(e->slots[e->staged_slots[i]].memo_valid, 0, sizeof(e->slots[0].memo_valid));
+}
+
+/* decides per frame: takes a set (mflag), makes one (owner), or neither; returns the number of frames that take one */
+static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, int walk)
+{
+	hvk_secam_args_t &a = e->sa;
+	const hvk_kconst_t &k = e->t.k;
+	int *rows = e->h_secam_rows, *mflag = rows + 4 * e->max_frames, *owner = rows + 5 * e->max_frames, *orow = rows + 6 * e->max_frames, *mrow = rows + 7 * e->max_frames;
+	const int fields = k.fields;
+	int taken = 0, any = 0;
+	const bool on = e->secam_memo_slots > 0 && !e->secam_memo_off && walk > 0 && e->secam_cell_cache && e->secam_seeds && a.seed && a.seedx && fields == 1;
+
+	for(int i = 0; i < nframes; i++) { mflag[i] = owner[i] = 0; orow[i] = i; mrow[i] = 0; }
+	if(!on)
+	{
+		/* (whatever walks these frames now writes their seeds: the sets they belong to are no longer one walk's) */
+		if(e->secam_memo_slots > 0) _secam_kept_drop(e, nframes);
+	}
+	else
+	{
+		std::vector<uint8_t> made((size_t) 6 * e->secam_memo_slots, 0);
+		for(int i = nframes - 1; i >= 0; i--)
+		{
+			const int slot = e->staged_slots[i];
+			const int ph6 = (int) ((first_frame + i + 1) % 6);
+			if(slot >= e->secam_memo_slots || first_frame + i == 0) continue;       /* (the stream's first frame has the two fill slots) */
+			const int set = slot * 6 + ph6;
+			mrow[i] = set;
+			if(e->slots[slot].memo_valid[ph6])
+			{
+				mflag[i] = 1;
+				orow[i] = e->max_frames + set;
+				rows[2 * e->max_frames + i] = 0;        /* (no entry state to estimate either) */
+				taken++;
+			}
+			else if(!made[(size_t) set])
+			{
+				/* the last frame of the block with this picture and number makes the set */
+				made[(size_t) set] = 1;
+				owner[i] = 1;
+				orow[i] = e->max_frames + set;
+			}
+		}
+		for(int i = 0; i < nframes; i++) any |= mflag[i];
+	}
+	a.mflag = any ? a.cbase + 4 * e->max_frames : NULL;
+	a.owner = on ? a.cbase + 5 * e->max_frames : NULL;      /* (sets in play: nobody but an owner writes the seeds; none: every walk does, as ever) */
+	for(int i = 0; i < nframes; i++) for(int f_ = 0; f_ <= fields; f_++) e->h_fdesc[(size_t) i * (fields + 1) + f_].chroma_row = orow[i];
+	/* (the halo descriptor of a frame names the frame before's picture, never its sub-carrier: the lines around a frame carry none) */
+	HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 8 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+	HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
+	e->secam_memo_frames += taken;
+	return(taken);
+}
+
+/* the block's first check found nothing wrong: the sets its owners made are valid */
+static void _secam_kept_commit(hvk_engine_t *e, int64_t first_frame, int nframes)
+{
+	const int *owner = e->h_secam_rows + 5 * e->max_frames;
+	for(int i = 0; i < nframes; i++) if(owner[i]) e->slots[e->staged_slots[i]].memo_valid[(first_frame + i + 1) % 6] = 1;
+}
+
 static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 {
 	const hvk_kconst_t &k = e->t.k;
@@ -256,17 +339,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
 	}
 
-	/* The chain writes every line on its task list whole and never another; the list follows the frame's parity. A slab
-	 * row that was last written with the same parity has nothing to clear (blocks of even length, one after the other:
-	 * none of them), the others are cleared in runs. */
-	for(int i = 0; i < nframes; )
-	{
-		int j = i;
-		while(j < nframes && e->chroma_par[j] != (signed char) ((first_frame + j + 1) & 1)) j++;
-		if(j > i) HIPCHK(hipMemsetAsync(e->d_chroma + (size_t) i * k.raster_samples, 0, (size_t) (j - i) * k.raster_samples * 2, e->stream));
-		for(int q = i; q < j; q++) e->chroma_par[q] = (signed char) ((first_frame + q + 1) & 1);
-		i = j + 1;
-	}
+	int memo_used = 0;
 	{
 		int want = a.kf == NULL;
 		for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
@@ -285,11 +358,34 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			if(e->secam_walk_mode >= 0) walk = e->secam_walk_mode > e->secam_walk_ok ? e->secam_walk_ok : e->secam_walk_mode;
 		}
 		e->secam_walk_stages[walk]++;
+		memo_used = _secam_kept_plan(e, first_frame, nframes, walk);
+		if(memo_used < 0) return(memo_used);
+		if(memo_used > 0 && a.kf != NULL)
+		{
+			want = 0;
+			for(int i = 0; i < nframes && !want; i++) want = e->h_secam_rows[2 * e->max_frames + i] < 0;
+		}
+		/* The chain writes every line on its task list whole and never another; the list follows the frame's parity. A slab
+		 * row that was last written with the same parity has nothing to clear (blocks of even length, one after the other:
+		 * none of them), the others are cleared in runs. (A frame that takes or makes a kept set leaves its row of the batch
+		 * alone; a set's rows are always written with the one parity of its number.) */
+		{
+			const int *orow = e->h_secam_rows + 6 * e->max_frames;
+			auto stale = [&](int j) { return(orow[j] == j && e->chroma_par[j] != (signed char) ((first_frame + j + 1) & 1)); };
+			for(int i = 0; i < nframes; )
+			{
+				int j = i;
+				while(j < nframes && stale(j)) j++;
+				if(j > i) HIPCHK(hipMemsetAsync(e->d_chroma + (size_t) i * k.raster_samples, 0, (size_t) (j - i) * k.raster_samples * 2, e->stream));
+				for(int q = i; q < j; q++) e->chroma_par[q] = (signed char) ((first_frame + q + 1) & 1);
+				i = j + 1;
+			}
+		}
 		if((r = hvk_launch_secam_cells_chain(&a, e->secam_est && want, walk, e->stream)) != HVK_OK) return(r);
 		if(e->secam_est && want) e->secam_est_stages++;
 		e->secam_est_ran = e->secam_est && want;
 	}
-	e->secam_counts[0] += a.total;
+	e->secam_counts[0] += (int64_t) (nframes - (memo_used > 0 ? memo_used : 0)) * a.ntasks;     /* (lines walked: not those of frames that took a kept set) */
 
 	/* Where recent blocks had lines that started wrong, the first check is followed at once by the redo round and ITS check (a redo
 	 * without failed runs returns at once): one wait for both counts instead of two -- a wrong start costs one trip to the host
@@ -318,6 +414,22 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 				if(bad) e->secam_spec_left = getenv("HVK_SECAM_NO_SPEC") ? 0 : 64;
 				else if(e->secam_spec_left > 0) e->secam_spec_left--;
 			}
+		}
+		if(bad && memo_used > 0)
+		{
+			/* A frame that took a kept set did not start from the state the set's walk had started from (or a line elsewhere started
+			 * wrong and the repair would run on into rows that several frames of the block share): every set this block touched is
+			 * dropped and the block's chain done again, every frame walked into its own row. Nothing of the first attempt is used,
+			 * and it says nothing about how well entry states are guessed: the warm-up length is left alone. */
+			_secam_kept_drop(e, nframes);
+			e->secam_memo_restarts++;
+			e->secam_memo_off++;
+			*e->h_secam_carry = e->secam_start;
+			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
+			memset(e->chroma_par, -1, (size_t) e->max_frames);
+			r = _secam_on_device(e, first_frame, nframes);
+			e->secam_memo_off--;
+			return(r);
 		}
 		if(rounds == 0 && e->secam_adapt && !(e->secam_est && a.kf == NULL))     /* (no kept states and the estimate for every line: no warm-up length to follow) */
 		{
@@ -378,6 +490,13 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 				if(r != HVK_OK) return(r);
 			}
 			hvk_secam_get_state(e->secam, e->h_secam_carry, NULL);
+			_secam_kept_drop(e, nframes);
+			{
+				/* (the host's chain writes the batch's own rows) */
+				const int fields = k.fields;
+				for(int i = 0; i < nframes; i++) for(int f_ = 0; f_ <= fields; f_++) e->h_fdesc[(size_t) i * (fields + 1) + f_].chroma_row = i;
+				HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
+			}
 			HIPCHK_P(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
 			e->secam_counts[3] += nframes;
@@ -389,6 +508,8 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		if((r = hvk_launch_secam_redo(&a, rounds, e->stream)) != HVK_OK) return(r);
 	}
 
+	if(rounds == 0) _secam_kept_commit(e, first_frame, nframes);        /* (not a line of the block started wrong: what its owners' walks left is what a later frame may take) */
+	else _secam_kept_drop(e, nframes);
 	if((r = hvk_launch_secam_carry(&a, e->stream)) != HVK_OK) return(r);
 	HIPCHK(hipMemcpyAsync(e->h_secam_carry, a.carry, sizeof(hvk_secam_state_t), hipMemcpyDeviceToHost, e->stream));
 	return(HVK_OK);
@@ -493,6 +614,7 @@ extern "C" int hvk_planes_refresh(hvk_engine_t *e, const int32_t *slots, int n)
 	{
 		e->slots[slots[i]].cells_valid[0] = e->slots[slots[i]].cells_valid[1] = 0;
 		memset(e->slots[slots[i]].seeds_valid, 0, sizeof(e->slots[slots[i]].seeds_valid));
+		memset(e->slots[slots[i]].memo_valid, 0, sizeof(e->slots[slots[i]].memo_valid));
 	}
 	if(!e->direct) return(HVK_OK);          /* this configuration renders straight from the pictures */
 	for(int i = 0; i < n; i++) { e->slots[slots[i]].plane_dirty = 1; e->slots[slots[i]].shown = 0; }
@@ -672,6 +794,7 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 			d->fb_valid = ss->valid;
 			if(ss->valid && ss->many_colours) many = 1;
 			d->parity = (int32_t) ((d->frame_index + 1) & 1);
+			d->chroma_row = i;              /* (SECAM: the frame's place in the batch, unless the stage takes or makes a kept set: _secam_on_device) */
 			d->plane_row0 = sl * k.lines;
 			d->clut_off0 = k.colour ? (uint32_t) (((uint64_t) d->frame_index * (uint64_t) k.raster_samples) % k.clw) : 0;
 		}

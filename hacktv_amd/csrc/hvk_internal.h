@@ -142,7 +142,8 @@ typedef struct {
 	uint32_t clut_off0;     /* colour table position of the frame's first line: (frame_index * lines * width) mod clw */
 	int32_t parity;         /* (frame number) & 1 with frames counted from 1: (frame_index + 1) & 1 */
 	int32_t plane_row0;     /* picture planes (hvk_direct.hip): the row of this picture's line 0; line l is row plane_row0 + l */
-	int32_t pad;
+	int32_t chroma_row;     /* SECAM: the row of the sub-carrier store ([rows][raster_samples]) this frame's colour chain output lies in -- its place
+	                         * in the batch, or the row kept for its picture and frame number modulo 6 (hvk_engine_stage.cpp: kept sub-carrier) */
 } hvk_framedesc_t;
 
 /* Host-built tables (hvk_tables.c) */

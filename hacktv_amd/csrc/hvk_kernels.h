@@ -217,6 +217,17 @@ typedef struct {
 	 * usual way of being wrong) differs from the true walk in those eight samples and the state it leaves alone: the redo
 	 * goes on from here instead of walking the line again (hvk_k_secam_redo). */
 	hvk_secam_mid_t *mid;       /* [tpad], NULL: none kept */
+	/* The kept sub-carrier (hvk_engine_stage.cpp). What a frame's walk leaves -- every line's entry state (seed), the state behind
+	 * its last line (seedx), its rows of the sub-carrier store -- is a function of the picture's cells, the frame's number modulo 6
+	 * and the state the frame starts from. A picture that stays meets all three again: the frame then TAKES the kept rows and
+	 * states (mflag), and what is left to do is the check that the state it starts from is the one the kept walk started from
+	 * (hvk_k_secam_check, as for every line). orow: the row of `chroma` a frame's lines are written to -- its place in the batch,
+	 * or, for the frame that (re)makes a kept set (owner), the set's row; only an owner writes seed / seedx. */
+	const int *mflag;           /* [nframes] 1: the frame's lines are not walked, NULL: no frame's */
+	const int *owner;           /* [nframes] 1: the frame's walk is the one kept for its picture and frame number modulo 6 */
+	const int *orow;            /* [nframes] */
+	const int *mrow;            /* [nframes] the set's index (slot * 6 + frame number modulo 6) */
+	hvk_secam_state_t *seedx;   /* [sets] the state behind a kept frame's last task */
 } hvk_secam_args_t;
 
 #ifdef __cplusplus

@@ -465,7 +465,7 @@ __device__ __forceinline__ int4 pack8(const int16_t *o)
 __device__ __forceinline__ int16_t *out_of(const hvk_secam_args_t &a, const task_view &v)
 {
 	if(v.line < 1) return(NULL);        /* the fill slots are never seen */
-	return(a.chroma + (size_t) v.frame * a.raster_samples + (size_t) (v.line - 1) * a.C.W);
+	return(a.chroma + (size_t) (a.orow ? a.orow[v.frame] : v.frame) * a.raster_samples + (size_t) (v.line - 1) * a.C.W);
 }
 
 typedef struct { double x, y; } dbl2_t;
@@ -737,7 +737,7 @@ void hvk_k_secam_chain(const hvk_secam_args_t a)
 	a.entry[r] = S;
 	for(; m < t1; m++)
 	{
-		if(a.seed) a.seed[seed_row(a, m)] = S;
+		if(a.seed && (!a.owner || a.owner[m / a.ntasks])) a.seed[seed_row(a, m)] = S;
 		run_task(a, m, S, true);
 	}
 	a.exit[r] = S;
@@ -930,15 +930,28 @@ void hvk_k_secam_walk(const hvk_secam_args_t a)
 	}
 	const int r = blockIdx.x * WALK_THREADS + threadIdx.x;
 	if(r >= a.total) return;
+	const int fr = r / a.ntasks;
+	const bool last_task = r - fr * a.ntasks == a.ntasks - 1;
+	if(a.mflag && a.mflag[fr])
+	{
+		/* the frame takes what its picture's last walk with this frame number modulo 6 left: its lines' rows lie in the store
+		 * already, a line started from the state kept for it and left the one kept for the next (the frame's last: seedx).
+		 * Whether the frame really starts from the state that walk started from is the check's to say. */
+		const int row = seed_row(a, r);
+		a.entry[r] = a.seed[row];
+		a.exit[r] = last_task ? a.seedx[a.mrow[fr]] : a.seed[row + 1];
+		return;
+	}
+	const bool keep = !a.owner || a.owner[fr];
 
 	hvk_secam_state_t S;
-	const int kk = a.kf ? a.kf[r / a.ntasks] : (a.est ? -1 : 0);
+	const int kk = a.kf ? a.kf[fr] : (a.est ? -1 : 0);
 	if(kk < 0) est_entry(a, r, S);
 	else if(r == 0) S = *a.carry;
 	else if(a.seed) S = a.seed[seed_row(a, r)];
 	else { S.ix = 0; S.iy = 0; for(int i = 0; i < 8; i++) S.tail[i] = 0; }
 	a.entry[r] = S;
-	if(a.seed) a.seed[seed_row(a, r)] = S;
+	if(a.seed && keep) a.seed[seed_row(a, r)] = S;
 	const task_view v = task_of(a, r);
 	if(v.valid)
 	{
@@ -946,6 +959,7 @@ void hvk_k_secam_walk(const hvk_secam_args_t a)
 		walk_fast<PH>(a, (const dbl2_t *) walk_lds, walk_lds + WALK_PHC, r, v, S, out_of(a, v));
 	}
 	a.exit[r] = S;
+	if(a.owner && a.owner[fr] && last_task) a.seedx[a.mrow[fr]] = S;
 }
 
 /* every index of the deviation range: the computed FM step and the decoded gain against the tables' entries */

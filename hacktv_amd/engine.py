@@ -27,7 +27,7 @@ SYMBOLS = [
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
     "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages", "hvk_levels_short_form",
-    "hvk_sound_source_end", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block", "hvk_kernel_plan",
+    "hvk_sound_source_end", "hvk_secam_kept", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block", "hvk_kernel_plan",
 ]
 
 _lib = None
@@ -153,6 +153,7 @@ def lib():
         L.hvk_frame_copy.argtypes = [vp, i32, vp, i32]
         L.hvk_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
         L.hvk_secam_walk_stages.argtypes = [vp, vp]
+        L.hvk_secam_kept.argtypes = [vp, vp]
         L.hvk_teletext_packets_block.argtypes = [vp, i32, i32, vp, vp]
         L.hvk_kernel_plan.argtypes = [vp, C.c_char_p, i32]
         _lib = L
@@ -330,6 +331,12 @@ class Engine:
         c = (C.c_int64 * 3)()
         ok = lib().hvk_secam_walk_stages(self.h, c)
         return ok, list(c)
+
+    def secam_kept(self):
+        """{frames that took a kept sub-carrier set, stages done again without them, picture slots sets are kept for} (hvk_secam_kept)"""
+        c = (C.c_int64 * 3)()
+        self._chk("hvk_secam_kept", lib().hvk_secam_kept(self.h, c))
+        return dict(zip(("frames_taken", "restarts", "slots"), list(c)))
 
     def levels_short_form(self):
         """1: computed levels use the short arithmetic, checked at open on all 2^24 colours (hvk_levels_short_form)."""

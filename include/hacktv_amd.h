@@ -332,6 +332,15 @@ int64_t hvk_secam_estimated_stages(const hvk_engine_t *e);
  * gains on every index of the deviation range and found them equal to the tables' (src/video.c:2218-2243, :2172-2185),
  * 1 where only the table form may be taken, 0 without the device's chain. HVK_SECAM_WALK=0 / 1 / 2 forces a kernel. */
 int hvk_secam_walk_stages(const hvk_engine_t *e, int64_t counts[3]);
+/* The kept sub-carrier. What the colour chain makes of a frame (src/video.c:3068-3233) is a function of the picture's cells,
+ * the frame's number modulo 6 (D'r / D'b: modulo 2; the sub-carrier's start phase, :3211-3212: modulo 3) and the state its first
+ * line starts from. A picture that stays meets all three again, so the rows of a walk whose every line passed the check are
+ * kept per picture slot and number, with every line's entry state and the state behind the last line; a later frame of that
+ * picture and number TAKES the set instead of being walked, and the same check that every line gets -- does it start where
+ * the line before ended, bit for bit -- decides whether it may. counts[0]: frames that took a set; [1]: stages done again
+ * without kept sets because a frame did not start where its set's walk had; [2]: picture slots sets are kept for (0: none --
+ * HVK_SECAM_KEEP=0, --interlace, the host's chain). SECAM-L test card, 128-frame blocks: 170 -> see DESIGN.md section 5. */
+int hvk_secam_kept(const hvk_engine_t *e, int64_t counts[3]);
 
 /* Levels computed per pixel (hvk_set_levels(): pictures with many colours) take the short form of the arithmetic -- fused
  * multiply-adds, the scale folded into the constants, rounding by a magic addend -- where hvk_open() has TRIED it on every one
