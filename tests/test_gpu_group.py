@@ -141,7 +141,7 @@ def test_gather_between_distinct_devices(golden, monkeypatch):
     digests, with sound (the chains handed on between engines on different devices) and without."""
     nd = _device_count()
     if nd < 2:
-        pytest.skip("one HIP device: hvk_group_gather's RCCL branch needs two (tools/probe_partitions.sh says whether this box can be partitioned)")
+        pytest.skip("one HIP device: hvk_group_gather's RCCL branch needs two (the pool's boxes offer one and refuse partitioning: profiles/r05_partition_probe.txt)")
     for devs in ([0, 1], list(range(min(nd, 4)))):
         monkeypatch.delenv("HVK_GATHER", raising=False)
         for case in ("i_vsb", "i_full"):
