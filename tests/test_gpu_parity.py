@@ -764,6 +764,80 @@ def test_secam_warm_ups_seeded_by_the_pictures_last_showing(golden, monkeypatch)
     assert st3["host_frames"] == 0 and st3["mismatches"] <= st3["tasks"] // 100, st3
 
 
+def test_secam_sub_carrier_of_a_picture_that_stays_is_kept_and_taken(golden, monkeypatch):
+    """SECAM: the rows, entry states and exit state a frame's walk left are kept per picture slot and frame number modulo 6
+    (hvk_secam_kept); a later frame of that picture and number takes them, and the check decides whether it may. 40 batches of
+    3 frames of the test card (a batch length that is not a multiple of 2 or of 6: every set is met at every place in a batch):
+    sets are made, frames do take them (most of the later ones), no stage has to be done again, and every sample equals the
+    reference's digests (the first frames) and the host's serial chain (all 120) -- as it does with HVK_SECAM_KEEP=0, where
+    nothing is kept and nothing taken."""
+    conf, sr = golden.conf("l_full")
+    cum = golden.cases["l_full"]["sha256_cumulative"]
+    def run():
+        import hashlib
+        h = hashlib.sha256()
+        marks = {}
+        with H.Engine(conf, sr, device=0, max_frames=3) as e:
+            e.frame_upload(0, golden.frame("l_full"))
+            for b in range(40):
+                while e.audio_needed(3) > 0:
+                    e.audio_write(golden.audio)
+                e.render(3)
+                h.update(e.fetch(0, 3 * 640000).tobytes())
+                marks[3 * (b + 1)] = h.hexdigest()
+            return marks, e.secam_stats(), e.secam_kept()
+    marks, st, kept = run()
+    for n, d in marks.items():
+        if n <= len(cum):
+            assert d == cum[n - 1], "the first %d frames differ from the reference's digest" % n
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    marks_host, _, _ = run()                 # (the host's serial chain, pinned against the reference on the CPU: all 120 frames)
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    assert marks == marks_host
+    assert st["host_frames"] == 0 and kept["slots"] >= 1
+    assert kept["frames_taken"] >= 60 and kept["restarts"] == 0, kept
+    monkeypatch.setenv("HVK_SECAM_KEEP", "0")
+    marks0, st0, kept0 = run()
+    assert marks0 == marks and kept0["frames_taken"] == 0 and kept0["slots"] == 0
+    assert st0["tasks"] > st["tasks"]         # (the lines of frames that took a set were not walked)
+
+
+def test_secam_a_kept_set_met_from_another_state_sends_the_block_through_the_chain_again(golden, monkeypatch):
+    """SECAM: a frame may take its picture's kept set only if it starts from the state the set's walk started from. The test
+    card stays until its sets are good and taken; a noisy picture (another slot) is shown for a batch early on and again later,
+    when neither picture is new any more: its frames then take sets that were made behind ANOTHER frame of the card, and the
+    card's frames behind it start from what the noisy picture left -- not what the kept walks started from. The check says so,
+    the block goes through the chain again with every frame walked (restarts), and the samples are the host's serial chain's
+    throughout; afterwards new sets are made and taken again."""
+    conf = H.preset("l", H.FLAG_FILTER | H.FLAG_NOAUDIO)
+    pics = [golden.frame("l_full")] + _secam_noisy(1, seed=41)
+    def plan(b):
+        return [1, 1] if b in (6, 30) else [0, 0]      # (batch 6: the other picture's cells and sets get made; batch 30: it comes back, not new)
+    def run():
+        out = []
+        with H.Engine(conf, 16000000, device=0, max_frames=2) as e:
+            e.frame_upload(0, pics[0])
+            e.frame_upload(1, pics[1])
+            taken = []
+            for b in range(60):
+                e.render(2, slots=plan(b))
+                out.append(e.fetch(0, 2 * 640000))
+                taken.append(e.secam_kept()["frames_taken"])
+            return np.concatenate(out), e.secam_stats(), e.secam_kept(), taken
+    monkeypatch.setenv("HVK_SECAM_HOST", "1")
+    want, _, _, _ = run()
+    monkeypatch.delenv("HVK_SECAM_HOST")
+    got, st, kept, taken = run()
+    assert np.array_equal(got, want)
+    assert st["host_frames"] == 0
+    assert taken[29] > 0, taken                    # the card's frames were taking their sets before the other picture came
+    assert kept["restarts"] >= 1, kept             # ... and the card's return behind it was caught by the check
+    assert taken[-1] > taken[40], taken            # sets were made again and taken again
+    monkeypatch.setenv("HVK_SECAM_KEEP", "0")
+    got0, _, _, _ = run()
+    assert np.array_equal(got0, want)
+
+
 @pytest.mark.parametrize("mode,sr,pr", [("apollo-fsc", 13500000, 0), ("apollo-fsc", 27000000, 13500000), ("cbs405", 17496000, 0)])
 def test_raw_baseband_lines_carry_no_field_sequential_flag(mode, sr, pr):
     """Field-sequential colour with --raw-bb-file: the lines are read, not drawn (src/video.c:2406-2446), and the flag pulse
