@@ -54,6 +54,9 @@ __device__ __forceinline__ int med3i(int v, int lo, int hi) { return(v < lo ? lo
 __device__ __forceinline__ int clamp16(int v) { return(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 /* a.lo * b.lo + a.hi * b.hi with nothing to add to: the three-operand form with the constant 0 (from the builtin the
  * compiler makes the two-operand v_dot2c, which accumulates into its destination -- and a v_mov of 0 in front of every one) */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "hvk_device.h is written for gfx950 (MI355X): dot2z()'s instruction and nicam_add()'s LDS addresses are that ISA's (gfx942 / gfx90a share them); make ARCH=gfx950"
+#endif
 __device__ __forceinline__ int dot2z(int a, int b)
 {
 #ifdef HVK_V_NO_DOT2Z

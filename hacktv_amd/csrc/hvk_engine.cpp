@@ -884,6 +884,8 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->ev_fork) (void) hipEventDestroy(e->ev_fork);
 		for(int i = 0; i < HVK_PREP_EVENTS; i++) if(e->ev_prep[i]) (void) hipEventDestroy(e->ev_prep[i]);
 		if(e->prep_stream) { (void) hipStreamSynchronize(e->prep_stream); (void) hipStreamDestroy(e->prep_stream); }
+		if(e->copy_stream) { (void) hipStreamSynchronize(e->copy_stream); (void) hipStreamDestroy(e->copy_stream); }
+		if(e->copy_out_ev) (void) hipEventDestroy(e->copy_out_ev);
 		for(int i = 0; i < HVK_FETCH_TICKETS; i++) if(e->fetch_ev[i]) (void) hipEventDestroy(e->fetch_ev[i]);
 		if(e->h_svrec) (void) hipHostFree(e->h_svrec);
 		void *host[] = { e->h_fdesc, e->h_car, e->h_sym, e->h_tile, e->h_chroma, e->h_tt_pk, e->h_tt_mask, e->h_ops, e->h_map, e->h_off, e->h_pass, e->h_fm, e->h_raw, e->h_sis_bits, e->h_secam_rows, e->h_frec };
@@ -1075,6 +1077,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 		memcpy(e->host_frames[slot], stage, (size_t) w * h * 4);
 	}
 	/* on the engine's stream: behind every launch that still reads the slot's old picture, in front of every later one */
+	if(e->copy_out_ev) HIPCHK(hipStreamWaitEvent(e->stream, e->copy_out_ev, 0));      /* (another engine may still be reading this pool: hvk_frame_copy) */
 	HIPCHK(hipMemcpyAsync(e->d_pool + slot * frame_px, stage, (size_t) w * h * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(hipEventRecord(e->up_ev[ub], e->stream));
 	e->up_busy[ub] = 1;
@@ -1118,6 +1121,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 
 	HIPCHK(hipSetDevice(e->device));
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
+	if(e->copy_out_ev) HIPCHK(hipStreamWaitEvent(e->stream, e->copy_out_ev, 0));
 	HIPCHK(hipMemcpy2DAsync(e->d_pool + slot * frame_px, (size_t) w * 4, src, (size_t) width * 4, (size_t) w * 4, (size_t) h,
 	                        hipMemcpyHostToDevice, e->stream));
 	return(HVK_OK);
@@ -1146,21 +1150,34 @@ extern "C" int hvk_frame_copy(hvk_engine_t *e, int slot, hvk_engine_t *from, int
 	memset(s->memo_valid, 0, sizeof(s->memo_valid));
 	if(!f->valid) return(HVK_OK);
 
+	/* The copy runs on a stream of the destination's own: behind what the source has queued (the picture's upload: a) and
+	 * behind what the destination has queued (a render that still reads the slot: c), in front of what the destination
+	 * queues from now on (b). The SOURCE's stream waits for nothing -- a wait for b would put it behind the destination's
+	 * renders, block b's launch behind block b + 1 - N's: with two engines one after the other; only an upload INTO the
+	 * source's pool waits for the last copy out of it (copy_out_ev, hvk_frame_upload*). */
 	const size_t frame_px = (size_t) k.active_width * k.active_lines;
-	hipEvent_t a = NULL, b = NULL;
-	HIPCHK(hipSetDevice(from->device));
-	HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-	HIPCHK(hipEventRecord(a, from->stream));
-	HIPCHK(hipSetDevice(e->device));
-	HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-	HIPCHK(hipStreamWaitEvent(e->stream, a, 0));
-	HIPCHK(hipMemcpyPeerAsync(e->d_pool + slot * frame_px, e->device, from->d_pool + from_slot * frame_px, from->device,
-	                          (size_t) f->width * f->height * 4, e->stream));
-	HIPCHK(hipEventRecord(b, e->stream));
-	HIPCHK(hipSetDevice(from->device));
-	HIPCHK(hipStreamWaitEvent(from->stream, b, 0));
-	(void) hipEventDestroy(a);      /* (released once the work queued on them is through) */
-	(void) hipEventDestroy(b);
+	hipEvent_t a = NULL, b = NULL, c = NULL;
+	int ok = 0;
+	do
+	{
+		if(hipSetDevice(e->device) != hipSuccess) break;
+		if(!e->copy_stream && hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) break;
+		if(hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c, hipEventDisableTiming) != hipSuccess) break;
+		if(hipEventRecord(c, e->stream) != hipSuccess) break;
+		if(hipSetDevice(from->device) != hipSuccess) break;
+		if(hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventRecord(a, from->stream) != hipSuccess) break;
+		if(hipSetDevice(e->device) != hipSuccess) break;
+		if(hipStreamWaitEvent(e->copy_stream, a, 0) != hipSuccess || hipStreamWaitEvent(e->copy_stream, c, 0) != hipSuccess) break;
+		if(hipMemcpyPeerAsync(e->d_pool + slot * frame_px, e->device, from->d_pool + from_slot * frame_px, from->device,
+		                      (size_t) f->width * f->height * 4, e->copy_stream) != hipSuccess) break;
+		if(hipEventRecord(b, e->copy_stream) != hipSuccess || hipStreamWaitEvent(e->stream, b, 0) != hipSuccess) break;
+		ok = 1;
+	} while(0);
+	if(a) (void) hipEventDestroy(a);      /* (released once the work queued on them is through) */
+	if(c) (void) hipEventDestroy(c);
+	if(!ok) { if(b) (void) hipEventDestroy(b); return(HVK_ERROR); }
+	if(from->copy_out_ev) (void) hipEventDestroy(from->copy_out_ev);
+	from->copy_out_ev = b;
 	return(HVK_OK);
 }
 
@@ -1209,6 +1226,9 @@ extern "C" int hvk_teletext_packets(hvk_engine_t *e, int frame_in_batch, const u
 extern "C" int hvk_teletext_packets_block(hvk_engine_t *e, int first_frame_in_batch, int nframes, const uint8_t *packets, const uint32_t *masks)
 {
 	if(!e || !packets || !masks || nframes < 0 || first_frame_in_batch < 0 || first_frame_in_batch + nframes > e->max_frames) return(HVK_ERROR);
+	/* (everything a single frame's call can refuse, before any frame is touched: the block is queued whole or not at all) */
+	if(!e->t.k.teletext) return(HVK_UNSUPPORTED);
+	if(e->device < 0) return(HVK_NO_DEVICE);
 	for(int i = 0; i < nframes; i++)
 	{
 		const int r = hvk_teletext_packets(e, first_frame_in_batch + i, packets + (size_t) i * 32 * 45, masks[i]);
@@ -1265,6 +1285,59 @@ extern "C" int hvk_sound_state_import(hvk_engine_t *e, const void *buf, size_t b
 	if(!e || !buf) return(HVK_ERROR);
 	if(!e->audio) return(HVK_UNSUPPORTED);
 	return(hvk_audio_state_import(e->audio, buf, bytes, source_position));
+}
+
+/* The colour chain's state between two frames (SECAM): what the last staged frame's last line left -- the pre-emphasis IIR's two
+ * doubles and the values behind the line (hvk_secam_state_t; src/video.c:3095-3099, :3160-3165, :3202-3229) -- and the number
+ * of the frame that comes next. 40 bytes; a group hands it from the engine of block b to the engine of block b + 1. */
+typedef struct { hvk_secam_state_t st; int64_t next_frame; } hvk_secam_handover_t;
+
+extern "C" size_t hvk_secam_state_size(const hvk_engine_t *e)
+{
+	return((e && e->secam) ? sizeof(hvk_secam_handover_t) : 0);
+}
+
+extern "C" int hvk_secam_state_export(hvk_engine_t *e, void *buf, size_t bytes)
+{
+	if(!e || !buf) return(HVK_ERROR);
+	if(!e->secam) return(HVK_UNSUPPORTED);
+	if(e->poisoned || bytes < sizeof(hvk_secam_handover_t)) return(HVK_ERROR);
+	hvk_secam_handover_t h;
+	memset(&h, 0, sizeof(h));
+	if(e->secam_dev)
+	{
+		/* (the stage's last copy brings the carried state to the host: behind it) */
+		HIPCHK(hipSetDevice(e->device));
+		HIPCHK(hipStreamSynchronize(e->stream));
+		h.st = *e->h_secam_carry;
+		h.next_frame = e->secam_next;
+	}
+	else hvk_secam_get_state(e->secam, &h.st, &h.next_frame);
+	memcpy(buf, &h, sizeof(h));
+	return(HVK_OK);
+}
+
+extern "C" int hvk_secam_state_import(hvk_engine_t *e, const void *buf, size_t bytes)
+{
+	if(!e || !buf) return(HVK_ERROR);
+	if(!e->secam) return(HVK_UNSUPPORTED);
+	if(e->poisoned || bytes < sizeof(hvk_secam_handover_t)) return(HVK_ERROR);
+	hvk_secam_handover_t h;
+	memcpy(&h, buf, sizeof(h));
+	if(h.next_frame < 0) return(HVK_ERROR);
+	e->secam_next = h.next_frame;
+	hvk_secam_set_state(e->secam, &h.st, h.next_frame);         /* (the host's chain: the fall-back goes on from here too) */
+	if(e->secam_dev)
+	{
+		HIPCHK(hipSetDevice(e->device));
+		HIPCHK(hipStreamSynchronize(e->stream));                /* (a copy from this pinned word may still be on its way) */
+		*e->h_secam_carry = h.st;
+		HIPCHK(hipMemcpyAsync(e->sa.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
+		/* the frame before the block's first was another engine's: its picture counts as new here (warm-up lines, no kept
+		 * state taken on trust -- the check decides as ever) */
+		e->secam_last_new = 1;
+	}
+	return(HVK_OK);
 }
 
 extern "C" int64_t hvk_sound_samples_generated(const hvk_engine_t *e)
@@ -1428,7 +1501,8 @@ extern "C" int hvk_stream_is_one_chain(const hvk_engine_t *e)
 	const hvk_kconst_t &k = e->t.k;
 	/* (sound-in-syncs: its burst encoder keeps the sound chains a line or more ahead of the requests, and a state that
 	 * stands past the last request is not one hvk_sound_state_export() hands on) */
-	return(k.secam || k.fm_video || k.rs_irr || k.has_passthru || k.rawbb || k.sis);
+	/* (SECAM colour is a chain too, but what it hands from frame to frame is 40 bytes: hvk_secam_state_export / _import) */
+	return(k.fm_video || k.rs_irr || k.has_passthru || k.rawbb || k.sis);
 }
 
 

@@ -185,6 +185,8 @@ struct hvk_engine {
 	 * beside hvk_k_direct of chunk c (one is bound by memory latency, the other by vector issue), and a chunk's planes
 	 * are read back while they still lie in the 256 MiB Infinity Cache */
 	hipStream_t prep_stream;
+	hipStream_t copy_stream;    /* hvk_frame_copy(): pictures that come from another engine arrive on it, not behind this engine's renders */
+	hipEvent_t copy_out_ev;     /* the last copy OUT of this engine's pool (another engine's hvk_frame_copy): an upload into the pool waits for it */
 	hipEvent_t ev_fork, ev_prep[HVK_PREP_EVENTS];
 	int prep_chunk;             /* frames per chunk (HVK_PREP_CHUNK) */
 	int prep_streams;           /* 2: the planes on a stream of their own (HVK_PREP_STREAMS) */

@@ -74,6 +74,8 @@ struct hvk_group {
 	int chains_taken;           /* the block being prepared has taken the chains over already */
 	std::vector<uint8_t> state; /* the chains as exported after the last block staged */
 	int have_state;
+	std::vector<uint8_t> cstate;    /* SECAM: the colour chain's state behind the last block staged (hvk_secam_state_export) */
+	int have_cstate;
 	/* gather */
 	rccl_t rccl;
 	std::vector<ncclComm_t> comms;
@@ -146,10 +148,11 @@ extern "C" int hvk_group_open(hvk_group_t **pg, const hvk_config_t *conf, unsign
 	g->prev_slot = block_frames;
 	g->distinct = 1;
 	for(int i = 0; i < ndevices; i++) for(int j = 0; j < i; j++) if(devices[i] == devices[j]) g->distinct = 0;
-	if(conf->interlace)
+	if(conf->interlace && ndevices > 1)
 	{
-		/* (two pictures per frame: the block's slot list, the upload call and the carried picture here all count frames) */
-		fprintf(stderr, "libhvk: refused: a group renders one picture per frame; --interlace (a picture per field, src/video.c:4873) goes through one engine's own calls\n");
+		/* (two pictures per frame: the block's slot list, the upload call and the carried picture here all count frames; a group of
+		 * ONE engine passes its blocks straight through -- hvk_group_stage()'s two-slots-per-frame list -- and takes it) */
+		fprintf(stderr, "libhvk: refused: a group of several engines renders one picture per frame; --interlace (a picture per field, src/video.c:4873) goes through one engine\n");
 		delete g;
 		return(HVK_UNSUPPORTED);
 	}
@@ -168,12 +171,13 @@ extern "C" int hvk_group_open(hvk_group_t **pg, const hvk_config_t *conf, unsign
 	g->needs_prev = hvk_last_line_shows_picture(g->eng[0]);
 	if(ndevices > 1 && hvk_stream_is_one_chain(g->eng[0]))
 	{
-		fprintf(stderr, "libhvk: refused: this configuration is one serial chain over the stream (SECAM colour, FM video, frames of two lengths, passthru, raw "
+		fprintf(stderr, "libhvk: refused: this configuration is one serial chain over the stream (FM video, frames of two lengths, passthru, raw "
 		                "baseband, or sound-in-syncs, whose burst encoder runs ahead of the sound chains): one engine renders it, a group of %d does not\n", ndevices);
 		hvk_group_close(g);
 		return(HVK_UNSUPPORTED);
 	}
 	g->state.resize(hvk_sound_state_size(g->eng[0]));
+	g->cstate.resize(hvk_secam_state_size(g->eng[0]));
 	/* HVK_GATHER=peer: hipMemcpyPeerAsync instead of RCCL (also between engines that share a device: the one-GPU test of
 	 * that branch); HVK_GATHER=rccl (the default between distinct devices) falls back to peer copies when librccl cannot
 	 * be loaded or its communicators cannot be made */
@@ -294,6 +298,9 @@ extern "C" int hvk_group_stage(hvk_group_t *g, int nframes, const int32_t *slots
 	if((r = _take_chains(g)) != HVK_OK) return(r);
 	if(g->has_sound && (r = _deal(g)) != HVK_OK) return(r);
 
+	/* SECAM: the colour chain goes on from where the engine of the block before left it */
+	if(!g->cstate.empty() && g->have_cstate && (r = hvk_secam_state_import(e, g->cstate.data(), g->cstate.size())) != HVK_OK) return(r);
+
 	std::vector<int32_t> id((size_t) nframes), prev((size_t) nframes, -1);
 	for(int i = 0; i < nframes; i++) id[i] = i;
 	if(g->needs_prev && g->next_frame > 0) prev[0] = g->prev_slot;     /* (uploaded there when the block before was staged) */
@@ -304,6 +311,11 @@ extern "C" int hvk_group_stage(hvk_group_t *g, int nframes, const int32_t *slots
 	{
 		if((r = hvk_sound_state_export(e, g->state.data(), g->state.size())) != HVK_OK) return(r);
 		g->have_state = 1;
+	}
+	if(!g->cstate.empty())
+	{
+		if((r = hvk_secam_state_export(e, g->cstate.data(), g->cstate.size())) != HVK_OK) return(r);
+		g->have_cstate = 1;
 	}
 	if(g->needs_prev)
 	{

@@ -27,7 +27,7 @@ SYMBOLS = [
     "hvk_group_open", "hvk_group_close", "hvk_group_size", "hvk_group_block_frames", "hvk_group_engine", "hvk_group_block_engine", "hvk_group_block_index",
     "hvk_group_next_frame", "hvk_group_frame_upload", "hvk_group_audio_write", "hvk_group_audio_needed", "hvk_group_stage", "hvk_group_launch",
     "hvk_group_gather", "hvk_group_gather_backend", "hvk_engine_stream", "hvk_last_line_shows_picture", "hvk_stream_is_one_chain", "hvk_block_sums", "hvk_fused_launches", "hvk_secam_estimated_stages", "hvk_levels_short_form",
-    "hvk_sound_source_end", "hvk_secam_kept", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block", "hvk_kernel_plan",
+    "hvk_sound_source_end", "hvk_secam_kept", "hvk_secam_state_size", "hvk_secam_state_export", "hvk_secam_state_import", "hvk_frame_copy", "hvk_rccl_probe", "hvk_secam_walk_stages", "hvk_teletext_packets_block", "hvk_kernel_plan",
 ]
 
 _lib = None
@@ -154,6 +154,10 @@ def lib():
         L.hvk_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
         L.hvk_secam_walk_stages.argtypes = [vp, vp]
         L.hvk_secam_kept.argtypes = [vp, vp]
+        L.hvk_secam_state_size.argtypes = [vp]
+        L.hvk_secam_state_size.restype = C.c_size_t
+        L.hvk_secam_state_export.argtypes = [vp, vp, C.c_size_t]
+        L.hvk_secam_state_import.argtypes = [vp, vp, C.c_size_t]
         L.hvk_teletext_packets_block.argtypes = [vp, i32, i32, vp, vp]
         L.hvk_kernel_plan.argtypes = [vp, C.c_char_p, i32]
         _lib = L
@@ -442,6 +446,16 @@ class Engine:
         pos = C.c_int64(0)
         self._chk("hvk_sound_state_import", lib().hvk_sound_state_import(self.h, state, len(state), C.byref(pos)))
         return pos.value
+
+    def secam_state_export(self):
+        """The colour chain's state behind the last frame staged (bytes; hvk_secam_state_export)."""
+        n = lib().hvk_secam_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        self._chk("hvk_secam_state_export", lib().hvk_secam_state_export(self.h, buf, n))
+        return buf.raw
+
+    def secam_state_import(self, state):
+        return self._chk("hvk_secam_state_import", lib().hvk_secam_state_import(self.h, state, len(state)))
 
     def sound_samples_generated(self):
         return lib().hvk_sound_samples_generated(self.h)

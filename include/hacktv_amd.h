@@ -480,8 +480,10 @@ const char *hvk_version(void);
  * b mod N, each engine on the device named for it (a device may be named more than once: N engines on one GPU). The
  * serial sound chains are handed from engine to engine in process, the 32 kHz source is kept by the group and dealt to
  * the engine whose block draws it, and on 525 lines the picture of the frame before a block reaches the block's engine
- * too (hvk_group.cpp). Configurations that are one chain over every sample of the stream (SECAM colour, FM video,
- * --pixelrate pairs with frames of two lengths, passthru, raw baseband, sound-in-syncs) are refused for N > 1.
+ * too (hvk_group.cpp), and the SECAM colour chain's state (the IIR pair and the values behind the last line: 40 bytes,
+ * hvk_secam_state_export / _import) travels with the blocks like the sound chains' does. Configurations that are one chain
+ * over every SAMPLE of the stream (FM video, --pixelrate pairs with frames of two lengths, passthru, raw baseband,
+ * sound-in-syncs) are refused for N > 1.
  *
  * A block: hvk_group_frame_upload() for its pictures (frame i of the block -> slot i of the block's engine),
  * hvk_group_audio_write() while hvk_group_audio_needed() > 0, anything per frame (teletext packets, caption pairs)
@@ -493,7 +495,7 @@ const char *hvk_version(void);
  *        one; HVK_GATHER=peer takes hipMemcpyPeerAsync instead (every sender pushing its block on a stream of its own),
  *        which is also what a machine without a usable librccl falls back to (hvk_group_gather_backend() says which was
  *        taken; hvk_rccl_probe() whether librccl.so.1 loads and has the seven entry points -- no device needed).
- * Refused: --interlace (a picture per field: one engine's own calls), and for N > 1 the configurations above and
+ * Refused for N > 1: --interlace (a picture per field; a group of one engine takes it), the configurations above and
  * sound-in-syncs. */
 typedef struct hvk_group hvk_group_t;
 int hvk_group_open(hvk_group_t **g, const hvk_config_t *conf, unsigned int sample_rate, unsigned int pixel_rate,
@@ -525,6 +527,13 @@ int hvk_rccl_probe(char *msg, size_t len);
 void *hvk_engine_stream(hvk_engine_t *e);
 int hvk_last_line_shows_picture(const hvk_engine_t *e);
 int hvk_stream_is_one_chain(const hvk_engine_t *e);
+/* SECAM: the colour chain's state between two frames -- the pre-emphasis IIR's two doubles, which the reference never resets
+ * (src/fir.c:721-735), and the values the FM loop's last steps leave behind a line (src/video.c:3202-3229) -- with the number
+ * of the frame that comes next: what the engine of block b hands to the engine of block b + 1 (hvk_group_stage does; 40
+ * bytes). Export waits for the engine's stage to be through; import makes the engine's next stage start there, at that frame. */
+size_t hvk_secam_state_size(const hvk_engine_t *e);
+int hvk_secam_state_export(hvk_engine_t *e, void *buf, size_t bytes);
+int hvk_secam_state_import(hvk_engine_t *e, const void *buf, size_t bytes);
 
 /* Two 64-bit sums over samples [first, first + count) of the last render, read as little-endian uint32 words w[i]
  * (an I/Q pair each): sums[0] = sum w[i], sums[1] = sum (i + 1) w[i], modulo 2^64 -- computed on the device, 16 bytes

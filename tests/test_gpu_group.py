@@ -227,14 +227,55 @@ def test_525_lines_the_picture_before_a_block(golden):
             assert h.copy().hexdigest() == ref[f], f
 
 
-def test_chains_over_the_whole_stream_are_refused(golden):
-    for case in ("l_full",):
+def test_chains_over_every_sample_are_refused(golden):
+    for case in ("pal_fm",):
         conf, sr = golden.conf(case)
         with pytest.raises(H.HvkError) as ei:
             H.Group(conf, sr, [0, 0], 2)
         assert ei.value.code == H.HVK_UNSUPPORTED
         with H.Group(conf, sr, [0], 2) as g:      # one engine: an ordinary stream
             assert g.n == 1
+
+
+@pytest.mark.parametrize("case,block,nblocks", [("l_full", 1, 4), ("l_full", 3, 7), ("d_full", 2, 6), ("secam_bb", 2, 5), ("l_fid", 2, 4)])
+def test_secam_colour_over_three_engines_equals_the_reference(golden, case, block, nblocks):
+    """SECAM over a group: the colour chain's state -- the IIR pair the reference never resets and the values behind a frame's last
+    line (src/video.c:3095-3099, :3160-3165, :3202-3229) -- handed from the engine of block b to the engine of block b + 1
+    (hvk_secam_state_export / _import) like the sound chains'. Blocks of 1, 2 and 3 frames dealt to three engines on the one
+    GPU, with sound (-m l --filter) and without, with the video filter and in the baseband: every frame's samples equal the
+    reference's digests where the golden file has them and ONE engine's stream throughout; no frame went through the host's
+    chain."""
+    if case not in golden.cases:
+        pytest.skip("no golden case " + case)
+    conf, sr = golden.conf(case)
+    c = golden.cases[case]
+    fs = c.get("frame_samples", c["width"] * c["lines"])
+    real = bool(c["real"])
+    n = block * nblocks
+    with H.Engine(conf, sr, device=0, max_frames=n) as one:
+        one.frame_upload(0, golden.frame(case))
+        while one.audio_needed(n) > 0:
+            one.audio_write(golden.audio)
+        one.render(n)
+        want = one.fetch(0, n * fs)
+    got = []
+    with H.Group(conf, sr, [0, 0, 0], block) as g:
+        for e in g.engines:
+            e.frame_upload(0, golden.frame(case))
+        for b in range(nblocks):
+            e = g.block_engine()
+            while g.audio_needed(block) > 0:
+                g.audio_write(golden.audio)
+            g.stage(block, slots=[0] * block)
+            g.launch()
+            got.append(e.fetch(0, block * fs))
+        hosts = sum(e.secam_stats()["host_frames"] for e in g.engines)
+    got = np.concatenate(got)
+    assert np.array_equal(got, want)
+    assert hosts == 0
+    cum = c["sha256_cumulative"]
+    for m in range(1, min(n, len(cum)) + 1):
+        assert util.sha256(util.stream_bytes(got[: m * fs], real)) == cum[m - 1], "first %d frames differ from the reference's digest" % m
 
 
 @pytest.mark.parametrize("flags,key", [(["-m", "i", "-s", "16000000", "--filter"], "i_full"),
