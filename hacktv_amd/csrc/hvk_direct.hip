@@ -990,6 +990,10 @@ extern "C" int hvk_launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *
 	case 21: return(_launch_prep<21>(a, g, npics, Lp, Cp, stream));
 	case 23: return(_launch_prep<23>(a, g, npics, Lp, Cp, stream));
 	case 25: return(_launch_prep<25>(a, g, npics, Lp, Cp, stream));
+	case 27: return(_launch_prep<27>(a, g, npics, Lp, Cp, stream));
+	case 29: return(_launch_prep<29>(a, g, npics, Lp, Cp, stream));
+	case 31: return(_launch_prep<31>(a, g, npics, Lp, Cp, stream));
+	case 33: return(_launch_prep<33>(a, g, npics, Lp, Cp, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

@@ -130,12 +130,12 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		e->levels_mode = !strcmp(v, "table") ? HVK_LEVELS_TABLE : (!strcmp(v, "compute") ? HVK_LEVELS_COMPUTE : HVK_LEVELS_AUTO);
 	}
 
-	/* the kernels exist for these chroma filter lengths (pixel rates of about 6 to 33 MHz) and for
+	/* the kernels exist for these chroma filter lengths (5 .. 33 taps: pixel rates of about 5 to 45 MHz) and for
 	 * the NICAM pulse lengths the LDS table holds: say so now, not at the first render */
 	if(e->t.k.colour)
 	{
 		const int nt = e->t.k.chroma_ntaps;
-		if((nt < 5 || nt > 25 || !(nt & 1)) && !(nt == 3 && e->t.chroma_unfiltered))
+		if((nt < 5 || nt > 33 || !(nt & 1)) && !(nt == 3 && e->t.chroma_unfiltered))
 		{
 			fprintf(stderr, "libhvk: no raster kernel for a %d-tap chroma filter (pixel rate %d Hz)\n", nt, e->t.pixel_rate);
 			hvk_close(e);

@@ -868,6 +868,10 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 		case 21: return(_launch_raster<21, 0, 1>(a, stream));
 		case 23: return(_launch_raster<23, 0, 1>(a, stream));
 		case 25: return(_launch_raster<25, 0, 1>(a, stream));
+		case 27: return(_launch_raster<27, 0, 1>(a, stream));
+		case 29: return(_launch_raster<29, 0, 1>(a, stream));
+		case 31: return(_launch_raster<31, 0, 1>(a, stream));
+		case 33: return(_launch_raster<33, 0, 1>(a, stream));
 		}
 		return(HVK_UNSUPPORTED);
 	}
@@ -887,6 +891,10 @@ extern "C" int hvk_launch_raster(const hvk_raster_args_t *a, hipStream_t stream)
 	case 21: return(_launch_raster<21, 0, 0>(a, stream));
 	case 23: return(_launch_raster<23, 0, 0>(a, stream));
 	case 25: return(_launch_raster<25, 0, 0>(a, stream));
+	case 27: return(_launch_raster<27, 0, 0>(a, stream));
+	case 29: return(_launch_raster<29, 0, 0>(a, stream));
+	case 31: return(_launch_raster<31, 0, 0>(a, stream));
+	case 33: return(_launch_raster<33, 0, 0>(a, stream));
 	}
 	return(HVK_UNSUPPORTED);
 }

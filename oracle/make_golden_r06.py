@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""oracle/make_golden_r06.py -- TEST INFRASTRUCTURE (not product code).
+
+Round 6: configurations the engine refused until now for a kernel table's size, not for anything in the reference
+(Missing 5). Adds to tests/golden/ref_digests.json / ref_lines.npz / testsrc.npz:
+
+  pal_36m        hacktv_ref -m pal -s 36000000                       (chroma low pass of more than 25 taps: 2304-sample lines)
+  pal_8fsc       hacktv_ref -m pal -s 35468950                       (8 x the PAL sub-carrier: 2270-sample lines)
+  i_36m          hacktv_ref -m i -s 36000000 --filter                (... with the video filter, FM sound and a NICAM pulse of 495 taps)
+  i_27m          hacktv_ref -m i -s 27000000 --filter                (the base of the next)
+  i_sis_27m      hacktv_ref -m i -s 27000000 --filter --sis dcsis    (sound-in-syncs bursts longer than 128 samples, src/sis.c:155-201)
+
+Rates at which the reference's own output changes from run to run (its chroma low pass reads past its buffer into allocator
+words, SURVEY.md H2: 34, 40 MHz PAL, 36 MHz NTSC among them) have nothing to pin and are not in the list; every case here is
+run several times and gave one output. Run from the repository root after `make -C oracle ref`:  python oracle/make_golden_r06.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import refprobe  # noqa: E402
+import make_golden_rates as rates  # noqa: E402
+import make_golden_sis as sis  # noqa: E402
+
+RATE_CASES = [
+    ("pal_36m",  "pal", 36000000, [],           0,                    True,  2),
+    ("pal_8fsc", "pal", 35468950, [],           0,                    True,  2),
+    ("i_36m",    "i",   36000000, ["--filter"], refprobe.FLAG_FILTER, False, 2),
+    ("i_27m",    "i",   27000000, ["--filter"], refprobe.FLAG_FILTER, False, 2),
+]
+SIS_CASES = [
+    ("i_sis_27m", "i_27m", "i", 27000000, ["--filter", "--sis", "dcsis"], refprobe.FLAG_FILTER, 6, {"sis": 1}, False),
+]
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    rates.CASES = [c for c in RATE_CASES if not only or c[0] in only]
+    sys.argv = sys.argv[:1]
+    if rates.CASES:
+        rates.main()
+    sis.CASES = [c for c in SIS_CASES if not only or c[0] in only]
+    if sis.CASES:
+        sis.main()

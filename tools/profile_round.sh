@@ -35,6 +35,11 @@ for kind in card noisy new; do
 	f=$(find "$OUT/secam_$kind" -name '*kernel_stats.csv' | head -1)
 	[ -n "$f" ] && cp "$f" "$OUT/${TAG}_secam_${kind}_kernel_stats.csv"
 done
+# 5b. BASELINE config 4 without its sound, 128-frame blocks (bench.py's 4_secam_l_teletext_noaudio_device)
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg4" -o p -- python $OLDPWD/tools/cfg4_blocks.py 128 20 > "$OUT/cfg4.log" 2>&1
+tail -1 "$OUT/cfg4.log"
+f=$(find "$OUT/cfg4" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$OUT/${TAG}_cfg4_kernel_stats.csv"
 # 6. pictures that change on every frame: the one kernel from the pixels (table levels) and the planes' two (computed levels)
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/moving" -o p -- env HVK_PATHS=0 HVK_CHUNKS=0 python $OLDPWD/tools/prep_speed.py 64 > "$OUT/moving.log" 2>&1
 grep " i " "$OUT/moving.log" | cut -c1-220
