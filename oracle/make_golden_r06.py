@@ -8,7 +8,8 @@ Round 6: configurations the engine refused until now for a kernel table's size, 
   pal_8fsc       hacktv_ref -m pal -s 35468950                       (8 x the PAL sub-carrier: 2270-sample lines)
   i_36m          hacktv_ref -m i -s 36000000 --filter                (... with the video filter, FM sound and a NICAM pulse of 495 taps)
   i_27m          hacktv_ref -m i -s 27000000 --filter                (the base of the next)
-  i_sis_27m      hacktv_ref -m i -s 27000000 --filter --sis dcsis    (sound-in-syncs bursts longer than 128 samples, src/sis.c:155-201)
+  i_sis_27m      hacktv_ref -m i -s 27000000 --filter --sis dcsis    (sound-in-syncs bursts longer than 128 samples, src/sis.c:155-201;
+                                                                      "skip_samples": 64 -- the stream's first 28 samples are not the reference's to say)
 
 Rates at which the reference's own output changes from run to run (its chroma low pass reads past its buffer into allocator
 words, SURVEY.md H2: 34, 40 MHz PAL, 36 MHz NTSC among them) have nothing to pin and are not in the list; every case here is
@@ -31,7 +32,9 @@ RATE_CASES = [
     ("i_27m",    "i",   27000000, ["--filter"], refprobe.FLAG_FILTER, False, 2),
 ]
 SIS_CASES = [
-    ("i_sis_27m", "i_27m", "i", 27000000, ["--filter", "--sis", "dcsis"], refprobe.FLAG_FILTER, 6, {"sis": 1}, False),
+    # (the reference's first 28 samples differ from run to run at this rate -- its burst renderer's first, never-emitted invocation
+    # reads a line buffer nobody has written: hashed from sample 64 on, every run the same from there)
+    ("i_sis_27m", "i_27m", "i", 27000000, ["--filter", "--sis", "dcsis"], refprobe.FLAG_FILTER, 6, {"sis": 1}, False, 64),
 ]
 
 if __name__ == "__main__":

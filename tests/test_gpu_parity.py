@@ -64,10 +64,10 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster",
                                   "ntsci_full", "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m",
                                   "palfm_f14_tail", "i_sis", "i_sis_filter", "l_sis_tt", "pal_rawbb_px135", "i_rawbb_px16",
-                                  "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14",
+                                  "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "i_sis_27m",
                                   "palfm_px135", "palfm_pass_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16",
                                   "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136",
-                                  "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
+                                  "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m", "pal_36m", "pal_8fsc", "i_36m",
                                   # the rasters other than 625 / 525 lines, field-sequential colour (oracle/make_golden_rasters.py)
                                   "e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
                                   "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"])
@@ -91,7 +91,7 @@ def test_stream_equals_reference_digests(golden, case):
             raise AssertionError("%s line %d: %d samples differ, first x=%d got %s want %s" %
                                  (case, g, d.size, d[0], mine[d[0]], ref[j][d[0]]))
     for n in range(nframes):
-        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        got = util.cum_sha(iq, (n + 1) * fs, c)
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 
@@ -161,7 +161,7 @@ def test_one_kernel_from_the_pixels_equals_reference_digests(golden, case, monke
     iq = np.concatenate(out)
     fs = c["width"] * c["lines"]
     for n in range(nframes):
-        got = util.sha256(util.stream_bytes(iq[: (n + 1) * fs], c["real"]))
+        got = util.cum_sha(iq, (n + 1) * fs, c)
         assert got == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)
 
 

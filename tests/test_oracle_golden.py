@@ -23,9 +23,10 @@ CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_f
 CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "secami_full", "secamb_raster", "ntsci_full",
                  "pal60i_full", "pal60_bb", "palfm_f14", "ntscfm_f18", "secamfm_f2025", "i_27m"]
 # sound-in-syncs: a NICAM stream of its own inside every sync pulse (oracle/make_golden_sis.py: ten runs of the reference, one output)
-CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14"]
+CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "i_sis_27m"]
 # rates outside the first rounds' 11 .. 28 MHz: chroma filters of 7, 19, 23 taps (oracle/make_golden_rates.py)
-CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m"]
+CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
+               "pal_36m", "pal_8fsc", "i_36m"]       # (round 6: chroma low pass of 27 .. 31 taps, oracle/make_golden_r06.py)
 # the rasters other than 625 / 525 lines and field-sequential colour (oracle/make_golden_rasters.py)
 CASES_RASTERS = ["e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"]
@@ -55,7 +56,7 @@ def test_oracle_stream_matches_reference_cli(golden, case):
     ends = c.get("frame_ends") or [(n + 1) * fs for n in range(nframes)]       # (rate pairs with frames of two lengths list them)
     assert iq.shape[0] == ends[nframes - 1]
     for n in range(nframes):
-        got = util.sha256(util.stream_bytes(iq[: ends[n]], c["real"]))
+        got = util.cum_sha(iq, ends[n], c)
         assert got == c["sha256_cumulative"][n], "frame %d of %s differs from the reference" % (n + 1, case)
     # the excerpted lines, for a readable failure
     idx = golden.lines[case + "_idx"]

@@ -108,5 +108,11 @@ def stream_bytes(iq, real):
     return (iq[:, 0].copy() if real else iq).tobytes()
 
 
+def cum_sha(iq, end, case):
+    """sha256 of the stream's first `end` samples as the golden file has it: the file sink's bytes, from sample
+    case["skip_samples"] on where the reference's own runs differ before that (oracle/make_golden_r06.py)."""
+    return sha256(stream_bytes(iq[case.get("skip_samples", 0): end], case["real"]))
+
+
 def sha256(b):
     return hashlib.sha256(b).hexdigest()
