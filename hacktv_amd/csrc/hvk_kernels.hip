@@ -47,6 +47,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "hvk_internal.h"
 #include "hvk_kernels.h"
 
@@ -543,6 +544,10 @@ extern "C" int hvk_launch_convert(const void *iq, size_t count, int type, int cp
 #define HVK_RS_WIN  (4 * HVK_RS_TILE + 72 + 8)      /* raster samples a tile can need: 1024 D / L + ataps, D <= 4 L */
 #define HVK_RS_NP   11                              /* tap pairs per phase: ataps is 21 or 22 for every L (ntaps = 21 L | 1) */
 #define HVK_RS_ROW  12                              /* dwords per phase row in LDS: 16-byte aligned rows */
+/* BIG: ratios of more than 256 phases (27 MHz <-> 4 x f_sc: 709379 : 1080000) -- the reference's filter then has millions of taps
+ * (src/fir.c:404: 21 L | 1) of which an output sample still uses 21 or 22: its phase's row, read from HBM where it is needed
+ * instead of from a table in LDS, and positions in 64-bit arithmetic (a frame's index times D leaves 32 bits). */
+template<bool BIG>
 __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, const int16_t *__restrict__ Sp, const int *__restrict__ taps,
                                                       int16_t *__restrict__ S2,
                                                       /* frames of two lengths (k.rs_irr): per frame { c, where its samples go in S2 } -- c = B D - f RS L in (-D, D)
@@ -551,7 +556,8 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
                                                       const int2v *__restrict__ frec)
 {
 	__shared__ __attribute__((aligned(16))) int win[HVK_RS_WIN / 2];        /* raster samples, two per dword */
-	__shared__ __attribute__((aligned(16))) int tp[256 * HVK_RS_ROW];       /* taps, two per dword, one row per phase */
+	__shared__ __attribute__((aligned(16))) int tp[BIG ? 4 : 256 * HVK_RS_ROW];     /* taps, two per dword, one row per phase */
+	typedef typename std::conditional<BIG, unsigned long long, unsigned>::type pos_t;
 
 	const int t = threadIdx.x;
 	const unsigned L = k.rs_L, D = k.rs_D;
@@ -559,11 +565,11 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	const long slab_in = (long) k.slab_lines * k.width;
 	const int16_t *in = Sp + (size_t) blockIdx.y * slab_in;     /* raster line -1 of the frame first */
 	const int2v fr = frec ? frec[blockIdx.y] : (int2v) { 0, 0 };
-	const unsigned cD = (unsigned) fr.x;         /* (added modulo 2^32: r D >= 2 D > |c|, hvk_tables.c) */
+	const pos_t cD = BIG ? (pos_t) (long long) fr.x : (pos_t) (unsigned) fr.x;     /* (added modulo 2^32 / 2^64: r D >= 2 D > |c|, hvk_tables.c) */
 	int16_t *out = frec ? S2 + fr.y : S2 + (size_t) blockIdx.y * k.s_stride;
 
 	const int q0 = blockIdx.x * HVK_RS_TILE;                    /* first slab sample of the tile */
-	const unsigned r0 = (unsigned) (q0 - k.s_lead + k.rs_shift); /* its resampled-stream index, frame local (>= 0; r D < 2^32, hvk_tables.c) */
+	const pos_t r0 = (pos_t) (unsigned) (q0 - k.s_lead + k.rs_shift); /* its resampled-stream index, frame local (>= 0; r D < 2^32 unless BIG, hvk_tables.c) */
 	/* first raster sample staged, frame local, rounded down to an even index so that pairs are dwords */
 	const long n_lo = (((long) ((r0 * D + cD) / L) - (A - 1)) & ~1L);
 	const long n_hi = (long) (((r0 + HVK_RS_TILE - 1) * D + cD) / L);
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	for(int i = 0; i < TPASS; i++)
 	{
 		const int j = t + i * 256;
-		trow[i] = ((const int4v *) taps)[j < nrows4 ? j : nrows4 - 1];
+		if(!BIG) trow[i] = ((const int4v *) taps)[j < nrows4 ? j : nrows4 - 1];
 	}
 #pragma unroll
 	for(int i = 0; i < WPASS; i++)
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	for(int i = 0; i < TPASS; i++)
 	{
 		const int j = t + i * 256;
-		if(j < nrows4) ((int4v *) tp)[j] = trow[i];
+		if(!BIG && j < nrows4) ((int4v *) tp)[j] = trow[i];
 	}
 #pragma unroll
 	for(int i = 0; i < WPASS; i++)
@@ -615,9 +621,9 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 	__syncthreads();
 
 	/* this lane's first output: position and phase by one division, the next three by stepping */
-	unsigned rd = (r0 + t * 4) * D + cD;
-	long n = rd / L;
-	unsigned ph = rd - (unsigned) n * L;
+	const pos_t rd = (r0 + (pos_t) (t * 4)) * D + cD;
+	long n = (long) (rd / L);
+	unsigned ph = (unsigned) (rd - (pos_t) n * L);
 
 	short v[4];
 #pragma unroll
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(256) void hvk_k_resample(const hvk_kconst_t k, cons
 		const int ws = (int) (n - n_lo) - (A - 1);              /* window start in samples */
 		const int *w = win + (ws >> 1);
 		const int sh = (ws & 1) * 16;                           /* odd start: every pair straddles two dwords */
-		const int4v *c = (const int4v *) (tp + ph * HVK_RS_ROW);
+		const int4v *c = BIG ? (const int4v *) (taps + (size_t) ph * HVK_RS_ROW) : (const int4v *) (tp + ph * HVK_RS_ROW);
 		const int4v c0 = c[0], c1 = c[1], c2 = c[2];
 		const int ct[HVK_RS_ROW] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w };
 		int a = 0, cur = w[0];
@@ -685,7 +691,8 @@ extern "C" int hvk_launch_svq(const void *rec, int nlines, const void *C2, const
 extern "C" int hvk_launch_resample(const hvk_kconst_t *k, const void *Sp, const void *taps, void *S2, int nframes, const void *frec, hipStream_t stream)
 {
 	const int tiles = (k->s_stride + HVK_RS_TILE - 1) / HVK_RS_TILE;
-	hipLaunchKernelGGL(hvk_k_resample, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2, (const int2v *) frec);
+	if(k->rs_L > 256) hipLaunchKernelGGL(hvk_k_resample<true>, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2, (const int2v *) frec);
+	else hipLaunchKernelGGL(hvk_k_resample<false>, dim3(tiles, nframes), dim3(256), 0, stream, *k, (const int16_t *) Sp, (const int *) taps, (int16_t *) S2, (const int2v *) frec);
 	return(hipGetLastError() == hipSuccess ? HVK_OK : HVK_ERROR);
 }
 

@@ -1692,8 +1692,11 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		L = sample_rate / a;
 		D = pixel_rate / a;
 
-		/* what the device kernel is sized for */
-		if(L > 256 || D > 4 * L) REFUSE("resampling %u -> %u Hz is %d : %d in lowest terms: the kernel takes up to 256 phases and a decimation of up to four times that", pixel_rate, sample_rate, L, D);
+		/* what the device kernel is sized for: a window of raster samples per tile (decimation of up to four times the
+		 * interpolation), a tap table that fits a 32-bit index. Up to 256 phases the table lives in LDS; beyond that
+		 * (27 MHz <-> 4 x f_sc: 709379 : 1080000, fifteen million taps, src/fir.c:404) a sample reads its phase's row from HBM
+		 * (hvk_k_resample<true>) */
+		if(D > 4 * (int64_t) L || L > 3000000) REFUSE("resampling %u -> %u Hz is %d : %d in lowest terms: the kernel takes a decimation of up to four times the interpolation and up to 3 000 000 phases", pixel_rate, sample_rate, L, D);
 		/* frames of constant length, or (525 lines at 13.5 -> 16 MHz: 450450 * 32 / 27) of two lengths one sample apart */
 		t->k.rs_irr = ((int64_t) t->k.raster_samples * L) % D != 0;
 
@@ -1708,7 +1711,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		t->k.rs_D = D;
 		t->k.rs_ataps = (ntaps + L - 1) / L;
 		total = t->k.rs_ataps * L;
-		if(total > 8192) { free(taps); REFUSE("the resampler %u -> %u Hz has %d taps: the kernel's table holds 8192", pixel_rate, sample_rate, total); }
+		if(L <= 256 && total > 8192) { free(taps); REFUSE("the resampler %u -> %u Hz has %d taps: the kernel's table holds 8192", pixel_rate, sample_rate, total); }
 		t->rs_taps = calloc(total, sizeof(int16_t));
 		if(!t->rs_taps) { free(taps); return(HVK_OUT_OF_MEMORY); }
 
@@ -1723,7 +1726,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		free(taps);
 
 		/* the kernel's position arithmetic is 32-bit: (frame-local resampled index) * D */
-		if(((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; REFUSE("resampling %u -> %u Hz: a frame's positions times %d leave the kernel's 32-bit arithmetic", pixel_rate, sample_rate, D); }
+		if(L <= 256 && ((uint64_t) t->k.raster_samples * L / D + 4 * (uint64_t) t->k.width * L / D + 4096) * D >= 0xFFFFFFFFull) { free(t->rs_taps); t->rs_taps = NULL; REFUSE("resampling %u -> %u Hz: a frame's positions times %d leave the kernel's 32-bit arithmetic", pixel_rate, sample_rate, D); }
 		t->k.frame_samples = (int32_t) ((int64_t) t->k.raster_samples * L / D) + (t->k.rs_irr ? 1 : 0);
 		t->k.slab_lines = t->k.lines + 3;
 		t->max_width = (int32_t) (((int64_t) t->k.width * L + D - 1) / D);   /* fir_int16_output_size, src/fir.c:376-381 */

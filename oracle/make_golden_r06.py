@@ -8,6 +8,9 @@ Round 6: configurations the engine refused until now for a kernel table's size, 
   pal_8fsc       hacktv_ref -m pal -s 35468950                       (8 x the PAL sub-carrier: 2270-sample lines)
   i_36m          hacktv_ref -m i -s 36000000 --filter                (... with the video filter, FM sound and a NICAM pulse of 495 taps)
   i_27m          hacktv_ref -m i -s 27000000 --filter                (the base of the next)
+  pal_27m        hacktv_ref -m pal -s 27000000                       (the base of the next)
+  pal_px27_s4fsc hacktv_ref -m pal -s 17734475 --pixelrate 27000000  (a resampler of 709379 phases, src/fir.c:393-428: refused above 256 until now)
+  i_px27_s4fsc   hacktv_ref -m i -s 17734475 --filter --pixelrate 27000000
   i_sis_27m      hacktv_ref -m i -s 27000000 --filter --sis dcsis    (sound-in-syncs bursts longer than 128 samples, src/sis.c:155-201;
                                                                       "skip_samples": 64 -- the stream's first 28 samples are not the reference's to say)
 
@@ -24,12 +27,20 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import refprobe  # noqa: E402
 import make_golden_rates as rates  # noqa: E402
 import make_golden_sis as sis  # noqa: E402
+import make_golden_r03 as r03  # noqa: E402
 
 RATE_CASES = [
     ("pal_36m",  "pal", 36000000, [],           0,                    True,  2),
     ("pal_8fsc", "pal", 35468950, [],           0,                    True,  2),
     ("i_36m",    "i",   36000000, ["--filter"], refprobe.FLAG_FILTER, False, 2),
     ("i_27m",    "i",   27000000, ["--filter"], refprobe.FLAG_FILTER, False, 2),
+    ("pal_27m",  "pal", 27000000, [],           0,                    True,  2),     # (the base of pal_px27_s4fsc)
+]
+# --pixelrate pairs of more than 256 phases (27 MHz -> 4 x the PAL sub-carrier is 709379 : 1080000 in lowest terms: a resampler of
+# 14 896 959 taps, src/fir.c:404): id, base case (same mode at the same PIXEL rate), mode, sample rate, pixel rate, CLI flags, probe flags, real, frames, extra
+PIXELRATE_CASES = [
+    ("pal_px27_s4fsc", "pal_27m", "pal", 17734475, 27000000, ["--pixelrate", "27000000"], 0, True, 3, {}),
+    ("i_px27_s4fsc",   "i_27m",   "i",   17734475, 27000000, ["--filter", "--pixelrate", "27000000"], refprobe.FLAG_FILTER, False, 3, {}),
 ]
 SIS_CASES = [
     # (the reference's first 28 samples differ from run to run at this rate -- its burst renderer's first, never-emitted invocation
@@ -46,3 +57,6 @@ if __name__ == "__main__":
     sis.CASES = [c for c in SIS_CASES if not only or c[0] in only]
     if sis.CASES:
         sis.main()
+    r03.CASES = [c for c in PIXELRATE_CASES if not only or c[0] in only]
+    if r03.CASES:
+        r03.main()

@@ -104,14 +104,17 @@ def test_bad_arguments_fail_with_codes_not_crashes():
 
 
 def test_rate_pairs_the_resampler_refuses():
-    """--pixelrate: small L / D only. (A pair at which a raster frame is not a whole number of samples -- 450450 * 32 / 27 --
-    is taken since round 3: frames of two lengths, hvk_frame_start().)"""
+    """--pixelrate: up to 3 000 000 phases (up to 256 until round 6; beyond that a sample's taps come from HBM, hvk_k_resample<true>)
+    and a decimation of up to four times the interpolation. (A pair at which a raster frame is not a whole number of samples --
+    450450 * 32 / 27 -- is taken since round 3: frames of two lengths, hvk_frame_start().)"""
     c = H.preset("m", 0)
     with H.Engine(c, 16000000, device=-1, pixel_rate=13500000) as e:
         assert e.info["frame_samples"] == 533867 and [e.frame_start(i) for i in range(4)] == [0, 533867, 1067734, 1601600]
     with H.Engine(c, 13500000, device=-1) as e:
         assert [e.frame_start(i) for i in range(3)] == [0, 450450, 900900]
-    for sr, pr in ((16000001, 13500000),):     # L = 16000001
+    with H.Engine(H.preset("pal", 0), 17734475, device=-1, pixel_rate=27000000) as e:      # 709379 : 1080000
+        assert e.info["frame_samples"] == 709379
+    for sr, pr in ((16000001, 13500000), (3000000, 27000000)):     # L = 16000001; D = 9 L
         try:
             H.Engine(c, sr, device=-1, pixel_rate=pr)
         except H.HvkError as err:
@@ -130,7 +133,7 @@ def test_rate_pairs_the_resampler_refuses():
 
 def test_sample_rates_without_a_kernel_are_refused_at_open():
     """Rates whose chroma filter or NICAM pulse has no kernel fail in hvk_open, not at the first render."""
-    for mode, flags, sr in (("i", H.FLAG_NOAUDIO, 64000000), ("i", 0, 48000000), ("pal", 0, 3000000), ("pal", 0, 36000000),
+    for mode, flags, sr in (("i", H.FLAG_NOAUDIO, 64000000), ("i", 0, 48000000), ("pal", 0, 3000000), ("pal", 0, 48000000), ("i", 0, 40000000),     # (36 MHz -- 27 chroma taps -- is rendered since round 6)
                             ("l", H.FLAG_NOAUDIO, 13500000), ("secam", 0, 14750000)):   # SECAM: the notch would leave the line
         try:
             H.Engine(H.preset(mode, flags), sr, device=-1)
@@ -138,7 +141,7 @@ def test_sample_rates_without_a_kernel_are_refused_at_open():
             assert err.code == H.HVK_UNSUPPORTED
         else:
             raise AssertionError("%s at %d Hz accepted" % (mode, sr))
-    for sr in (7000000, 9000000, 12000000, 13500000, 14000000, 16000000, 17734475, 20250000, 24000000, 27000000, 30000000, 33000000):
+    for sr in (7000000, 9000000, 12000000, 13500000, 14000000, 16000000, 17734475, 20250000, 24000000, 27000000, 30000000, 33000000, 36000000, 38000000):
         with H.Engine(H.preset("i", H.FLAG_NOAUDIO), sr, device=-1) as e:
             assert e.info["sample_rate"] == sr
     with H.Engine(H.preset("i"), 27000000, device=-1) as e:      # NICAM's 373-tap pulse at the top of the range

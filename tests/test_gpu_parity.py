@@ -57,7 +57,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_tt", "l_tt",
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
                                   "pal_fm_pass",
-                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136",
+                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_px27_s4fsc", "i_px27_s4fsc", "pal_27m",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
                                   "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv",
                                   "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb",

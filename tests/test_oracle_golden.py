@@ -15,7 +15,9 @@ CASES_FAST = ["pal_bb", "i_raster", "i_vsb", "i_fm", "i_audio", "i_full", "m_ful
 # --pixelrate: raster at the pixel rate + poly-phase resampler (the last one has lines of 870 / 871 samples)
 CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_rawbb_px135", "i_rawbb_px16", "pal_sv_px135", "ntsc_sv_f_px18", "secam_sv_f_px2025", "i_pass_px135", "pal_pass_px135_s136", "m_px135_s16", "ntsc_px16_s135",
                    # S-Video behind resampler + filter, lines of two widths: the ring of line buffers (oracle/make_golden_r05.py)
-                   "ntsc_sv_f_px135_s16", "ntsc_sv_f_px18_s16", "pal60_sv_f_px27_s16", "ntsc_sv_f_px16_s27", "ntsc_sv_f_px16_s18"]
+                   "ntsc_sv_f_px135_s16", "ntsc_sv_f_px18_s16", "pal60_sv_f_px27_s16", "ntsc_sv_f_px16_s27", "ntsc_sv_f_px16_s18",
+                   # a resampler of 709379 phases: 27 MHz -> 4 x the PAL sub-carrier (oracle/make_golden_r06.py)
+                   "pal_px27_s4fsc", "i_px27_s4fsc"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
 CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
 CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb"]
@@ -26,7 +28,7 @@ CASES_PRESETS = ["pald_full", "palm_full", "paln_full", "pal525_bb", "d_full", "
 CASES_SIS = ["i_sis", "i_sis_filter", "l_sis_tt", "pal_sv_sis", "i_rawbb_sis", "i_sis_px135", "i_sis_px2025", "l_sis_px16_s14", "i_sis_27m"]
 # rates outside the first rounds' 11 .. 28 MHz: chroma filters of 7, 19, 23 taps (oracle/make_golden_rates.py)
 CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
-               "pal_36m", "pal_8fsc", "i_36m"]       # (round 6: chroma low pass of 27 .. 31 taps, oracle/make_golden_r06.py)
+               "pal_36m", "pal_8fsc", "i_36m", "pal_27m"]       # (round 6: chroma low pass of 27 .. 31 taps, oracle/make_golden_r06.py)
 # the rasters other than 625 / 525 lines and field-sequential colour (oracle/make_golden_rasters.py)
 CASES_RASTERS = ["e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"]
