@@ -1696,7 +1696,7 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 		 * interpolation), a tap table that fits a 32-bit index. Up to 256 phases the table lives in LDS; beyond that
 		 * (27 MHz <-> 4 x f_sc: 709379 : 1080000, fifteen million taps, src/fir.c:404) a sample reads its phase's row from HBM
 		 * (hvk_k_resample<true>) */
-		if(D > 4 * (int64_t) L || L > 3000000) REFUSE("resampling %u -> %u Hz is %d : %d in lowest terms: the kernel takes a decimation of up to four times the interpolation and up to 3 000 000 phases", pixel_rate, sample_rate, L, D);
+		if(D > 4 * (int64_t) L || L > 20000000) REFUSE("resampling %u -> %u Hz is %d : %d in lowest terms: the kernel takes a decimation of up to four times the interpolation and up to 20 000 000 phases", pixel_rate, sample_rate, L, D);
 		/* frames of constant length, or (525 lines at 13.5 -> 16 MHz: 450450 * 32 / 27) of two lengths one sample apart */
 		t->k.rs_irr = ((int64_t) t->k.raster_samples * L) % D != 0;
 

@@ -104,7 +104,7 @@ def test_bad_arguments_fail_with_codes_not_crashes():
 
 
 def test_rate_pairs_the_resampler_refuses():
-    """--pixelrate: up to 3 000 000 phases (up to 256 until round 6; beyond that a sample's taps come from HBM, hvk_k_resample<true>)
+    """--pixelrate: up to 20 000 000 phases (up to 256 until round 6; beyond that a sample's taps come from HBM, hvk_k_resample<true>)
     and a decimation of up to four times the interpolation. (A pair at which a raster frame is not a whole number of samples --
     450450 * 32 / 27 -- is taken since round 3: frames of two lengths, hvk_frame_start().)"""
     c = H.preset("m", 0)
@@ -114,7 +114,7 @@ def test_rate_pairs_the_resampler_refuses():
         assert [e.frame_start(i) for i in range(3)] == [0, 450450, 900900]
     with H.Engine(H.preset("pal", 0), 17734475, device=-1, pixel_rate=27000000) as e:      # 709379 : 1080000
         assert e.info["frame_samples"] == 709379
-    for sr, pr in ((16000001, 13500000), (3000000, 27000000)):     # L = 16000001; D = 9 L
+    for sr, pr in ((40000001, 13500000), (3000000, 27000000)):     # L = 40000001; D = 9 L
         try:
             H.Engine(c, sr, device=-1, pixel_rate=pr)
         except H.HvkError as err:
