@@ -1631,7 +1631,10 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			 * (src/video.c:3690-3730; hvk_fm_taps.h has the tables), real, in front of the modulator */
 			const hvk_fm_taps_t *f = hvk_fm_taps;
 			int k;
-			while(f->lines && !(f->lines == c->lines && (f->sample_rate == (int) sample_rate || f->sample_rate == 0))) f++;
+			/* (the reference tests for 525 lines and takes the 625-line tables for every other count -- Apollo's 320 lines
+			 * among them, src/video.c:3693, :3711) */
+			const int ll = c->lines == 525 ? 525 : 625;
+			while(f->lines && !(f->lines == ll && (f->sample_rate == (int) sample_rate || f->sample_rate == 0))) f++;
 			if(!f->lines || f->ntaps > HVK_MAX_VF_TAPS) REFUSE("no FM video pre-emphasis taps for %d lines at %u Hz (src/video.c:3452-3564)", c->lines, sample_rate);
 			ntaps = f->ntaps;
 			t->k.vf_type = 1;

@@ -11,6 +11,8 @@ Round 6: configurations the engine refused until now for a kernel table's size, 
   pal_27m        hacktv_ref -m pal -s 27000000                       (the base of the next)
   pal_px27_s4fsc hacktv_ref -m pal -s 17734475 --pixelrate 27000000  (a resampler of 709379 phases, src/fir.c:393-428: refused above 256 until now)
   i_px27_s4fsc   hacktv_ref -m i -s 17734475 --filter --pixelrate 27000000
+  apollofm_f     hacktv_ref -m apollo-fm -s 8000000 --filter         (FM video pre-emphasis on 320 lines: the 625-line 20.25 MHz table, src/video.c:3711-3734)
+  apollofscfm_f  hacktv_ref -m apollo-fsc-fm -s 13500000 --filter    (525 lines, field-sequential colour: the 525-line 20.25 MHz table)
   i_sis_27m      hacktv_ref -m i -s 27000000 --filter --sis dcsis    (sound-in-syncs bursts longer than 128 samples, src/sis.c:155-201;
                                                                       "skip_samples": 64 -- the stream's first 28 samples are not the reference's to say)
 
@@ -28,6 +30,7 @@ import refprobe  # noqa: E402
 import make_golden_rates as rates  # noqa: E402
 import make_golden_sis as sis  # noqa: E402
 import make_golden_r03 as r03  # noqa: E402
+import make_golden_rasters as rasters  # noqa: E402
 
 RATE_CASES = [
     ("pal_36m",  "pal", 36000000, [],           0,                    True,  2),
@@ -41,6 +44,12 @@ RATE_CASES = [
 PIXELRATE_CASES = [
     ("pal_px27_s4fsc", "pal_27m", "pal", 17734475, 27000000, ["--pixelrate", "27000000"], 0, True, 3, {}),
     ("i_px27_s4fsc",   "i_27m",   "i",   17734475, 27000000, ["--filter", "--pixelrate", "27000000"], refprobe.FLAG_FILTER, False, 3, {}),
+]
+# FM video's pre-emphasis filter on a raster that has neither 625 nor 525 lines: the reference takes its 625-line tables for every
+# count but 525 (src/video.c:3693, :3711) -- Apollo's 320 lines at 8 MHz get the 20.25 MHz table and a warning
+RASTER_CASES = [
+    ("apollofm_f",    "apollo-fm",      8000000, ["--filter"], refprobe.FLAG_FILTER, False, 3),
+    ("apollofscfm_f", "apollo-fsc-fm", 13500000, ["--filter"], refprobe.FLAG_FILTER, False, 3),
 ]
 SIS_CASES = [
     # (the reference's first 28 samples differ from run to run at this rate -- its burst renderer's first, never-emitted invocation
@@ -57,6 +66,9 @@ if __name__ == "__main__":
     sis.CASES = [c for c in SIS_CASES if not only or c[0] in only]
     if sis.CASES:
         sis.main()
+    rasters.CASES = [c for c in RASTER_CASES if not only or c[0] in only]
+    if rasters.CASES:
+        rasters.main()
     r03.CASES = [c for c in PIXELRATE_CASES if not only or c[0] in only]
     if r03.CASES:
         r03.main()

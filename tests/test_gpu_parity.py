@@ -70,7 +70,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m", "pal_36m", "pal_8fsc", "i_36m",
                                   # the rasters other than 625 / 525 lines, field-sequential colour (oracle/make_golden_rasters.py)
                                   "e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
-                                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"])
+                                  "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full", "apollofm_f", "apollofscfm_f"])
 def test_stream_equals_reference_digests(golden, case):
     """First frames of every configuration against sha256 of the reference CLI's output."""
     c = golden.cases[case]

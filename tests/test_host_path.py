@@ -339,7 +339,6 @@ def test_sound_in_syncs_bursts_equal_the_oracles(golden, case, loud):
     ("pal-k", 40000001, 13500000, 0, {}, "lowest terms"),                                  # 40 000 001 phases (27 MHz -> 4 f_sc, 709379 phases and this row until round 6, is rendered now)
     ("pal", 48000000, 0, 0, {}, "reads further past the line"),                           # a 37-tap chroma low pass: the over-read model holds 32 samples (SiS at 27 MHz, this row until round 6, is rendered now)
     ("m", 13500000, 0, 0, {"wss": 8}, "625-line"),
-    ("apollo-fm", 8000000, 0, H.FLAG_FILTER, {}, "pre-emphasis taps"),
 ])
 def test_refusals_say_why(capfd, mode, sr, pr, flags, members, words):
     """A configuration the engine does not render is refused at open with HVK_UNSUPPORTED and one line on stderr that says

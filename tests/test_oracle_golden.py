@@ -31,7 +31,7 @@ CASES_RATES = ["pal_8m", "pal_9m", "i_24m", "ntsc_24m", "m_4fsc", "pal_30m",
                "pal_36m", "pal_8fsc", "i_36m", "pal_27m"]       # (round 6: chroma low pass of 27 .. 31 taps, oracle/make_golden_r06.py)
 # the rasters other than 625 / 525 lines and field-sequential colour (oracle/make_golden_rasters.py)
 CASES_RASTERS = ["e_full", "819_bb", "a_full", "405i_full", "405_bb", "ntsc405_bb", "ntsca_full", "240am", "240_bb", "30_bb", "30am", "nbtv_bb", "nbtvam",
-                 "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full"]
+                 "apollo_bb", "apollofm", "apollofsc_bb", "apollofscfm", "cbs405_bb", "mcbs405_full", "apollofm_f", "apollofscfm_f"]
 CASES_TAIL = ["i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail", "pal_fm_pass", "palfm_f14_tail",
               "palfm_px135", "palfm_pass_px135", "palfm_f14_px135", "secamfm_px18", "ntscfm_f18_px135", "palfm_s14_px16", "ntscfm_s18_px16"]
 
