@@ -216,6 +216,7 @@ typedef struct {
 	const int16_t *chroma;        /* SECAM: [frames][frame_samples] values to add; raw baseband input: the slab */
 	const int *vbi_sym;           /* VBI data lines: every table's symbols, { first sample, length, start } */
 	const int16_t *vbi_val;       /*   symbol values */
+	const int *vbi_cov;           /*   per table and sample: the (at most HVK_VBI_COVER) symbols that lie over it and their values there */
 	const unsigned *vbi_ops;      /*   [frames][HVK_VBI_OPS][16]: symbol base, bits, blank range, -, 12 data words (LSB first) */
 	const signed char *vbi_map;   /* [frames][lines]: op of the line or -1 */
 	const int16_t *vits_l;        /* VITS: [n][width] luma added */
@@ -876,6 +877,48 @@ __device__ __forceinline__ void raster_compute(const hvk_kconst_t &k, const hvk_
 				const int lo = seg & 0xFFFF, hi = (unsigned) seg >> 16;
 #pragma unroll
 				for(int i = 0; i < SPL; i++) if(x0 + i >= lo && x0 + i < hi) s[i] = (q & 1) ? lb : la;
+			}
+		}
+		else if(nbits > 0 && P.vbi_cov && (op[3] >> 31))
+		{
+			/* The same sum as a GATHER. Which symbols lie over a sample, and with which values, depends on the table alone (a
+			 * symbol's place is fixed, src/vbidata.c:36-81), and they are a run of consecutive symbols -- teletext's raised
+			 * cosines are 2.3 samples apart and 54 to 59 long: up to 26 over one sample. The host lists per sample the run's
+			 * first symbol, its length and the values (hvk_engine.cpp); a lane takes, for each of its 8 samples, the 32 bits of
+			 * the line's data from that symbol on and adds the values whose bit is set: no accumulator in LDS, no atomics, no
+			 * barrier, and no walk over the set bits with a round of 56 atomic adds each -- that walk was 100 of the 116 us
+			 * the teletext lines of a 128-frame block took. The line's bits: word w in lane w of every wave, fetched across the
+			 * wave by number (lanes from 12 on hold zeros: what lies in front of and behind the data). */
+			const int o3 = __builtin_amdgcn_readfirstlane((int) op[3]);
+			const int lut = o3 & 0xFF, first = (o3 >> 8) & 0xFFFF;
+			unsigned wl = op[4 + ((t & 63) < 12 ? (t & 63) : 11)];
+			{
+				const int wlo = (t & 63) * 32;              /* (bits from nbits on are not rendered) */
+				if(wlo + 32 > nbits) wl = wlo >= nbits ? 0u : (wl & ((1u << (nbits - wlo)) - 1u));
+				if((t & 63) >= 12) wl = 0u;
+			}
+			/* (the lanes that hold the words, a wave's first twelve, have the wave's lowest samples: active whenever one is) */
+			if(x0 < W)
+			{
+				const int4v *cv = (const int4v *) (P.vbi_cov + ((size_t) lut * W + x0) * 16);
+				static_assert(HVK_VBI_COVER == 30, "a sample's entry: the run's start and length, then 30 values in 15 dwords");
+#pragma unroll 2
+				for(int i = 0; i < SPL; i++)
+				{
+					const int4v c0 = cv[i * 4 + 0], c1 = cv[i * 4 + 1], c2 = cv[i * 4 + 2], c3 = cv[i * 4 + 3];
+					const int idx0 = (c0.x & 0xFFFF) - first;                           /* the run's first symbol as a bit of the line's data (may lie in front of it) */
+					const unsigned w_lo = (unsigned) __shfl((int) wl, (idx0 >> 5) & 63), w_hi = (unsigned) __shfl((int) wl, ((idx0 >> 5) + 1) & 63);
+					const unsigned mask = __builtin_amdgcn_alignbit(w_hi, w_lo, (unsigned) idx0 & 31u);
+					const int vd[15] = { c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
+					int a = 0;
+#pragma unroll
+					for(int m = 0; m < 15; m++)
+					{
+						a += (int) ((mask >> (2 * m)) & 1u) * (int) (short) (vd[m] & 0xFFFF);
+						a += (int) ((mask >> (2 * m + 1)) & 1u) * (vd[m] >> 16);
+					}
+					if(x0 + i < W) s[i] = wrap16(s[i] + a);
+				}
 			}
 		}
 		else if(nbits > 0)

@@ -534,6 +534,38 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 		{
 			OPENCHK(_upload(&e->d_vbi_sym, e->t.vbi_sym, sizeof(int32_t) * 3 * e->t.vbi_nsym));
 			OPENCHK(_upload(&e->d_vbi_val, e->t.vbi_val, sizeof(int16_t) * (e->t.vbi_total + 8)));
+			/* The data lines as a gather (raster_compute()): per table and sample the RUN of consecutive symbols that lie over it
+			 * -- its first symbol, its length -- and their values there: 16 dwords a sample. A table in which some sample's
+			 * symbols are not one run of at most HVK_VBI_COVER keeps the walk over the set bits. */
+			if(!(getenv("HVK_VBI_GATHER") && atoi(getenv("HVK_VBI_GATHER")) == 0))
+			{
+				const size_t W = (size_t) k.width;
+				std::vector<int> cov((size_t) HVK_VBI_LUTS * W * 16 + 8 * 16, 0);
+				std::vector<int> b0(W), n(W);
+				for(int u = 0; u < HVK_VBI_LUTS; u++)
+				{
+					e->vbi_cov_ok[u] = e->t.lut_nsym[u] > 0 && e->t.lut_nsym[u] < 0x7000;
+					std::fill(b0.begin(), b0.end(), 0);
+					std::fill(n.begin(), n.end(), 0);
+					for(int sy = 0; sy < e->t.lut_nsym[u] && e->vbi_cov_ok[u]; sy++)
+					{
+						const int32_t *q = e->t.vbi_sym + (size_t) (e->t.lut_base[u] + sy) * 3;
+						for(int j = 0; j < q[1]; j++)
+						{
+							const long x = (long) q[0] + j;
+							if(x < 0 || x >= (long) W) continue;
+							if(n[(size_t) x] == 0) b0[(size_t) x] = sy;
+							if(sy != b0[(size_t) x] + n[(size_t) x] || n[(size_t) x] >= HVK_VBI_COVER) { e->vbi_cov_ok[u] = 0; break; }
+							int *ent = cov.data() + ((size_t) u * W + (size_t) x) * 16;
+							const int m = n[(size_t) x]++;
+							const unsigned v = (unsigned) (uint16_t) e->t.vbi_val[q[2] + j];
+							ent[1 + m / 2] |= (int) ((m & 1) ? (v << 16) : v);
+							ent[0] = b0[(size_t) x] | (n[(size_t) x] << 16);
+						}
+					}
+				}
+				OPENCHK(_upload(&e->d_vbi_cov, cov.data(), cov.size() * sizeof(int)));
+			}
 		}
 		OPENHIP(hipMalloc((void **) &e->d_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4));
 		OPENHIP(hipHostMalloc((void **) &e->h_ops, (size_t) max_frames * HVK_VBI_OPS * HVK_VBI_OPWORDS * 4, hipHostMallocDefault));
@@ -874,7 +906,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		if(e->stream) (void) hipStreamSynchronize(e->stream);
 		for(int i = 0; i < HVK_TIMING_SLOTS; i++) for(int j = 0; j < 3; j++) if(e->ev[i][j]) (void) hipEventDestroy(e->ev[i][j]);
 		void *dev[] = { e->d_yuv, e->d_yuvparams, e->d_desc, e->d_pulses, e->d_linebase, e->d_clut, e->d_burst, e->d_ghost, e->d_Lp, e->d_Cp, e->d_UVp, e->d_clut3, e->d_lineoff,
-		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2_alloc ? (void *) e->d_C2_alloc : (void *) e->d_C2, e->d_Cq, e->d_svrec, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
+		                e->d_tapd, e->d_cca, e->d_pool_alloc, e->d_fdesc, e->d_S, e->d_car, e->d_sym, e->d_tile, e->d_out, e->d_chroma_alloc, e->d_vbi_sym, e->d_vbi_val, e->d_vbi_cov, e->d_ops, e->d_map, e->d_vits_l, e->d_vits_c, e->d_sis_dense, e->d_sis_win, e->d_sis_first, e->d_sis_bits, e->d_conv, e->d_off, e->d_pass, e->d_S2, e->d_C2_alloc ? (void *) e->d_C2_alloc : (void *) e->d_C2, e->d_Cq, e->d_svrec, e->d_rs_taps, e->d_C, e->d_raw, e->d_mfma_a, e->d_frec, e->d_ovr_list, e->d_ovr_idx, e->d_sums, e->d_mfma_a28, e->d_tilerec, e->d_fsc_rows };
 		for(void *p : dev) if(p) (void) hipFree(p);
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);

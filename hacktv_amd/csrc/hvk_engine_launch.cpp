@@ -119,6 +119,7 @@ void hvk_e_kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t 
 	ra.chroma = e->t.k.rawbb ? e->d_raw : e->d_chroma;
 	ra.vbi_sym = (const int *) e->d_vbi_sym;
 	ra.vbi_val = (const int16_t *) e->d_vbi_val;
+	ra.vbi_cov = (const int *) e->d_vbi_cov;
 	ra.vbi_ops = e->d_ops;
 	ra.vbi_map = (const signed char *) e->d_map;
 	ra.fsc_rows = (const int16_t *) e->d_fsc_rows;

@@ -88,6 +88,8 @@ struct hvk_engine {
 	uint32_t *h_tt_mask;        /* [max_frames] rows present */
 	/* VBI data lines (teletext, WSS, VITC): symbol store, per-frame op list and line map */
 	void *d_vbi_sym, *d_vbi_val;
+	void *d_vbi_cov;            /* the tables' cover lists (hvk_rptrs_t.vbi_cov); vbi_cov_ok[u]: table u has one (no sample under more than HVK_VBI_COVER symbols) */
+	int vbi_cov_ok[HVK_VBI_LUTS];
 	uint32_t *d_ops, *h_ops;    /* [max_frames][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	int8_t *d_map, *h_map;      /* [max_frames][lines] */
 	void *d_vits_l, *d_vits_c, *d_fsc_rows;

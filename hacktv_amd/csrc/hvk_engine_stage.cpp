@@ -48,6 +48,8 @@ static void _build_vbi_ops(hvk_engine *e, int nframes)
 			op[0] = (uint32_t) (t.lut_base[lut] + first_symbol);
 			op[1] = (uint32_t) nbits;
 			op[2] = (uint32_t) blank_lo | ((uint32_t) blank_hi << 16);
+			/* (the table, the first symbol the data's bit 0 stands for, and whether the table has cover lists: the gather) */
+			op[3] = (uint32_t) lut | ((uint32_t) first_symbol << 8) | ((e->d_vbi_cov && e->vbi_cov_ok[lut] && first_symbol < 0x7FFF) ? 0x80000000u : 0u);
 			memcpy(op + 4, bytes, 48);
 			link(line0);
 			n++;

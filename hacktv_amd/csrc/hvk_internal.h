@@ -23,6 +23,7 @@ extern "C" {
 #define HVK_VBI_OPS      64     /* VBI lines per frame (32 teletext + WSS + 4 VITC + CC608 + 20 ACP + spare) */
 #define HVK_VBI_OPWORDS  16     /* dwords per op: sym_base, nbits, blank range, spare, 12 data words */
 #define HVK_SIS_SPAN     256    /* samples at a line's start the sound-in-syncs burst and its window lie in */
+#define HVK_VBI_COVER    30     /* symbols that may lie over one sample in a table's cover list (hvk_engine.cpp: the data lines as a gather); a sample's entry: 16 dwords */
 #define HVK_VBI_LUTS     4      /* 0 teletext, 1 WSS, 2 VITC, 3 CC608 (32 bit cells + the clock run-in as a 33rd symbol) */
 
 typedef struct { int16_t i, q; } hvk_c16_t;

@@ -32,6 +32,7 @@ typedef struct {
 	const int16_t *chroma;      /* SECAM: [nframes][frame_samples]; raw baseband input: [nframes][slab_lines][width] */
 	const int *vbi_sym;         /* VBI data lines: symbol index of every table */
 	const int16_t *vbi_val;
+	const int *vbi_cov;         /* [HVK_VBI_LUTS][width][16]: { first symbol over the sample | how many << 16, then their values there as int16 pairs }; NULL: no cover lists */
 	const unsigned *vbi_ops;    /* [nframes][HVK_VBI_OPS][HVK_VBI_OPWORDS] */
 	const signed char *vbi_map; /* [nframes][lines] */
 	const int16_t *vits_l, *vits_c;

@@ -793,6 +793,7 @@ extern "C" void hvk_raster_ptrs(const hvk_raster_args_t *a, hvk_rptrs_t *P)
 	P->chroma = a->chroma;
 	P->vbi_sym = a->vbi_sym;
 	P->vbi_val = a->vbi_val;
+	P->vbi_cov = a->vbi_cov;
 	P->vbi_ops = a->vbi_ops;
 	P->vbi_map = a->vbi_map;
 	P->vits_l = a->vits_l;
