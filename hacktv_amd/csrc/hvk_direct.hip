@@ -757,7 +757,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int crow = COLOUR == 2 ? __builtin_amdgcn_readfirstlane(D.fdesc[2 * y + 1].chroma_row) : 0;     /* SECAM: where the frame's sub-carrier lies */
 	int b1, b2;
 	dline_t lA, lB, lC;
-	if(OVR || !TR)
+	if(!TR)
 	{
 		const int p0 = n0 - LEAD;                               /* stream position (frame local) of window position 0 */
 		const int lineA = p0 < 0 ? -1 : (int) __builtin_amdgcn_readfirstlane((int) __umulhi((unsigned) p0, D.inv_w));
@@ -787,6 +787,13 @@ void hvk_k_direct(const hvk_kconst_t k,
 			const bool zero = prev && first;        /* before the stream: the filter's history is zero, not blanking */
 			l3[X].lb = zero ? D.zero_row * W + R.nws[X] : (prev ? row0_prev : row0_own) * W + R.lw[X];
 			l3[X].cb = 2 * D.creg + R.nws[X];
+			if(OVR && R.ovr[X] >= 0)
+			{
+				/* rendered whole by the raster kernel for this frame (VBI data, test signals, their sub-carrier): nothing to add (direct_line()) */
+				l3[X].lb = (D.ovr_row0 + y * D.ovr_n + R.ovr[X]) * W + R.nws[X];
+				if(COLOUR == 2) l3[X].cb = D.chroma_zero + R.nws[X];
+				continue;
+			}
 			if(COLOUR == 2) l3[X].cb = (own && !zero ? crow * (int) k.raster_samples + line0 * W : D.chroma_zero) + R.nws[X];
 			if(COLOUR == 1 && !zero && pal != 0)
 			{
@@ -1021,7 +1028,7 @@ static int _launch_direct2(const hvk_direct_args_t *a, hipStream_t stream)
 	(const hvk_tilerec_t *) a->tilerec, a->tiles_pad, (const int *) a->carriers, a->tilesyms, \
 	a->nicam_tapd, a->nicam_cca, (const int4v *) a->mfma_a, a->mfma_ci, a->mfma_cq, (int *) a->iq, a->out_stride, tiles, a->first_frame, a->frame_stride)
 /* (no tile records -- HVK_TILEREC=0 -- : the lines of a tile's window worked out by every wave, the second opinion) */
-#define DIRECT3(EX, OV, SN) do { if(OV == 0 && a->tilerec) DIRECT4(EX, OV, SN, (OV == 0 ? 1 : 0)); else DIRECT4(EX, OV, SN, 0); } while(0)
+#define DIRECT3(EX, OV, SN) do { if(a->tilerec) DIRECT4(EX, OV, SN, 1); else DIRECT4(EX, OV, SN, 0); } while(0)
 #define DIRECT2(EX, OV) do { if(VF && OV == 0 && a->k.has_carriers && a->k.has_nicam) DIRECT3(EX, OV, (VF && OV == 0 ? 1 : 0)); else DIRECT3(EX, OV, 0); } while(0)
 #define DIRECT(EX) do { if(a->D.ovr_idx) DIRECT2(EX, 1); else DIRECT2(EX, 0); } while(0)
 	if(a->k.frame_samples % HVK_TILE == 0) DIRECT(1); else DIRECT(0);

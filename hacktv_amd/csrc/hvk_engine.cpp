@@ -321,6 +321,9 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 				e->ovr_row0 = e->plane_rows;
 				OPENCHK(_upload((void **) &e->d_ovr_list, list.data(), list.size() * sizeof(int16_t)));
 				OPENCHK(_upload((void **) &e->d_ovr_idx, idx.data(), idx.size() * sizeof(int16_t)));
+				e->h_ovr_idx = (int16_t *) malloc(idx.size() * sizeof(int16_t));
+				if(!e->h_ovr_idx) { *pe = NULL; hvk_close(e); return(HVK_OUT_OF_MEMORY); }
+				memcpy(e->h_ovr_idx, idx.data(), idx.size() * sizeof(int16_t));
 			}
 		}
 		if(e->direct)
@@ -380,13 +383,15 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			std::vector<uint32_t> lo((size_t) k.lines + 4, 0);
 			for(int j = 0; j < k.lines + 4 && k.colour && !k.secam && k.clw > 0; j++) lo[j] = (uint32_t) ((((int64_t) (j - 1) * k.width) % k.clw + k.clw) % k.clw);
 			OPENCHK(_upload((void **) &e->d_lineoff, lo.data(), lo.size() * 4));
-			if(e->direct && !e->ovr_n && !(getenv("HVK_TILEREC") && atoi(getenv("HVK_TILEREC")) == 0))
+			if(e->direct && !(getenv("HVK_TILEREC") && atoi(getenv("HVK_TILEREC")) == 0))
 			{
 				/* per frame parity and tile of 1024 outputs (the tiles of the last, partial workgroup included): the lines its window
 				 * lies in -- the arithmetic of hvk_direct.hip:direct_line_loads() / direct_line(), done once here */
 				const int DGT = 4, lead = k.vf_type ? 26 : 0, W = k.width, tiles = (k.frame_samples + HVK_TILE - 1) / HVK_TILE;
 				e->tiles_pad = (tiles + DGT - 1) / DGT * DGT;
 				std::vector<hvk_tilerec_t> rec((size_t) 2 * e->tiles_pad);
+				std::vector<int16_t> ovr_of_line((size_t) k.lines, -1);
+				if(e->ovr_n) for(int l = 0; l < k.lines; l++) ovr_of_line[(size_t) l] = e->h_ovr_idx[(size_t) l];
 				memset(rec.data(), 0, rec.size() * sizeof(hvk_tilerec_t));
 				for(int par_own = 0; par_own < 2; par_own++) for(int tl = 0; tl < e->tiles_pad; tl++)
 				{
@@ -406,6 +411,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 						R.lw[X] = line0 * W - wstart;
 						R.nws[X] = -wstart;
 						R.off[X] = lo[rel + 1 < k.lines + 3 ? rel + 1 : k.lines + 3];
+						R.ovr[X] = (own && e->ovr_n) ? (int) ovr_of_line[(size_t) line0] : -1;       /* (a line the optional stages can write to: the frame's own row of it) */
 					}
 				}
 				OPENCHK(_upload(&e->d_tilerec, rec.data(), rec.size() * sizeof(hvk_tilerec_t)));
@@ -927,6 +933,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 
 	free(e->sym_tmp);
 	free(e->chroma_par);
+	free(e->h_ovr_idx);
 	free(e->fm_prime_car);
 	free(e->cc_pairs);
 	delete e->raw_q;
@@ -1550,7 +1557,7 @@ extern "C" int hvk_kernel_names(const hvk_engine_t *e, char *buf, int n)
 	{
 		const int exact = k.frame_samples % HVK_TILE == 0 ? 1 : 0, vf = k.vf_type ? 1 : 0, col = k.secam ? 2 : (k.colour ? 1 : 0);
 		char dk[96];
-		snprintf(dk, sizeof(dk), "hvk_k_direct<%d, %d, %d, %d, %d, %d>", vf, col, exact, e->ovr_n ? 1 : 0, (k.has_carriers && k.has_nicam && vf && !e->ovr_n) ? 1 : 0, e->d_tilerec ? 1 : 0);
+		snprintf(dk, sizeof(dk), "hvk_k_direct<%d, %d, %d, %d, %d, %d>", vf, col, exact, e->ovr_n ? 1 : 0, (k.has_carriers && k.has_nicam && vf && !e->ovr_n) ? 1 : 0, e->d_tilerec ? 1 : 0);      /* (tile records with rows of the optional stages too since round 6) */
 		if(e->ovr_n) snprintf(buf, n, "hvk_k_raster<%d, %d, 0, 1, 0, %d>;%s", nt, k.secam ? 1 : 0, lv, dk);
 		else snprintf(buf, n, "%s", dk);
 		return(HVK_OK);

@@ -87,6 +87,7 @@ struct hvk_engine {
 	uint32_t *h_tt_pk;          /* teletext packets queued for the next batch: [max_frames][32][12] */
 	uint32_t *h_tt_mask;        /* [max_frames] rows present */
 	/* VBI data lines (teletext, WSS, VITC): symbol store, per-frame op list and line map */
+	int16_t *h_ovr_idx;         /* [lines] host copy of hvk_dptrs_t.ovr_idx (the tile records carry it) */
 	void *d_vbi_sym, *d_vbi_val;
 	void *d_vbi_cov;            /* the tables' cover lists (hvk_rptrs_t.vbi_cov); vbi_cov_ok[u]: table u has one (no sample under more than HVK_VBI_COVER symbols) */
 	int vbi_cov_ok[HVK_VBI_LUTS];

@@ -108,13 +108,13 @@ typedef struct {
 	int32_t lw[3];              /* line * width - (window position of the line's sample 0): a plane index less the picture's first row's */
 	int32_t nws[3];             /* - (window position of the line's sample 0) */
 	uint32_t off[3];            /* (line * width) mod clw */
-	int32_t pad[3];
+	int32_t ovr[3];             /* the line's place among a frame's rows of the optional stages (hvk_dptrs_t.ovr_idx), -1: a line of the planes */
 } __attribute__((aligned(64))) hvk_tilerec_t;
 
 typedef struct {
 	hvk_kconst_t k;
 	hvk_dptrs_t D;
-	const void *tilerec;        /* [2][tiles_pad] hvk_tilerec_t, NULL with rows of the optional stages (D.ovr_idx) */
+	const void *tilerec;        /* [2][tiles_pad] hvk_tilerec_t (HVK_TILEREC=0: NULL, the lines worked out by every wave) */
 	int tiles_pad;
 	const hvk_c16_t *carriers;
 	const int *tilesyms;

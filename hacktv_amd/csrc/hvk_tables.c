@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <gnu/libc-version.h>
 #include "hvk_internal.h"
 #include "hvk_fm_taps.h"
 
@@ -456,6 +457,18 @@ void hvk_tables_default_ghost(hvk_tables_t *t)
 
 	memset(t->ghost, 0, sizeof(t->ghost));
 	if(t->k.chroma_ntaps == 0 || t->chroma_unfiltered || t->burst_win == NULL) return;
+	{
+		/* the model is glibc 2.35's malloc (chunk sizes, the size word's flag bits, which freed chunk the next request gets):
+		 * said once where the process runs on another, instead of silently */
+		static int said;
+		const char *v = gnu_get_libc_version();
+		if(!said && v && strncmp(v, "2.35", 4) != 0 && !getenv("HVK_QUIET"))
+		{
+			said = 1;
+			fprintf(stderr, "libhvk: note: the samples the reference's chroma low pass reads past its buffer (src/fir.c:365-372) are modelled "
+			                "for glibc 2.35; this is glibc %s -- a reference built here may end its colour lines differently: hvk_set_chroma_ghost()\n", v);
+		}
+	}
 
 	o = slack;
 	if(o + 4 > HVK_GHOST_LEN) return;
