@@ -19,7 +19,16 @@ extern "C" {
 #define HVK_MAX_VF_TAPS  72     /* (51 for the designed filters; the FM pre-emphasis tables have 67 and 71) */
 #define HVK_PULSE_PAD    8      /* zero int16 either side of every sync pulse in the flat value table */
 #define HVK_NICAM_LEAD   8      /* zero dwords in front of the duplicated NICAM pulse table */
-#define HVK_NICAM_BACK   7      /* symbols that can overlap a lane's 8 samples */
+#ifndef HVK_NICAM_BACK
+/* Symbols that can lie over a lane's 8 samples. A symbol started at st reaches sample n while 0 <= n - st < ntaps, so a lane's samples
+ * [x0, x0 + 7] see the starts in (x0 - ntaps, x0 + 7]: ntaps + 7 positions. Starts are sps or sps - 1 apart (sps = ceil(rate / 364000),
+ * src/nicam728.c:302-304, :398-407), ntaps <= 5 rate / 364000 + 2 (:268): at most floor((ntaps + 6) / (sps - 1)) + 1 = 6 of them for
+ * every rate above 5.1 MHz (16 MHz: 227 / 43 -> 5 + 1; 10 MHz: 145 / 27; 36 MHz: 501 / 98) -- NICAM is taken from 10 MHz up. Rounds 1-5
+ * walk 7: the seventh always reads the pulse table's zero tail. 6 is exact (every parity gate) and was measured in round 6 -- 14 vector
+ * instructions and two LDS reads fewer a lane of 401 and 33 -- at 0.2027 / 0.2039 / 0.2020 ms against 0.2013 / 0.2023 / 0.2017 with 7 on
+ * one box (profiles/r06_direct_persistent_pipelined_experiment.txt): the launch does not follow its instruction count. 7 stays. */
+#define HVK_NICAM_BACK   7
+#endif
 #define HVK_VBI_OPS      64     /* VBI lines per frame (32 teletext + WSS + 4 VITC + CC608 + 20 ACP + spare) */
 #define HVK_VBI_OPWORDS  16     /* dwords per op: sym_base, nbits, blank range, spare, 12 data words */
 #define HVK_SIS_SPAN     256    /* samples at a line's start the sound-in-syncs burst and its window lie in */
