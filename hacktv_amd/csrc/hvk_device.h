@@ -1154,8 +1154,10 @@ __device__ __forceinline__ void split_planes(const int4u d, int2v &ph, int2v &pl
  * low accumulator. Then >> 15 and the saturating pack (src/fir.c:605-608), into `outl` (packed I/Q, indexed
  * by output) for the lane that owns the 8 outputs. xh / xl: the planes, position 0 = 26 samples before the
  * tile's first output; t: lane of the tile (0 .. 127). */
-__device__ __forceinline__ void mfma_filter(const unsigned char *xh, const unsigned char *xl, int *outl, const int t,
-                                            const int4v a_hh, const int4v a_hl, const int mfma_ci, const int mfma_cq)
+/* emit(j, seg, g, pk): the two finished outputs 2 g, 2 g + 1 of segment seg = 64 (t >> 6) + 16 j + c (packed I/Q each), in the lane the matrix unit leaves them in */
+template<class EMIT>
+__device__ __forceinline__ void mfma_filter_each(const unsigned char *xh, const unsigned char *xl, const int t,
+                                                 const int4v a_hh, const int4v a_hl, const int mfma_ci, const int mfma_cq, EMIT &&emit)
 {
 	const int lane = t & 63, g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -1185,8 +1187,14 @@ __device__ __forceinline__ void mfma_filter(const unsigned char *xh, const unsig
 		int2v pk;
 		pk.x = sat_pack16(y[0] >> 15, y[1] >> 15);
 		pk.y = sat_pack16(y[2] >> 15, y[3] >> 15);
-		*(int2v *) (outl + seg * 8 + 2 * g) = pk;
+		emit(j, seg, g, pk);
 	}
+}
+
+__device__ __forceinline__ void mfma_filter(const unsigned char *xh, const unsigned char *xl, int *outl, const int t,
+                                            const int4v a_hh, const int4v a_hl, const int mfma_ci, const int mfma_cq)
+{
+	mfma_filter_each(xh, xl, t, a_hh, a_hl, mfma_ci, mfma_cq, [&](const int, const int seg, const int g, const int2v pk) { *(int2v *) (outl + seg * 8 + 2 * g) = pk; });
 }
 
 #endif

@@ -685,6 +685,17 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const int64_t frame_stride)
 {
 	constexpr int LEAD = VF ? DLEAD : 0;
+	/* FIN: the configuration has the filter, carriers and NICAM (the metric's class) -- the sample is FINISHED in the lane the
+	 * matrix unit leaves it in: the NICAM contribution, computed per 8 consecutive samples as ever, goes through LDS to that lane
+	 * (the exchange the filter's outputs used to make in the other direction), the carriers are read and the samples stored there,
+	 * 8 bytes a lane and 512 contiguous bytes a wave instruction. With 8 consecutive samples a lane the two 16-byte accesses of
+	 * a lane interleaved: every instruction touched half of every 32 bytes of a wave's 2 KB (tools/ablate_direct.py: whole
+	 * kilobytes per instruction are worth 9 % of the launch, the carriers' reads 7 of them). */
+#ifdef HVK_V_OLDFIN
+	constexpr bool FIN = false;
+#else
+	constexpr bool FIN = VF && SND && !OVR;
+#endif
 	constexpr int NP = DG * HVK_TILE + 64;      /* window positions of the workgroup: its tiles follow each other in the stream */
 	constexpr int TL = HVK_TILE / HVK_SPL;      /* lanes of a tile */
 	__shared__ __attribute__((aligned(16))) unsigned char xh[VF ? NP : 16], xl[VF ? NP : 16];
@@ -842,14 +853,37 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int4u g0 = direct_group_make<COLOUR>(D, G0, x0);
 
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
-	if(has_car && (SND || whole))
+	int2u cj[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+	if(FIN)
+	{
+		/* the carriers of the two samples the lane finishes in each of the filter's four passes (mfma_filter_each) */
+		const int fl = t & 63, fg = fl >> 4, fc = fl & 15;
+#pragma unroll
+		for(int j = 0; j < 4; j++)
+		{
+			const int nn = n0 + ((t >> 6) * 64 + j * 16 + fc) * 8 + 2 * fg;
+			const bool ok2 = tile_valid && (EXACT || nn + 2 <= FS);
+			cj[j] = __builtin_nontemporal_load((const int2u *) (carriers + (size_t) y * FS + (ok2 ? nn : 0)));
+		}
+	}
+	else if(has_car && (SND || whole) && !ABLATE(256))      /* (ABLATE: measuring builds only, tools/ablate_direct.py) */
 	{
 		/* (SND: unconditionally -- a lane outside the frame reads the frame's first run instead, and uses nothing of it) */
 		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + (whole ? n : 0));
 		/* read once, like the output is written once: marked as streaming so that neither pushes the plane rows and the
 		 * colour table's slices, which every frame comes back to, out of the XCD's L2 (+5 % on the metric configuration) */
+		if(ABLATE(8192))
+		{
+			/* (timing only: a wave's two reads as two contiguous kilobytes instead of interleaved halves of every 32 bytes) */
+			const int4u *cw = (const int4u *) (carriers + (size_t) y * FS + (n - (t & 63) * SPL));
+			car0 = __builtin_nontemporal_load(&cw[t & 63]);
+			car1 = __builtin_nontemporal_load(&cw[64 + (t & 63)]);
+		}
+		else
+		{
 		car0 = __builtin_nontemporal_load(&c[0]);
 		car1 = __builtin_nontemporal_load(&c[1]);
+		}
 	}
 
 	if(tap_mine) ((int4v *) tapd)[threadIdx.x] = tap_stage;
@@ -894,9 +928,43 @@ void hvk_k_direct(const hvk_kconst_t k,
 		nicam_mix_rows(nicam_cca, k.nicam_cc_len + 8, cp, mix);
 	}
 
+	if(FIN)
+	{
+		/* NICAM on its own (the adds are modulo 2^16 per channel: their order is free), handed to the lanes that finish the samples */
+		int nic[SPL] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		nicam_add(k, x0, sym_st, sym_ent, tapd, mix, nic);
+		((int4v *) (outl + x0))[0] = (int4v) { nic[0], nic[1], nic[2], nic[3] };
+		((int4v *) (outl + x0))[1] = (int4v) { nic[4], nic[5], nic[6], nic[7] };
+		PT(3);
+		/* (the exchange is within a wave -- mfma_filter_each(): wave t >> 6 finishes segments 64 (t >> 6) .. + 63, its own lanes'
+		 * samples -- and a wave's LDS operations are carried out in the order it issues them: a fence for the compiler, no barrier) */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		PT(4);
+		int *const frame_out = iq + (size_t) y * out_stride * FS;
+		mfma_filter_each(xh + sub * HVK_TILE, xl + sub * HVK_TILE, t, a_hh, a_hl, mfma_ci, mfma_cq,
+		                 [&](const int j, const int seg, const int g, const int2v pk)
+		{
+			const int2v nv = *(const int2v *) (outl + seg * 8 + 2 * g);
+			const int nn = n0 + seg * 8 + 2 * g;
+			int2u ov;
+			ov.x = pk_add16(pk_add16(pk.x, cj[j].x), nv.x);
+			ov.y = pk_add16(pk_add16(pk.y, cj[j].y), nv.y);
+			if(tile_valid && (EXACT || nn + 2 <= FS)) __builtin_nontemporal_store(ov, (int2u *) (frame_out + nn));
+			else if(tile_valid && nn < FS)
+			{
+				/* (a frame of an odd number of samples: its last one) */
+				frame_out[nn] = pk_add16(pk_add16(pk.x, carriers[(size_t) y * FS + nn]), nv.x);
+			}
+		});
+		PT(5); PT(6); PT(7);
+		return;
+	}
+
 	if(VF)
 	{
-		mfma_filter(xh + sub * HVK_TILE, xl + sub * HVK_TILE, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
+		if(!ABLATE(2048)) mfma_filter(xh + sub * HVK_TILE, xl + sub * HVK_TILE, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
 		PT(3);  /* the filter on the matrix unit */
 		__syncthreads();
 		PT(4);  /* the second barrier */
@@ -923,11 +991,20 @@ void hvk_k_direct(const hvk_kconst_t k,
 	}
 
 	PT(5);      /* the filter's outputs back from LDS, the carriers added */
-	if(has_nic) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
+	if(has_nic && !ABLATE(1024)) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
 	PT(6);      /* NICAM */
 
 	/* interleaved int16 I/Q, 32 bytes per lane */
 	int *dst = iq + (size_t) y * out_stride * FS + n;
+	if(ABLATE(512) && o[0] != 0x12345) return;
+	if(ABLATE(4096) && whole)
+	{
+		/* (timing only: a wave's two stores as two contiguous kilobytes) */
+		int4u *dw = (int4u *) (dst - (t & 63) * SPL);
+		__builtin_nontemporal_store(((int4u) { o[0], o[1], o[2], o[3] }), &dw[t & 63]);
+		__builtin_nontemporal_store(((int4u) { o[4], o[5], o[6], o[7] }), &dw[64 + (t & 63)]);
+		return;
+	}
 	if(whole)
 	{
 		__builtin_nontemporal_store(((int4u) { o[0], o[1], o[2], o[3] }), &((int4u *) dst)[0]);
