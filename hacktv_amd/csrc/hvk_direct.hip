@@ -685,16 +685,16 @@ void hvk_k_direct(const hvk_kconst_t k,
                   const int64_t frame_stride)
 {
 	constexpr int LEAD = VF ? DLEAD : 0;
-	/* FIN: the configuration has the filter, carriers and NICAM (the metric's class) -- the sample is FINISHED in the lane the
-	 * matrix unit leaves it in: the NICAM contribution, computed per 8 consecutive samples as ever, goes through LDS to that lane
-	 * (the exchange the filter's outputs used to make in the other direction), the carriers are read and the samples stored there,
-	 * 8 bytes a lane and 512 contiguous bytes a wave instruction. With 8 consecutive samples a lane the two 16-byte accesses of
-	 * a lane interleaved: every instruction touched half of every 32 bytes of a wave's 2 KB (tools/ablate_direct.py: whole
-	 * kilobytes per instruction are worth 9 % of the launch, the carriers' reads 7 of them). */
+	/* FIN (every configuration with the video filter): the sample is FINISHED in the lane the matrix unit leaves it in. The NICAM
+	 * contribution, computed per 8 consecutive samples as ever, goes through LDS to that lane (the exchange the filter's outputs
+	 * used to make in the other direction; none without NICAM), the carriers are read and the samples stored there, 8 bytes a
+	 * lane and 512 contiguous bytes a wave instruction. With 8 consecutive samples a lane the two 16-byte accesses of a lane
+	 * interleaved: every instruction touched half of every 32 bytes of a wave's 2 KB (tools/ablate_direct.py: whole kilobytes
+	 * per instruction are worth 9 % of the metric's launch, the carriers' reads 7 of them; round 6: 0.194-0.202 -> 0.179-0.185 ms). */
 #ifdef HVK_V_OLDFIN
 	constexpr bool FIN = false;
 #else
-	constexpr bool FIN = VF && SND && !OVR;
+	constexpr bool FIN = VF != 0;
 #endif
 	constexpr int NP = DG * HVK_TILE + 64;      /* window positions of the workgroup: its tiles follow each other in the stream */
 	constexpr int TL = HVK_TILE / HVK_SPL;      /* lanes of a tile */
@@ -854,7 +854,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
 	int2u cj[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
-	if(FIN)
+	if(FIN && has_car)
 	{
 		/* the carriers of the two samples the lane finishes in each of the filter's four passes (mfma_filter_each) */
 		const int fl = t & 63, fg = fl >> 4, fc = fl & 15;
@@ -866,7 +866,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 			cj[j] = __builtin_nontemporal_load((const int2u *) (carriers + (size_t) y * FS + (ok2 ? nn : 0)));
 		}
 	}
-	else if(has_car && (SND || whole) && !ABLATE(256))      /* (ABLATE: measuring builds only, tools/ablate_direct.py) */
+	else if(!FIN && has_car && (SND || whole) && !ABLATE(256))      /* (ABLATE: measuring builds only, tools/ablate_direct.py) */
 	{
 		/* (SND: unconditionally -- a lane outside the frame reads the frame's first run instead, and uses nothing of it) */
 		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + (whole ? n : 0));
@@ -931,10 +931,13 @@ void hvk_k_direct(const hvk_kconst_t k,
 	if(FIN)
 	{
 		/* NICAM on its own (the adds are modulo 2^16 per channel: their order is free), handed to the lanes that finish the samples */
-		int nic[SPL] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		nicam_add(k, x0, sym_st, sym_ent, tapd, mix, nic);
-		((int4v *) (outl + x0))[0] = (int4v) { nic[0], nic[1], nic[2], nic[3] };
-		((int4v *) (outl + x0))[1] = (int4v) { nic[4], nic[5], nic[6], nic[7] };
+		if(has_nic)
+		{
+			int nic[SPL] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			nicam_add(k, x0, sym_st, sym_ent, tapd, mix, nic);
+			((int4v *) (outl + x0))[0] = (int4v) { nic[0], nic[1], nic[2], nic[3] };
+			((int4v *) (outl + x0))[1] = (int4v) { nic[4], nic[5], nic[6], nic[7] };
+		}
 		PT(3);
 		/* (the exchange is within a wave -- mfma_filter_each(): wave t >> 6 finishes segments 64 (t >> 6) .. + 63, its own lanes'
 		 * samples -- and a wave's LDS operations are carried out in the order it issues them: a fence for the compiler, no barrier) */
@@ -946,7 +949,8 @@ void hvk_k_direct(const hvk_kconst_t k,
 		mfma_filter_each(xh + sub * HVK_TILE, xl + sub * HVK_TILE, t, a_hh, a_hl, mfma_ci, mfma_cq,
 		                 [&](const int j, const int seg, const int g, const int2v pk)
 		{
-			const int2v nv = *(const int2v *) (outl + seg * 8 + 2 * g);
+			int2v nv = { 0, 0 };
+			if(has_nic) nv = *(const int2v *) (outl + seg * 8 + 2 * g);
 			const int nn = n0 + seg * 8 + 2 * g;
 			int2u ov;
 			ov.x = pk_add16(pk_add16(pk.x, cj[j].x), nv.x);
@@ -955,7 +959,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 			else if(tile_valid && nn < FS)
 			{
 				/* (a frame of an odd number of samples: its last one) */
-				frame_out[nn] = pk_add16(pk_add16(pk.x, carriers[(size_t) y * FS + nn]), nv.x);
+				frame_out[nn] = pk_add16(pk_add16(pk.x, has_car ? carriers[(size_t) y * FS + nn] : 0), nv.x);
 			}
 		});
 		PT(5); PT(6); PT(7);
