@@ -275,7 +275,7 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		cc_tile = row[HVK_NICAM_SYMS];
 		symv = row[t < HVK_NICAM_SYMS ? t : HVK_NICAM_SYMS - 1];
 	}
-	const int n = n0 + x0;
+	(void) x0;
 
 	/* ---- the line: part 1 ---- */
 	fline_t F;
@@ -288,12 +288,18 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 	/* (asked for behind the first barrier: the line's own reads are through, these have all of part 2 and the filter to arrive in,
 	 * and sixteen registers fewer are live while the levels are made) */
 	const int4v a_hh = mfma_a[t & 63], a_hl = mfma_a[64 + (t & 63)];
-	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
+	/* the carriers of the two samples the lane FINISHES in each of the filter's four passes (hvk_k_direct's FIN: samples are
+	 * finished in the lane the matrix unit leaves them in, 8 bytes a lane and 512 contiguous bytes a wave instruction) */
+	int2u cj[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
 	if(k.has_carriers && tile_valid)
 	{
-		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + n);
-		car0 = __builtin_nontemporal_load(&c[0]);
-		car1 = __builtin_nontemporal_load(&c[1]);
+		const int fl = t & 63, fg = fl >> 4, fc = fl & 15;
+#pragma unroll
+		for(int j = 0; j < 4; j++)
+		{
+			const int nn = n0 + ((t >> 6) * 64 + j * 16 + fc) * 8 + 2 * fg;
+			cj[j] = __builtin_nontemporal_load((const int2u *) (carriers + (size_t) y * FS + nn));
+		}
 	}
 
 	/* ---- part 2, and into the byte planes: window position of sample x of the group's line j is j * 1024 + x + FLEAD ---- */
@@ -343,26 +349,30 @@ void hvk_k_fused(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		nicam_mix_rows(nicam_cca, k.nicam_cc_len + 8, cp, mix);
 	}
 	int *const outl = stage_g[sub];
-	if(!halo) mfma_filter(xh + sub * FW, xl + sub * FW, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
-	__syncthreads();
-	if(halo || !tile_valid) return;
+	if(halo || !tile_valid) return;         /* (no barrier behind this point: the exchange below is within a wave) */
 
-	int o[SPL];
+	/* NICAM on its own (the adds are modulo 2^16 per channel: their order is free), handed through LDS to the lanes that finish the samples */
+	if(k.has_nicam)
 	{
-		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
-		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
-		o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
+		int nic[SPL] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		nicam_add(k, x0, sym_st_g[sub], sym_ent_g + 1 + sub * HVK_NICAM_SYMS, tapd, mix, nic);
+		((int4v *) (outl + x0))[0] = (int4v) { nic[0], nic[1], nic[2], nic[3] };
+		((int4v *) (outl + x0))[1] = (int4v) { nic[4], nic[5], nic[6], nic[7] };
 	}
-	if(k.has_carriers)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	int *const frame_out = iq + (size_t) y * out_stride * FS;
+	const bool has_nic = k.has_nicam != 0;
+	mfma_filter_each(xh + sub * FW, xl + sub * FW, t, a_hh, a_hl, mfma_ci, mfma_cq, [&](const int j, const int seg, const int g, const int2v pk)
 	{
-		o[0] = pk_add16(o[0], car0.x); o[1] = pk_add16(o[1], car0.y); o[2] = pk_add16(o[2], car0.z); o[3] = pk_add16(o[3], car0.w);
-		o[4] = pk_add16(o[4], car1.x); o[5] = pk_add16(o[5], car1.y); o[6] = pk_add16(o[6], car1.z); o[7] = pk_add16(o[7], car1.w);
-	}
-	if(k.has_nicam) nicam_add(k, x0, sym_st_g[sub], sym_ent_g + 1 + sub * HVK_NICAM_SYMS, tapd, mix, o);
-
-	int *dst = iq + (size_t) y * out_stride * FS + n;
-	__builtin_nontemporal_store(((int4u) { o[0], o[1], o[2], o[3] }), &((int4u *) dst)[0]);
-	__builtin_nontemporal_store(((int4u) { o[4], o[5], o[6], o[7] }), &((int4u *) dst)[1]);
+		int2v nv = { 0, 0 };
+		if(has_nic) nv = *(const int2v *) (outl + seg * 8 + 2 * g);
+		int2u ov;
+		ov.x = pk_add16(pk_add16(pk.x, cj[j].x), nv.x);
+		ov.y = pk_add16(pk_add16(pk.y, cj[j].y), nv.y);
+		__builtin_nontemporal_store(ov, (int2u *) (frame_out + n0 + seg * 8 + 2 * g));
+	});
 }
 
 /* ------------------------------------------------------------------ */
