@@ -696,10 +696,18 @@ void hvk_k_direct(const hvk_kconst_t k,
 #else
 	constexpr bool FIN = VF != 0;
 #endif
+	/* FIN0 (no video filter): the lane's 8 finished samples change lanes through LDS -- within their wave -- so that a wave's
+	 * carriers are read and its samples stored as whole kilobytes per instruction here too (lane L: samples 4 L .. 4 L + 3 of
+	 * the wave's first 256, then of its second 256) */
+#ifdef HVK_V_OLDFIN
+	constexpr bool FIN0 = false;
+#else
+	constexpr bool FIN0 = VF == 0;
+#endif
 	constexpr int NP = DG * HVK_TILE + 64;      /* window positions of the workgroup: its tiles follow each other in the stream */
 	constexpr int TL = HVK_TILE / HVK_SPL;      /* lanes of a tile */
 	__shared__ __attribute__((aligned(16))) unsigned char xh[VF ? NP : 16], xl[VF ? NP : 16];
-	__shared__ __attribute__((aligned(16))) int outl_g[DG][VF ? HVK_TILE : 4];
+	__shared__ __attribute__((aligned(16))) int outl_g[DG][HVK_TILE];
 	__shared__ __attribute__((aligned(16))) int16_t tapd[HVK_NICAM_COPIES * HVK_NICAM_TAPD];
 	__shared__ int sym_st_g[DG][HVK_NICAM_SYMS];
 	__shared__ __attribute__((aligned(16))) int4v sym_ent_g[1 + DG * HVK_NICAM_SYMS];     /* (an entry of slack in front: nicam_add()) */
@@ -732,6 +740,7 @@ void hvk_k_direct(const hvk_kconst_t k,
 	const int sub = __builtin_amdgcn_readfirstlane((int) threadIdx.x / TL);   /* which of the workgroup's tiles: the same for a wave */
 	const int t = threadIdx.x % TL;
 	const int x0 = t * SPL;
+	const int f0_w = (t >> 6) * 512 + (t & 63) * 4;     /* FIN0: the lane's first sample of the tile in the store's order */
 	/* a workgroup that reaches past the frame's last tile still fills its planes (the last tile's filter looks into
 	 * them); nothing of such a tile is stored */
 	const int tile_raw = bx * DG + sub;
@@ -866,7 +875,14 @@ void hvk_k_direct(const hvk_kconst_t k,
 			cj[j] = __builtin_nontemporal_load((const int2u *) (carriers + (size_t) y * FS + (ok2 ? nn : 0)));
 		}
 	}
-	else if(!FIN && has_car && (SND || whole) && !ABLATE(256))      /* (ABLATE: measuring builds only, tools/ablate_direct.py) */
+	else if(FIN0 && has_car)
+	{
+		const int nA = n0 + f0_w, nB = nA + 256;
+		const bool okA = tile_valid && (EXACT || nA + 4 <= FS), okB = tile_valid && (EXACT || nB + 4 <= FS);
+		car0 = __builtin_nontemporal_load((const int4u *) (carriers + (size_t) y * FS + (okA ? nA : 0)));
+		car1 = __builtin_nontemporal_load((const int4u *) (carriers + (size_t) y * FS + (okB ? nB : 0)));
+	}
+	else if(!FIN && !FIN0 && has_car && (SND || whole) && !ABLATE(256))      /* (ABLATE: measuring builds only, tools/ablate_direct.py) */
 	{
 		/* (SND: unconditionally -- a lane outside the frame reads the frame's first run instead, and uses nothing of it) */
 		const int4u *c = (const int4u *) (carriers + (size_t) y * FS + (whole ? n : 0));
@@ -975,6 +991,37 @@ void hvk_k_direct(const hvk_kconst_t k,
 		const int4v oa = ((const int4v *) (outl + x0))[0], ob = ((const int4v *) (outl + x0))[1];
 		o[0] = oa.x; o[1] = oa.y; o[2] = oa.z; o[3] = oa.w;
 		o[4] = ob.x; o[5] = ob.y; o[6] = ob.z; o[7] = ob.w;
+	}
+
+	if(FIN0)
+	{
+		if(has_nic) nicam_add(k, x0, sym_st, sym_ent, tapd, mix, o);
+		((int4v *) (outl + x0))[0] = (int4v) { o[0], o[1], o[2], o[3] };
+		((int4v *) (outl + x0))[1] = (int4v) { o[4], o[5], o[6], o[7] };
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		int *const frame_out = iq + (size_t) y * out_stride * FS;
+#pragma unroll
+		for(int h = 0; h < 2; h++)
+		{
+			const int nn = n0 + f0_w + h * 256;
+			const int4v v = *(const int4v *) (outl + f0_w + h * 256);
+			const int4u c4 = h ? car1 : car0;
+			if(tile_valid && (EXACT || nn + 4 <= FS))
+			{
+				int4u ov = { v.x, v.y, v.z, v.w };
+				if(has_car) ov = (int4u) { pk_add16(v.x, c4.x), pk_add16(v.y, c4.y), pk_add16(v.z, c4.z), pk_add16(v.w, c4.w) };
+				__builtin_nontemporal_store(ov, (int4u *) (frame_out + nn));
+			}
+			else if(tile_valid)
+			{
+				const int vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for(int i = 0; i < 4; i++) if(nn + i < FS) frame_out[nn + i] = has_car ? pk_add16(vv[i], carriers[(size_t) y * FS + nn + i]) : vv[i];
+			}
+		}
+		return;
 	}
 
 	/* serial carriers (FM / AM sound), computed on the host: a plain add of int16 pairs with wrap-around
