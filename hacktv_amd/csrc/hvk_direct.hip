@@ -400,6 +400,26 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 			}
 		}
 	}
+	/* A lane's 8 dwords of the C plane as whole kilobytes per wave instruction: with 8 consecutive samples a lane the two 16-byte
+	 * stores of a lane interleave -- each instruction writes half of every 32 bytes of the wave's 2 KB (hvk_k_direct has the
+	 * measurement: the pattern of an HBM stream is worth a tenth of a launch and more). The dwords change lanes through LDS,
+	 * within their wave: lane l then stores samples 4 l .. 4 l + 3 of the wave's first 256, then of its second 256. */
+	const bool wave_inside = (((t | 63) + 1) * SPL) <= W;          /* (the same for the wave: every lane's 8 samples lie on the line) */
+	int *const xw = (int *) (lds + 2 * CL) + (t >> 6) * 512;        /* (behind U and V: the launch asks for 2 KB a wave more) */
+	auto store_c8 = [&](const int (&q)[SPL])
+	{
+		int *const row = Cp + (at - x0) + (t >> 6) * 512;
+		((int4v *) (xw + (t & 63) * 8))[0] = (int4v) { q[0], q[1], q[2], q[3] };
+		((int4v *) (xw + (t & 63) * 8))[1] = (int4v) { q[4], q[5], q[6], q[7] };
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const int4v a4 = ((const int4v *) xw)[t & 63], b4 = ((const int4v *) (xw + 256))[t & 63];
+		((int4u *) row)[t & 63] = (int4u) { a4.x, a4.y, a4.z, a4.w };
+		((int4u *) (row + 256))[t & 63] = (int4u) { b4.x, b4.y, b4.z, b4.w };
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      /* (the wave's next exchange writes the same words) */
+		__builtin_amdgcn_wave_barrier();
+	};
 	if(SC && Cp && L.has_pix && x0 + SPL <= W)
 	{
 		int q[SPL];
@@ -409,8 +429,12 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 			q[2 * m] = (up[m] & 0xFFFF) | (vp[m] << 16);
 			q[2 * m + 1] = ((up[m] >> 16) & 0xFFFF) | (vp[m] & (int) 0xFFFF0000u);
 		}
-		((int4u *) (Cp + at))[0] = (int4u) { q[0], q[1], q[2], q[3] };
-		((int4u *) (Cp + at))[1] = (int4u) { q[4], q[5], q[6], q[7] };
+		if(wave_inside) store_c8(q);
+		else
+		{
+			((int4u *) (Cp + at))[0] = (int4u) { q[0], q[1], q[2], q[3] };
+			((int4u *) (Cp + at))[1] = (int4u) { q[4], q[5], q[6], q[7] };
+		}
 	}
 
 	if(x0 + SPL <= W)
@@ -418,8 +442,12 @@ void hvk_k_prep8(const hvk_kconst_t k, const hvk_packed_taps_t ctaps, const hvk_
 		*(int4a2 *) (Lp + at) = (int4a2) { sp[0], sp[1], sp[2], sp[3] };
 		if(NT > 1)
 		{
-			((int4u *) (Cp + at))[0] = (int4u) { c[0], c[1], c[2], c[3] };
-			((int4u *) (Cp + at))[1] = (int4u) { c[4], c[5], c[6], c[7] };
+			if(wave_inside) store_c8(c);
+			else
+			{
+				((int4u *) (Cp + at))[0] = (int4u) { c[0], c[1], c[2], c[3] };
+				((int4u *) (Cp + at))[1] = (int4u) { c[4], c[5], c[6], c[7] };
+			}
 		}
 	}
 	else
@@ -1080,7 +1108,8 @@ static int _launch_prep(const hvk_raster_args_t *a, const hvk_prepgeo_t *g, int 
 	const int W = a->k.width;
 	int threads = (W + SPL - 1) / SPL;
 	threads = (threads + 63) / 64 * 64;
-	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64;
+	/* (behind the staging buffers: 2 KB a wave for hvk_k_prep8's C plane exchange) */
+	const size_t lds = ((size_t) ((W + 8 + 7) & ~7) + 2 * (size_t) ((W + 2 * HVK_CHROMA_LEAD + 7) & ~7)) * sizeof(int16_t) + 64 + (size_t) (threads / 64) * 2048;
 	hvk_rptrs_t P;
 	hvk_raster_ptrs(a, &P);
 	const dim3 grid((a->k.lines + 7) & ~7, npics), block(threads);
