@@ -273,10 +273,26 @@ void hvk_k_filter(const hvk_kconst_t k,
 			wd[i] = d;
 		}
 	}
+	/* FIN (the filter on the matrix unit, no S-Video): the samples are FINISHED in the lane the matrix unit leaves them in, as in
+	 * hvk_k_direct -- NICAM goes through LDS to that lane, the carriers are read and the samples stored there, 8 bytes a lane and
+	 * 512 contiguous bytes a wave instruction (hvk_direct.hip has the measurement: with 8 consecutive samples a lane every
+	 * instruction touched half of every 32 bytes of a wave's 2 KB) */
+	constexpr bool FIN = VF != 0 && MF && !SV;
+	int2u cj[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
 	/* the serial-carrier samples of this lane: needed last */
 	const int nl = n0 + x0;
 	int4u car0 = { 0, 0, 0, 0 }, car1 = { 0, 0, 0, 0 };
-	if(k.has_carriers && (EXACT || nl + SPL <= FS))
+	if(FIN && k.has_carriers)
+	{
+		const int fl = t & 63, fg = fl >> 4, fc = fl & 15;
+#pragma unroll
+		for(int j = 0; j < 4; j++)
+		{
+			const int nn = n0 + ((t >> 6) * 64 + j * 16 + fc) * 8 + 2 * fg;
+			cj[j] = __builtin_nontemporal_load((const int2u *) (carriers + (size_t) blockIdx.y * FS + ((EXACT || nn + 2 <= FS) ? nn : 0)));
+		}
+	}
+	else if(k.has_carriers && (EXACT || nl + SPL <= FS))
 	{
 		const int4u *c = (const int4u *) (carriers + (size_t) blockIdx.y * FS + nl);
 		car0 = __builtin_nontemporal_load(&c[0]);      /* streaming, like the stores below (hvk_direct.hip has the measurement) */
@@ -348,7 +364,37 @@ void hvk_k_filter(const hvk_kconst_t k,
 
 	int o[SPL];                                 /* packed (I, Q) int16 */
 
-	if(VF != 0 && MF)
+	if(FIN)
+	{
+		const bool has_nic = k.has_nicam != 0, has_car = k.has_carriers != 0;
+		if(has_nic)
+		{
+			/* NICAM on its own (the adds are modulo 2^16 per channel: their order is free), handed to the lanes that finish the samples */
+			int nic[SPL] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			nicam_add(k, x0, sym_st, sym_ent, tapd, mix, nic);
+			((int4v *) (outl + x0))[0] = (int4v) { nic[0], nic[1], nic[2], nic[3] };
+			((int4v *) (outl + x0))[1] = (int4v) { nic[4], nic[5], nic[6], nic[7] };
+		}
+		/* (the exchange is within a wave: mfma_filter_each()) */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		int *const frame_out = iq + (size_t) blockIdx.y * out_stride * FS;
+		mfma_filter_each(xh, xl, t, a_hh, a_hl, mfma_ci, mfma_cq, [&](const int j, const int seg, const int g, const int2v pk)
+		{
+			int2v nv = { 0, 0 };
+			if(has_nic) nv = *(const int2v *) (outl + seg * 8 + 2 * g);
+			const int nn = n0 + seg * 8 + 2 * g;
+			int2u ov;
+			ov.x = pk_add16(pk_add16(pk.x, cj[j].x), nv.x);
+			ov.y = pk_add16(pk_add16(pk.y, cj[j].y), nv.y);
+			if(EXACT || nn + 2 <= FS) __builtin_nontemporal_store(ov, (int2u *) (frame_out + nn));
+			else if(nn < FS) frame_out[nn] = pk_add16(pk_add16(pk.x, has_car ? carriers[(size_t) blockIdx.y * FS + nn] : 0), nv.x);
+		});
+		__syncthreads();                            /* the next tile re-uses the LDS window and symbol table */
+		continue;
+	}
+	else if(VF != 0 && MF)
 	{
 		/* the FIR as a banded matrix product on the matrix unit (hvk_device.h), then through LDS to the lane that owns the 8 outputs */
 		mfma_filter(xh, xl, outl, t, a_hh, a_hl, mfma_ci, mfma_cq);
