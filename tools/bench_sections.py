@@ -56,12 +56,18 @@ def a2_prepass(H, pcm):
 
 
 
-def time_steps(step, sync, warmup, steps):
-    """`warmup` untimed calls of step(), then `steps` timed ones between two sync()s: seconds per step. The sections' clock
-    (the headline has its own: settle phase, barriers, maximum over ranks -- main())."""
+def time_steps(step, sync, warmup, steps, settle=0.0):
+    """`warmup` untimed calls of step(), then -- settle > 0 -- the same calls untimed for that many seconds (sustained clocks: a
+    section whose timed region is a few milliseconds otherwise sees the first moments after an idle period, as the headline's
+    --settle says), then `steps` timed ones between two sync()s: seconds per step."""
     for _ in range(warmup):
         step()
     sync()
+    t_set = time.perf_counter()
+    while time.perf_counter() - t_set < settle:
+        for _ in range(10):
+            step()
+        sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -163,7 +169,7 @@ def case_section(H, g, case, F, steps, warmup, device, label, stage_every_step=F
             stage_block()
         e.launch()
 
-    dt = time_steps(step, e.sync, warmup, steps)
+    dt = time_steps(step, e.sync, warmup, steps, settle=0.0 if stage_every_step else 0.3)
     res = {
         "workload": " ".join(["-m", c["mode"], "-s", str(sr)] + [f if not f.startswith("raw:") else "raw:tests/golden/ttraw.bin" for f in flags] + ["test"]),
         "frames_per_step": F,
