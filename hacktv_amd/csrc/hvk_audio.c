@@ -348,7 +348,8 @@ static void _nicam_build_frame(_nicam_t *n)
  * position runs out, from the newest 32-sample block the audio process has handed over -- in the reference an unlocked
  * hand-over between two threads (src/video.c:3370-3373): the engine's reading is "the newest block completed in an
  * EARLIER step of the pipeline", i.e. before the audio line that runs beside this invocation. */
-#define KEPT_LINES 4
+#define KEPT_LINES 8            /* `ahead` is at most 4 (SECAM's three slots + the resampler's line); counted in lines of the WIDEST width, that is up to five
+                                * lines past a request's end where most lines are a sample narrower, and the line the request ended in */
 typedef struct {
 	int on;
 	int dummies;            /* invocations in front of line 1: 1, or 3 behind a threaded colour process (hvk_tables.c) */
@@ -402,7 +403,9 @@ struct hvk_audio {
 	size_t sym_len, sym_cap;
 
 	/* the carriers of the last lines generated, newest in slot `kept_at`: a request may start inside them, and with
-	 * sound-in-syncs behind a threaded colour process (SECAM) the chains run two lines ahead of the requests */
+	 * sound-in-syncs behind a threaded colour process (SECAM) the chains run three lines ahead of the requests, four behind
+	 * the resampler. (Four kept lines were one too few exactly there -- SECAM, sound-in-syncs, a rate pair with lines of two
+	 * widths: the first request was refused; found by tools/fuzz_parity.py, round 6) */
 	int16_t *kept[KEPT_LINES];
 	int64_t kept_pos[KEPT_LINES];
 	int kept_w[KEPT_LINES];

@@ -860,6 +860,16 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 		const int64_t A0 = _fstart(e, first_frame), T = _fstart(e, first_frame + nframes) - A0;
 		int r = stage_audio(A0, T, 0, 0, e->symbol_stride * nframes, (int) ((T + HVK_TILE - 1) / HVK_TILE), first_frame);
 		if(r != HVK_OK) return(r);
+		if(k.sis)
+		{
+			/* (the raster is made frame by frame: every frame its own rows of bursts, not the batch's first frame's alone) */
+			const int rows = k.lines + (k.rs_L ? 2 : 1);
+			for(int i = 1; i < nframes; i++)
+			{
+				r = hvk_audio_sis_fetch(e->audio, (first_frame + i) * k.lines, rows, (uint8_t *) (e->h_sis_bits + (size_t) i * rows * 2));
+				if(r != HVK_OK) { e->poisoned = 1; return(r); }
+			}
+		}
 	}
 
 	/* The frame before each frame: the one staged just before it, the last frame of the batch before

@@ -44,6 +44,10 @@ RATE_CASES = [
 PIXELRATE_CASES = [
     ("pal_px27_s4fsc", "pal_27m", "pal", 17734475, 27000000, ["--pixelrate", "27000000"], 0, True, 3, {}),
     ("i_px27_s4fsc",   "i_27m",   "i",   17734475, 27000000, ["--filter", "--pixelrate", "27000000"], refprobe.FLAG_FILTER, False, 3, {}),
+    # sound-in-syncs where the frames have two lengths (the fuzzer's find of round 6: every frame of a batch its own bursts; SECAM's
+    # chains four lines ahead of the requests)
+    ("i_sis_px2025_s4fsc", "i_20m",    "i", 17734475, 20250000, ["--filter", "--sis", "dcsis", "--pixelrate", "20250000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
+    ("l_sis_px2025_s4fsc", "l_px2025", "l", 17734475, 20250000, ["--filter", "--sis", "dcsis", "--pixelrate", "20250000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
 ]
 # FM video's pre-emphasis filter on a raster that has neither 625 nor 525 lines: the reference takes its 625-line tables for every
 # count but 525 (src/video.c:3693, :3711) -- Apollo's 320 lines at 8 MHz get the 20.25 MHz table and a warning
