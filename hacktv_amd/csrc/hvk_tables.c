@@ -1824,6 +1824,12 @@ int hvk_tables_build(hvk_tables_t *t, const hvk_config_t *conf, unsigned int sam
 			const int olines = _ring_lines(t);
 			t->k.sv_ring = olines > t->k.delay_lines + 2 ? olines : t->k.delay_lines + 2;
 			if(getenv("HVK_SV_EXPERIMENT")) t->k.sv_ring = 0;       /* (tools/sv_probe.py: the sub-carrier at the luma's own position, as before) */
+			/* hvk_k_svq walks the batch's sub-carrier as ONE run of samples, the end of the batch before in front of it: the layout of
+			 * frames of two lengths, also where only the LINES have two widths and a frame is a whole number of samples (4 x the PAL
+			 * sub-carrier from 18 MHz pixels: 1135.0064 samples a line, 709379 a frame -- found by tools/fuzz_parity.py, round 6: the
+			 * records were made for that layout, the frames lay s_stride apart, and the per-frame record the lines' places are
+			 * worked out from was not there). frame_samples stays the exact length. */
+			if(t->k.sv_ring) t->k.rs_irr = 1;
 		}
 		t->k.s_video = 1;
 	}

@@ -47,6 +47,12 @@ PIXELRATE_CASES = [
     # sound-in-syncs where the frames have two lengths (the fuzzer's find of round 6: every frame of a batch its own bursts; SECAM's
     # chains four lines ahead of the requests)
     ("i_sis_px2025_s4fsc", "i_20m",    "i", 17734475, 20250000, ["--filter", "--sis", "dcsis", "--pixelrate", "20250000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
+    # S-Video behind resampler + filter where the LINES have two widths and the frames one length (the fuzzer's second find of round 6)
+    # (the find itself was from 18 MHz pixels; PAL at 18 MHz -- as a sample rate or a pixel rate, with or without S-Video -- is one of the rates at
+    # which the reference's own runs differ from each other, in one to two samples of a hundred from the first colour line on: what its chroma
+    # low pass reads past its buffer is another thread's memory there. Nothing to pin: the cases below are from 16 and 27 MHz pixels, three runs one output)
+    ("pal_sv_f_px27_s4fsc", "pal_sv", "pal", 17734475, 27000000, ["--s-video", "--filter", "--pixelrate", "27000000"], refprobe.FLAG_FILTER, False, 3, {"s_video": 1}),
+    ("pal_sv_f_px16_s4fsc", "pal_sv", "pal", 17734475, 16000000, ["--s-video", "--filter", "--pixelrate", "16000000"], refprobe.FLAG_FILTER, False, 3, {"s_video": 1}),
     ("l_sis_px2025_s4fsc", "l_px2025", "l", 17734475, 20250000, ["--filter", "--sis", "dcsis", "--pixelrate", "20250000"], refprobe.FLAG_FILTER, False, 4, {"sis": 1}),
 ]
 # FM video's pre-emphasis filter on a raster that has neither 625 nor 525 lines: the reference takes its 625-line tables for every

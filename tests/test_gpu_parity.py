@@ -57,7 +57,7 @@ def test_device_yuv_table_equals_oracle(golden):
                                   "i_tt", "l_tt",
                                   "i_offset", "i_swap_pass", "m_offset_pass", "pal_fm", "ntsc_fm", "secam_fm_tail",
                                   "pal_fm_pass",
-                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_px27_s4fsc", "i_px27_s4fsc", "i_sis_px2025_s4fsc", "l_sis_px2025_s4fsc", "pal_27m",
+                                  "i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s27", "pal_px135_s136", "pal_px27_s4fsc", "i_px27_s4fsc", "i_sis_px2025_s4fsc", "l_sis_px2025_s4fsc", "pal_sv_f_px27_s4fsc", "pal_sv_f_px16_s4fsc", "pal_27m",
                                   "i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc",
                                   "g_a2", "m_a2", "i_wss_auto", "pal_sv", "ntsc_sv_f", "secam_sv",
                                   "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb",
@@ -884,7 +884,10 @@ def test_raw_baseband_lines_carry_no_field_sequential_flag(mode, sr, pr):
                                           ("ntscfm_s18_px16", (2, 2, 1)), ("ntscfm_s18_px16", (1, 3, 1)), ("ntscfm_s18_px16", (5,)),
                                           # sound-in-syncs there: every frame of a batch its own lines' bursts; SECAM's chains four lines ahead of the requests,
                                           # counted in lines of the wider width (found by tools/fuzz_parity.py, round 6: the first request was refused)
-                                          ("i_sis_px2025_s4fsc", (3, 1)), ("i_sis_px2025_s4fsc", (1, 1, 2)), ("l_sis_px2025_s4fsc", (1, 2, 1)), ("l_sis_px2025_s4fsc", (4,))])
+                                          ("i_sis_px2025_s4fsc", (3, 1)), ("i_sis_px2025_s4fsc", (1, 1, 2)), ("l_sis_px2025_s4fsc", (1, 2, 1)), ("l_sis_px2025_s4fsc", (4,)),
+                                          # S-Video's ring of line buffers where the lines have two widths and the frames one length (the same run: the per-frame
+                                          # record its places are worked out from was not there, and the frames did not lie one behind the other)
+                                          ("pal_sv_f_px16_s4fsc", (3,)), ("pal_sv_f_px16_s4fsc", (1, 1, 1)), ("pal_sv_f_px27_s4fsc", (2, 1)), ("pal_sv_f_px27_s4fsc", (1, 2))])
 def test_frames_of_two_lengths(golden, case, batches):
     """--pixelrate pairs at which a raster frame is not a whole number of samples (858 x 525 x 32 / 27 up, 1017 x 525 x
     27 / 32 down): frames of two lengths one sample apart, a batch one run of samples (hvk_frame_start()). Batches of
@@ -903,10 +906,12 @@ def test_frames_of_two_lengths(golden, case, batches):
             out.append(e.fetch(0, cnt))
             f += n
         # a stride, or interleaved output slots, would tear such a stream: refused
-        with pytest.raises(H.HvkError):
-            e.stage(f, 2, 1)
+        # (the cases at 4 x the PAL sub-carrier have LINES of two widths and frames of one length: nothing to refuse there)
+        if "frame_ends" in c:
+            with pytest.raises(H.HvkError):
+                e.stage(f, 2, 1)
     iq = np.concatenate(out)
-    ends = c["frame_ends"]
+    ends = c.get("frame_ends", [(i + 1) * c["frame_samples"] for i in range(f)])
     assert iq.shape[0] == ends[f - 1]
     for n in range(f):
         assert util.sha256(util.stream_bytes(iq[: ends[n]], c["real"])) == c["sha256_cumulative"][n], "frame %d of %s" % (n + 1, case)

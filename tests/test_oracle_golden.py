@@ -17,7 +17,7 @@ CASES_PIXELRATE = ["i_px135", "i_px2025", "l_px2025", "pal_px16_s14", "m_px135_s
                    # S-Video behind resampler + filter, lines of two widths: the ring of line buffers (oracle/make_golden_r05.py)
                    "ntsc_sv_f_px135_s16", "ntsc_sv_f_px18_s16", "pal60_sv_f_px27_s16", "ntsc_sv_f_px16_s27", "ntsc_sv_f_px16_s18",
                    # a resampler of 709379 phases: 27 MHz -> 4 x the PAL sub-carrier (oracle/make_golden_r06.py)
-                   "pal_px27_s4fsc", "i_px27_s4fsc", "i_sis_px2025_s4fsc", "l_sis_px2025_s4fsc"]
+                   "pal_px27_s4fsc", "i_px27_s4fsc", "i_sis_px2025_s4fsc", "l_sis_px2025_s4fsc", "pal_sv_f_px27_s4fsc", "pal_sv_f_px16_s4fsc"]
 # VBI inserters (insertion test signals, widescreen signalling, time code)
 CASES_VBI = ["i_vbi", "i_vbi_tt", "m_vbi", "l_vbi", "pal_vbi_px", "i_acp_cc", "m_acp_cc", "i_wss_auto"]
 CASES_A2 = ["g_a2", "m_a2", "pal_sv", "ntsc_sv_f", "secam_sv", "l_fid", "secam_fid4", "i_rawbb", "pal_rawbb", "l_rawbb"]

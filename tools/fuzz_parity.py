@@ -91,10 +91,12 @@ while done < N and time.time() - t_start < LIMIT:
     if rng.random() < 0.15: conf.offset = int(rng.integers(-8, 9)) * 50000 or 250000; opts.append("offset=%d" % conf.offset)
     pr = 0
     if lines in (625, 525) and rng.random() < 0.3:
-        cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
+        # (FUZZ_FSC_PIXELS=1: 4 x the sub-carrier as a PIXEL rate as well -- resamplers of hundreds of thousands of phases, taken since round 6)
+        cand = [r for r in RATES[lines] if r != sr and (os.environ.get("FUZZ_FSC_PIXELS") or r not in (17734475, 14318181))]
         pr = int(cand[int(rng.integers(len(cand)))])
     levels = int(rng.integers(1, 3))
     desc = "%-13s %9d px %9d flags %d %s levels %d" % (mode, sr, pr, flags, " ".join(opts), levels)
+    if os.environ.get("FUZZ_ANNOUNCE"): print("case     ", desc, flush=True)       # (before anything is made: a case that ends the process is the last one named)
     try:
         e = H.Engine(conf, sr, device=0, max_frames=3 if FRAMES == 3 else 6, pixel_rate=pr)
     except H.HvkError as err:
