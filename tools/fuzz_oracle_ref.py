@@ -137,7 +137,7 @@ def draw(rng, case):
             over["par"] = [[16, 11], [12, 11], [64, 45], [1, 1], [10, 11], [40, 33]][int(rng.integers(6))]
     pr = 0
     if lines in (625, 525) and rng.random() < 0.3:
-        cand = [r for r in RATES[lines] if r != sr and r not in (17734475, 14318181)]
+        cand = [r for r in RATES[lines] if r != sr and (os.environ.get("FUZZ_FSC_PIXELS") or r not in (17734475, 14318181))]       # (FUZZ_FSC_PIXELS=1: 4 x the sub-carrier as a pixel rate as well, taken since round 6)
         pr = int(cand[int(rng.integers(len(cand)))])
     nfr = (2 if lines >= 405 else 4) + (int(rng.integers(0, 4)) if WIDE and rng.random() < 0.25 else 0)     # (PAL's sub-carrier sequence is four frames long)
     if LONG:
