@@ -338,7 +338,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			if(!fresh && !e->secam_last_new) kf[i] = (e->secam_est && a.K >= 3) ? -1 : a.K;
 			e->secam_last_new = fresh;
 		}
-		HIPCHK_P(hipMemcpyAsync(e->d_secam[10], rows, (size_t) e->max_frames * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+		/* (the lists go to the device with the kept sets' -- _secam_kept_plan, below, in front of the first kernel that reads them) */
 	}
 
 	int memo_used = 0;
@@ -947,7 +947,9 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 		}
 		else e->carry.fb_valid = 0;
 	}
-	HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
+	/* (SECAM on the device: the descriptors go once the colour chain's plan has named every frame's sub-carrier rows -- _secam_kept_plan;
+	 * nothing in front of it reads them: the planes are made from the slots' geometry) */
+	if(!e->secam_dev) HIPCHK_P(hipMemcpyAsync(e->d_fdesc, e->h_fdesc, sizeof(hvk_framedesc_t) * nframes * (fields + 1), hipMemcpyHostToDevice, e->stream));
 	if(e->h_ops)
 	{
 		_build_vbi_ops(e, nframes);
