@@ -106,6 +106,7 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 
 	e = (hvk_engine *) calloc(1, sizeof(hvk_engine));
 	if(!e) return(HVK_OUT_OF_MEMORY);
+	e->secam_last_frame = -1;
 	e->device = device;
 	e->max_frames = max_frames;
 	/* one source frame slot per frame of a batch, so a batch can show a different
@@ -816,6 +817,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			OPENHIP(hipMemset(e->d_secam[4], 0, (size_t) a.cpad * k.width * 2));
 			OPENHIP(hipMemset(e->d_secam[5], 0, (size_t) a.cpad * 32));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_rows, (size_t) max_frames * 8 * sizeof(int), hipHostMallocDefault));
+			e->secam_prev_key = (int64_t *) calloc((size_t) max_frames, sizeof(int64_t));
+			if(!e->secam_prev_key) OPENCHK(HVK_OUT_OF_MEMORY);
 			memset(e->h_secam_rows, 0, (size_t) max_frames * 8 * sizeof(int));
 			if(e->secam_memo_slots > 0)
 			{
@@ -932,6 +935,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 	}
 
 	free(e->sym_tmp);
+	free(e->secam_prev_key);
 	free(e->chroma_par);
 	free(e->h_ovr_idx);
 	free(e->fm_prime_car);
@@ -1082,6 +1086,7 @@ extern "C" int hvk_frame_upload(hvk_engine_t *e, int slot, const uint32_t *fb, i
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	memset(s->memo_valid, 0, sizeof(s->memo_valid));
+	s->gen++;
 	if(fb == NULL)
 	{
 		/* av_read_video() past the end hands back an empty frame (src/av.c:55-59) */
@@ -1153,6 +1158,7 @@ extern "C" int hvk_frame_upload_pinned(hvk_engine_t *e, int slot, const uint32_t
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	memset(s->memo_valid, 0, sizeof(s->memo_valid));
+	s->gen++;
 	if(!s->valid) return(HVK_OK);
 
 	const uint32_t *src = fb + (size_t) y * width + x;
@@ -1187,6 +1193,7 @@ extern "C" int hvk_frame_copy(hvk_engine_t *e, int slot, hvk_engine_t *from, int
 	s->cells_valid[0] = s->cells_valid[1] = 0;
 	memset(s->seeds_valid, 0, sizeof(s->seeds_valid));
 	memset(s->memo_valid, 0, sizeof(s->memo_valid));
+	s->gen++;
 	if(!f->valid) return(HVK_OK);
 
 	/* The copy runs on a stream of the destination's own: behind what the source has queued (the picture's upload: a) and
@@ -1375,6 +1382,7 @@ extern "C" int hvk_secam_state_import(hvk_engine_t *e, const void *buf, size_t b
 		/* the frame before the block's first was another engine's: its picture counts as new here (warm-up lines, no kept
 		 * state taken on trust -- the check decides as ever) */
 		e->secam_last_new = 1;
+		e->secam_last_frame = -1;       /* (... nor a kept sub-carrier set: behind which picture its first frame stands is not known here) */
 	}
 	return(HVK_OK);
 }

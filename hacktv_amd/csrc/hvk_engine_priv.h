@@ -46,13 +46,20 @@ struct hvk_slot_t {
 	int cells_valid[2];         /* SECAM: the picture's low-passed colour cells (hvk_secam.hip) stand in the store, by frame parity */
 	int seeds_valid[6];         /* SECAM: the picture has been shown with this frame number modulo 6: its lines' entry states are kept */
 	int memo_valid[6];          /* SECAM: ... and the sub-carrier rows and states that walk left are kept whole (hvk_engine_stage.cpp: kept sub-carrier) */
+	int64_t memo_prev[6];       /*   ... behind WHICH picture the set's frame stood (hvk_slot_key() of the frame before it): what the frame started from */
+	uint32_t gen;               /* counts the pictures the slot has held */
 };
+
+/* a picture by slot and count: the same key, the same pixels */
+static inline int64_t hvk_slot_key(const hvk_slot_t *slots, int slot) { return(((int64_t) slot << 32) | slots[slot].gen); }
 
 struct hvk_engine {
 	hvk_tables_t t;
 	hvk_audio_t *audio;
 	hvk_secam_t *secam;
 	int64_t secam_next;        /* next frame the SECAM pre-pass expects */
+	int64_t *secam_prev_key;    /* [max_frames] the staged frames' pictures before them (kept sub-carrier sets: hvk_engine_stage.cpp) */
+	int64_t secam_last_frame, secam_last_key;   /* the last frame the device's colour chain went through and the picture it showed (-1: none) */
 	uint32_t **host_frames;     /* SECAM: host copy of every frame slot (cropped, dense) */
 	int16_t *d_chroma, *h_chroma;
 	signed char *chroma_par;    /* [max_frames] the frame parity the slab's rows were last written with by the device's chain (-1: clear before use) */

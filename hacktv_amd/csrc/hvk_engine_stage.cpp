@@ -215,6 +215,7 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 	int *rows = e->h_secam_rows, *mflag = rows + 4 * e->max_frames, *owner = rows + 5 * e->max_frames, *orow = rows + 6 * e->max_frames, *mrow = rows + 7 * e->max_frames;
 	const int fields = k.fields;
 	int taken = 0, any = 0;
+	int64_t *pkey = e->secam_prev_key;
 	const bool on = e->secam_memo_slots > 0 && !e->secam_memo_off && walk > 0 && e->secam_cell_cache && e->secam_seeds && a.seed && a.seedx && fields == 1;
 
 	for(int i = 0; i < nframes; i++) { mflag[i] = owner[i] = 0; orow[i] = i; mrow[i] = 0; }
@@ -226,6 +227,13 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 	else
 	{
 		std::vector<uint8_t> made((size_t) 6 * e->secam_memo_slots, 0);
+		/* What a frame starts from is what the frame before it leaves behind, and that is a matter of that frame's picture and number
+		 * alone (a line's start state is forgotten within some thirty lines): a set is taken where the frame stands behind the picture
+		 * its set's frame stood behind -- a picture that follows ANOTHER one is walked, one frame, instead of being taken on trust,
+		 * failing the check and sending the block through the chain again (round 6's fuzzer of staying pictures: one restart in five
+		 * blocks before). The check decides as ever: the rule only chooses what is worth trying. */
+		for(int i = 0; i < nframes; i++)
+			pkey[i] = i > 0 ? hvk_slot_key(e->slots, e->staged_slots[i - 1]) : (e->secam_last_frame >= 0 && e->secam_last_frame + 1 == first_frame ? e->secam_last_key : -1);
 		for(int i = nframes - 1; i >= 0; i--)
 		{
 			const int slot = e->staged_slots[i];
@@ -233,7 +241,14 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 			if(slot >= e->secam_memo_slots || first_frame + i == 0) continue;       /* (the stream's first frame has the two fill slots) */
 			const int set = slot * 6 + ph6;
 			mrow[i] = set;
-			if(e->slots[slot].memo_valid[ph6])
+			if(e->slots[slot].memo_valid[ph6] && (pkey[i] < 0 || e->slots[slot].memo_prev[ph6] != pkey[i]) && !getenv("HVK_SECAM_KEEP_ANY"))
+			{
+				/* (kept, but behind another picture: walked into the batch's own row, the set stays as it is. The states kept for its
+				 * lines are the set's: the first line's would be wrong for certain, so the frame's are estimated as a new picture's are) */
+				mrow[i] = 0;
+				if(e->secam_est) rows[2 * e->max_frames + i] = -1;
+			}
+			else if(e->slots[slot].memo_valid[ph6])
 			{
 				mflag[i] = 1;
 				orow[i] = e->max_frames + set;
@@ -264,7 +279,12 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 static void _secam_kept_commit(hvk_engine_t *e, int64_t first_frame, int nframes)
 {
 	const int *owner = e->h_secam_rows + 5 * e->max_frames;
-	for(int i = 0; i < nframes; i++) if(owner[i]) e->slots[e->staged_slots[i]].memo_valid[(first_frame + i + 1) % 6] = 1;
+	for(int i = 0; i < nframes; i++) if(owner[i])
+	{
+		hvk_slot_t &sl = e->slots[e->staged_slots[i]];
+		sl.memo_valid[(first_frame + i + 1) % 6] = 1;
+		sl.memo_prev[(first_frame + i + 1) % 6] = e->secam_prev_key[i];
+	}
 }
 
 static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
@@ -976,6 +996,8 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 	{
 		int r = _secam_on_device(e, first_frame, nframes);
 		if(r != HVK_OK) { e->poisoned = 1; return(r); }
+		e->secam_last_frame = stride == 1 ? first_frame + nframes - 1 : -1;
+		e->secam_last_key = hvk_slot_key(e->slots, e->staged_slots[nframes - 1]);
 	}
 	else if(e->h_chroma) HIPCHK(hipMemcpyAsync(e->d_chroma, e->h_chroma, (size_t) nframes * k.raster_samples * 2, hipMemcpyHostToDevice, e->stream));
 	if(e->h_sis_bits) HIPCHK_P(hipMemcpyAsync(e->d_sis_bits, e->h_sis_bits, (size_t) nframes * (k.lines + (k.rs_L ? 2 : 1)) * 8, hipMemcpyHostToDevice, e->stream));

@@ -337,7 +337,9 @@ int hvk_secam_walk_stages(const hvk_engine_t *e, int64_t counts[3]);
  * line starts from. A picture that stays meets all three again, so the rows of a walk whose every line passed the check are
  * kept per picture slot and number, with every line's entry state and the state behind the last line; a later frame of that
  * picture and number TAKES the set instead of being walked, and the same check that every line gets -- does it start where
- * the line before ended, bit for bit -- decides whether it may. counts[0]: frames that took a set; [1]: stages done again
+ * the line before ended, bit for bit -- decides whether it may. A set is tried only behind the picture its frame stood behind
+ * when it was made (what a frame starts from is what the frame before it leaves: its picture and number); the frame behind a
+ * change of picture is walked from estimated states. counts[0]: frames that took a set; [1]: stages done again
  * without kept sets because a frame did not start where its set's walk had; [2]: picture slots sets are kept for (0: none --
  * HVK_SECAM_KEEP=0, --interlace, the host's chain). SECAM-L test card, 128-frame blocks: 170 -> see DESIGN.md section 5. */
 int hvk_secam_kept(const hvk_engine_t *e, int64_t counts[3]);

@@ -827,12 +827,24 @@ def test_secam_a_kept_set_met_from_another_state_sends_the_block_through_the_cha
     monkeypatch.setenv("HVK_SECAM_HOST", "1")
     want, _, _, _ = run()
     monkeypatch.delenv("HVK_SECAM_HOST")
+    # (a set taken whatever picture stands in front of the frame: the rule of the round's first form, kept behind this switch so
+    # that the check's catch and the restart stay tested)
+    monkeypatch.setenv("HVK_SECAM_KEEP_ANY", "1")
     got, st, kept, taken = run()
     assert np.array_equal(got, want)
     assert st["host_frames"] == 0
     assert taken[29] > 0, taken                    # the card's frames were taking their sets before the other picture came
     assert kept["restarts"] >= 1, kept             # ... and the card's return behind it was caught by the check
     assert taken[-1] > taken[40], taken            # sets were made again and taken again
+    # As built: a set is taken only behind the picture its frame stood behind when it was made (what a frame starts from is what
+    # the frame before it leaves) -- the frame behind a change of picture is walked from estimated states instead, one frame, and
+    # nothing is done again
+    monkeypatch.delenv("HVK_SECAM_KEEP_ANY")
+    got1, st1, kept1, taken1 = run()
+    assert np.array_equal(got1, want)
+    assert st1["host_frames"] == 0
+    assert kept1["restarts"] == 0, kept1
+    assert kept1["frames_taken"] > kept["frames_taken"], (kept1, kept)
     monkeypatch.setenv("HVK_SECAM_KEEP", "0")
     got0, _, _, _ = run()
     assert np.array_equal(got0, want)
