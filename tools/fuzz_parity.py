@@ -27,6 +27,8 @@ MODES = ["i", "b", "g", "pal-d", "pal-k", "pal-fm", "pal", "pal-m", "pal-n", "52
          "apollo-fsc-fm", "apollo-fsc", "apollo-fm", "apollo", "m-cbs405", "cbs405"]
 RATES = {625: [16000000, 13500000, 14000000, 18000000, 20250000, 17734475, 27000000], 525: [13500000, 16000000, 14318181, 18000000, 27000000], 819: [24570000, 16380000],
          405: [8100000, 16200000, 12150000], 240: [4800000], 30: [750000], 32: [800000], 320: [3200000, 8000000, 13500000]}
+WIDE_RATES = {625: [8000000, 9000000, 10000000, 12000000, 15000000, 21000000, 24000000, 30000000, 36000000, 35468950, 38000000, 16384000],
+              525: [8000000, 9000000, 10000000, 12272727, 15000000, 21000000, 24545454, 28636362, 30000000, 36000000]}
 done = refused = bad = 0
 bad_lines = []
 t_start = time.time()
@@ -44,6 +46,8 @@ while done < N and time.time() - t_start < LIMIT:
     else:
         rates = RATES.get(lines, [16000000])
     sr = int(rates[int(rng.integers(len(rates)))])
+    if os.environ.get("FUZZ_WIDE_RATES") and lines in WIDE_RATES and rng.random() < 0.5:
+        sr = int(WIDE_RATES[lines][int(rng.integers(len(WIDE_RATES[lines])))])     # (round 6: chroma low passes of 5 .. 33 taps, lines that are not a whole number of samples)
     flags = 0
     for f, p in ((H.FLAG_FILTER, 0.5), (H.FLAG_NOAUDIO, 0.35), (H.FLAG_NONICAM, 0.2)):
         if rng.random() < p:
