@@ -232,6 +232,7 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 		 * its set's frame stood behind -- a picture that follows ANOTHER one is walked, one frame, instead of being taken on trust,
 		 * failing the check and sending the block through the chain again (round 6's fuzzer of staying pictures: one restart in five
 		 * blocks before). The check decides as ever: the rule only chooses what is worth trying. */
+		const bool keep_any = getenv("HVK_SECAM_KEEP_ANY") != NULL;     /* (the round's first form: a set tried behind any picture -- the check's catch and the restart stay testable) */
 		for(int i = 0; i < nframes; i++)
 			pkey[i] = i > 0 ? hvk_slot_key(e->slots, e->staged_slots[i - 1]) : (e->secam_last_frame >= 0 && e->secam_last_frame + 1 == first_frame ? e->secam_last_key : -1);
 		for(int i = nframes - 1; i >= 0; i--)
@@ -241,7 +242,7 @@ static int _secam_kept_plan(hvk_engine_t *e, int64_t first_frame, int nframes, i
 			if(slot >= e->secam_memo_slots || first_frame + i == 0) continue;       /* (the stream's first frame has the two fill slots) */
 			const int set = slot * 6 + ph6;
 			mrow[i] = set;
-			if(e->slots[slot].memo_valid[ph6] && (pkey[i] < 0 || e->slots[slot].memo_prev[ph6] != pkey[i]) && !getenv("HVK_SECAM_KEEP_ANY"))
+			if(e->slots[slot].memo_valid[ph6] && (pkey[i] < 0 || e->slots[slot].memo_prev[ph6] != pkey[i]) && !keep_any)
 			{
 				/* (kept, but behind another picture: walked into the batch's own row, the set stays as it is. The states kept for its
 				 * lines are the set's: the first line's would be wrong for certain, so the frame's are estimated as a new picture's are) */
