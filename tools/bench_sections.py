@@ -627,7 +627,7 @@ def quick_sections(H, g, args, res, log):
         "1_pal_baseband": case_section(H, g, "pal_bb", F, k, 3, dev, "config 1"),
         "2_noaudio": case_section(H, g, "i_vsb", F, k, 3, dev, "config 2 --noaudio", fresh_e2e=True),
         "3_ntsc_m": case_section(H, g, "m_full", F, k, 3, dev, "config 3"),
-        "4_secam_l_teletext_noaudio_device": case_section(H, g, "l_tt", F, 5, 16, dev, "config 4 --noaudio (raw packets)",
+        "4_secam_l_teletext_noaudio_device": case_section(H, g, "l_tt", F, 20, 16, dev, "config 4 --noaudio (raw packets)",
                                                           stage_every_step=True, teletext=True, noaudio=True),
     }
     hf = _g(configs, "4_secam_l_teletext_noaudio_device", "secam_lines", "host_frames")
