@@ -283,6 +283,38 @@ def test_audio_runs_over_the_resamplers_startup_lines(golden):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["l_sis_px2025_s4fsc", "i_sis_px2025_s4fsc"])
+def test_sound_chains_ahead_of_the_requests_where_lines_have_two_widths(golden, case):
+    """Sound-in-syncs keeps the sound chains lines AHEAD of the requests (three behind SECAM's threaded colour process, one more
+    behind the resampler), counted in lines of the widest width; at 4 x the PAL sub-carrier most lines are a sample narrower, so the
+    chains stand up to five lines past a request's end -- and the next request starts inside lines that must still be kept. Four
+    were (round 6's GPU fuzzer: SECAM-L's first request was refused); the carriers of frame after frame, asked for in one piece
+    and in pieces that end inside lines, equal the oracle's, and every line's burst is there."""
+    conf, sr = golden.conf(case)
+    c = golden.cases[case]
+    pr, fs, L = c["pixel_rate"], c["frame_samples"], c["lines"]
+    with oracle.Oracle(conf, sr, pr) as o:
+        o.set_frame(golden.frame(case))
+        o.set_audio(golden.audio, True)
+        o.render_lines(2 * L)
+        want = o.last_carrier()
+    def run(pieces):
+        with H.Engine(conf, sr, device=-1, pixel_rate=pr) as e:
+            for _ in range(3):
+                e.audio_write(golden.audio)
+            pos, out = e.info["startup_samples"], []
+            for n in pieces:
+                out.append(e.host_side_streams(pos, n)[0])
+                pos += n
+            bursts = e.host_sis_bursts(0, 2 * L)
+        return np.concatenate(out), bursts
+    whole, b0 = run([fs, fs])
+    assert np.array_equal(whole[: len(want)], want[: len(whole)])
+    parts, b1 = run([fs - 777, 777 + 5, fs - 5 - 1135 * 3, 1135 * 3])
+    assert np.array_equal(parts, whole) and np.array_equal(b0, b1)
+    assert (b0[:, 7] >= 44).all()           # (every line has its burst: 44 or 48 bits)
+
+
 def test_passthru_needs_whole_lines_and_stays_ended(golden):
     conf, sr = golden.conf("pal_fm_pass")
     W = golden.cases["pal_fm_pass"]["width"]
