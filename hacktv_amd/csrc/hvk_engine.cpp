@@ -827,6 +827,8 @@ extern "C" int hvk_open_rates(hvk_engine_t **pe, const hvk_config_t *conf, unsig
 			}
 			OPENHIP(hipMemset(e->d_secam[8], 0, sizeof(hvk_secam_state_t) + 64));
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_count, 64, hipHostMallocDefault));
+			OPENHIP(hipEventCreateWithFlags(&e->secam_ev, hipEventDisableTiming));
+			e->secam_defer = !(getenv("HVK_SECAM_DEFER") && atoi(getenv("HVK_SECAM_DEFER")) == 0);
 			OPENHIP(hipHostMalloc((void **) &e->h_secam_carry, sizeof(hvk_secam_state_t), hipHostMallocDefault));
 			memset(e->h_secam_carry, 0, sizeof(hvk_secam_state_t));
 			a.tasks = (const hvk_secam_task_t *) e->d_secam[0];
@@ -920,6 +922,7 @@ extern "C" void hvk_close(hvk_engine_t *e)
 		for(int i = 0; i < HVK_UPLOAD_RING; i++) { if(e->h_frame[i]) (void) hipHostFree(e->h_frame[i]); if(e->up_ev[i]) (void) hipEventDestroy(e->up_ev[i]); }
 		for(void *p : e->d_secam) if(p) (void) hipFree(p);
 		if(e->h_secam_count) (void) hipHostFree(e->h_secam_count);
+		if(e->secam_ev) (void) hipEventDestroy(e->secam_ev);
 		if(e->h_secam_carry) (void) hipHostFree(e->h_secam_carry);
 		if(e->ev_staged) (void) hipEventDestroy(e->ev_staged);
 		if(e->ev_fork) (void) hipEventDestroy(e->ev_fork);
@@ -1354,6 +1357,7 @@ extern "C" int hvk_secam_state_export(hvk_engine_t *e, void *buf, size_t bytes)
 	{
 		/* (the stage's last copy brings the carried state to the host: behind it) */
 		HIPCHK(hipSetDevice(e->device));
+		if(e->secam_pending) { const int r_ = hvk_e_secam_resolve(e); if(r_ < 0) return(r_); }
 		HIPCHK(hipStreamSynchronize(e->stream));
 		h.st = *e->h_secam_carry;
 		h.next_frame = e->secam_next;
@@ -1459,6 +1463,7 @@ extern "C" int hvk_secam_stats(hvk_engine_t *e, int64_t counts[4])
 {
 	if(!e || !counts) return(HVK_ERROR);
 	if(!e->secam) return(HVK_UNSUPPORTED);
+	if(e->secam_pending && hvk_e_secam_resolve(e) < 0) return(HVK_ERROR);    /* (a block staged and not yet launched: its check's count is part of the figures) */
 	hvk_secam_counters(e->secam, &counts[0], &counts[1], &counts[2]);
 	counts[3] = 0;
 	if(e->secam_dev) for(int i = 0; i < 4; i++) counts[i] = e->secam_counts[i];
@@ -1478,6 +1483,7 @@ extern "C" int64_t hvk_secam_estimated_stages(const hvk_engine_t *e)
 extern "C" int hvk_secam_kept(const hvk_engine_t *e, int64_t counts[3])
 {
 	if(!e || !counts) return(HVK_ERROR);
+	if(e->secam_pending && hvk_e_secam_resolve(const_cast<hvk_engine_t *>(e)) < 0) return(HVK_ERROR);
 	counts[0] = e->secam_dev ? e->secam_memo_frames : 0;
 	counts[1] = e->secam_dev ? e->secam_memo_restarts : 0;
 	counts[2] = e->secam_dev ? e->secam_memo_slots : 0;
@@ -1501,6 +1507,7 @@ extern "C" int hvk_secam_warmup_lines(hvk_engine_t *e)
 {
 	if(!e) return(HVK_ERROR);
 	if(!e->secam || !e->secam_dev) return(HVK_UNSUPPORTED);
+	if(e->secam_pending && hvk_e_secam_resolve(e) < 0) return(HVK_ERROR);
 	return(e->sa.K);
 }
 extern "C" int hvk_passthru_write(hvk_engine_t *e, const int16_t *iq, size_t nsamples)

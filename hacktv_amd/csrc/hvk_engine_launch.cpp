@@ -173,7 +173,20 @@ extern "C" int hvk_launch(hvk_engine_t *e, void *d_iq)
 	return(hvk_launch_strided_out(e, d_iq, 1));
 }
 
+static int _launch_body(hvk_engine_t *e, void *d_iq, int64_t out_stride);
+
 extern "C" int hvk_launch_strided_out(hvk_engine_t *e, void *d_iq, int64_t out_stride)
+{
+	int r = _launch_body(e, d_iq, out_stride);
+	if(r != HVK_OK || !e->secam_pending) return(r);
+	/* SECAM: the colour chain's check of the staged block is still out -- its count is read now that the render is queued behind
+	 * it (hvk_engine_stage.cpp); a block whose check failed has been repaired by the time this returns 1 and is rendered again */
+	r = hvk_e_secam_resolve(e);
+	if(r < 0) return(r);
+	return(r > 0 ? _launch_body(e, d_iq, out_stride) : HVK_OK);
+}
+
+static int _launch_body(hvk_engine_t *e, void *d_iq, int64_t out_stride)
 {
 	if(!e || out_stride < 1) return(HVK_ERROR);
 	if(out_stride != 1 && d_iq == NULL) return(HVK_ERROR);

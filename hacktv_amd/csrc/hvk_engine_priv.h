@@ -89,6 +89,9 @@ struct hvk_engine {
 	int secam_clean, secam_patience;    /* batches without a wrong start in a row; how many of them before a line less is tried */
 	hvk_secam_state_t *h_secam_carry;   /* pinned: the state after the last batch */
 	hvk_secam_state_t secam_start;      /* ... as the host's chain would need it to take over */
+	int secam_defer, secam_pending, secam_resolving;    /* the first check's count read in hvk_launch, behind the queued render (hvk_e_secam_resolve) */
+	int64_t secam_p_first; int secam_p_n, secam_p_memo;
+	hipEvent_t secam_ev;
 	int64_t secam_counts[4];
 	int32_t *staged_slots2;     /* [max_frames] the slot of the second field's picture */
 	uint32_t *h_tt_pk;          /* teletext packets queued for the next batch: [max_frames][32][12] */
@@ -257,6 +260,7 @@ int hvk_e_prep_dirty(hvk_engine *e, const int32_t *slots, int n, hipStream_t str
 int hvk_e_prep_staged(hvk_engine *e, int y0, int n, hipStream_t stream);
 int hvk_e_carry_copy(hvk_engine *e);
 int hvk_e_flush_planes(hvk_engine *e);
+int hvk_e_secam_resolve(hvk_engine *e);       /* hvk_engine_stage.cpp */
 int hvk_e_sv_ring_records(hvk_engine *e, int64_t first_frame, int nframes);  /* hvk_k_svq's per-line records of a batch being staged (hvk_engine_launch.cpp) */
 int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframes, const int32_t *slots, const int32_t *prev_slots);
 void hvk_e_kernel_args(hvk_engine *e, hvk_raster_args_t *pra, hvk_filter_args_t *pfa, void *d_iq, int64_t out_stride);

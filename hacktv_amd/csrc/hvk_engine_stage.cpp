@@ -185,6 +185,7 @@ extern "C" int hvk_stage_strided_prev(hvk_engine_t *e, int64_t first_frame, int6
  * descriptors and pictures are on their way to the device (same stream). */
 
 static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes);
+static int _secam_rounds(hvk_engine_t *e, int64_t first_frame, int nframes, int memo_used, int first_bad);
 
 /* ---- The kept sub-carrier -------------------------------------------------------------------------------------------
  * What the colour chain makes of a frame is a function of three things: the picture's cells (kept per slot and parity already),
@@ -292,7 +293,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 {
 	const hvk_kconst_t &k = e->t.k;
 	hvk_secam_args_t &a = e->sa;
-	int r, rounds = 0;
+	int r;
 
 	a.nframes = nframes;
 	a.total = nframes * a.ntasks;
@@ -314,7 +315,6 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	if(a.R < 1) a.R = 1;
 	if(getenv("HVK_SECAM_RUN")) a.R = atoi(getenv("HVK_SECAM_RUN")) > 0 ? atoi(getenv("HVK_SECAM_RUN")) : 1;
 	a.nruns = (a.total + a.R - 1) / a.R;
-	e->secam_start = *e->h_secam_carry;
 
 	/* Which rows of the cell stores the frames read, and which of them are made now: a picture's cells depend on the
 	 * picture and on the parity of the frame's number only (which of the two colour-difference signals a line carries,
@@ -410,6 +410,33 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	}
 	e->secam_counts[0] += (int64_t) (nframes - (memo_used > 0 ? memo_used : 0)) * a.ntasks;     /* (lines walked: not those of frames that took a kept set) */
 
+	/* The check's count is not waited for here where the last blocks' checks found nothing: it is queued, hvk_launch queues the
+	 * render behind it and only then reads the count (hvk_e_secam_resolve) -- the GPU goes from the check straight into the
+	 * render instead of standing idle for the trip to the host and the launches that follow it (40 of config 4's 200 us a block);
+	 * the rare block whose check fails is repaired as ever and rendered again. (HVK_SECAM_DEFER=0: the count awaited here.) */
+	if(e->secam_defer && !e->secam_resolving && e->secam_memo_off == 0 && e->secam_spec_left == 0 && !k.fm_video
+	   && !getenv("HVK_SECAM_DEBUG") && !getenv("HVK_SECAM_FORCE_FALLBACK"))
+	{
+		if((r = hvk_launch_secam_check(&a, e->stream)) != HVK_OK) return(r);
+		HIPCHK(hipMemcpyAsync(e->h_secam_count, a.count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+		HIPCHK(hipEventRecord(e->secam_ev, e->stream));
+		e->secam_pending = 1;
+		e->secam_p_first = first_frame;
+		e->secam_p_n = nframes;
+		e->secam_p_memo = memo_used;
+		return(HVK_OK);
+	}
+	return(_secam_rounds(e, first_frame, nframes, memo_used, -1));
+}
+
+/* The first check's count is in (first_bad >= 0), or the check is still to be made (-1): the rounds of repair, what the stage
+ * learns from the count, the kept sets made valid or dropped, the state carried on */
+static int _secam_rounds(hvk_engine_t *e, int64_t first_frame, int nframes, int memo_used, int first_bad)
+{
+	const hvk_kconst_t &k = e->t.k;
+	hvk_secam_args_t &a = e->sa;
+	int r, rounds = 0;
+
 	/* Where recent blocks had lines that started wrong, the first check is followed at once by the redo round and ITS check (a redo
 	 * without failed runs returns at once): one wait for both counts instead of two -- a wrong start costs one trip to the host
 	 * less (HVK_SECAM_NO_SPEC=1: one check per wait, as before) */
@@ -418,6 +445,12 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	{
 		int bad;
 		if(pending >= 0) { bad = pending; pending = -1; }
+		else if(first_bad >= 0)
+		{
+			bad = first_bad;
+			first_bad = -1;
+			if(bad) e->secam_spec_left = getenv("HVK_SECAM_NO_SPEC") ? 0 : 64;
+		}
 		else
 		{
 			const bool spec = rounds == 0 && e->secam_spec_left > 0 && !getenv("HVK_SECAM_DEBUG");
@@ -447,7 +480,8 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 			_secam_kept_drop(e, nframes);
 			e->secam_memo_restarts++;
 			e->secam_memo_off++;
-			*e->h_secam_carry = e->secam_start;
+			/* (the state the block began with: the pinned word still holds it -- this block's own is copied there only when it is through) */
+			e->secam_start = *e->h_secam_carry;
 			HIPCHK(hipMemcpyAsync(a.carry, e->h_secam_carry, sizeof(hvk_secam_state_t), hipMemcpyHostToDevice, e->stream));
 			memset(e->chroma_par, -1, (size_t) e->max_frames);
 			r = _secam_on_device(e, first_frame, nframes);
@@ -502,6 +536,7 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 		if(++rounds > HVK_SECAM_ROUNDS || getenv("HVK_SECAM_FORCE_FALLBACK"))
 		{
 			/* the host's chain takes the batch over from the state it began with */
+			e->secam_start = *e->h_secam_carry;
 			hvk_secam_set_state(e->secam, &e->secam_start, first_frame);
 			for(int i = 0; i < nframes; i++)
 			{
@@ -536,6 +571,21 @@ static int _secam_on_device(hvk_engine_t *e, int64_t first_frame, int nframes)
 	if((r = hvk_launch_secam_carry(&a, e->stream)) != HVK_OK) return(r);
 	HIPCHK(hipMemcpyAsync(e->h_secam_carry, a.carry, sizeof(hvk_secam_state_t), hipMemcpyDeviceToHost, e->stream));
 	return(HVK_OK);
+}
+
+/* A stage whose check is still out (above): the count is read -- behind the render hvk_launch has queued by now -- and what
+ * follows from it done. 0: the block's sub-carrier stands as rendered; 1: it was made again (render again); < 0: failure. */
+int hvk_e_secam_resolve(hvk_engine *e)
+{
+	if(!e->secam_pending) return(0);
+	e->secam_pending = 0;
+	HIPCHK(hipEventSynchronize(e->secam_ev));
+	const int bad = e->h_secam_count[0];
+	e->secam_resolving = 1;
+	const int r = _secam_rounds(e, e->secam_p_first, e->secam_p_n, e->secam_p_memo, bad);
+	e->secam_resolving = 0;
+	if(r != HVK_OK) { e->poisoned = 1; return(r); }
+	return(bad ? 1 : 0);
 }
 
 /* The picture planes (hvk_direct.hip) of those of the named slots whose picture is new since its planes were made: one
@@ -653,6 +703,7 @@ int hvk_e_stage(hvk_engine_t *e, int64_t first_frame, int64_t stride, int nframe
 	 * without anyone noticing. Everything that can be checked is checked before the first of them is touched, and a
 	 * failure after that point poisons the engine: every later call fails too. */
 	if(e->poisoned) return(HVK_ERROR);
+	if(e->secam_pending) { int r_ = hvk_e_secam_resolve(e); if(r_ < 0) return(r_); }     /* (a block staged and not launched) */
 	for(int i = 0; i < nframes * e->t.k.fields; i++)
 	{
 		if(slots && (slots[i] < 0 || slots[i] >= e->frame_slots)) return(HVK_ERROR);
